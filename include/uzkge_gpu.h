@@ -1,0 +1,133 @@
+/*
+ * uzkge_gpu.h -- C ABI of the MI355X (gfx950) backend for uzkge's PlonK prover hot path.
+ *
+ * The reference (zypher-game/uzkge, /root/reference) has no FFI/plugin surface; the boundary is
+ * the pair of Rust call sites that carry the heavy arithmetic:
+ *
+ *   G1Projective::msm(&points_raw, &coefs)   uzkge/src/poly_commit/kzg_poly_commitment.rs:287-290
+ *   domain.fft(&self.coefs)                   uzkge/src/poly_commit/field_polynomial.rs:585
+ *   domain.ifft(&values)                      uzkge/src/poly_commit/field_polynomial.rs:595
+ *
+ * A Rust `uzkge-gpu-sys` shim binds exactly these symbols (INTEGRATION.md shows the binding).
+ *
+ * Data layout (bit-identical to ark-ff `Fp<MontBackend<_,4>,4>`'s inner `BigInt<4>`):
+ *   field element  = 4 x uint64 little-endian limbs, Montgomery form, R = 2^256
+ *   uzk_g1_affine  = x || y (64 B); the point at infinity is encoded as x = y = 0
+ *   uzk_g1_jac     = x || y || z (96 B), Jacobian (x/z^2, y/z^3); infinity <=> z == 0
+ * The Jacobian representative of a result is not unique; compare after affine normalisation.
+ *
+ * Ownership: every pointer is caller-owned for the duration of the call; the library keeps no
+ * reference except data explicitly copied (or adopted) by uzk_srs_register*.  Outputs go to
+ * caller memory.  All functions are thread-safe (one internal lock); none panics or aborts.
+ *
+ * Error codes map onto `UzkgeError` (uzkge/src/errors.rs:5-44):
+ *   UZK_ERR_DEGREE     -> UzkgeError::DegreeError      (commit: len > SRS len, kzg_poly_commitment.rs:283-285)
+ *   UZK_ERR_FFT        -> UzkgeError::FFTError         (no evaluation domain of that size)
+ *   UZK_ERR_COMMITMENT -> UzkgeError::CommitmentError  (length mismatch: ark `msm` Err(min_len))
+ *   UZK_ERR_PARAMETER  -> UzkgeError::ParameterError   (bad handle / null pointer)
+ *   UZK_ERR_DEVICE     -> (new) no gfx950 device, HIP runtime failure, out of device memory
+ * There is NO CPU fallback: without a usable GPU every compute entry point returns UZK_ERR_DEVICE.
+ */
+#ifndef UZKGE_GPU_H
+#define UZKGE_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UZK_OK 0
+#define UZK_ERR_PARAMETER 1
+#define UZK_ERR_DEGREE 2
+#define UZK_ERR_FFT 3
+#define UZK_ERR_COMMITMENT 4
+#define UZK_ERR_DEVICE 5
+
+typedef struct { uint64_t x[4], y[4]; } uzk_g1_affine;
+typedef struct { uint64_t x[4], y[4], z[4]; } uzk_g1_jac;
+
+/* ---- lifecycle ------------------------------------------------------------------------ */
+/* Bind the calling process to HIP device `device` (one process per GPU); idempotent for the
+ * same ordinal.  Creates the library stream and workspaces. */
+int uzk_init(int device);
+int uzk_shutdown(void);
+/* Number of visible HIP devices (0 when none / no driver); never fails. */
+int uzk_device_count(void);
+/* Thread-local description of the last non-OK return on this thread. */
+const char* uzk_last_error(void);
+const char* uzk_version(void);
+
+/* ---- SRS (the static bases of KZG commit) --------------------------------------------- */
+/* Copy `n` affine points to HBM once; replaces the per-commit `normalize_batch` of
+ * kzg_poly_commitment.rs:287-288.  Returns an opaque handle (never 0). */
+int uzk_srs_register(const uzk_g1_affine* points, size_t n, uint64_t* handle_out);
+/* Adopt points that already live in device memory (no copy; caller keeps them alive). */
+int uzk_srs_register_device(const void* d_points, size_t n, uint64_t* handle_out);
+int uzk_srs_release(uint64_t handle);
+int uzk_srs_len(uint64_t handle, size_t* n_out);
+
+/* ---- MSM: replaces G1Projective::msm (kzg_poly_commitment.rs:290) ---------------------- */
+/* out = sum_{i<n} scalars[i] * SRS[offset + i].  n == 0 -> infinity.  offset + n > len ->
+ * UZK_ERR_DEGREE.  Zero scalars and infinity bases contribute the identity. */
+int uzk_msm_g1(uint64_t srs_handle, size_t offset, const uint64_t* scalars_mont, size_t n,
+               uzk_g1_jac* out);
+/* Same with the scalars already resident in device memory (the bench / pipelined path). */
+int uzk_msm_g1_device(uint64_t srs_handle, size_t offset, const void* d_scalars_mont, size_t n,
+                      uzk_g1_jac* out);
+/* One-shot, nothing cached: points and scalars are host arrays of the same length. */
+int uzk_msm_g1_raw(const uzk_g1_affine* points, const uint64_t* scalars_mont, size_t n,
+                   uzk_g1_jac* out);
+/* Host-side fold of partial sums (point-chunk sharded MSM: ranks all-gather their 96-byte
+ * partials over RCCL, then every rank folds; EC addition is not an RCCL reduce op). */
+int uzk_g1_fold(const uzk_g1_jac* partials, size_t count, uzk_g1_jac* out);
+/* Host-side Jacobian -> affine (for comparing results). */
+int uzk_g1_to_affine(const uzk_g1_jac* p, uzk_g1_affine* out);
+
+/* ---- NTT: replaces EvaluationDomain::{fft, ifft} (field_polynomial.rs:585,595) --------- */
+/* 1 if an evaluation domain of size n exists (n = 2^k, k <= 28, or n = 3 * 2^k), else 0
+ * (FpPolynomial::{evaluation_domain, quotient_evaluation_domain}, field_polynomial.rs:554-567). */
+int uzk_domain_supported(uint64_t n);
+/* group_gen of the size-n domain (5^((r-1)/n)), Montgomery form. */
+int uzk_domain_group_gen(uint64_t n, uint64_t out_mont[4]);
+/* In-place transform of `n` elements in natural order over <group_gen(n)>.
+ * inverse != 0: includes the 1/n scaling.  coset_shift (4 limbs, Montgomery) or NULL:
+ * forward: c_j *= shift^j before the transform (coset_fft_with_domain, :589-591);
+ * inverse: c_j *= shift^j after the transform -- pass k^-1 (coset_ifft_with_domain, :601-607).
+ * The caller zero-pads short inputs (it owns the Vec). */
+int uzk_ntt_fr(uint64_t* data, uint64_t n, int inverse, const uint64_t* coset_shift_mont);
+/* Device-resident variant: d_in -> d_out (may alias), asynchronous on the library stream
+ * unless `sync` != 0. */
+int uzk_ntt_fr_device(const void* d_in, void* d_out, uint64_t n, int inverse,
+                      const uint64_t* coset_shift_mont, int sync);
+
+/* ---- synthetic workloads (bench / tests; generated on device, nothing uploaded) -------- */
+/* d_points[i] = (i + 1) * Q with Q = seed_scalar * G: n distinct valid G1 points whose discrete
+ * logs relative to Q are known, so MSM(points, s) == (sum_i s_i (i+1)) * Q for any size. */
+int uzk_synth_points_arith(void* d_points, size_t n, const uint64_t* seed_scalar_mont);
+/* d_points[i] = hash-to-curve of a SplitMix64 counter stream (try-and-increment on x):
+ * pseudo-random G1 points with unknown discrete logs. */
+int uzk_synth_points_random(void* d_points, size_t n, uint64_t seed);
+/* Uniform Fr elements (Montgomery form) from a SplitMix64 counter stream. */
+int uzk_synth_scalars(void* d_scalars, size_t n, uint64_t seed);
+
+/* ---- measurement ---------------------------------------------------------------------- */
+/* When enabled, every kernel launch is bracketed by hipEvents on the library stream. */
+int uzk_profile_enable(int on);
+int uzk_profile_reset(void);
+/* Total elapsed ms and launch count of kernel `name` since the last reset. */
+int uzk_profile_get(const char* name, double* total_ms, uint64_t* launches);
+/* Newline-separated "name launches total_ms" table into buf. */
+int uzk_profile_dump(char* buf, size_t cap);
+/* Block until the library stream is idle. */
+int uzk_sync(void);
+/* The library's hipStream_t (so callers can order their own work against it). */
+void* uzk_stream(void);
+/* Tuning knobs (0 = automatic): MSM window bits. */
+int uzk_msm_set_window_bits(int c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UZKGE_GPU_H */

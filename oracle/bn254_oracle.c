@@ -1,0 +1,394 @@
+/*
+ * CPU ORACLE (plain C, gcc) for the uzkge PlonK hot path: BN254 G1 MSM and Fr NTT.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this library, and only as the checker / reported CPU baseline.
+ * The product path (uzkge_amd/, include/) never links or calls it.
+ *
+ * Reference call sites restated (paths relative to /root/reference):
+ *   MSM  : G1Projective::msm(&points_raw, &coefs)   uzkge/src/poly_commit/kzg_poly_commitment.rs:287-290
+ *   NTT  : domain.fft / domain.ifft                 uzkge/src/poly_commit/field_polynomial.rs:583-597
+ *   coset: mul_var_assign + fft / ifft + mul_var    uzkge/src/poly_commit/field_polynomial.rs:470-477,589-607
+ *   domains 2^k and 3*2^k                           uzkge/src/poly_commit/field_polynomial.rs:554-567
+ * The arithmetic proper is in un-vendored crates (ark-ec-zypher / ark-poly-zypher / ark-ff-zypher /
+ * ark-bn254-zypher "0.4", Cargo.toml:28-38; no lockfile, no sources in the container), so this file
+ * restates the published algorithms: Montgomery CIOS on 4x64-bit limbs with R = 2^256 (ark-ff
+ * MontBackend), Jacobian/mixed addition on y^2 = x^3 + 3, Pippenger bucket method
+ * (ark-ec VariableBaseMSM), radix-2 Cooley-Tukey with omega_n = 5^((r-1)/n) (ark-poly
+ * Radix2EvaluationDomain / MixedRadixEvaluationDomain; natural order in and out).
+ * Pinned against the reference's own SRS files by tests/test_oracle_pinning.py.
+ *
+ * Wire format everywhere: field element = 4 x uint64 little-endian limbs, Montgomery form;
+ * affine point = x||y (64 B), infinity = all zero; Jacobian = x||y||z (96 B), infinity <=> z == 0.
+ */
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef unsigned __int128 u128;
+typedef struct { uint64_t l[4]; } fe;             /* field element, Montgomery form */
+typedef struct { fe x, y; } g1a;                  /* affine; (0,0) = infinity */
+typedef struct { fe x, y, z; } g1j;               /* Jacobian; z == 0 = infinity */
+typedef struct { fe m; fe r; fe r2; uint64_t inv; } field;
+
+static const field FQ = {
+    {{0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL}},
+    {{0xd35d438dc58f0d9dULL, 0x0a78eb28f5c70b3dULL, 0x666ea36f7879462cULL, 0x0e0a77c19a07df2fULL}},
+    {{0xf32cfc5b538afa89ULL, 0xb5e71911d44501fbULL, 0x47ab1eff0a417ff6ULL, 0x06d89f71cab8351fULL}},
+    0x87d20782e4866389ULL};
+static const field FR = {
+    {{0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL}},
+    {{0xac96341c4ffffffbULL, 0x36fc76959f60cd29ULL, 0x666ea36f7879462eULL, 0x0e0a77c19a07df2fULL}},
+    {{0x1bb8e645ae216da7ULL, 0x53fe3ab1e35c59e3ULL, 0x8c49833d53bb8085ULL, 0x0216d0b17f4e44a5ULL}},
+    0xc2e1f593efffffffULL};
+
+/* ------------------------------------------------------------------ field arithmetic */
+static inline int fe_is_zero(const fe *a) { return (a->l[0] | a->l[1] | a->l[2] | a->l[3]) == 0; }
+static inline int fe_eq(const fe *a, const fe *b) { return memcmp(a, b, sizeof(fe)) == 0; }
+static inline int fe_geq(const fe *a, const fe *b) {
+    for (int i = 3; i >= 0; --i) { if (a->l[i] != b->l[i]) return a->l[i] > b->l[i]; }
+    return 1;
+}
+static inline uint64_t add4(fe *r, const fe *a, const fe *b) {
+    u128 c = 0;
+    for (int i = 0; i < 4; ++i) { c += (u128)a->l[i] + b->l[i]; r->l[i] = (uint64_t)c; c >>= 64; }
+    return (uint64_t)c;
+}
+static inline uint64_t sub4(fe *r, const fe *a, const fe *b) {
+    uint64_t br = 0;
+    for (int i = 0; i < 4; ++i) {
+        u128 d = (u128)a->l[i] - b->l[i] - br; r->l[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1;
+    }
+    return br;
+}
+static inline void f_add(const field *F, fe *r, const fe *a, const fe *b) {
+    fe t; add4(&t, a, b);                     /* moduli are < 2^254: no carry out */
+    if (fe_geq(&t, &F->m)) sub4(&t, &t, &F->m);
+    *r = t;
+}
+static inline void f_sub(const field *F, fe *r, const fe *a, const fe *b) {
+    fe t; if (sub4(&t, a, b)) add4(&t, &t, &F->m);
+    *r = t;
+}
+static inline void f_neg(const field *F, fe *r, const fe *a) {
+    if (fe_is_zero(a)) { *r = *a; return; }
+    sub4(r, &F->m, a);
+}
+static inline void f_dbl(const field *F, fe *r, const fe *a) { f_add(F, r, a, a); }
+/* Montgomery product a*b*2^-256 mod m (CIOS, 64-bit words). */
+static void f_mul(const field *F, fe *r, const fe *a, const fe *b) {
+    uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; ++i) {
+        u128 c = 0;
+        for (int j = 0; j < 4; ++j) { c += (u128)a->l[j] * b->l[i] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
+        c += t[4]; t[4] = (uint64_t)c; t[5] = (uint64_t)(c >> 64);
+        uint64_t m = t[0] * F->inv;
+        c = (u128)m * F->m.l[0] + t[0]; c >>= 64;
+        for (int j = 1; j < 4; ++j) { c += (u128)m * F->m.l[j] + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
+        c += t[4]; t[3] = (uint64_t)c; t[4] = t[5] + (uint64_t)(c >> 64);
+    }
+    fe o = {{t[0], t[1], t[2], t[3]}};
+    if (t[4] || fe_geq(&o, &F->m)) sub4(&o, &o, &F->m);
+    *r = o;
+}
+static inline void f_sqr(const field *F, fe *r, const fe *a) { f_mul(F, r, a, a); }
+static void f_from_mont(const field *F, fe *r, const fe *a) { fe one = {{1, 0, 0, 0}}; f_mul(F, r, a, &one); }
+static void f_to_mont(const field *F, fe *r, const fe *a) { f_mul(F, r, a, &F->r2); }
+/* a^e, e = canonical 256-bit exponent (not Montgomery) */
+static void f_pow(const field *F, fe *r, const fe *a, const fe *e) {
+    fe acc = F->r, base = *a;
+    for (int i = 0; i < 256; ++i) {
+        if ((e->l[i >> 6] >> (i & 63)) & 1) f_mul(F, &acc, &acc, &base);
+        f_sqr(F, &base, &base);
+    }
+    *r = acc;
+}
+static void f_inv(const field *F, fe *r, const fe *a) {   /* Fermat: a^(m-2) */
+    fe e = F->m, two = {{2, 0, 0, 0}}; sub4(&e, &e, &two);
+    f_pow(F, r, a, &e);
+}
+static void f_from_u64(const field *F, fe *r, uint64_t v) { fe t = {{v, 0, 0, 0}}; f_to_mont(F, r, &t); }
+
+/* ------------------------------------------------------------------ G1: y^2 = x^3 + 3 */
+static inline int a_is_inf(const g1a *p) { return fe_is_zero(&p->x) && fe_is_zero(&p->y); }
+static inline void j_set_inf(g1j *p) { memset(p, 0, sizeof *p); p->x = FQ.r; p->y = FQ.r; }
+static inline void j_from_a(g1j *r, const g1a *p) {
+    if (a_is_inf(p)) { j_set_inf(r); return; }
+    r->x = p->x; r->y = p->y; r->z = FQ.r;
+}
+static void j_double(g1j *r, const g1j *p) {      /* dbl-2009-l (a = 0) */
+    if (fe_is_zero(&p->z)) { *r = *p; return; }
+    fe A, B, C, D, E, Fv, t, X3, Y3, Z3;
+    f_sqr(&FQ, &A, &p->x); f_sqr(&FQ, &B, &p->y); f_sqr(&FQ, &C, &B);
+    f_add(&FQ, &t, &p->x, &B); f_sqr(&FQ, &t, &t); f_sub(&FQ, &t, &t, &A); f_sub(&FQ, &t, &t, &C);
+    f_dbl(&FQ, &D, &t);
+    f_dbl(&FQ, &E, &A); f_add(&FQ, &E, &E, &A);
+    f_sqr(&FQ, &Fv, &E);
+    f_dbl(&FQ, &t, &D); f_sub(&FQ, &X3, &Fv, &t);
+    f_sub(&FQ, &t, &D, &X3); f_mul(&FQ, &Y3, &E, &t);
+    f_dbl(&FQ, &t, &C); f_dbl(&FQ, &t, &t); f_dbl(&FQ, &t, &t); f_sub(&FQ, &Y3, &Y3, &t);
+    f_mul(&FQ, &Z3, &p->y, &p->z); f_dbl(&FQ, &Z3, &Z3);
+    r->x = X3; r->y = Y3; r->z = Z3;
+}
+static void j_add(g1j *r, const g1j *p, const g1j *q) {   /* add-2007-bl, complete via branches */
+    if (fe_is_zero(&p->z)) { *r = *q; return; }
+    if (fe_is_zero(&q->z)) { *r = *p; return; }
+    fe Z1Z1, Z2Z2, U1, U2, S1, S2, H, I, J, rr, V, t, X3, Y3, Z3;
+    f_sqr(&FQ, &Z1Z1, &p->z); f_sqr(&FQ, &Z2Z2, &q->z);
+    f_mul(&FQ, &U1, &p->x, &Z2Z2); f_mul(&FQ, &U2, &q->x, &Z1Z1);
+    f_mul(&FQ, &S1, &p->y, &q->z); f_mul(&FQ, &S1, &S1, &Z2Z2);
+    f_mul(&FQ, &S2, &q->y, &p->z); f_mul(&FQ, &S2, &S2, &Z1Z1);
+    if (fe_eq(&U1, &U2)) {
+        if (fe_eq(&S1, &S2)) { j_double(r, p); return; }
+        j_set_inf(r); return;
+    }
+    f_sub(&FQ, &H, &U2, &U1);
+    f_dbl(&FQ, &I, &H); f_sqr(&FQ, &I, &I);
+    f_mul(&FQ, &J, &H, &I);
+    f_sub(&FQ, &rr, &S2, &S1); f_dbl(&FQ, &rr, &rr);
+    f_mul(&FQ, &V, &U1, &I);
+    f_sqr(&FQ, &X3, &rr); f_sub(&FQ, &X3, &X3, &J); f_dbl(&FQ, &t, &V); f_sub(&FQ, &X3, &X3, &t);
+    f_sub(&FQ, &t, &V, &X3); f_mul(&FQ, &Y3, &rr, &t);
+    f_mul(&FQ, &t, &S1, &J); f_dbl(&FQ, &t, &t); f_sub(&FQ, &Y3, &Y3, &t);
+    f_add(&FQ, &Z3, &p->z, &q->z); f_sqr(&FQ, &Z3, &Z3); f_sub(&FQ, &Z3, &Z3, &Z1Z1);
+    f_sub(&FQ, &Z3, &Z3, &Z2Z2); f_mul(&FQ, &Z3, &Z3, &H);
+    r->x = X3; r->y = Y3; r->z = Z3;
+}
+static void j_add_affine(g1j *r, const g1j *p, const g1a *q, int negate) {   /* madd-2007-bl */
+    if (a_is_inf(q)) { *r = *p; return; }
+    fe qy = q->y; if (negate) f_neg(&FQ, &qy, &qy);
+    if (fe_is_zero(&p->z)) { r->x = q->x; r->y = qy; r->z = FQ.r; return; }
+    fe Z1Z1, U2, S2, H, HH, I, J, rr, V, t, X3, Y3, Z3;
+    f_sqr(&FQ, &Z1Z1, &p->z);
+    f_mul(&FQ, &U2, &q->x, &Z1Z1);
+    f_mul(&FQ, &S2, &qy, &p->z); f_mul(&FQ, &S2, &S2, &Z1Z1);
+    if (fe_eq(&p->x, &U2)) {
+        if (fe_eq(&p->y, &S2)) { j_double(r, p); return; }
+        j_set_inf(r); return;
+    }
+    f_sub(&FQ, &H, &U2, &p->x); f_sqr(&FQ, &HH, &H);
+    f_dbl(&FQ, &I, &HH); f_dbl(&FQ, &I, &I);
+    f_mul(&FQ, &J, &H, &I);
+    f_sub(&FQ, &rr, &S2, &p->y); f_dbl(&FQ, &rr, &rr);
+    f_mul(&FQ, &V, &p->x, &I);
+    f_sqr(&FQ, &X3, &rr); f_sub(&FQ, &X3, &X3, &J); f_dbl(&FQ, &t, &V); f_sub(&FQ, &X3, &X3, &t);
+    f_sub(&FQ, &t, &V, &X3); f_mul(&FQ, &Y3, &rr, &t);
+    f_mul(&FQ, &t, &p->y, &J); f_dbl(&FQ, &t, &t); f_sub(&FQ, &Y3, &Y3, &t);
+    f_add(&FQ, &Z3, &p->z, &H); f_sqr(&FQ, &Z3, &Z3); f_sub(&FQ, &Z3, &Z3, &Z1Z1); f_sub(&FQ, &Z3, &Z3, &HH);
+    r->x = X3; r->y = Y3; r->z = Z3;
+}
+static void j_to_affine(g1a *r, const g1j *p) {
+    if (fe_is_zero(&p->z)) { memset(r, 0, sizeof *r); return; }
+    fe zi, zi2, zi3;
+    f_inv(&FQ, &zi, &p->z); f_sqr(&FQ, &zi2, &zi); f_mul(&FQ, &zi3, &zi2, &zi);
+    f_mul(&FQ, &r->x, &p->x, &zi2); f_mul(&FQ, &r->y, &p->y, &zi3);
+}
+/* k = canonical scalar (NOT Montgomery), 256 bits */
+static void j_mul_canon(g1j *r, const g1j *p, const fe *k) {
+    g1j acc; j_set_inf(&acc);
+    for (int i = 255; i >= 0; --i) {
+        j_double(&acc, &acc);
+        if ((k->l[i >> 6] >> (i & 63)) & 1) j_add(&acc, &acc, p);
+    }
+    *r = acc;
+}
+
+/* ------------------------------------------------------------------ exported: field / group KATs */
+void oracle_fq_mul(const uint64_t *a, const uint64_t *b, uint64_t *out) { f_mul(&FQ, (fe *)out, (const fe *)a, (const fe *)b); }
+void oracle_fr_mul(const uint64_t *a, const uint64_t *b, uint64_t *out) { f_mul(&FR, (fe *)out, (const fe *)a, (const fe *)b); }
+void oracle_fr_add(const uint64_t *a, const uint64_t *b, uint64_t *out) { f_add(&FR, (fe *)out, (const fe *)a, (const fe *)b); }
+void oracle_fr_sub(const uint64_t *a, const uint64_t *b, uint64_t *out) { f_sub(&FR, (fe *)out, (const fe *)a, (const fe *)b); }
+void oracle_fr_inv(const uint64_t *a, uint64_t *out) { f_inv(&FR, (fe *)out, (const fe *)a); }
+void oracle_fq_inv(const uint64_t *a, uint64_t *out) { f_inv(&FQ, (fe *)out, (const fe *)a); }
+void oracle_fr_to_mont(const uint64_t *a, uint64_t *out) { f_to_mont(&FR, (fe *)out, (const fe *)a); }
+void oracle_fr_from_mont(const uint64_t *a, uint64_t *out) { f_from_mont(&FR, (fe *)out, (const fe *)a); }
+void oracle_fq_to_mont(const uint64_t *a, uint64_t *out) { f_to_mont(&FQ, (fe *)out, (const fe *)a); }
+void oracle_fq_from_mont(const uint64_t *a, uint64_t *out) { f_from_mont(&FQ, (fe *)out, (const fe *)a); }
+void oracle_g1_add(const uint64_t *p, const uint64_t *q, uint64_t *out) { j_add((g1j *)out, (const g1j *)p, (const g1j *)q); }
+void oracle_g1_double(const uint64_t *p, uint64_t *out) { j_double((g1j *)out, (const g1j *)p); }
+void oracle_g1_add_affine(const uint64_t *p, const uint64_t *q, uint64_t *out) { j_add_affine((g1j *)out, (const g1j *)p, (const g1a *)q, 0); }
+void oracle_g1_to_affine(const uint64_t *p, uint64_t *out) { j_to_affine((g1a *)out, (const g1j *)p); }
+/* scalar in Montgomery form (wire format) */
+void oracle_g1_mul(const uint64_t *p_affine, const uint64_t *scalar_mont, uint64_t *out_jac) {
+    fe k; f_from_mont(&FR, &k, (const fe *)scalar_mont);
+    g1j b; j_from_a(&b, (const g1a *)p_affine);
+    j_mul_canon((g1j *)out_jac, &b, &k);
+}
+int oracle_g1_is_on_curve(const uint64_t *p_affine) {
+    const g1a *p = (const g1a *)p_affine;
+    if (a_is_inf(p)) return 1;
+    fe l, r3, three;
+    f_sqr(&FQ, &l, &p->y); f_sqr(&FQ, &r3, &p->x); f_mul(&FQ, &r3, &r3, &p->x);
+    f_from_u64(&FQ, &three, 3); f_add(&FQ, &r3, &r3, &three);
+    return fe_eq(&l, &r3);
+}
+
+/* ------------------------------------------------------------------ MSM */
+/* Definition used by the reference's own test_commit (kzg_poly_commitment.rs:526-548):
+ * one double-and-add per term, summed. */
+void oracle_msm_naive(const uint64_t *points, const uint64_t *scalars_mont, size_t n, uint64_t *out_jac) {
+    const g1a *P = (const g1a *)points; const fe *S = (const fe *)scalars_mont;
+    g1j acc; j_set_inf(&acc);
+    for (size_t i = 0; i < n; ++i) {
+        fe k; f_from_mont(&FR, &k, &S[i]);
+        if (fe_is_zero(&k) || a_is_inf(&P[i])) continue;
+        g1j b, t; j_from_a(&b, &P[i]); j_mul_canon(&t, &b, &k); j_add(&acc, &acc, &t);
+    }
+    *(g1j *)out_jac = acc;
+}
+
+typedef struct {
+    const g1a *P; const fe *K; size_t n; int c; int w_begin, w_end; g1j *win_out;
+} msm_job;
+
+static inline uint32_t get_bits(const fe *k, int lo, int c) {
+    int limb = lo >> 6, sh = lo & 63;
+    if (limb >= 4) return 0;
+    uint64_t v = k->l[limb] >> sh;
+    if (sh + c > 64 && limb + 1 < 4) v |= k->l[limb + 1] << (64 - sh);
+    return (uint32_t)(v & ((1ULL << c) - 1));
+}
+static void *msm_worker(void *arg) {
+    msm_job *j = (msm_job *)arg;
+    size_t nb = (size_t)1 << j->c;
+    g1j *buckets = (g1j *)malloc(nb * sizeof(g1j));
+    for (int w = j->w_begin; w < j->w_end; ++w) {
+        for (size_t b = 0; b < nb; ++b) j_set_inf(&buckets[b]);
+        for (size_t i = 0; i < j->n; ++i) {
+            uint32_t d = get_bits(&j->K[i], w * j->c, j->c);
+            if (d) j_add_affine(&buckets[d], &buckets[d], &j->P[i], 0);
+        }
+        g1j run, acc; j_set_inf(&run); j_set_inf(&acc);
+        for (size_t b = nb - 1; b >= 1; --b) { j_add(&run, &run, &buckets[b]); j_add(&acc, &acc, &run); }
+        j->win_out[w] = acc;
+    }
+    free(buckets);
+    return NULL;
+}
+/* Pippenger bucket method, plain (unsigned) windows of c bits, threads over windows.
+ * This is the timed "port" CPU baseline in bench.py. */
+void oracle_msm_pippenger(const uint64_t *points, const uint64_t *scalars_mont, size_t n,
+                          int c, int threads, uint64_t *out_jac) {
+    if (c < 1) {
+        c = 3; while ((1ULL << (c + 3)) < n && c < 16) ++c;     /* ~ log2(n) - 3 */
+    }
+    int nwin = (254 + c - 1) / c;
+    fe *K = (fe *)malloc((n ? n : 1) * sizeof(fe));
+    for (size_t i = 0; i < n; ++i) f_from_mont(&FR, &K[i], &((const fe *)scalars_mont)[i]);
+    g1j *win = (g1j *)malloc(nwin * sizeof(g1j));
+    if (threads < 1) threads = 1;
+    if (threads > nwin) threads = nwin;
+    pthread_t *th = (pthread_t *)malloc(threads * sizeof(pthread_t));
+    msm_job *jobs = (msm_job *)malloc(threads * sizeof(msm_job));
+    for (int t = 0; t < threads; ++t) {
+        jobs[t] = (msm_job){(const g1a *)points, K, n, c, (int)((long)nwin * t / threads),
+                            (int)((long)nwin * (t + 1) / threads), win};
+        pthread_create(&th[t], NULL, msm_worker, &jobs[t]);
+    }
+    for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);
+    g1j total; j_set_inf(&total);
+    for (int w = nwin - 1; w >= 0; --w) {
+        for (int b = 0; b < c; ++b) j_double(&total, &total);
+        j_add(&total, &total, &win[w]);
+    }
+    *(g1j *)out_jac = total;
+    free(K); free(win); free(th); free(jobs);
+}
+
+/* ------------------------------------------------------------------ NTT */
+static void fr_root_of_unity(fe *w, uint64_t n) {   /* 5^((r-1)/n), Montgomery form */
+    fe e = FR.m, one = {{1, 0, 0, 0}}, q = {{0, 0, 0, 0}};
+    sub4(&e, &e, &one);
+    u128 rem = 0;                                   /* q = (r-1) / n, long division by a word */
+    for (int i = 3; i >= 0; --i) { u128 cur = (rem << 64) | e.l[i]; q.l[i] = (uint64_t)(cur / n); rem = cur % n; }
+    fe g; f_from_u64(&FR, &g, 5);
+    f_pow(&FR, w, &g, &q);
+}
+int oracle_domain_supported(uint64_t n) {
+    if (n == 0) return 0;
+    uint64_t m = (n % 3 == 0) ? n / 3 : n;
+    return (m & (m - 1)) == 0 && m <= (1ULL << 28);
+}
+void oracle_root_of_unity(uint64_t n, uint64_t *out_mont) { fr_root_of_unity((fe *)out_mont, n); }
+
+typedef struct { fe *a; const fe *tw; size_t n, half, step, lo, hi; } ntt_job;
+static void *ntt_stage_worker(void *arg) {
+    ntt_job *j = (ntt_job *)arg;
+    /* butterflies b in [lo,hi): group = b / half, pos = b % half */
+    for (size_t b = j->lo; b < j->hi; ++b) {
+        size_t g = b / j->half, p = b % j->half;
+        fe *u = &j->a[g * 2 * j->half + p], *v = u + j->half, t;
+        f_mul(&FR, &t, v, &j->tw[p * j->step]);
+        f_sub(&FR, v, u, &t); f_add(&FR, u, u, &t);
+    }
+    return NULL;
+}
+/* In-place radix-2 DIT on a power-of-two length with root w (bit-reverse first). */
+static void ntt_pow2(fe *a, size_t n, const fe *w, int threads) {
+    if (n <= 1) return;
+    for (size_t i = 1, j = 0; i < n; ++i) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) { fe t = a[i]; a[i] = a[j]; a[j] = t; }
+    }
+    fe *tw = (fe *)malloc((n / 2) * sizeof(fe));
+    tw[0] = FR.r;
+    for (size_t i = 1; i < n / 2; ++i) f_mul(&FR, &tw[i], &tw[i - 1], w);
+    if (threads < 1) threads = 1;
+    pthread_t *th = (pthread_t *)malloc(threads * sizeof(pthread_t));
+    ntt_job *jobs = (ntt_job *)malloc(threads * sizeof(ntt_job));
+    for (size_t half = 1; half < n; half <<= 1) {
+        size_t step = n / (2 * half), nb = n / 2;
+        int T = (nb < 4096) ? 1 : threads;
+        for (int t = 0; t < T; ++t) {
+            jobs[t] = (ntt_job){a, tw, n, half, step, nb * t / T, nb * (t + 1) / T};
+            if (T == 1) ntt_stage_worker(&jobs[t]); else pthread_create(&th[t], NULL, ntt_stage_worker, &jobs[t]);
+        }
+        if (T > 1) for (int t = 0; t < T; ++t) pthread_join(th[t], NULL);
+    }
+    free(tw); free(th); free(jobs);
+}
+/* `EvaluationDomain::fft` / `ifft` over the size-n domain (n = 2^k or 3*2^k), in place,
+ * natural order in and out; `data` holds n Montgomery elements (caller zero-pads). */
+int oracle_ntt(uint64_t *data, uint64_t n, int inverse, int threads) {
+    if (!oracle_domain_supported(n)) return 1;
+    fe *a = (fe *)data, w;
+    fr_root_of_unity(&w, n);
+    if (inverse) f_inv(&FR, &w, &w);
+    if (n % 3 != 0) {
+        ntt_pow2(a, n, &w, threads);
+    } else {
+        /* decimation in time by 3: x_k[j] = a[3j+k]; X[i] = sum_k w^(ik) X_k[i mod m] */
+        size_t m = n / 3;
+        fe *sub = (fe *)malloc(n * sizeof(fe)), w3, wi = FR.r;
+        for (size_t j = 0; j < m; ++j) for (int k = 0; k < 3; ++k) sub[k * m + j] = a[3 * j + k];
+        f_sqr(&FR, &w3, &w); f_mul(&FR, &w3, &w3, &w);
+        for (int k = 0; k < 3; ++k) ntt_pow2(sub + k * m, m, &w3, threads);
+        for (size_t i = 0; i < n; ++i) {
+            fe t1, t2, wi2;
+            f_sqr(&FR, &wi2, &wi);
+            f_mul(&FR, &t1, &wi, &sub[m + i % m]); f_mul(&FR, &t2, &wi2, &sub[2 * m + i % m]);
+            f_add(&FR, &a[i], &sub[i % m], &t1); f_add(&FR, &a[i], &a[i], &t2);
+            f_mul(&FR, &wi, &wi, &w);
+        }
+        free(sub);
+    }
+    if (inverse) {
+        fe ninv; f_from_u64(&FR, &ninv, n); f_inv(&FR, &ninv, &ninv);
+        for (size_t i = 0; i < n; ++i) f_mul(&FR, &a[i], &a[i], &ninv);
+    }
+    return 0;
+}
+/* mul_var_assign (field_polynomial.rs:470-477): c_j *= k^j, serial like the reference. */
+void oracle_mul_var(uint64_t *data, uint64_t len, const uint64_t *k_mont) {
+    fe *a = (fe *)data, x = FR.r;
+    for (uint64_t j = 0; j < len; ++j) { f_mul(&FR, &a[j], &a[j], &x); f_mul(&FR, &x, &x, (const fe *)k_mont); }
+}
+/* Horner evaluation (field_polynomial.rs:198-209). */
+void oracle_poly_eval(const uint64_t *coefs, uint64_t len, const uint64_t *x_mont, uint64_t *out) {
+    fe acc = {{0, 0, 0, 0}};
+    for (uint64_t j = len; j-- > 0;) { f_mul(&FR, &acc, &acc, (const fe *)x_mont); f_add(&FR, &acc, &acc, &((const fe *)coefs)[j]); }
+    *(fe *)out = acc;
+}

@@ -1,0 +1,160 @@
+"""ctypes loader for the C oracle (oracle/bn254_oracle.c).  TEST INFRASTRUCTURE ONLY:
+import from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never from the
+product path.  All buffers are numpy uint64 arrays in the C-ABI wire format
+(Montgomery 4x64 LE limbs; affine = 8 words, Jacobian = 12 words)."""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liboracle_bn254.so")
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "bn254_oracle.c")
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle_bn254.so"])
+    return _LIB
+
+
+def _load():
+    build()
+    lib = ctypes.CDLL(_LIB)
+    P = ctypes.c_void_p
+    sigs = {
+        "oracle_fq_mul": [P, P, P], "oracle_fr_mul": [P, P, P], "oracle_fr_add": [P, P, P],
+        "oracle_fr_sub": [P, P, P], "oracle_fr_inv": [P, P], "oracle_fq_inv": [P, P],
+        "oracle_fr_to_mont": [P, P], "oracle_fr_from_mont": [P, P],
+        "oracle_fq_to_mont": [P, P], "oracle_fq_from_mont": [P, P],
+        "oracle_g1_add": [P, P, P], "oracle_g1_double": [P, P], "oracle_g1_add_affine": [P, P, P],
+        "oracle_g1_to_affine": [P, P], "oracle_g1_mul": [P, P, P],
+        "oracle_msm_naive": [P, P, ctypes.c_size_t, P],
+        "oracle_msm_pippenger": [P, P, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, P],
+        "oracle_root_of_unity": [ctypes.c_uint64, P],
+        "oracle_mul_var": [P, ctypes.c_uint64, P],
+        "oracle_poly_eval": [P, ctypes.c_uint64, P, P],
+    }
+    for name, args in sigs.items():
+        getattr(lib, name).argtypes = args
+        getattr(lib, name).restype = None
+    lib.oracle_ntt.argtypes = [P, ctypes.c_uint64, ctypes.c_int, ctypes.c_int]
+    lib.oracle_ntt.restype = ctypes.c_int
+    lib.oracle_domain_supported.argtypes = [ctypes.c_uint64]
+    lib.oracle_domain_supported.restype = ctypes.c_int
+    lib.oracle_g1_is_on_curve.argtypes = [P]
+    lib.oracle_g1_is_on_curve.restype = ctypes.c_int
+    return lib
+
+
+lib = _load()
+
+
+def _p(a: np.ndarray):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _binop(fn, a, b):
+    out = np.empty(4, dtype=np.uint64)
+    fn(_p(np.ascontiguousarray(a)), _p(np.ascontiguousarray(b)), _p(out))
+    return out
+
+
+def fq_mul(a, b): return _binop(lib.oracle_fq_mul, a, b)
+def fr_mul(a, b): return _binop(lib.oracle_fr_mul, a, b)
+def fr_add(a, b): return _binop(lib.oracle_fr_add, a, b)
+def fr_sub(a, b): return _binop(lib.oracle_fr_sub, a, b)
+
+
+def fr_inv(a):
+    out = np.empty(4, dtype=np.uint64); lib.oracle_fr_inv(_p(np.ascontiguousarray(a)), _p(out)); return out
+
+
+def root_of_unity(n: int) -> np.ndarray:
+    out = np.empty(4, dtype=np.uint64); lib.oracle_root_of_unity(n, _p(out)); return out
+
+
+def g1_to_affine(jac: np.ndarray) -> np.ndarray:
+    out = np.empty(8, dtype=np.uint64); lib.oracle_g1_to_affine(_p(np.ascontiguousarray(jac)), _p(out)); return out
+
+
+def g1_add(p: np.ndarray, q: np.ndarray) -> np.ndarray:
+    out = np.empty(12, dtype=np.uint64)
+    lib.oracle_g1_add(_p(np.ascontiguousarray(p)), _p(np.ascontiguousarray(q)), _p(out)); return out
+
+
+def g1_mul(p_affine: np.ndarray, scalar_mont: np.ndarray) -> np.ndarray:
+    out = np.empty(12, dtype=np.uint64)
+    lib.oracle_g1_mul(_p(np.ascontiguousarray(p_affine)), _p(np.ascontiguousarray(scalar_mont)), _p(out)); return out
+
+
+def msm_naive(points: np.ndarray, scalars: np.ndarray) -> np.ndarray:
+    """points [n,8] u64, scalars [n,4] u64 -> Jacobian [12]."""
+    n = scalars.shape[0]
+    out = np.empty(12, dtype=np.uint64)
+    lib.oracle_msm_naive(_p(np.ascontiguousarray(points)), _p(np.ascontiguousarray(scalars)), n, _p(out))
+    return out
+
+
+def msm_pippenger(points: np.ndarray, scalars: np.ndarray, c: int = 0, threads: int = 1) -> np.ndarray:
+    n = scalars.shape[0]
+    out = np.empty(12, dtype=np.uint64)
+    lib.oracle_msm_pippenger(_p(np.ascontiguousarray(points)), _p(np.ascontiguousarray(scalars)), n, c, threads, _p(out))
+    return out
+
+
+def ntt(data: np.ndarray, inverse: bool = False, threads: int = 1) -> np.ndarray:
+    """data [n,4] u64 (Montgomery), n = 2^k or 3*2^k; returns a new array."""
+    a = np.ascontiguousarray(data).copy()
+    rc = lib.oracle_ntt(_p(a), a.shape[0], int(inverse), threads)
+    if rc != 0:
+        raise ValueError(f"unsupported domain size {a.shape[0]}")
+    return a
+
+
+def mul_var(data: np.ndarray, k_mont: np.ndarray) -> np.ndarray:
+    a = np.ascontiguousarray(data).copy()
+    lib.oracle_mul_var(_p(a), a.shape[0], _p(np.ascontiguousarray(k_mont)))
+    return a
+
+
+def poly_eval(coefs: np.ndarray, x_mont: np.ndarray) -> np.ndarray:
+    out = np.empty(4, dtype=np.uint64)
+    lib.oracle_poly_eval(_p(np.ascontiguousarray(coefs)), coefs.shape[0], _p(np.ascontiguousarray(x_mont)), _p(out))
+    return out
+
+
+# ---- numpy <-> python-int helpers (wire format) ----
+def fr_from_ints(xs, mod=None) -> np.ndarray:
+    """canonical ints -> [n,4] Montgomery limbs (Fr unless mod given)."""
+    from bn254_py import R, to_mont  # same directory; test infra only
+    m = R if mod is None else mod
+    out = np.empty((len(xs), 4), dtype=np.uint64)
+    for i, x in enumerate(xs):
+        v = to_mont(x % m, m)
+        for k in range(4):
+            out[i, k] = (v >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
+    return out
+
+
+def fr_to_ints(a: np.ndarray, mod=None):
+    from bn254_py import R, from_mont
+    m = R if mod is None else mod
+    a = np.asarray(a, dtype=np.uint64).reshape(-1, 4)
+    return [from_mont(sum(int(a[i, k]) << (64 * k) for k in range(4)), m) for i in range(a.shape[0])]
+
+
+def points_from_affine(pts) -> np.ndarray:
+    """list of canonical affine tuples / None -> [n,8] wire array."""
+    from bn254_py import affine_to_wire
+    buf = b"".join(affine_to_wire(p) for p in pts)
+    return np.frombuffer(buf, dtype=np.uint64).reshape(-1, 8).copy()
+
+
+def jac_to_affine_ints(jac: np.ndarray):
+    from bn254_py import jac_wire_to_affine
+    return jac_wire_to_affine(np.ascontiguousarray(jac).tobytes())

@@ -1,0 +1,174 @@
+"""MSM parity: HIP Pippenger (through the C ABI) vs the CPU oracle, compared after affine
+normalisation (the Jacobian representative is not unique).  Mirrors the reference's
+`test_commit` (uzkge/src/poly_commit/kzg_poly_commitment.rs:526-548: commit == naive sum of
+coef_i * SRS_i) and `test_homomorphic_poly_com_elem` (:483-514)."""
+import numpy as np
+import pytest
+
+import bn254_py as opy
+import oracle_c as oc
+from util import affine_of, load_srs, rand_fr, rand_fr_wire
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lagrange(gpu):
+    wire, pts = load_srs("lagrange-srs-4096.bin")
+    srs = gpu.Srs.from_host(wire)
+    yield srs, wire, pts
+    srs.release()
+
+
+def _check(gpu, srs, wire, scalars, offset=0):
+    got = affine_of(gpu.msm(srs, scalars, offset=offset))
+    n = scalars.shape[0]
+    want = affine_of(oc.msm_pippenger(wire[offset:offset + n], scalars, 0, 8))
+    assert got == want
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 33, 64, 255, 1024, 4096])
+def test_uniform_scalars(gpu, lagrange, n):
+    srs, wire, _ = lagrange
+    _check(gpu, srs, wire, rand_fr_wire(n, 500 + n))
+
+
+def test_matches_naive_definition(gpu, lagrange):
+    """test_commit's definition: sum of per-term scalar multiplications."""
+    srs, wire, _ = lagrange
+    s = rand_fr_wire(40, 9)
+    assert affine_of(gpu.msm(srs, s)) == affine_of(oc.msm_naive(wire[:40], s))
+
+
+@pytest.mark.parametrize("kind", ["zeros", "ones", "minus_one", "boolean", "small", "prover_mix", "same"])
+def test_special_scalar_sets(gpu, lagrange, kind):
+    """Value classes the real prover produces: padding zeros, boolean wires,
+    +1 / -1 = r-1 selectors, small values, and a mixture; plus all-equal scalars (one bucket)."""
+    srs, wire, _ = lagrange
+    n = 4096
+    rng = np.random.default_rng(77)
+    if kind == "zeros":
+        ints = [0] * n
+    elif kind == "ones":
+        ints = [1] * n
+    elif kind == "minus_one":
+        ints = [opy.R - 1] * n
+    elif kind == "boolean":
+        ints = [int(v) for v in rng.integers(0, 2, n)]
+    elif kind == "small":
+        ints = [int(v) for v in rng.integers(0, 1 << 16, n)]
+    elif kind == "same":
+        ints = [0x1234567890ABCDEF1234567890ABCDEF] * n
+    else:
+        u = rand_fr(n, 5)
+        cls = rng.integers(0, 10, n)
+        ints = [0 if c < 5 else 1 if c < 7 else opy.R - 1 if c < 8 else int(rng.integers(0, 1 << 16)) if c < 9 else u[i]
+                for i, c in enumerate(cls)]
+    _check(gpu, srs, wire, oc.fr_from_ints(ints))
+
+
+def test_all_zero_vector_arrives_as_single_zero(gpu, lagrange):
+    """from_coefs trims trailing zeros, so an all-zero evaluation vector reaches commit as n = 1
+    with scalar 0: must return infinity (z == 0), not an error."""
+    srs, _, _ = lagrange
+    out = gpu.msm(srs, oc.fr_from_ints([0]))
+    assert affine_of(out) is None
+    assert not out[8:12].any()
+    assert affine_of(gpu.msm(srs, np.zeros((0, 4), dtype=np.uint64))) is None
+
+
+def test_degree_error(gpu, lagrange):
+    """commit: degree + 1 > SRS length -> DegreeError (kzg_poly_commitment.rs:283-285)."""
+    from uzkge_amd import UzkgeError
+    srs, _, _ = lagrange
+    with pytest.raises(UzkgeError) as e:
+        gpu.msm(srs, rand_fr_wire(4097, 1))
+    assert e.value.kind == "DegreeError"
+    with pytest.raises(UzkgeError):
+        gpu.msm(srs, rand_fr_wire(10, 1), offset=4090)
+
+
+def test_offset_window(gpu, lagrange):
+    srs, wire, _ = lagrange
+    _check(gpu, srs, wire, rand_fr_wire(100, 3), offset=1000)
+
+
+def test_infinity_bases_are_identity(gpu):
+    """The monomial SRS holds identity points between 2051 and n (gen_params/mod.rs:160-173):
+    affine (0,0) must act as the identity."""
+    wire, _ = load_srs("lagrange-srs-4096.bin")
+    pts = wire[:64].copy()
+    pts[5] = 0
+    pts[17] = 0
+    s = rand_fr_wire(64, 21)
+    got = affine_of(gpu.msm_raw(pts, s))
+    assert got == affine_of(oc.msm_pippenger(pts, s, 0, 1))
+
+
+def test_repeated_and_opposite_points(gpu):
+    """P + P (doubling branch) and P + (-P) (-> infinity branch) inside one bucket."""
+    wire, _ = load_srs("lagrange-srs-4096.bin")
+    p = wire[7]
+    pts = np.stack([p, p, p, p])
+    one = oc.fr_from_ints([1, 1, 1, opy.R - 1])
+    assert affine_of(gpu.msm_raw(pts, one)) == affine_of(oc.msm_naive(pts, one))
+    two = oc.fr_from_ints([5, opy.R - 5])
+    assert affine_of(gpu.msm_raw(pts[:2], two)) is None
+
+
+def test_homomorphism(gpu, lagrange):
+    """commit(p + q) == commit(p) + commit(q); commit(5 p) == 5 commit(p)."""
+    srs, wire, _ = lagrange
+    n = 512
+    a, b = rand_fr(n, 31), rand_fr(n, 32)
+    ca = gpu.msm(srs, oc.fr_from_ints(a))
+    cb = gpu.msm(srs, oc.fr_from_ints(b))
+    cab = gpu.msm(srs, oc.fr_from_ints([(x + y) % opy.R for x, y in zip(a, b)]))
+    assert affine_of(gpu.g1_fold(np.stack([ca, cb]))) == affine_of(cab)
+    c5 = gpu.msm(srs, oc.fr_from_ints([5 * x % opy.R for x in a]))
+    assert affine_of(c5) == opy.g1_mul(affine_of(ca), 5)
+
+
+def test_lagrange_srs_identities(gpu, lagrange):
+    """Known answers from the reference's own parameter files: sum_i L_i == G and
+    sum_i w^i L_i == [tau]G (srs-padding.bin[1]) -- pins omega and ordering on the GPU path."""
+    srs, _, _ = lagrange
+    _, mono = load_srs("srs-padding.bin")
+    assert affine_of(gpu.msm(srs, oc.fr_from_ints([1] * 4096))) == opy.G1_GEN
+    w = opy.root_of_unity(4096)
+    ws = oc.fr_from_ints([pow(w, i, opy.R) for i in range(4096)])
+    assert affine_of(gpu.msm(srs, ws)) == mono[1]
+
+
+def test_ntt_then_msm_equals_monomial_commit(gpu, lagrange):
+    """MSM(lagrange_srs, NTT(c)) == MSM(monomial_srs, c): NTT and MSM together against
+    reference data (the shape of every commit in prover_with_lagrange, prover.rs:132-149)."""
+    srs, _, _ = lagrange
+    mono_wire, _ = load_srs("srs-padding.bin")
+    c = rand_fr(2051, 41)
+    ev = gpu.ntt(oc.fr_from_ints(c + [0] * (4096 - 2051)))
+    lhs = affine_of(gpu.msm(srs, ev))
+    rhs = affine_of(gpu.msm_raw(mono_wire[:2051], oc.fr_from_ints(c)))
+    assert lhs == rhs == affine_of(oc.msm_pippenger(mono_wire[:2051], oc.fr_from_ints(c), 0, 8))
+
+
+def test_prover_size_16384(gpu):
+    """The real workload: n = 2^14 over lagrange-srs-16384.bin."""
+    wire, _ = load_srs("lagrange-srs-16384.bin")
+    srs = gpu.Srs.from_host(wire)
+    try:
+        s = rand_fr_wire(16384, 14)
+        assert affine_of(gpu.msm(srs, s)) == affine_of(oc.msm_pippenger(wire, s, 0, 8))
+    finally:
+        srs.release()
+
+
+@pytest.mark.parametrize("c", [6, 9, 13, 16])
+def test_window_bits_do_not_change_result(gpu, lagrange, c):
+    srs, wire, _ = lagrange
+    s = rand_fr_wire(3000, 60 + c)
+    gpu.set_msm_window_bits(c)
+    try:
+        _check(gpu, srs, wire, s)
+    finally:
+        gpu.set_msm_window_bits(0)

@@ -1,0 +1,62 @@
+"""Full-size checks through size-independent properties (no oracle pass over 2^24 points):
+with P_i = (i+1) Q the MSM has the closed form (sum_i s_i (i+1)) Q."""
+import numpy as np
+import pytest
+import torch
+
+import bn254_py as opy
+import oracle_c as oc
+from util import affine_of, weighted_index_sum
+
+pytestmark = pytest.mark.gpu
+
+
+def _wire(t):
+    return t.cpu().numpy().view(np.uint64).reshape(-1, 4)
+
+
+@pytest.mark.parametrize("log_n", [10, 16, 20])
+def test_arith_points_closed_form(gpu, log_n):
+    n = 1 << log_n
+    pts = torch.empty((n, 8), dtype=torch.int64, device="cuda")
+    sc = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    seed = oc.fr_from_ints([0x755A6B67655F6D73])[0]
+    gpu.synth_points_arith(pts.data_ptr(), n, seed)
+    gpu.synth_scalars(sc.data_ptr(), n, 42)
+    srs = gpu.Srs.from_device(pts.data_ptr(), n)
+    try:
+        got = affine_of(gpu.msm_device(srs, sc.data_ptr(), n))
+    finally:
+        srs.release()
+    k = weighted_index_sum(_wire(sc))
+    q = opy.g1_mul(opy.G1_GEN, 0x755A6B67655F6D73)
+    assert got == opy.g1_mul(q, k)
+    # the generated points themselves: first few equal (i+1) Q and lie on the curve
+    head = pts[:4].cpu().numpy().view(np.uint64)
+    for i in range(4):
+        assert opy.wire_to_affine(head[i].tobytes()) == opy.g1_mul(q, i + 1)
+
+
+def test_random_points_on_curve_and_split_property(gpu):
+    """hash-to-curve points are valid; MSM(all) == MSM(first half) + MSM(second half); and the
+    result equals the CPU oracle at 2^16."""
+    n = 1 << 16
+    pts = torch.empty((n, 8), dtype=torch.int64, device="cuda")
+    sc = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    gpu.synth_points_random(pts.data_ptr(), n, 1234)
+    gpu.synth_scalars(sc.data_ptr(), n, 99)
+    hp = pts.cpu().numpy().view(np.uint64).reshape(-1, 8)
+    hs = sc.cpu().numpy().view(np.uint64).reshape(-1, 4)
+    for i in (0, 1, 1000, n - 1):
+        assert oc.lib.oracle_g1_is_on_curve(oc._p(np.ascontiguousarray(hp[i]))) == 1
+    srs = gpu.Srs.from_device(pts.data_ptr(), n)
+    try:
+        full = gpu.msm_device(srs, sc.data_ptr(), n)
+        h1 = gpu.msm_device(srs, sc.data_ptr(), n // 2)
+        h2 = gpu.msm_device(srs, sc.data_ptr() + (n // 2) * 32, n // 2, offset=n // 2)
+    finally:
+        srs.release()
+    assert affine_of(gpu.g1_fold(np.stack([h1, h2]))) == affine_of(full)
+    assert affine_of(full) == affine_of(oc.msm_pippenger(hp, hs, 0, 16))

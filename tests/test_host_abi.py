@@ -1,0 +1,78 @@
+"""CPU-side checks of the product: the C-ABI library loads, exports every symbol
+include/uzkge_gpu.h declares, its host-only entry points (domain queries, fold, to_affine)
+agree with the oracle, and compute entry points fail loudly without a GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import bn254_py as opy
+import oracle_c as oc
+from util import load_srs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    from uzkge_amd import _native as N
+    hdr = open(os.path.join(ROOT, "include", "uzkge_gpu.h")).read()
+    declared = set(re.findall(r"\b(uzk_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"uzk_g1_affine", "uzk_g1_jac"}
+    assert declared, "header parse failed"
+    for name in sorted(declared):
+        assert hasattr(N.lib, name), f"{name} declared in include/uzkge_gpu.h but not exported"
+    assert declared == set(N.PROTOTYPES), (declared ^ set(N.PROTOTYPES))
+
+
+def test_domain_queries_match_oracle():
+    from uzkge_amd import backend as b
+    for n in (1, 2, 3, 4, 48, 1 << 14, 98304, 1 << 22, 1 << 28):
+        assert b.domain_supported(n)
+        assert np.array_equal(b.domain_group_gen(n), oc.root_of_unity(n))
+    for n in (0, 5, 9, 1 << 29):
+        assert not b.domain_supported(n)
+
+
+def test_host_fold_and_to_affine_match_oracle():
+    from uzkge_amd import backend as b
+    wire, pts = load_srs("lagrange-srs-4096.bin")
+    one_q = oc.fr_from_ints([1], mod=opy.P)[0]
+    parts = np.stack([np.concatenate([wire[i], one_q]) for i in range(8)])
+    parts[3, 8:12] = 0                                   # an infinity partial (z == 0)
+    want = None
+    for i in range(8):
+        if i != 3:
+            want = opy.g1_add(want, pts[i])
+    folded = b.g1_fold(parts)
+    assert oc.jac_to_affine_ints(folded) == want
+    aff = b.g1_to_affine(folded)
+    assert opy.wire_to_affine(aff.tobytes()) == want
+    # P + P and P + (-P) through the fold
+    assert oc.jac_to_affine_ints(b.g1_fold(np.stack([parts[0], parts[0]]))) == opy.g1_add(pts[0], pts[0])
+    neg = oc.points_from_affine([opy.g1_neg(pts[0])])[0]
+    assert oc.jac_to_affine_ints(b.g1_fold(np.stack([parts[0], np.concatenate([neg, one_q])]))) is None
+    assert not b.g1_to_affine(np.zeros(12, dtype=np.uint64)).any()
+
+
+def test_compute_fails_loudly_without_gpu():
+    from uzkge_amd import UzkgeError, backend as b
+    if b.device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(UzkgeError) as e:
+        b.ntt(np.zeros((4, 4), dtype=np.uint64))
+    assert e.value.kind == "DeviceError"
+    with pytest.raises(UzkgeError):
+        b.msm_raw(np.zeros((1, 8), dtype=np.uint64), np.zeros((1, 4), dtype=np.uint64))
+    with pytest.raises(UzkgeError) as e:
+        b.ntt(np.zeros((5, 4), dtype=np.uint64))          # bad domain is reported before the device
+    assert e.value.kind == "FFTError"
+
+
+def test_product_does_not_import_oracle():
+    """The product path must never route through the oracle."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "uzkge_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle" not in src.lower() or f == "__init__.py" and False, f"{f} mentions the oracle"

@@ -1,0 +1,68 @@
+"""ctypes binding of libuzkge_gpu.so (C ABI: include/uzkge_gpu.h).
+
+The library is the product; this module only loads it and declares the prototypes.  There is no
+Python or CPU fallback: if the shared object is missing (not built) the import fails loudly, and
+if no gfx950 device is usable every compute call raises `UzkgeError(DEVICE)`.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libuzkge_gpu.so")
+
+UZK_OK, UZK_ERR_PARAMETER, UZK_ERR_DEGREE, UZK_ERR_FFT, UZK_ERR_COMMITMENT, UZK_ERR_DEVICE = range(6)
+
+# symbol -> (restype, argtypes); every symbol include/uzkge_gpu.h declares
+_P = ctypes.c_void_p
+_SZ = ctypes.c_size_t
+_U64 = ctypes.c_uint64
+_I = ctypes.c_int
+PROTOTYPES = {
+    "uzk_init": (_I, [_I]),
+    "uzk_shutdown": (_I, []),
+    "uzk_device_count": (_I, []),
+    "uzk_last_error": (ctypes.c_char_p, []),
+    "uzk_version": (ctypes.c_char_p, []),
+    "uzk_srs_register": (_I, [_P, _SZ, ctypes.POINTER(_U64)]),
+    "uzk_srs_register_device": (_I, [_P, _SZ, ctypes.POINTER(_U64)]),
+    "uzk_srs_release": (_I, [_U64]),
+    "uzk_srs_len": (_I, [_U64, ctypes.POINTER(_SZ)]),
+    "uzk_msm_g1": (_I, [_U64, _SZ, _P, _SZ, _P]),
+    "uzk_msm_g1_device": (_I, [_U64, _SZ, _P, _SZ, _P]),
+    "uzk_msm_g1_raw": (_I, [_P, _P, _SZ, _P]),
+    "uzk_g1_fold": (_I, [_P, _SZ, _P]),
+    "uzk_g1_to_affine": (_I, [_P, _P]),
+    "uzk_domain_supported": (_I, [_U64]),
+    "uzk_domain_group_gen": (_I, [_U64, _P]),
+    "uzk_ntt_fr": (_I, [_P, _U64, _I, _P]),
+    "uzk_ntt_fr_device": (_I, [_P, _P, _U64, _I, _P, _I]),
+    "uzk_synth_points_arith": (_I, [_P, _SZ, _P]),
+    "uzk_synth_points_random": (_I, [_P, _SZ, _U64]),
+    "uzk_synth_scalars": (_I, [_P, _SZ, _U64]),
+    "uzk_profile_enable": (_I, [_I]),
+    "uzk_profile_reset": (_I, []),
+    "uzk_profile_get": (_I, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_U64)]),
+    "uzk_profile_dump": (_I, [ctypes.c_char_p, _SZ]),
+    "uzk_sync": (_I, []),
+    "uzk_stream": (_P, []),
+    "uzk_msm_set_window_bits": (_I, [_I]),
+}
+
+
+def load() -> ctypes.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C uzkge_amd/csrc` (hipcc, gfx950). The MI355X backend has no fallback path."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)   # AttributeError here == header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = load()

@@ -1,0 +1,172 @@
+"""Thin numpy-facing wrappers over the C ABI.  Field elements travel as uint64 arrays in the wire
+format of include/uzkge_gpu.h (Montgomery, 4 LE limbs): scalars [n,4], affine points [n,8],
+Jacobian results [12]."""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import numpy as np
+
+from . import _native as N
+from .errors import check
+
+lib = N.lib
+
+
+def _ptr(a: np.ndarray) -> ctypes.c_void_p:
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"], "need C-contiguous uint64"
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def init(device: int = 0) -> None:
+    check(lib.uzk_init(device))
+
+
+def shutdown() -> None:
+    check(lib.uzk_shutdown())
+
+
+def device_count() -> int:
+    return lib.uzk_device_count()
+
+
+def sync() -> None:
+    check(lib.uzk_sync())
+
+
+class Srs:
+    """Device-resident SRS (static bases of KZG commit)."""
+
+    def __init__(self, handle: int, n: int):
+        self.handle, self.n = handle, n
+
+    @classmethod
+    def from_host(cls, points: np.ndarray) -> "Srs":
+        pts = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 8)
+        h = ctypes.c_uint64(0)
+        check(lib.uzk_srs_register(_ptr(pts), pts.shape[0], ctypes.byref(h)))
+        return cls(h.value, pts.shape[0])
+
+    @classmethod
+    def from_device(cls, d_ptr: int, n: int) -> "Srs":
+        h = ctypes.c_uint64(0)
+        check(lib.uzk_srs_register_device(ctypes.c_void_p(d_ptr), n, ctypes.byref(h)))
+        return cls(h.value, n)
+
+    def release(self) -> None:
+        if self.handle:
+            check(lib.uzk_srs_release(self.handle))
+            self.handle = 0
+
+
+def msm(srs: Srs, scalars: np.ndarray, offset: int = 0) -> np.ndarray:
+    """sum_i scalars[i] * SRS[offset+i] -> Jacobian [12] (G1Projective::msm, kzg_poly_commitment.rs:290)."""
+    s = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+    out = np.zeros(12, dtype=np.uint64)
+    check(lib.uzk_msm_g1(srs.handle, offset, _ptr(s) if s.shape[0] else None, s.shape[0], _ptr(out)))
+    return out
+
+
+def msm_device(srs: Srs, d_scalars: int, n: int, offset: int = 0) -> np.ndarray:
+    out = np.zeros(12, dtype=np.uint64)
+    check(lib.uzk_msm_g1_device(srs.handle, offset, ctypes.c_void_p(d_scalars), n, _ptr(out)))
+    return out
+
+
+def msm_raw(points: np.ndarray, scalars: np.ndarray) -> np.ndarray:
+    p = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 8)
+    s = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+    if p.shape[0] != s.shape[0]:
+        # ark_ec::VariableBaseMSM::msm returns Err(min_len) here; the reference unwraps it
+        from .errors import UzkgeError
+        raise UzkgeError(N.UZK_ERR_COMMITMENT, f"points ({p.shape[0]}) and scalars ({s.shape[0]}) differ in length")
+    out = np.zeros(12, dtype=np.uint64)
+    check(lib.uzk_msm_g1_raw(_ptr(p) if p.shape[0] else None, _ptr(s) if s.shape[0] else None, s.shape[0], _ptr(out)))
+    return out
+
+
+def g1_fold(partials: np.ndarray) -> np.ndarray:
+    p = np.ascontiguousarray(partials, dtype=np.uint64).reshape(-1, 12)
+    out = np.zeros(12, dtype=np.uint64)
+    check(lib.uzk_g1_fold(_ptr(p), p.shape[0], _ptr(out)))
+    return out
+
+
+def g1_to_affine(jac: np.ndarray) -> np.ndarray:
+    j = np.ascontiguousarray(jac, dtype=np.uint64).reshape(12)
+    out = np.zeros(8, dtype=np.uint64)
+    check(lib.uzk_g1_to_affine(_ptr(j), _ptr(out)))
+    return out
+
+
+def domain_supported(n: int) -> bool:
+    return bool(lib.uzk_domain_supported(n))
+
+
+def domain_group_gen(n: int) -> np.ndarray:
+    out = np.zeros(4, dtype=np.uint64)
+    check(lib.uzk_domain_group_gen(n, _ptr(out)))
+    return out
+
+
+def ntt(data: np.ndarray, inverse: bool = False, coset_shift: Optional[np.ndarray] = None) -> np.ndarray:
+    """EvaluationDomain::fft / ifft over the size-len(data) domain (field_polynomial.rs:583-597);
+    returns a new [n,4] array, natural order."""
+    a = np.ascontiguousarray(data, dtype=np.uint64).reshape(-1, 4).copy()
+    cs = None
+    if coset_shift is not None:
+        cs = np.ascontiguousarray(coset_shift, dtype=np.uint64).reshape(4)
+    check(lib.uzk_ntt_fr(_ptr(a), a.shape[0], int(inverse), _ptr(cs) if cs is not None else None))
+    return a
+
+
+def ntt_device(d_in: int, d_out: int, n: int, inverse: bool = False, coset_shift: Optional[np.ndarray] = None,
+               sync: bool = False) -> None:
+    cs = None
+    if coset_shift is not None:
+        cs = np.ascontiguousarray(coset_shift, dtype=np.uint64).reshape(4)
+    check(lib.uzk_ntt_fr_device(ctypes.c_void_p(d_in), ctypes.c_void_p(d_out), n, int(inverse),
+                                _ptr(cs) if cs is not None else None, int(sync)))
+
+
+def synth_points_arith(d_points: int, n: int, seed_scalar_mont: np.ndarray) -> None:
+    s = np.ascontiguousarray(seed_scalar_mont, dtype=np.uint64).reshape(4)
+    check(lib.uzk_synth_points_arith(ctypes.c_void_p(d_points), n, _ptr(s)))
+
+
+def synth_points_random(d_points: int, n: int, seed: int) -> None:
+    check(lib.uzk_synth_points_random(ctypes.c_void_p(d_points), n, seed))
+
+
+def synth_scalars(d_scalars: int, n: int, seed: int) -> None:
+    check(lib.uzk_synth_scalars(ctypes.c_void_p(d_scalars), n, seed))
+
+
+def profile_enable(on: bool) -> None:
+    check(lib.uzk_profile_enable(int(on)))
+
+
+def profile_reset() -> None:
+    check(lib.uzk_profile_reset())
+
+
+def profile_get(name: str):
+    ms = ctypes.c_double(0)
+    cnt = ctypes.c_uint64(0)
+    check(lib.uzk_profile_get(name.encode(), ctypes.byref(ms), ctypes.byref(cnt)))
+    return ms.value, cnt.value
+
+
+def profile_table() -> dict:
+    buf = ctypes.create_string_buffer(1 << 16)
+    check(lib.uzk_profile_dump(buf, len(buf)))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, cnt, ms = line.split()
+        out[name] = (int(cnt), float(ms))
+    return out
+
+
+def set_msm_window_bits(c: int) -> None:
+    check(lib.uzk_msm_set_window_bits(c))

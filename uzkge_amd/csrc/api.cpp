@@ -1,0 +1,438 @@
+// extern "C" surface of libuzkge_gpu.so (declared in include/uzkge_gpu.h).
+// Thin: argument checks, staging of host buffers, error mapping; all compute is in the .hip files.
+// There is deliberately no CPU fallback: without a gfx950 device every compute call fails with
+// UZK_ERR_DEVICE.
+#include <cstdarg>
+#include <cstring>
+
+#include "ctx.hpp"
+#include "host_math.hpp"
+
+namespace uzk {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+Ctx& ctx() {
+    static Ctx c;
+    return c;
+}
+std::mutex& ctx_mutex() {
+    static std::mutex m;
+    return m;
+}
+
+int DevBuf::reserve(size_t bytes) {
+    if (bytes <= cap) return UZK_OK;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    size_t want = bytes + (bytes >> 3);   // 12.5 % head-room against regrowth
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+        want = bytes;
+        e = hipMalloc(&p, want);
+    }
+    if (e != hipSuccess) {
+        p = nullptr;
+        set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        return UZK_ERR_DEVICE;
+    }
+    cap = want;
+    return UZK_OK;
+}
+void DevBuf::release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+}
+
+hipEvent_t Ctx::get_event() {
+    if (!event_pool.empty()) {
+        hipEvent_t e = event_pool.back();
+        event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+void Ctx::prof_begin(const char* name) {
+    ProfEntry pe;
+    pe.name = name;
+    pe.e0 = get_event();
+    pe.e1 = get_event();
+    (void)hipEventRecord(pe.e0, stream);
+    prof_pending.push_back(pe);
+}
+void Ctx::prof_end() {
+    if (!prof_pending.empty()) (void)hipEventRecord(prof_pending.back().e1, stream);
+}
+int Ctx::prof_collect() {
+    if (prof_pending.empty()) return UZK_OK;
+    UZK_HIP(hipStreamSynchronize(stream));
+    for (auto& pe : prof_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pe.e0, pe.e1) == hipSuccess) {
+            auto& t = prof_totals[pe.name];
+            t.first += ms;
+            t.second += 1;
+        }
+        event_pool.push_back(pe.e0);
+        event_pool.push_back(pe.e1);
+    }
+    prof_pending.clear();
+    return UZK_OK;
+}
+
+int require_ready() {
+    Ctx& c = ctx();
+    if (c.ready) return UZK_OK;
+    // lazy init on device 0 so a plain library user need not call uzk_init
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        set_error("no HIP device visible: the MI355X backend has no CPU fallback");
+        return UZK_ERR_DEVICE;
+    }
+    UZK_HIP(hipSetDevice(0));
+    UZK_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    hipDeviceProp_t prop;
+    UZK_HIP(hipGetDeviceProperties(&prop, 0));
+    c.num_cus = prop.multiProcessorCount;
+    c.device = 0;
+    c.ready = true;
+    return UZK_OK;
+}
+
+static const Fp* as_fp(const uint64_t* p) { return reinterpret_cast<const Fp*>(p); }
+
+}  // namespace uzk
+
+using namespace uzk;
+
+#define API_LOCK std::lock_guard<std::mutex> _lk(ctx_mutex())
+
+extern "C" {
+
+const char* uzk_version(void) { return "uzkge-amd 0.1 (gfx950)"; }
+const char* uzk_last_error(void) { return g_err; }
+
+int uzk_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int uzk_init(int device) {
+    API_LOCK;
+    Ctx& c = ctx();
+    if (c.ready) {
+        if (c.device == device) return UZK_OK;
+        set_error("uzk_init(%d): already bound to device %d (one process per GPU)", device, c.device);
+        return UZK_ERR_PARAMETER;
+    }
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        set_error("no HIP device visible: the MI355X backend has no CPU fallback");
+        return UZK_ERR_DEVICE;
+    }
+    if (device < 0 || device >= n) {
+        set_error("uzk_init(%d): %d device(s) visible", device, n);
+        return UZK_ERR_PARAMETER;
+    }
+    UZK_HIP(hipSetDevice(device));
+    UZK_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    hipDeviceProp_t prop;
+    UZK_HIP(hipGetDeviceProperties(&prop, device));
+    c.num_cus = prop.multiProcessorCount;
+    c.device = device;
+    c.ready = true;
+    return UZK_OK;
+}
+
+int uzk_shutdown(void) {
+    API_LOCK;
+    Ctx& c = ctx();
+    if (!c.ready) return UZK_OK;
+    (void)hipStreamSynchronize(c.stream);
+    ntt_free_plans(c);
+    msm_free(c);
+    for (auto& kv : c.srs) if (kv.second.owned && kv.second.d_points) (void)hipFree(kv.second.d_points);
+    c.srs.clear();
+    c.ntt_scratch[0].release(); c.ntt_scratch[1].release(); c.ntt_io.release(); c.msm_scalars.release();
+    for (auto& pe : c.prof_pending) { (void)hipEventDestroy(pe.e0); (void)hipEventDestroy(pe.e1); }
+    c.prof_pending.clear();
+    for (auto e : c.event_pool) (void)hipEventDestroy(e);
+    c.event_pool.clear();
+    (void)hipStreamDestroy(c.stream);
+    c.stream = nullptr;
+    c.ready = false;
+    c.device = -1;
+    return UZK_OK;
+}
+
+/* ---- SRS ---------------------------------------------------------------------------------- */
+int uzk_srs_register(const uzk_g1_affine* points, size_t n, uint64_t* handle_out) {
+    API_LOCK;
+    if (!handle_out || (n > 0 && !points)) { set_error("uzk_srs_register: null pointer"); return UZK_ERR_PARAMETER; }
+    UZK_TRY(require_ready());
+    Ctx& c = ctx();
+    Ctx::Srs s;
+    s.n = n;
+    s.owned = true;
+    if (n > 0) {
+        UZK_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_points), n * sizeof(Affine)));
+        UZK_HIP(hipMemcpyAsync(s.d_points, points, n * sizeof(Affine), hipMemcpyHostToDevice, c.stream));
+        UZK_HIP(hipStreamSynchronize(c.stream));
+    }
+    const uint64_t h = c.next_handle++;
+    c.srs[h] = s;
+    *handle_out = h;
+    return UZK_OK;
+}
+
+int uzk_srs_register_device(const void* d_points, size_t n, uint64_t* handle_out) {
+    API_LOCK;
+    if (!handle_out || (n > 0 && !d_points)) { set_error("uzk_srs_register_device: null pointer"); return UZK_ERR_PARAMETER; }
+    UZK_TRY(require_ready());
+    Ctx& c = ctx();
+    Ctx::Srs s;
+    s.n = n;
+    s.owned = false;
+    s.d_points = const_cast<Affine*>(static_cast<const Affine*>(d_points));
+    const uint64_t h = c.next_handle++;
+    c.srs[h] = s;
+    *handle_out = h;
+    return UZK_OK;
+}
+
+int uzk_srs_release(uint64_t handle) {
+    API_LOCK;
+    Ctx& c = ctx();
+    auto it = c.srs.find(handle);
+    if (it == c.srs.end()) { set_error("uzk_srs_release: unknown handle %llu", (unsigned long long)handle); return UZK_ERR_PARAMETER; }
+    if (it->second.owned && it->second.d_points) {
+        (void)hipStreamSynchronize(c.stream);
+        (void)hipFree(it->second.d_points);
+    }
+    c.srs.erase(it);
+    return UZK_OK;
+}
+
+int uzk_srs_len(uint64_t handle, size_t* n_out) {
+    API_LOCK;
+    Ctx& c = ctx();
+    auto it = c.srs.find(handle);
+    if (it == c.srs.end() || !n_out) { set_error("uzk_srs_len: unknown handle"); return UZK_ERR_PARAMETER; }
+    *n_out = it->second.n;
+    return UZK_OK;
+}
+
+/* ---- MSM ---------------------------------------------------------------------------------- */
+static int msm_checked(uint64_t srs_handle, size_t offset, size_t n, const Affine** pts) {
+    Ctx& c = ctx();
+    auto it = c.srs.find(srs_handle);
+    if (it == c.srs.end()) { set_error("msm: unknown SRS handle %llu", (unsigned long long)srs_handle); return UZK_ERR_PARAMETER; }
+    if (offset > it->second.n || n > it->second.n - offset) {
+        // KZG commit: degree + 1 > SRS length (kzg_poly_commitment.rs:283-285)
+        set_error("msm: offset %zu + n %zu exceeds SRS length %zu", offset, n, it->second.n);
+        return UZK_ERR_DEGREE;
+    }
+    *pts = it->second.d_points + offset;
+    return UZK_OK;
+}
+
+int uzk_msm_g1_device(uint64_t srs_handle, size_t offset, const void* d_scalars_mont, size_t n, uzk_g1_jac* out) {
+    API_LOCK;
+    if (!out || (n > 0 && !d_scalars_mont)) { set_error("uzk_msm_g1_device: null pointer"); return UZK_ERR_PARAMETER; }
+    UZK_TRY(require_ready());
+    const Affine* pts = nullptr;
+    UZK_TRY(msm_checked(srs_handle, offset, n, &pts));
+    Jac r;
+    UZK_TRY(msm_run(ctx(), pts, static_cast<const Fp*>(d_scalars_mont), n, &r));
+    std::memcpy(out, &r, sizeof r);
+    return UZK_OK;
+}
+
+int uzk_msm_g1(uint64_t srs_handle, size_t offset, const uint64_t* scalars_mont, size_t n, uzk_g1_jac* out) {
+    API_LOCK;
+    if (!out || (n > 0 && !scalars_mont)) { set_error("uzk_msm_g1: null pointer"); return UZK_ERR_PARAMETER; }
+    UZK_TRY(require_ready());
+    Ctx& c = ctx();
+    const Affine* pts = nullptr;
+    UZK_TRY(msm_checked(srs_handle, offset, n, &pts));
+    Jac r = jac_inf();
+    if (n > 0) {
+        UZK_TRY(c.msm_scalars.reserve(n * sizeof(Fp)));
+        UZK_HIP(hipMemcpyAsync(c.msm_scalars.p, scalars_mont, n * sizeof(Fp), hipMemcpyHostToDevice, c.stream));
+        UZK_TRY(msm_run(c, pts, c.msm_scalars.as<Fp>(), n, &r));
+    }
+    std::memcpy(out, &r, sizeof r);
+    return UZK_OK;
+}
+
+int uzk_msm_g1_raw(const uzk_g1_affine* points, const uint64_t* scalars_mont, size_t n, uzk_g1_jac* out) {
+    if (!out || (n > 0 && (!points || !scalars_mont))) { set_error("uzk_msm_g1_raw: null pointer"); return UZK_ERR_PARAMETER; }
+    uint64_t h = 0;
+    UZK_TRY(uzk_srs_register(points, n, &h));
+    int rc = uzk_msm_g1(h, 0, scalars_mont, n, out);
+    (void)uzk_srs_release(h);
+    return rc;
+}
+
+int uzk_g1_fold(const uzk_g1_jac* partials, size_t count, uzk_g1_jac* out) {
+    if (!out || (count > 0 && !partials)) { set_error("uzk_g1_fold: null pointer"); return UZK_ERR_PARAMETER; }
+    XYZZ acc = xyzz_inf();
+    for (size_t i = 0; i < count; ++i) {
+        Jac j;
+        std::memcpy(&j, &partials[i], sizeof j);
+        XYZZ q = xyzz_from_jac(j);
+        xyzz_add(acc, q);
+    }
+    Jac r = xyzz_to_jac(acc);
+    std::memcpy(out, &r, sizeof r);
+    return UZK_OK;
+}
+
+int uzk_g1_to_affine(const uzk_g1_jac* p, uzk_g1_affine* out) {
+    if (!p || !out) { set_error("uzk_g1_to_affine: null pointer"); return UZK_ERR_PARAMETER; }
+    Jac j;
+    std::memcpy(&j, p, sizeof j);
+    Affine a = jac_to_affine_host(j);
+    std::memcpy(out, &a, sizeof a);
+    return UZK_OK;
+}
+
+/* ---- NTT ---------------------------------------------------------------------------------- */
+int uzk_domain_supported(uint64_t n) { return domain_supported(n) ? 1 : 0; }
+
+int uzk_domain_group_gen(uint64_t n, uint64_t out_mont[4]) {
+    if (!out_mont) { set_error("uzk_domain_group_gen: null pointer"); return UZK_ERR_PARAMETER; }
+    if (!domain_supported(n)) { set_error("no evaluation domain of size %llu", (unsigned long long)n); return UZK_ERR_FFT; }
+    Fp w = fr_root_of_unity(n);
+    std::memcpy(out_mont, &w, sizeof w);
+    return UZK_OK;
+}
+
+int uzk_ntt_fr_device(const void* d_in, void* d_out, uint64_t n, int inverse, const uint64_t* coset_shift_mont, int sync) {
+    API_LOCK;
+    if (!domain_supported(n)) {
+        set_error("no evaluation domain of size %llu (need 2^k, k<=28, or 3*2^k)", (unsigned long long)n);
+        return UZK_ERR_FFT;
+    }
+    if (!d_in || !d_out) { set_error("uzk_ntt_fr_device: null pointer"); return UZK_ERR_PARAMETER; }
+    UZK_TRY(require_ready());
+    Ctx& c = ctx();
+    UZK_TRY(ntt_run(c, static_cast<const Fp*>(d_in), static_cast<Fp*>(d_out), n, inverse != 0,
+                    coset_shift_mont ? as_fp(coset_shift_mont) : nullptr));
+    if (sync) UZK_HIP(hipStreamSynchronize(c.stream));
+    return UZK_OK;
+}
+
+int uzk_ntt_fr(uint64_t* data, uint64_t n, int inverse, const uint64_t* coset_shift_mont) {
+    API_LOCK;
+    if (!domain_supported(n)) {
+        set_error("no evaluation domain of size %llu (need 2^k, k<=28, or 3*2^k)", (unsigned long long)n);
+        return UZK_ERR_FFT;
+    }
+    if (!data) { set_error("uzk_ntt_fr: null pointer"); return UZK_ERR_PARAMETER; }
+    UZK_TRY(require_ready());
+    Ctx& c = ctx();
+    const size_t bytes = (size_t)n * sizeof(Fp);
+    UZK_TRY(c.ntt_io.reserve(bytes));
+    UZK_HIP(hipMemcpyAsync(c.ntt_io.p, data, bytes, hipMemcpyHostToDevice, c.stream));
+    UZK_TRY(ntt_run(c, c.ntt_io.as<Fp>(), c.ntt_io.as<Fp>(), n, inverse != 0,
+                    coset_shift_mont ? as_fp(coset_shift_mont) : nullptr));
+    UZK_HIP(hipMemcpyAsync(data, c.ntt_io.p, bytes, hipMemcpyDeviceToHost, c.stream));
+    UZK_HIP(hipStreamSynchronize(c.stream));
+    return UZK_OK;
+}
+
+/* ---- synthetic workloads ------------------------------------------------------------------ */
+int uzk_synth_points_arith(void* d_points, size_t n, const uint64_t* seed_scalar_mont) {
+    API_LOCK;
+    if ((n > 0 && !d_points) || !seed_scalar_mont) { set_error("uzk_synth_points_arith: null pointer"); return UZK_ERR_PARAMETER; }
+    UZK_TRY(require_ready());
+    return synth_points_arith(ctx(), static_cast<Affine*>(d_points), n, *as_fp(seed_scalar_mont));
+}
+int uzk_synth_points_random(void* d_points, size_t n, uint64_t seed) {
+    API_LOCK;
+    if (n > 0 && !d_points) { set_error("uzk_synth_points_random: null pointer"); return UZK_ERR_PARAMETER; }
+    UZK_TRY(require_ready());
+    UZK_TRY(synth_points_random(ctx(), static_cast<Affine*>(d_points), n, seed));
+    UZK_HIP(hipStreamSynchronize(ctx().stream));
+    return UZK_OK;
+}
+int uzk_synth_scalars(void* d_scalars, size_t n, uint64_t seed) {
+    API_LOCK;
+    if (n > 0 && !d_scalars) { set_error("uzk_synth_scalars: null pointer"); return UZK_ERR_PARAMETER; }
+    UZK_TRY(require_ready());
+    UZK_TRY(synth_scalars(ctx(), static_cast<Fp*>(d_scalars), n, seed));
+    UZK_HIP(hipStreamSynchronize(ctx().stream));
+    return UZK_OK;
+}
+
+/* ---- measurement -------------------------------------------------------------------------- */
+int uzk_profile_enable(int on) {
+    API_LOCK;
+    UZK_TRY(require_ready());
+    Ctx& c = ctx();
+    UZK_TRY(c.prof_collect());
+    c.prof_on = on != 0;
+    return UZK_OK;
+}
+int uzk_profile_reset(void) {
+    API_LOCK;
+    Ctx& c = ctx();
+    if (c.ready) UZK_TRY(c.prof_collect());
+    c.prof_totals.clear();
+    return UZK_OK;
+}
+int uzk_profile_get(const char* name, double* total_ms, uint64_t* launches) {
+    API_LOCK;
+    Ctx& c = ctx();
+    if (!name) { set_error("uzk_profile_get: null name"); return UZK_ERR_PARAMETER; }
+    if (c.ready) UZK_TRY(c.prof_collect());
+    auto it = c.prof_totals.find(name);
+    if (total_ms) *total_ms = (it == c.prof_totals.end()) ? 0.0 : it->second.first;
+    if (launches) *launches = (it == c.prof_totals.end()) ? 0 : it->second.second;
+    return UZK_OK;
+}
+int uzk_profile_dump(char* buf, size_t cap) {
+    API_LOCK;
+    Ctx& c = ctx();
+    if (!buf || cap == 0) { set_error("uzk_profile_dump: null buffer"); return UZK_ERR_PARAMETER; }
+    if (c.ready) UZK_TRY(c.prof_collect());
+    size_t off = 0;
+    buf[0] = 0;
+    for (auto& kv : c.prof_totals) {
+        int w = snprintf(buf + off, cap - off, "%s %llu %.6f\n", kv.first.c_str(),
+                         (unsigned long long)kv.second.second, kv.second.first);
+        if (w < 0 || (size_t)w >= cap - off) break;
+        off += (size_t)w;
+    }
+    return UZK_OK;
+}
+int uzk_sync(void) {
+    API_LOCK;
+    UZK_TRY(require_ready());
+    UZK_HIP(hipStreamSynchronize(ctx().stream));
+    return UZK_OK;
+}
+void* uzk_stream(void) {
+    API_LOCK;
+    if (require_ready() != UZK_OK) return nullptr;
+    return ctx().stream;
+}
+int uzk_msm_set_window_bits(int c) {
+    API_LOCK;
+    if (c != 0 && (c < 4 || c > 16)) { set_error("window bits must be 0 (auto) or 4..16"); return UZK_ERR_PARAMETER; }
+    ctx().msm_window_bits = c;
+    return UZK_OK;
+}
+
+}  // extern "C"

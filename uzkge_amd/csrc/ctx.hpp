@@ -1,0 +1,105 @@
+// Process-wide backend context: one HIP device, one stream, grow-only HBM workspaces, per-kernel
+// hipEvent profiling.  One process per GPU (the multi-GPU MSM runs one process per device and
+// exchanges 96-byte partial sums through the host language's RCCL binding).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/uzkge_gpu.h"
+#include "ec.hpp"
+
+namespace uzk {
+
+void set_error(const char* fmt, ...);
+
+#define UZK_HIP(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            ::uzk::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return UZK_ERR_DEVICE;                                                         \
+        }                                                                                  \
+    } while (0)
+
+#define UZK_TRY(expr)                  \
+    do {                               \
+        int _rc = (expr);              \
+        if (_rc != UZK_OK) return _rc; \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes);   // grow-only; contents NOT preserved on growth
+    void release();
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct ProfEntry {
+    std::string name;
+    hipEvent_t e0, e1;
+};
+
+struct NttPlan;   // ntt.hip
+struct MsmWork;   // msm.hip
+
+struct Ctx {
+    bool ready = false;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    int num_cus = 256;
+    // profiling
+    bool prof_on = false;
+    std::vector<ProfEntry> prof_pending;
+    std::vector<hipEvent_t> event_pool;
+    std::map<std::string, std::pair<double, uint64_t>> prof_totals;
+    // NTT plans keyed by (n << 1 | inverse)
+    std::map<uint64_t, NttPlan*> ntt_plans;
+    DevBuf ntt_scratch[2];
+    DevBuf ntt_io;            // staging for the host-pointer API
+    // MSM
+    MsmWork* msm = nullptr;
+    DevBuf msm_scalars;       // staging for host scalars
+    int msm_window_bits = 0;  // 0 = auto
+    // SRS registry
+    struct Srs {
+        Affine* d_points = nullptr;
+        size_t n = 0;
+        bool owned = false;
+    };
+    std::map<uint64_t, Srs> srs;
+    uint64_t next_handle = 1;
+
+    hipEvent_t get_event();
+    void prof_begin(const char* name);
+    void prof_end();
+    int prof_collect();   // sync + fold pending events into totals
+};
+
+Ctx& ctx();
+std::mutex& ctx_mutex();
+int require_ready();
+
+// RAII kernel-launch bracket:  { KernelScope ks(c, "name"); kernel<<<...>>>(...); }
+struct KernelScope {
+    Ctx& c;
+    KernelScope(Ctx& c_, const char* name) : c(c_) { if (c.prof_on) c.prof_begin(name); }
+    ~KernelScope() { if (c.prof_on) c.prof_end(); }
+};
+
+// entry points implemented in the .hip files
+int ntt_run(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse, const Fp* coset_shift_host);
+void ntt_free_plans(Ctx& c);
+int msm_run(Ctx& c, const Affine* d_points, const Fp* d_scalars, size_t n, Jac* out_host);
+void msm_free(Ctx& c);
+int synth_points_arith(Ctx& c, Affine* d_points, size_t n, const Fp& seed_scalar_mont);
+int synth_points_random(Ctx& c, Affine* d_points, size_t n, uint64_t seed);
+int synth_scalars(Ctx& c, Fp* d_scalars, size_t n, uint64_t seed);
+
+}  // namespace uzk

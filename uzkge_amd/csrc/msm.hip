@@ -1,0 +1,337 @@
+// BN254 G1 multi-scalar multiplication (Pippenger bucket method) for gfx950.
+// Replaces `G1Projective::msm(&points_raw, &coefs)` at
+//   uzkge/src/poly_commit/kzg_poly_commitment.rs:287-290
+// (the `normalize_batch` of :287-288 disappears: the SRS is registered once, affine, in HBM).
+//
+// Pipeline (all on the library stream; see DESIGN.md "MSM"):
+//   1 msm_digits      scalar -> canonical (one Montgomery mul by 1) -> signed c-bit digits
+//                     d_w in [-2^(c-1), 2^(c-1)], stored [window][i] (coalesced both ways)
+//   2 msm_hist        per (chunk, window) workgroup: bucket histogram in LDS (<= 128 KiB)
+//   3 msm_scan_*      bucket totals, per-chunk offsets, per-window exclusive scan
+//   4 msm_scatter     counting-sort scatter: LDS cursors, writes point indices grouped by bucket
+//   5 msm_accumulate  one lane per (window, bucket): walks its run of indices, gathers the
+//                     64-byte affine point from HBM (next point prefetched under the current
+//                     mixed add), XYZZ accumulator in VGPRs -- the dominant kernel
+//   6 msm_reduce      per window sum_b b*B_b: 16-bucket running sums per lane, one short
+//                     double-and-add for the segment weight, LDS tree per workgroup
+//   7 host            fold the <= W*8 partials and combine windows (Horner, c doublings each)
+// No MFMA anywhere: the work is 254-bit modular integer arithmetic on v_mad_u64_u32.
+#include <algorithm>
+#include <cstring>
+
+#include "ctx.hpp"
+#include "host_math.hpp"
+
+namespace uzk {
+
+constexpr int kMsmThreads = 1024;   // hist / scatter workgroups
+constexpr int kSeg = 16;            // buckets per lane in the reduction
+constexpr uint32_t kSignBit = 0x80000000u;
+
+struct MsmWork {
+    DevBuf digits, chunk_hist, bucket_count, bucket_start, sorted, buckets, partials;
+    XYZZ* h_partials = nullptr;   // pinned
+    size_t h_partials_cap = 0;
+};
+
+__host__ __device__ inline int msm_num_windows(int c) {
+    int W = (254 + c - 1) / c;
+    if (254 - (W - 1) * c == c) ++W;   // top window must leave room for the signed carry
+    return W;
+}
+
+// ---- 1. digits -------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void msm_digits_kernel(const Fp* __restrict__ scalars, uint32_t* __restrict__ digits,
+                                                         uint32_t n, int c, int W) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fp k = Fr::from_mont(scalars[i]);
+    const uint32_t mask = (1u << c) - 1, half = 1u << (c - 1);
+    uint32_t carry = 0;
+    for (int w = 0; w < W; ++w) {
+        uint32_t d = (k.v[0] & mask) + carry;
+        // k >>= c
+#pragma unroll
+        for (int j = 0; j < 7; ++j) k.v[j] = __funnelshift_r(k.v[j], k.v[j + 1], c);
+        k.v[7] >>= c;
+        uint32_t out;
+        if (d > half) { out = ((1u << c) - d) | kSignBit; carry = 1; }
+        else { out = d; carry = 0; }
+        digits[(size_t)w * n + i] = out;
+    }
+}
+
+// ---- 2. histogram -----------------------------------------------------------------------------
+// grid (numChunks, W); dynamic LDS: NB counters
+__global__ __launch_bounds__(kMsmThreads) void msm_hist_kernel(const uint32_t* __restrict__ digits,
+                                                               uint32_t* __restrict__ chunk_hist, uint32_t n,
+                                                               uint32_t chunk_size, uint32_t NB) {
+    extern __shared__ uint32_t lds_hist[];
+    const uint32_t ch = blockIdx.x, w = blockIdx.y, nch = gridDim.x;
+    for (uint32_t b = threadIdx.x; b < NB; b += blockDim.x) lds_hist[b] = 0;
+    __syncthreads();
+    const uint32_t lo = ch * chunk_size, hi = min(n, lo + chunk_size);
+    const uint32_t* dw = digits + (size_t)w * n;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) atomicAdd(&lds_hist[dw[i] & ~kSignBit], 1u);
+    __syncthreads();
+    uint32_t* dst = chunk_hist + ((size_t)w * nch + ch) * NB;
+    for (uint32_t b = threadIdx.x; b < NB; b += blockDim.x) dst[b] = lds_hist[b];
+}
+
+// ---- 3. scans -----------------------------------------------------------------------------------
+// lane per (w, b): turn per-chunk counts into exclusive per-chunk prefixes, emit bucket total
+__global__ __launch_bounds__(256) void msm_scan_chunks_kernel(uint32_t* __restrict__ chunk_hist,
+                                                              uint32_t* __restrict__ bucket_count, uint32_t NB,
+                                                              uint32_t nch, uint32_t W) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)W * NB) return;
+    const uint32_t w = (uint32_t)(t / NB), b = (uint32_t)(t % NB);
+    uint32_t run = 0;
+    for (uint32_t ch = 0; ch < nch; ++ch) {
+        uint32_t* p = chunk_hist + ((size_t)w * nch + ch) * NB + b;
+        uint32_t v = *p;
+        *p = run;
+        run += v;
+    }
+    bucket_count[t] = run;
+}
+// one workgroup per window: exclusive scan of bucket_count[w][0..NB) -> bucket_start
+__global__ __launch_bounds__(1024) void msm_scan_buckets_kernel(const uint32_t* __restrict__ bucket_count,
+                                                                uint32_t* __restrict__ bucket_start, uint32_t NB) {
+    __shared__ uint32_t part[1024];
+    const uint32_t w = blockIdx.x, tid = threadIdx.x;
+    const uint32_t per = (NB + 1023) / 1024;
+    const uint32_t lo = min(NB, tid * per), hi = min(NB, lo + per);
+    const uint32_t* cnt = bucket_count + (size_t)w * NB;
+    uint32_t s = 0;
+    for (uint32_t b = lo; b < hi; ++b) s += cnt[b];
+    part[tid] = s;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan
+        uint32_t v = (tid >= off) ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - s;
+    uint32_t* st = bucket_start + (size_t)w * NB;
+    for (uint32_t b = lo; b < hi; ++b) { st[b] = run; run += cnt[b]; }
+}
+
+// ---- 4. scatter ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(kMsmThreads) void msm_scatter_kernel(const uint32_t* __restrict__ digits,
+                                                                  const uint32_t* __restrict__ chunk_off,
+                                                                  const uint32_t* __restrict__ bucket_start,
+                                                                  uint32_t* __restrict__ sorted, uint32_t n,
+                                                                  uint32_t chunk_size, uint32_t NB) {
+    extern __shared__ uint32_t lds_cur[];
+    const uint32_t ch = blockIdx.x, w = blockIdx.y, nch = gridDim.x;
+    const uint32_t* off = chunk_off + ((size_t)w * nch + ch) * NB;
+    const uint32_t* st = bucket_start + (size_t)w * NB;
+    for (uint32_t b = threadIdx.x; b < NB; b += blockDim.x) lds_cur[b] = st[b] + off[b];
+    __syncthreads();
+    const uint32_t lo = ch * chunk_size, hi = min(n, lo + chunk_size);
+    const uint32_t* dw = digits + (size_t)w * n;
+    uint32_t* sw = sorted + (size_t)w * n;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const uint32_t d = dw[i], mag = d & ~kSignBit;
+        if (mag != 0) {
+            const uint32_t pos = atomicAdd(&lds_cur[mag], 1u);
+            sw[pos] = i | (d & kSignBit);
+        }
+    }
+}
+
+// ---- 5. bucket accumulation (dominant kernel) -------------------------------------------------
+__device__ __forceinline__ Affine load_point(const Affine* __restrict__ pts, uint32_t idx) {
+    return pts[idx];
+}
+
+__global__ __launch_bounds__(256) void msm_accumulate_kernel(const Affine* __restrict__ points,
+                                                             const uint32_t* __restrict__ sorted,
+                                                             const uint32_t* __restrict__ bucket_start,
+                                                             const uint32_t* __restrict__ bucket_count,
+                                                             XYZZ* __restrict__ buckets, uint32_t n, uint32_t NB,
+                                                             uint32_t W) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t nbk = NB - 1;
+    if (t >= (size_t)W * nbk) return;
+    const uint32_t w = (uint32_t)(t / nbk), b = (uint32_t)(t % nbk) + 1;
+    const uint32_t start = bucket_start[(size_t)w * NB + b], cnt = bucket_count[(size_t)w * NB + b];
+    const uint32_t* run = sorted + (size_t)w * n + start;
+    XYZZ acc = xyzz_inf();
+    if (cnt > 0) {
+        uint32_t e = run[0];
+        Affine p = load_point(points, e & ~kSignBit);
+        for (uint32_t j = 0; j < cnt; ++j) {
+            const Affine cur = p;
+            const bool neg = (e & kSignBit) != 0;
+            if (j + 1 < cnt) {
+                e = run[j + 1];
+                p = load_point(points, e & ~kSignBit);
+            }
+            xyzz_madd(acc, cur, neg);
+        }
+    }
+    buckets[t] = acc;
+}
+
+// ---- 6. bucket reduction ------------------------------------------------------------------------
+// Window sum = sum_{b=1}^{nbk} b * B_b.  Lane g owns buckets [g*kSeg + 1, (g+1)*kSeg]:
+//   run_g = sum B_b, acc_g = sum (b - g*kSeg) B_b (running-sum trick), T_g = acc_g + (g*kSeg) run_g.
+// A 256-lane workgroup tree-adds its T_g through LDS and writes one partial.
+__global__ __launch_bounds__(256) void msm_reduce_kernel(const XYZZ* __restrict__ buckets, XYZZ* __restrict__ partials,
+                                                         uint32_t nbk, uint32_t groups_per_window) {
+    __shared__ XYZZ sh[256];
+    const uint32_t w = blockIdx.y, tid = threadIdx.x;
+    const uint32_t g = blockIdx.x * blockDim.x + tid;
+    const XYZZ* bw = buckets + (size_t)w * nbk;
+    XYZZ run = xyzz_inf(), acc = xyzz_inf();
+    const uint32_t lo = g * kSeg;   // bucket ids lo+1 .. lo+kSeg  (array index = id - 1)
+    if (lo < nbk) {
+        const uint32_t hi = min(nbk, lo + kSeg);
+        for (uint32_t idx = hi; idx-- > lo;) {
+            XYZZ bk = bw[idx];
+            xyzz_add(run, bk);
+            xyzz_add(acc, run);
+        }
+        // acc += lo * run   (double-and-add, lo < 2^24)
+        if (lo != 0 && !xyzz_is_inf(run)) {
+            XYZZ m = xyzz_inf();
+            for (int bit = 31 - __clz(lo); bit >= 0; --bit) {
+                m = xyzz_dbl(m);
+                if ((lo >> bit) & 1) xyzz_add(m, run);
+            }
+            xyzz_add(acc, m);
+        }
+    }
+    sh[tid] = acc;
+    __syncthreads();
+    for (uint32_t s = 128; s > 0; s >>= 1) {
+        if (tid < s) {
+            XYZZ a = sh[tid];
+            XYZZ b2 = sh[tid + s];
+            xyzz_add(a, b2);
+            sh[tid] = a;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) partials[(size_t)w * groups_per_window + blockIdx.x] = sh[0];
+}
+
+// ---------------------------------------------------------------------------------------------
+// host
+// ---------------------------------------------------------------------------------------------
+static int choose_window_bits(size_t n, int forced) {
+    if (forced >= 4 && forced <= 16) return forced;
+    int lg = 0;
+    while ((1ull << (lg + 1)) <= n) ++lg;
+    int c = lg - 7;
+    if (lg >= 22) c = 16;
+    return std::max(6, std::min(16, c));
+}
+
+void msm_free(Ctx& c) {
+    if (!c.msm) return;
+    MsmWork* m = c.msm;
+    m->digits.release(); m->chunk_hist.release(); m->bucket_count.release(); m->bucket_start.release();
+    m->sorted.release(); m->buckets.release(); m->partials.release();
+    if (m->h_partials) (void)hipHostFree(m->h_partials);
+    delete m;
+    c.msm = nullptr;
+}
+
+static int set_dyn_lds(const void* fn, size_t bytes) {
+    UZK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return UZK_OK;
+}
+
+int msm_run(Ctx& c, const Affine* d_points, const Fp* d_scalars, size_t n, Jac* out_host) {
+    if (n == 0) { *out_host = jac_inf(); return UZK_OK; }
+    if (n >= (1ull << 31)) { set_error("msm: n = %zu exceeds 2^31 - 1 points per call", n); return UZK_ERR_PARAMETER; }
+    if (!c.msm) c.msm = new MsmWork();
+    MsmWork& m = *c.msm;
+    const int cb = choose_window_bits(n, c.msm_window_bits);
+    const int W = msm_num_windows(cb);
+    const uint32_t NB = (1u << (cb - 1)) + 1, nbk = NB - 1;
+    const uint32_t n32 = (uint32_t)n;
+    uint32_t nch = (uint32_t)std::min<size_t>(32, (n + 8191) / 8192);
+    const uint32_t chunk_size = (n32 + nch - 1) / nch;
+    nch = (n32 + chunk_size - 1) / chunk_size;
+    const uint32_t groups = (nbk + kSeg * 256 - 1) / (kSeg * 256);
+
+    UZK_TRY(m.digits.reserve((size_t)W * n * 4));
+    UZK_TRY(m.sorted.reserve((size_t)W * n * 4));
+    UZK_TRY(m.chunk_hist.reserve((size_t)W * nch * NB * 4));
+    UZK_TRY(m.bucket_count.reserve((size_t)W * NB * 4));
+    UZK_TRY(m.bucket_start.reserve((size_t)W * NB * 4));
+    UZK_TRY(m.buckets.reserve((size_t)W * nbk * sizeof(XYZZ)));
+    UZK_TRY(m.partials.reserve((size_t)W * groups * sizeof(XYZZ)));
+    const size_t np = (size_t)W * groups;
+    if (m.h_partials_cap < np) {
+        if (m.h_partials) (void)hipHostFree(m.h_partials);
+        UZK_HIP(hipHostMalloc(reinterpret_cast<void**>(&m.h_partials), np * sizeof(XYZZ), hipHostMallocDefault));
+        m.h_partials_cap = np;
+    }
+    const size_t lds_bytes = (size_t)NB * 4;
+    UZK_TRY(set_dyn_lds(reinterpret_cast<const void*>(msm_hist_kernel), lds_bytes));
+    UZK_TRY(set_dyn_lds(reinterpret_cast<const void*>(msm_scatter_kernel), lds_bytes));
+
+    uint32_t* digits = m.digits.as<uint32_t>();
+    uint32_t* sorted = m.sorted.as<uint32_t>();
+    uint32_t* chunk_hist = m.chunk_hist.as<uint32_t>();
+    uint32_t* bcount = m.bucket_count.as<uint32_t>();
+    uint32_t* bstart = m.bucket_start.as<uint32_t>();
+    XYZZ* buckets = m.buckets.as<XYZZ>();
+    XYZZ* partials = m.partials.as<XYZZ>();
+    hipStream_t st = c.stream;
+
+    {
+        KernelScope ks(c, "msm_digits");
+        hipLaunchKernelGGL(msm_digits_kernel, dim3((n32 + 255) / 256), dim3(256), 0, st, d_scalars, digits, n32, cb, W);
+    }
+    {
+        KernelScope ks(c, "msm_hist");
+        hipLaunchKernelGGL(msm_hist_kernel, dim3(nch, W), dim3(kMsmThreads), lds_bytes, st, digits, chunk_hist, n32,
+                           chunk_size, NB);
+    }
+    {
+        KernelScope ks(c, "msm_scan_chunks");
+        const size_t tot = (size_t)W * NB;
+        hipLaunchKernelGGL(msm_scan_chunks_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, chunk_hist,
+                           bcount, NB, nch, (uint32_t)W);
+    }
+    {
+        KernelScope ks(c, "msm_scan_buckets");
+        hipLaunchKernelGGL(msm_scan_buckets_kernel, dim3(W), dim3(1024), 0, st, bcount, bstart, NB);
+    }
+    {
+        KernelScope ks(c, "msm_scatter");
+        hipLaunchKernelGGL(msm_scatter_kernel, dim3(nch, W), dim3(kMsmThreads), lds_bytes, st, digits, chunk_hist,
+                           bstart, sorted, n32, chunk_size, NB);
+    }
+    {
+        KernelScope ks(c, "msm_accumulate");
+        const size_t tot = (size_t)W * nbk;
+        hipLaunchKernelGGL(msm_accumulate_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_points,
+                           sorted, bstart, bcount, buckets, n32, NB, (uint32_t)W);
+    }
+    {
+        KernelScope ks(c, "msm_reduce");
+        hipLaunchKernelGGL(msm_reduce_kernel, dim3(groups, W), dim3(256), 0, st, buckets, partials, nbk, groups);
+    }
+    UZK_HIP(hipGetLastError());
+    UZK_HIP(hipMemcpyAsync(m.h_partials, partials, np * sizeof(XYZZ), hipMemcpyDeviceToHost, st));
+    UZK_HIP(hipStreamSynchronize(st));
+
+    // 7. host: fold partials per window, then Horner over windows (c doublings per step)
+    XYZZ total = xyzz_inf();
+    for (int w = W - 1; w >= 0; --w) {
+        for (int d = 0; d < cb; ++d) total = xyzz_dbl(total);
+        for (uint32_t g = 0; g < groups; ++g) xyzz_add(total, m.h_partials[(size_t)w * groups + g]);
+    }
+    *out_host = xyzz_to_jac(total);
+    return UZK_OK;
+}
+
+}  // namespace uzk

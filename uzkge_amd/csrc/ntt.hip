@@ -1,0 +1,511 @@
+// BN254 Fr NTT for gfx950: natural order in and out, omega_n = 5^((r-1)/n).
+// Replaces EvaluationDomain::{fft,ifft} as called from
+//   uzkge/src/poly_commit/field_polynomial.rs:583-597 (fft_with_domain / ifft_with_domain)
+// and the coset wrappers :589-591 / :601-607; domains 2^k and 3*2^k (:554-567).
+//
+// Design (MI355X-first, see DESIGN.md "NTT"):
+//  * n = 2^k <= 2048: one workgroup, radix-2 DIT in LDS (latency path for tiny transforms).
+//  * n = 2^k >= 4096: P = ceil(k/8) Stockham autosort passes of radix R = 2^b (b in 5..8).
+//    A pass needs no transposition kernel: pass p reads x[i + r*N/R] (coalesced over i) and
+//    writes y[m'*S*R + sigma*S + s] (S = product of earlier radices, i = m'*S + s), so after the
+//    last pass the data is in natural order.  One workgroup (256 threads, 4 waves) owns a tile of
+//    T = 2048/R adjacent columns: every global access is a run of T*32 B >= 256 B.
+//    Inside the tile each thread keeps 8 elements in VGPRs and runs radix-8/4/2 register
+//    butterflies; the sub-pass exchanges go through 64 KiB of LDS (two 16-byte planes per
+//    element, conflict-free ds_read/write_b128).  Inter-pass twiddles omega_N^(S*m'*sigma) come
+//    from HBM/L2-resident tables laid out in write order (pass 0's table is N entries and is
+//    streamed, coalesced, exactly once; the 1/n of the inverse transform is folded into it).
+//  * The kernel is bound by 256-bit modular multiplies (about 11 per element at 2^22), not by
+//    HBM: no MFMA, no GEMM reshaping (north star).
+//  * n = 3 * 2^k: decimation in time by 3 -> three radix-2 transforms + one combine kernel.
+#include <cstring>
+
+#include "ctx.hpp"
+#include "host_math.hpp"
+
+namespace uzk {
+
+// ---------------------------------------------------------------------------------------------
+// plans
+// ---------------------------------------------------------------------------------------------
+struct NttPlan {
+    uint64_t n = 0;          // power of two
+    int log_n = 0;
+    bool inverse = false;
+    bool scaled = false;     // inverse only: fold 1/n in
+    int npass = 0;
+    int bits[4] = {0, 0, 0, 0};
+    Fp* d_tw256 = nullptr;        // omega_256^e (direction-specific), e < 256   (n >= 4096)
+    Fp* d_tw_pass[4] = {nullptr, nullptr, nullptr, nullptr};
+    Fp* d_small_tw = nullptr;     // omega_n^e, e < n/2                          (n <= 2048)
+    Fp scale;                     // 1/n (Montgomery) when scaled, else one
+    // three-level power tables of omega (device): A[j]=w^j, B[j]=w^(1024 j), C[j]=w^(2^20 j)
+    Fp* d_pow = nullptr;
+};
+
+static void host_pow_tables(const Fp& w, std::vector<Fp>& tab) {
+    tab.resize(3 * 1024);
+    Fp step = w;
+    for (int lvl = 0; lvl < 3; ++lvl) {
+        Fp cur = Fr::one();
+        for (int j = 0; j < 1024; ++j) {
+            tab[lvl * 1024 + j] = cur;
+            cur = Fr::mul(cur, step);
+        }
+        step = cur;   // step^1024
+    }
+}
+
+// out[idx] = w^(e(idx)) [* scale], e(idx) = (S * m' * sigma) with idx = m' * R + sigma
+__global__ __launch_bounds__(256) void ntt_gen_pass_tw_kernel(Fp* __restrict__ out, uint64_t count,
+                                                              int log_S, int B,
+                                                              const Fp* __restrict__ pw, Fp scale,
+                                                              int use_scale) {
+    uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count) return;
+    uint64_t mp = idx >> B, sg = idx & ((1u << B) - 1);
+    uint64_t e = (mp * sg) << log_S;
+    Fp v = Fr::mul(pw[e & 1023], pw[1024 + ((e >> 10) & 1023)]);
+    v = Fr::mul(v, pw[2048 + (e >> 20)]);
+    if (use_scale) v = Fr::mul(v, scale);
+    out[idx] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// small transform: one workgroup, LDS radix-2 DIT
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t bitrev(uint32_t x, int bits) {
+    return bits == 0 ? 0u : (__brev(x) >> (32 - bits));
+}
+
+__global__ __launch_bounds__(256) void ntt_small_kernel(const Fp* __restrict__ in, Fp* __restrict__ out,
+                                                        int log_n, const Fp* __restrict__ tw,
+                                                        Fp scale, int use_scale) {
+    extern __shared__ uint4 lds_small[];
+    Fp* s = reinterpret_cast<Fp*>(lds_small);
+    const uint32_t n = 1u << log_n;
+    const Fp* src = in + (uint64_t)blockIdx.x * n;
+    Fp* dst = out + (uint64_t)blockIdx.x * n;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) s[bitrev(i, log_n)] = src[i];
+    __syncthreads();
+    for (int lh = 0; lh < log_n; ++lh) {
+        const uint32_t half = 1u << lh;
+        const int shift = log_n - 1 - lh;   // twiddle stride = n / (2*half)
+        for (uint32_t b = threadIdx.x; b < n / 2; b += blockDim.x) {
+            uint32_t g = b >> lh, p = b & (half - 1);
+            uint32_t iu = (g << (lh + 1)) + p, iv = iu + half;
+            Fp u = s[iu];
+            Fp v = Fr::mul(s[iv], tw[p << shift]);
+            s[iu] = Fr::add(u, v);
+            s[iv] = Fr::sub(u, v);
+        }
+        __syncthreads();
+    }
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        Fp v = s[i];
+        if (use_scale) v = Fr::mul(v, scale);
+        dst[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// register butterflies (natural order in, natural order out)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bf2(Fp& a, Fp& b) {
+    Fp s = Fr::add(a, b);
+    b = Fr::sub(a, b);
+    a = s;
+}
+__device__ __forceinline__ void swap_fp(Fp& a, Fp& b) { Fp t = a; a = b; b = t; }
+
+// X[s] = sum_r x[r] w8^(r s); w1,w2,w3 = w8^1, w8^2, w8^3.  5 multiplications.
+__device__ __forceinline__ void radix8(Fp (&x)[8], const Fp& w1, const Fp& w2, const Fp& w3) {
+    bf2(x[0], x[4]);
+    bf2(x[1], x[5]); x[5] = Fr::mul(x[5], w1);
+    bf2(x[2], x[6]); x[6] = Fr::mul(x[6], w2);
+    bf2(x[3], x[7]); x[7] = Fr::mul(x[7], w3);
+    bf2(x[0], x[2]);
+    bf2(x[1], x[3]); x[3] = Fr::mul(x[3], w2);
+    bf2(x[4], x[6]);
+    bf2(x[5], x[7]); x[7] = Fr::mul(x[7], w2);
+    bf2(x[0], x[1]); bf2(x[2], x[3]); bf2(x[4], x[5]); bf2(x[6], x[7]);
+    swap_fp(x[1], x[4]);
+    swap_fp(x[3], x[6]);
+}
+// size-4 DFT, w4 = w8^2.  1 multiplication.
+__device__ __forceinline__ void radix4(Fp& x0, Fp& x1, Fp& x2, Fp& x3, const Fp& w4) {
+    bf2(x0, x2);
+    bf2(x1, x3); x3 = Fr::mul(x3, w4);
+    bf2(x0, x1);
+    bf2(x2, x3);
+    swap_fp(x1, x2);
+}
+
+struct PassArgs {
+    uint64_t stride;       // N / R
+    int log_S;             // log2 of the product of earlier radices
+    const Fp* tw256;       // omega_256^e, direction-specific
+    const Fp* twp;         // pass table [m'][sigma] (nullptr on the last pass)
+};
+
+constexpr int kPlane = 2048 + 64;   // uint4 slots per LDS plane (transposed layout needs T*(R+1))
+
+__device__ __forceinline__ void lds_put(uint4* lds, int idx, const Fp& v) {
+    const uint4* p = reinterpret_cast<const uint4*>(&v);
+    lds[idx] = p[0];
+    lds[kPlane + idx] = p[1];
+}
+__device__ __forceinline__ Fp lds_get(const uint4* lds, int idx) {
+    Fp v;
+    uint4* p = reinterpret_cast<uint4*>(&v);
+    p[0] = lds[idx];
+    p[1] = lds[kPlane + idx];
+    return v;
+}
+
+template <int B, bool FIRST>
+__global__ __launch_bounds__(256) void ntt_pass_kernel(const Fp* __restrict__ in, Fp* __restrict__ out,
+                                                       PassArgs a) {
+    constexpr int R = 1 << B, T = 2048 / R, Q = R / 8, SH = 8 - B;
+    __shared__ uint4 lds[2 * kPlane];
+    const int tid = threadIdx.x;
+    const int col = tid % T, q = tid / T;
+    const uint64_t i0 = (uint64_t)blockIdx.x * T;
+    const uint64_t i = i0 + col;
+
+    const Fp w1 = a.tw256[32], w2 = a.tw256[64], w3 = a.tw256[96];
+    Fp x[8];
+    int rows[8];
+
+    // ---- sub-pass 1: radix 8 on rows q + t*Q, straight from global memory
+#pragma unroll
+    for (int t = 0; t < 8; ++t) x[t] = in[i + (uint64_t)(q + t * Q) * a.stride];
+    radix8(x, w1, w2, w3);
+#pragma unroll
+    for (int s = 1; s < 8; ++s) x[s] = Fr::mul(x[s], a.tw256[(q * s) << SH]);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) lds_put(lds, (q * 8 + s) * T + col, x[s]);
+    __syncthreads();
+
+    // ---- sub-pass 2
+    if constexpr (B == 5) {
+        // two radix-4 butterflies: i2 = q + u*Q, rows i2 + t*8; final rows sigma*8 + i2
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i2 = q + u * Q;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) x[u * 4 + t] = lds_get(lds, (i2 + t * 8) * T + col);
+            radix4(x[u * 4 + 0], x[u * 4 + 1], x[u * 4 + 2], x[u * 4 + 3], w2);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) rows[u * 4 + s] = s * 8 + i2;
+        }
+    } else {
+        const int mp = q >> 3, sl = q & 7;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) x[t] = lds_get(lds, (q + t * Q) * T + col);
+        radix8(x, w1, w2, w3);
+        if constexpr (B > 6) {
+#pragma unroll
+            for (int s = 1; s < 8; ++s) x[s] = Fr::mul(x[s], a.tw256[(8 * mp * s) << SH]);
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) rows[s] = mp * 64 + s * 8 + sl;
+        if constexpr (B > 6) {
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < 8; ++s) lds_put(lds, rows[s] * T + col, x[s]);
+            __syncthreads();
+            // ---- sub-pass 3
+            if constexpr (B == 7) {
+                // four radix-2 butterflies: i3 = q + u*16, rows i3, i3 + 64
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i3 = q + u * Q;
+                    x[u * 2] = lds_get(lds, i3 * T + col);
+                    x[u * 2 + 1] = lds_get(lds, (i3 + 64) * T + col);
+                    bf2(x[u * 2], x[u * 2 + 1]);
+                    rows[u * 2] = i3;
+                    rows[u * 2 + 1] = i3 + 64;
+                }
+            } else {
+                // two radix-4 butterflies: i3 = q + u*32, rows i3 + t*64; final rows sigma*64 + i3
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int i3 = q + u * Q;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) x[u * 4 + t] = lds_get(lds, (i3 + t * 64) * T + col);
+                    radix4(x[u * 4 + 0], x[u * 4 + 1], x[u * 4 + 2], x[u * 4 + 3], w2);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) rows[u * 4 + s] = s * 64 + i3;
+                }
+            }
+        }
+    }
+
+    // ---- write back
+    if constexpr (FIRST) {
+        // S = 1: out[i*R + row] -- transpose through LDS so the tile's T*R outputs leave as one
+        // contiguous run, multiplied by the streamed pass-0 twiddles.
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) lds_put(lds, col * (R + 1) + rows[j], x[j]);
+        __syncthreads();
+        const uint64_t base = i0 * R;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int e = tid + j * 256;
+            const int ce = e / R, re = e % R;
+            Fp v = lds_get(lds, ce * (R + 1) + re);
+            v = Fr::mul(v, a.twp[base + e]);
+            out[base + e] = v;
+        }
+    } else {
+        const uint64_t mp = i >> a.log_S, sp = i & ((1ull << a.log_S) - 1);
+        const uint64_t base = (mp << (a.log_S + B)) + sp;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            Fp v = x[j];
+            if (a.twp != nullptr) v = Fr::mul(v, a.twp[(mp << B) + rows[j]]);
+            out[base + ((uint64_t)rows[j] << a.log_S)] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// helpers for coset scaling and the 3 * 2^k domain
+// ---------------------------------------------------------------------------------------------
+// out[j] = in[j] * g^j, powers from a three-level table of g.
+__global__ __launch_bounds__(256) void ntt_scale_pows_kernel(const Fp* __restrict__ in, Fp* __restrict__ out,
+                                                             uint64_t n, const Fp* __restrict__ pw) {
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    Fp g = Fr::mul(pw[j & 1023], pw[1024 + ((j >> 10) & 1023)]);
+    g = Fr::mul(g, pw[2048 + (j >> 20)]);
+    out[j] = Fr::mul(in[j], g);
+}
+// sub[k*m + j] = in[3j + k]
+__global__ __launch_bounds__(256) void ntt_decimate3_kernel(const Fp* __restrict__ in, Fp* __restrict__ sub, uint64_t m) {
+    uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 3 * m) return;
+    uint64_t j = idx / 3, k = idx % 3;
+    sub[k * m + j] = in[idx];
+}
+// out[i] = (X0[i%m] + w^i X1[i%m] + w^2i X2[i%m]) * scale
+__global__ __launch_bounds__(256) void ntt_combine3_kernel(const Fp* __restrict__ sub, Fp* __restrict__ out, uint64_t m,
+                                                           const Fp* __restrict__ pw, Fp scale, int use_scale) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * m) return;
+    uint64_t j = i % m;
+    Fp w = Fr::mul(pw[i & 1023], pw[1024 + ((i >> 10) & 1023)]);
+    w = Fr::mul(w, pw[2048 + (i >> 20)]);
+    Fp w2 = Fr::sqr(w);
+    Fp v = Fr::add(sub[j], Fr::add(Fr::mul(w, sub[m + j]), Fr::mul(w2, sub[2 * m + j])));
+    if (use_scale) v = Fr::mul(v, scale);
+    out[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static int upload(Fp** dst, const std::vector<Fp>& src, hipStream_t st) {
+    UZK_HIP(hipMalloc(reinterpret_cast<void**>(dst), src.size() * sizeof(Fp)));
+    UZK_HIP(hipMemcpyAsync(*dst, src.data(), src.size() * sizeof(Fp), hipMemcpyHostToDevice, st));
+    UZK_HIP(hipStreamSynchronize(st));
+    return UZK_OK;
+}
+
+static int get_plan(Ctx& c, uint64_t n, bool inverse, bool scaled, NttPlan** out) {
+    const uint64_t key = (n << 2) | (inverse ? 1u : 0u) | (scaled ? 2u : 0u);
+    auto it = c.ntt_plans.find(key);
+    if (it != c.ntt_plans.end()) { *out = it->second; return UZK_OK; }
+    NttPlan* p = new NttPlan();
+    p->n = n;
+    p->inverse = inverse;
+    p->scaled = scaled;
+    int k = 0;
+    while ((1ull << k) < n) ++k;
+    p->log_n = k;
+    Fp w = fr_root_of_unity(n);
+    if (inverse) w = fr_inv(w);
+    p->scale = scaled ? fr_inv(fr_from_u64(n)) : Fr::one();
+    if (k <= 11) {
+        std::vector<Fp> tw(n >= 2 ? n / 2 : 1);
+        Fp cur = Fr::one();
+        for (size_t e = 0; e < tw.size(); ++e) { tw[e] = cur; cur = Fr::mul(cur, w); }
+        UZK_TRY(upload(&p->d_small_tw, tw, c.stream));
+    } else {
+        p->npass = (k + 7) / 8;
+        int base = k / p->npass, extra = k % p->npass;
+        for (int j = 0; j < p->npass; ++j) p->bits[j] = base + (j < extra ? 1 : 0);
+        std::vector<Fp> pw;
+        host_pow_tables(w, pw);
+        UZK_TRY(upload(&p->d_pow, pw, c.stream));
+        // omega_256^e = w^(e * n/256)
+        std::vector<Fp> t256(256);
+        Fp w256 = f_pow_u64<Fr>(w, n / 256), cur = Fr::one();
+        for (int e = 0; e < 256; ++e) { t256[e] = cur; cur = Fr::mul(cur, w256); }
+        UZK_TRY(upload(&p->d_tw256, t256, c.stream));
+        int log_S = 0;
+        for (int j = 0; j + 1 < p->npass; ++j) {
+            const uint64_t count = n >> log_S;   // (N / (S R)) * R
+            UZK_HIP(hipMalloc(reinterpret_cast<void**>(&p->d_tw_pass[j]), count * sizeof(Fp)));
+            const bool fold = scaled && j == 0;
+            {
+                KernelScope ks(c, "ntt_gen_pass_tw");
+                hipLaunchKernelGGL(ntt_gen_pass_tw_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0,
+                                   c.stream, p->d_tw_pass[j], count, log_S, p->bits[j], p->d_pow, p->scale,
+                                   fold ? 1 : 0);
+            }
+            log_S += p->bits[j];
+        }
+        UZK_HIP(hipStreamSynchronize(c.stream));
+    }
+    c.ntt_plans[key] = p;
+    *out = p;
+    return UZK_OK;
+}
+
+void ntt_free_plans(Ctx& c) {
+    for (auto& kv : c.ntt_plans) {
+        NttPlan* p = kv.second;
+        if (p->d_tw256) (void)hipFree(p->d_tw256);
+        if (p->d_small_tw) (void)hipFree(p->d_small_tw);
+        if (p->d_pow) (void)hipFree(p->d_pow);
+        for (auto* t : p->d_tw_pass) if (t) (void)hipFree(t);
+        delete p;
+    }
+    c.ntt_plans.clear();
+}
+
+template <int B>
+static void launch_pass(Ctx& c, bool first, const Fp* in, Fp* out, const PassArgs& a, uint64_t n) {
+    constexpr int R = 1 << B, T = 2048 / R;
+    const unsigned grid = (unsigned)((n / R) / T);
+    if (first) {
+        KernelScope ks(c, "ntt_pass_first");
+        hipLaunchKernelGGL((ntt_pass_kernel<B, true>), dim3(grid), dim3(256), 0, c.stream, in, out, a);
+    } else {
+        KernelScope ks(c, "ntt_pass");
+        hipLaunchKernelGGL((ntt_pass_kernel<B, false>), dim3(grid), dim3(256), 0, c.stream, in, out, a);
+    }
+}
+
+// power-of-two transform d_in -> d_out (may alias)
+static int ntt_pow2(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse, bool scaled) {
+    NttPlan* p = nullptr;
+    UZK_TRY(get_plan(c, n, inverse, scaled, &p));
+    if (p->log_n <= 11) {
+        KernelScope ks(c, "ntt_small");
+        const size_t shmem = (size_t)n * sizeof(Fp);
+        hipLaunchKernelGGL(ntt_small_kernel, dim3(1), dim3(256), shmem, c.stream, d_in, d_out, p->log_n,
+                           p->d_small_tw, p->scale, scaled ? 1 : 0);
+        UZK_HIP(hipGetLastError());
+        return UZK_OK;
+    }
+    const size_t bytes = (size_t)n * sizeof(Fp);
+    UZK_TRY(c.ntt_scratch[0].reserve(bytes));
+    Fp* s0 = c.ntt_scratch[0].as<Fp>();
+    Fp* s1 = nullptr;
+    const bool in_place = (d_in == d_out);
+    if (in_place && (p->npass & 1)) {
+        UZK_TRY(c.ntt_scratch[1].reserve(bytes));
+        s1 = c.ntt_scratch[1].as<Fp>();
+    }
+    // buffer schedule: the last pass writes d_out; earlier passes alternate scratch/d_out and
+    // never write the buffer they read.
+    const Fp* src = d_in;
+    int log_S = 0;
+    for (int j = 0; j < p->npass; ++j) {
+        const int remaining = p->npass - 1 - j;
+        Fp* dst = (remaining % 2 == 0) ? d_out : s0;
+        if (dst == src) dst = s1;   // only when in_place and npass is odd, at j == 0
+        PassArgs a;
+        a.stride = n >> p->bits[j];
+        a.log_S = log_S;
+        a.tw256 = p->d_tw256;
+        a.twp = p->d_tw_pass[j];
+        const bool first = (j == 0);
+        switch (p->bits[j]) {
+            case 5: launch_pass<5>(c, first, src, dst, a, n); break;
+            case 6: launch_pass<6>(c, first, src, dst, a, n); break;
+            case 7: launch_pass<7>(c, first, src, dst, a, n); break;
+            case 8: launch_pass<8>(c, first, src, dst, a, n); break;
+            default: set_error("ntt: bad radix bits %d", p->bits[j]); return UZK_ERR_FFT;
+        }
+        UZK_HIP(hipGetLastError());
+        // after a diverted first pass (dst == s1) continue the normal alternation
+        src = dst;
+        log_S += p->bits[j];
+    }
+    return UZK_OK;
+}
+
+// three-level power table of an arbitrary element, cached on the last value
+struct PowCache {
+    Fp key;
+    bool valid = false;
+    DevBuf buf;
+};
+static PowCache g_coset_cache, g_mixed_cache[2];
+
+static int pow_table_device(Ctx& c, PowCache& pc, const Fp& g, const Fp** out) {
+    if (!pc.valid || !Fr::eq(pc.key, g)) {
+        std::vector<Fp> pw;
+        host_pow_tables(g, pw);
+        UZK_TRY(pc.buf.reserve(pw.size() * sizeof(Fp)));
+        UZK_HIP(hipMemcpyAsync(pc.buf.p, pw.data(), pw.size() * sizeof(Fp), hipMemcpyHostToDevice, c.stream));
+        UZK_HIP(hipStreamSynchronize(c.stream));
+        pc.key = g;
+        pc.valid = true;
+    }
+    *out = pc.buf.as<Fp>();
+    return UZK_OK;
+}
+
+int ntt_run(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse, const Fp* coset_shift_host) {
+    if (!domain_supported(n)) {
+        set_error("no evaluation domain of size %llu (need 2^k, k<=28, or 3*2^k)", (unsigned long long)n);
+        return UZK_ERR_FFT;
+    }
+    const unsigned eblocks = (unsigned)((n + 255) / 256);
+    const Fp* src = d_in;
+    if (coset_shift_host != nullptr && !inverse) {
+        const Fp* pw = nullptr;
+        UZK_TRY(pow_table_device(c, g_coset_cache, *coset_shift_host, &pw));
+        KernelScope ks(c, "ntt_scale_pows");
+        hipLaunchKernelGGL(ntt_scale_pows_kernel, dim3(eblocks), dim3(256), 0, c.stream, src, d_out, n, pw);
+        src = d_out;
+    }
+    if (n % 3 != 0) {
+        UZK_TRY(ntt_pow2(c, src, d_out, n, inverse, inverse));
+    } else {
+        const uint64_t m = n / 3;
+        UZK_TRY(c.ntt_io.reserve(0));   // no-op; keeps the staging buffer untouched
+        static DevBuf sub;              // 3 * m decimated / transformed sub-vectors
+        UZK_TRY(sub.reserve((size_t)n * sizeof(Fp)));
+        Fp* s = sub.as<Fp>();
+        {
+            KernelScope ks(c, "ntt_decimate3");
+            hipLaunchKernelGGL(ntt_decimate3_kernel, dim3(eblocks), dim3(256), 0, c.stream, src, s, m);
+        }
+        for (int k = 0; k < 3; ++k) UZK_TRY(ntt_pow2(c, s + k * m, s + k * m, m, inverse, false));
+        Fp w = fr_root_of_unity(n);
+        if (inverse) w = fr_inv(w);
+        const Fp* pw = nullptr;
+        UZK_TRY(pow_table_device(c, g_mixed_cache[inverse ? 1 : 0], w, &pw));
+        Fp scale = inverse ? fr_inv(fr_from_u64(n)) : Fr::one();
+        KernelScope ks(c, "ntt_combine3");
+        hipLaunchKernelGGL(ntt_combine3_kernel, dim3(eblocks), dim3(256), 0, c.stream, s, d_out, m, pw, scale,
+                           inverse ? 1 : 0);
+    }
+    if (coset_shift_host != nullptr && inverse) {
+        const Fp* pw = nullptr;
+        UZK_TRY(pow_table_device(c, g_coset_cache, *coset_shift_host, &pw));
+        KernelScope ks(c, "ntt_scale_pows");
+        hipLaunchKernelGGL(ntt_scale_pows_kernel, dim3(eblocks), dim3(256), 0, c.stream, d_out, d_out, n, pw);
+    }
+    UZK_HIP(hipGetLastError());
+    return UZK_OK;
+}
+
+}  // namespace uzk
