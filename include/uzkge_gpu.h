@@ -112,6 +112,14 @@ int uzk_synth_points_random(void* d_points, size_t n, uint64_t seed);
 /* Uniform Fr elements (Montgomery form) from a SplitMix64 counter stream. */
 int uzk_synth_scalars(void* d_scalars, size_t n, uint64_t seed);
 
+/* ---- known-answer entry points (tests): the DEVICE primitives applied element-wise -------- */
+/* field: 0 = Fq, 1 = Fr.  op: 0 mul (assembly FIPS), 1 add, 2 sub, 3 mul (portable CIOS), 4 sqr,
+ * 5 neg, 6 from_mont, 7 to_mont.  a, b, out: n elements (host memory). */
+int uzk_field_op_device(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+/* op: 0 a + b (mixed add), 1 a + b (full XYZZ add), 2 2a, 3 a - b, 4 2(a + b).  Inputs affine
+ * (infinity = zeros), outputs Jacobian. */
+int uzk_g1_op_device(int op, const uzk_g1_affine* a, const uzk_g1_affine* b, uzk_g1_jac* out, size_t n);
+
 /* ---- measurement ---------------------------------------------------------------------- */
 /* When enabled, every kernel launch is bracketed by hipEvents on the library stream. */
 int uzk_profile_enable(int on);

@@ -1,0 +1,93 @@
+"""Known-answer tests of the DEVICE field and group primitives against the oracle, word for word:
+the inline-assembly Montgomery product (mont_mul_gfx950.inc), the portable CIOS product, add, sub,
+neg, to/from Montgomery for Fq and Fr; G1 mixed add / full add / double including the P + P,
+P + (-P) and infinity branches."""
+import numpy as np
+import pytest
+
+import bn254_py as opy
+import oracle_c as oc
+from util import load_srs, rand_fr_wire
+
+pytestmark = pytest.mark.gpu
+
+
+def _edge_values(mod):
+    vals = [0, 1, 2, mod - 1, mod - 2, (1 << 256) % mod, (1 << 255) % mod, (mod - 1) // 2, 0xFFFFFFFF, 0xFFFFFFFFFFFFFFFF,
+            (1 << 253) - 1, mod - (1 << 32), 0xFFFFFFFF00000000FFFFFFFF00000000FFFFFFFF % mod]
+    out = np.zeros((len(vals), 4), dtype=np.uint64)
+    for i, v in enumerate(vals):
+        out[i] = opy.int_to_limbs(v)
+    return out
+
+
+@pytest.mark.parametrize("field,mod", [("fq", opy.P), ("fr", opy.R)])
+def test_field_ops_match_oracle(gpu, field, mod):
+    n = 1 << 16
+    a = rand_fr_wire(n, 1)
+    b = rand_fr_wire(n, 2)
+    e = _edge_values(mod)
+    ea = np.repeat(e, len(e), axis=0)
+    eb = np.tile(e, (len(e), 1))
+    a = np.concatenate([ea, a])
+    b = np.concatenate([eb, b])
+    mul_asm = gpu.field_op(field, 0, a, b)
+    mul_c = gpu.field_op(field, 3, a, b)
+    assert np.array_equal(mul_asm, mul_c)
+    add = gpu.field_op(field, 1, a, b)
+    sub = gpu.field_op(field, 2, a, b)
+    sqr = gpu.field_op(field, 4, a, b)
+    neg = gpu.field_op(field, 5, a, b)
+    frm = gpu.field_op(field, 6, a, b)
+    tom = gpu.field_op(field, 7, a, b)
+    to_int = lambda row: opy.limbs_to_int(row)
+    idx = list(range(len(ea))) + list(range(len(ea), len(a), 97))
+    for i in idx:
+        x, y = to_int(a[i]), to_int(b[i])
+        assert to_int(mul_asm[i]) == opy.mont_mul(x, y, mod), (field, i)
+        assert to_int(add[i]) == (x + y) % mod
+        assert to_int(sub[i]) == (x - y) % mod
+        assert to_int(sqr[i]) == opy.mont_mul(x, x, mod)
+        assert to_int(neg[i]) == (-x) % mod
+        assert to_int(frm[i]) == opy.from_mont(x, mod)
+        assert to_int(tom[i]) == opy.to_mont(x, mod)
+    # the whole random block against the C oracle product
+    fn = oc.lib.oracle_fq_mul if field == "fq" else oc.lib.oracle_fr_mul
+    want = np.zeros(4, dtype=np.uint64)
+    for i in range(len(ea), len(a), 7):
+        fn(oc._p(np.ascontiguousarray(a[i])), oc._p(np.ascontiguousarray(b[i])), oc._p(want))
+        assert np.array_equal(mul_asm[i], want)
+
+
+def test_asm_product_equals_portable_on_a_million(gpu):
+    n = 1 << 20
+    a = rand_fr_wire(n, 11)
+    b = rand_fr_wire(n, 12)
+    for field in ("fq", "fr"):
+        assert np.array_equal(gpu.field_op(field, 0, a, b), gpu.field_op(field, 3, a, b))
+
+
+def test_group_ops_match_oracle(gpu):
+    wire, pts = load_srs("lagrange-srs-4096.bin")
+    n = 512
+    a, b = wire[:n].copy(), wire[n:2 * n].copy()
+    pa, pb = list(pts[:n]), list(pts[n:2 * n])
+    # forced edge cases: P + P, P + (-P), inf + Q, P + inf, inf + inf
+    b[0] = a[0]; pb[0] = pa[0]
+    b[1] = oc.points_from_affine([opy.g1_neg(pa[1])])[0]; pb[1] = opy.g1_neg(pa[1])
+    a[2] = 0; pa[2] = None
+    b[3] = 0; pb[3] = None
+    a[4] = 0; b[4] = 0; pa[4] = pb[4] = None
+    aff = lambda j: oc.jac_to_affine_ints(j)
+    madd = gpu.g1_op(0, a, b)
+    full = gpu.g1_op(1, a, b)
+    dbl = gpu.g1_op(2, a, b)
+    msub = gpu.g1_op(3, a, b)
+    twice = gpu.g1_op(4, a, b)
+    for i in range(n):
+        s = opy.g1_add(pa[i], pb[i])
+        assert aff(madd[i]) == s, i
+        assert aff(full[i]) == s, i
+        assert aff(dbl[i]) == opy.g1_add(pa[i], pa[i]), i
+        assert aff(msub[i]) == opy.g1_add(pa[i], opy.g1_neg(pb[i])), i
+        assert aff(twice[i]) == opy.g1_add(s, s), i

@@ -41,6 +41,8 @@ PROTOTYPES = {
     "uzk_synth_points_arith": (_I, [_P, _SZ, _P]),
     "uzk_synth_points_random": (_I, [_P, _SZ, _U64]),
     "uzk_synth_scalars": (_I, [_P, _SZ, _U64]),
+    "uzk_field_op_device": (_I, [_I, _I, _P, _P, _P, _SZ]),
+    "uzk_g1_op_device": (_I, [_I, _P, _P, _P, _SZ]),
     "uzk_profile_enable": (_I, [_I]),
     "uzk_profile_reset": (_I, []),
     "uzk_profile_get": (_I, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_U64)]),

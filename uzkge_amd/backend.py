@@ -143,6 +143,23 @@ def synth_scalars(d_scalars: int, n: int, seed: int) -> None:
     check(lib.uzk_synth_scalars(ctypes.c_void_p(d_scalars), n, seed))
 
 
+def field_op(field: str, op: int, a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """Device field primitive applied element-wise (KATs).  field: 'fq' | 'fr'."""
+    x = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+    y = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 4)
+    out = np.zeros_like(x)
+    check(lib.uzk_field_op_device(0 if field == "fq" else 1, op, _ptr(x), _ptr(y), _ptr(out), x.shape[0]))
+    return out
+
+
+def g1_op(op: int, a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    x = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 8)
+    y = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 8)
+    out = np.zeros((x.shape[0], 12), dtype=np.uint64)
+    check(lib.uzk_g1_op_device(op, _ptr(x), _ptr(y), _ptr(out), x.shape[0]))
+    return out
+
+
 def profile_enable(on: bool) -> None:
     check(lib.uzk_profile_enable(int(on)))
 

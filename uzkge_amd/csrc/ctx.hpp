@@ -101,5 +101,7 @@ void msm_free(Ctx& c);
 int synth_points_arith(Ctx& c, Affine* d_points, size_t n, const Fp& seed_scalar_mont);
 int synth_points_random(Ctx& c, Affine* d_points, size_t n, uint64_t seed);
 int synth_scalars(Ctx& c, Fp* d_scalars, size_t n, uint64_t seed);
+int field_op_device(Ctx& c, int field, int op, const Fp* a, const Fp* b, Fp* out, size_t n);
+int g1_op_device(Ctx& c, int op, const Affine* a, const Affine* b, Jac* out, size_t n);
 
 }  // namespace uzk

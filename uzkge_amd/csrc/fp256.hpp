@@ -43,6 +43,11 @@ struct FrCfg {
     static constexpr uint32_t INV = 0xefffffffu;
 };
 
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class C>
+__device__ __forceinline__ Fp mont_mul_fips(const Fp& a, const Fp& b);
+#endif
+
 template <class C>
 struct Field {
     UZK_HD static Fp zero() { Fp r; for (int i = 0; i < 8; ++i) r.v[i] = 0; return r; }
@@ -100,6 +105,14 @@ struct Field {
     // Montgomery product a*b*2^-256 mod M.  CIOS over 32-bit words; every step is
     // x*y + z + w with 32-bit z,w, which never exceeds 2^64-1 (no 65th bit anywhere).
     UZK_HD static Fp mul(const Fp& a, const Fp& b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(UZK_PORTABLE_MUL)
+        return mont_mul_fips<C>(a, b);     // inline-asm FIPS, mont_mul_gfx950.inc
+#else
+        return mul_portable(a, b);
+#endif
+    }
+    // Portable CIOS (host code, and the device cross-check of the assembly version).
+    UZK_HD static Fp mul_portable(const Fp& a, const Fp& b) {
         uint32_t t[9];
         for (int i = 0; i < 9; ++i) t[i] = 0;
 #pragma unroll
@@ -140,5 +153,9 @@ struct Field {
 
 using Fq = Field<FqCfg>;
 using Fr = Field<FrCfg>;
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#include "mont_mul_gfx950.inc"
+#endif
 
 }  // namespace uzk
