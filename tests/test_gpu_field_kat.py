@@ -34,6 +34,8 @@ def test_field_ops_match_oracle(gpu, field, mod):
     mul_asm = gpu.field_op(field, 0, a, b)
     mul_c = gpu.field_op(field, 3, a, b)
     assert np.array_equal(mul_asm, mul_c)
+    assert np.array_equal(gpu.field_op(field, 1, a, b), gpu.field_op(field, 8, a, b))   # asm add vs portable
+    assert np.array_equal(gpu.field_op(field, 2, a, b), gpu.field_op(field, 9, a, b))   # asm sub vs portable
     add = gpu.field_op(field, 1, a, b)
     sub = gpu.field_op(field, 2, a, b)
     sqr = gpu.field_op(field, 4, a, b)

@@ -63,7 +63,63 @@ def gen(square=False):
         if k < 15:
             L.append("    acc = (acc >> 32) | ((uint64_t)top << 32);")
             L.append("    top = 0;")
-    L.append("    return Field<C>::reduce_once(r);")
+    L.append("    fp_reduce_once_asm<C>(r);")
+    L.append("    return r;")
+    L.append("}")
+    return "\n".join(L)
+
+
+def gen_addsub():
+    """add / sub / dbl-free helpers: carry chains through VCC, modulus limbs in VGPRs (a VOP2 with
+    carry-in cannot also read an SGPR: one constant-bus read per instruction on gfx9)."""
+    L = []
+    # ---- conditional subtract: r in [0, 2M) -> [0, M)
+    L.append("template <class C>")
+    L.append("__device__ __forceinline__ void fp_reduce_once_asm(Fp& r) {")
+    L.append("    uint32_t t0, t1, t2, t3, t4, t5, t6, t7;")
+    body = ["v_sub_co_u32_e32 %8, vcc, %0, %16"]
+    for i in range(1, 8):
+        body.append(f"v_subb_co_u32_e32 %{8 + i}, vcc, %{i}, %{16 + i}, vcc")
+    for i in range(8):
+        body.append(f"v_cndmask_b32_e32 %{i}, %{8 + i}, %{i}, vcc")      # borrow ? r : t
+    outs = ", ".join([f'"+v"(r.v[{i}])' for i in range(8)] + [f'"=&v"(t{i})' for i in range(8)])
+    ins = ", ".join(f'"v"(C::M[{i}])' for i in range(8))
+    L.append('    asm("' + "\\n\\t".join(body) + '"\n        : ' + outs + "\n        : " + ins + '\n        : "vcc");')
+    L.append("}")
+    # ---- add
+    L.append("template <class C>")
+    L.append("__device__ __forceinline__ Fp fp_add_asm(const Fp& a, const Fp& b) {")
+    L.append("    Fp r = a;")
+    body = ["v_add_co_u32_e32 %0, vcc, %0, %8"]
+    for i in range(1, 8):
+        body.append(f"v_addc_co_u32_e32 %{i}, vcc, %{i}, %{8 + i}, vcc")
+    outs = ", ".join(f'"+v"(r.v[{i}])' for i in range(8))
+    ins = ", ".join(f'"v"(b.v[{i}])' for i in range(8))
+    L.append('    asm("' + "\\n\\t".join(body) + '"\n        : ' + outs + "\n        : " + ins + '\n        : "vcc");')
+    L.append("    fp_reduce_once_asm<C>(r);")
+    L.append("    return r;")
+    L.append("}")
+    # ---- sub: d = a - b; mask = borrow ? ~0 : 0; d += M & mask   (M stays in SGPRs here)
+    L.append("template <class C>")
+    L.append("__device__ __forceinline__ Fp fp_sub_asm(const Fp& a, const Fp& b) {")
+    L.append("    Fp r = a;")
+    L.append("    uint32_t mask;")
+    L.append("    uint32_t t0, t1, t2, t3, t4, t5, t6, t7;")
+    body = ["v_sub_co_u32_e32 %0, vcc, %0, %9"]
+    for i in range(1, 8):
+        body.append(f"v_subb_co_u32_e32 %{i}, vcc, %{i}, %{9 + i}, vcc")
+    body.append("v_cndmask_b32_e64 %8, 0, -1, vcc")
+    outs = ", ".join([f'"+v"(r.v[{i}])' for i in range(8)] + ['"=&v"(mask)'])
+    ins = ", ".join(f'"v"(b.v[{i}])' for i in range(8))
+    L.append('    asm("' + "\\n\\t".join(body) + '"\n        : ' + outs + "\n        : " + ins + '\n        : "vcc");')
+    body = [f"v_and_b32_e32 %{8 + i}, %{17 + i}, %16" for i in range(8)]
+    body.append("v_add_co_u32_e32 %0, vcc, %0, %8")
+    for i in range(1, 8):
+        body.append(f"v_addc_co_u32_e32 %{i}, vcc, %{i}, %{8 + i}, vcc")
+    outs = ", ".join([f'"+v"(r.v[{i}])' for i in range(8)] + [f'"=&v"(t{i})' for i in range(8)])
+    ins = ", ".join(['"v"(mask)'] + [f'"s"(C::M[{i}])' for i in range(8)])
+    L.append('    asm("' + "\\n\\t".join(body) + '"\n        : ' + outs + "\n        : " + ins + '\n        : "vcc");')
+    L.append("    return r;")
     L.append("}")
     return "\n".join(L)
 
@@ -74,6 +130,8 @@ def main():
         f.write("// GENERATED by tools/gen_mont_asm.py -- do not edit.\n")
         f.write("// Montgomery product a*b*2^-256 mod M for gfx950: FIPS over 32-bit limbs, one\n")
         f.write("// v_mad_u64_u32 + v_addc_co_u32 per partial product (128 pairs + 8 v_mul_lo_u32).\n")
+        f.write(gen_addsub())
+        f.write("\n\n")
         f.write(gen(False))
         f.write("\n")
 

@@ -19,6 +19,8 @@ __global__ __launch_bounds__(256) void field_op_kernel(int op, const Fp* __restr
         case 4: r = F::sqr(x); break;
         case 5: r = F::neg(x); break;
         case 6: r = F::from_mont(x); break;
+        case 8: r = F::add_portable(x, y); break;
+        case 9: r = F::sub_portable(x, y); break;
         default: r = F::to_mont(x); break;
     }
     out[i] = r;

@@ -46,6 +46,10 @@ struct FrCfg {
 #if defined(__HIP_DEVICE_COMPILE__)
 template <class C>
 __device__ __forceinline__ Fp mont_mul_fips(const Fp& a, const Fp& b);
+template <class C>
+__device__ __forceinline__ Fp fp_add_asm(const Fp& a, const Fp& b);
+template <class C>
+__device__ __forceinline__ Fp fp_sub_asm(const Fp& a, const Fp& b);
 #endif
 
 template <class C>
@@ -75,11 +79,25 @@ struct Field {
         return r;
     }
     UZK_HD static Fp add(const Fp& a, const Fp& b) {   // moduli < 2^254: no carry out of limb 7
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(UZK_PORTABLE_MUL)
+        return fp_add_asm<C>(a, b);
+#else
+        return add_portable(a, b);
+#endif
+    }
+    UZK_HD static Fp add_portable(const Fp& a, const Fp& b) {
         Fp s; uint64_t c = 0;
         for (int i = 0; i < 8; ++i) { c += (uint64_t)a.v[i] + b.v[i]; s.v[i] = (uint32_t)c; c >>= 32; }
         return reduce_once(s);
     }
     UZK_HD static Fp sub(const Fp& a, const Fp& b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(UZK_PORTABLE_MUL)
+        return fp_sub_asm<C>(a, b);
+#else
+        return sub_portable(a, b);
+#endif
+    }
+    UZK_HD static Fp sub_portable(const Fp& a, const Fp& b) {
         Fp d; uint64_t br = 0;
         for (int i = 0; i < 8; ++i) {
             uint64_t t = (uint64_t)a.v[i] - b.v[i] - br;
