@@ -60,3 +60,34 @@ def test_random_points_on_curve_and_split_property(gpu):
         srs.release()
     assert affine_of(gpu.g1_fold(np.stack([h1, h2]))) == affine_of(full)
     assert affine_of(full) == affine_of(oc.msm_pippenger(hp, hs, 0, 16))
+
+
+@pytest.mark.parametrize("kind", ["all_ones", "all_minus_one", "two_values", "prover_mix"])
+def test_skewed_scalars_closed_form(gpu, kind):
+    """Heavily skewed scalar sets at 2^16 (one bucket holds every point, so the multi-level
+    partial-sum folding runs) checked with the arithmetic-progression closed form."""
+    n = 1 << 16
+    pts = torch.empty((n, 8), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    seed_int = 0x1234567
+    gpu.synth_points_arith(pts.data_ptr(), n, oc.fr_from_ints([seed_int])[0])
+    rng = np.random.default_rng(5)
+    if kind == "all_ones":
+        ints = [1] * n
+    elif kind == "all_minus_one":
+        ints = [opy.R - 1] * n
+    elif kind == "two_values":
+        ints = [3 if v else (opy.R - 7) for v in rng.integers(0, 2, n)]
+    else:
+        cls = rng.integers(0, 10, n)
+        u = rng.integers(1, 1 << 62, n)
+        ints = [0 if c < 5 else 1 if c < 7 else opy.R - 1 if c < 8 else int(u[i]) & 0xFFFF if c < 9 else int(u[i]) ** 4 % opy.R
+                for i, c in enumerate(cls)]
+    wire = oc.fr_from_ints(ints)
+    srs = gpu.Srs.from_device(pts.data_ptr(), n)
+    try:
+        got = affine_of(gpu.msm(srs, wire))
+    finally:
+        srs.release()
+    k = sum(s * (i + 1) for i, s in enumerate(ints)) % opy.R
+    assert got == opy.g1_mul(opy.g1_mul(opy.G1_GEN, seed_int), k)

@@ -9,9 +9,13 @@
 //   2 msm_hist        per (chunk, window) workgroup: bucket histogram in LDS (<= 128 KiB)
 //   3 msm_scan_*      bucket totals, per-chunk offsets, per-window exclusive scan
 //   4 msm_scatter     counting-sort scatter: LDS cursors, writes point indices grouped by bucket
-//   5 msm_accumulate  one lane per (window, bucket): walks its run of indices, gathers the
-//                     64-byte affine point from HBM (next point prefetched under the current
-//                     mixed add), XYZZ accumulator in VGPRs -- the dominant kernel
+//   5 msm_accumulate  one lane per TASK = a run of <= L sorted indices of one bucket (buckets are
+//                     split so that skewed scalar sets and small n still fill the chip and the
+//                     grid has no long tail): gathers the 64-byte affine point from HBM (next
+//                     point prefetched under the current mixed add), XYZZ accumulator in VGPRs
+//                     -- the dominant kernel
+//   5b msm_combine /  partial sums of one bucket are folded <= 32 at a time (extra levels only
+//      msm_finalize   when one bucket holds more than 32*L points), last level writes buckets
 //   6 msm_reduce      per window sum_b b*B_b: 16-bucket running sums per lane, one short
 //                     double-and-add for the segment weight, LDS tree per workgroup
 //   7 host            fold the <= W*8 partials and combine windows (Horner, c doublings each)
@@ -30,9 +34,12 @@ constexpr uint32_t kSignBit = 0x80000000u;
 
 struct MsmWork {
     DevBuf digits, chunk_hist, bucket_count, bucket_start, sorted, buckets, partials;
+    DevBuf lvl_cnt[2], lvl_off[2], lvl_part[2], small;   // task levels; small = win totals/bases/max
     XYZZ* h_partials = nullptr;   // pinned
     size_t h_partials_cap = 0;
+    uint32_t* h_max = nullptr;    // pinned: largest bucket population of the current call
 };
+constexpr uint32_t kCombineFan = 32;   // partial sums folded per lane and level
 
 __host__ __device__ inline int msm_num_windows(int c) {
     int W = (254 + c - 1) / c;
@@ -95,16 +102,29 @@ __global__ __launch_bounds__(256) void msm_scan_chunks_kernel(uint32_t* __restri
     }
     bucket_count[t] = run;
 }
-// one workgroup per window: exclusive scan of bucket_count[w][0..NB) -> bucket_start
-__global__ __launch_bounds__(1024) void msm_scan_buckets_kernel(const uint32_t* __restrict__ bucket_count,
-                                                                uint32_t* __restrict__ bucket_start, uint32_t NB) {
+// One workgroup per window: v[b] = div ? ceil(cnt[b] / div) : cnt[b] (v[0] = 0 when skip0);
+// writes v (optional), the exclusive prefix of v within the window, the window total, and
+// folds max(cnt[b >= 1]) into *max_out (optional).
+__global__ __launch_bounds__(1024) void msm_scan_win_kernel(const uint32_t* __restrict__ cnt_in, uint32_t div,
+                                                            int skip0, uint32_t* __restrict__ v_out,
+                                                            uint32_t* __restrict__ off_out,
+                                                            uint32_t* __restrict__ win_total,
+                                                            uint32_t* __restrict__ max_out, uint32_t NB) {
     __shared__ uint32_t part[1024];
     const uint32_t w = blockIdx.x, tid = threadIdx.x;
     const uint32_t per = (NB + 1023) / 1024;
     const uint32_t lo = min(NB, tid * per), hi = min(NB, lo + per);
-    const uint32_t* cnt = bucket_count + (size_t)w * NB;
-    uint32_t s = 0;
-    for (uint32_t b = lo; b < hi; ++b) s += cnt[b];
+    const uint32_t* cnt = cnt_in + (size_t)w * NB;
+    auto val = [&](uint32_t b) -> uint32_t {
+        if (skip0 && b == 0) return 0u;
+        const uint32_t c = cnt[b];
+        return div ? (c + div - 1) / div : c;
+    };
+    uint32_t s = 0, mx = 0;
+    for (uint32_t b = lo; b < hi; ++b) {
+        s += val(b);
+        if (b != 0) mx = max(mx, cnt[b]);
+    }
     part[tid] = s;
     __syncthreads();
     for (uint32_t off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan
@@ -114,8 +134,27 @@ __global__ __launch_bounds__(1024) void msm_scan_buckets_kernel(const uint32_t* 
         __syncthreads();
     }
     uint32_t run = part[tid] - s;
-    uint32_t* st = bucket_start + (size_t)w * NB;
-    for (uint32_t b = lo; b < hi; ++b) { st[b] = run; run += cnt[b]; }
+    uint32_t* off_o = off_out + (size_t)w * NB;
+    uint32_t* v_o = v_out ? v_out + (size_t)w * NB : nullptr;
+    for (uint32_t b = lo; b < hi; ++b) {
+        const uint32_t v = val(b);
+        off_o[b] = run;
+        if (v_o) v_o[b] = v;
+        run += v;
+    }
+    if (tid == 1023) win_total[w] = part[1023];
+    if (max_out) {
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_down((int)mx, o));
+        if ((tid & 63) == 0 && mx) atomicMax(max_out, mx);
+    }
+}
+// win_base[w] = sum of win_total[0..w), win_base[W] = grand total
+__global__ void msm_win_base_kernel(const uint32_t* __restrict__ win_total, uint32_t* __restrict__ win_base, uint32_t W) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        uint32_t run = 0;
+        for (uint32_t w = 0; w < W; ++w) { win_base[w] = run; run += win_total[w]; }
+        win_base[W] = run;
+    }
 }
 
 // ---- 4. scatter ---------------------------------------------------------------------------------
@@ -147,31 +186,90 @@ __device__ __forceinline__ Affine load_point(const Affine* __restrict__ pts, uin
     return pts[idx];
 }
 
+// task id -> (window, bucket, j): window by a short scan of win_base, bucket by binary search in the
+// window's exclusive task prefix (the largest b with off[b] <= local id is the non-empty one).
+__device__ __forceinline__ void find_task(uint32_t tid, const uint32_t* __restrict__ win_base, uint32_t W,
+                                          const uint32_t* __restrict__ task_off, uint32_t NB, uint32_t& w,
+                                          uint32_t& b, uint32_t& j) {
+    w = 0;
+    while (w + 1 < W && win_base[w + 1] <= tid) ++w;
+    const uint32_t lt = tid - win_base[w];
+    const uint32_t* off = task_off + (size_t)w * NB;
+    uint32_t lo = 0, hi = NB;          // invariant: off[lo] <= lt, answer in [lo, hi)
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (off[mid] <= lt) lo = mid; else hi = mid;
+    }
+    b = lo;
+    j = lt - off[lo];
+}
+
 __global__ __launch_bounds__(256) void msm_accumulate_kernel(const Affine* __restrict__ points,
                                                              const uint32_t* __restrict__ sorted,
                                                              const uint32_t* __restrict__ bucket_start,
                                                              const uint32_t* __restrict__ bucket_count,
-                                                             XYZZ* __restrict__ buckets, uint32_t n, uint32_t NB,
-                                                             uint32_t W) {
+                                                             const uint32_t* __restrict__ task_off,
+                                                             const uint32_t* __restrict__ win_base,
+                                                             XYZZ* __restrict__ partials, uint32_t n, uint32_t NB,
+                                                             uint32_t W, uint32_t L) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= win_base[W]) return;
+    uint32_t w, b, j;
+    find_task(tid, win_base, W, task_off, NB, w, b, j);
+    const uint32_t total = bucket_count[(size_t)w * NB + b];
+    const uint32_t first = j * L;
+    const uint32_t cnt = min(L, total - first);
+    const uint32_t* run = sorted + (size_t)w * n + bucket_start[(size_t)w * NB + b] + first;
+    XYZZ acc = xyzz_inf();
+    uint32_t e = run[0];
+    Affine p = load_point(points, e & ~kSignBit);
+    for (uint32_t k = 0; k < cnt; ++k) {
+        const Affine cur = p;
+        const bool neg = (e & kSignBit) != 0;
+        if (k + 1 < cnt) {
+            e = run[k + 1];
+            p = load_point(points, e & ~kSignBit);
+        }
+        xyzz_madd(acc, cur, neg);
+    }
+    partials[tid] = acc;
+}
+
+// Intermediate level (only for buckets holding > G*L points): out task = sum of <= G partials.
+__global__ __launch_bounds__(256) void msm_combine_kernel(const XYZZ* __restrict__ in, const uint32_t* __restrict__ in_cnt,
+                                                          const uint32_t* __restrict__ in_off,
+                                                          const uint32_t* __restrict__ in_base,
+                                                          const uint32_t* __restrict__ task_off,
+                                                          const uint32_t* __restrict__ win_base, XYZZ* __restrict__ out,
+                                                          uint32_t NB, uint32_t W, uint32_t G) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= win_base[W]) return;
+    uint32_t w, b, j;
+    find_task(tid, win_base, W, task_off, NB, w, b, j);
+    const uint32_t total = in_cnt[(size_t)w * NB + b];
+    const uint32_t first = j * G;
+    const uint32_t cnt = min(G, total - first);
+    const XYZZ* src = in + in_base[w] + in_off[(size_t)w * NB + b] + first;
+    XYZZ acc = src[0];
+    for (uint32_t k = 1; k < cnt; ++k) { XYZZ q = src[k]; xyzz_add(acc, q); }
+    out[tid] = acc;
+}
+
+// Last level: one lane per bucket folds its <= G partials into the dense bucket array.
+__global__ __launch_bounds__(256) void msm_finalize_kernel(const XYZZ* __restrict__ in, const uint32_t* __restrict__ in_cnt,
+                                                           const uint32_t* __restrict__ in_off,
+                                                           const uint32_t* __restrict__ in_base,
+                                                           XYZZ* __restrict__ buckets, uint32_t NB, uint32_t W) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t nbk = NB - 1;
     if (t >= (size_t)W * nbk) return;
     const uint32_t w = (uint32_t)(t / nbk), b = (uint32_t)(t % nbk) + 1;
-    const uint32_t start = bucket_start[(size_t)w * NB + b], cnt = bucket_count[(size_t)w * NB + b];
-    const uint32_t* run = sorted + (size_t)w * n + start;
+    const uint32_t cnt = in_cnt[(size_t)w * NB + b];
     XYZZ acc = xyzz_inf();
     if (cnt > 0) {
-        uint32_t e = run[0];
-        Affine p = load_point(points, e & ~kSignBit);
-        for (uint32_t j = 0; j < cnt; ++j) {
-            const Affine cur = p;
-            const bool neg = (e & kSignBit) != 0;
-            if (j + 1 < cnt) {
-                e = run[j + 1];
-                p = load_point(points, e & ~kSignBit);
-            }
-            xyzz_madd(acc, cur, neg);
-        }
+        const XYZZ* src = in + in_base[w] + in_off[(size_t)w * NB + b];
+        acc = src[0];
+        for (uint32_t k = 1; k < cnt; ++k) { XYZZ q = src[k]; xyzz_add(acc, q); }
     }
     buckets[t] = acc;
 }
@@ -235,8 +333,10 @@ void msm_free(Ctx& c) {
     if (!c.msm) return;
     MsmWork* m = c.msm;
     m->digits.release(); m->chunk_hist.release(); m->bucket_count.release(); m->bucket_start.release();
-    m->sorted.release(); m->buckets.release(); m->partials.release();
+    m->sorted.release(); m->buckets.release(); m->partials.release(); m->small.release();
+    for (int k = 0; k < 2; ++k) { m->lvl_cnt[k].release(); m->lvl_off[k].release(); m->lvl_part[k].release(); }
     if (m->h_partials) (void)hipHostFree(m->h_partials);
+    if (m->h_max) (void)hipHostFree(m->h_max);
     delete m;
     c.msm = nullptr;
 }
@@ -252,13 +352,19 @@ int msm_run(Ctx& c, const Affine* d_points, const Fp* d_scalars, size_t n, Jac* 
     if (!c.msm) c.msm = new MsmWork();
     MsmWork& m = *c.msm;
     const int cb = choose_window_bits(n, c.msm_window_bits);
-    const int W = msm_num_windows(cb);
+    const uint32_t W = (uint32_t)msm_num_windows(cb);
     const uint32_t NB = (1u << (cb - 1)) + 1, nbk = NB - 1;
     const uint32_t n32 = (uint32_t)n;
+    if ((uint64_t)W * n >= (1ull << 32)) { set_error("msm: W*n overflows the 32-bit task space"); return UZK_ERR_PARAMETER; }
     uint32_t nch = (uint32_t)std::min<size_t>(32, (n + 8191) / 8192);
     const uint32_t chunk_size = (n32 + nch - 1) / nch;
     nch = (n32 + chunk_size - 1) / chunk_size;
     const uint32_t groups = (nbk + kSeg * 256 - 1) / (kSeg * 256);
+    const uint64_t entries = (uint64_t)W * n;
+    const uint32_t L = (uint32_t)std::max<uint64_t>(16, std::min<uint64_t>(128, entries >> 20));
+    const uint32_t G = kCombineFan;
+    const uint64_t bound0 = entries / L + (uint64_t)W * nbk;          // upper bound on level-0 tasks
+    const uint64_t part_cap = bound0 + 2ull * W * nbk;               // every later level fits too
 
     UZK_TRY(m.digits.reserve((size_t)W * n * 4));
     UZK_TRY(m.sorted.reserve((size_t)W * n * 4));
@@ -267,12 +373,19 @@ int msm_run(Ctx& c, const Affine* d_points, const Fp* d_scalars, size_t n, Jac* 
     UZK_TRY(m.bucket_start.reserve((size_t)W * NB * 4));
     UZK_TRY(m.buckets.reserve((size_t)W * nbk * sizeof(XYZZ)));
     UZK_TRY(m.partials.reserve((size_t)W * groups * sizeof(XYZZ)));
+    for (int k = 0; k < 2; ++k) {
+        UZK_TRY(m.lvl_cnt[k].reserve((size_t)W * NB * 4));
+        UZK_TRY(m.lvl_off[k].reserve((size_t)W * NB * 4));
+    }
+    UZK_TRY(m.lvl_part[0].reserve((size_t)part_cap * sizeof(XYZZ)));
+    UZK_TRY(m.small.reserve(4096));
     const size_t np = (size_t)W * groups;
     if (m.h_partials_cap < np) {
         if (m.h_partials) (void)hipHostFree(m.h_partials);
         UZK_HIP(hipHostMalloc(reinterpret_cast<void**>(&m.h_partials), np * sizeof(XYZZ), hipHostMallocDefault));
         m.h_partials_cap = np;
     }
+    if (!m.h_max) UZK_HIP(hipHostMalloc(reinterpret_cast<void**>(&m.h_max), 64, hipHostMallocDefault));
     const size_t lds_bytes = (size_t)NB * 4;
     UZK_TRY(set_dyn_lds(reinterpret_cast<const void*>(msm_hist_kernel), lds_bytes));
     UZK_TRY(set_dyn_lds(reinterpret_cast<const void*>(msm_scatter_kernel), lds_bytes));
@@ -284,11 +397,17 @@ int msm_run(Ctx& c, const Affine* d_points, const Fp* d_scalars, size_t n, Jac* 
     uint32_t* bstart = m.bucket_start.as<uint32_t>();
     XYZZ* buckets = m.buckets.as<XYZZ>();
     XYZZ* partials = m.partials.as<XYZZ>();
+    // small: [0..64) window totals, [64..192) win_base ping, [192..320) win_base pong, [320] max
+    uint32_t* sm = m.small.as<uint32_t>();
+    uint32_t* win_tot = sm;
+    uint32_t* win_base[2] = {sm + 64, sm + 192};
+    uint32_t* d_max = sm + 320;
     hipStream_t st = c.stream;
 
+    UZK_HIP(hipMemsetAsync(d_max, 0, 4, st));
     {
         KernelScope ks(c, "msm_digits");
-        hipLaunchKernelGGL(msm_digits_kernel, dim3((n32 + 255) / 256), dim3(256), 0, st, d_scalars, digits, n32, cb, W);
+        hipLaunchKernelGGL(msm_digits_kernel, dim3((n32 + 255) / 256), dim3(256), 0, st, d_scalars, digits, n32, cb, (int)W);
     }
     {
         KernelScope ks(c, "msm_hist");
@@ -299,22 +418,70 @@ int msm_run(Ctx& c, const Affine* d_points, const Fp* d_scalars, size_t n, Jac* 
         KernelScope ks(c, "msm_scan_chunks");
         const size_t tot = (size_t)W * NB;
         hipLaunchKernelGGL(msm_scan_chunks_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, chunk_hist,
-                           bcount, NB, nch, (uint32_t)W);
+                           bcount, NB, nch, W);
     }
     {
-        KernelScope ks(c, "msm_scan_buckets");
-        hipLaunchKernelGGL(msm_scan_buckets_kernel, dim3(W), dim3(1024), 0, st, bcount, bstart, NB);
+        KernelScope ks(c, "msm_scan_win");
+        hipLaunchKernelGGL(msm_scan_win_kernel, dim3(W), dim3(1024), 0, st, bcount, 0u, 0, (uint32_t*)nullptr, bstart,
+                           win_tot, d_max, NB);
     }
+    UZK_HIP(hipMemcpyAsync(m.h_max, d_max, 4, hipMemcpyDeviceToHost, st));
     {
         KernelScope ks(c, "msm_scatter");
         hipLaunchKernelGGL(msm_scatter_kernel, dim3(nch, W), dim3(kMsmThreads), lds_bytes, st, digits, chunk_hist,
                            bstart, sorted, n32, chunk_size, NB);
     }
+    // level-0 tasks (runs of <= L indices)
+    uint32_t* cnt_cur = m.lvl_cnt[0].as<uint32_t>();
+    uint32_t* off_cur = m.lvl_off[0].as<uint32_t>();
+    uint32_t* base_cur = win_base[0];
+    XYZZ* part_cur = m.lvl_part[0].as<XYZZ>();
+    {
+        KernelScope ks(c, "msm_scan_win");
+        hipLaunchKernelGGL(msm_scan_win_kernel, dim3(W), dim3(1024), 0, st, bcount, L, 1, cnt_cur, off_cur, win_tot,
+                           (uint32_t*)nullptr, NB);
+        hipLaunchKernelGGL(msm_win_base_kernel, dim3(1), dim3(64), 0, st, win_tot, base_cur, W);
+    }
     {
         KernelScope ks(c, "msm_accumulate");
+        hipLaunchKernelGGL(msm_accumulate_kernel, dim3((unsigned)((bound0 + 255) / 256)), dim3(256), 0, st, d_points,
+                           sorted, bstart, bcount, off_cur, base_cur, part_cur, n32, NB, W, L);
+    }
+    UZK_HIP(hipGetLastError());
+    // the largest bucket decides how many fold levels are needed (one tiny read-back)
+    UZK_HIP(hipStreamSynchronize(st));
+    uint64_t tmax = ((uint64_t)m.h_max[0] + L - 1) / L;
+    int lvl = 0;
+    uint64_t bound_prev = bound0;
+    while (tmax > G) {
+        const int nx = (lvl + 1) & 1;
+        UZK_TRY(m.lvl_part[nx].reserve((size_t)part_cap * sizeof(XYZZ)));   // no-op for buffer 0
+        uint32_t* cnt_nx = m.lvl_cnt[nx].as<uint32_t>();
+        uint32_t* off_nx = m.lvl_off[nx].as<uint32_t>();
+        uint32_t* base_nx = win_base[nx];
+        const uint64_t bound_nx = bound_prev / G + (uint64_t)W * nbk;
+        XYZZ* part_nx = m.lvl_part[nx].as<XYZZ>();
+        {
+            KernelScope ks(c, "msm_scan_win");
+            hipLaunchKernelGGL(msm_scan_win_kernel, dim3(W), dim3(1024), 0, st, cnt_cur, G, 1, cnt_nx, off_nx, win_tot,
+                               (uint32_t*)nullptr, NB);
+            hipLaunchKernelGGL(msm_win_base_kernel, dim3(1), dim3(64), 0, st, win_tot, base_nx, W);
+        }
+        {
+            KernelScope ks(c, "msm_combine");
+            hipLaunchKernelGGL(msm_combine_kernel, dim3((unsigned)((bound_nx + 255) / 256)), dim3(256), 0, st, part_cur,
+                               cnt_cur, off_cur, base_cur, off_nx, base_nx, part_nx, NB, W, G);
+        }
+        cnt_cur = cnt_nx; off_cur = off_nx; base_cur = base_nx; part_cur = part_nx;
+        bound_prev = bound_nx;
+        tmax = (tmax + G - 1) / G;
+        lvl = nx;
+    }
+    {
+        KernelScope ks(c, "msm_finalize");
         const size_t tot = (size_t)W * nbk;
-        hipLaunchKernelGGL(msm_accumulate_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_points,
-                           sorted, bstart, bcount, buckets, n32, NB, (uint32_t)W);
+        hipLaunchKernelGGL(msm_finalize_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, part_cur, cnt_cur,
+                           off_cur, base_cur, buckets, NB, W);
     }
     {
         KernelScope ks(c, "msm_reduce");
@@ -326,7 +493,7 @@ int msm_run(Ctx& c, const Affine* d_points, const Fp* d_scalars, size_t n, Jac* 
 
     // 7. host: fold partials per window, then Horner over windows (c doublings per step)
     XYZZ total = xyzz_inf();
-    for (int w = W - 1; w >= 0; --w) {
+    for (int w = (int)W - 1; w >= 0; --w) {
         for (int d = 0; d < cb; ++d) total = xyzz_dbl(total);
         for (uint32_t g = 0; g < groups; ++g) xyzz_add(total, m.h_partials[(size_t)w * groups + g]);
     }
