@@ -1,0 +1,205 @@
+"""Host-side mirror of the reference's polynomial layer for the hot path, over the C ABI.
+
+  FpPolynomial                 uzkge/src/poly_commit/field_polynomial.rs:13-17, 86-90, 154-159,
+                               198-209 (eval), 470-477 (mul_var), 554-607 (domains, fft wrappers)
+  KZGCommitmentSchemeBN254     uzkge/src/poly_commit/kzg_poly_commitment.rs:170-313
+                               (from_unchecked_bytes :228-264, commit :278-293,
+                                apply_blind_factors :299-313)
+
+Same names, argument meaning and error behaviour as the Rust (errors are `UzkgeError` with the
+reference's variant names).  All heavy work goes to the GPU through `backend`; what stays here is
+what stays in Rust in the real integration: trimming, zero-padding, domain choice, length checks.
+Coefficients are numpy uint64 arrays [n, 4] in the wire format (Montgomery, 4 LE limbs).
+"""
+from __future__ import annotations
+
+import struct
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _native as N
+from . import backend as B
+from .errors import UzkgeError
+
+FR_MODULUS = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+FQ_MODULUS = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
+_MASK64 = (1 << 64) - 1
+
+
+def _to_wire(x: int, mod: int) -> np.ndarray:
+    v = (x << 256) % mod
+    return np.array([(v >> (64 * i)) & _MASK64 for i in range(4)], dtype=np.uint64)
+
+
+def _wire_int(row: np.ndarray) -> int:
+    return sum(int(row[i]) << (64 * i) for i in range(4))
+
+
+def fr_from_int(x: int) -> np.ndarray:
+    """canonical integer -> Montgomery wire limbs."""
+    return _to_wire(x % FR_MODULUS, FR_MODULUS)
+
+
+def fr_to_int(row: np.ndarray) -> int:
+    return _wire_int(row) * pow(1 << 256, -1, FR_MODULUS) % FR_MODULUS
+
+
+def fr_neg(rows: np.ndarray) -> np.ndarray:
+    """-x on wire-format rows (Montgomery form is linear: r - x)."""
+    out = np.zeros_like(rows)
+    for i, row in enumerate(rows.reshape(-1, 4)):
+        v = _wire_int(row)
+        v = (FR_MODULUS - v) % FR_MODULUS
+        out.reshape(-1, 4)[i] = [(v >> (64 * k)) & _MASK64 for k in range(4)]
+    return out
+
+
+class FpPolynomial:
+    """Dense polynomial over BN254 Fr, coefficients low to high."""
+
+    def __init__(self, coefs: np.ndarray):
+        self.coefs = np.ascontiguousarray(coefs, dtype=np.uint64).reshape(-1, 4)
+
+    # -- construction -------------------------------------------------------------------------
+    @classmethod
+    def from_coefs(cls, coefs: np.ndarray) -> "FpPolynomial":
+        """Trims trailing zeros like the reference (field_polynomial.rs:86-90,154-159); the zero
+        polynomial keeps one zero coefficient."""
+        c = np.ascontiguousarray(coefs, dtype=np.uint64).reshape(-1, 4)
+        nz = np.flatnonzero(c.any(axis=1))
+        keep = int(nz[-1]) + 1 if nz.size else 1
+        if c.shape[0] == 0:
+            c = np.zeros((1, 4), dtype=np.uint64)
+        return cls(c[:keep].copy())
+
+    @classmethod
+    def from_ints(cls, ints: Sequence[int]) -> "FpPolynomial":
+        return cls.from_coefs(np.stack([fr_from_int(x) for x in ints]) if len(ints) else np.zeros((0, 4), np.uint64))
+
+    def get_coefs_ref(self) -> np.ndarray:
+        return self.coefs
+
+    def degree(self) -> int:
+        nz = np.flatnonzero(self.coefs.any(axis=1))
+        return int(nz[-1]) if nz.size else 0
+
+    # -- small host-side helpers ---------------------------------------------------------------
+    def eval(self, point: int) -> int:
+        """Horner (field_polynomial.rs:198-209), canonical ints."""
+        acc = 0
+        for row in self.coefs[::-1]:
+            acc = (acc * point + fr_to_int(row)) % FR_MODULUS
+        return acc
+
+    # -- domains (field_polynomial.rs:554-567) ------------------------------------------------
+    @staticmethod
+    def evaluation_domain(num_coeffs: int) -> Optional[int]:
+        assert num_coeffs > 0 and num_coeffs & (num_coeffs - 1) == 0
+        return num_coeffs if B.domain_supported(num_coeffs) else None
+
+    @staticmethod
+    def quotient_evaluation_domain(num_coeffs: int) -> Optional[int]:
+        m = num_coeffs // 3 if num_coeffs % 3 == 0 else num_coeffs
+        assert num_coeffs > 0 and m & (m - 1) == 0
+        return num_coeffs if B.domain_supported(num_coeffs) else None
+
+    # -- transforms ---------------------------------------------------------------------------
+    def _padded(self, n: int) -> np.ndarray:
+        out = np.zeros((n, 4), dtype=np.uint64)
+        out[: self.coefs.shape[0]] = self.coefs
+        return out
+
+    def fft(self, num_coeffs: int) -> Optional[np.ndarray]:
+        """field_polynomial.rs:570-580."""
+        assert num_coeffs > self.degree()
+        dom = (self.evaluation_domain(num_coeffs) if num_coeffs & (num_coeffs - 1) == 0
+               else self.quotient_evaluation_domain(num_coeffs))
+        if dom is None:
+            return None
+        return self.fft_with_domain(dom)
+
+    def fft_with_domain(self, domain: int) -> np.ndarray:
+        """`domain.fft(&self.coefs)` (field_polynomial.rs:583-586): zero-pad, natural order."""
+        assert domain > self.degree()
+        return B.ntt(self._padded(domain)[:domain] if self.coefs.shape[0] <= domain else self.coefs[:domain])
+
+    def coset_fft_with_domain(self, domain: int, k: np.ndarray) -> np.ndarray:
+        """fft of p(kX) (field_polynomial.rs:589-591); the k^j scaling is fused on the device."""
+        assert domain > self.degree()
+        return B.ntt(self._padded(domain), coset_shift=k)
+
+    @classmethod
+    def ifft_with_domain(cls, domain: int, values: np.ndarray) -> "FpPolynomial":
+        """`domain.ifft(values)` then from_coefs (field_polynomial.rs:594-597)."""
+        v = np.ascontiguousarray(values, dtype=np.uint64).reshape(-1, 4)
+        buf = np.zeros((domain, 4), dtype=np.uint64)
+        buf[: v.shape[0]] = v
+        return cls.from_coefs(B.ntt(buf, inverse=True))
+
+    @classmethod
+    def coset_ifft_with_domain(cls, domain: int, values: np.ndarray, k_inv: np.ndarray) -> "FpPolynomial":
+        """ifft then mul_var(k_inv) (field_polynomial.rs:601-607)."""
+        v = np.ascontiguousarray(values, dtype=np.uint64).reshape(-1, 4)
+        buf = np.zeros((domain, 4), dtype=np.uint64)
+        buf[: v.shape[0]] = v
+        return cls.from_coefs(B.ntt(buf, inverse=True, coset_shift=k_inv))
+
+    def __eq__(self, other) -> bool:
+        return isinstance(other, FpPolynomial) and np.array_equal(
+            FpPolynomial.from_coefs(self.coefs).coefs, FpPolynomial.from_coefs(other.coefs).coefs)
+
+
+class KZGCommitmentSchemeBN254:
+    """KZG over BN254 with the G1 powers resident on the GPU."""
+
+    def __init__(self, g1_wire: np.ndarray):
+        self.public_parameter_group_1 = np.ascontiguousarray(g1_wire, dtype=np.uint64).reshape(-1, 8)
+        self._srs = B.Srs.from_host(self.public_parameter_group_1)
+
+    @classmethod
+    def from_unchecked_bytes(cls, data: bytes) -> "KZGCommitmentSchemeBN254":
+        """Reference SRS blob: u32 len_g1 | u32 len_g2 | len_g1 x (x LE32 || y LE32, flags in the
+        top two bits of the last byte) | G2 points (kzg_poly_commitment.rs:228-264).  The G2 part is
+        only used by the verifier and is ignored here."""
+        if len(data) < 8:
+            raise UzkgeError(N.UZK_ERR_PARAMETER, "DeserializationError: short SRS blob")
+        len1, _len2 = struct.unpack_from("<II", data, 0)
+        if len(data) < 8 + 64 * len1:
+            raise UzkgeError(N.UZK_ERR_PARAMETER, "DeserializationError: truncated G1 section")
+        out = np.zeros((len1, 8), dtype=np.uint64)
+        for i in range(len1):
+            off = 8 + 64 * i
+            x = int.from_bytes(data[off:off + 32], "little")
+            yb = bytearray(data[off + 32:off + 64])
+            flags = yb[31] & 0xC0
+            yb[31] &= 0x3F
+            if flags & 0x40:
+                continue                       # infinity -> (0, 0)
+            y = int.from_bytes(bytes(yb), "little")
+            out[i, :4] = _to_wire(x, FQ_MODULUS)
+            out[i, 4:] = _to_wire(y, FQ_MODULUS)
+        return cls(out)
+
+    def max_degree(self) -> int:
+        return self.public_parameter_group_1.shape[0] - 1
+
+    def commit(self, polynomial: FpPolynomial) -> np.ndarray:
+        """C = sum_i coef_i * SRS_i (kzg_poly_commitment.rs:278-293).  DegreeError when
+        degree + 1 > SRS length; an all-zero polynomial commits to infinity."""
+        degree = polynomial.degree()
+        if degree + 1 > self.public_parameter_group_1.shape[0]:
+            raise UzkgeError(N.UZK_ERR_DEGREE, "polynomial degree exceeds the SRS")
+        return B.msm(self._srs, polynomial.get_coefs_ref()[: degree + 1])
+
+    def apply_blind_factors(self, commitment: np.ndarray, blinds: np.ndarray, zeroing_degree: int) -> np.ndarray:
+        """C += sum_i b_i * (SRS[i] - SRS[zeroing_degree + i]) (kzg_poly_commitment.rs:299-313)."""
+        b = np.ascontiguousarray(blinds, dtype=np.uint64).reshape(-1, 4)
+        if b.shape[0] == 0:
+            return commitment
+        plus = B.msm(self._srs, b, offset=0)
+        minus = B.msm(self._srs, fr_neg(b), offset=zeroing_degree)
+        return B.g1_fold(np.stack([np.asarray(commitment, dtype=np.uint64).reshape(12), plus, minus]))
+
+    def release(self) -> None:
+        self._srs.release()
