@@ -135,6 +135,9 @@ int uzk_sync(void);
 void* uzk_stream(void);
 /* Tuning knobs (0 = automatic): MSM window bits. */
 int uzk_msm_set_window_bits(int c);
+/* Experiment switches for A/B measurements in one process (keys: "msm_acc_variant",
+ * "msm_task_len"); never needed for correctness. */
+int uzk_tune(const char* key, int value);
 
 #ifdef __cplusplus
 }

@@ -50,6 +50,7 @@ PROTOTYPES = {
     "uzk_sync": (_I, []),
     "uzk_stream": (_P, []),
     "uzk_msm_set_window_bits": (_I, [_I]),
+    "uzk_tune": (_I, [ctypes.c_char_p, _I]),
 }
 
 

@@ -187,3 +187,7 @@ def profile_table() -> dict:
 
 def set_msm_window_bits(c: int) -> None:
     check(lib.uzk_msm_set_window_bits(c))
+
+
+def tune(key: str, value: int) -> None:
+    check(lib.uzk_tune(key.encode(), value))

@@ -452,4 +452,14 @@ int uzk_msm_set_window_bits(int c) {
     return UZK_OK;
 }
 
+int uzk_tune(const char* key, int value) {
+    API_LOCK;
+    if (!key) { set_error("uzk_tune: null key"); return UZK_ERR_PARAMETER; }
+    Ctx& c = ctx();
+    if (!std::strcmp(key, "msm_acc_variant")) c.tune_acc_variant = value;
+    else if (!std::strcmp(key, "msm_task_len")) c.tune_task_len = value;
+    else { set_error("uzk_tune: unknown key %s", key); return UZK_ERR_PARAMETER; }
+    return UZK_OK;
+}
+
 }  // extern "C"

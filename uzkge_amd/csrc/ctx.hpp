@@ -67,6 +67,8 @@ struct Ctx {
     MsmWork* msm = nullptr;
     DevBuf msm_scalars;       // staging for host scalars
     int msm_window_bits = 0;  // 0 = auto
+    int tune_acc_variant = 0; // experiments (uzk_tune)
+    int tune_task_len = 0;
     // SRS registry
     struct Srs {
         Affine* d_points = nullptr;

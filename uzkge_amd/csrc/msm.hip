@@ -204,7 +204,8 @@ __device__ __forceinline__ void find_task(uint32_t tid, const uint32_t* __restri
     j = lt - off[lo];
 }
 
-__global__ __launch_bounds__(256) void msm_accumulate_kernel(const Affine* __restrict__ points,
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void msm_accumulate_kernel(const Affine* __restrict__ points,
                                                              const uint32_t* __restrict__ sorted,
                                                              const uint32_t* __restrict__ bucket_start,
                                                              const uint32_t* __restrict__ bucket_count,
@@ -216,9 +217,13 @@ __global__ __launch_bounds__(256) void msm_accumulate_kernel(const Affine* __res
     if (tid >= win_base[W]) return;
     uint32_t w, b, j;
     find_task(tid, win_base, W, task_off, NB, w, b, j);
+    // balanced split: the bucket's T = ceil(total / L) tasks get floor(total/T) or +1 points each,
+    // so lanes of one wave (consecutive tasks) run the same trip count to within one point
     const uint32_t total = bucket_count[(size_t)w * NB + b];
-    const uint32_t first = j * L;
-    const uint32_t cnt = min(L, total - first);
+    const uint32_t T = (total + L - 1) / L;
+    const uint32_t q = total / T, r = total - q * T;
+    const uint32_t first = j * q + min(j, r);
+    const uint32_t cnt = q + (j < r ? 1u : 0u);
     const uint32_t* run = sorted + (size_t)w * n + bucket_start[(size_t)w * NB + b] + first;
     XYZZ acc = xyzz_inf();
     uint32_t e = run[0];
@@ -361,7 +366,8 @@ int msm_run(Ctx& c, const Affine* d_points, const Fp* d_scalars, size_t n, Jac* 
     nch = (n32 + chunk_size - 1) / chunk_size;
     const uint32_t groups = (nbk + kSeg * 256 - 1) / (kSeg * 256);
     const uint64_t entries = (uint64_t)W * n;
-    const uint32_t L = (uint32_t)std::max<uint64_t>(16, std::min<uint64_t>(128, entries >> 20));
+    const uint32_t L = c.tune_task_len > 0 ? (uint32_t)c.tune_task_len
+                                           : (uint32_t)std::max<uint64_t>(16, std::min<uint64_t>(64, entries >> 21));
     const uint32_t G = kCombineFan;
     const uint64_t bound0 = entries / L + (uint64_t)W * nbk;          // upper bound on level-0 tasks
     const uint64_t part_cap = bound0 + 2ull * W * nbk;               // every later level fits too
@@ -444,8 +450,13 @@ int msm_run(Ctx& c, const Affine* d_points, const Fp* d_scalars, size_t n, Jac* 
     }
     {
         KernelScope ks(c, "msm_accumulate");
-        hipLaunchKernelGGL(msm_accumulate_kernel, dim3((unsigned)((bound0 + 255) / 256)), dim3(256), 0, st, d_points,
-                           sorted, bstart, bcount, off_cur, base_cur, part_cur, n32, NB, W, L);
+        const dim3 grid((unsigned)((bound0 + 255) / 256));
+        if (c.tune_acc_variant == 1)
+            hipLaunchKernelGGL(msm_accumulate_kernel<4>, grid, dim3(256), 0, st, d_points, sorted, bstart, bcount,
+                               off_cur, base_cur, part_cur, n32, NB, W, L);
+        else
+            hipLaunchKernelGGL(msm_accumulate_kernel<1>, grid, dim3(256), 0, st, d_points, sorted, bstart, bcount,
+                               off_cur, base_cur, part_cur, n32, NB, W, L);
     }
     UZK_HIP(hipGetLastError());
     // the largest bucket decides how many fold levels are needed (one tiny read-back)
