@@ -28,12 +28,12 @@
 
 namespace uzk {
 
-constexpr int kMsmThreads = 1024;   // hist / scatter workgroups
 constexpr int kSeg = 16;            // buckets per lane in the reduction
 constexpr uint32_t kSignBit = 0x80000000u;
 
 struct MsmWork {
     DevBuf digits, chunk_hist, bucket_count, bucket_start, sorted, buckets, partials;
+    DevBuf part_a, seg_a_start, seg_a_len, counts_b;   // two-pass sort
     DevBuf lvl_cnt[2], lvl_off[2], lvl_part[2], small;   // task levels; small = win totals/bases/max
     XYZZ* h_partials = nullptr;   // pinned
     size_t h_partials_cap = 0;
@@ -68,45 +68,177 @@ __global__ __launch_bounds__(256) void msm_digits_kernel(const Fp* __restrict__ 
     }
 }
 
-// ---- 2. histogram -----------------------------------------------------------------------------
-// grid (numChunks, W); dynamic LDS: NB counters
-__global__ __launch_bounds__(kMsmThreads) void msm_hist_kernel(const uint32_t* __restrict__ digits,
-                                                               uint32_t* __restrict__ chunk_hist, uint32_t n,
-                                                               uint32_t chunk_size, uint32_t NB) {
-    extern __shared__ uint32_t lds_hist[];
-    const uint32_t ch = blockIdx.x, w = blockIdx.y, nch = gridDim.x;
-    for (uint32_t b = threadIdx.x; b < NB; b += blockDim.x) lds_hist[b] = 0;
-    __syncthreads();
-    const uint32_t lo = ch * chunk_size, hi = min(n, lo + chunk_size);
-    const uint32_t* dw = digits + (size_t)w * n;
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) atomicAdd(&lds_hist[dw[i] & ~kSignBit], 1u);
-    __syncthreads();
-    uint32_t* dst = chunk_hist + ((size_t)w * nch + ch) * NB;
-    for (uint32_t b = threadIdx.x; b < NB; b += blockDim.x) dst[b] = lds_hist[b];
+// ---- 2-4. counting sort of (window, bucket) --------------------------------------------------
+// Bucket index bi = |digit| - 1 in [0, 2^(c-1)); zero digits are dropped.  Up to 9 low bits are
+// sorted per pass: c <= 10 needs one pass straight from the digits; larger c first partitions on
+// the high bits (pass A, 8-byte {key, index|sign} entries) and then sorts each partition on the
+// low bits (pass B, 4-byte output).  Both passes are the same three kernels: per-(segment, chunk)
+// histogram in LDS, a per-segment scan, and a scatter that counting-sorts one tile of entries in
+// LDS first, so that every global store run is contiguous (tens of entries per bin and tile)
+// instead of one 4-byte store per entry.
+struct RadixArgs {
+    const uint32_t* digits;      // FROM_DIGITS: [W][n]
+    const uint2* in_entries;     // else: {key, val}
+    const uint32_t* seg_start;   // else: absolute start / length of each input segment
+    const uint32_t* seg_len;
+    uint32_t n;                  // FROM_DIGITS: entries per segment (= points)
+    uint32_t shift, mask, bins;  // bin = (key >> shift) & mask
+    uint32_t* counts;            // [seg][chunk][bins]  (hist: counts, after scan: exclusive chunk prefixes)
+    uint32_t* bin_base;          // [seg][bins] absolute output start of each bin
+    uint32_t* bin_count;         // [seg][bins]
+    uint2* out_entries;          // !OUT_VAL
+    uint32_t* out_vals;          // OUT_VAL
+};
+
+template <bool FROM_DIGITS>
+__device__ __forceinline__ void radix_chunk_bounds(const RadixArgs& a, uint32_t seg, uint32_t ch, uint32_t nch,
+                                                   uint32_t& base, uint32_t& lo, uint32_t& hi) {
+    uint32_t len;
+    if constexpr (FROM_DIGITS) { base = 0; len = a.n; }
+    else { base = a.seg_start[seg]; len = a.seg_len[seg]; }
+    const uint32_t cs = (len + nch - 1) / nch;
+    lo = min(len, ch * cs);
+    hi = min(len, lo + cs);
+}
+template <bool FROM_DIGITS>
+__device__ __forceinline__ bool radix_load(const RadixArgs& a, uint32_t seg, uint32_t base, uint32_t k, uint32_t& key,
+                                           uint32_t& val) {
+    if constexpr (FROM_DIGITS) {
+        const uint32_t d = a.digits[(size_t)seg * a.n + k];
+        const uint32_t mag = d & ~kSignBit;
+        key = mag - 1;
+        val = k | (d & kSignBit);
+        return mag != 0;
+    } else {
+        const uint2 e = a.in_entries[(size_t)base + k];
+        key = e.x;
+        val = e.y;
+        return true;
+    }
 }
 
-// ---- 3. scans -----------------------------------------------------------------------------------
-// lane per (w, b): turn per-chunk counts into exclusive per-chunk prefixes, emit bucket total
-__global__ __launch_bounds__(256) void msm_scan_chunks_kernel(uint32_t* __restrict__ chunk_hist,
-                                                              uint32_t* __restrict__ bucket_count, uint32_t NB,
-                                                              uint32_t nch, uint32_t W) {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (size_t)W * NB) return;
-    const uint32_t w = (uint32_t)(t / NB), b = (uint32_t)(t % NB);
-    uint32_t run = 0;
-    for (uint32_t ch = 0; ch < nch; ++ch) {
-        uint32_t* p = chunk_hist + ((size_t)w * nch + ch) * NB + b;
-        uint32_t v = *p;
-        *p = run;
-        run += v;
+// grid (nch, nseg)
+template <bool FROM_DIGITS>
+__global__ __launch_bounds__(1024) void msm_radix_hist_kernel(RadixArgs a) {
+    __shared__ uint32_t cnt[512];
+    const uint32_t ch = blockIdx.x, seg = blockIdx.y, nch = gridDim.x;
+    for (uint32_t b = threadIdx.x; b < a.bins; b += blockDim.x) cnt[b] = 0;
+    __syncthreads();
+    uint32_t base, lo, hi;
+    radix_chunk_bounds<FROM_DIGITS>(a, seg, ch, nch, base, lo, hi);
+    for (uint32_t k = lo + threadIdx.x; k < hi; k += blockDim.x) {
+        uint32_t key, val;
+        if (radix_load<FROM_DIGITS>(a, seg, base, k, key, val)) atomicAdd(&cnt[(key >> a.shift) & a.mask], 1u);
     }
-    bucket_count[t] = run;
+    __syncthreads();
+    uint32_t* dst = a.counts + ((size_t)seg * nch + ch) * a.bins;
+    for (uint32_t b = threadIdx.x; b < a.bins; b += blockDim.x) dst[b] = cnt[b];
 }
-// One workgroup per window: v[b] = div ? ceil(cnt[b] / div) : cnt[b] (v[0] = 0 when skip0);
-// writes v (optional), the exclusive prefix of v within the window, the window total, and
-// folds max(cnt[b >= 1]) into *max_out (optional).
+
+// grid (nseg), block 512: chunk prefixes per bin, bin totals, exclusive scan over bins.
+// out_start: absolute output start of the segment = out_start_of[seg] (or seg * stride when null).
+__global__ __launch_bounds__(512) void msm_radix_scan_kernel(RadixArgs a, uint32_t nch, const uint32_t* __restrict__ out_start_of,
+                                                             uint32_t out_stride) {
+    __shared__ uint32_t tot[512];
+    __shared__ uint32_t wsum[8];
+    const uint32_t seg = blockIdx.x, b = threadIdx.x;
+    uint32_t run = 0;
+    if (b < a.bins) {
+        for (uint32_t ch = 0; ch < nch; ++ch) {
+            uint32_t* p = a.counts + ((size_t)seg * nch + ch) * a.bins + b;
+            const uint32_t v = *p;
+            *p = run;
+            run += v;
+        }
+    }
+    // exclusive scan of `run` over the 512 lanes: wave scan + wave totals
+    uint32_t incl = run;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up((int)incl, o);
+        if ((int)(b & 63) >= o) incl += t;
+    }
+    if ((b & 63) == 63) wsum[b >> 6] = incl;
+    __syncthreads();
+    uint32_t pre = 0;
+    for (uint32_t w = 0; w < (b >> 6); ++w) pre += wsum[w];
+    const uint32_t excl = pre + incl - run;
+    (void)tot;
+    if (b < a.bins) {
+        const uint32_t start = out_start_of ? out_start_of[seg] : seg * out_stride;
+        a.bin_base[(size_t)seg * a.bins + b] = start + excl;
+        a.bin_count[(size_t)seg * a.bins + b] = run;
+    }
+}
+
+// grid (nch, nseg), block TB, tile = TB * E entries sorted in LDS before they are written out
+template <int TB, int E, bool FROM_DIGITS, bool OUT_VAL>
+__global__ __launch_bounds__(TB) void msm_radix_scatter_kernel(RadixArgs a) {
+    constexpr int TILE = TB * E;
+    __shared__ uint2 buf[TILE];
+    __shared__ uint32_t tcnt[512], toff[512], gcur[512], wsum[16];
+    const uint32_t ch = blockIdx.x, seg = blockIdx.y, nch = gridDim.x, tid = threadIdx.x;
+    uint32_t base, lo, hi;
+    radix_chunk_bounds<FROM_DIGITS>(a, seg, ch, nch, base, lo, hi);
+    const uint32_t* coff = a.counts + ((size_t)seg * nch + ch) * a.bins;
+    for (uint32_t b = tid; b < a.bins; b += TB) gcur[b] = a.bin_base[(size_t)seg * a.bins + b] + coff[b];
+    for (uint32_t t0 = lo; t0 < hi; t0 += TILE) {
+        for (uint32_t b = tid; b < a.bins; b += TB) tcnt[b] = 0;
+        __syncthreads();
+        uint32_t key[E], val[E], rank[E];
+        bool ok[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const uint32_t k = t0 + tid + e * TB;
+            ok[e] = (k < hi) && radix_load<FROM_DIGITS>(a, seg, base, k, key[e], val[e]);
+            if (ok[e]) rank[e] = atomicAdd(&tcnt[(key[e] >> a.shift) & a.mask], 1u);
+        }
+        __syncthreads();
+        // exclusive scan of tcnt[0..bins) -> toff: each wave scans whole 64-bin groups (any TB >= 64)
+        {
+            const uint32_t ngroups = (a.bins + 63) / 64, lane = tid & 63;
+            for (uint32_t g = tid >> 6; g < ngroups; g += TB / 64) {
+                const uint32_t b = g * 64 + lane;
+                const uint32_t v = (b < a.bins) ? tcnt[b] : 0;
+                uint32_t incl = v;
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t t = __shfl_up((int)incl, o);
+                    if ((int)lane >= o) incl += t;
+                }
+                if (b < a.bins) toff[b] = incl - v;
+                if (lane == 63) wsum[g] = incl;
+            }
+            __syncthreads();
+            for (uint32_t b = tid; b < a.bins; b += TB) {
+                uint32_t pre = 0;
+                for (uint32_t g = 0; g < (b >> 6); ++g) pre += wsum[g];
+                toff[b] += pre;
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if (ok[e]) buf[toff[(key[e] >> a.shift) & a.mask] + rank[e]] = make_uint2(key[e], val[e]);
+        }
+        __syncthreads();
+        const uint32_t last = a.bins - 1;
+        const uint32_t total = toff[last] + tcnt[last];
+        for (uint32_t k = tid; k < total; k += TB) {
+            const uint2 en = buf[k];
+            const uint32_t bin = (en.x >> a.shift) & a.mask;
+            const uint32_t pos = gcur[bin] + (k - toff[bin]);
+            if constexpr (OUT_VAL) a.out_vals[pos] = en.y;
+            else a.out_entries[pos] = en;
+        }
+        __syncthreads();
+        for (uint32_t b = tid; b < a.bins; b += TB) gcur[b] += tcnt[b];
+        __syncthreads();
+    }
+}
+
+// One workgroup per window: v[b] = div ? ceil(cnt[b] / div) : cnt[b]; writes v (optional), the
+// exclusive prefix of v within the window, the window total, and folds max(cnt) into *max_out.
 __global__ __launch_bounds__(1024) void msm_scan_win_kernel(const uint32_t* __restrict__ cnt_in, uint32_t div,
-                                                            int skip0, uint32_t* __restrict__ v_out,
+                                                            uint32_t* __restrict__ v_out,
                                                             uint32_t* __restrict__ off_out,
                                                             uint32_t* __restrict__ win_total,
                                                             uint32_t* __restrict__ max_out, uint32_t NB) {
@@ -116,14 +248,13 @@ __global__ __launch_bounds__(1024) void msm_scan_win_kernel(const uint32_t* __re
     const uint32_t lo = min(NB, tid * per), hi = min(NB, lo + per);
     const uint32_t* cnt = cnt_in + (size_t)w * NB;
     auto val = [&](uint32_t b) -> uint32_t {
-        if (skip0 && b == 0) return 0u;
         const uint32_t c = cnt[b];
         return div ? (c + div - 1) / div : c;
     };
     uint32_t s = 0, mx = 0;
     for (uint32_t b = lo; b < hi; ++b) {
         s += val(b);
-        if (b != 0) mx = max(mx, cnt[b]);
+        mx = max(mx, cnt[b]);
     }
     part[tid] = s;
     __syncthreads();
@@ -154,30 +285,6 @@ __global__ void msm_win_base_kernel(const uint32_t* __restrict__ win_total, uint
         uint32_t run = 0;
         for (uint32_t w = 0; w < W; ++w) { win_base[w] = run; run += win_total[w]; }
         win_base[W] = run;
-    }
-}
-
-// ---- 4. scatter ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(kMsmThreads) void msm_scatter_kernel(const uint32_t* __restrict__ digits,
-                                                                  const uint32_t* __restrict__ chunk_off,
-                                                                  const uint32_t* __restrict__ bucket_start,
-                                                                  uint32_t* __restrict__ sorted, uint32_t n,
-                                                                  uint32_t chunk_size, uint32_t NB) {
-    extern __shared__ uint32_t lds_cur[];
-    const uint32_t ch = blockIdx.x, w = blockIdx.y, nch = gridDim.x;
-    const uint32_t* off = chunk_off + ((size_t)w * nch + ch) * NB;
-    const uint32_t* st = bucket_start + (size_t)w * NB;
-    for (uint32_t b = threadIdx.x; b < NB; b += blockDim.x) lds_cur[b] = st[b] + off[b];
-    __syncthreads();
-    const uint32_t lo = ch * chunk_size, hi = min(n, lo + chunk_size);
-    const uint32_t* dw = digits + (size_t)w * n;
-    uint32_t* sw = sorted + (size_t)w * n;
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const uint32_t d = dw[i], mag = d & ~kSignBit;
-        if (mag != 0) {
-            const uint32_t pos = atomicAdd(&lds_cur[mag], 1u);
-            sw[pos] = i | (d & kSignBit);
-        }
     }
 }
 
@@ -224,7 +331,7 @@ __global__ __launch_bounds__(256, MINW) void msm_accumulate_kernel(const Affine*
     const uint32_t q = total / T, r = total - q * T;
     const uint32_t first = j * q + min(j, r);
     const uint32_t cnt = q + (j < r ? 1u : 0u);
-    const uint32_t* run = sorted + (size_t)w * n + bucket_start[(size_t)w * NB + b] + first;
+    const uint32_t* run = sorted + bucket_start[(size_t)w * NB + b] + first;   // absolute start
     XYZZ acc = xyzz_inf();
     uint32_t e = run[0];
     Affine p = load_point(points, e & ~kSignBit);
@@ -266,13 +373,12 @@ __global__ __launch_bounds__(256) void msm_finalize_kernel(const XYZZ* __restric
                                                            const uint32_t* __restrict__ in_base,
                                                            XYZZ* __restrict__ buckets, uint32_t NB, uint32_t W) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t nbk = NB - 1;
-    if (t >= (size_t)W * nbk) return;
-    const uint32_t w = (uint32_t)(t / nbk), b = (uint32_t)(t % nbk) + 1;
-    const uint32_t cnt = in_cnt[(size_t)w * NB + b];
+    if (t >= (size_t)W * NB) return;
+    const uint32_t w = (uint32_t)(t / NB);
+    const uint32_t cnt = in_cnt[t];
     XYZZ acc = xyzz_inf();
     if (cnt > 0) {
-        const XYZZ* src = in + in_base[w] + in_off[(size_t)w * NB + b];
+        const XYZZ* src = in + in_base[w] + in_off[t];
         acc = src[0];
         for (uint32_t k = 1; k < cnt; ++k) { XYZZ q = src[k]; xyzz_add(acc, q); }
     }
@@ -339,6 +445,7 @@ void msm_free(Ctx& c) {
     MsmWork* m = c.msm;
     m->digits.release(); m->chunk_hist.release(); m->bucket_count.release(); m->bucket_start.release();
     m->sorted.release(); m->buckets.release(); m->partials.release(); m->small.release();
+    m->part_a.release(); m->seg_a_start.release(); m->seg_a_len.release(); m->counts_b.release();
     for (int k = 0; k < 2; ++k) { m->lvl_cnt[k].release(); m->lvl_off[k].release(); m->lvl_part[k].release(); }
     if (m->h_partials) (void)hipHostFree(m->h_partials);
     if (m->h_max) (void)hipHostFree(m->h_max);
@@ -346,10 +453,6 @@ void msm_free(Ctx& c) {
     c.msm = nullptr;
 }
 
-static int set_dyn_lds(const void* fn, size_t bytes) {
-    UZK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    return UZK_OK;
-}
 
 int msm_run(Ctx& c, const Affine* d_points, const Fp* d_scalars, size_t n, Jac* out_host) {
     if (n == 0) { *out_host = jac_inf(); return UZK_OK; }
@@ -358,27 +461,38 @@ int msm_run(Ctx& c, const Affine* d_points, const Fp* d_scalars, size_t n, Jac* 
     MsmWork& m = *c.msm;
     const int cb = choose_window_bits(n, c.msm_window_bits);
     const uint32_t W = (uint32_t)msm_num_windows(cb);
-    const uint32_t NB = (1u << (cb - 1)) + 1, nbk = NB - 1;
+    const uint32_t NB = 1u << (cb - 1);            // buckets per window, dense index = |digit| - 1
     const uint32_t n32 = (uint32_t)n;
-    if ((uint64_t)W * n >= (1ull << 32)) { set_error("msm: W*n overflows the 32-bit task space"); return UZK_ERR_PARAMETER; }
-    uint32_t nch = (uint32_t)std::min<size_t>(32, (n + 8191) / 8192);
-    const uint32_t chunk_size = (n32 + nch - 1) / nch;
-    nch = (n32 + chunk_size - 1) / chunk_size;
-    const uint32_t groups = (nbk + kSeg * 256 - 1) / (kSeg * 256);
+    if ((uint64_t)W * n >= (1ull << 32)) { set_error("msm: W*n overflows the 32-bit index space"); return UZK_ERR_PARAMETER; }
+    const uint32_t groups = (NB + kSeg * 256 - 1) / (kSeg * 256);
     const uint64_t entries = (uint64_t)W * n;
     const uint32_t L = c.tune_task_len > 0 ? (uint32_t)c.tune_task_len
                                            : (uint32_t)std::max<uint64_t>(16, std::min<uint64_t>(64, entries >> 21));
     const uint32_t G = kCombineFan;
-    const uint64_t bound0 = entries / L + (uint64_t)W * nbk;          // upper bound on level-0 tasks
-    const uint64_t part_cap = bound0 + 2ull * W * nbk;               // every later level fits too
+    const uint64_t bound0 = entries / L + (uint64_t)W * NB;           // upper bound on level-0 tasks
+    const uint64_t part_cap = bound0 + 2ull * W * NB;                 // every later level fits too
+    // radix plan
+    const uint32_t kb = (uint32_t)cb - 1;
+    const uint32_t lb = std::min<uint32_t>(kb, 9), hb = kb - lb;
+    const uint32_t bins_a = 1u << hb, bins_b = 1u << lb;
+    const uint32_t nch_a = (uint32_t)std::max<size_t>(1, std::min<size_t>(32, n / 8192));
+    const uint32_t nseg_b = W * bins_a;
+    const uint32_t nch_b = hb == 0 ? nch_a
+                                   : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(8, (n / bins_a) / 16384));
 
     UZK_TRY(m.digits.reserve((size_t)W * n * 4));
     UZK_TRY(m.sorted.reserve((size_t)W * n * 4));
-    UZK_TRY(m.chunk_hist.reserve((size_t)W * nch * NB * 4));
+    UZK_TRY(m.chunk_hist.reserve((size_t)W * nch_a * std::max(bins_a, bins_b) * 4));
     UZK_TRY(m.bucket_count.reserve((size_t)W * NB * 4));
     UZK_TRY(m.bucket_start.reserve((size_t)W * NB * 4));
-    UZK_TRY(m.buckets.reserve((size_t)W * nbk * sizeof(XYZZ)));
+    UZK_TRY(m.buckets.reserve((size_t)W * NB * sizeof(XYZZ)));
     UZK_TRY(m.partials.reserve((size_t)W * groups * sizeof(XYZZ)));
+    if (hb > 0) {
+        UZK_TRY(m.part_a.reserve((size_t)W * n * sizeof(uint2)));
+        UZK_TRY(m.seg_a_start.reserve((size_t)nseg_b * 4));
+        UZK_TRY(m.seg_a_len.reserve((size_t)nseg_b * 4));
+        UZK_TRY(m.counts_b.reserve((size_t)nseg_b * nch_b * bins_b * 4));
+    }
     for (int k = 0; k < 2; ++k) {
         UZK_TRY(m.lvl_cnt[k].reserve((size_t)W * NB * 4));
         UZK_TRY(m.lvl_off[k].reserve((size_t)W * NB * 4));
@@ -392,13 +506,9 @@ int msm_run(Ctx& c, const Affine* d_points, const Fp* d_scalars, size_t n, Jac* 
         m.h_partials_cap = np;
     }
     if (!m.h_max) UZK_HIP(hipHostMalloc(reinterpret_cast<void**>(&m.h_max), 64, hipHostMallocDefault));
-    const size_t lds_bytes = (size_t)NB * 4;
-    UZK_TRY(set_dyn_lds(reinterpret_cast<const void*>(msm_hist_kernel), lds_bytes));
-    UZK_TRY(set_dyn_lds(reinterpret_cast<const void*>(msm_scatter_kernel), lds_bytes));
 
     uint32_t* digits = m.digits.as<uint32_t>();
     uint32_t* sorted = m.sorted.as<uint32_t>();
-    uint32_t* chunk_hist = m.chunk_hist.as<uint32_t>();
     uint32_t* bcount = m.bucket_count.as<uint32_t>();
     uint32_t* bstart = m.bucket_start.as<uint32_t>();
     XYZZ* buckets = m.buckets.as<XYZZ>();
@@ -415,27 +525,61 @@ int msm_run(Ctx& c, const Affine* d_points, const Fp* d_scalars, size_t n, Jac* 
         KernelScope ks(c, "msm_digits");
         hipLaunchKernelGGL(msm_digits_kernel, dim3((n32 + 255) / 256), dim3(256), 0, st, d_scalars, digits, n32, cb, (int)W);
     }
-    {
-        KernelScope ks(c, "msm_hist");
-        hipLaunchKernelGGL(msm_hist_kernel, dim3(nch, W), dim3(kMsmThreads), lds_bytes, st, digits, chunk_hist, n32,
-                           chunk_size, NB);
-    }
-    {
-        KernelScope ks(c, "msm_scan_chunks");
-        const size_t tot = (size_t)W * NB;
-        hipLaunchKernelGGL(msm_scan_chunks_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, chunk_hist,
-                           bcount, NB, nch, W);
-    }
-    {
-        KernelScope ks(c, "msm_scan_win");
-        hipLaunchKernelGGL(msm_scan_win_kernel, dim3(W), dim3(1024), 0, st, bcount, 0u, 0, (uint32_t*)nullptr, bstart,
-                           win_tot, d_max, NB);
-    }
-    UZK_HIP(hipMemcpyAsync(m.h_max, d_max, 4, hipMemcpyDeviceToHost, st));
-    {
-        KernelScope ks(c, "msm_scatter");
-        hipLaunchKernelGGL(msm_scatter_kernel, dim3(nch, W), dim3(kMsmThreads), lds_bytes, st, digits, chunk_hist,
-                           bstart, sorted, n32, chunk_size, NB);
+    // ---- counting sort of (window, bucket): pass A on the high bits (if any), pass B on the low bits
+    RadixArgs ra{};
+    ra.digits = digits;
+    ra.n = n32;
+    ra.counts = m.chunk_hist.as<uint32_t>();
+    if (hb == 0) {
+        ra.shift = 0; ra.mask = bins_b - 1; ra.bins = bins_b;
+        ra.bin_base = bstart; ra.bin_count = bcount; ra.out_vals = sorted;
+        {
+            KernelScope ks(c, "msm_sort_hist");
+            hipLaunchKernelGGL(msm_radix_hist_kernel<true>, dim3(nch_a, W), dim3(1024), 0, st, ra);
+        }
+        {
+            KernelScope ks(c, "msm_sort_scan");
+            hipLaunchKernelGGL(msm_radix_scan_kernel, dim3(W), dim3(512), 0, st, ra, nch_a, (const uint32_t*)nullptr, n32);
+        }
+        {
+            KernelScope ks(c, "msm_sort_scatter");
+            hipLaunchKernelGGL((msm_radix_scatter_kernel<1024, 8, true, true>), dim3(nch_a, W), dim3(1024), 0, st, ra);
+        }
+    } else {
+        ra.shift = lb; ra.mask = bins_a - 1; ra.bins = bins_a;
+        ra.bin_base = m.seg_a_start.as<uint32_t>(); ra.bin_count = m.seg_a_len.as<uint32_t>();
+        ra.out_entries = m.part_a.as<uint2>();
+        {
+            KernelScope ks(c, "msm_sort_hist");
+            hipLaunchKernelGGL(msm_radix_hist_kernel<true>, dim3(nch_a, W), dim3(1024), 0, st, ra);
+        }
+        {
+            KernelScope ks(c, "msm_sort_scan");
+            hipLaunchKernelGGL(msm_radix_scan_kernel, dim3(W), dim3(512), 0, st, ra, nch_a, (const uint32_t*)nullptr, n32);
+        }
+        {
+            KernelScope ks(c, "msm_sort_scatter_a");
+            hipLaunchKernelGGL((msm_radix_scatter_kernel<1024, 8, true, false>), dim3(nch_a, W), dim3(1024), 0, st, ra);
+        }
+        RadixArgs rb{};
+        rb.in_entries = m.part_a.as<uint2>();
+        rb.seg_start = m.seg_a_start.as<uint32_t>();
+        rb.seg_len = m.seg_a_len.as<uint32_t>();
+        rb.shift = 0; rb.mask = bins_b - 1; rb.bins = bins_b;
+        rb.counts = m.counts_b.as<uint32_t>();
+        rb.bin_base = bstart; rb.bin_count = bcount; rb.out_vals = sorted;
+        {
+            KernelScope ks(c, "msm_sort_hist");
+            hipLaunchKernelGGL(msm_radix_hist_kernel<false>, dim3(nch_b, nseg_b), dim3(256), 0, st, rb);
+        }
+        {
+            KernelScope ks(c, "msm_sort_scan");
+            hipLaunchKernelGGL(msm_radix_scan_kernel, dim3(nseg_b), dim3(512), 0, st, rb, nch_b, rb.seg_start, 0u);
+        }
+        {
+            KernelScope ks(c, "msm_sort_scatter_b");
+            hipLaunchKernelGGL((msm_radix_scatter_kernel<256, 16, false, true>), dim3(nch_b, nseg_b), dim3(256), 0, st, rb);
+        }
     }
     // level-0 tasks (runs of <= L indices)
     uint32_t* cnt_cur = m.lvl_cnt[0].as<uint32_t>();
@@ -444,8 +588,8 @@ int msm_run(Ctx& c, const Affine* d_points, const Fp* d_scalars, size_t n, Jac* 
     XYZZ* part_cur = m.lvl_part[0].as<XYZZ>();
     {
         KernelScope ks(c, "msm_scan_win");
-        hipLaunchKernelGGL(msm_scan_win_kernel, dim3(W), dim3(1024), 0, st, bcount, L, 1, cnt_cur, off_cur, win_tot,
-                           (uint32_t*)nullptr, NB);
+        hipLaunchKernelGGL(msm_scan_win_kernel, dim3(W), dim3(1024), 0, st, bcount, L, cnt_cur, off_cur, win_tot,
+                           d_max, NB);
         hipLaunchKernelGGL(msm_win_base_kernel, dim3(1), dim3(64), 0, st, win_tot, base_cur, W);
     }
     {
@@ -460,6 +604,7 @@ int msm_run(Ctx& c, const Affine* d_points, const Fp* d_scalars, size_t n, Jac* 
     }
     UZK_HIP(hipGetLastError());
     // the largest bucket decides how many fold levels are needed (one tiny read-back)
+    UZK_HIP(hipMemcpyAsync(m.h_max, d_max, 4, hipMemcpyDeviceToHost, st));
     UZK_HIP(hipStreamSynchronize(st));
     uint64_t tmax = ((uint64_t)m.h_max[0] + L - 1) / L;
     int lvl = 0;
@@ -470,11 +615,11 @@ int msm_run(Ctx& c, const Affine* d_points, const Fp* d_scalars, size_t n, Jac* 
         uint32_t* cnt_nx = m.lvl_cnt[nx].as<uint32_t>();
         uint32_t* off_nx = m.lvl_off[nx].as<uint32_t>();
         uint32_t* base_nx = win_base[nx];
-        const uint64_t bound_nx = bound_prev / G + (uint64_t)W * nbk;
+        const uint64_t bound_nx = bound_prev / G + (uint64_t)W * NB;
         XYZZ* part_nx = m.lvl_part[nx].as<XYZZ>();
         {
             KernelScope ks(c, "msm_scan_win");
-            hipLaunchKernelGGL(msm_scan_win_kernel, dim3(W), dim3(1024), 0, st, cnt_cur, G, 1, cnt_nx, off_nx, win_tot,
+            hipLaunchKernelGGL(msm_scan_win_kernel, dim3(W), dim3(1024), 0, st, cnt_cur, G, cnt_nx, off_nx, win_tot,
                                (uint32_t*)nullptr, NB);
             hipLaunchKernelGGL(msm_win_base_kernel, dim3(1), dim3(64), 0, st, win_tot, base_nx, W);
         }
@@ -490,13 +635,13 @@ int msm_run(Ctx& c, const Affine* d_points, const Fp* d_scalars, size_t n, Jac* 
     }
     {
         KernelScope ks(c, "msm_finalize");
-        const size_t tot = (size_t)W * nbk;
+        const size_t tot = (size_t)W * NB;
         hipLaunchKernelGGL(msm_finalize_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, part_cur, cnt_cur,
                            off_cur, base_cur, buckets, NB, W);
     }
     {
         KernelScope ks(c, "msm_reduce");
-        hipLaunchKernelGGL(msm_reduce_kernel, dim3(groups, W), dim3(256), 0, st, buckets, partials, nbk, groups);
+        hipLaunchKernelGGL(msm_reduce_kernel, dim3(groups, W), dim3(256), 0, st, buckets, partials, NB, groups);
     }
     UZK_HIP(hipGetLastError());
     UZK_HIP(hipMemcpyAsync(m.h_partials, partials, np * sizeof(XYZZ), hipMemcpyDeviceToHost, st));
