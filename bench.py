@@ -120,9 +120,20 @@ def main() -> None:
     acc_cnt, acc_ms = prof.get("msm_accumulate", (0, 0.0))
     acc_avg_ms = acc_ms / max(acc_cnt, 1)
     achieved = (96.0 * n) / (acc_avg_ms * 1e-3) / 1e9 if acc_cnt else 0.0
+    # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json), valid for
+    # the configuration they were collected on (same kernel, same log_n, default window bits)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pmc = json.load(f)
+        ent = pmc.get("msm_accumulate", {}).get(str(args.log_n))
+        if ent and args.points == "random" and not args.window_bits:
+            traffic = ent["traffic_bytes"]
+    except (OSError, ValueError, KeyError):
+        traffic = None
     roofline = {
         "bound": "hbm", "kernel": "msm_accumulate", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
         "avg_launch_ms": round(acc_avg_ms, 4), "algorithmic_bytes_per_launch": 96 * n,
         "note": "integer-ALU bound (254-bit modular arithmetic on v_mad_u64_u32), not HBM bound; see DESIGN.md",
     }

@@ -390,15 +390,15 @@ __global__ __launch_bounds__(256) void msm_finalize_kernel(const XYZZ* __restric
 //   run_g = sum B_b, acc_g = sum (b - g*kSeg) B_b (running-sum trick), T_g = acc_g + (g*kSeg) run_g.
 // A 256-lane workgroup tree-adds its T_g through LDS and writes one partial.
 __global__ __launch_bounds__(256) void msm_reduce_kernel(const XYZZ* __restrict__ buckets, XYZZ* __restrict__ partials,
-                                                         uint32_t nbk, uint32_t groups_per_window) {
+                                                         uint32_t nbk, uint32_t groups_per_window, uint32_t seg) {
     __shared__ XYZZ sh[256];
     const uint32_t w = blockIdx.y, tid = threadIdx.x;
     const uint32_t g = blockIdx.x * blockDim.x + tid;
     const XYZZ* bw = buckets + (size_t)w * nbk;
     XYZZ run = xyzz_inf(), acc = xyzz_inf();
-    const uint32_t lo = g * kSeg;   // bucket ids lo+1 .. lo+kSeg  (array index = id - 1)
+    const uint32_t lo = g * seg;   // bucket ids lo+1 .. lo+seg  (array index = id - 1)
     if (lo < nbk) {
-        const uint32_t hi = min(nbk, lo + kSeg);
+        const uint32_t hi = min(nbk, lo + seg);
         for (uint32_t idx = hi; idx-- > lo;) {
             XYZZ bk = bw[idx];
             xyzz_add(run, bk);
@@ -464,7 +464,10 @@ int msm_run(Ctx& c, const Affine* d_points, const Fp* d_scalars, size_t n, Jac* 
     const uint32_t NB = 1u << (cb - 1);            // buckets per window, dense index = |digit| - 1
     const uint32_t n32 = (uint32_t)n;
     if ((uint64_t)W * n >= (1ull << 32)) { set_error("msm: W*n overflows the 32-bit index space"); return UZK_ERR_PARAMETER; }
-    const uint32_t groups = (NB + kSeg * 256 - 1) / (kSeg * 256);
+    // reduction geometry: 256 lanes per group, `seg` buckets per lane (short segments when a window has few
+    // buckets, so the dependent chain of full additions stays short for small n)
+    const uint32_t seg = std::max<uint32_t>(1, std::min<uint32_t>(kSeg, NB / 256));
+    const uint32_t groups = (NB + seg * 256 - 1) / (seg * 256);
     const uint64_t entries = (uint64_t)W * n;
     const uint32_t L = c.tune_task_len > 0 ? (uint32_t)c.tune_task_len
                                            : (uint32_t)std::max<uint64_t>(16, std::min<uint64_t>(64, entries >> 21));
@@ -641,7 +644,7 @@ int msm_run(Ctx& c, const Affine* d_points, const Fp* d_scalars, size_t n, Jac* 
     }
     {
         KernelScope ks(c, "msm_reduce");
-        hipLaunchKernelGGL(msm_reduce_kernel, dim3(groups, W), dim3(256), 0, st, buckets, partials, NB, groups);
+        hipLaunchKernelGGL(msm_reduce_kernel, dim3(groups, W), dim3(256), 0, st, buckets, partials, NB, groups, seg);
     }
     UZK_HIP(hipGetLastError());
     UZK_HIP(hipMemcpyAsync(m.h_partials, partials, np * sizeof(XYZZ), hipMemcpyDeviceToHost, st));
