@@ -66,6 +66,11 @@ int uzk_srs_register(const uzk_g1_affine* points, size_t n, uint64_t* handle_out
 /* Adopt points that already live in device memory (no copy; caller keeps them alive). */
 int uzk_srs_register_device(const void* d_points, size_t n, uint64_t* handle_out);
 int uzk_srs_release(uint64_t handle);
+/* Optional, for a static SRS (KZG): build the window table T[j][i] = 2^(c*j) * SRS[i] in HBM
+ * (W * n * 64 bytes, W = ceil(254 / c); c = window_bits or automatic when 0).  Later MSMs on this
+ * handle then use one shared bucket set (larger windows, no per-window reduction, no host
+ * combination).  Results are identical; only speed and memory change. */
+int uzk_srs_precompute(uint64_t handle, int window_bits);
 int uzk_srs_len(uint64_t handle, size_t* n_out);
 
 /* ---- MSM: replaces G1Projective::msm (kzg_poly_commitment.rs:290) ---------------------- */
@@ -136,7 +141,7 @@ void* uzk_stream(void);
 /* Tuning knobs (0 = automatic): MSM window bits. */
 int uzk_msm_set_window_bits(int c);
 /* Experiment switches for A/B measurements in one process (keys: "msm_acc_variant",
- * "msm_task_len"); never needed for correctness. */
+ * "msm_task_len", "msm_no_precompute"); never needed for correctness. */
 int uzk_tune(const char* key, int value);
 
 #ifdef __cplusplus

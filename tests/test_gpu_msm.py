@@ -172,3 +172,34 @@ def test_window_bits_do_not_change_result(gpu, lagrange, c):
         _check(gpu, srs, wire, s)
     finally:
         gpu.set_msm_window_bits(0)
+
+
+# ---- precomputed-window mode (uzk_srs_precompute): same results, one shared bucket set ----------
+@pytest.mark.parametrize("c", [0, 6, 9, 13, 16, 20, 22])
+def test_precomputed_mode_matches_oracle(gpu, c):
+    """c <= 10: one radix pass, 11..19: two, >= 20: three."""
+    wire, _ = load_srs("lagrange-srs-4096.bin")
+    pts = wire.copy()
+    pts[7] = 0                      # an infinity base must stay the identity in every window table
+    srs = gpu.Srs.from_host(pts)
+    try:
+        srs.precompute(c)
+        for n, seed in ((1, 1), (2, 2), (33, 3), (1000, 4), (4096, 5)):
+            s = rand_fr_wire(n, 900 + seed + c)
+            assert affine_of(gpu.msm(srs, s)) == affine_of(oc.msm_pippenger(pts[:n], s, 0, 8)), (c, n)
+        s = rand_fr_wire(100, 77)
+        assert affine_of(gpu.msm(srs, s, offset=1000)) == affine_of(oc.msm_pippenger(pts[1000:1100], s, 0, 2))
+        ints = [0, 1, opy.R - 1, 2, opy.R - 2] * 200
+        sw = oc.fr_from_ints(ints)
+        assert affine_of(gpu.msm(srs, sw)) == affine_of(oc.msm_pippenger(pts[:1000], sw, 0, 4))
+        assert affine_of(gpu.msm(srs, oc.fr_from_ints([0]))) is None
+        # switching the table off gives the same commitment
+        gpu.tune("msm_no_precompute", 1)
+        try:
+            s = rand_fr_wire(4096, 123)
+            a = affine_of(gpu.msm(srs, s))
+        finally:
+            gpu.tune("msm_no_precompute", 0)
+        assert a == affine_of(gpu.msm(srs, s))
+    finally:
+        srs.release()

@@ -91,3 +91,23 @@ def test_skewed_scalars_closed_form(gpu, kind):
         srs.release()
     k = sum(s * (i + 1) for i, s in enumerate(ints)) % opy.R
     assert got == opy.g1_mul(opy.g1_mul(opy.G1_GEN, seed_int), k)
+
+
+@pytest.mark.parametrize("log_n,c", [(16, 0), (20, 0), (20, 22)])
+def test_precomputed_closed_form(gpu, log_n, c):
+    """Window-table mode at size: MSM(P_i = (i+1)Q) == (sum s_i (i+1)) Q."""
+    n = 1 << log_n
+    pts = torch.empty((n, 8), dtype=torch.int64, device="cuda")
+    sc = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    seed_int = 0xABCDEF12345
+    gpu.synth_points_arith(pts.data_ptr(), n, oc.fr_from_ints([seed_int])[0])
+    gpu.synth_scalars(sc.data_ptr(), n, 4242)
+    srs = gpu.Srs.from_device(pts.data_ptr(), n)
+    try:
+        srs.precompute(c)
+        got = affine_of(gpu.msm_device(srs, sc.data_ptr(), n))
+    finally:
+        srs.release()
+    k = weighted_index_sum(_wire(sc))
+    assert got == opy.g1_mul(opy.g1_mul(opy.G1_GEN, seed_int), k)

@@ -17,13 +17,18 @@ pts = torch.empty((n, 8), dtype=torch.int64, device="cuda"); sc = torch.empty((n
 torch.cuda.synchronize()
 b.synth_points_random(pts.data_ptr(), n, 1); b.synth_scalars(sc.data_ptr(), n, 2)
 srs = b.Srs.from_device(pts.data_ptr(), n)
-DEFAULTS = {"msm_acc_variant": 0, "msm_task_len": 0, "window_bits": 0}
+DEFAULTS = {"msm_acc_variant": 0, "msm_task_len": 0, "window_bits": 0, "precompute": -1}
 def apply(v):
     cfg = dict(DEFAULTS)
     for kv in v.split(","):
         if kv and kv != "base":
             k, x = kv.split("="); cfg[k] = int(x)
     b.set_msm_window_bits(cfg.pop("window_bits"))
+    pc = cfg.pop("precompute")
+    if pc >= 0:
+        srs.precompute(pc); b.tune("msm_no_precompute", 0)
+    else:
+        b.tune("msm_no_precompute", 1)
     for k, x in cfg.items(): b.tune(k, x)
 res = {v: [] for v in a.variants}; kern = {v: {} for v in a.variants}
 ref = None

@@ -28,6 +28,7 @@ PROTOTYPES = {
     "uzk_srs_register": (_I, [_P, _SZ, ctypes.POINTER(_U64)]),
     "uzk_srs_register_device": (_I, [_P, _SZ, ctypes.POINTER(_U64)]),
     "uzk_srs_release": (_I, [_U64]),
+    "uzk_srs_precompute": (_I, [_U64, _I]),
     "uzk_srs_len": (_I, [_U64, ctypes.POINTER(_SZ)]),
     "uzk_msm_g1": (_I, [_U64, _SZ, _P, _SZ, _P]),
     "uzk_msm_g1_device": (_I, [_U64, _SZ, _P, _SZ, _P]),

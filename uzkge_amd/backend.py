@@ -54,6 +54,10 @@ class Srs:
         check(lib.uzk_srs_register_device(ctypes.c_void_p(d_ptr), n, ctypes.byref(h)))
         return cls(h.value, n)
 
+    def precompute(self, window_bits: int = 0) -> None:
+        """Build the window table for a static SRS (uzk_srs_precompute)."""
+        check(lib.uzk_srs_precompute(self.handle, window_bits))
+
     def release(self) -> None:
         if self.handle:
             check(lib.uzk_srs_release(self.handle))

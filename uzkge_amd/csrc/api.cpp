@@ -161,7 +161,10 @@ int uzk_shutdown(void) {
     (void)hipStreamSynchronize(c.stream);
     ntt_free_plans(c);
     msm_free(c);
-    for (auto& kv : c.srs) if (kv.second.owned && kv.second.d_points) (void)hipFree(kv.second.d_points);
+    for (auto& kv : c.srs) {
+        if (kv.second.owned && kv.second.d_points) (void)hipFree(kv.second.d_points);
+        if (kv.second.d_table) (void)hipFree(kv.second.d_table);
+    }
     c.srs.clear();
     c.ntt_scratch[0].release(); c.ntt_scratch[1].release(); c.ntt_io.release(); c.msm_scalars.release();
     for (auto& pe : c.prof_pending) { (void)hipEventDestroy(pe.e0); (void)hipEventDestroy(pe.e1); }
@@ -215,11 +218,34 @@ int uzk_srs_release(uint64_t handle) {
     Ctx& c = ctx();
     auto it = c.srs.find(handle);
     if (it == c.srs.end()) { set_error("uzk_srs_release: unknown handle %llu", (unsigned long long)handle); return UZK_ERR_PARAMETER; }
-    if (it->second.owned && it->second.d_points) {
-        (void)hipStreamSynchronize(c.stream);
-        (void)hipFree(it->second.d_points);
-    }
+    (void)hipStreamSynchronize(c.stream);
+    if (it->second.owned && it->second.d_points) (void)hipFree(it->second.d_points);
+    if (it->second.d_table) (void)hipFree(it->second.d_table);
     c.srs.erase(it);
+    return UZK_OK;
+}
+
+int uzk_srs_precompute(uint64_t handle, int window_bits) {
+    API_LOCK;
+    UZK_TRY(require_ready());
+    Ctx& c = ctx();
+    auto it = c.srs.find(handle);
+    if (it == c.srs.end()) { set_error("uzk_srs_precompute: unknown handle"); return UZK_ERR_PARAMETER; }
+    if (window_bits != 0 && (window_bits < 4 || window_bits > 24)) {
+        set_error("uzk_srs_precompute: window bits must be 0 (auto) or 4..24");
+        return UZK_ERR_PARAMETER;
+    }
+    Ctx::Srs& s = it->second;
+    if (s.n == 0) return UZK_OK;
+    const int cb = msm_precompute_window_bits(s.n, window_bits);
+    if (s.d_table && s.pre_c == cb) return UZK_OK;
+    if (s.d_table) { (void)hipStreamSynchronize(c.stream); (void)hipFree(s.d_table); s.d_table = nullptr; s.pre_c = 0; }
+    Affine* table = nullptr;
+    uint32_t W = 0;
+    UZK_TRY(msm_build_table(c, s.d_points, s.n, cb, &table, &W));
+    s.d_table = table;
+    s.pre_c = cb;
+    s.pre_W = W;
     return UZK_OK;
 }
 
@@ -233,7 +259,7 @@ int uzk_srs_len(uint64_t handle, size_t* n_out) {
 }
 
 /* ---- MSM ---------------------------------------------------------------------------------- */
-static int msm_checked(uint64_t srs_handle, size_t offset, size_t n, const Affine** pts) {
+static int msm_checked(uint64_t srs_handle, size_t offset, size_t n, const Ctx::Srs** srs_out) {
     Ctx& c = ctx();
     auto it = c.srs.find(srs_handle);
     if (it == c.srs.end()) { set_error("msm: unknown SRS handle %llu", (unsigned long long)srs_handle); return UZK_ERR_PARAMETER; }
@@ -242,18 +268,25 @@ static int msm_checked(uint64_t srs_handle, size_t offset, size_t n, const Affin
         set_error("msm: offset %zu + n %zu exceeds SRS length %zu", offset, n, it->second.n);
         return UZK_ERR_DEGREE;
     }
-    *pts = it->second.d_points + offset;
+    *srs_out = &it->second;
     return UZK_OK;
+}
+// general mode unless the handle carries a window table
+static int msm_dispatch(const Ctx::Srs& s, size_t offset, const Fp* d_scalars, size_t n, Jac* out) {
+    Ctx& c = ctx();
+    if (s.d_table && !c.tune_no_precompute)
+        return msm_run(c, s.d_table, d_scalars, n, out, s.pre_c, (uint32_t)s.n, (uint32_t)offset);
+    return msm_run(c, s.d_points + offset, d_scalars, n, out, 0, 0, 0);
 }
 
 int uzk_msm_g1_device(uint64_t srs_handle, size_t offset, const void* d_scalars_mont, size_t n, uzk_g1_jac* out) {
     API_LOCK;
     if (!out || (n > 0 && !d_scalars_mont)) { set_error("uzk_msm_g1_device: null pointer"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
-    const Affine* pts = nullptr;
-    UZK_TRY(msm_checked(srs_handle, offset, n, &pts));
+    const Ctx::Srs* srs = nullptr;
+    UZK_TRY(msm_checked(srs_handle, offset, n, &srs));
     Jac r;
-    UZK_TRY(msm_run(ctx(), pts, static_cast<const Fp*>(d_scalars_mont), n, &r));
+    UZK_TRY(msm_dispatch(*srs, offset, static_cast<const Fp*>(d_scalars_mont), n, &r));
     std::memcpy(out, &r, sizeof r);
     return UZK_OK;
 }
@@ -263,13 +296,13 @@ int uzk_msm_g1(uint64_t srs_handle, size_t offset, const uint64_t* scalars_mont,
     if (!out || (n > 0 && !scalars_mont)) { set_error("uzk_msm_g1: null pointer"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
     Ctx& c = ctx();
-    const Affine* pts = nullptr;
-    UZK_TRY(msm_checked(srs_handle, offset, n, &pts));
+    const Ctx::Srs* srs = nullptr;
+    UZK_TRY(msm_checked(srs_handle, offset, n, &srs));
     Jac r = jac_inf();
     if (n > 0) {
         UZK_TRY(c.msm_scalars.reserve(n * sizeof(Fp)));
         UZK_HIP(hipMemcpyAsync(c.msm_scalars.p, scalars_mont, n * sizeof(Fp), hipMemcpyHostToDevice, c.stream));
-        UZK_TRY(msm_run(c, pts, c.msm_scalars.as<Fp>(), n, &r));
+        UZK_TRY(msm_dispatch(*srs, offset, c.msm_scalars.as<Fp>(), n, &r));
     }
     std::memcpy(out, &r, sizeof r);
     return UZK_OK;
@@ -458,6 +491,7 @@ int uzk_tune(const char* key, int value) {
     Ctx& c = ctx();
     if (!std::strcmp(key, "msm_acc_variant")) c.tune_acc_variant = value;
     else if (!std::strcmp(key, "msm_task_len")) c.tune_task_len = value;
+    else if (!std::strcmp(key, "msm_no_precompute")) c.tune_no_precompute = value;
     else { set_error("uzk_tune: unknown key %s", key); return UZK_ERR_PARAMETER; }
     return UZK_OK;
 }

@@ -69,11 +69,16 @@ struct Ctx {
     int msm_window_bits = 0;  // 0 = auto
     int tune_acc_variant = 0; // experiments (uzk_tune)
     int tune_task_len = 0;
+    int tune_no_precompute = 0;
     // SRS registry
     struct Srs {
         Affine* d_points = nullptr;
         size_t n = 0;
         bool owned = false;
+        // optional window table (uzk_srs_precompute): table[j*n + i] = 2^(pre_c*j) * P_i
+        Affine* d_table = nullptr;
+        int pre_c = 0;
+        uint32_t pre_W = 0;
     };
     std::map<uint64_t, Srs> srs;
     uint64_t next_handle = 1;
@@ -98,7 +103,10 @@ struct KernelScope {
 // entry points implemented in the .hip files
 int ntt_run(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse, const Fp* coset_shift_host);
 void ntt_free_plans(Ctx& c);
-int msm_run(Ctx& c, const Affine* d_points, const Fp* d_scalars, size_t n, Jac* out_host);
+int msm_run(Ctx& c, const Affine* points, const Fp* d_scalars, size_t n, Jac* out_host, int pre_c,
+            uint32_t pre_stride, uint32_t pre_off);
+int msm_build_table(Ctx& c, const Affine* d_points, size_t n, int cb, Affine** table_out, uint32_t* W_out);
+int msm_precompute_window_bits(size_t n, int forced);
 void msm_free(Ctx& c);
 int synth_points_arith(Ctx& c, Affine* d_points, size_t n, const Fp& seed_scalar_mont);
 int synth_points_random(Ctx& c, Affine* d_points, size_t n, uint64_t seed);

@@ -6,19 +6,25 @@
 // Pipeline (all on the library stream; see DESIGN.md "MSM"):
 //   1 msm_digits      scalar -> canonical (one Montgomery mul by 1) -> signed c-bit digits
 //                     d_w in [-2^(c-1), 2^(c-1)], stored [window][i] (coalesced both ways)
-//   2 msm_hist        per (chunk, window) workgroup: bucket histogram in LDS (<= 128 KiB)
-//   3 msm_scan_*      bucket totals, per-chunk offsets, per-window exclusive scan
-//   4 msm_scatter     counting-sort scatter: LDS cursors, writes point indices grouped by bucket
-//   5 msm_accumulate  one lane per TASK = a run of <= L sorted indices of one bucket (buckets are
-//                     split so that skewed scalar sets and small n still fill the chip and the
-//                     grid has no long tail): gathers the 64-byte affine point from HBM (next
-//                     point prefetched under the current mixed add), XYZZ accumulator in VGPRs
-//                     -- the dominant kernel
-//   5b msm_combine /  partial sums of one bucket are folded <= 32 at a time (extra levels only
-//      msm_finalize   when one bucket holds more than 32*L points), last level writes buckets
-//   6 msm_reduce      per window sum_b b*B_b: 16-bucket running sums per lane, one short
-//                     double-and-add for the segment weight, LDS tree per workgroup
-//   7 host            fold the <= W*8 partials and combine windows (Horner, c doublings each)
+//   2 msm_sort_*      counting sort of the (window, bucket) keys in 1-3 radix passes of <= 9 bits;
+//                     every pass = LDS histogram per (segment, chunk), per-segment scan, scatter
+//                     that sorts an 8192/4096-entry tile in LDS first so global stores are runs
+//   3 msm_scan_win    bucket populations -> task counts (runs of <= L points) + prefixes
+//   4 msm_accumulate  one lane per TASK: gathers the 64-byte affine point from HBM (next point
+//                     prefetched under the current mixed add), XYZZ accumulator in VGPRs -- the
+//                     dominant kernel; buckets are split so skewed scalar sets and small n still
+//                     fill the chip and the grid has no long tail
+//   5 msm_combine /   partial sums of one bucket are folded <= 32 at a time (extra levels only
+//     msm_finalize    when one bucket holds more than 32*L points), last level writes buckets
+//   6 msm_reduce      sum_b b*B_b: short running sums per lane, double-and-add for the segment
+//                     weight, LDS tree per workgroup; msm_fold_partials adds the group results
+//   7 host            general mode: Horner over the W window sums (c doublings each)
+//
+// Two modes share every kernel:
+//   general      W windows, each its own set of 2^(c-1) buckets (any bases, nothing cached)
+//   precomputed  the SRS handle carries T[j][i] = 2^(c*j) * P_i (uzk_srs_precompute; 288 GB of HBM
+//                make W*n*64 B cheap), so all W*n (point, window) pairs fall into ONE bucket set:
+//                larger c, ~25 % fewer additions, no per-window reduction and no host Horner.
 // No MFMA anywhere: the work is 254-bit modular integer arithmetic on v_mad_u64_u32.
 #include <algorithm>
 #include <cstring>
@@ -28,18 +34,20 @@
 
 namespace uzk {
 
-constexpr int kSeg = 16;            // buckets per lane in the reduction
+constexpr uint32_t kSeg = 16;          // max buckets per lane in the reduction
 constexpr uint32_t kSignBit = 0x80000000u;
+constexpr uint32_t kCombineFan = 32;   // partial sums folded per lane and level
+constexpr int kMaxPasses = 3;
 
 struct MsmWork {
-    DevBuf digits, chunk_hist, bucket_count, bucket_start, sorted, buckets, partials;
-    DevBuf part_a, seg_a_start, seg_a_len, counts_b;   // two-pass sort
-    DevBuf lvl_cnt[2], lvl_off[2], lvl_part[2], small;   // task levels; small = win totals/bases/max
-    XYZZ* h_partials = nullptr;   // pinned
-    size_t h_partials_cap = 0;
-    uint32_t* h_max = nullptr;    // pinned: largest bucket population of the current call
+    DevBuf digits, bucket_count, bucket_start, sorted, buckets, partials, win_sums;
+    DevBuf ent[2];                           // radix ping-pong ({key, val} entries)
+    DevBuf counts[kMaxPasses], segs_start[kMaxPasses], segs_len[kMaxPasses];
+    DevBuf lvl_cnt[2], lvl_off[2], lvl_part[2], small;
+    XYZZ* h_sums = nullptr;                  // pinned
+    size_t h_sums_cap = 0;
+    uint32_t* h_max = nullptr;               // pinned: largest bucket population of the current call
 };
-constexpr uint32_t kCombineFan = 32;   // partial sums folded per lane and level
 
 __host__ __device__ inline int msm_num_windows(int c) {
     int W = (254 + c - 1) / c;
@@ -68,20 +76,18 @@ __global__ __launch_bounds__(256) void msm_digits_kernel(const Fp* __restrict__ 
     }
 }
 
-// ---- 2-4. counting sort of (window, bucket) --------------------------------------------------
-// Bucket index bi = |digit| - 1 in [0, 2^(c-1)); zero digits are dropped.  Up to 9 low bits are
-// sorted per pass: c <= 10 needs one pass straight from the digits; larger c first partitions on
-// the high bits (pass A, 8-byte {key, index|sign} entries) and then sorts each partition on the
-// low bits (pass B, 4-byte output).  Both passes are the same three kernels: per-(segment, chunk)
-// histogram in LDS, a per-segment scan, and a scatter that counting-sorts one tile of entries in
-// LDS first, so that every global store run is contiguous (tens of entries per bin and tile)
-// instead of one 4-byte store per entry.
+// ---- 2. counting sort --------------------------------------------------------------------------
+// Bucket key = |digit| - 1 in [0, 2^(c-1)); zero digits are dropped.  A pass sorts every segment on
+// one bit field of the key.  Pass 0 reads the digit array (FROM_DIGITS), later passes read 8-byte
+// {key, val} entries; the last pass writes only val = point index | sign (OUT_VAL).
 struct RadixArgs {
-    const uint32_t* digits;      // FROM_DIGITS: [W][n]
+    const uint32_t* digits;      // FROM_DIGITS: [nseg][n]
     const uint2* in_entries;     // else: {key, val}
     const uint32_t* seg_start;   // else: absolute start / length of each input segment
     const uint32_t* seg_len;
-    uint32_t n;                  // FROM_DIGITS: entries per segment (= points)
+    uint32_t n;                  // FROM_DIGITS: entries per segment
+    uint32_t remap_cnt;          // FROM_DIGITS, precomputed mode: val = (k / cnt) * stride + off + k % cnt
+    uint32_t remap_stride, remap_off;
     uint32_t shift, mask, bins;  // bin = (key >> shift) & mask
     uint32_t* counts;            // [seg][chunk][bins]  (hist: counts, after scan: exclusive chunk prefixes)
     uint32_t* bin_base;          // [seg][bins] absolute output start of each bin
@@ -107,7 +113,9 @@ __device__ __forceinline__ bool radix_load(const RadixArgs& a, uint32_t seg, uin
         const uint32_t d = a.digits[(size_t)seg * a.n + k];
         const uint32_t mag = d & ~kSignBit;
         key = mag - 1;
-        val = k | (d & kSignBit);
+        uint32_t idx = k;
+        if (a.remap_cnt) idx = (k / a.remap_cnt) * a.remap_stride + a.remap_off + (k % a.remap_cnt);
+        val = idx | (d & kSignBit);
         return mag != 0;
     } else {
         const uint2 e = a.in_entries[(size_t)base + k];
@@ -127,8 +135,12 @@ __global__ __launch_bounds__(1024) void msm_radix_hist_kernel(RadixArgs a) {
     uint32_t base, lo, hi;
     radix_chunk_bounds<FROM_DIGITS>(a, seg, ch, nch, base, lo, hi);
     for (uint32_t k = lo + threadIdx.x; k < hi; k += blockDim.x) {
-        uint32_t key, val;
-        if (radix_load<FROM_DIGITS>(a, seg, base, k, key, val)) atomicAdd(&cnt[(key >> a.shift) & a.mask], 1u);
+        if constexpr (FROM_DIGITS) {
+            const uint32_t mag = a.digits[(size_t)seg * a.n + k] & ~kSignBit;
+            if (mag) atomicAdd(&cnt[((mag - 1) >> a.shift) & a.mask], 1u);
+        } else {
+            atomicAdd(&cnt[(a.in_entries[(size_t)base + k].x >> a.shift) & a.mask], 1u);
+        }
     }
     __syncthreads();
     uint32_t* dst = a.counts + ((size_t)seg * nch + ch) * a.bins;
@@ -136,10 +148,9 @@ __global__ __launch_bounds__(1024) void msm_radix_hist_kernel(RadixArgs a) {
 }
 
 // grid (nseg), block 512: chunk prefixes per bin, bin totals, exclusive scan over bins.
-// out_start: absolute output start of the segment = out_start_of[seg] (or seg * stride when null).
+// Absolute output start of the segment = out_start_of[seg] (or seg * out_stride when null).
 __global__ __launch_bounds__(512) void msm_radix_scan_kernel(RadixArgs a, uint32_t nch, const uint32_t* __restrict__ out_start_of,
                                                              uint32_t out_stride) {
-    __shared__ uint32_t tot[512];
     __shared__ uint32_t wsum[8];
     const uint32_t seg = blockIdx.x, b = threadIdx.x;
     uint32_t run = 0;
@@ -151,7 +162,6 @@ __global__ __launch_bounds__(512) void msm_radix_scan_kernel(RadixArgs a, uint32
             run += v;
         }
     }
-    // exclusive scan of `run` over the 512 lanes: wave scan + wave totals
     uint32_t incl = run;
     for (int o = 1; o < 64; o <<= 1) {
         const uint32_t t = __shfl_up((int)incl, o);
@@ -162,7 +172,6 @@ __global__ __launch_bounds__(512) void msm_radix_scan_kernel(RadixArgs a, uint32
     uint32_t pre = 0;
     for (uint32_t w = 0; w < (b >> 6); ++w) pre += wsum[w];
     const uint32_t excl = pre + incl - run;
-    (void)tot;
     if (b < a.bins) {
         const uint32_t start = out_start_of ? out_start_of[seg] : seg * out_stride;
         a.bin_base[(size_t)seg * a.bins + b] = start + excl;
@@ -235,7 +244,8 @@ __global__ __launch_bounds__(TB) void msm_radix_scatter_kernel(RadixArgs a) {
     }
 }
 
-// One workgroup per window: v[b] = div ? ceil(cnt[b] / div) : cnt[b]; writes v (optional), the
+// ---- 3. task scans -----------------------------------------------------------------------------
+// One workgroup per bucket window: v[b] = div ? ceil(cnt[b] / div) : cnt[b]; writes v (optional), the
 // exclusive prefix of v within the window, the window total, and folds max(cnt) into *max_out.
 __global__ __launch_bounds__(1024) void msm_scan_win_kernel(const uint32_t* __restrict__ cnt_in, uint32_t div,
                                                             uint32_t* __restrict__ v_out,
@@ -279,30 +289,43 @@ __global__ __launch_bounds__(1024) void msm_scan_win_kernel(const uint32_t* __re
         if ((tid & 63) == 0 && mx) atomicMax(max_out, mx);
     }
 }
-// win_base[w] = sum of win_total[0..w), win_base[W] = grand total
-__global__ void msm_win_base_kernel(const uint32_t* __restrict__ win_total, uint32_t* __restrict__ win_base, uint32_t W) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        uint32_t run = 0;
-        for (uint32_t w = 0; w < W; ++w) { win_base[w] = run; run += win_total[w]; }
-        win_base[W] = run;
+// win_base[w] = sum of win_total[0..w), win_base[W] = grand total   (W <= 1024)
+__global__ __launch_bounds__(1024) void msm_win_base_kernel(const uint32_t* __restrict__ win_total,
+                                                            uint32_t* __restrict__ win_base, uint32_t W) {
+    __shared__ uint32_t part[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t v = tid < W ? win_total[tid] : 0;
+    part[tid] = v;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        uint32_t t = (tid >= off) ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += t;
+        __syncthreads();
     }
+    if (tid < W) win_base[tid] = part[tid] - v;
+    if (tid == 1023) win_base[W] = part[1023];
 }
 
-// ---- 5. bucket accumulation (dominant kernel) -------------------------------------------------
+// ---- 4. bucket accumulation (dominant kernel) -------------------------------------------------
 __device__ __forceinline__ Affine load_point(const Affine* __restrict__ pts, uint32_t idx) {
     return pts[idx];
 }
 
-// task id -> (window, bucket, j): window by a short scan of win_base, bucket by binary search in the
-// window's exclusive task prefix (the largest b with off[b] <= local id is the non-empty one).
+// task id -> (window, bucket, j): binary search in win_base, then in the window's exclusive task
+// prefix (the largest b with off[b] <= local id is the non-empty one).
 __device__ __forceinline__ void find_task(uint32_t tid, const uint32_t* __restrict__ win_base, uint32_t W,
                                           const uint32_t* __restrict__ task_off, uint32_t NB, uint32_t& w,
                                           uint32_t& b, uint32_t& j) {
-    w = 0;
-    while (w + 1 < W && win_base[w + 1] <= tid) ++w;
+    uint32_t lo = 0, hi = W;           // invariant: win_base[lo] <= tid
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (win_base[mid] <= tid) lo = mid; else hi = mid;
+    }
+    w = lo;
     const uint32_t lt = tid - win_base[w];
     const uint32_t* off = task_off + (size_t)w * NB;
-    uint32_t lo = 0, hi = NB;          // invariant: off[lo] <= lt, answer in [lo, hi)
+    lo = 0; hi = NB;                   // invariant: off[lo] <= lt, answer in [lo, hi)
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
         if (off[mid] <= lt) lo = mid; else hi = mid;
@@ -318,7 +341,7 @@ __global__ __launch_bounds__(256, MINW) void msm_accumulate_kernel(const Affine*
                                                              const uint32_t* __restrict__ bucket_count,
                                                              const uint32_t* __restrict__ task_off,
                                                              const uint32_t* __restrict__ win_base,
-                                                             XYZZ* __restrict__ partials, uint32_t n, uint32_t NB,
+                                                             XYZZ* __restrict__ partials, uint32_t NB,
                                                              uint32_t W, uint32_t L) {
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= win_base[W]) return;
@@ -386,9 +409,9 @@ __global__ __launch_bounds__(256) void msm_finalize_kernel(const XYZZ* __restric
 }
 
 // ---- 6. bucket reduction ------------------------------------------------------------------------
-// Window sum = sum_{b=1}^{nbk} b * B_b.  Lane g owns buckets [g*kSeg + 1, (g+1)*kSeg]:
-//   run_g = sum B_b, acc_g = sum (b - g*kSeg) B_b (running-sum trick), T_g = acc_g + (g*kSeg) run_g.
-// A 256-lane workgroup tree-adds its T_g through LDS and writes one partial.
+// Logical window sum = sum_{b=1}^{nbk} b * B_b.  Lane g owns buckets [g*seg + 1, (g+1)*seg]:
+//   run_g = sum B_b, acc_g = sum (b - g*seg) B_b (running-sum trick), T_g = acc_g + (g*seg) run_g.
+// A 256-lane workgroup tree-adds its T_g through LDS and writes one partial.  grid (groups, windows).
 __global__ __launch_bounds__(256) void msm_reduce_kernel(const XYZZ* __restrict__ buckets, XYZZ* __restrict__ partials,
                                                          uint32_t nbk, uint32_t groups_per_window, uint32_t seg) {
     __shared__ XYZZ sh[256];
@@ -396,15 +419,16 @@ __global__ __launch_bounds__(256) void msm_reduce_kernel(const XYZZ* __restrict_
     const uint32_t g = blockIdx.x * blockDim.x + tid;
     const XYZZ* bw = buckets + (size_t)w * nbk;
     XYZZ run = xyzz_inf(), acc = xyzz_inf();
-    const uint32_t lo = g * seg;   // bucket ids lo+1 .. lo+seg  (array index = id - 1)
-    if (lo < nbk) {
+    const uint64_t lo64 = (uint64_t)g * seg;   // bucket ids lo+1 .. lo+seg  (array index = id - 1)
+    if (lo64 < nbk) {
+        const uint32_t lo = (uint32_t)lo64;
         const uint32_t hi = min(nbk, lo + seg);
         for (uint32_t idx = hi; idx-- > lo;) {
             XYZZ bk = bw[idx];
             xyzz_add(run, bk);
             xyzz_add(acc, run);
         }
-        // acc += lo * run   (double-and-add, lo < 2^24)
+        // acc += lo * run   (double-and-add)
         if (lo != 0 && !xyzz_is_inf(run)) {
             XYZZ m = xyzz_inf();
             for (int bit = 31 - __clz(lo); bit >= 0; --bit) {
@@ -427,6 +451,75 @@ __global__ __launch_bounds__(256) void msm_reduce_kernel(const XYZZ* __restrict_
     }
     if (tid == 0) partials[(size_t)w * groups_per_window + blockIdx.x] = sh[0];
 }
+// out[w] = sum of partials[w][0..groups)   (one 256-lane workgroup per window)
+__global__ __launch_bounds__(256) void msm_fold_partials_kernel(const XYZZ* __restrict__ partials, XYZZ* __restrict__ out,
+                                                                uint32_t groups) {
+    __shared__ XYZZ sh[256];
+    const uint32_t w = blockIdx.x, tid = threadIdx.x;
+    XYZZ acc = xyzz_inf();
+    for (uint32_t g = tid; g < groups; g += 256) { XYZZ q = partials[(size_t)w * groups + g]; xyzz_add(acc, q); }
+    sh[tid] = acc;
+    __syncthreads();
+    for (uint32_t s = 128; s > 0; s >>= 1) {
+        if (tid < s) {
+            XYZZ a = sh[tid];
+            XYZZ b2 = sh[tid + s];
+            xyzz_add(a, b2);
+            sh[tid] = a;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) out[w] = sh[0];
+}
+
+// ---- precomputation: T[j][i] = 2^c * T[j-1][i], affine --------------------------------------------
+__device__ inline Fp fq_inv_pow(const Fp& a) {   // a^(p-2)
+    const uint32_t e[8] = {0xd87cfd45u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u,
+                           0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+    Fp acc = Fq::one();
+    for (int i = 253; i >= 0; --i) {
+        acc = Fq::sqr(acc);
+        if ((e[i >> 5] >> (i & 31)) & 1) acc = Fq::mul(acc, a);
+    }
+    return acc;
+}
+constexpr int kPreRun = 16;   // points normalised per lane with one inversion (Montgomery's trick)
+__global__ __launch_bounds__(64) void msm_precompute_kernel(const Affine* __restrict__ prev, Affine* __restrict__ out,
+                                                            Fp* __restrict__ tmp_z, Fp* __restrict__ tmp_p, uint32_t n,
+                                                            int c) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lo = t * kPreRun;
+    if (lo >= n) return;
+    const uint32_t hi = min(n, lo + kPreRun);
+    Fp prod = Fq::one();
+    for (uint32_t i = lo; i < hi; ++i) {
+        XYZZ a = xyzz_from_affine(prev[i]);
+        for (int d = 0; d < c; ++d) a = xyzz_dbl(a);
+        Affine xy;
+        Fp z;
+        if (xyzz_is_inf(a)) {            // infinity base stays infinity in every window
+            xy.x = Fq::zero(); xy.y = Fq::zero(); z = Fq::one();
+        } else {
+            xy.x = Fq::mul(a.x, a.zz);   // Jacobian-like (X*ZZ, Y*ZZZ, Z = ZZ)
+            xy.y = Fq::mul(a.y, a.zzz);
+            z = a.zz;
+        }
+        out[i] = xy;
+        tmp_z[i] = z;
+        tmp_p[i] = prod;
+        prod = Fq::mul(prod, z);
+    }
+    Fp inv = fq_inv_pow(prod);
+    for (uint32_t i = hi; i-- > lo;) {
+        Fp zi = Fq::mul(inv, tmp_p[i]);
+        inv = Fq::mul(inv, tmp_z[i]);
+        Fp zi2 = Fq::sqr(zi);
+        Affine xy = out[i];
+        xy.x = Fq::mul(xy.x, zi2);
+        xy.y = Fq::mul(xy.y, Fq::mul(zi2, zi));
+        out[i] = xy;
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
 // host
@@ -439,74 +532,140 @@ static int choose_window_bits(size_t n, int forced) {
     if (lg >= 22) c = 16;
     return std::max(6, std::min(16, c));
 }
+int msm_precompute_window_bits(size_t n, int forced) {
+    if (forced >= 4 && forced <= 24) return forced;
+    int lg = 0;
+    while ((1ull << (lg + 1)) <= n) ++lg;
+    return std::max(8, std::min(22, lg - 2));
+}
 
 void msm_free(Ctx& c) {
     if (!c.msm) return;
     MsmWork* m = c.msm;
-    m->digits.release(); m->chunk_hist.release(); m->bucket_count.release(); m->bucket_start.release();
-    m->sorted.release(); m->buckets.release(); m->partials.release(); m->small.release();
-    m->part_a.release(); m->seg_a_start.release(); m->seg_a_len.release(); m->counts_b.release();
-    for (int k = 0; k < 2; ++k) { m->lvl_cnt[k].release(); m->lvl_off[k].release(); m->lvl_part[k].release(); }
-    if (m->h_partials) (void)hipHostFree(m->h_partials);
+    m->digits.release(); m->bucket_count.release(); m->bucket_start.release(); m->sorted.release();
+    m->buckets.release(); m->partials.release(); m->win_sums.release(); m->small.release();
+    for (int k = 0; k < 2; ++k) {
+        m->ent[k].release(); m->lvl_cnt[k].release(); m->lvl_off[k].release(); m->lvl_part[k].release();
+    }
+    for (int k = 0; k < kMaxPasses; ++k) { m->counts[k].release(); m->segs_start[k].release(); m->segs_len[k].release(); }
+    if (m->h_sums) (void)hipHostFree(m->h_sums);
     if (m->h_max) (void)hipHostFree(m->h_max);
     delete m;
     c.msm = nullptr;
 }
 
+// Builds the window table of a registered SRS: table[j*n + i] = 2^(cb*j) * P_i, j < W.
+int msm_build_table(Ctx& c, const Affine* d_points, size_t n, int cb, Affine** table_out, uint32_t* W_out) {
+    const uint32_t W = (uint32_t)msm_num_windows(cb);
+    if ((uint64_t)W * n >= (1ull << 31)) {
+        set_error("precompute: W*n = %llu exceeds 2^31 - 1", (unsigned long long)W * n);
+        return UZK_ERR_PARAMETER;
+    }
+    Affine* table = nullptr;
+    UZK_HIP(hipMalloc(reinterpret_cast<void**>(&table), (size_t)W * n * sizeof(Affine)));
+    Fp *tz = nullptr, *tp = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&tz), n * sizeof(Fp));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&tp), n * sizeof(Fp));
+    if (e == hipSuccess) e = hipMemcpyAsync(table, d_points, n * sizeof(Affine), hipMemcpyDeviceToDevice, c.stream);
+    if (e == hipSuccess) {
+        const uint32_t threads = (uint32_t)((n + kPreRun - 1) / kPreRun);
+        for (uint32_t j = 1; j < W; ++j) {
+            KernelScope ks(c, "msm_precompute");
+            hipLaunchKernelGGL(msm_precompute_kernel, dim3((threads + 63) / 64), dim3(64), 0, c.stream,
+                               table + (size_t)(j - 1) * n, table + (size_t)j * n, tz, tp, (uint32_t)n, cb);
+        }
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
+    }
+    if (tz) (void)hipFree(tz);
+    if (tp) (void)hipFree(tp);
+    if (e != hipSuccess) {
+        (void)hipFree(table);
+        set_error("precompute failed: %s", hipGetErrorString(e));
+        return UZK_ERR_DEVICE;
+    }
+    *table_out = table;
+    *W_out = W;
+    return UZK_OK;
+}
 
-int msm_run(Ctx& c, const Affine* d_points, const Fp* d_scalars, size_t n, Jac* out_host) {
+struct SortPass { uint32_t shift, bins, nseg, nch; };
+
+// `points`: base array the sorted indices refer to (the SRS slice, or the window table).
+// Precomputed mode (pre_c > 0): `points` = table, entries of window j index pre_stride * j + pre_off + i.
+int msm_run(Ctx& c, const Affine* points, const Fp* d_scalars, size_t n, Jac* out_host, int pre_c,
+            uint32_t pre_stride, uint32_t pre_off) {
     if (n == 0) { *out_host = jac_inf(); return UZK_OK; }
     if (n >= (1ull << 31)) { set_error("msm: n = %zu exceeds 2^31 - 1 points per call", n); return UZK_ERR_PARAMETER; }
     if (!c.msm) c.msm = new MsmWork();
     MsmWork& m = *c.msm;
-    const int cb = choose_window_bits(n, c.msm_window_bits);
+    const bool pre = pre_c > 0;
+    const int cb = pre ? pre_c : choose_window_bits(n, c.msm_window_bits);
     const uint32_t W = (uint32_t)msm_num_windows(cb);
-    const uint32_t NB = 1u << (cb - 1);            // buckets per window, dense index = |digit| - 1
     const uint32_t n32 = (uint32_t)n;
-    if ((uint64_t)W * n >= (1ull << 32)) { set_error("msm: W*n overflows the 32-bit index space"); return UZK_ERR_PARAMETER; }
-    // reduction geometry: 256 lanes per group, `seg` buckets per lane (short segments when a window has few
-    // buckets, so the dependent chain of full additions stays short for small n)
-    const uint32_t seg = std::max<uint32_t>(1, std::min<uint32_t>(kSeg, NB / 256));
-    const uint32_t groups = (NB + seg * 256 - 1) / (seg * 256);
     const uint64_t entries = (uint64_t)W * n;
+    if (entries >= (1ull << 31)) { set_error("msm: W*n overflows the 31-bit index space"); return UZK_ERR_PARAMETER; }
+    const uint32_t kb = (uint32_t)cb - 1;                  // bucket key bits
+    const uint32_t NBL = 1u << kb;                         // buckets of one logical window
+    // sort segments: one per window (general) or one for everything (precomputed)
+    const uint32_t S0 = pre ? 1u : W;
+    const uint32_t seg_n = pre ? (uint32_t)entries : n32;  // entries per initial segment
+    // bucket windows as seen by the scan / task kernels: <= 2^15 buckets each
+    const uint32_t NB = std::min<uint32_t>(NBL, 1u << 15);
+    const uint32_t Wd = (uint32_t)(((uint64_t)S0 * NBL) / NB);
+    const uint64_t TBK = (uint64_t)Wd * NB;                // all buckets
+    if (Wd > 1024) { set_error("msm: too many bucket windows (%u)", Wd); return UZK_ERR_PARAMETER; }
+    // reduction geometry: `seg` buckets per lane, 256 lanes per group
+    const uint32_t RW = pre ? 1u : W;                      // logical windows in the reduction
+    const uint32_t seg = std::max<uint32_t>(1, std::min<uint32_t>(kSeg, NBL / 256));
+    const uint32_t groups = (NBL + seg * 256 - 1) / (seg * 256);
     const uint32_t L = c.tune_task_len > 0 ? (uint32_t)c.tune_task_len
                                            : (uint32_t)std::max<uint64_t>(16, std::min<uint64_t>(64, entries >> 21));
     const uint32_t G = kCombineFan;
-    const uint64_t bound0 = entries / L + (uint64_t)W * NB;           // upper bound on level-0 tasks
-    const uint64_t part_cap = bound0 + 2ull * W * NB;                 // every later level fits too
-    // radix plan
-    const uint32_t kb = (uint32_t)cb - 1;
-    const uint32_t lb = std::min<uint32_t>(kb, 9), hb = kb - lb;
-    const uint32_t bins_a = 1u << hb, bins_b = 1u << lb;
-    const uint32_t nch_a = (uint32_t)std::max<size_t>(1, std::min<size_t>(32, n / 8192));
-    const uint32_t nseg_b = W * bins_a;
-    const uint32_t nch_b = hb == 0 ? nch_a
-                                   : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(8, (n / bins_a) / 16384));
+    const uint64_t bound0 = entries / L + TBK;             // upper bound on level-0 tasks
+    const uint64_t part_cap = bound0 + 2 * TBK;            // every later level fits too
+    // radix plan: P passes of <= 9 bits, high bits first
+    const int P = kb <= 9 ? 1 : (kb <= 18 ? 2 : 3);
+    SortPass sp[kMaxPasses];
+    {
+        uint32_t rem = kb, nseg = S0;
+        for (int p = 0; p < P; ++p) {
+            const uint32_t bits = (rem + (uint32_t)(P - p) - 1) / (uint32_t)(P - p);
+            rem -= bits;
+            sp[p].shift = rem;
+            sp[p].bins = 1u << bits;
+            sp[p].nseg = nseg;
+            const uint64_t avg = std::max<uint64_t>(1, (S0 * (uint64_t)seg_n) / nseg);
+            sp[p].nch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(1024, avg / 32768));
+            nseg *= sp[p].bins;
+        }
+    }
 
-    UZK_TRY(m.digits.reserve((size_t)W * n * 4));
-    UZK_TRY(m.sorted.reserve((size_t)W * n * 4));
-    UZK_TRY(m.chunk_hist.reserve((size_t)W * nch_a * std::max(bins_a, bins_b) * 4));
-    UZK_TRY(m.bucket_count.reserve((size_t)W * NB * 4));
-    UZK_TRY(m.bucket_start.reserve((size_t)W * NB * 4));
-    UZK_TRY(m.buckets.reserve((size_t)W * NB * sizeof(XYZZ)));
-    UZK_TRY(m.partials.reserve((size_t)W * groups * sizeof(XYZZ)));
-    if (hb > 0) {
-        UZK_TRY(m.part_a.reserve((size_t)W * n * sizeof(uint2)));
-        UZK_TRY(m.seg_a_start.reserve((size_t)nseg_b * 4));
-        UZK_TRY(m.seg_a_len.reserve((size_t)nseg_b * 4));
-        UZK_TRY(m.counts_b.reserve((size_t)nseg_b * nch_b * bins_b * 4));
+    UZK_TRY(m.digits.reserve((size_t)entries * 4));
+    UZK_TRY(m.sorted.reserve((size_t)entries * 4));
+    UZK_TRY(m.bucket_count.reserve((size_t)TBK * 4));
+    UZK_TRY(m.bucket_start.reserve((size_t)TBK * 4));
+    UZK_TRY(m.buckets.reserve((size_t)TBK * sizeof(XYZZ)));
+    UZK_TRY(m.partials.reserve((size_t)RW * groups * sizeof(XYZZ)));
+    UZK_TRY(m.win_sums.reserve((size_t)RW * sizeof(XYZZ)));
+    for (int p = 0; p < P; ++p) {
+        UZK_TRY(m.counts[p].reserve((size_t)sp[p].nseg * sp[p].nch * sp[p].bins * 4));
+        if (p + 1 < P) {
+            UZK_TRY(m.segs_start[p].reserve((size_t)sp[p].nseg * sp[p].bins * 4));
+            UZK_TRY(m.segs_len[p].reserve((size_t)sp[p].nseg * sp[p].bins * 4));
+            UZK_TRY(m.ent[p & 1].reserve((size_t)entries * sizeof(uint2)));
+        }
     }
     for (int k = 0; k < 2; ++k) {
-        UZK_TRY(m.lvl_cnt[k].reserve((size_t)W * NB * 4));
-        UZK_TRY(m.lvl_off[k].reserve((size_t)W * NB * 4));
+        UZK_TRY(m.lvl_cnt[k].reserve((size_t)TBK * 4));
+        UZK_TRY(m.lvl_off[k].reserve((size_t)TBK * 4));
     }
     UZK_TRY(m.lvl_part[0].reserve((size_t)part_cap * sizeof(XYZZ)));
-    UZK_TRY(m.small.reserve(4096));
-    const size_t np = (size_t)W * groups;
-    if (m.h_partials_cap < np) {
-        if (m.h_partials) (void)hipHostFree(m.h_partials);
-        UZK_HIP(hipHostMalloc(reinterpret_cast<void**>(&m.h_partials), np * sizeof(XYZZ), hipHostMallocDefault));
-        m.h_partials_cap = np;
+    UZK_TRY(m.small.reserve(16384));
+    if (m.h_sums_cap < RW) {
+        if (m.h_sums) (void)hipHostFree(m.h_sums);
+        UZK_HIP(hipHostMalloc(reinterpret_cast<void**>(&m.h_sums), (size_t)RW * sizeof(XYZZ), hipHostMallocDefault));
+        m.h_sums_cap = RW;
     }
     if (!m.h_max) UZK_HIP(hipHostMalloc(reinterpret_cast<void**>(&m.h_max), 64, hipHostMallocDefault));
 
@@ -516,11 +675,12 @@ int msm_run(Ctx& c, const Affine* d_points, const Fp* d_scalars, size_t n, Jac* 
     uint32_t* bstart = m.bucket_start.as<uint32_t>();
     XYZZ* buckets = m.buckets.as<XYZZ>();
     XYZZ* partials = m.partials.as<XYZZ>();
-    // small: [0..64) window totals, [64..192) win_base ping, [192..320) win_base pong, [320] max
+    XYZZ* win_sums = m.win_sums.as<XYZZ>();
+    // small: [0..1024) window totals, [1024..2049) win_base ping, [2080..3105) win_base pong, [3200] max
     uint32_t* sm = m.small.as<uint32_t>();
     uint32_t* win_tot = sm;
-    uint32_t* win_base[2] = {sm + 64, sm + 192};
-    uint32_t* d_max = sm + 320;
+    uint32_t* win_base[2] = {sm + 1024, sm + 2080};
+    uint32_t* d_max = sm + 3200;
     hipStream_t st = c.stream;
 
     UZK_HIP(hipMemsetAsync(d_max, 0, 4, st));
@@ -528,82 +688,65 @@ int msm_run(Ctx& c, const Affine* d_points, const Fp* d_scalars, size_t n, Jac* 
         KernelScope ks(c, "msm_digits");
         hipLaunchKernelGGL(msm_digits_kernel, dim3((n32 + 255) / 256), dim3(256), 0, st, d_scalars, digits, n32, cb, (int)W);
     }
-    // ---- counting sort of (window, bucket): pass A on the high bits (if any), pass B on the low bits
-    RadixArgs ra{};
-    ra.digits = digits;
-    ra.n = n32;
-    ra.counts = m.chunk_hist.as<uint32_t>();
-    if (hb == 0) {
-        ra.shift = 0; ra.mask = bins_b - 1; ra.bins = bins_b;
-        ra.bin_base = bstart; ra.bin_count = bcount; ra.out_vals = sorted;
+    // ---- counting sort, high bits first
+    for (int p = 0; p < P; ++p) {
+        const bool first = (p == 0), last = (p == P - 1);
+        RadixArgs a{};
+        a.shift = sp[p].shift; a.bins = sp[p].bins; a.mask = sp[p].bins - 1;
+        a.counts = m.counts[p].as<uint32_t>();
+        if (first) {
+            a.digits = digits;
+            a.n = seg_n;
+            if (pre) { a.remap_cnt = n32; a.remap_stride = pre_stride; a.remap_off = pre_off; }
+        } else {
+            a.in_entries = m.ent[(p - 1) & 1].as<uint2>();
+            a.seg_start = m.segs_start[p - 1].as<uint32_t>();
+            a.seg_len = m.segs_len[p - 1].as<uint32_t>();
+        }
+        if (last) { a.bin_base = bstart; a.bin_count = bcount; a.out_vals = sorted; }
+        else {
+            a.bin_base = m.segs_start[p].as<uint32_t>(); a.bin_count = m.segs_len[p].as<uint32_t>();
+            a.out_entries = m.ent[p & 1].as<uint2>();
+        }
+        const dim3 grid(sp[p].nch, sp[p].nseg);
         {
             KernelScope ks(c, "msm_sort_hist");
-            hipLaunchKernelGGL(msm_radix_hist_kernel<true>, dim3(nch_a, W), dim3(1024), 0, st, ra);
+            if (first) hipLaunchKernelGGL(msm_radix_hist_kernel<true>, grid, dim3(1024), 0, st, a);
+            else hipLaunchKernelGGL(msm_radix_hist_kernel<false>, grid, dim3(256), 0, st, a);
         }
         {
             KernelScope ks(c, "msm_sort_scan");
-            hipLaunchKernelGGL(msm_radix_scan_kernel, dim3(W), dim3(512), 0, st, ra, nch_a, (const uint32_t*)nullptr, n32);
+            hipLaunchKernelGGL(msm_radix_scan_kernel, dim3(sp[p].nseg), dim3(512), 0, st, a, sp[p].nch,
+                               first ? (const uint32_t*)nullptr : a.seg_start, first ? seg_n : 0u);
         }
         {
             KernelScope ks(c, "msm_sort_scatter");
-            hipLaunchKernelGGL((msm_radix_scatter_kernel<1024, 8, true, true>), dim3(nch_a, W), dim3(1024), 0, st, ra);
-        }
-    } else {
-        ra.shift = lb; ra.mask = bins_a - 1; ra.bins = bins_a;
-        ra.bin_base = m.seg_a_start.as<uint32_t>(); ra.bin_count = m.seg_a_len.as<uint32_t>();
-        ra.out_entries = m.part_a.as<uint2>();
-        {
-            KernelScope ks(c, "msm_sort_hist");
-            hipLaunchKernelGGL(msm_radix_hist_kernel<true>, dim3(nch_a, W), dim3(1024), 0, st, ra);
-        }
-        {
-            KernelScope ks(c, "msm_sort_scan");
-            hipLaunchKernelGGL(msm_radix_scan_kernel, dim3(W), dim3(512), 0, st, ra, nch_a, (const uint32_t*)nullptr, n32);
-        }
-        {
-            KernelScope ks(c, "msm_sort_scatter_a");
-            hipLaunchKernelGGL((msm_radix_scatter_kernel<1024, 8, true, false>), dim3(nch_a, W), dim3(1024), 0, st, ra);
-        }
-        RadixArgs rb{};
-        rb.in_entries = m.part_a.as<uint2>();
-        rb.seg_start = m.seg_a_start.as<uint32_t>();
-        rb.seg_len = m.seg_a_len.as<uint32_t>();
-        rb.shift = 0; rb.mask = bins_b - 1; rb.bins = bins_b;
-        rb.counts = m.counts_b.as<uint32_t>();
-        rb.bin_base = bstart; rb.bin_count = bcount; rb.out_vals = sorted;
-        {
-            KernelScope ks(c, "msm_sort_hist");
-            hipLaunchKernelGGL(msm_radix_hist_kernel<false>, dim3(nch_b, nseg_b), dim3(256), 0, st, rb);
-        }
-        {
-            KernelScope ks(c, "msm_sort_scan");
-            hipLaunchKernelGGL(msm_radix_scan_kernel, dim3(nseg_b), dim3(512), 0, st, rb, nch_b, rb.seg_start, 0u);
-        }
-        {
-            KernelScope ks(c, "msm_sort_scatter_b");
-            hipLaunchKernelGGL((msm_radix_scatter_kernel<256, 16, false, true>), dim3(nch_b, nseg_b), dim3(256), 0, st, rb);
+            if (first && last) hipLaunchKernelGGL((msm_radix_scatter_kernel<1024, 8, true, true>), grid, dim3(1024), 0, st, a);
+            else if (first) hipLaunchKernelGGL((msm_radix_scatter_kernel<1024, 8, true, false>), grid, dim3(1024), 0, st, a);
+            else if (last) hipLaunchKernelGGL((msm_radix_scatter_kernel<256, 16, false, true>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((msm_radix_scatter_kernel<1024, 8, false, false>), grid, dim3(1024), 0, st, a);
         }
     }
-    // level-0 tasks (runs of <= L indices)
+    // ---- level-0 tasks (runs of <= L indices)
     uint32_t* cnt_cur = m.lvl_cnt[0].as<uint32_t>();
     uint32_t* off_cur = m.lvl_off[0].as<uint32_t>();
     uint32_t* base_cur = win_base[0];
     XYZZ* part_cur = m.lvl_part[0].as<XYZZ>();
     {
         KernelScope ks(c, "msm_scan_win");
-        hipLaunchKernelGGL(msm_scan_win_kernel, dim3(W), dim3(1024), 0, st, bcount, L, cnt_cur, off_cur, win_tot,
+        hipLaunchKernelGGL(msm_scan_win_kernel, dim3(Wd), dim3(1024), 0, st, bcount, L, cnt_cur, off_cur, win_tot,
                            d_max, NB);
-        hipLaunchKernelGGL(msm_win_base_kernel, dim3(1), dim3(64), 0, st, win_tot, base_cur, W);
+        hipLaunchKernelGGL(msm_win_base_kernel, dim3(1), dim3(1024), 0, st, win_tot, base_cur, Wd);
     }
     {
         KernelScope ks(c, "msm_accumulate");
         const dim3 grid((unsigned)((bound0 + 255) / 256));
         if (c.tune_acc_variant == 1)
-            hipLaunchKernelGGL(msm_accumulate_kernel<4>, grid, dim3(256), 0, st, d_points, sorted, bstart, bcount,
-                               off_cur, base_cur, part_cur, n32, NB, W, L);
+            hipLaunchKernelGGL(msm_accumulate_kernel<4>, grid, dim3(256), 0, st, points, sorted, bstart, bcount,
+                               off_cur, base_cur, part_cur, NB, Wd, L);
         else
-            hipLaunchKernelGGL(msm_accumulate_kernel<1>, grid, dim3(256), 0, st, d_points, sorted, bstart, bcount,
-                               off_cur, base_cur, part_cur, n32, NB, W, L);
+            hipLaunchKernelGGL(msm_accumulate_kernel<1>, grid, dim3(256), 0, st, points, sorted, bstart, bcount,
+                               off_cur, base_cur, part_cur, NB, Wd, L);
     }
     UZK_HIP(hipGetLastError());
     // the largest bucket decides how many fold levels are needed (one tiny read-back)
@@ -618,18 +761,18 @@ int msm_run(Ctx& c, const Affine* d_points, const Fp* d_scalars, size_t n, Jac* 
         uint32_t* cnt_nx = m.lvl_cnt[nx].as<uint32_t>();
         uint32_t* off_nx = m.lvl_off[nx].as<uint32_t>();
         uint32_t* base_nx = win_base[nx];
-        const uint64_t bound_nx = bound_prev / G + (uint64_t)W * NB;
+        const uint64_t bound_nx = bound_prev / G + TBK;
         XYZZ* part_nx = m.lvl_part[nx].as<XYZZ>();
         {
             KernelScope ks(c, "msm_scan_win");
-            hipLaunchKernelGGL(msm_scan_win_kernel, dim3(W), dim3(1024), 0, st, cnt_cur, G, cnt_nx, off_nx, win_tot,
+            hipLaunchKernelGGL(msm_scan_win_kernel, dim3(Wd), dim3(1024), 0, st, cnt_cur, G, cnt_nx, off_nx, win_tot,
                                (uint32_t*)nullptr, NB);
-            hipLaunchKernelGGL(msm_win_base_kernel, dim3(1), dim3(64), 0, st, win_tot, base_nx, W);
+            hipLaunchKernelGGL(msm_win_base_kernel, dim3(1), dim3(1024), 0, st, win_tot, base_nx, Wd);
         }
         {
             KernelScope ks(c, "msm_combine");
             hipLaunchKernelGGL(msm_combine_kernel, dim3((unsigned)((bound_nx + 255) / 256)), dim3(256), 0, st, part_cur,
-                               cnt_cur, off_cur, base_cur, off_nx, base_nx, part_nx, NB, W, G);
+                               cnt_cur, off_cur, base_cur, off_nx, base_nx, part_nx, NB, Wd, G);
         }
         cnt_cur = cnt_nx; off_cur = off_nx; base_cur = base_nx; part_cur = part_nx;
         bound_prev = bound_nx;
@@ -638,23 +781,23 @@ int msm_run(Ctx& c, const Affine* d_points, const Fp* d_scalars, size_t n, Jac* 
     }
     {
         KernelScope ks(c, "msm_finalize");
-        const size_t tot = (size_t)W * NB;
-        hipLaunchKernelGGL(msm_finalize_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, part_cur, cnt_cur,
-                           off_cur, base_cur, buckets, NB, W);
+        hipLaunchKernelGGL(msm_finalize_kernel, dim3((unsigned)((TBK + 255) / 256)), dim3(256), 0, st, part_cur, cnt_cur,
+                           off_cur, base_cur, buckets, NB, Wd);
     }
     {
         KernelScope ks(c, "msm_reduce");
-        hipLaunchKernelGGL(msm_reduce_kernel, dim3(groups, W), dim3(256), 0, st, buckets, partials, NB, groups, seg);
+        hipLaunchKernelGGL(msm_reduce_kernel, dim3(groups, RW), dim3(256), 0, st, buckets, partials, NBL, groups, seg);
+        hipLaunchKernelGGL(msm_fold_partials_kernel, dim3(RW), dim3(256), 0, st, partials, win_sums, groups);
     }
     UZK_HIP(hipGetLastError());
-    UZK_HIP(hipMemcpyAsync(m.h_partials, partials, np * sizeof(XYZZ), hipMemcpyDeviceToHost, st));
+    UZK_HIP(hipMemcpyAsync(m.h_sums, win_sums, (size_t)RW * sizeof(XYZZ), hipMemcpyDeviceToHost, st));
     UZK_HIP(hipStreamSynchronize(st));
 
-    // 7. host: fold partials per window, then Horner over windows (c doublings per step)
+    // 7. host: Horner over the logical windows (c doublings per step); one window when precomputed
     XYZZ total = xyzz_inf();
-    for (int w = (int)W - 1; w >= 0; --w) {
-        for (int d = 0; d < cb; ++d) total = xyzz_dbl(total);
-        for (uint32_t g = 0; g < groups; ++g) xyzz_add(total, m.h_partials[(size_t)w * groups + g]);
+    for (int w = (int)RW - 1; w >= 0; --w) {
+        if (w != (int)RW - 1) for (int d = 0; d < cb; ++d) total = xyzz_dbl(total);
+        xyzz_add(total, m.h_sums[w]);
     }
     *out_host = xyzz_to_jac(total);
     return UZK_OK;
