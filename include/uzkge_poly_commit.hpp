@@ -1,0 +1,148 @@
+// uzkge_poly_commit.hpp -- header-only C++ mirror of the reference's polynomial layer for the hot
+// path, over the C ABI of uzkge_gpu.h.  Same names, argument meaning and error behaviour as
+//   FpPolynomial                uzkge/src/poly_commit/field_polynomial.rs:13-17,86-90,154-159,554-607
+//   KZGCommitmentSchemeBN254    uzkge/src/poly_commit/kzg_poly_commitment.rs:170-313
+//   UzkgeError                  uzkge/src/errors.rs:5-44
+// What lives here is what stays on the host in the Rust integration: trimming,
+// zero-padding, domain choice, length checks.  All arithmetic runs on the GPU.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "uzkge_gpu.h"
+
+namespace uzkge {
+
+enum class UzkgeError { ParameterError = 1, DegreeError = 2, FFTError = 3, CommitmentError = 4, DeviceError = 5, DeserializationError = 6 };
+
+struct UzkgeException : std::runtime_error {
+    UzkgeError kind;
+    UzkgeException(UzkgeError k, const std::string& what) : std::runtime_error(what), kind(k) {}
+};
+inline void check(int rc) {
+    if (rc != UZK_OK) throw UzkgeException(static_cast<UzkgeError>(rc), uzk_last_error());
+}
+
+struct Fr {                       // Montgomery limbs, the wire format
+    uint64_t l[4] = {0, 0, 0, 0};
+    bool is_zero() const { return (l[0] | l[1] | l[2] | l[3]) == 0; }
+    bool operator==(const Fr& o) const { return std::memcmp(l, o.l, sizeof l) == 0; }
+};
+using G1Projective = uzk_g1_jac;
+using G1Affine = uzk_g1_affine;
+
+class FpPolynomial {
+  public:
+    std::vector<Fr> coefs;        // low to high
+
+    // Trims trailing zeros; the zero polynomial keeps one zero coefficient (field_polynomial.rs:86-90).
+    static FpPolynomial from_coefs(std::vector<Fr> c) {
+        while (c.size() > 1 && c.back().is_zero()) c.pop_back();
+        if (c.empty()) c.push_back(Fr{});
+        FpPolynomial p;
+        p.coefs = std::move(c);
+        return p;
+    }
+    const std::vector<Fr>& get_coefs_ref() const { return coefs; }
+    size_t degree() const {
+        for (size_t i = coefs.size(); i-- > 0;) if (!coefs[i].is_zero()) return i;
+        return 0;
+    }
+    // field_polynomial.rs:554-567
+    static std::optional<uint64_t> evaluation_domain(uint64_t num_coeffs) {
+        if (num_coeffs == 0 || (num_coeffs & (num_coeffs - 1)) != 0) throw std::invalid_argument("num_coeffs must be 2^k");
+        return uzk_domain_supported(num_coeffs) ? std::optional<uint64_t>(num_coeffs) : std::nullopt;
+    }
+    static std::optional<uint64_t> quotient_evaluation_domain(uint64_t num_coeffs) {
+        const uint64_t m = (num_coeffs % 3 == 0) ? num_coeffs / 3 : num_coeffs;
+        if (num_coeffs == 0 || (m & (m - 1)) != 0) throw std::invalid_argument("num_coeffs must be 2^k or 3*2^k");
+        return uzk_domain_supported(num_coeffs) ? std::optional<uint64_t>(num_coeffs) : std::nullopt;
+    }
+    // field_polynomial.rs:570-580
+    std::optional<std::vector<Fr>> fft(uint64_t num_coeffs) const {
+        if (!(num_coeffs > degree())) throw std::invalid_argument("num_coeffs must exceed the degree");
+        auto d = (num_coeffs & (num_coeffs - 1)) == 0 ? evaluation_domain(num_coeffs) : quotient_evaluation_domain(num_coeffs);
+        if (!d) return std::nullopt;
+        return fft_with_domain(*d);
+    }
+    // `domain.fft(&self.coefs)`: zero-pad to the domain, natural order (field_polynomial.rs:583-586)
+    std::vector<Fr> fft_with_domain(uint64_t domain) const { return transform(domain, coefs, 0, nullptr); }
+    // fft of p(kX) (field_polynomial.rs:589-591); the serial mul_var is fused into the device transform
+    std::vector<Fr> coset_fft_with_domain(uint64_t domain, const Fr& k) const { return transform(domain, coefs, 0, &k); }
+    // `domain.ifft(values)` then from_coefs (field_polynomial.rs:594-597)
+    static FpPolynomial ifft_with_domain(uint64_t domain, const std::vector<Fr>& values) {
+        return from_coefs(transform(domain, values, 1, nullptr));
+    }
+    // ifft then mul_var(k_inv) (field_polynomial.rs:601-607)
+    static FpPolynomial coset_ifft_with_domain(uint64_t domain, const std::vector<Fr>& values, const Fr& k_inv) {
+        return from_coefs(transform(domain, values, 1, &k_inv));
+    }
+    bool operator==(const FpPolynomial& o) const { return from_coefs(coefs).coefs == from_coefs(o.coefs).coefs; }
+
+  private:
+    static std::vector<Fr> transform(uint64_t domain, const std::vector<Fr>& in, int inverse, const Fr* shift) {
+        if (in.size() > domain) throw std::invalid_argument("more coefficients than the domain holds");
+        std::vector<Fr> buf(domain);
+        std::copy(in.begin(), in.end(), buf.begin());
+        check(uzk_ntt_fr(reinterpret_cast<uint64_t*>(buf.data()), domain, inverse, shift ? shift->l : nullptr));
+        return buf;
+    }
+};
+
+class KZGCommitmentSchemeBN254 {
+  public:
+    std::vector<G1Affine> public_parameter_group_1;   // affine, Montgomery coordinates
+
+    explicit KZGCommitmentSchemeBN254(std::vector<G1Affine> g1) : public_parameter_group_1(std::move(g1)) {
+        check(uzk_srs_register(public_parameter_group_1.data(), public_parameter_group_1.size(), &handle_));
+    }
+    KZGCommitmentSchemeBN254(const KZGCommitmentSchemeBN254&) = delete;
+    KZGCommitmentSchemeBN254& operator=(const KZGCommitmentSchemeBN254&) = delete;
+    ~KZGCommitmentSchemeBN254() { if (handle_) (void)uzk_srs_release(handle_); }
+
+    // u32 len_g1 | u32 len_g2 | len_g1 x (x LE32 || y LE32, flags in the top two bits of the last
+    // byte) | G2 (kzg_poly_commitment.rs:228-264).  Coordinates are canonical in the file and are
+    // converted to Montgomery form on the device.
+    static KZGCommitmentSchemeBN254 from_unchecked_bytes(const std::vector<uint8_t>& bytes) {
+        if (bytes.size() < 8) throw UzkgeException(UzkgeError::DeserializationError, "short SRS blob");
+        uint32_t len1;
+        std::memcpy(&len1, bytes.data(), 4);
+        if (bytes.size() < 8 + 64ull * len1) throw UzkgeException(UzkgeError::DeserializationError, "truncated G1 section");
+        std::vector<uint64_t> canon(8ull * len1), mont(8ull * len1), dummy(8ull * len1, 0);
+        std::vector<bool> inf(len1);
+        for (uint32_t i = 0; i < len1; ++i) {
+            uint8_t rec[64];
+            std::memcpy(rec, bytes.data() + 8 + 64ull * i, 64);
+            inf[i] = (rec[63] & 0x40) != 0;
+            rec[63] &= 0x3F;
+            std::memcpy(&canon[8ull * i], rec, 64);
+        }
+        check(uzk_field_op_device(/*Fq*/ 0, /*to_mont*/ 7, canon.data(), dummy.data(), mont.data(), 2ull * len1));
+        std::vector<G1Affine> g1(len1);
+        for (uint32_t i = 0; i < len1; ++i) {
+            if (inf[i]) { std::memset(&g1[i], 0, sizeof(G1Affine)); continue; }
+            std::memcpy(&g1[i], &mont[8ull * i], 64);
+        }
+        return KZGCommitmentSchemeBN254(std::move(g1));
+    }
+    size_t max_degree() const { return public_parameter_group_1.size() - 1; }
+
+    // kzg_poly_commitment.rs:278-293
+    G1Projective commit(const FpPolynomial& polynomial) const {
+        const size_t degree = polynomial.degree();
+        if (degree + 1 > public_parameter_group_1.size()) throw UzkgeException(UzkgeError::DegreeError, "degree exceeds the SRS");
+        G1Projective out;
+        check(uzk_msm_g1(handle_, 0, reinterpret_cast<const uint64_t*>(polynomial.get_coefs_ref().data()), degree + 1, &out));
+        return out;
+    }
+    uint64_t handle() const { return handle_; }
+
+  private:
+    uint64_t handle_ = 0;
+};
+
+}  // namespace uzkge

@@ -524,13 +524,17 @@ __global__ __launch_bounds__(64) void msm_precompute_kernel(const Affine* __rest
 // ---------------------------------------------------------------------------------------------
 // host
 // ---------------------------------------------------------------------------------------------
+// Window size of the general mode, from a measured sweep (tools/sweep_c.py, MI355X): what matters
+// besides the W*n additions is the population of the TOP window (254 mod c bits): a narrow top
+// window piles n / 2^bits points into each of its few buckets and costs extra fold levels, so only
+// sizes with a wide top window are used (c = 8: 6 bits, c = 15/16: 14 bits).
 static int choose_window_bits(size_t n, int forced) {
     if (forced >= 4 && forced <= 16) return forced;
     int lg = 0;
     while ((1ull << (lg + 1)) <= n) ++lg;
-    int c = lg - 7;
-    if (lg >= 22) c = 16;
-    return std::max(6, std::min(16, c));
+    if (lg <= 18) return 8;
+    if (lg <= 21) return 15;
+    return 16;
 }
 int msm_precompute_window_bits(size_t n, int forced) {
     if (forced >= 4 && forced <= 24) return forced;
