@@ -163,6 +163,12 @@ def main() -> None:
         b.profile_enable(False)
         p2 = b.profile_table()
         kern_ms = sum(v[1] for k, v in p2.items() if k.startswith("ntt_pass")) / reps
+        ntt_traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                ntt_traffic = json.load(f).get("ntt_pass", {}).get(str(args.ntt_log_n), {}).get("traffic_bytes_per_transform")
+        except (OSError, ValueError):
+            ntt_traffic = None
         extra["ntt"] = {
             "metric": "bn254_fr_ntt_elements_per_sec", "log_n": args.ntt_log_n,
             "value": nn / ntt_s, "ms_per_transform": round(ntt_s * 1e3, 4),
@@ -171,7 +177,7 @@ def main() -> None:
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(64.0 * nn / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if kern_ms else 0.0,
                          "hbm_read_frac": round((32.0 * nn / (HBM_PEAK_GBS * 1e9)) / (kern_ms * 1e-3), 5) if kern_ms else 0.0,
-                         "traffic": None},
+                         "traffic": ntt_traffic},
             "kernels": {k: {"launches": v[0], "avg_ms": round(v[1] / max(v[0], 1), 4)} for k, v in sorted(p2.items())},
         }
 
