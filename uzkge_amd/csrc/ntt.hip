@@ -8,11 +8,11 @@
 //  * n = 2^k >= 4096: P = ceil(k/8) Stockham autosort passes of radix R = 2^b (b in 5..8).
 //    A pass needs no transposition kernel: pass p reads x[i + r*N/R] (coalesced over i) and
 //    writes y[m'*S*R + sigma*S + s] (S = product of earlier radices, i = m'*S + s), so after the
-//    last pass the data is in natural order.  One workgroup (256 threads, 4 waves) owns a tile of
+//    last pass the data is in natural order.  One workgroup (512 threads, 8 waves) owns a tile of
 //    T = 2048/R adjacent columns: every global access is a run of T*32 B >= 256 B.
-//    Inside the tile each thread keeps 8 elements in VGPRs and runs radix-8/4/2 register
-//    butterflies; the sub-pass exchanges go through 64 KiB of LDS (two 16-byte planes per
-//    element, conflict-free ds_read/write_b128).  Inter-pass twiddles omega_N^(S*m'*sigma) come
+//    Inside the tile each of the 512 threads keeps 4 elements in VGPRs (four waves per SIMD fit)
+//    and runs radix-4/2 register butterflies; the sub-pass exchanges go through 64 KiB of LDS
+//    (two 16-byte planes per element, conflict-free ds_read/write_b128).  Inter-pass twiddles omega_N^(S*m'*sigma) come
 //    from HBM/L2-resident tables laid out in write order (pass 0's table is N entries and is
 //    streamed, coalesced, exactly once; the 1/n of the inverse transform is folded into it).
 //  * The kernel is bound by 256-bit modular multiplies (about 11 per element at 2^22), not by
@@ -118,20 +118,6 @@ __device__ __forceinline__ void bf2(Fp& a, Fp& b) {
 }
 __device__ __forceinline__ void swap_fp(Fp& a, Fp& b) { Fp t = a; a = b; b = t; }
 
-// X[s] = sum_r x[r] w8^(r s); w1,w2,w3 = w8^1, w8^2, w8^3.  5 multiplications.
-__device__ __forceinline__ void radix8(Fp (&x)[8], const Fp& w1, const Fp& w2, const Fp& w3) {
-    bf2(x[0], x[4]);
-    bf2(x[1], x[5]); x[5] = Fr::mul(x[5], w1);
-    bf2(x[2], x[6]); x[6] = Fr::mul(x[6], w2);
-    bf2(x[3], x[7]); x[7] = Fr::mul(x[7], w3);
-    bf2(x[0], x[2]);
-    bf2(x[1], x[3]); x[3] = Fr::mul(x[3], w2);
-    bf2(x[4], x[6]);
-    bf2(x[5], x[7]); x[7] = Fr::mul(x[7], w2);
-    bf2(x[0], x[1]); bf2(x[2], x[3]); bf2(x[4], x[5]); bf2(x[6], x[7]);
-    swap_fp(x[1], x[4]);
-    swap_fp(x[3], x[6]);
-}
 // size-4 DFT, w4 = w8^2.  1 multiplication.
 __device__ __forceinline__ void radix4(Fp& x0, Fp& x1, Fp& x2, Fp& x3, const Fp& w4) {
     bf2(x0, x2);
@@ -163,82 +149,73 @@ __device__ __forceinline__ Fp lds_get(const uint4* lds, int idx) {
     return v;
 }
 
+// One Stockham pass of radix R = 2^B over a tile of T = 2048/R adjacent columns.  512 threads, four
+// elements per lane (32 VGPRs of data, so four waves per SIMD fit): the size-R transform of a column
+// is itself a Stockham chain of radix-4 register butterflies (plus one radix-2 step when B is odd)
+// whose exchanges go through LDS.  Sub-pass k (radix g, S = product of earlier sub-radices):
+// butterfly ib reads rows ib + t*R/g, writes rows m'*S*g + sigma*S + s (ib = m'*S + s) times
+// omega_R^(S*m'*sigma).
 template <int B, bool FIRST>
-__global__ __launch_bounds__(256) void ntt_pass_kernel(const Fp* __restrict__ in, Fp* __restrict__ out,
+__global__ __launch_bounds__(512) void ntt_pass_kernel(const Fp* __restrict__ in, Fp* __restrict__ out,
                                                        PassArgs a) {
-    constexpr int R = 1 << B, T = 2048 / R, Q = R / 8, SH = 8 - B;
+    constexpr int R = 1 << B, T = 2048 / R, Q = R / 4, SH = 8 - B;
+    constexpr int N4 = B / 2;            // radix-4 sub-passes
+    constexpr bool TAIL2 = (B & 1) != 0; // one final radix-2 sub-pass
     __shared__ uint4 lds[2 * kPlane];
     const int tid = threadIdx.x;
     const int col = tid % T, q = tid / T;
     const uint64_t i0 = (uint64_t)blockIdx.x * T;
     const uint64_t i = i0 + col;
 
-    const Fp w1 = a.tw256[32], w2 = a.tw256[64], w3 = a.tw256[96];
-    Fp x[8];
-    int rows[8];
+    const Fp w4 = a.tw256[64];
+    Fp x[4];
+    int rows[4];
 
-    // ---- sub-pass 1: radix 8 on rows q + t*Q, straight from global memory
+    // ---- sub-pass 0: radix 4 on rows q + t*Q, straight from global memory (S = 1: m' = q, s = 0)
 #pragma unroll
-    for (int t = 0; t < 8; ++t) x[t] = in[i + (uint64_t)(q + t * Q) * a.stride];
-    radix8(x, w1, w2, w3);
+    for (int t = 0; t < 4; ++t) x[t] = in[i + (uint64_t)(q + t * Q) * a.stride];
+    radix4(x[0], x[1], x[2], x[3], w4);
+    if constexpr (N4 > 1 || TAIL2) {
 #pragma unroll
-    for (int s = 1; s < 8; ++s) x[s] = Fr::mul(x[s], a.tw256[(q * s) << SH]);
+        for (int s = 1; s < 4; ++s) x[s] = Fr::mul(x[s], a.tw256[(q * s) << SH]);
+    }
 #pragma unroll
-    for (int s = 0; s < 8; ++s) lds_put(lds, (q * 8 + s) * T + col, x[s]);
-    __syncthreads();
+    for (int s = 0; s < 4; ++s) rows[s] = q * 4 + s;
 
-    // ---- sub-pass 2
-    if constexpr (B == 5) {
-        // two radix-4 butterflies: i2 = q + u*Q, rows i2 + t*8; final rows sigma*8 + i2
+    // ---- radix-4 sub-passes 1 .. N4-1
+#pragma unroll
+    for (int k = 1; k < N4; ++k) {
+        const int S = 1 << (2 * k);
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) lds_put(lds, rows[s] * T + col, x[s]);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) x[t] = lds_get(lds, (q + t * Q) * T + col);
+        radix4(x[0], x[1], x[2], x[3], w4);
+        const int mp = q >> (2 * k), sl = q & (S - 1);
+        const bool more = (R >> (2 * k + 2)) > 1;    // M' = R / (S*4) > 1: further sub-passes follow
+        if (more) {
+#pragma unroll
+            for (int s = 1; s < 4; ++s) x[s] = Fr::mul(x[s], a.tw256[((S * mp * s)) << SH]);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) rows[s] = (mp << (2 * k + 2)) + s * S + sl;
+    }
+    // ---- final radix-2 sub-pass (B odd): S = R/2, butterflies ib = q + u*Q, rows ib and ib + R/2
+    if constexpr (TAIL2) {
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) lds_put(lds, rows[s] * T + col, x[s]);
+        __syncthreads();
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int i2 = q + u * Q;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) x[u * 4 + t] = lds_get(lds, (i2 + t * 8) * T + col);
-            radix4(x[u * 4 + 0], x[u * 4 + 1], x[u * 4 + 2], x[u * 4 + 3], w2);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) rows[u * 4 + s] = s * 8 + i2;
-        }
-    } else {
-        const int mp = q >> 3, sl = q & 7;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) x[t] = lds_get(lds, (q + t * Q) * T + col);
-        radix8(x, w1, w2, w3);
-        if constexpr (B > 6) {
-#pragma unroll
-            for (int s = 1; s < 8; ++s) x[s] = Fr::mul(x[s], a.tw256[(8 * mp * s) << SH]);
-        }
-#pragma unroll
-        for (int s = 0; s < 8; ++s) rows[s] = mp * 64 + s * 8 + sl;
-        if constexpr (B > 6) {
-            __syncthreads();
-#pragma unroll
-            for (int s = 0; s < 8; ++s) lds_put(lds, rows[s] * T + col, x[s]);
-            __syncthreads();
-            // ---- sub-pass 3
-            if constexpr (B == 7) {
-                // four radix-2 butterflies: i3 = q + u*16, rows i3, i3 + 64
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int i3 = q + u * Q;
-                    x[u * 2] = lds_get(lds, i3 * T + col);
-                    x[u * 2 + 1] = lds_get(lds, (i3 + 64) * T + col);
-                    bf2(x[u * 2], x[u * 2 + 1]);
-                    rows[u * 2] = i3;
-                    rows[u * 2 + 1] = i3 + 64;
-                }
-            } else {
-                // two radix-4 butterflies: i3 = q + u*32, rows i3 + t*64; final rows sigma*64 + i3
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int i3 = q + u * Q;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) x[u * 4 + t] = lds_get(lds, (i3 + t * 64) * T + col);
-                    radix4(x[u * 4 + 0], x[u * 4 + 1], x[u * 4 + 2], x[u * 4 + 3], w2);
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) rows[u * 4 + s] = s * 64 + i3;
-                }
-            }
+            const int ib = q + u * Q;
+            x[2 * u] = lds_get(lds, ib * T + col);
+            x[2 * u + 1] = lds_get(lds, (ib + R / 2) * T + col);
+            bf2(x[2 * u], x[2 * u + 1]);
+            rows[2 * u] = ib;
+            rows[2 * u + 1] = ib + R / 2;
         }
     }
 
@@ -248,12 +225,12 @@ __global__ __launch_bounds__(256) void ntt_pass_kernel(const Fp* __restrict__ in
         // contiguous run, multiplied by the streamed pass-0 twiddles.
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 8; ++j) lds_put(lds, col * (R + 1) + rows[j], x[j]);
+        for (int j = 0; j < 4; ++j) lds_put(lds, col * (R + 1) + rows[j], x[j]);
         __syncthreads();
         const uint64_t base = i0 * R;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int e = tid + j * 256;
+        for (int j = 0; j < 4; ++j) {
+            const int e = tid + j * 512;
             const int ce = e / R, re = e % R;
             Fp v = lds_get(lds, ce * (R + 1) + re);
             v = Fr::mul(v, a.twp[base + e]);
@@ -263,7 +240,7 @@ __global__ __launch_bounds__(256) void ntt_pass_kernel(const Fp* __restrict__ in
         const uint64_t mp = i >> a.log_S, sp = i & ((1ull << a.log_S) - 1);
         const uint64_t base = (mp << (a.log_S + B)) + sp;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < 4; ++j) {
             Fp v = x[j];
             if (a.twp != nullptr) v = Fr::mul(v, a.twp[(mp << B) + rows[j]]);
             out[base + ((uint64_t)rows[j] << a.log_S)] = v;
@@ -383,10 +360,10 @@ static void launch_pass(Ctx& c, bool first, const Fp* in, Fp* out, const PassArg
     const unsigned grid = (unsigned)((n / R) / T);
     if (first) {
         KernelScope ks(c, "ntt_pass_first");
-        hipLaunchKernelGGL((ntt_pass_kernel<B, true>), dim3(grid), dim3(256), 0, c.stream, in, out, a);
+        hipLaunchKernelGGL((ntt_pass_kernel<B, true>), dim3(grid), dim3(512), 0, c.stream, in, out, a);
     } else {
         KernelScope ks(c, "ntt_pass");
-        hipLaunchKernelGGL((ntt_pass_kernel<B, false>), dim3(grid), dim3(256), 0, c.stream, in, out, a);
+        hipLaunchKernelGGL((ntt_pass_kernel<B, false>), dim3(grid), dim3(512), 0, c.stream, in, out, a);
     }
 }
 
