@@ -81,6 +81,14 @@ int uzk_msm_g1(uint64_t srs_handle, size_t offset, const uint64_t* scalars_mont,
 /* Same with the scalars already resident in device memory (the bench / pipelined path). */
 int uzk_msm_g1_device(uint64_t srs_handle, size_t offset, const void* d_scalars_mont, size_t n,
                       uzk_g1_jac* out);
+/* `batch` scalar vectors of n elements each (scalars[b*n + i]) against the SAME bases
+ * SRS[offset .. offset+n): out[b] = sum_i scalars[b][i] * SRS[offset+i].  One launch sequence for
+ * the prover's independent commits (5 wires + 3 selectors, prover.rs:160-192; the 5 chunks of t,
+ * helpers.rs:1390); shorter polynomials are zero-padded by the caller. */
+int uzk_msm_g1_batch(uint64_t srs_handle, size_t offset, const uint64_t* scalars_mont, size_t n, uint32_t batch,
+                     uzk_g1_jac* out);
+int uzk_msm_g1_batch_device(uint64_t srs_handle, size_t offset, const void* d_scalars_mont, size_t n,
+                            uint32_t batch, uzk_g1_jac* out);
 /* One-shot, nothing cached: points and scalars are host arrays of the same length. */
 int uzk_msm_g1_raw(const uzk_g1_affine* points, const uint64_t* scalars_mont, size_t n,
                    uzk_g1_jac* out);
@@ -106,6 +114,13 @@ int uzk_ntt_fr(uint64_t* data, uint64_t n, int inverse, const uint64_t* coset_sh
  * unless `sync` != 0. */
 int uzk_ntt_fr_device(const void* d_in, void* d_out, uint64_t n, int inverse,
                       const uint64_t* coset_shift_mont, int sync);
+
+/* `batch` independent transforms of the same size over contiguous vectors (the prover's 5 wire +
+ * 3 selector iFFTs, prover.rs:160-192, or the ten coset FFTs of t_poly, helpers.rs:256-266, in one
+ * launch sequence instead of 8-10). */
+int uzk_ntt_fr_batch(uint64_t* data, uint64_t n, uint32_t batch, int inverse, const uint64_t* coset_shift_mont);
+int uzk_ntt_fr_batch_device(const void* d_in, void* d_out, uint64_t n, uint32_t batch, int inverse,
+                            const uint64_t* coset_shift_mont, int sync);
 
 /* ---- synthetic workloads (bench / tests; generated on device, nothing uploaded) -------- */
 /* d_points[i] = (i + 1) * Q with Q = seed_scalar * G: n distinct valid G1 points whose discrete

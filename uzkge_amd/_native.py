@@ -32,6 +32,8 @@ PROTOTYPES = {
     "uzk_srs_len": (_I, [_U64, ctypes.POINTER(_SZ)]),
     "uzk_msm_g1": (_I, [_U64, _SZ, _P, _SZ, _P]),
     "uzk_msm_g1_device": (_I, [_U64, _SZ, _P, _SZ, _P]),
+    "uzk_msm_g1_batch": (_I, [_U64, _SZ, _P, _SZ, ctypes.c_uint32, _P]),
+    "uzk_msm_g1_batch_device": (_I, [_U64, _SZ, _P, _SZ, ctypes.c_uint32, _P]),
     "uzk_msm_g1_raw": (_I, [_P, _P, _SZ, _P]),
     "uzk_g1_fold": (_I, [_P, _SZ, _P]),
     "uzk_g1_to_affine": (_I, [_P, _P]),
@@ -39,6 +41,8 @@ PROTOTYPES = {
     "uzk_domain_group_gen": (_I, [_U64, _P]),
     "uzk_ntt_fr": (_I, [_P, _U64, _I, _P]),
     "uzk_ntt_fr_device": (_I, [_P, _P, _U64, _I, _P, _I]),
+    "uzk_ntt_fr_batch": (_I, [_P, _U64, ctypes.c_uint32, _I, _P]),
+    "uzk_ntt_fr_batch_device": (_I, [_P, _P, _U64, ctypes.c_uint32, _I, _P, _I]),
     "uzk_synth_points_arith": (_I, [_P, _SZ, _P]),
     "uzk_synth_points_random": (_I, [_P, _SZ, _U64]),
     "uzk_synth_scalars": (_I, [_P, _SZ, _U64]),

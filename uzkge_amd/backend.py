@@ -78,6 +78,21 @@ def msm_device(srs: Srs, d_scalars: int, n: int, offset: int = 0) -> np.ndarray:
     return out
 
 
+def msm_batch(srs: Srs, scalars: np.ndarray, offset: int = 0) -> np.ndarray:
+    """scalars [batch, n, 4] against the same bases -> [batch, 12] Jacobian results."""
+    s = np.ascontiguousarray(scalars, dtype=np.uint64)
+    assert s.ndim == 3 and s.shape[2] == 4
+    out = np.zeros((s.shape[0], 12), dtype=np.uint64)
+    check(lib.uzk_msm_g1_batch(srs.handle, offset, _ptr(s) if s.size else None, s.shape[1], s.shape[0], _ptr(out)))
+    return out
+
+
+def msm_batch_device(srs: Srs, d_scalars: int, n: int, batch: int, offset: int = 0) -> np.ndarray:
+    out = np.zeros((batch, 12), dtype=np.uint64)
+    check(lib.uzk_msm_g1_batch_device(srs.handle, offset, ctypes.c_void_p(d_scalars), n, batch, _ptr(out)))
+    return out
+
+
 def msm_raw(points: np.ndarray, scalars: np.ndarray) -> np.ndarray:
     p = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 8)
     s = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
@@ -123,6 +138,26 @@ def ntt(data: np.ndarray, inverse: bool = False, coset_shift: Optional[np.ndarra
         cs = np.ascontiguousarray(coset_shift, dtype=np.uint64).reshape(4)
     check(lib.uzk_ntt_fr(_ptr(a), a.shape[0], int(inverse), _ptr(cs) if cs is not None else None))
     return a
+
+
+def ntt_batch(data: np.ndarray, inverse: bool = False, coset_shift: Optional[np.ndarray] = None) -> np.ndarray:
+    """`data` [batch, n, 4]: batch independent transforms of size n in one call."""
+    a = np.ascontiguousarray(data, dtype=np.uint64).copy()
+    assert a.ndim == 3 and a.shape[2] == 4
+    cs = None
+    if coset_shift is not None:
+        cs = np.ascontiguousarray(coset_shift, dtype=np.uint64).reshape(4)
+    check(lib.uzk_ntt_fr_batch(_ptr(a), a.shape[1], a.shape[0], int(inverse), _ptr(cs) if cs is not None else None))
+    return a
+
+
+def ntt_batch_device(d_in: int, d_out: int, n: int, batch: int, inverse: bool = False,
+                     coset_shift: Optional[np.ndarray] = None, sync: bool = False) -> None:
+    cs = None
+    if coset_shift is not None:
+        cs = np.ascontiguousarray(coset_shift, dtype=np.uint64).reshape(4)
+    check(lib.uzk_ntt_fr_batch_device(ctypes.c_void_p(d_in), ctypes.c_void_p(d_out), n, batch, int(inverse),
+                                      _ptr(cs) if cs is not None else None, int(sync)))
 
 
 def ntt_device(d_in: int, d_out: int, n: int, inverse: bool = False, coset_shift: Optional[np.ndarray] = None,

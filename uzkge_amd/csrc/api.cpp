@@ -272,11 +272,11 @@ static int msm_checked(uint64_t srs_handle, size_t offset, size_t n, const Ctx::
     return UZK_OK;
 }
 // general mode unless the handle carries a window table
-static int msm_dispatch(const Ctx::Srs& s, size_t offset, const Fp* d_scalars, size_t n, Jac* out) {
+static int msm_dispatch(const Ctx::Srs& s, size_t offset, const Fp* d_scalars, size_t n, uint32_t batch, Jac* out) {
     Ctx& c = ctx();
     if (s.d_table && !c.tune_no_precompute)
-        return msm_run(c, s.d_table, d_scalars, n, out, s.pre_c, (uint32_t)s.n, (uint32_t)offset);
-    return msm_run(c, s.d_points + offset, d_scalars, n, out, 0, 0, 0);
+        return msm_run(c, s.d_table, d_scalars, n, batch, out, s.pre_c, (uint32_t)s.n, (uint32_t)offset);
+    return msm_run(c, s.d_points + offset, d_scalars, n, batch, out, 0, 0, 0);
 }
 
 int uzk_msm_g1_device(uint64_t srs_handle, size_t offset, const void* d_scalars_mont, size_t n, uzk_g1_jac* out) {
@@ -286,7 +286,7 @@ int uzk_msm_g1_device(uint64_t srs_handle, size_t offset, const void* d_scalars_
     const Ctx::Srs* srs = nullptr;
     UZK_TRY(msm_checked(srs_handle, offset, n, &srs));
     Jac r;
-    UZK_TRY(msm_dispatch(*srs, offset, static_cast<const Fp*>(d_scalars_mont), n, &r));
+    UZK_TRY(msm_dispatch(*srs, offset, static_cast<const Fp*>(d_scalars_mont), n, 1, &r));
     std::memcpy(out, &r, sizeof r);
     return UZK_OK;
 }
@@ -302,9 +302,41 @@ int uzk_msm_g1(uint64_t srs_handle, size_t offset, const uint64_t* scalars_mont,
     if (n > 0) {
         UZK_TRY(c.msm_scalars.reserve(n * sizeof(Fp)));
         UZK_HIP(hipMemcpyAsync(c.msm_scalars.p, scalars_mont, n * sizeof(Fp), hipMemcpyHostToDevice, c.stream));
-        UZK_TRY(msm_dispatch(*srs, offset, c.msm_scalars.as<Fp>(), n, &r));
+        UZK_TRY(msm_dispatch(*srs, offset, c.msm_scalars.as<Fp>(), n, 1, &r));
     }
     std::memcpy(out, &r, sizeof r);
+    return UZK_OK;
+}
+
+int uzk_msm_g1_batch_device(uint64_t srs_handle, size_t offset, const void* d_scalars_mont, size_t n, uint32_t batch,
+                            uzk_g1_jac* out) {
+    API_LOCK;
+    if (batch > 0 && (!out || (n > 0 && !d_scalars_mont))) { set_error("uzk_msm_g1_batch_device: null pointer"); return UZK_ERR_PARAMETER; }
+    UZK_TRY(require_ready());
+    const Ctx::Srs* srs = nullptr;
+    UZK_TRY(msm_checked(srs_handle, offset, n, &srs));
+    std::vector<Jac> r(batch);
+    UZK_TRY(msm_dispatch(*srs, offset, static_cast<const Fp*>(d_scalars_mont), n, batch, r.data()));
+    if (batch) std::memcpy(out, r.data(), (size_t)batch * sizeof(Jac));
+    return UZK_OK;
+}
+
+int uzk_msm_g1_batch(uint64_t srs_handle, size_t offset, const uint64_t* scalars_mont, size_t n, uint32_t batch,
+                     uzk_g1_jac* out) {
+    API_LOCK;
+    if (batch > 0 && (!out || (n > 0 && !scalars_mont))) { set_error("uzk_msm_g1_batch: null pointer"); return UZK_ERR_PARAMETER; }
+    UZK_TRY(require_ready());
+    Ctx& c = ctx();
+    const Ctx::Srs* srs = nullptr;
+    UZK_TRY(msm_checked(srs_handle, offset, n, &srs));
+    std::vector<Jac> r(batch, jac_inf());
+    if (n > 0 && batch > 0) {
+        const size_t bytes = (size_t)n * batch * sizeof(Fp);
+        UZK_TRY(c.msm_scalars.reserve(bytes));
+        UZK_HIP(hipMemcpyAsync(c.msm_scalars.p, scalars_mont, bytes, hipMemcpyHostToDevice, c.stream));
+        UZK_TRY(msm_dispatch(*srs, offset, c.msm_scalars.as<Fp>(), n, batch, r.data()));
+    }
+    if (batch) std::memcpy(out, r.data(), (size_t)batch * sizeof(Jac));
     return UZK_OK;
 }
 
@@ -351,38 +383,55 @@ int uzk_domain_group_gen(uint64_t n, uint64_t out_mont[4]) {
     return UZK_OK;
 }
 
-int uzk_ntt_fr_device(const void* d_in, void* d_out, uint64_t n, int inverse, const uint64_t* coset_shift_mont, int sync) {
-    API_LOCK;
+static int ntt_device_common(const void* d_in, void* d_out, uint64_t n, uint32_t batch, int inverse,
+                             const uint64_t* coset_shift_mont, int sync) {
     if (!domain_supported(n)) {
         set_error("no evaluation domain of size %llu (need 2^k, k<=28, or 3*2^k)", (unsigned long long)n);
         return UZK_ERR_FFT;
     }
-    if (!d_in || !d_out) { set_error("uzk_ntt_fr_device: null pointer"); return UZK_ERR_PARAMETER; }
+    if (!d_in || !d_out) { set_error("uzk_ntt_fr*_device: null pointer"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
     Ctx& c = ctx();
     UZK_TRY(ntt_run(c, static_cast<const Fp*>(d_in), static_cast<Fp*>(d_out), n, inverse != 0,
-                    coset_shift_mont ? as_fp(coset_shift_mont) : nullptr));
+                    coset_shift_mont ? as_fp(coset_shift_mont) : nullptr, batch));
     if (sync) UZK_HIP(hipStreamSynchronize(c.stream));
     return UZK_OK;
 }
-
-int uzk_ntt_fr(uint64_t* data, uint64_t n, int inverse, const uint64_t* coset_shift_mont) {
-    API_LOCK;
+static int ntt_host_common(uint64_t* data, uint64_t n, uint32_t batch, int inverse, const uint64_t* coset_shift_mont) {
     if (!domain_supported(n)) {
         set_error("no evaluation domain of size %llu (need 2^k, k<=28, or 3*2^k)", (unsigned long long)n);
         return UZK_ERR_FFT;
     }
-    if (!data) { set_error("uzk_ntt_fr: null pointer"); return UZK_ERR_PARAMETER; }
+    if (!data) { set_error("uzk_ntt_fr*: null pointer"); return UZK_ERR_PARAMETER; }
+    if (batch == 0) return UZK_OK;
     UZK_TRY(require_ready());
     Ctx& c = ctx();
-    const size_t bytes = (size_t)n * sizeof(Fp);
+    const size_t bytes = (size_t)n * batch * sizeof(Fp);
     UZK_TRY(c.ntt_io.reserve(bytes));
     UZK_HIP(hipMemcpyAsync(c.ntt_io.p, data, bytes, hipMemcpyHostToDevice, c.stream));
     UZK_TRY(ntt_run(c, c.ntt_io.as<Fp>(), c.ntt_io.as<Fp>(), n, inverse != 0,
-                    coset_shift_mont ? as_fp(coset_shift_mont) : nullptr));
+                    coset_shift_mont ? as_fp(coset_shift_mont) : nullptr, batch));
     UZK_HIP(hipMemcpyAsync(data, c.ntt_io.p, bytes, hipMemcpyDeviceToHost, c.stream));
     UZK_HIP(hipStreamSynchronize(c.stream));
     return UZK_OK;
+}
+
+int uzk_ntt_fr_device(const void* d_in, void* d_out, uint64_t n, int inverse, const uint64_t* coset_shift_mont, int sync) {
+    API_LOCK;
+    return ntt_device_common(d_in, d_out, n, 1, inverse, coset_shift_mont, sync);
+}
+int uzk_ntt_fr_batch_device(const void* d_in, void* d_out, uint64_t n, uint32_t batch, int inverse,
+                            const uint64_t* coset_shift_mont, int sync) {
+    API_LOCK;
+    return ntt_device_common(d_in, d_out, n, batch, inverse, coset_shift_mont, sync);
+}
+int uzk_ntt_fr(uint64_t* data, uint64_t n, int inverse, const uint64_t* coset_shift_mont) {
+    API_LOCK;
+    return ntt_host_common(data, n, 1, inverse, coset_shift_mont);
+}
+int uzk_ntt_fr_batch(uint64_t* data, uint64_t n, uint32_t batch, int inverse, const uint64_t* coset_shift_mont) {
+    API_LOCK;
+    return ntt_host_common(data, n, batch, inverse, coset_shift_mont);
 }
 
 /* ---- synthetic workloads ------------------------------------------------------------------ */

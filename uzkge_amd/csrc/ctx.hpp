@@ -101,9 +101,9 @@ struct KernelScope {
 };
 
 // entry points implemented in the .hip files
-int ntt_run(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse, const Fp* coset_shift_host);
+int ntt_run(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse, const Fp* coset_shift_host, uint32_t batch);
 void ntt_free_plans(Ctx& c);
-int msm_run(Ctx& c, const Affine* points, const Fp* d_scalars, size_t n, Jac* out_host, int pre_c,
+int msm_run(Ctx& c, const Affine* points, const Fp* d_scalars, size_t n, uint32_t batch, Jac* out_host, int pre_c,
             uint32_t pre_stride, uint32_t pre_off);
 int msm_build_table(Ctx& c, const Affine* d_points, size_t n, int cb, Affine** table_out, uint32_t* W_out);
 int msm_precompute_window_bits(size_t n, int forced);

@@ -56,13 +56,16 @@ __host__ __device__ inline int msm_num_windows(int c) {
 }
 
 // ---- 1. digits -------------------------------------------------------------------------------
+// scalars: [batch][n]; digits: [batch][W][n]
 __global__ __launch_bounds__(256) void msm_digits_kernel(const Fp* __restrict__ scalars, uint32_t* __restrict__ digits,
-                                                         uint32_t n, int c, int W) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Fp k = Fr::from_mont(scalars[i]);
+                                                         uint32_t n, uint32_t batch, int c, int W) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (uint64_t)n * batch) return;
+    const uint32_t b = (uint32_t)(t / n), i = (uint32_t)(t % n);
+    Fp k = Fr::from_mont(scalars[t]);
     const uint32_t mask = (1u << c) - 1, half = 1u << (c - 1);
     uint32_t carry = 0;
+    uint32_t* dst = digits + (size_t)b * W * n + i;
     for (int w = 0; w < W; ++w) {
         uint32_t d = (k.v[0] & mask) + carry;
         // k >>= c
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(256) void msm_digits_kernel(const Fp* __restrict__ 
         uint32_t out;
         if (d > half) { out = ((1u << c) - d) | kSignBit; carry = 1; }
         else { out = d; carry = 0; }
-        digits[(size_t)w * n + i] = out;
+        dst[(size_t)w * n] = out;
     }
 }
 
@@ -597,9 +600,11 @@ struct SortPass { uint32_t shift, bins, nseg, nch; };
 
 // `points`: base array the sorted indices refer to (the SRS slice, or the window table).
 // Precomputed mode (pre_c > 0): `points` = table, entries of window j index pre_stride * j + pre_off + i.
-int msm_run(Ctx& c, const Affine* points, const Fp* d_scalars, size_t n, Jac* out_host, int pre_c,
+// `batch` scalar vectors of n elements each share the same bases; out_host[batch].
+int msm_run(Ctx& c, const Affine* points, const Fp* d_scalars, size_t n, uint32_t batch, Jac* out_host, int pre_c,
             uint32_t pre_stride, uint32_t pre_off) {
-    if (n == 0) { *out_host = jac_inf(); return UZK_OK; }
+    if (batch == 0) return UZK_OK;
+    if (n == 0) { for (uint32_t b = 0; b < batch; ++b) out_host[b] = jac_inf(); return UZK_OK; }
     if (n >= (1ull << 31)) { set_error("msm: n = %zu exceeds 2^31 - 1 points per call", n); return UZK_ERR_PARAMETER; }
     if (!c.msm) c.msm = new MsmWork();
     MsmWork& m = *c.msm;
@@ -607,20 +612,21 @@ int msm_run(Ctx& c, const Affine* points, const Fp* d_scalars, size_t n, Jac* ou
     const int cb = pre ? pre_c : choose_window_bits(n, c.msm_window_bits);
     const uint32_t W = (uint32_t)msm_num_windows(cb);
     const uint32_t n32 = (uint32_t)n;
-    const uint64_t entries = (uint64_t)W * n;
-    if (entries >= (1ull << 31)) { set_error("msm: W*n overflows the 31-bit index space"); return UZK_ERR_PARAMETER; }
+    const uint64_t per_poly = (uint64_t)W * n;                 // (point, window) pairs of one scalar vector
+    const uint64_t entries = per_poly * batch;
+    if (entries >= (1ull << 31)) { set_error("msm: batch*W*n overflows the 31-bit index space"); return UZK_ERR_PARAMETER; }
     const uint32_t kb = (uint32_t)cb - 1;                  // bucket key bits
     const uint32_t NBL = 1u << kb;                         // buckets of one logical window
     // sort segments: one per window (general) or one for everything (precomputed)
-    const uint32_t S0 = pre ? 1u : W;
-    const uint32_t seg_n = pre ? (uint32_t)entries : n32;  // entries per initial segment
+    const uint32_t S0 = pre ? batch : batch * W;
+    const uint32_t seg_n = pre ? (uint32_t)per_poly : n32;  // entries per initial segment
     // bucket windows as seen by the scan / task kernels: <= 2^15 buckets each
     const uint32_t NB = std::min<uint32_t>(NBL, 1u << 15);
     const uint32_t Wd = (uint32_t)(((uint64_t)S0 * NBL) / NB);
     const uint64_t TBK = (uint64_t)Wd * NB;                // all buckets
-    if (Wd > 1024) { set_error("msm: too many bucket windows (%u)", Wd); return UZK_ERR_PARAMETER; }
+    if (Wd > 1024) { set_error("msm: too many bucket windows (%u): lower the batch", Wd); return UZK_ERR_PARAMETER; }
     // reduction geometry: `seg` buckets per lane, 256 lanes per group
-    const uint32_t RW = pre ? 1u : W;                      // logical windows in the reduction
+    const uint32_t RW = pre ? batch : batch * W;            // logical windows in the reduction
     const uint32_t seg = std::max<uint32_t>(1, std::min<uint32_t>(kSeg, NBL / 256));
     const uint32_t groups = (NBL + seg * 256 - 1) / (seg * 256);
     const uint32_t L = c.tune_task_len > 0 ? (uint32_t)c.tune_task_len
@@ -690,7 +696,9 @@ int msm_run(Ctx& c, const Affine* points, const Fp* d_scalars, size_t n, Jac* ou
     UZK_HIP(hipMemsetAsync(d_max, 0, 4, st));
     {
         KernelScope ks(c, "msm_digits");
-        hipLaunchKernelGGL(msm_digits_kernel, dim3((n32 + 255) / 256), dim3(256), 0, st, d_scalars, digits, n32, cb, (int)W);
+        const uint64_t tot = (uint64_t)n32 * batch;
+        hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_scalars, digits, n32,
+                           batch, cb, (int)W);
     }
     // ---- counting sort, high bits first
     for (int p = 0; p < P; ++p) {
@@ -797,13 +805,17 @@ int msm_run(Ctx& c, const Affine* points, const Fp* d_scalars, size_t n, Jac* ou
     UZK_HIP(hipMemcpyAsync(m.h_sums, win_sums, (size_t)RW * sizeof(XYZZ), hipMemcpyDeviceToHost, st));
     UZK_HIP(hipStreamSynchronize(st));
 
-    // 7. host: Horner over the logical windows (c doublings per step); one window when precomputed
-    XYZZ total = xyzz_inf();
-    for (int w = (int)RW - 1; w >= 0; --w) {
-        if (w != (int)RW - 1) for (int d = 0; d < cb; ++d) total = xyzz_dbl(total);
-        xyzz_add(total, m.h_sums[w]);
+    // 7. host: per scalar vector, Horner over its logical windows (c doublings per step); one window
+    //    each when precomputed
+    const uint32_t wpp = pre ? 1u : W;
+    for (uint32_t b = 0; b < batch; ++b) {
+        XYZZ total = xyzz_inf();
+        for (int w = (int)wpp - 1; w >= 0; --w) {
+            if (w != (int)wpp - 1) for (int d = 0; d < cb; ++d) total = xyzz_dbl(total);
+            xyzz_add(total, m.h_sums[(size_t)b * wpp + w]);
+        }
+        out_host[b] = xyzz_to_jac(total);
     }
-    *out_host = xyzz_to_jac(total);
     return UZK_OK;
 }
 

@@ -128,6 +128,7 @@ __device__ __forceinline__ void radix4(Fp& x0, Fp& x1, Fp& x2, Fp& x3, const Fp&
 }
 
 struct PassArgs {
+    uint64_t batch_stride; // elements between consecutive vectors of a batch (= N)
     uint64_t stride;       // N / R
     int log_S;             // log2 of the product of earlier radices
     const Fp* tw256;       // omega_256^e, direction-specific
@@ -166,6 +167,8 @@ __global__ __launch_bounds__(512) void ntt_pass_kernel(const Fp* __restrict__ in
     const int col = tid % T, q = tid / T;
     const uint64_t i0 = (uint64_t)blockIdx.x * T;
     const uint64_t i = i0 + col;
+    in += (uint64_t)blockIdx.y * a.batch_stride;     // batch of independent transforms
+    out += (uint64_t)blockIdx.y * a.batch_stride;
 
     const Fp w4 = a.tw256[64];
     Fp x[4];
@@ -256,6 +259,8 @@ __global__ __launch_bounds__(256) void ntt_scale_pows_kernel(const Fp* __restric
                                                              uint64_t n, const Fp* __restrict__ pw) {
     uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
+    in += (uint64_t)blockIdx.y * n;
+    out += (uint64_t)blockIdx.y * n;
     Fp g = Fr::mul(pw[j & 1023], pw[1024 + ((j >> 10) & 1023)]);
     g = Fr::mul(g, pw[2048 + (j >> 20)]);
     out[j] = Fr::mul(in[j], g);
@@ -264,6 +269,8 @@ __global__ __launch_bounds__(256) void ntt_scale_pows_kernel(const Fp* __restric
 __global__ __launch_bounds__(256) void ntt_decimate3_kernel(const Fp* __restrict__ in, Fp* __restrict__ sub, uint64_t m) {
     uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= 3 * m) return;
+    in += (uint64_t)blockIdx.y * 3 * m;
+    sub += (uint64_t)blockIdx.y * 3 * m;
     uint64_t j = idx / 3, k = idx % 3;
     sub[k * m + j] = in[idx];
 }
@@ -272,6 +279,8 @@ __global__ __launch_bounds__(256) void ntt_combine3_kernel(const Fp* __restrict_
                                                            const Fp* __restrict__ pw, Fp scale, int use_scale) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 3 * m) return;
+    sub += (uint64_t)blockIdx.y * 3 * m;
+    out += (uint64_t)blockIdx.y * 3 * m;
     uint64_t j = i % m;
     Fp w = Fr::mul(pw[i & 1023], pw[1024 + ((i >> 10) & 1023)]);
     w = Fr::mul(w, pw[2048 + (i >> 20)]);
@@ -342,6 +351,7 @@ static int get_plan(Ctx& c, uint64_t n, bool inverse, bool scaled, NttPlan** out
     return UZK_OK;
 }
 
+static void release_ntt_caches();
 void ntt_free_plans(Ctx& c) {
     for (auto& kv : c.ntt_plans) {
         NttPlan* p = kv.second;
@@ -352,34 +362,36 @@ void ntt_free_plans(Ctx& c) {
         delete p;
     }
     c.ntt_plans.clear();
+    release_ntt_caches();
 }
 
 template <int B>
-static void launch_pass(Ctx& c, bool first, const Fp* in, Fp* out, const PassArgs& a, uint64_t n) {
+static void launch_pass(Ctx& c, bool first, const Fp* in, Fp* out, const PassArgs& a, uint64_t n, uint32_t batch) {
     constexpr int R = 1 << B, T = 2048 / R;
     const unsigned grid = (unsigned)((n / R) / T);
     if (first) {
         KernelScope ks(c, "ntt_pass_first");
-        hipLaunchKernelGGL((ntt_pass_kernel<B, true>), dim3(grid), dim3(512), 0, c.stream, in, out, a);
+        hipLaunchKernelGGL((ntt_pass_kernel<B, true>), dim3(grid, batch), dim3(512), 0, c.stream, in, out, a);
     } else {
         KernelScope ks(c, "ntt_pass");
-        hipLaunchKernelGGL((ntt_pass_kernel<B, false>), dim3(grid), dim3(512), 0, c.stream, in, out, a);
+        hipLaunchKernelGGL((ntt_pass_kernel<B, false>), dim3(grid, batch), dim3(512), 0, c.stream, in, out, a);
     }
 }
 
 // power-of-two transform d_in -> d_out (may alias)
-static int ntt_pow2(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse, bool scaled) {
+// `batch` contiguous vectors of n elements each, d_in -> d_out (may alias)
+static int ntt_pow2(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse, bool scaled, uint32_t batch) {
     NttPlan* p = nullptr;
     UZK_TRY(get_plan(c, n, inverse, scaled, &p));
     if (p->log_n <= 11) {
         KernelScope ks(c, "ntt_small");
         const size_t shmem = (size_t)n * sizeof(Fp);
-        hipLaunchKernelGGL(ntt_small_kernel, dim3(1), dim3(256), shmem, c.stream, d_in, d_out, p->log_n,
+        hipLaunchKernelGGL(ntt_small_kernel, dim3(batch), dim3(256), shmem, c.stream, d_in, d_out, p->log_n,
                            p->d_small_tw, p->scale, scaled ? 1 : 0);
         UZK_HIP(hipGetLastError());
         return UZK_OK;
     }
-    const size_t bytes = (size_t)n * sizeof(Fp);
+    const size_t bytes = (size_t)n * batch * sizeof(Fp);
     UZK_TRY(c.ntt_scratch[0].reserve(bytes));
     Fp* s0 = c.ntt_scratch[0].as<Fp>();
     Fp* s1 = nullptr;
@@ -397,16 +409,17 @@ static int ntt_pow2(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse,
         Fp* dst = (remaining % 2 == 0) ? d_out : s0;
         if (dst == src) dst = s1;   // only when in_place and npass is odd, at j == 0
         PassArgs a;
+        a.batch_stride = n;
         a.stride = n >> p->bits[j];
         a.log_S = log_S;
         a.tw256 = p->d_tw256;
         a.twp = p->d_tw_pass[j];
         const bool first = (j == 0);
         switch (p->bits[j]) {
-            case 5: launch_pass<5>(c, first, src, dst, a, n); break;
-            case 6: launch_pass<6>(c, first, src, dst, a, n); break;
-            case 7: launch_pass<7>(c, first, src, dst, a, n); break;
-            case 8: launch_pass<8>(c, first, src, dst, a, n); break;
+            case 5: launch_pass<5>(c, first, src, dst, a, n, batch); break;
+            case 6: launch_pass<6>(c, first, src, dst, a, n, batch); break;
+            case 7: launch_pass<7>(c, first, src, dst, a, n, batch); break;
+            case 8: launch_pass<8>(c, first, src, dst, a, n, batch); break;
             default: set_error("ntt: bad radix bits %d", p->bits[j]); return UZK_ERR_FFT;
         }
         UZK_HIP(hipGetLastError());
@@ -424,6 +437,13 @@ struct PowCache {
     DevBuf buf;
 };
 static PowCache g_coset_cache, g_mixed_cache[2];
+static DevBuf g_sub;   // decimated sub-vectors of the 3 * 2^k path
+
+static void release_ntt_caches() {
+    g_coset_cache.buf.release(); g_coset_cache.valid = false;
+    for (auto& m : g_mixed_cache) { m.buf.release(); m.valid = false; }
+    g_sub.release();
+}
 
 static int pow_table_device(Ctx& c, PowCache& pc, const Fp& g, const Fp** out) {
     if (!pc.valid || !Fr::eq(pc.key, g)) {
@@ -439,47 +459,48 @@ static int pow_table_device(Ctx& c, PowCache& pc, const Fp& g, const Fp** out) {
     return UZK_OK;
 }
 
-int ntt_run(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse, const Fp* coset_shift_host) {
+// `batch` independent transforms over contiguous vectors of n elements (d_in -> d_out, may alias).
+int ntt_run(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse, const Fp* coset_shift_host, uint32_t batch) {
     if (!domain_supported(n)) {
         set_error("no evaluation domain of size %llu (need 2^k, k<=28, or 3*2^k)", (unsigned long long)n);
         return UZK_ERR_FFT;
     }
-    const unsigned eblocks = (unsigned)((n + 255) / 256);
+    if (batch == 0) return UZK_OK;
+    if (batch > 65535) { set_error("ntt: batch %u exceeds 65535", batch); return UZK_ERR_PARAMETER; }
+    const dim3 egrid((unsigned)((n + 255) / 256), batch);
     const Fp* src = d_in;
     if (coset_shift_host != nullptr && !inverse) {
         const Fp* pw = nullptr;
         UZK_TRY(pow_table_device(c, g_coset_cache, *coset_shift_host, &pw));
         KernelScope ks(c, "ntt_scale_pows");
-        hipLaunchKernelGGL(ntt_scale_pows_kernel, dim3(eblocks), dim3(256), 0, c.stream, src, d_out, n, pw);
+        hipLaunchKernelGGL(ntt_scale_pows_kernel, egrid, dim3(256), 0, c.stream, src, d_out, n, pw);
         src = d_out;
     }
     if (n % 3 != 0) {
-        UZK_TRY(ntt_pow2(c, src, d_out, n, inverse, inverse));
+        UZK_TRY(ntt_pow2(c, src, d_out, n, inverse, inverse, batch));
     } else {
+        // decimation in time by 3: per vector, sub[k][j] = x[3j + k]; 3*batch transforms of size m
         const uint64_t m = n / 3;
-        UZK_TRY(c.ntt_io.reserve(0));   // no-op; keeps the staging buffer untouched
-        static DevBuf sub;              // 3 * m decimated / transformed sub-vectors
-        UZK_TRY(sub.reserve((size_t)n * sizeof(Fp)));
-        Fp* s = sub.as<Fp>();
+        UZK_TRY(g_sub.reserve((size_t)n * batch * sizeof(Fp)));
+        Fp* s = g_sub.as<Fp>();
         {
             KernelScope ks(c, "ntt_decimate3");
-            hipLaunchKernelGGL(ntt_decimate3_kernel, dim3(eblocks), dim3(256), 0, c.stream, src, s, m);
+            hipLaunchKernelGGL(ntt_decimate3_kernel, egrid, dim3(256), 0, c.stream, src, s, m);
         }
-        for (int k = 0; k < 3; ++k) UZK_TRY(ntt_pow2(c, s + k * m, s + k * m, m, inverse, false));
+        UZK_TRY(ntt_pow2(c, s, s, m, inverse, false, 3 * batch));
         Fp w = fr_root_of_unity(n);
         if (inverse) w = fr_inv(w);
         const Fp* pw = nullptr;
         UZK_TRY(pow_table_device(c, g_mixed_cache[inverse ? 1 : 0], w, &pw));
         Fp scale = inverse ? fr_inv(fr_from_u64(n)) : Fr::one();
         KernelScope ks(c, "ntt_combine3");
-        hipLaunchKernelGGL(ntt_combine3_kernel, dim3(eblocks), dim3(256), 0, c.stream, s, d_out, m, pw, scale,
-                           inverse ? 1 : 0);
+        hipLaunchKernelGGL(ntt_combine3_kernel, egrid, dim3(256), 0, c.stream, s, d_out, m, pw, scale, inverse ? 1 : 0);
     }
     if (coset_shift_host != nullptr && inverse) {
         const Fp* pw = nullptr;
         UZK_TRY(pow_table_device(c, g_coset_cache, *coset_shift_host, &pw));
         KernelScope ks(c, "ntt_scale_pows");
-        hipLaunchKernelGGL(ntt_scale_pows_kernel, dim3(eblocks), dim3(256), 0, c.stream, d_out, d_out, n, pw);
+        hipLaunchKernelGGL(ntt_scale_pows_kernel, egrid, dim3(256), 0, c.stream, d_out, d_out, n, pw);
     }
     UZK_HIP(hipGetLastError());
     return UZK_OK;
