@@ -39,6 +39,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
     ap.add_argument("--window-bits", type=int, default=0)
+    ap.add_argument("--no-extras", action="store_true", help="skip the window-table and prover-shape extras")
     args = ap.parse_args()
 
     import numpy as np
@@ -180,6 +181,35 @@ def main() -> None:
                          "traffic": ntt_traffic},
             "kernels": {k: {"launches": v[0], "avg_ms": round(v[1] / max(v[0], 1), 4)} for k, v in sorted(p2.items())},
         }
+
+    # ---- opt-in window-table mode and the real prover's call mix (rank 0, N = 1 only) ----------
+    if rank == 0 and world == 1 and not args.no_extras:
+        try:
+            srs.precompute(20 if args.log_n >= 22 else 0)
+            b.msm_device(srs, sc.data_ptr(), n)
+            b.sync()
+            t2 = time.perf_counter()
+            for _ in range(3):
+                pre_res = b.msm_device(srs, sc.data_ptr(), n)
+            b.sync()
+            pre_s = (time.perf_counter() - t2) / 3
+            same = bool(np.array_equal(b.g1_to_affine(pre_res), b.g1_to_affine(result)))
+            extra["msm_precomputed"] = {"ms_per_msm": round(pre_s * 1e3, 4), "points_per_sec": n / pre_s,
+                                        "window_bits": 20 if args.log_n >= 22 else "auto",
+                                        "same_commitment_as_general_mode": same,
+                                        "note": "uzk_srs_precompute: window table resident in HBM (opt-in; not the headline)"}
+        except Exception as e:   # e.g. not enough HBM for the table at a larger --log-n
+            extra["msm_precomputed"] = {"error": str(e)}
+        finally:
+            b.tune("msm_no_precompute", 1)
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import prover_shape
+            extra["prover_shape"] = prover_shape.run(reps=3)
+            extra["prover_shape"]["what"] = ("one 52-card proof's hot-path calls (n = 2^14: 16 MSM, 17 NTT(n), 11 NTT(6n)), "
+                                             "device-resident data: call by call vs batched entry points, ms")
+        except Exception as e:
+            extra["prover_shape"] = {"error": str(e)}
 
     # ---- CPU baseline + parity on a bounded sample (rank 0, N = 1 only) -----------------------
     cpu_baseline = None

@@ -541,6 +541,7 @@ int uzk_tune(const char* key, int value) {
     if (!std::strcmp(key, "msm_acc_variant")) c.tune_acc_variant = value;
     else if (!std::strcmp(key, "msm_task_len")) c.tune_task_len = value;
     else if (!std::strcmp(key, "msm_no_precompute")) c.tune_no_precompute = value;
+    else if (!std::strcmp(key, "msm_fold_group")) c.tune_fold_group = value;
     else { set_error("uzk_tune: unknown key %s", key); return UZK_ERR_PARAMETER; }
     return UZK_OK;
 }

@@ -70,6 +70,7 @@ struct Ctx {
     int tune_acc_variant = 0; // experiments (uzk_tune)
     int tune_task_len = 0;
     int tune_no_precompute = 0;
+    int tune_fold_group = 0;  // 1: force one lane per bucket in the fold kernels
     // SRS registry
     struct Srs {
         Affine* d_points = nullptr;

@@ -28,6 +28,8 @@
 // No MFMA anywhere: the work is 254-bit modular integer arithmetic on v_mad_u64_u32.
 #include <algorithm>
 #include <cstring>
+#include <thread>
+#include <vector>
 
 #include "ctx.hpp"
 #include "host_math.hpp"
@@ -373,42 +375,64 @@ __global__ __launch_bounds__(256, MINW) void msm_accumulate_kernel(const Affine*
     partials[tid] = acc;
 }
 
+// Folding partial sums.  GS lanes of one wave cooperate on one output: lane `sub` adds the partials
+// sub, sub + GS, ... and a shuffle tree adds the GS lane sums, so the dependent chain is
+// ceil(cnt / GS) + log2(GS) additions instead of cnt (GS = 1 for large problems, where throughput
+// matters and every lane has its own bucket; 4 or 16 for small n, where latency does).
+__device__ __forceinline__ XYZZ xyzz_shfl_down(const XYZZ& p, int delta) {
+    XYZZ r;
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(&p);
+    uint32_t* d = reinterpret_cast<uint32_t*>(&r);
+#pragma unroll
+    for (int k = 0; k < 32; ++k) d[k] = (uint32_t)__shfl_down((int)s[k], delta);
+    return r;
+}
+template <int GS>
+__device__ __forceinline__ XYZZ fold_partials(const XYZZ* __restrict__ src, uint32_t cnt, uint32_t sub) {
+    XYZZ acc = xyzz_inf();
+    for (uint32_t k = sub; k < cnt; k += GS) { XYZZ q = src[k]; xyzz_add(acc, q); }
+    for (int o = GS / 2; o > 0; o >>= 1) {
+        XYZZ q = xyzz_shfl_down(acc, o);
+        xyzz_add(acc, q);
+    }
+    return acc;   // valid in lane sub == 0
+}
+
 // Intermediate level (only for buckets holding > G*L points): out task = sum of <= G partials.
+template <int GS>
 __global__ __launch_bounds__(256) void msm_combine_kernel(const XYZZ* __restrict__ in, const uint32_t* __restrict__ in_cnt,
                                                           const uint32_t* __restrict__ in_off,
                                                           const uint32_t* __restrict__ in_base,
                                                           const uint32_t* __restrict__ task_off,
                                                           const uint32_t* __restrict__ win_base, XYZZ* __restrict__ out,
                                                           uint32_t NB, uint32_t W, uint32_t G) {
-    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= win_base[W]) return;
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t tid = gt / GS, sub = gt % GS;
+    if (tid >= win_base[W]) return;          // whole groups leave together
     uint32_t w, b, j;
     find_task(tid, win_base, W, task_off, NB, w, b, j);
     const uint32_t total = in_cnt[(size_t)w * NB + b];
     const uint32_t first = j * G;
     const uint32_t cnt = min(G, total - first);
     const XYZZ* src = in + in_base[w] + in_off[(size_t)w * NB + b] + first;
-    XYZZ acc = src[0];
-    for (uint32_t k = 1; k < cnt; ++k) { XYZZ q = src[k]; xyzz_add(acc, q); }
-    out[tid] = acc;
+    XYZZ acc = fold_partials<GS>(src, cnt, sub);
+    if (sub == 0) out[tid] = acc;
 }
 
-// Last level: one lane per bucket folds its <= G partials into the dense bucket array.
+// Last level: one group per bucket folds its <= G partials into the dense bucket array.
+template <int GS>
 __global__ __launch_bounds__(256) void msm_finalize_kernel(const XYZZ* __restrict__ in, const uint32_t* __restrict__ in_cnt,
                                                            const uint32_t* __restrict__ in_off,
                                                            const uint32_t* __restrict__ in_base,
                                                            XYZZ* __restrict__ buckets, uint32_t NB, uint32_t W) {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t t = gt / GS;
+    const uint32_t sub = (uint32_t)(gt % GS);
     if (t >= (size_t)W * NB) return;
     const uint32_t w = (uint32_t)(t / NB);
     const uint32_t cnt = in_cnt[t];
-    XYZZ acc = xyzz_inf();
-    if (cnt > 0) {
-        const XYZZ* src = in + in_base[w] + in_off[t];
-        acc = src[0];
-        for (uint32_t k = 1; k < cnt; ++k) { XYZZ q = src[k]; xyzz_add(acc, q); }
-    }
-    buckets[t] = acc;
+    XYZZ acc = fold_partials<GS>(in + in_base[w] + in_off[t], cnt, sub);
+    if (sub == 0) buckets[t] = acc;
 }
 
 // ---- 6. bucket reduction ------------------------------------------------------------------------
@@ -765,6 +789,8 @@ int msm_run(Ctx& c, const Affine* points, const Fp* d_scalars, size_t n, uint32_
     UZK_HIP(hipMemcpyAsync(m.h_max, d_max, 4, hipMemcpyDeviceToHost, st));
     UZK_HIP(hipStreamSynchronize(st));
     uint64_t tmax = ((uint64_t)m.h_max[0] + L - 1) / L;
+    // lanes per fold group: latency mode for small problems, one lane per bucket for large ones
+    const uint32_t gs = (TBK >= (1u << 18) || c.tune_fold_group == 1) ? 1u : (tmax > 8 ? 16u : (tmax > 2 ? 4u : 1u));
     int lvl = 0;
     uint64_t bound_prev = bound0;
     while (tmax > G) {
@@ -783,8 +809,16 @@ int msm_run(Ctx& c, const Affine* points, const Fp* d_scalars, size_t n, uint32_
         }
         {
             KernelScope ks(c, "msm_combine");
-            hipLaunchKernelGGL(msm_combine_kernel, dim3((unsigned)((bound_nx + 255) / 256)), dim3(256), 0, st, part_cur,
-                               cnt_cur, off_cur, base_cur, off_nx, base_nx, part_nx, NB, Wd, G);
+            const dim3 grid((unsigned)((bound_nx * gs + 255) / 256));
+            if (gs == 16)
+                hipLaunchKernelGGL(msm_combine_kernel<16>, grid, dim3(256), 0, st, part_cur, cnt_cur, off_cur, base_cur,
+                                   off_nx, base_nx, part_nx, NB, Wd, G);
+            else if (gs == 4)
+                hipLaunchKernelGGL(msm_combine_kernel<4>, grid, dim3(256), 0, st, part_cur, cnt_cur, off_cur, base_cur,
+                                   off_nx, base_nx, part_nx, NB, Wd, G);
+            else
+                hipLaunchKernelGGL(msm_combine_kernel<1>, grid, dim3(256), 0, st, part_cur, cnt_cur, off_cur, base_cur,
+                                   off_nx, base_nx, part_nx, NB, Wd, G);
         }
         cnt_cur = cnt_nx; off_cur = off_nx; base_cur = base_nx; part_cur = part_nx;
         bound_prev = bound_nx;
@@ -793,8 +827,16 @@ int msm_run(Ctx& c, const Affine* points, const Fp* d_scalars, size_t n, uint32_
     }
     {
         KernelScope ks(c, "msm_finalize");
-        hipLaunchKernelGGL(msm_finalize_kernel, dim3((unsigned)((TBK + 255) / 256)), dim3(256), 0, st, part_cur, cnt_cur,
-                           off_cur, base_cur, buckets, NB, Wd);
+        const dim3 grid((unsigned)((TBK * gs + 255) / 256));
+        if (gs == 16)
+            hipLaunchKernelGGL(msm_finalize_kernel<16>, grid, dim3(256), 0, st, part_cur, cnt_cur, off_cur, base_cur,
+                               buckets, NB, Wd);
+        else if (gs == 4)
+            hipLaunchKernelGGL(msm_finalize_kernel<4>, grid, dim3(256), 0, st, part_cur, cnt_cur, off_cur, base_cur,
+                               buckets, NB, Wd);
+        else
+            hipLaunchKernelGGL(msm_finalize_kernel<1>, grid, dim3(256), 0, st, part_cur, cnt_cur, off_cur, base_cur,
+                               buckets, NB, Wd);
     }
     {
         KernelScope ks(c, "msm_reduce");
@@ -808,13 +850,23 @@ int msm_run(Ctx& c, const Affine* points, const Fp* d_scalars, size_t n, uint32_
     // 7. host: per scalar vector, Horner over its logical windows (c doublings per step); one window
     //    each when precomputed
     const uint32_t wpp = pre ? 1u : W;
-    for (uint32_t b = 0; b < batch; ++b) {
+    auto horner = [&](uint32_t b) {
         XYZZ total = xyzz_inf();
         for (int w = (int)wpp - 1; w >= 0; --w) {
             if (w != (int)wpp - 1) for (int d = 0; d < cb; ++d) total = xyzz_dbl(total);
             xyzz_add(total, m.h_sums[(size_t)b * wpp + w]);
         }
         out_host[b] = xyzz_to_jac(total);
+    };
+    if (batch > 1 && wpp > 1) {
+        // 254 dependent doublings per vector: ~0.1 ms each on one core, so spread the vectors over threads
+        const uint32_t nt = std::min<uint32_t>(batch, 8);
+        std::vector<std::thread> th;
+        for (uint32_t t = 0; t < nt; ++t)
+            th.emplace_back([&, t] { for (uint32_t b = t; b < batch; b += nt) horner(b); });
+        for (auto& x : th) x.join();
+    } else {
+        for (uint32_t b = 0; b < batch; ++b) horner(b);
     }
     return UZK_OK;
 }
