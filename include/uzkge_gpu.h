@@ -122,6 +122,18 @@ int uzk_ntt_fr_batch(uint64_t* data, uint64_t n, uint32_t batch, int inverse, co
 int uzk_ntt_fr_batch_device(const void* d_in, void* d_out, uint64_t n, uint32_t batch, int inverse,
                             const uint64_t* coset_shift_mont, int sync);
 
+/* ---- polynomial helpers next to the hot path ------------------------ */
+/* out[b] = sum_j coefs[b*n + j] * x^j : FpPolynomial::eval (field_polynomial.rs:198-209) for a batch of
+ * polynomials at one point (the prover's 19 + 20 openings at zeta / zeta*omega, prover.rs:246-273). */
+int uzk_poly_eval_batch(const uint64_t* coefs, uint64_t n, uint32_t batch, const uint64_t* x_mont, uint64_t* out);
+int uzk_poly_eval_batch_device(const void* d_coefs, uint64_t n, uint32_t batch, const uint64_t* x_mont, uint64_t* out);
+/* The permutation grand product z_poly (uzkge/src/plonk/helpers.rs:160-220), evaluations only:
+ * z[0] = 1, z[i+1] = z[i] * prod_j (w[j*n+i] + beta*k[j]*group[i] + gamma)
+ *                         / (w[j*n+i] + beta*k[perm/n]*group[perm%n] + gamma),  perm = perm[j*n+i].
+ * w: n_wires*n elements, perm: n_wires*n indices < n_wires*n, group: n elements (omega^i), k: n_wires. */
+int uzk_z_poly(const uint64_t* w, const uint32_t* perm, const uint64_t* group, const uint64_t* k,
+               const uint64_t* beta_mont, const uint64_t* gamma_mont, uint32_t n, uint32_t n_wires, uint64_t* z_out);
+
 /* ---- synthetic workloads (bench / tests; generated on device, nothing uploaded) -------- */
 /* d_points[i] = (i + 1) * Q with Q = seed_scalar * G: n distinct valid G1 points whose discrete
  * logs relative to Q are known, so MSM(points, s) == (sum_i s_i (i+1)) * Q for any size. */

@@ -392,3 +392,40 @@ void oracle_poly_eval(const uint64_t *coefs, uint64_t len, const uint64_t *x_mon
     for (uint64_t j = len; j-- > 0;) { f_mul(&FR, &acc, &acc, (const fe *)x_mont); f_add(&FR, &acc, &acc, &((const fe *)coefs)[j]); }
     *(fe *)out = acc;
 }
+
+/* z_poly (uzkge/src/plonk/helpers.rs:160-220), restated literally: per-row numerator/denominator,
+ * batch inversion (Montgomery's trick, as ark_ff::batch_inversion), serial prefix product. */
+void oracle_z_poly(const uint64_t *w_, const uint32_t *perm, const uint64_t *group_, const uint64_t *k_,
+                   const uint64_t *beta_, const uint64_t *gamma_, uint32_t n, uint32_t n_wires, uint64_t *z_out) {
+    const fe *w = (const fe *)w_, *group = (const fe *)group_, *k = (const fe *)k_;
+    const fe *beta = (const fe *)beta_, *gamma = (const fe *)gamma_;
+    fe *z = (fe *)z_out;
+    if (n == 0) return;
+    uint32_t m = n - 1;
+    fe *num = (fe *)malloc((m ? m : 1) * sizeof(fe)), *den = (fe *)malloc((m ? m : 1) * sizeof(fe));
+    for (uint32_t i = 0; i < m; ++i) {
+        fe nm = FR.r, dn = FR.r;
+        for (uint32_t j = 0; j < n_wires; ++j) {
+            fe kx, t, a, px, b;
+            f_mul(&FR, &kx, &k[j], &group[i]);
+            const fe *fx = &w[(size_t)j * n + i];
+            f_add(&FR, &a, fx, gamma); f_mul(&FR, &t, beta, &kx); f_add(&FR, &a, &a, &t);
+            f_mul(&FR, &nm, &nm, &a);
+            uint32_t pv = perm[(size_t)j * n + i];
+            /* p_of_x: k[i] * group[perm % n] for the coset the index falls in (helpers.rs:174-182) */
+            f_mul(&FR, &px, &k[pv / n], &group[pv % n]);
+            f_add(&FR, &b, fx, gamma); f_mul(&FR, &t, beta, &px); f_add(&FR, &b, &b, &t);
+            f_mul(&FR, &dn, &dn, &b);
+        }
+        num[i] = nm; den[i] = dn;
+    }
+    /* batch inversion of den */
+    fe *pre = (fe *)malloc((m ? m : 1) * sizeof(fe)), acc = FR.r;
+    for (uint32_t i = 0; i < m; ++i) { pre[i] = acc; f_mul(&FR, &acc, &acc, &den[i]); }
+    fe inv; f_inv(&FR, &inv, &acc);
+    for (uint32_t i = m; i-- > 0;) { fe t; f_mul(&FR, &t, &inv, &pre[i]); f_mul(&FR, &inv, &inv, &den[i]); den[i] = t; }
+    fe prev = FR.r;
+    z[0] = prev;
+    for (uint32_t i = 0; i < m; ++i) { fe t; f_mul(&FR, &t, &num[i], &den[i]); f_mul(&FR, &prev, &prev, &t); z[i + 1] = prev; }
+    free(num); free(den); free(pre);
+}

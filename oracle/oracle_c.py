@@ -41,6 +41,8 @@ def _load():
     for name, args in sigs.items():
         getattr(lib, name).argtypes = args
         getattr(lib, name).restype = None
+    lib.oracle_z_poly.argtypes = [P, P, P, P, P, P, ctypes.c_uint32, ctypes.c_uint32, P]
+    lib.oracle_z_poly.restype = None
     lib.oracle_ntt.argtypes = [P, ctypes.c_uint64, ctypes.c_int, ctypes.c_int]
     lib.oracle_ntt.restype = ctypes.c_int
     lib.oracle_domain_supported.argtypes = [ctypes.c_uint64]
@@ -125,6 +127,17 @@ def mul_var(data: np.ndarray, k_mont: np.ndarray) -> np.ndarray:
 def poly_eval(coefs: np.ndarray, x_mont: np.ndarray) -> np.ndarray:
     out = np.empty(4, dtype=np.uint64)
     lib.oracle_poly_eval(_p(np.ascontiguousarray(coefs)), coefs.shape[0], _p(np.ascontiguousarray(x_mont)), _p(out))
+    return out
+
+
+def z_poly(w: np.ndarray, perm: np.ndarray, group: np.ndarray, k: np.ndarray, beta: np.ndarray, gamma: np.ndarray) -> np.ndarray:
+    """helpers.rs:160-220 on the CPU.  w [n_wires, n, 4], perm [n_wires, n] uint32."""
+    wv = np.ascontiguousarray(w, dtype=np.uint64)
+    n_wires, n = wv.shape[0], wv.shape[1]
+    pm = np.ascontiguousarray(perm, dtype=np.uint32)
+    out = np.zeros((n, 4), dtype=np.uint64)
+    lib.oracle_z_poly(_p(wv), pm.ctypes.data_as(ctypes.c_void_p), _p(np.ascontiguousarray(group)), _p(np.ascontiguousarray(k)),
+                      _p(np.ascontiguousarray(beta)), _p(np.ascontiguousarray(gamma)), n, n_wires, _p(out))
     return out
 
 

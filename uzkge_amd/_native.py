@@ -43,6 +43,9 @@ PROTOTYPES = {
     "uzk_ntt_fr_device": (_I, [_P, _P, _U64, _I, _P, _I]),
     "uzk_ntt_fr_batch": (_I, [_P, _U64, ctypes.c_uint32, _I, _P]),
     "uzk_ntt_fr_batch_device": (_I, [_P, _P, _U64, ctypes.c_uint32, _I, _P, _I]),
+    "uzk_poly_eval_batch": (_I, [_P, _U64, ctypes.c_uint32, _P, _P]),
+    "uzk_poly_eval_batch_device": (_I, [_P, _U64, ctypes.c_uint32, _P, _P]),
+    "uzk_z_poly": (_I, [_P, _P, _P, _P, _P, _P, ctypes.c_uint32, ctypes.c_uint32, _P]),
     "uzk_synth_points_arith": (_I, [_P, _SZ, _P]),
     "uzk_synth_points_random": (_I, [_P, _SZ, _U64]),
     "uzk_synth_scalars": (_I, [_P, _SZ, _U64]),

@@ -169,6 +169,30 @@ def ntt_device(d_in: int, d_out: int, n: int, inverse: bool = False, coset_shift
                                 _ptr(cs) if cs is not None else None, int(sync)))
 
 
+def poly_eval_batch(coefs: np.ndarray, x_mont: np.ndarray) -> np.ndarray:
+    """coefs [batch, n, 4] -> [batch, 4]: p_b(x) (FpPolynomial::eval for a batch at one point)."""
+    c = np.ascontiguousarray(coefs, dtype=np.uint64)
+    assert c.ndim == 3 and c.shape[2] == 4
+    x = np.ascontiguousarray(x_mont, dtype=np.uint64).reshape(4)
+    out = np.zeros((c.shape[0], 4), dtype=np.uint64)
+    check(lib.uzk_poly_eval_batch(_ptr(c) if c.size else None, c.shape[1], c.shape[0], _ptr(x), _ptr(out)))
+    return out
+
+
+def z_poly(w: np.ndarray, perm: np.ndarray, group: np.ndarray, k: np.ndarray, beta: np.ndarray, gamma: np.ndarray) -> np.ndarray:
+    """Permutation grand product evaluations (helpers.rs:160-220).  w [n_wires, n, 4], perm [n_wires, n] uint32."""
+    wv = np.ascontiguousarray(w, dtype=np.uint64)
+    n_wires, n = wv.shape[0], wv.shape[1]
+    pm = np.ascontiguousarray(perm, dtype=np.uint32).reshape(n_wires, n)
+    g = np.ascontiguousarray(group, dtype=np.uint64).reshape(n, 4)
+    kk = np.ascontiguousarray(k, dtype=np.uint64).reshape(n_wires, 4)
+    out = np.zeros((n, 4), dtype=np.uint64)
+    check(lib.uzk_z_poly(_ptr(wv), pm.ctypes.data_as(ctypes.c_void_p), _ptr(g), _ptr(kk),
+                         _ptr(np.ascontiguousarray(beta, dtype=np.uint64).reshape(4)),
+                         _ptr(np.ascontiguousarray(gamma, dtype=np.uint64).reshape(4)), n, n_wires, _ptr(out)))
+    return out
+
+
 def synth_points_arith(d_points: int, n: int, seed_scalar_mont: np.ndarray) -> None:
     s = np.ascontiguousarray(seed_scalar_mont, dtype=np.uint64).reshape(4)
     check(lib.uzk_synth_points_arith(ctypes.c_void_p(d_points), n, _ptr(s)))

@@ -161,6 +161,7 @@ int uzk_shutdown(void) {
     (void)hipStreamSynchronize(c.stream);
     ntt_free_plans(c);
     msm_free(c);
+    poly_free(c);
     for (auto& kv : c.srs) {
         if (kv.second.owned && kv.second.d_points) (void)hipFree(kv.second.d_points);
         if (kv.second.d_table) (void)hipFree(kv.second.d_table);
@@ -432,6 +433,29 @@ int uzk_ntt_fr(uint64_t* data, uint64_t n, int inverse, const uint64_t* coset_sh
 int uzk_ntt_fr_batch(uint64_t* data, uint64_t n, uint32_t batch, int inverse, const uint64_t* coset_shift_mont) {
     API_LOCK;
     return ntt_host_common(data, n, batch, inverse, coset_shift_mont);
+}
+
+/* ---- polynomial helpers next to the hot path ------------------------------------------------ */
+int uzk_poly_eval_batch(const uint64_t* coefs, uint64_t n, uint32_t batch, const uint64_t* x_mont, uint64_t* out) {
+    API_LOCK;
+    if (!x_mont || (batch > 0 && (!out || (n > 0 && !coefs)))) { set_error("uzk_poly_eval_batch: null pointer"); return UZK_ERR_PARAMETER; }
+    UZK_TRY(require_ready());
+    return poly_eval_batch_host(ctx(), as_fp(coefs), n, batch, *as_fp(x_mont), reinterpret_cast<Fp*>(out));
+}
+int uzk_poly_eval_batch_device(const void* d_coefs, uint64_t n, uint32_t batch, const uint64_t* x_mont, uint64_t* out) {
+    API_LOCK;
+    if (!x_mont || (batch > 0 && (!out || (n > 0 && !d_coefs)))) { set_error("uzk_poly_eval_batch_device: null pointer"); return UZK_ERR_PARAMETER; }
+    UZK_TRY(require_ready());
+    return poly_eval_batch(ctx(), static_cast<const Fp*>(d_coefs), n, batch, *as_fp(x_mont), reinterpret_cast<Fp*>(out));
+}
+int uzk_z_poly(const uint64_t* w, const uint32_t* perm, const uint64_t* group, const uint64_t* k, const uint64_t* beta_mont,
+               const uint64_t* gamma_mont, uint32_t n, uint32_t n_wires, uint64_t* z_out) {
+    API_LOCK;
+    if (!w || !perm || !group || !k || !beta_mont || !gamma_mont || !z_out) { set_error("uzk_z_poly: null pointer"); return UZK_ERR_PARAMETER; }
+    if (n_wires == 0 || n_wires > 8 || (uint64_t)n * n_wires >= (1ull << 32)) { set_error("uzk_z_poly: bad shape"); return UZK_ERR_PARAMETER; }
+    UZK_TRY(require_ready());
+    return z_poly_run(ctx(), as_fp(w), perm, as_fp(group), as_fp(k), *as_fp(beta_mont), *as_fp(gamma_mont), n, n_wires,
+                      reinterpret_cast<Fp*>(z_out));
 }
 
 /* ---- synthetic workloads ------------------------------------------------------------------ */

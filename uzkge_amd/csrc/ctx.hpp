@@ -112,6 +112,11 @@ void msm_free(Ctx& c);
 int synth_points_arith(Ctx& c, Affine* d_points, size_t n, const Fp& seed_scalar_mont);
 int synth_points_random(Ctx& c, Affine* d_points, size_t n, uint64_t seed);
 int synth_scalars(Ctx& c, Fp* d_scalars, size_t n, uint64_t seed);
+int poly_eval_batch(Ctx& c, const Fp* d_coefs, uint64_t n, uint32_t batch, const Fp& x, Fp* out_host);
+int poly_eval_batch_host(Ctx& c, const Fp* coefs_host, uint64_t n, uint32_t batch, const Fp& x, Fp* out_host);
+int z_poly_run(Ctx& c, const Fp* w_host, const uint32_t* perm_host, const Fp* group_host, const Fp* k_host,
+               const Fp& beta, const Fp& gamma, uint32_t n, uint32_t n_wires, Fp* z_host);
+void poly_free(Ctx& c);
 int field_op_device(Ctx& c, int field, int op, const Fp* a, const Fp* b, Fp* out, size_t n);
 int g1_op_device(Ctx& c, int op, const Affine* a, const Affine* b, Jac* out, size_t n);
 

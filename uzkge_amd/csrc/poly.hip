@@ -1,0 +1,259 @@
+// Polynomial helpers next to the hot path: the O(n) host loops the prover runs
+// between its transforms and commits, kept on the device so evaluations need not leave HBM.
+//   fr_scan_mul      prefix / suffix products over Fr (building block)
+//   poly_eval_batch  p_b(x) for a batch of polynomials at one point -- FpPolynomial::eval,
+//                    uzkge/src/poly_commit/field_polynomial.rs:198-209 (19 + 20 Horner evaluations
+//                    per proof, uzkge/src/plonk/prover.rs:246-273, pcs.rs:126)
+//   z_poly           the permutation grand product, uzkge/src/plonk/helpers.rs:160-220:
+//                    z_0 = 1, z_{i+1} = z_i * prod_j (f_j(i) + beta k_j w^i + gamma)
+//                                              / (f_j(i) + beta perm_j(i) + gamma)
+//                    (rayon map + batch_inversion + a serial prefix product in the reference;
+//                    here two product scans and ONE inversion)
+// All values are exact field elements, so any evaluation order gives the reference's bytes.
+#include "ctx.hpp"
+#include "host_math.hpp"
+
+namespace uzk {
+
+constexpr int kScanPer = 8;                    // elements per lane
+constexpr int kScanBlock = 256 * kScanPer;     // elements per workgroup
+
+// Inclusive product scan of one block of `in` (reverse: from the right end), block totals out.
+__global__ __launch_bounds__(256) void fr_scan_block_kernel(const Fp* __restrict__ in, Fp* __restrict__ out,
+                                                            Fp* __restrict__ block_tot, uint64_t n, int reverse) {
+    __shared__ Fp sh[256];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t base = (uint64_t)blockIdx.x * kScanBlock + (uint64_t)tid * kScanPer;
+    Fp v[kScanPer];
+    Fp run = Fr::one();
+#pragma unroll
+    for (int e = 0; e < kScanPer; ++e) {
+        const uint64_t i = base + e;
+        Fp x = Fr::one();
+        if (i < n) x = in[reverse ? n - 1 - i : i];
+        run = Fr::mul(run, x);
+        v[e] = run;
+    }
+    sh[tid] = run;
+    __syncthreads();
+    for (uint32_t off = 1; off < 256; off <<= 1) {   // Hillis-Steele inclusive scan of lane totals
+        Fp t = (tid >= off) ? sh[tid - off] : Fr::one();
+        __syncthreads();
+        if (tid >= off) sh[tid] = Fr::mul(sh[tid], t);
+        __syncthreads();
+    }
+    const Fp pre = tid ? sh[tid - 1] : Fr::one();
+#pragma unroll
+    for (int e = 0; e < kScanPer; ++e) {
+        const uint64_t i = base + e;
+        if (i < n) out[reverse ? n - 1 - i : i] = tid ? Fr::mul(v[e], pre) : v[e];
+    }
+    if (tid == 255 && block_tot) block_tot[blockIdx.x] = sh[255];
+}
+// out[i] *= (exclusive prefix of block totals)[block of i]
+__global__ __launch_bounds__(256) void fr_scan_apply_kernel(Fp* __restrict__ out, const Fp* __restrict__ tot_scan, uint64_t n,
+                                                            int reverse) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t blk = i / kScanBlock;
+    if (blk == 0) return;
+    const uint64_t pos = reverse ? n - 1 - i : i;
+    out[pos] = Fr::mul(out[pos], tot_scan[blk - 1]);
+}
+
+// d_out[i] = prod_{t <= i} d_in[t]  (reverse: prod_{t >= i}); n <= 2048^2
+static int fr_scan_mul(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool reverse, DevBuf& tmp) {
+    if (n == 0) return UZK_OK;
+    const uint64_t nb = (n + kScanBlock - 1) / kScanBlock;
+    if (nb > (uint64_t)kScanBlock) { set_error("scan: n = %llu too large", (unsigned long long)n); return UZK_ERR_PARAMETER; }
+    UZK_TRY(tmp.reserve(2 * nb * sizeof(Fp)));
+    Fp* tot = tmp.as<Fp>();
+    Fp* tot_scan = tot + nb;
+    KernelScope ks(c, "fr_scan");
+    hipLaunchKernelGGL(fr_scan_block_kernel, dim3((unsigned)nb), dim3(256), 0, c.stream, d_in, d_out, tot, n, reverse ? 1 : 0);
+    if (nb > 1) {
+        hipLaunchKernelGGL(fr_scan_block_kernel, dim3(1), dim3(256), 0, c.stream, tot, tot_scan, (Fp*)nullptr, nb, 0);
+        hipLaunchKernelGGL(fr_scan_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, d_out, tot_scan, n,
+                           reverse ? 1 : 0);
+    }
+    UZK_HIP(hipGetLastError());
+    return UZK_OK;
+}
+
+// ---- batched evaluation at one point -----------------------------------------------------------
+__device__ inline Fp fr_pow_u64(Fp base, uint64_t e) {
+    Fp acc = Fr::one();
+    while (e) {
+        if (e & 1) acc = Fr::mul(acc, base);
+        base = Fr::sqr(base);
+        e >>= 1;
+    }
+    return acc;
+}
+constexpr int kEvalPer = 16;                    // coefficients per lane (Horner)
+constexpr int kEvalBlock = 256 * kEvalPer;      // coefficients per workgroup
+// tab[t] = x^(16 t), t < 256;  tab[256 + b] = x^(4096 b), b < nblocks
+__global__ __launch_bounds__(256) void poly_eval_tables_kernel(Fp* __restrict__ tab, Fp x, uint32_t nblocks) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < 256) tab[t] = fr_pow_u64(x, (uint64_t)t * kEvalPer);
+    else if (t < 256 + nblocks) tab[t] = fr_pow_u64(x, (uint64_t)(t - 256) * kEvalBlock);
+}
+// grid (nblocks, batch): partial[b][blk] = x^(4096 blk) * sum_{j in block} c_j x^(j - 4096 blk)
+__global__ __launch_bounds__(256) void poly_eval_kernel(const Fp* __restrict__ coefs, uint64_t n, Fp x,
+                                                        const Fp* __restrict__ tab, Fp* __restrict__ partial) {
+    __shared__ Fp sh[256];
+    const uint32_t tid = threadIdx.x, blk = blockIdx.x, nblocks = gridDim.x;
+    const Fp* c = coefs + (uint64_t)blockIdx.y * n;
+    const uint64_t base = (uint64_t)blk * kEvalBlock + (uint64_t)tid * kEvalPer;
+    Fp h = Fr::zero();
+#pragma unroll
+    for (int e = kEvalPer - 1; e >= 0; --e) {
+        const uint64_t j = base + e;
+        h = Fr::mul(h, x);
+        if (j < n) h = Fr::add(h, c[j]);
+    }
+    sh[tid] = Fr::mul(h, tab[tid]);
+    __syncthreads();
+    for (uint32_t s = 128; s > 0; s >>= 1) {
+        if (tid < s) sh[tid] = Fr::add(sh[tid], sh[tid + s]);
+        __syncthreads();
+    }
+    if (tid == 0) partial[(uint64_t)blockIdx.y * nblocks + blk] = Fr::mul(sh[0], tab[256 + blk]);
+}
+__global__ __launch_bounds__(64) void poly_eval_finish_kernel(const Fp* __restrict__ partial, uint32_t nblocks, uint32_t batch,
+                                                             Fp* __restrict__ out) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    Fp acc = Fr::zero();
+    for (uint32_t k = 0; k < nblocks; ++k) acc = Fr::add(acc, partial[(uint64_t)b * nblocks + k]);
+    out[b] = acc;
+}
+
+static DevBuf g_poly_tmp, g_poly_tmp2, g_poly_io;
+
+int poly_eval_batch(Ctx& c, const Fp* d_coefs, uint64_t n, uint32_t batch, const Fp& x, Fp* out_host) {
+    if (batch == 0) return UZK_OK;
+    if (n == 0) { for (uint32_t b = 0; b < batch; ++b) out_host[b] = Fr::zero(); return UZK_OK; }
+    if (batch > 65535) { set_error("poly_eval: batch %u exceeds 65535", batch); return UZK_ERR_PARAMETER; }
+    const uint32_t nblocks = (uint32_t)((n + kEvalBlock - 1) / kEvalBlock);
+    UZK_TRY(g_poly_tmp.reserve(((size_t)256 + nblocks + (size_t)batch * nblocks + batch) * sizeof(Fp)));
+    Fp* tab = g_poly_tmp.as<Fp>();
+    Fp* partial = tab + 256 + nblocks;
+    Fp* d_out = partial + (size_t)batch * nblocks;
+    {
+        KernelScope ks(c, "poly_eval");
+        hipLaunchKernelGGL(poly_eval_tables_kernel, dim3((256 + nblocks + 255) / 256), dim3(256), 0, c.stream, tab, x, nblocks);
+        hipLaunchKernelGGL(poly_eval_kernel, dim3(nblocks, batch), dim3(256), 0, c.stream, d_coefs, n, x, tab, partial);
+        hipLaunchKernelGGL(poly_eval_finish_kernel, dim3((batch + 63) / 64), dim3(64), 0, c.stream, partial, nblocks, batch, d_out);
+    }
+    UZK_HIP(hipGetLastError());
+    UZK_HIP(hipMemcpyAsync(out_host, d_out, (size_t)batch * sizeof(Fp), hipMemcpyDeviceToHost, c.stream));
+    UZK_HIP(hipStreamSynchronize(c.stream));
+    return UZK_OK;
+}
+
+// ---- z_poly -------------------------------------------------------------------------------------
+struct ZPolyArgs {
+    const Fp* w;            // [n_wires][n] wire values
+    const uint32_t* perm;   // [n_wires][n] permutation (values < n_wires * n)
+    const Fp* group;        // [n] omega^i
+    Fp k[8];                // coset representatives k_j (n_wires <= 8)
+    Fp beta, gamma;
+    uint32_t n, n_wires;
+};
+// i < n-1: num[i] = prod_j (f_j(i) + gamma + beta k_j w^i), den[i] = prod_j (f_j(i) + gamma + beta perm_j(i))
+__global__ __launch_bounds__(256) void z_poly_terms_kernel(ZPolyArgs a, Fp* __restrict__ num, Fp* __restrict__ den) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i + 1 >= a.n) return;
+    const Fp gi = a.group[i];
+    Fp nm = Fr::one(), dn = Fr::one();
+    for (uint32_t j = 0; j < a.n_wires; ++j) {
+        const Fp f = a.w[(size_t)j * a.n + i];
+        const Fp fg = Fr::add(f, a.gamma);
+        nm = Fr::mul(nm, Fr::add(fg, Fr::mul(a.beta, Fr::mul(a.k[j], gi))));
+        const uint32_t pv = a.perm[(size_t)j * a.n + i];
+        const Fp px = Fr::mul(a.k[pv / a.n], a.group[pv % a.n]);      // p_of_x, helpers.rs:174-182
+        dn = Fr::mul(dn, Fr::add(fg, Fr::mul(a.beta, px)));
+    }
+    num[i] = nm;
+    den[i] = dn;
+}
+// z[0] = 1; z[i+1] = P[i] * S[i+1] * inv_total  (P = prefix products of num, S = suffix products of den,
+// S[n-1] = 1, inv_total = 1 / S[0])
+__global__ __launch_bounds__(256) void z_poly_combine_kernel(const Fp* __restrict__ P, const Fp* __restrict__ S, Fp inv_total,
+                                                             uint32_t n, Fp* __restrict__ z) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (i == 0) { z[0] = Fr::one(); return; }
+    Fp v = Fr::mul(P[i - 1], inv_total);
+    if (i < n - 1) v = Fr::mul(v, S[i]);
+    z[i] = v;
+}
+
+int z_poly_run(Ctx& c, const Fp* w_host, const uint32_t* perm_host, const Fp* group_host, const Fp* k_host,
+               const Fp& beta, const Fp& gamma, uint32_t n, uint32_t n_wires, Fp* z_host) {
+    if (n == 0) return UZK_OK;
+    if (n_wires == 0 || n_wires > 8) { set_error("z_poly: n_wires must be 1..8"); return UZK_ERR_PARAMETER; }
+    if (n == 1) { z_host[0] = Fr::one(); return UZK_OK; }
+    const size_t wn = (size_t)n_wires * n;
+    // staging: w | group | num | den | P | S | z   (Fp), perm (u32)
+    UZK_TRY(g_poly_io.reserve((wn + 6 * (size_t)n) * sizeof(Fp) + wn * sizeof(uint32_t)));
+    Fp* d_w = g_poly_io.as<Fp>();
+    Fp* d_group = d_w + wn;
+    Fp* d_num = d_group + n;
+    Fp* d_den = d_num + n;
+    Fp* d_P = d_den + n;
+    Fp* d_S = d_P + n;
+    Fp* d_z = d_S + n;
+    uint32_t* d_perm = reinterpret_cast<uint32_t*>(d_z + n);
+    UZK_HIP(hipMemcpyAsync(d_w, w_host, wn * sizeof(Fp), hipMemcpyHostToDevice, c.stream));
+    UZK_HIP(hipMemcpyAsync(d_group, group_host, (size_t)n * sizeof(Fp), hipMemcpyHostToDevice, c.stream));
+    UZK_HIP(hipMemcpyAsync(d_perm, perm_host, wn * sizeof(uint32_t), hipMemcpyHostToDevice, c.stream));
+    ZPolyArgs a;
+    a.w = d_w; a.perm = d_perm; a.group = d_group;
+    for (uint32_t j = 0; j < 8; ++j) a.k[j] = j < n_wires ? k_host[j] : Fr::zero();
+    a.beta = beta; a.gamma = gamma; a.n = n; a.n_wires = n_wires;
+    const uint32_t m = n - 1;
+    {
+        KernelScope ks(c, "z_poly_terms");
+        hipLaunchKernelGGL(z_poly_terms_kernel, dim3((m + 255) / 256), dim3(256), 0, c.stream, a, d_num, d_den);
+    }
+    UZK_TRY(fr_scan_mul(c, d_num, d_P, m, false, g_poly_tmp));
+    UZK_TRY(fr_scan_mul(c, d_den, d_S, m, true, g_poly_tmp2));
+    Fp total;
+    UZK_HIP(hipMemcpyAsync(&total, d_S, sizeof(Fp), hipMemcpyDeviceToHost, c.stream));
+    UZK_HIP(hipStreamSynchronize(c.stream));
+    if (Fr::is_zero(total)) {
+        // a zero denominator: the reference's batch_inversion leaves zeros in place; mirror it by
+        // refusing rather than inventing a value (cannot happen for random beta, gamma)
+        set_error("z_poly: a permutation denominator is zero");
+        return UZK_ERR_PARAMETER;
+    }
+    const Fp inv_total = fr_inv(total);     // the single inversion, on the host (~15 us)
+    {
+        KernelScope ks(c, "z_poly_combine");
+        hipLaunchKernelGGL(z_poly_combine_kernel, dim3((n + 255) / 256), dim3(256), 0, c.stream, d_P, d_S, inv_total, n, d_z);
+    }
+    UZK_HIP(hipGetLastError());
+    UZK_HIP(hipMemcpyAsync(z_host, d_z, (size_t)n * sizeof(Fp), hipMemcpyDeviceToHost, c.stream));
+    UZK_HIP(hipStreamSynchronize(c.stream));
+    return UZK_OK;
+}
+
+int poly_eval_batch_host(Ctx& c, const Fp* coefs_host, uint64_t n, uint32_t batch, const Fp& x, Fp* out_host) {
+    if (batch == 0) return UZK_OK;
+    const size_t bytes = (size_t)n * batch * sizeof(Fp);
+    if (bytes) {
+        UZK_TRY(g_poly_io.reserve(bytes));
+        UZK_HIP(hipMemcpyAsync(g_poly_io.p, coefs_host, bytes, hipMemcpyHostToDevice, c.stream));
+    }
+    return poly_eval_batch(c, g_poly_io.as<Fp>(), n, batch, x, out_host);
+}
+
+void poly_free(Ctx&) {
+    g_poly_tmp.release();
+    g_poly_tmp2.release();
+    g_poly_io.release();
+}
+
+}  // namespace uzk
