@@ -49,18 +49,26 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # UZK_BENCH_BACKEND=gloo rehearses the multi-rank control flow on a box with fewer GPUs than ranks
+    # (ranks then share a device and exchange their partials through host memory); the driver's runs
+    # use the default: one rank per GPU over RCCL.
+    backend = os.environ.get("UZK_BENCH_BACKEND", "nccl")
+    ndev = max(torch.cuda.device_count(), 1)
+    dev_index = local_rank if backend == "nccl" else local_rank % ndev
+    torch.cuda.set_device(dev_index)
     if world > 1:
         import torch.distributed as dist  # type: ignore
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
+    dev = torch.device("cuda", dev_index)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
 
     from uzkge_amd import backend as b
 
-    b.init(local_rank)
+    b.init(dev_index)
     if args.window_bits:
         b.set_msm_window_bits(args.window_bits)
 
@@ -77,8 +85,8 @@ def main() -> None:
         b.synth_points_arith(pts.data_ptr(), n, k)
     b.synth_scalars(sc.data_ptr(), n, seed ^ 0x5CA1AB1E)
     srs = b.Srs.from_device(pts.data_ptr(), n)
-    gather_in = torch.zeros(96, dtype=torch.uint8, device=dev)
-    gather_out = torch.zeros(96 * world, dtype=torch.uint8, device=dev)
+    gather_in = torch.zeros(96, dtype=torch.uint8, device=coll_dev)
+    gather_out = torch.zeros(96 * world, dtype=torch.uint8, device=coll_dev)
 
     def step():
         part = b.msm_device(srs, sc.data_ptr(), n)
@@ -111,7 +119,7 @@ def main() -> None:
     b.profile_enable(False)
     prof = b.profile_table()
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
