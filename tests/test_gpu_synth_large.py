@@ -111,3 +111,25 @@ def test_precomputed_closed_form(gpu, log_n, c):
         srs.release()
     k = weighted_index_sum(_wire(sc))
     assert got == opy.g1_mul(opy.g1_mul(opy.G1_GEN, seed_int), k)
+
+
+def test_maximum_size_chunked_closed_form(gpu):
+    """Beyond 2^26 points one sort pass would overflow its 31-bit index: the ABI cuts the input into
+    point chunks and folds the partial sums.  n = 2^26 + 4097 (BASELINE.json's largest configuration is
+    2^26), checked with the arithmetic-progression closed form."""
+    n = (1 << 26) + 4097
+    pts = torch.empty((n, 8), dtype=torch.int64, device="cuda")
+    sc = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    seed_int = 0x5EED5EED
+    gpu.synth_points_arith(pts.data_ptr(), n, oc.fr_from_ints([seed_int])[0])
+    gpu.synth_scalars(sc.data_ptr(), n, 2626)
+    srs = gpu.Srs.from_device(pts.data_ptr(), n)
+    try:
+        got = affine_of(gpu.msm_device(srs, sc.data_ptr(), n))
+    finally:
+        srs.release()
+    k = weighted_index_sum(_wire(sc))
+    del pts, sc
+    torch.cuda.empty_cache()
+    assert got == opy.g1_mul(opy.g1_mul(opy.G1_GEN, seed_int), k)

@@ -2,6 +2,7 @@
 // Thin: argument checks, staging of host buffers, error mapping; all compute is in the .hip files.
 // There is deliberately no CPU fallback: without a gfx950 device every compute call fails with
 // UZK_ERR_DEVICE.
+#include <algorithm>
 #include <cstdarg>
 #include <cstring>
 
@@ -273,11 +274,28 @@ static int msm_checked(uint64_t srs_handle, size_t offset, size_t n, const Ctx::
     return UZK_OK;
 }
 // general mode unless the handle carries a window table
-static int msm_dispatch(const Ctx::Srs& s, size_t offset, const Fp* d_scalars, size_t n, uint32_t batch, Jac* out) {
+static int msm_dispatch_one(const Ctx::Srs& s, size_t offset, const Fp* d_scalars, size_t n, uint32_t batch, Jac* out) {
     Ctx& c = ctx();
     if (s.d_table && !c.tune_no_precompute)
         return msm_run(c, s.d_table, d_scalars, n, batch, out, s.pre_c, (uint32_t)s.n, (uint32_t)offset);
     return msm_run(c, s.d_points + offset, d_scalars, n, batch, out, 0, 0, 0);
+}
+// The sort indexes (point, window) pairs with 31 bits, so one pass handles at most 2^26 points per
+// scalar vector (2^26 * 16 windows); longer inputs are cut into point chunks whose partial sums are
+// folded on the host -- the same decomposition the multi-GPU path uses across ranks.
+static int msm_dispatch(const Ctx::Srs& s, size_t offset, const Fp* d_scalars, size_t n, uint32_t batch, Jac* out) {
+    const size_t kChunk = (size_t)1 << 26;
+    if (n <= kChunk || batch != 1) return msm_dispatch_one(s, offset, d_scalars, n, batch, out);
+    XYZZ acc = xyzz_inf();
+    for (size_t lo = 0; lo < n; lo += kChunk) {
+        const size_t len = std::min(kChunk, n - lo);
+        Jac part;
+        UZK_TRY(msm_dispatch_one(s, offset + lo, d_scalars + lo, len, 1, &part));
+        XYZZ q = xyzz_from_jac(part);
+        xyzz_add(acc, q);
+    }
+    *out = xyzz_to_jac(acc);
+    return UZK_OK;
 }
 
 int uzk_msm_g1_device(uint64_t srs_handle, size_t offset, const void* d_scalars_mont, size_t n, uzk_g1_jac* out) {
