@@ -37,9 +37,9 @@ def emit_terms(terms, lines):
         emit_stmt(terms[i:i + per], lines)
 
 
-def gen(square=False):
+def gen(square=False, relaxed=False):
     L = []
-    name = "mont_sqr_fips" if square else "mont_mul_fips"
+    name = "mont_sqr_fips" if square else ("mont_mul_fips_relaxed" if relaxed else "mont_mul_fips")
     args = "const Fp& a" if square else "const Fp& a, const Fp& b"
     L.append("template <class C>")
     L.append(f"__device__ __forceinline__ Fp {name}({args}) {{")
@@ -63,19 +63,20 @@ def gen(square=False):
         if k < 15:
             L.append("    acc = (acc >> 32) | ((uint64_t)top << 32);")
             L.append("    top = 0;")
-    L.append("    fp_reduce_once_asm<C>(r);")
+    if not relaxed:
+        L.append("    fp_reduce_once_asm<C>(r);")
     L.append("    return r;")
     L.append("}")
     return "\n".join(L)
 
 
-def gen_addsub():
+def gen_addsub(marr="M", suf=""):
     """add / sub / dbl-free helpers: carry chains through VCC, modulus limbs in VGPRs (a VOP2 with
     carry-in cannot also read an SGPR: one constant-bus read per instruction on gfx9)."""
     L = []
     # ---- conditional subtract: r in [0, 2M) -> [0, M)
     L.append("template <class C>")
-    L.append("__device__ __forceinline__ void fp_reduce_once_asm(Fp& r) {")
+    L.append(f"__device__ __forceinline__ void fp_reduce_once{suf}_asm(Fp& r) {{")
     L.append("    uint32_t t0, t1, t2, t3, t4, t5, t6, t7;")
     body = ["v_sub_co_u32_e32 %8, vcc, %0, %16"]
     for i in range(1, 8):
@@ -83,12 +84,12 @@ def gen_addsub():
     for i in range(8):
         body.append(f"v_cndmask_b32_e32 %{i}, %{8 + i}, %{i}, vcc")      # borrow ? r : t
     outs = ", ".join([f'"+v"(r.v[{i}])' for i in range(8)] + [f'"=&v"(t{i})' for i in range(8)])
-    ins = ", ".join(f'"v"(C::M[{i}])' for i in range(8))
+    ins = ", ".join(f'"v"(C::{marr}[{i}])' for i in range(8))
     L.append('    asm("' + "\\n\\t".join(body) + '"\n        : ' + outs + "\n        : " + ins + '\n        : "vcc");')
     L.append("}")
     # ---- add
     L.append("template <class C>")
-    L.append("__device__ __forceinline__ Fp fp_add_asm(const Fp& a, const Fp& b) {")
+    L.append(f"__device__ __forceinline__ Fp fp_add{suf}_asm(const Fp& a, const Fp& b) {{")
     L.append("    Fp r = a;")
     body = ["v_add_co_u32_e32 %0, vcc, %0, %8"]
     for i in range(1, 8):
@@ -96,12 +97,12 @@ def gen_addsub():
     outs = ", ".join(f'"+v"(r.v[{i}])' for i in range(8))
     ins = ", ".join(f'"v"(b.v[{i}])' for i in range(8))
     L.append('    asm("' + "\\n\\t".join(body) + '"\n        : ' + outs + "\n        : " + ins + '\n        : "vcc");')
-    L.append("    fp_reduce_once_asm<C>(r);")
+    L.append(f"    fp_reduce_once{suf}_asm<C>(r);")
     L.append("    return r;")
     L.append("}")
     # ---- sub: d = a - b; mask = borrow ? ~0 : 0; d += M & mask   (M stays in SGPRs here)
     L.append("template <class C>")
-    L.append("__device__ __forceinline__ Fp fp_sub_asm(const Fp& a, const Fp& b) {")
+    L.append(f"__device__ __forceinline__ Fp fp_sub{suf}_asm(const Fp& a, const Fp& b) {{")
     L.append("    Fp r = a;")
     L.append("    uint32_t mask;")
     L.append("    uint32_t t0, t1, t2, t3, t4, t5, t6, t7;")
@@ -117,7 +118,7 @@ def gen_addsub():
     for i in range(1, 8):
         body.append(f"v_addc_co_u32_e32 %{i}, vcc, %{i}, %{8 + i}, vcc")
     outs = ", ".join([f'"+v"(r.v[{i}])' for i in range(8)] + [f'"=&v"(t{i})' for i in range(8)])
-    ins = ", ".join(['"v"(mask)'] + [f'"s"(C::M[{i}])' for i in range(8)])
+    ins = ", ".join(['"v"(mask)'] + [f'"s"(C::{marr}[{i}])' for i in range(8)])
     L.append('    asm("' + "\\n\\t".join(body) + '"\n        : ' + outs + "\n        : " + ins + '\n        : "vcc");')
     L.append("    return r;")
     L.append("}")
@@ -133,6 +134,12 @@ def main():
         f.write(gen_addsub())
         f.write("\n\n")
         f.write(gen(False))
+        f.write("\n\n")
+        f.write("// ---- relaxed domain [0, 2M): the product skips its final conditional subtraction\n")
+        f.write("// (inputs < 2M give outputs < 2M because 4M < 2^256); add/sub wrap at 2M.\n")
+        f.write(gen_addsub("M2", "_2m"))
+        f.write("\n\n")
+        f.write(gen(False, relaxed=True))
         f.write("\n")
 
 

@@ -92,6 +92,43 @@ UZK_HD void xyzz_madd(XYZZ& acc, const Affine& p_in, bool negate) {
     acc.zz = Fq::mul(acc.zz, PP);
     acc.zzz = Fq::mul(acc.zzz, PPP);
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+// The bucket loop's mixed addition with the accumulator kept in the relaxed domain [0, 2M): same
+// formulas, ten products without their final conditional subtraction.  p is canonical (an SRS
+// point); the rare doubling / cancellation branches go through the canonical code.
+__device__ __forceinline__ void xyzz_canon(XYZZ& a) {
+    a.x = Fq::canon(a.x); a.y = Fq::canon(a.y); a.zz = Fq::canon(a.zz); a.zzz = Fq::canon(a.zzz);
+}
+__device__ __forceinline__ void xyzz_madd_rx(XYZZ& acc, const Affine& p_in, bool negate) {
+    if (affine_is_inf(p_in)) return;
+    Affine p = p_in;
+    if (negate) p.y = Fq::neg(p.y);
+    if (Fq::is_zero_rx(acc.zz)) { acc = xyzz_from_affine(p); return; }
+    Fp U2 = Fq::mul_rx(p.x, acc.zz);
+    Fp S2 = Fq::mul_rx(p.y, acc.zzz);
+    Fp Pd = Fq::sub_rx(U2, acc.x);
+    Fp Rd = Fq::sub_rx(S2, acc.y);
+    if (Fq::is_zero_rx(Pd)) {
+        if (Fq::is_zero_rx(Rd)) acc = xyzz_dbl_affine(p);
+        else acc = xyzz_inf();
+        return;
+    }
+    Fp PP = Fq::mul_rx(Pd, Pd);
+    Fp PPP = Fq::mul_rx(Pd, PP);
+    Fp Q = Fq::mul_rx(acc.x, PP);
+    Fp X3 = Fq::sub_rx(Fq::sub_rx(Fq::mul_rx(Rd, Rd), PPP), Fq::dbl_rx(Q));
+    Fp Y3 = Fq::sub_rx(Fq::mul_rx(Rd, Fq::sub_rx(Q, X3)), Fq::mul_rx(acc.y, PPP));
+    acc.x = X3;
+    acc.y = Y3;
+    acc.zz = Fq::mul_rx(acc.zz, PP);
+    acc.zzz = Fq::mul_rx(acc.zzz, PPP);
+}
+#elif defined(__HIPCC__)
+// host pass of a HIP translation unit: kernels that call these are only parsed, never emitted
+__device__ void xyzz_canon(XYZZ& a);
+__device__ void xyzz_madd_rx(XYZZ& acc, const Affine& p_in, bool negate);
+#endif
+
 // acc += q, both XYZZ.  12M + 2S.
 UZK_HD void xyzz_add(XYZZ& acc, const XYZZ& q) {
     if (xyzz_is_inf(q)) return;

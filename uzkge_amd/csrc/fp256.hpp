@@ -32,6 +32,8 @@ struct FqCfg {
     static constexpr uint32_t R2[8] = {0x538afa89u, 0xf32cfc5bu, 0xd44501fbu, 0xb5e71911u,
                                        0x0a417ff6u, 0x47ab1effu, 0xcab8351fu, 0x06d89f71u};
     static constexpr uint32_t INV = 0xe4866389u;   // -M^-1 mod 2^32
+    static constexpr uint32_t M2[8] = {0xb0f9fa8eu, 0x7841182du, 0xd0e3951au, 0x2f02d522u,
+                                       0x0302b0bbu, 0x70a08b6du, 0xc2634053u, 0x60c89ce5u};   // 2M
 };
 struct FrCfg {
     static constexpr uint32_t M[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u,
@@ -41,6 +43,8 @@ struct FrCfg {
     static constexpr uint32_t R2[8] = {0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u,
                                        0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u};
     static constexpr uint32_t INV = 0xefffffffu;
+    static constexpr uint32_t M2[8] = {0xe0000002u, 0x87c3eb27u, 0xf372e122u, 0x5067d090u,
+                                       0x0302b0bau, 0x70a08b6du, 0xc2634053u, 0x60c89ce5u};   // 2M
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -50,6 +54,14 @@ template <class C>
 __device__ __forceinline__ Fp fp_add_asm(const Fp& a, const Fp& b);
 template <class C>
 __device__ __forceinline__ Fp fp_sub_asm(const Fp& a, const Fp& b);
+template <class C>
+__device__ __forceinline__ Fp mont_mul_fips_relaxed(const Fp& a, const Fp& b);
+template <class C>
+__device__ __forceinline__ Fp fp_add_2m_asm(const Fp& a, const Fp& b);
+template <class C>
+__device__ __forceinline__ Fp fp_sub_2m_asm(const Fp& a, const Fp& b);
+template <class C>
+__device__ __forceinline__ void fp_reduce_once_asm(Fp& r);
 #endif
 
 template <class C>
@@ -194,6 +206,28 @@ struct Field {
         return reduce_once(r);     // result < 2M and M < 2^254 so t[8] == 0 here
     }
     UZK_HD static Fp sqr(const Fp& a) { return mul(a, a); }
+#if defined(__HIP_DEVICE_COMPILE__)
+    // Relaxed domain [0, 2M) (device hot loops only): the product skips its final conditional
+    // subtraction -- inputs < 2M give (ab + mM)/2^256 < 1.76 M -- and add/sub wrap at 2M.
+    __device__ __forceinline__ static Fp mul_rx(const Fp& a, const Fp& b) { return mont_mul_fips_relaxed<C>(a, b); }
+    __device__ __forceinline__ static Fp sub_rx(const Fp& a, const Fp& b) { return fp_sub_2m_asm<C>(a, b); }
+    __device__ __forceinline__ static Fp add_rx(const Fp& a, const Fp& b) { return fp_add_2m_asm<C>(a, b); }
+    __device__ __forceinline__ static Fp dbl_rx(const Fp& a) { return fp_add_2m_asm<C>(a, a); }
+    __device__ __forceinline__ static bool is_zero_rx(const Fp& a) {      // a in [0, 2M): zero mod M <=> a in {0, M}
+        uint32_t z = 0, m = 0;
+        for (int i = 0; i < 8; ++i) { z |= a.v[i]; m |= a.v[i] ^ C::M[i]; }
+        return z == 0 || m == 0;
+    }
+    __device__ __forceinline__ static Fp canon(const Fp& a) { Fp r = a; fp_reduce_once_asm<C>(r); return r; }
+#elif defined(__HIPCC__)
+    // host pass of a HIP translation unit: device code that calls these is parsed, never emitted
+    __device__ static Fp mul_rx(const Fp& a, const Fp& b);
+    __device__ static Fp sub_rx(const Fp& a, const Fp& b);
+    __device__ static Fp add_rx(const Fp& a, const Fp& b);
+    __device__ static Fp dbl_rx(const Fp& a);
+    __device__ static bool is_zero_rx(const Fp& a);
+    __device__ static Fp canon(const Fp& a);
+#endif
     UZK_HD static Fp from_mont(const Fp& a) {
         Fp o = zero(); o.v[0] = 1;
         return mul(a, o);

@@ -339,7 +339,7 @@ __device__ __forceinline__ void find_task(uint32_t tid, const uint32_t* __restri
     j = lt - off[lo];
 }
 
-template <int MINW>
+template <int MINW, bool RELAXED>
 __global__ __launch_bounds__(256, MINW) void msm_accumulate_kernel(const Affine* __restrict__ points,
                                                              const uint32_t* __restrict__ sorted,
                                                              const uint32_t* __restrict__ bucket_start,
@@ -370,8 +370,10 @@ __global__ __launch_bounds__(256, MINW) void msm_accumulate_kernel(const Affine*
             e = run[k + 1];
             p = load_point(points, e & ~kSignBit);
         }
-        xyzz_madd(acc, cur, neg);
+        if constexpr (RELAXED) xyzz_madd_rx(acc, cur, neg);
+        else xyzz_madd(acc, cur, neg);
     }
+    if constexpr (RELAXED) xyzz_canon(acc);
     partials[tid] = acc;
 }
 
@@ -777,11 +779,11 @@ int msm_run(Ctx& c, const Affine* points, const Fp* d_scalars, size_t n, uint32_
     {
         KernelScope ks(c, "msm_accumulate");
         const dim3 grid((unsigned)((bound0 + 255) / 256));
-        if (c.tune_acc_variant == 1)
-            hipLaunchKernelGGL(msm_accumulate_kernel<4>, grid, dim3(256), 0, st, points, sorted, bstart, bcount,
+        if (c.tune_acc_variant == 1)        // canonical arithmetic throughout (cross-check of the relaxed loop)
+            hipLaunchKernelGGL((msm_accumulate_kernel<1, false>), grid, dim3(256), 0, st, points, sorted, bstart, bcount,
                                off_cur, base_cur, part_cur, NB, Wd, L);
         else
-            hipLaunchKernelGGL(msm_accumulate_kernel<1>, grid, dim3(256), 0, st, points, sorted, bstart, bcount,
+            hipLaunchKernelGGL((msm_accumulate_kernel<1, true>), grid, dim3(256), 0, st, points, sorted, bstart, bcount,
                                off_cur, base_cur, part_cur, NB, Wd, L);
     }
     UZK_HIP(hipGetLastError());

@@ -127,6 +127,21 @@ __device__ __forceinline__ void radix4(Fp& x0, Fp& x1, Fp& x2, Fp& x3, const Fp&
     swap_fp(x1, x2);
 }
 
+// The pass kernels keep their data in the relaxed domain [0, 2M) (fp256.hpp): every product skips
+// its final conditional subtraction; only the LAST pass canonicalises, on its way to memory.
+__device__ __forceinline__ void bf2_rx(Fp& a, Fp& b) {
+    Fp s = Fr::add_rx(a, b);
+    b = Fr::sub_rx(a, b);
+    a = s;
+}
+__device__ __forceinline__ void radix4_rx(Fp& x0, Fp& x1, Fp& x2, Fp& x3, const Fp& w4) {
+    bf2_rx(x0, x2);
+    bf2_rx(x1, x3); x3 = Fr::mul_rx(x3, w4);
+    bf2_rx(x0, x1);
+    bf2_rx(x2, x3);
+    swap_fp(x1, x2);
+}
+
 struct PassArgs {
     uint64_t batch_stride; // elements between consecutive vectors of a batch (= N)
     uint64_t stride;       // N / R
@@ -177,10 +192,10 @@ __global__ __launch_bounds__(512) void ntt_pass_kernel(const Fp* __restrict__ in
     // ---- sub-pass 0: radix 4 on rows q + t*Q, straight from global memory (S = 1: m' = q, s = 0)
 #pragma unroll
     for (int t = 0; t < 4; ++t) x[t] = in[i + (uint64_t)(q + t * Q) * a.stride];
-    radix4(x[0], x[1], x[2], x[3], w4);
+    radix4_rx(x[0], x[1], x[2], x[3], w4);
     if constexpr (N4 > 1 || TAIL2) {
 #pragma unroll
-        for (int s = 1; s < 4; ++s) x[s] = Fr::mul(x[s], a.tw256[(q * s) << SH]);
+        for (int s = 1; s < 4; ++s) x[s] = Fr::mul_rx(x[s], a.tw256[(q * s) << SH]);
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s) rows[s] = q * 4 + s;
@@ -195,12 +210,12 @@ __global__ __launch_bounds__(512) void ntt_pass_kernel(const Fp* __restrict__ in
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < 4; ++t) x[t] = lds_get(lds, (q + t * Q) * T + col);
-        radix4(x[0], x[1], x[2], x[3], w4);
+        radix4_rx(x[0], x[1], x[2], x[3], w4);
         const int mp = q >> (2 * k), sl = q & (S - 1);
         const bool more = (R >> (2 * k + 2)) > 1;    // M' = R / (S*4) > 1: further sub-passes follow
         if (more) {
 #pragma unroll
-            for (int s = 1; s < 4; ++s) x[s] = Fr::mul(x[s], a.tw256[((S * mp * s)) << SH]);
+            for (int s = 1; s < 4; ++s) x[s] = Fr::mul_rx(x[s], a.tw256[((S * mp * s)) << SH]);
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) rows[s] = (mp << (2 * k + 2)) + s * S + sl;
@@ -216,7 +231,7 @@ __global__ __launch_bounds__(512) void ntt_pass_kernel(const Fp* __restrict__ in
             const int ib = q + u * Q;
             x[2 * u] = lds_get(lds, ib * T + col);
             x[2 * u + 1] = lds_get(lds, (ib + R / 2) * T + col);
-            bf2(x[2 * u], x[2 * u + 1]);
+            bf2_rx(x[2 * u], x[2 * u + 1]);
             rows[2 * u] = ib;
             rows[2 * u + 1] = ib + R / 2;
         }
@@ -236,7 +251,7 @@ __global__ __launch_bounds__(512) void ntt_pass_kernel(const Fp* __restrict__ in
             const int e = tid + j * 512;
             const int ce = e / R, re = e % R;
             Fp v = lds_get(lds, ce * (R + 1) + re);
-            v = Fr::mul(v, a.twp[base + e]);
+            v = Fr::mul_rx(v, a.twp[base + e]);      // FIRST is never the last pass: stays relaxed
             out[base + e] = v;
         }
     } else {
@@ -245,7 +260,8 @@ __global__ __launch_bounds__(512) void ntt_pass_kernel(const Fp* __restrict__ in
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             Fp v = x[j];
-            if (a.twp != nullptr) v = Fr::mul(v, a.twp[(mp << B) + rows[j]]);
+            if (a.twp != nullptr) v = Fr::mul_rx(v, a.twp[(mp << B) + rows[j]]);
+            else v = Fr::canon(v);                 // last pass: back to [0, M)
             out[base + ((uint64_t)rows[j] << a.log_S)] = v;
         }
     }
