@@ -571,7 +571,7 @@ void* uzk_stream(void) {
 }
 int uzk_msm_set_window_bits(int c) {
     API_LOCK;
-    if (c != 0 && (c < 4 || c > 16)) { set_error("window bits must be 0 (auto) or 4..16"); return UZK_ERR_PARAMETER; }
+    if (c != 0 && (c < 4 || c > 22)) { set_error("window bits must be 0 (auto) or 4..22"); return UZK_ERR_PARAMETER; }
     ctx().msm_window_bits = c;
     return UZK_OK;
 }

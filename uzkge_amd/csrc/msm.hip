@@ -45,7 +45,7 @@ struct MsmWork {
     DevBuf digits, bucket_count, bucket_start, sorted, buckets, partials, win_sums;
     DevBuf ent[2];                           // radix ping-pong ({key, val} entries)
     DevBuf counts[kMaxPasses], segs_start[kMaxPasses], segs_len[kMaxPasses];
-    DevBuf lvl_cnt[2], lvl_off[2], lvl_part[2], small;
+    DevBuf lvl_cnt[2], lvl_off[2], lvl_part[2], small, task_desc;
     XYZZ* h_sums = nullptr;                  // pinned
     size_t h_sums_cap = 0;
     uint32_t* h_max = nullptr;               // pinned: largest bucket population of the current call
@@ -339,27 +339,93 @@ __device__ __forceinline__ void find_task(uint32_t tid, const uint32_t* __restri
     j = lt - off[lo];
 }
 
-template <int MINW, bool RELAXED>
-__global__ __launch_bounds__(256, MINW) void msm_accumulate_kernel(const Affine* __restrict__ points,
-                                                             const uint32_t* __restrict__ sorted,
-                                                             const uint32_t* __restrict__ bucket_start,
-                                                             const uint32_t* __restrict__ bucket_count,
-                                                             const uint32_t* __restrict__ task_off,
-                                                             const uint32_t* __restrict__ win_base,
-                                                             XYZZ* __restrict__ partials, uint32_t NB,
-                                                             uint32_t W, uint32_t L) {
-    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= win_base[W]) return;
+// Length-ordered task schedule.  Lanes of a wave run consecutive schedule slots, so slots are grouped
+// by trip count (longest first): a wave then has no idle lanes waiting for its longest run, and the
+// grid's tail is made of the shortest tasks.  desc[slot] = {first sorted index (absolute), count}.
+// Pass 1 counts task lengths (<= 255) per workgroup and reserves output ranges; pass 2 fills them.
+struct TaskDesc { uint32_t start, cnt, task; uint32_t pad; };
+constexpr uint32_t kLenBins = 256;
+
+__device__ __forceinline__ void task_extent(uint32_t tid, const uint32_t* __restrict__ win_base, uint32_t W,
+                                            const uint32_t* __restrict__ task_off, const uint32_t* __restrict__ bucket_start,
+                                            const uint32_t* __restrict__ bucket_count, uint32_t NB, uint32_t L,
+                                            uint32_t& start, uint32_t& cnt) {
     uint32_t w, b, j;
     find_task(tid, win_base, W, task_off, NB, w, b, j);
-    // balanced split: the bucket's T = ceil(total / L) tasks get floor(total/T) or +1 points each,
-    // so lanes of one wave (consecutive tasks) run the same trip count to within one point
+    // balanced split: the bucket's T = ceil(total / L) tasks get floor(total/T) or +1 points each
     const uint32_t total = bucket_count[(size_t)w * NB + b];
     const uint32_t T = (total + L - 1) / L;
     const uint32_t q = total / T, r = total - q * T;
-    const uint32_t first = j * q + min(j, r);
-    const uint32_t cnt = q + (j < r ? 1u : 0u);
-    const uint32_t* run = sorted + bucket_start[(size_t)w * NB + b] + first;   // absolute start
+    start = bucket_start[(size_t)w * NB + b] + j * q + min(j, r);
+    cnt = q + (j < r ? 1u : 0u);
+}
+// hist[len] += number of tasks of that length
+__global__ __launch_bounds__(256) void msm_task_hist_kernel(const uint32_t* __restrict__ win_base, uint32_t W,
+                                                            const uint32_t* __restrict__ task_off,
+                                                            const uint32_t* __restrict__ bucket_start,
+                                                            const uint32_t* __restrict__ bucket_count, uint32_t NB, uint32_t L,
+                                                            uint32_t* __restrict__ hist) {
+    __shared__ uint32_t h[kLenBins];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid < win_base[W]) {
+        uint32_t start, cnt;
+        task_extent(tid, win_base, W, task_off, bucket_start, bucket_count, NB, L, start, cnt);
+        atomicAdd(&h[min(cnt, kLenBins - 1)], 1u);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+// cursor[len] = number of tasks strictly longer than len  (longest first)
+__global__ __launch_bounds__(256) void msm_task_scan_kernel(const uint32_t* __restrict__ hist, uint32_t* __restrict__ cursor) {
+    __shared__ uint32_t h[kLenBins];
+    h[threadIdx.x] = hist[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int l = kLenBins - 1; l >= 0; --l) { const uint32_t v = h[l]; h[l] = run; run += v; }
+    }
+    __syncthreads();
+    cursor[threadIdx.x] = h[threadIdx.x];
+}
+__global__ __launch_bounds__(256) void msm_task_fill_kernel(const uint32_t* __restrict__ win_base, uint32_t W,
+                                                            const uint32_t* __restrict__ task_off,
+                                                            const uint32_t* __restrict__ bucket_start,
+                                                            const uint32_t* __restrict__ bucket_count, uint32_t NB, uint32_t L,
+                                                            uint32_t* __restrict__ cursor, TaskDesc* __restrict__ desc) {
+    __shared__ uint32_t h[kLenBins], base[kLenBins];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = tid < win_base[W];
+    uint32_t start = 0, cnt = 0, key = 0, rank = 0;
+    if (live) {
+        task_extent(tid, win_base, W, task_off, bucket_start, bucket_count, NB, L, start, cnt);
+        key = min(cnt, kLenBins - 1);
+        rank = atomicAdd(&h[key], 1u);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], h[threadIdx.x]);
+    __syncthreads();
+    if (live) {
+        TaskDesc d;
+        d.start = start; d.cnt = cnt; d.task = tid; d.pad = 0;
+        desc[base[key] + rank] = d;
+    }
+}
+
+template <int MINW, bool RELAXED>
+__global__ __launch_bounds__(256, MINW) void msm_accumulate_kernel(const Affine* __restrict__ points,
+                                                             const uint32_t* __restrict__ sorted,
+                                                             const TaskDesc* __restrict__ desc,
+                                                             const uint32_t* __restrict__ win_base,
+                                                             XYZZ* __restrict__ partials, uint32_t W) {
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= win_base[W]) return;
+    const TaskDesc d = desc[slot];
+    const uint32_t cnt = d.cnt;
+    const uint32_t* run = sorted + d.start;
     XYZZ acc = xyzz_inf();
     uint32_t e = run[0];
     Affine p = load_point(points, e & ~kSignBit);
@@ -374,7 +440,7 @@ __global__ __launch_bounds__(256, MINW) void msm_accumulate_kernel(const Affine*
         else xyzz_madd(acc, cur, neg);
     }
     if constexpr (RELAXED) xyzz_canon(acc);
-    partials[tid] = acc;
+    partials[d.task] = acc;
 }
 
 // Folding partial sums.  GS lanes of one wave cooperate on one output: lane `sub` adds the partials
@@ -553,17 +619,18 @@ __global__ __launch_bounds__(64) void msm_precompute_kernel(const Affine* __rest
 // ---------------------------------------------------------------------------------------------
 // host
 // ---------------------------------------------------------------------------------------------
-// Window size of the general mode, from a measured sweep (tools/sweep_c.py, MI355X): what matters
-// besides the W*n additions is the population of the TOP window (254 mod c bits): a narrow top
-// window piles n / 2^bits points into each of its few buckets and costs extra fold levels, so only
-// sizes with a wide top window are used (c = 8: 6 bits, c = 15/16: 14 bits).
+// Window size of the general mode, from measured sweeps (tools/sweep_c.py, tools/ab_msm.py, MI355X).
+// Besides the W*n additions what matters is the population of the TOP window (254 mod c bits): a
+// narrow top window piles n / 2^bits points into each of its few buckets and both the sort and the
+// fold levels pay for it, so only sizes with a wide top window are used
+// (c = 8: 6 bits, c = 16: 14 bits, c = 17: 16 bits and only 15 windows).
 static int choose_window_bits(size_t n, int forced) {
-    if (forced >= 4 && forced <= 16) return forced;
+    if (forced >= 4 && forced <= 22) return forced;
     int lg = 0;
     while ((1ull << (lg + 1)) <= n) ++lg;
     if (lg <= 18) return 8;
-    if (lg <= 21) return 15;
-    return 16;
+    if (lg <= 21) return 16;
+    return 17;
 }
 int msm_precompute_window_bits(size_t n, int forced) {
     if (forced >= 4 && forced <= 24) return forced;
@@ -576,7 +643,7 @@ void msm_free(Ctx& c) {
     if (!c.msm) return;
     MsmWork* m = c.msm;
     m->digits.release(); m->bucket_count.release(); m->bucket_start.release(); m->sorted.release();
-    m->buckets.release(); m->partials.release(); m->win_sums.release(); m->small.release();
+    m->buckets.release(); m->partials.release(); m->win_sums.release(); m->small.release(); m->task_desc.release();
     for (int k = 0; k < 2; ++k) {
         m->ent[k].release(); m->lvl_cnt[k].release(); m->lvl_off[k].release(); m->lvl_part[k].release();
     }
@@ -656,7 +723,7 @@ int msm_run(Ctx& c, const Affine* points, const Fp* d_scalars, size_t n, uint32_
     const uint32_t seg = std::max<uint32_t>(1, std::min<uint32_t>(kSeg, NBL / 256));
     const uint32_t groups = (NBL + seg * 256 - 1) / (seg * 256);
     const uint32_t L = c.tune_task_len > 0 ? (uint32_t)c.tune_task_len
-                                           : (uint32_t)std::max<uint64_t>(16, std::min<uint64_t>(64, entries >> 21));
+                                           : (uint32_t)std::max<uint64_t>(16, std::min<uint64_t>(96, entries >> 21));
     const uint32_t G = kCombineFan;
     const uint64_t bound0 = entries / L + TBK;             // upper bound on level-0 tasks
     const uint64_t part_cap = bound0 + 2 * TBK;            // every later level fits too
@@ -698,6 +765,7 @@ int msm_run(Ctx& c, const Affine* points, const Fp* d_scalars, size_t n, uint32_
     }
     UZK_TRY(m.lvl_part[0].reserve((size_t)part_cap * sizeof(XYZZ)));
     UZK_TRY(m.small.reserve(16384));
+    UZK_TRY(m.task_desc.reserve((size_t)bound0 * sizeof(TaskDesc)));
     if (m.h_sums_cap < RW) {
         if (m.h_sums) (void)hipHostFree(m.h_sums);
         UZK_HIP(hipHostMalloc(reinterpret_cast<void**>(&m.h_sums), (size_t)RW * sizeof(XYZZ), hipHostMallocDefault));
@@ -776,15 +844,26 @@ int msm_run(Ctx& c, const Affine* points, const Fp* d_scalars, size_t n, uint32_
                            d_max, NB);
         hipLaunchKernelGGL(msm_win_base_kernel, dim3(1), dim3(1024), 0, st, win_tot, base_cur, Wd);
     }
+    TaskDesc* desc = m.task_desc.as<TaskDesc>();
+    {
+        KernelScope ks(c, "msm_task_order");
+        uint32_t* len_hist = sm + 3328;      // 256 counters, then 256 cursors
+        uint32_t* len_cur = sm + 3328 + kLenBins;
+        UZK_HIP(hipMemsetAsync(len_hist, 0, kLenBins * 4, st));
+        const dim3 tgrid((unsigned)((bound0 + 255) / 256));
+        hipLaunchKernelGGL(msm_task_hist_kernel, tgrid, dim3(256), 0, st, base_cur, Wd, off_cur, bstart, bcount, NB, L, len_hist);
+        hipLaunchKernelGGL(msm_task_scan_kernel, dim3(1), dim3(256), 0, st, len_hist, len_cur);
+        hipLaunchKernelGGL(msm_task_fill_kernel, tgrid, dim3(256), 0, st, base_cur, Wd, off_cur, bstart, bcount, NB, L, len_cur, desc);
+    }
     {
         KernelScope ks(c, "msm_accumulate");
         const dim3 grid((unsigned)((bound0 + 255) / 256));
         if (c.tune_acc_variant == 1)        // canonical arithmetic throughout (cross-check of the relaxed loop)
-            hipLaunchKernelGGL((msm_accumulate_kernel<1, false>), grid, dim3(256), 0, st, points, sorted, bstart, bcount,
-                               off_cur, base_cur, part_cur, NB, Wd, L);
+            hipLaunchKernelGGL((msm_accumulate_kernel<1, false>), grid, dim3(256), 0, st, points, sorted, desc, base_cur,
+                               part_cur, Wd);
         else
-            hipLaunchKernelGGL((msm_accumulate_kernel<1, true>), grid, dim3(256), 0, st, points, sorted, bstart, bcount,
-                               off_cur, base_cur, part_cur, NB, Wd, L);
+            hipLaunchKernelGGL((msm_accumulate_kernel<1, true>), grid, dim3(256), 0, st, points, sorted, desc, base_cur,
+                               part_cur, Wd);
     }
     UZK_HIP(hipGetLastError());
     // the largest bucket decides how many fold levels are needed (one tiny read-back)
