@@ -44,7 +44,7 @@ constexpr int kMaxPasses = 3;
 struct MsmWork {
     DevBuf digits, bucket_count, bucket_start, sorted, buckets, partials, win_sums;
     DevBuf ent[2];                           // radix ping-pong ({key, val} entries)
-    DevBuf counts[kMaxPasses], segs_start[kMaxPasses], segs_len[kMaxPasses];
+    DevBuf counts[kMaxPasses], segs_start[kMaxPasses], segs_len[kMaxPasses], items[kMaxPasses];
     DevBuf lvl_cnt[2], lvl_off[2], lvl_part[2], small, task_desc;
     XYZZ* h_sums = nullptr;                  // pinned
     size_t h_sums_cap = 0;
@@ -93,23 +93,49 @@ struct RadixArgs {
     uint32_t n;                  // FROM_DIGITS: entries per segment
     uint32_t remap_cnt;          // FROM_DIGITS, precomputed mode: val = (k / cnt) * stride + off + k % cnt
     uint32_t remap_stride, remap_off;
+    const uint32_t* item_off;    // else: work items (fixed-size chunks) of segment s are item_off[s] .. item_off[s+1]
+    uint32_t nseg, chunk;        // else: number of segments, entries per work item
     uint32_t shift, mask, bins;  // bin = (key >> shift) & mask
-    uint32_t* counts;            // [seg][chunk][bins]  (hist: counts, after scan: exclusive chunk prefixes)
+    uint32_t* counts;            // pass 0: [seg][chunk][bins], later passes: [item][bins]
+                                 // (hist: counts, after scan: exclusive chunk prefixes)
     uint32_t* bin_base;          // [seg][bins] absolute output start of each bin
     uint32_t* bin_count;         // [seg][bins]
     uint2* out_entries;          // !OUT_VAL
     uint32_t* out_vals;          // OUT_VAL
 };
 
+// Which (segment, chunk) does this workgroup own, where are its counters, and which entries?
+// Pass 0 (FROM_DIGITS): equal segments, grid (nch, nseg).  Later passes: segment lengths are data
+// dependent (a skewed scalar set can put every entry into one segment), so the work is a 1-D list
+// of fixed-size items built from the actual lengths; workgroups past the end of the list leave.
 template <bool FROM_DIGITS>
-__device__ __forceinline__ void radix_chunk_bounds(const RadixArgs& a, uint32_t seg, uint32_t ch, uint32_t nch,
-                                                   uint32_t& base, uint32_t& lo, uint32_t& hi) {
-    uint32_t len;
-    if constexpr (FROM_DIGITS) { base = 0; len = a.n; }
-    else { base = a.seg_start[seg]; len = a.seg_len[seg]; }
-    const uint32_t cs = (len + nch - 1) / nch;
-    lo = min(len, ch * cs);
-    hi = min(len, lo + cs);
+__device__ __forceinline__ bool radix_work(const RadixArgs& a, uint32_t& seg, size_t& cidx, uint32_t& base,
+                                           uint32_t& lo, uint32_t& hi) {
+    if constexpr (FROM_DIGITS) {
+        const uint32_t ch = blockIdx.x, nch = gridDim.x;
+        seg = blockIdx.y;
+        cidx = ((size_t)seg * nch + ch) * a.bins;
+        base = 0;
+        const uint32_t cs = (a.n + nch - 1) / nch;
+        lo = min(a.n, ch * cs);
+        hi = min(a.n, lo + cs);
+        return true;
+    } else {
+        const uint32_t item = blockIdx.x;
+        if (item >= a.item_off[a.nseg]) return false;
+        uint32_t l = 0, h = a.nseg;            // largest s with item_off[s] <= item (skips empty segments)
+        while (h - l > 1) {
+            const uint32_t mid = (l + h) >> 1;
+            if (a.item_off[mid] <= item) l = mid; else h = mid;
+        }
+        seg = l;
+        cidx = (size_t)item * a.bins;
+        base = a.seg_start[seg];
+        const uint32_t len = a.seg_len[seg];
+        lo = min(len, (item - a.item_off[seg]) * a.chunk);
+        hi = min(len, lo + a.chunk);
+        return true;
+    }
 }
 template <bool FROM_DIGITS>
 __device__ __forceinline__ bool radix_load(const RadixArgs& a, uint32_t seg, uint32_t base, uint32_t k, uint32_t& key,
@@ -130,15 +156,14 @@ __device__ __forceinline__ bool radix_load(const RadixArgs& a, uint32_t seg, uin
     }
 }
 
-// grid (nch, nseg)
 template <bool FROM_DIGITS>
 __global__ __launch_bounds__(1024) void msm_radix_hist_kernel(RadixArgs a) {
     __shared__ uint32_t cnt[512];
-    const uint32_t ch = blockIdx.x, seg = blockIdx.y, nch = gridDim.x;
+    uint32_t seg, base, lo, hi;
+    size_t cidx;
+    if (!radix_work<FROM_DIGITS>(a, seg, cidx, base, lo, hi)) return;
     for (uint32_t b = threadIdx.x; b < a.bins; b += blockDim.x) cnt[b] = 0;
     __syncthreads();
-    uint32_t base, lo, hi;
-    radix_chunk_bounds<FROM_DIGITS>(a, seg, ch, nch, base, lo, hi);
     for (uint32_t k = lo + threadIdx.x; k < hi; k += blockDim.x) {
         if constexpr (FROM_DIGITS) {
             const uint32_t mag = a.digits[(size_t)seg * a.n + k] & ~kSignBit;
@@ -148,7 +173,7 @@ __global__ __launch_bounds__(1024) void msm_radix_hist_kernel(RadixArgs a) {
         }
     }
     __syncthreads();
-    uint32_t* dst = a.counts + ((size_t)seg * nch + ch) * a.bins;
+    uint32_t* dst = a.counts + cidx;
     for (uint32_t b = threadIdx.x; b < a.bins; b += blockDim.x) dst[b] = cnt[b];
 }
 
@@ -160,8 +185,11 @@ __global__ __launch_bounds__(512) void msm_radix_scan_kernel(RadixArgs a, uint32
     const uint32_t seg = blockIdx.x, b = threadIdx.x;
     uint32_t run = 0;
     if (b < a.bins) {
-        for (uint32_t ch = 0; ch < nch; ++ch) {
-            uint32_t* p = a.counts + ((size_t)seg * nch + ch) * a.bins + b;
+        size_t first = (size_t)seg * nch;
+        uint32_t cnt = nch;
+        if (a.item_off) { first = a.item_off[seg]; cnt = a.item_off[seg + 1] - a.item_off[seg]; }
+        for (uint32_t ch = 0; ch < cnt; ++ch) {
+            uint32_t* p = a.counts + (first + ch) * a.bins + b;
             const uint32_t v = *p;
             *p = run;
             run += v;
@@ -184,16 +212,39 @@ __global__ __launch_bounds__(512) void msm_radix_scan_kernel(RadixArgs a, uint32
     }
 }
 
-// grid (nch, nseg), block TB, tile = TB * E entries sorted in LDS before they are written out
+// item_off[s] = sum_{t < s} ceil(seg_len[t] / chunk), item_off[nseg] = total  (one workgroup)
+__global__ __launch_bounds__(1024) void msm_radix_items_kernel(const uint32_t* __restrict__ seg_len, uint32_t nseg,
+                                                               uint32_t chunk, uint32_t* __restrict__ item_off) {
+    __shared__ uint32_t part[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (nseg + 1023) / 1024;
+    const uint32_t lo = min(nseg, tid * per), hi = min(nseg, lo + per);
+    uint32_t s = 0;
+    for (uint32_t k = lo; k < hi; ++k) s += (seg_len[k] + chunk - 1) / chunk;
+    part[tid] = s;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        uint32_t v = (tid >= off) ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - s;
+    for (uint32_t k = lo; k < hi; ++k) { item_off[k] = run; run += (seg_len[k] + chunk - 1) / chunk; }
+    if (tid == 1023) item_off[nseg] = part[1023];
+}
+
+// block TB, tile = TB * E entries sorted in LDS before they are written out
 template <int TB, int E, bool FROM_DIGITS, bool OUT_VAL>
 __global__ __launch_bounds__(TB) void msm_radix_scatter_kernel(RadixArgs a) {
     constexpr int TILE = TB * E;
     __shared__ uint2 buf[TILE];
     __shared__ uint32_t tcnt[512], toff[512], gcur[512], wsum[16];
-    const uint32_t ch = blockIdx.x, seg = blockIdx.y, nch = gridDim.x, tid = threadIdx.x;
-    uint32_t base, lo, hi;
-    radix_chunk_bounds<FROM_DIGITS>(a, seg, ch, nch, base, lo, hi);
-    const uint32_t* coff = a.counts + ((size_t)seg * nch + ch) * a.bins;
+    const uint32_t tid = threadIdx.x;
+    uint32_t seg, base, lo, hi;
+    size_t cidx;
+    if (!radix_work<FROM_DIGITS>(a, seg, cidx, base, lo, hi)) return;
+    const uint32_t* coff = a.counts + cidx;
     for (uint32_t b = tid; b < a.bins; b += TB) gcur[b] = a.bin_base[(size_t)seg * a.bins + b] + coff[b];
     for (uint32_t t0 = lo; t0 < hi; t0 += TILE) {
         for (uint32_t b = tid; b < a.bins; b += TB) tcnt[b] = 0;
@@ -647,7 +698,9 @@ void msm_free(Ctx& c) {
     for (int k = 0; k < 2; ++k) {
         m->ent[k].release(); m->lvl_cnt[k].release(); m->lvl_off[k].release(); m->lvl_part[k].release();
     }
-    for (int k = 0; k < kMaxPasses; ++k) { m->counts[k].release(); m->segs_start[k].release(); m->segs_len[k].release(); }
+    for (int k = 0; k < kMaxPasses; ++k) {
+        m->counts[k].release(); m->segs_start[k].release(); m->segs_len[k].release(); m->items[k].release();
+    }
     if (m->h_sums) (void)hipHostFree(m->h_sums);
     if (m->h_max) (void)hipHostFree(m->h_max);
     delete m;
@@ -689,7 +742,7 @@ int msm_build_table(Ctx& c, const Affine* d_points, size_t n, int cb, Affine** t
     return UZK_OK;
 }
 
-struct SortPass { uint32_t shift, bins, nseg, nch; };
+struct SortPass { uint32_t shift, bins, nseg, nch, chunk, items_bound; };
 
 // `points`: base array the sorted indices refer to (the SRS slice, or the window table).
 // Precomputed mode (pre_c > 0): `points` = table, entries of window j index pre_stride * j + pre_off + i.
@@ -740,6 +793,9 @@ int msm_run(Ctx& c, const Affine* points, const Fp* d_scalars, size_t n, uint32_
             sp[p].nseg = nseg;
             const uint64_t avg = std::max<uint64_t>(1, (S0 * (uint64_t)seg_n) / nseg);
             sp[p].nch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(1024, avg / 32768));
+            // later passes: fixed-size work items over the actual segment lengths
+            sp[p].chunk = (p == P - 1) ? 16384u : 32768u;
+            sp[p].items_bound = (uint32_t)(entries / sp[p].chunk) + nseg;
             nseg *= sp[p].bins;
         }
     }
@@ -752,7 +808,8 @@ int msm_run(Ctx& c, const Affine* points, const Fp* d_scalars, size_t n, uint32_
     UZK_TRY(m.partials.reserve((size_t)RW * groups * sizeof(XYZZ)));
     UZK_TRY(m.win_sums.reserve((size_t)RW * sizeof(XYZZ)));
     for (int p = 0; p < P; ++p) {
-        UZK_TRY(m.counts[p].reserve((size_t)sp[p].nseg * sp[p].nch * sp[p].bins * 4));
+        UZK_TRY(m.counts[p].reserve((size_t)(p == 0 ? sp[p].nseg * sp[p].nch : sp[p].items_bound) * sp[p].bins * 4));
+        if (p > 0) UZK_TRY(m.items[p].reserve(((size_t)sp[p].nseg + 1) * 4));
         if (p + 1 < P) {
             UZK_TRY(m.segs_start[p].reserve((size_t)sp[p].nseg * sp[p].bins * 4));
             UZK_TRY(m.segs_len[p].reserve((size_t)sp[p].nseg * sp[p].bins * 4));
@@ -814,7 +871,15 @@ int msm_run(Ctx& c, const Affine* points, const Fp* d_scalars, size_t n, uint32_
             a.bin_base = m.segs_start[p].as<uint32_t>(); a.bin_count = m.segs_len[p].as<uint32_t>();
             a.out_entries = m.ent[p & 1].as<uint2>();
         }
-        const dim3 grid(sp[p].nch, sp[p].nseg);
+        if (!first) {
+            a.item_off = m.items[p].as<uint32_t>();
+            a.nseg = sp[p].nseg;
+            a.chunk = sp[p].chunk;
+            KernelScope ks(c, "msm_sort_items");
+            hipLaunchKernelGGL(msm_radix_items_kernel, dim3(1), dim3(1024), 0, st, a.seg_len, a.nseg, a.chunk,
+                               m.items[p].as<uint32_t>());
+        }
+        const dim3 grid = first ? dim3(sp[p].nch, sp[p].nseg) : dim3(sp[p].items_bound);
         {
             KernelScope ks(c, "msm_sort_hist");
             if (first) hipLaunchKernelGGL(msm_radix_hist_kernel<true>, grid, dim3(1024), 0, st, a);
