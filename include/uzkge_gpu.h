@@ -168,7 +168,7 @@ void* uzk_stream(void);
 /* Tuning knobs (0 = automatic): MSM window bits. */
 int uzk_msm_set_window_bits(int c);
 /* Experiment switches for A/B measurements in one process (keys: "msm_acc_variant",
- * "msm_task_len", "msm_no_precompute"); never needed for correctness. */
+ * "msm_task_len", "msm_no_precompute", "msm_fold_group", "msm_overlap"); never needed for correctness. */
 int uzk_tune(const char* key, int value);
 
 #ifdef __cplusplus

@@ -203,3 +203,26 @@ def test_precomputed_mode_matches_oracle(gpu, c):
         assert a == affine_of(gpu.msm(srs, s))
     finally:
         srs.release()
+
+
+def test_experiment_switches_do_not_change_the_result(gpu):
+    """uzk_tune knobs (canonical-arithmetic accumulate loop, two overlapping pipeline groups, forced
+    one-lane folds) are speed experiments: the commitment must be identical with each of them."""
+    import torch
+    n = 1 << 20
+    pts = torch.empty((n, 8), dtype=torch.int64, device="cuda")
+    sc = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    gpu.synth_points_random(pts.data_ptr(), n, 3)
+    gpu.synth_scalars(sc.data_ptr(), n, 4)
+    srs = gpu.Srs.from_device(pts.data_ptr(), n)
+    try:
+        ref = gpu.g1_to_affine(gpu.msm_device(srs, sc.data_ptr(), n))
+        for key in ("msm_acc_variant", "msm_overlap", "msm_fold_group"):
+            gpu.tune(key, 1)
+            try:
+                assert np.array_equal(gpu.g1_to_affine(gpu.msm_device(srs, sc.data_ptr(), n)), ref), key
+            finally:
+                gpu.tune(key, 0)
+    finally:
+        srs.release()

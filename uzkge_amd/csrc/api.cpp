@@ -67,15 +67,16 @@ void Ctx::prof_begin(const char* name) {
     pe.name = name;
     pe.e0 = get_event();
     pe.e1 = get_event();
-    (void)hipEventRecord(pe.e0, stream);
+    (void)hipEventRecord(pe.e0, cur_stream ? cur_stream : stream);
     prof_pending.push_back(pe);
 }
 void Ctx::prof_end() {
-    if (!prof_pending.empty()) (void)hipEventRecord(prof_pending.back().e1, stream);
+    if (!prof_pending.empty()) (void)hipEventRecord(prof_pending.back().e1, cur_stream ? cur_stream : stream);
 }
 int Ctx::prof_collect() {
     if (prof_pending.empty()) return UZK_OK;
     UZK_HIP(hipStreamSynchronize(stream));
+    if (stream2) UZK_HIP(hipStreamSynchronize(stream2));
     for (auto& pe : prof_pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, pe.e0, pe.e1) == hipSuccess) {
@@ -175,6 +176,7 @@ int uzk_shutdown(void) {
     c.event_pool.clear();
     (void)hipStreamDestroy(c.stream);
     c.stream = nullptr;
+    c.cur_stream = nullptr;
     c.ready = false;
     c.device = -1;
     return UZK_OK;
@@ -584,6 +586,7 @@ int uzk_tune(const char* key, int value) {
     else if (!std::strcmp(key, "msm_task_len")) c.tune_task_len = value;
     else if (!std::strcmp(key, "msm_no_precompute")) c.tune_no_precompute = value;
     else if (!std::strcmp(key, "msm_fold_group")) c.tune_fold_group = value;
+    else if (!std::strcmp(key, "msm_overlap")) c.tune_overlap = value;
     else { set_error("uzk_tune: unknown key %s", key); return UZK_ERR_PARAMETER; }
     return UZK_OK;
 }

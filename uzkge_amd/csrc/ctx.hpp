@@ -53,6 +53,8 @@ struct Ctx {
     bool ready = false;
     int device = -1;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;     // second pipeline instance of large MSMs
+    hipStream_t cur_stream = nullptr;  // stream the profiling events are recorded on
     int num_cus = 256;
     // profiling
     bool prof_on = false;
@@ -70,7 +72,8 @@ struct Ctx {
     int tune_acc_variant = 0; // experiments (uzk_tune)
     int tune_task_len = 0;
     int tune_no_precompute = 0;
-    int tune_fold_group = 0;  // 1: force one lane per bucket in the fold kernels
+    int tune_fold_group = 0;
+    int tune_overlap = 0;     // 1: run large MSMs as two overlapping pipeline instances (experiment)  // 1: force one lane per bucket in the fold kernels
     // SRS registry
     struct Srs {
         Affine* d_points = nullptr;

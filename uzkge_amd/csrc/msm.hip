@@ -58,17 +58,17 @@ __host__ __device__ inline int msm_num_windows(int c) {
 }
 
 // ---- 1. digits -------------------------------------------------------------------------------
-// scalars: [batch][n]; digits: [batch][W][n]
+// scalars: [batch][n]; digits: [batch][wcnt][n] for the windows w0 .. w0 + wcnt of the W-window recoding
 __global__ __launch_bounds__(256) void msm_digits_kernel(const Fp* __restrict__ scalars, uint32_t* __restrict__ digits,
-                                                         uint32_t n, uint32_t batch, int c, int W) {
+                                                         uint32_t n, uint32_t batch, int c, int W, int w0, int wcnt) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (uint64_t)n * batch) return;
     const uint32_t b = (uint32_t)(t / n), i = (uint32_t)(t % n);
     Fp k = Fr::from_mont(scalars[t]);
     const uint32_t mask = (1u << c) - 1, half = 1u << (c - 1);
     uint32_t carry = 0;
-    uint32_t* dst = digits + (size_t)b * W * n + i;
-    for (int w = 0; w < W; ++w) {
+    uint32_t* dst = digits + (size_t)b * wcnt * n + i;
+    for (int w = 0; w < w0 + wcnt && w < W; ++w) {       // the carry chain starts at window 0
         uint32_t d = (k.v[0] & mask) + carry;
         // k >>= c
 #pragma unroll
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void msm_digits_kernel(const Fp* __restrict__ 
         uint32_t out;
         if (d > half) { out = ((1u << c) - d) | kSignBit; carry = 1; }
         else { out = d; carry = 0; }
-        dst[(size_t)w * n] = out;
+        if (w >= w0) dst[(size_t)(w - w0) * n] = out;
     }
 }
 
@@ -692,19 +692,22 @@ int msm_precompute_window_bits(size_t n, int forced) {
 
 void msm_free(Ctx& c) {
     if (!c.msm) return;
-    MsmWork* m = c.msm;
-    m->digits.release(); m->bucket_count.release(); m->bucket_start.release(); m->sorted.release();
-    m->buckets.release(); m->partials.release(); m->win_sums.release(); m->small.release(); m->task_desc.release();
-    for (int k = 0; k < 2; ++k) {
-        m->ent[k].release(); m->lvl_cnt[k].release(); m->lvl_off[k].release(); m->lvl_part[k].release();
+    for (int q = 0; q < 2; ++q) {
+        MsmWork* m = &c.msm[q];
+        m->digits.release(); m->bucket_count.release(); m->bucket_start.release(); m->sorted.release();
+        m->buckets.release(); m->partials.release(); m->win_sums.release(); m->small.release(); m->task_desc.release();
+        for (int k = 0; k < 2; ++k) {
+            m->ent[k].release(); m->lvl_cnt[k].release(); m->lvl_off[k].release(); m->lvl_part[k].release();
+        }
+        for (int k = 0; k < kMaxPasses; ++k) {
+            m->counts[k].release(); m->segs_start[k].release(); m->segs_len[k].release(); m->items[k].release();
+        }
+        if (m->h_sums) (void)hipHostFree(m->h_sums);
+        if (m->h_max) (void)hipHostFree(m->h_max);
     }
-    for (int k = 0; k < kMaxPasses; ++k) {
-        m->counts[k].release(); m->segs_start[k].release(); m->segs_len[k].release(); m->items[k].release();
-    }
-    if (m->h_sums) (void)hipHostFree(m->h_sums);
-    if (m->h_max) (void)hipHostFree(m->h_max);
-    delete m;
+    delete[] c.msm;
     c.msm = nullptr;
+    if (c.stream2) { (void)hipStreamDestroy(c.stream2); c.stream2 = nullptr; }
 }
 
 // Builds the window table of a registered SRS: table[j*n + i] = 2^(cb*j) * P_i, j < W.
@@ -744,123 +747,128 @@ int msm_build_table(Ctx& c, const Affine* d_points, size_t n, int cb, Affine** t
 
 struct SortPass { uint32_t shift, bins, nseg, nch, chunk, items_bound; };
 
-// `points`: base array the sorted indices refer to (the SRS slice, or the window table).
-// Precomputed mode (pre_c > 0): `points` = table, entries of window j index pre_stride * j + pre_off + i.
-// `batch` scalar vectors of n elements each share the same bases; out_host[batch].
-int msm_run(Ctx& c, const Affine* points, const Fp* d_scalars, size_t n, uint32_t batch, Jac* out_host, int pre_c,
-            uint32_t pre_stride, uint32_t pre_off) {
-    if (batch == 0) return UZK_OK;
-    if (n == 0) { for (uint32_t b = 0; b < batch; ++b) out_host[b] = jac_inf(); return UZK_OK; }
-    if (n >= (1ull << 31)) { set_error("msm: n = %zu exceeds 2^31 - 1 points per call", n); return UZK_ERR_PARAMETER; }
-    if (!c.msm) c.msm = new MsmWork();
-    MsmWork& m = *c.msm;
-    const bool pre = pre_c > 0;
-    const int cb = pre ? pre_c : choose_window_bits(n, c.msm_window_bits);
-    const uint32_t W = (uint32_t)msm_num_windows(cb);
-    const uint32_t n32 = (uint32_t)n;
-    const uint64_t per_poly = (uint64_t)W * n;                 // (point, window) pairs of one scalar vector
-    const uint64_t entries = per_poly * batch;
-    if (entries >= (1ull << 31)) { set_error("msm: batch*W*n overflows the 31-bit index space"); return UZK_ERR_PARAMETER; }
-    const uint32_t kb = (uint32_t)cb - 1;                  // bucket key bits
-    const uint32_t NBL = 1u << kb;                         // buckets of one logical window
-    // sort segments: one per window (general) or one for everything (precomputed)
-    const uint32_t S0 = pre ? batch : batch * W;
-    const uint32_t seg_n = pre ? (uint32_t)per_poly : n32;  // entries per initial segment
-    // bucket windows as seen by the scan / task kernels: <= 2^15 buckets each
-    const uint32_t NB = std::min<uint32_t>(NBL, 1u << 15);
-    const uint32_t Wd = (uint32_t)(((uint64_t)S0 * NBL) / NB);
-    const uint64_t TBK = (uint64_t)Wd * NB;                // all buckets
-    if (Wd > 1024) { set_error("msm: too many bucket windows (%u): lower the batch", Wd); return UZK_ERR_PARAMETER; }
-    // reduction geometry: `seg` buckets per lane, 256 lanes per group
-    const uint32_t RW = pre ? batch : batch * W;            // logical windows in the reduction
-    const uint32_t seg = std::max<uint32_t>(1, std::min<uint32_t>(kSeg, NBL / 256));
-    const uint32_t groups = (NBL + seg * 256 - 1) / (seg * 256);
-    const uint32_t L = c.tune_task_len > 0 ? (uint32_t)c.tune_task_len
-                                           : (uint32_t)std::max<uint64_t>(16, std::min<uint64_t>(96, entries >> 21));
-    const uint32_t G = kCombineFan;
-    const uint64_t bound0 = entries / L + TBK;             // upper bound on level-0 tasks
-    const uint64_t part_cap = bound0 + 2 * TBK;            // every later level fits too
-    // radix plan: P passes of <= 9 bits, high bits first
-    const int P = kb <= 9 ? 1 : (kb <= 18 ? 2 : 3);
+// One pipeline instance: the windows [w0, w0 + W) of every scalar vector, on its own stream with its
+// own workspace.  One instance per call by default; an experimental two-instance mode lets the second
+// group's digit extraction and sort run underneath the first group's bucket accumulation.
+struct MsmGroup {
+    MsmWork* m = nullptr;
+    hipStream_t st = nullptr;
+    // geometry
+    bool pre = false;
+    int cb = 0;
+    uint32_t W_total = 0, w0 = 0, W = 0, n32 = 0, batch = 0;
+    uint64_t per_poly = 0, entries = 0, TBK = 0, bound0 = 0, part_cap = 0;
+    uint32_t kb = 0, NBL = 0, S0 = 0, seg_n = 0, NB = 0, Wd = 0, RW = 0, seg = 0, groups = 0, L = 0;
+    int P = 0;
     SortPass sp[kMaxPasses];
-    {
-        uint32_t rem = kb, nseg = S0;
-        for (int p = 0; p < P; ++p) {
-            const uint32_t bits = (rem + (uint32_t)(P - p) - 1) / (uint32_t)(P - p);
-            rem -= bits;
-            sp[p].shift = rem;
-            sp[p].bins = 1u << bits;
-            sp[p].nseg = nseg;
-            const uint64_t avg = std::max<uint64_t>(1, (S0 * (uint64_t)seg_n) / nseg);
-            sp[p].nch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(1024, avg / 32768));
-            // later passes: fixed-size work items over the actual segment lengths
-            sp[p].chunk = (p == P - 1) ? 16384u : 32768u;
-            sp[p].items_bound = (uint32_t)(entries / sp[p].chunk) + nseg;
-            nseg *= sp[p].bins;
-        }
-    }
+    // state carried from phase 1 to phase 2
+    uint32_t *cnt_cur = nullptr, *off_cur = nullptr, *base_cur = nullptr;
+    XYZZ* part_cur = nullptr;
+};
 
-    UZK_TRY(m.digits.reserve((size_t)entries * 4));
-    UZK_TRY(m.sorted.reserve((size_t)entries * 4));
-    UZK_TRY(m.bucket_count.reserve((size_t)TBK * 4));
-    UZK_TRY(m.bucket_start.reserve((size_t)TBK * 4));
-    UZK_TRY(m.buckets.reserve((size_t)TBK * sizeof(XYZZ)));
-    UZK_TRY(m.partials.reserve((size_t)RW * groups * sizeof(XYZZ)));
-    UZK_TRY(m.win_sums.reserve((size_t)RW * sizeof(XYZZ)));
-    for (int p = 0; p < P; ++p) {
-        UZK_TRY(m.counts[p].reserve((size_t)(p == 0 ? sp[p].nseg * sp[p].nch : sp[p].items_bound) * sp[p].bins * 4));
-        if (p > 0) UZK_TRY(m.items[p].reserve(((size_t)sp[p].nseg + 1) * 4));
-        if (p + 1 < P) {
-            UZK_TRY(m.segs_start[p].reserve((size_t)sp[p].nseg * sp[p].bins * 4));
-            UZK_TRY(m.segs_len[p].reserve((size_t)sp[p].nseg * sp[p].bins * 4));
-            UZK_TRY(m.ent[p & 1].reserve((size_t)entries * sizeof(uint2)));
+static int msm_group_plan(Ctx& c, MsmGroup& g, size_t n, uint32_t batch, int cb, bool pre, uint32_t W_total, uint32_t w0,
+                          uint32_t W) {
+    g.pre = pre; g.cb = cb; g.W_total = W_total; g.w0 = w0; g.W = W; g.n32 = (uint32_t)n; g.batch = batch;
+    g.per_poly = (uint64_t)W * n;
+    g.entries = g.per_poly * batch;
+    if (g.entries >= (1ull << 31)) { set_error("msm: batch*W*n overflows the 31-bit index space"); return UZK_ERR_PARAMETER; }
+    g.kb = (uint32_t)cb - 1;
+    g.NBL = 1u << g.kb;
+    g.S0 = pre ? batch : batch * W;                         // sort segments
+    g.seg_n = pre ? (uint32_t)g.per_poly : g.n32;
+    g.NB = std::min<uint32_t>(g.NBL, 1u << 15);             // bucket windows of <= 2^15 buckets for the scans
+    g.Wd = (uint32_t)(((uint64_t)g.S0 * g.NBL) / g.NB);
+    g.TBK = (uint64_t)g.Wd * g.NB;
+    if (g.Wd > 1024) { set_error("msm: too many bucket windows (%u): lower the batch", g.Wd); return UZK_ERR_PARAMETER; }
+    g.RW = pre ? batch : batch * W;                         // logical windows in the reduction
+    g.seg = std::max<uint32_t>(1, std::min<uint32_t>(kSeg, g.NBL / 256));
+    g.groups = (g.NBL + g.seg * 256 - 1) / (g.seg * 256);
+    const uint64_t all_entries = (uint64_t)W_total * n * batch;
+    g.L = c.tune_task_len > 0 ? (uint32_t)c.tune_task_len
+                              : (uint32_t)std::max<uint64_t>(16, std::min<uint64_t>(96, all_entries >> 21));
+    g.bound0 = g.entries / g.L + g.TBK;                     // upper bound on level-0 tasks
+    g.part_cap = g.bound0 + 2 * g.TBK;                      // every later level fits too
+    g.P = g.kb <= 9 ? 1 : (g.kb <= 18 ? 2 : 3);             // radix passes of <= 9 bits, high bits first
+    uint32_t rem = g.kb, nseg = g.S0;
+    for (int p = 0; p < g.P; ++p) {
+        const uint32_t bits = (rem + (uint32_t)(g.P - p) - 1) / (uint32_t)(g.P - p);
+        rem -= bits;
+        g.sp[p].shift = rem;
+        g.sp[p].bins = 1u << bits;
+        g.sp[p].nseg = nseg;
+        const uint64_t avg = std::max<uint64_t>(1, (g.S0 * (uint64_t)g.seg_n) / nseg);
+        g.sp[p].nch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(1024, avg / 32768));
+        g.sp[p].chunk = (p == g.P - 1) ? 16384u : 32768u;   // later passes: fixed-size work items
+        g.sp[p].items_bound = (uint32_t)(g.entries / g.sp[p].chunk) + nseg;
+        nseg *= g.sp[p].bins;
+    }
+    MsmWork& m = *g.m;
+    UZK_TRY(m.digits.reserve((size_t)g.entries * 4));
+    UZK_TRY(m.sorted.reserve((size_t)g.entries * 4));
+    UZK_TRY(m.bucket_count.reserve((size_t)g.TBK * 4));
+    UZK_TRY(m.bucket_start.reserve((size_t)g.TBK * 4));
+    UZK_TRY(m.buckets.reserve((size_t)g.TBK * sizeof(XYZZ)));
+    UZK_TRY(m.partials.reserve((size_t)g.RW * g.groups * sizeof(XYZZ)));
+    UZK_TRY(m.win_sums.reserve((size_t)g.RW * sizeof(XYZZ)));
+    for (int p = 0; p < g.P; ++p) {
+        UZK_TRY(m.counts[p].reserve((size_t)(p == 0 ? g.sp[p].nseg * g.sp[p].nch : g.sp[p].items_bound) * g.sp[p].bins * 4));
+        if (p > 0) UZK_TRY(m.items[p].reserve(((size_t)g.sp[p].nseg + 1) * 4));
+        if (p + 1 < g.P) {
+            UZK_TRY(m.segs_start[p].reserve((size_t)g.sp[p].nseg * g.sp[p].bins * 4));
+            UZK_TRY(m.segs_len[p].reserve((size_t)g.sp[p].nseg * g.sp[p].bins * 4));
+            UZK_TRY(m.ent[p & 1].reserve((size_t)g.entries * sizeof(uint2)));
         }
     }
     for (int k = 0; k < 2; ++k) {
-        UZK_TRY(m.lvl_cnt[k].reserve((size_t)TBK * 4));
-        UZK_TRY(m.lvl_off[k].reserve((size_t)TBK * 4));
+        UZK_TRY(m.lvl_cnt[k].reserve((size_t)g.TBK * 4));
+        UZK_TRY(m.lvl_off[k].reserve((size_t)g.TBK * 4));
     }
-    UZK_TRY(m.lvl_part[0].reserve((size_t)part_cap * sizeof(XYZZ)));
+    UZK_TRY(m.lvl_part[0].reserve((size_t)g.part_cap * sizeof(XYZZ)));
     UZK_TRY(m.small.reserve(16384));
-    UZK_TRY(m.task_desc.reserve((size_t)bound0 * sizeof(TaskDesc)));
-    if (m.h_sums_cap < RW) {
+    UZK_TRY(m.task_desc.reserve((size_t)g.bound0 * sizeof(TaskDesc)));
+    if (m.h_sums_cap < g.RW) {
         if (m.h_sums) (void)hipHostFree(m.h_sums);
-        UZK_HIP(hipHostMalloc(reinterpret_cast<void**>(&m.h_sums), (size_t)RW * sizeof(XYZZ), hipHostMallocDefault));
-        m.h_sums_cap = RW;
+        UZK_HIP(hipHostMalloc(reinterpret_cast<void**>(&m.h_sums), (size_t)g.RW * sizeof(XYZZ), hipHostMallocDefault));
+        m.h_sums_cap = g.RW;
     }
     if (!m.h_max) UZK_HIP(hipHostMalloc(reinterpret_cast<void**>(&m.h_max), 64, hipHostMallocDefault));
+    return UZK_OK;
+}
 
+// Phase 1 (asynchronous on g.st): digits, sort, task schedule, bucket accumulation, copy of the
+// largest bucket population to the host.
+static int msm_group_phase1(Ctx& c, MsmGroup& g, const Affine* points, const Fp* d_scalars, uint32_t pre_stride,
+                            uint32_t pre_off) {
+    MsmWork& m = *g.m;
+    hipStream_t st = g.st;
+    c.cur_stream = st;
     uint32_t* digits = m.digits.as<uint32_t>();
     uint32_t* sorted = m.sorted.as<uint32_t>();
     uint32_t* bcount = m.bucket_count.as<uint32_t>();
     uint32_t* bstart = m.bucket_start.as<uint32_t>();
-    XYZZ* buckets = m.buckets.as<XYZZ>();
-    XYZZ* partials = m.partials.as<XYZZ>();
-    XYZZ* win_sums = m.win_sums.as<XYZZ>();
-    // small: [0..1024) window totals, [1024..2049) win_base ping, [2080..3105) win_base pong, [3200] max
+    // small: [0..1024) window totals, [1024..2049) win_base ping, [2080..3105) win_base pong, [3200] max,
+    //        [3328..3584) task-length histogram, [3584..3840) cursors
     uint32_t* sm = m.small.as<uint32_t>();
     uint32_t* win_tot = sm;
-    uint32_t* win_base[2] = {sm + 1024, sm + 2080};
     uint32_t* d_max = sm + 3200;
-    hipStream_t st = c.stream;
-
     UZK_HIP(hipMemsetAsync(d_max, 0, 4, st));
     {
         KernelScope ks(c, "msm_digits");
-        const uint64_t tot = (uint64_t)n32 * batch;
-        hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_scalars, digits, n32,
-                           batch, cb, (int)W);
+        const uint64_t tot = (uint64_t)g.n32 * g.batch;
+        hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_scalars, digits, g.n32,
+                           g.batch, g.cb, (int)g.W_total, (int)g.w0, (int)g.W);
     }
     // ---- counting sort, high bits first
-    for (int p = 0; p < P; ++p) {
-        const bool first = (p == 0), last = (p == P - 1);
+    for (int p = 0; p < g.P; ++p) {
+        const bool first = (p == 0), last = (p == g.P - 1);
+        const SortPass& sp = g.sp[p];
         RadixArgs a{};
-        a.shift = sp[p].shift; a.bins = sp[p].bins; a.mask = sp[p].bins - 1;
+        a.shift = sp.shift; a.bins = sp.bins; a.mask = sp.bins - 1;
         a.counts = m.counts[p].as<uint32_t>();
         if (first) {
             a.digits = digits;
-            a.n = seg_n;
-            if (pre) { a.remap_cnt = n32; a.remap_stride = pre_stride; a.remap_off = pre_off; }
+            a.n = g.seg_n;
+            if (g.pre) { a.remap_cnt = g.n32; a.remap_stride = pre_stride; a.remap_off = pre_off; }
         } else {
             a.in_entries = m.ent[(p - 1) & 1].as<uint2>();
             a.seg_start = m.segs_start[p - 1].as<uint32_t>();
@@ -873,13 +881,13 @@ int msm_run(Ctx& c, const Affine* points, const Fp* d_scalars, size_t n, uint32_
         }
         if (!first) {
             a.item_off = m.items[p].as<uint32_t>();
-            a.nseg = sp[p].nseg;
-            a.chunk = sp[p].chunk;
+            a.nseg = sp.nseg;
+            a.chunk = sp.chunk;
             KernelScope ks(c, "msm_sort_items");
             hipLaunchKernelGGL(msm_radix_items_kernel, dim3(1), dim3(1024), 0, st, a.seg_len, a.nseg, a.chunk,
                                m.items[p].as<uint32_t>());
         }
-        const dim3 grid = first ? dim3(sp[p].nch, sp[p].nseg) : dim3(sp[p].items_bound);
+        const dim3 grid = first ? dim3(sp.nch, sp.nseg) : dim3(sp.items_bound);
         {
             KernelScope ks(c, "msm_sort_hist");
             if (first) hipLaunchKernelGGL(msm_radix_hist_kernel<true>, grid, dim3(1024), 0, st, a);
@@ -887,8 +895,8 @@ int msm_run(Ctx& c, const Affine* points, const Fp* d_scalars, size_t n, uint32_
         }
         {
             KernelScope ks(c, "msm_sort_scan");
-            hipLaunchKernelGGL(msm_radix_scan_kernel, dim3(sp[p].nseg), dim3(512), 0, st, a, sp[p].nch,
-                               first ? (const uint32_t*)nullptr : a.seg_start, first ? seg_n : 0u);
+            hipLaunchKernelGGL(msm_radix_scan_kernel, dim3(sp.nseg), dim3(512), 0, st, a, sp.nch,
+                               first ? (const uint32_t*)nullptr : a.seg_start, first ? g.seg_n : 0u);
         }
         {
             KernelScope ks(c, "msm_sort_scatter");
@@ -898,109 +906,170 @@ int msm_run(Ctx& c, const Affine* points, const Fp* d_scalars, size_t n, uint32_
             else hipLaunchKernelGGL((msm_radix_scatter_kernel<1024, 8, false, false>), grid, dim3(1024), 0, st, a);
         }
     }
-    // ---- level-0 tasks (runs of <= L indices)
-    uint32_t* cnt_cur = m.lvl_cnt[0].as<uint32_t>();
-    uint32_t* off_cur = m.lvl_off[0].as<uint32_t>();
-    uint32_t* base_cur = win_base[0];
-    XYZZ* part_cur = m.lvl_part[0].as<XYZZ>();
+    // ---- level-0 tasks (runs of <= L indices), longest first
+    g.cnt_cur = m.lvl_cnt[0].as<uint32_t>();
+    g.off_cur = m.lvl_off[0].as<uint32_t>();
+    g.base_cur = sm + 1024;
+    g.part_cur = m.lvl_part[0].as<XYZZ>();
     {
         KernelScope ks(c, "msm_scan_win");
-        hipLaunchKernelGGL(msm_scan_win_kernel, dim3(Wd), dim3(1024), 0, st, bcount, L, cnt_cur, off_cur, win_tot,
-                           d_max, NB);
-        hipLaunchKernelGGL(msm_win_base_kernel, dim3(1), dim3(1024), 0, st, win_tot, base_cur, Wd);
+        hipLaunchKernelGGL(msm_scan_win_kernel, dim3(g.Wd), dim3(1024), 0, st, bcount, g.L, g.cnt_cur, g.off_cur, win_tot,
+                           d_max, g.NB);
+        hipLaunchKernelGGL(msm_win_base_kernel, dim3(1), dim3(1024), 0, st, win_tot, g.base_cur, g.Wd);
     }
     TaskDesc* desc = m.task_desc.as<TaskDesc>();
     {
         KernelScope ks(c, "msm_task_order");
-        uint32_t* len_hist = sm + 3328;      // 256 counters, then 256 cursors
+        uint32_t* len_hist = sm + 3328;
         uint32_t* len_cur = sm + 3328 + kLenBins;
         UZK_HIP(hipMemsetAsync(len_hist, 0, kLenBins * 4, st));
-        const dim3 tgrid((unsigned)((bound0 + 255) / 256));
-        hipLaunchKernelGGL(msm_task_hist_kernel, tgrid, dim3(256), 0, st, base_cur, Wd, off_cur, bstart, bcount, NB, L, len_hist);
+        const dim3 tgrid((unsigned)((g.bound0 + 255) / 256));
+        hipLaunchKernelGGL(msm_task_hist_kernel, tgrid, dim3(256), 0, st, g.base_cur, g.Wd, g.off_cur, bstart, bcount, g.NB,
+                           g.L, len_hist);
         hipLaunchKernelGGL(msm_task_scan_kernel, dim3(1), dim3(256), 0, st, len_hist, len_cur);
-        hipLaunchKernelGGL(msm_task_fill_kernel, tgrid, dim3(256), 0, st, base_cur, Wd, off_cur, bstart, bcount, NB, L, len_cur, desc);
+        hipLaunchKernelGGL(msm_task_fill_kernel, tgrid, dim3(256), 0, st, g.base_cur, g.Wd, g.off_cur, bstart, bcount, g.NB,
+                           g.L, len_cur, desc);
     }
     {
         KernelScope ks(c, "msm_accumulate");
-        const dim3 grid((unsigned)((bound0 + 255) / 256));
+        const dim3 grid((unsigned)((g.bound0 + 255) / 256));
         if (c.tune_acc_variant == 1)        // canonical arithmetic throughout (cross-check of the relaxed loop)
-            hipLaunchKernelGGL((msm_accumulate_kernel<1, false>), grid, dim3(256), 0, st, points, sorted, desc, base_cur,
-                               part_cur, Wd);
+            hipLaunchKernelGGL((msm_accumulate_kernel<1, false>), grid, dim3(256), 0, st, points, sorted, desc, g.base_cur,
+                               g.part_cur, g.Wd);
         else
-            hipLaunchKernelGGL((msm_accumulate_kernel<1, true>), grid, dim3(256), 0, st, points, sorted, desc, base_cur,
-                               part_cur, Wd);
+            hipLaunchKernelGGL((msm_accumulate_kernel<1, true>), grid, dim3(256), 0, st, points, sorted, desc, g.base_cur,
+                               g.part_cur, g.Wd);
     }
     UZK_HIP(hipGetLastError());
     // the largest bucket decides how many fold levels are needed (one tiny read-back)
     UZK_HIP(hipMemcpyAsync(m.h_max, d_max, 4, hipMemcpyDeviceToHost, st));
+    return UZK_OK;
+}
+
+// Phase 2: wait for the read-back, fold the partial sums, reduce the buckets, copy the window sums.
+static int msm_group_phase2(Ctx& c, MsmGroup& g) {
+    MsmWork& m = *g.m;
+    hipStream_t st = g.st;
+    c.cur_stream = st;
     UZK_HIP(hipStreamSynchronize(st));
-    uint64_t tmax = ((uint64_t)m.h_max[0] + L - 1) / L;
+    uint32_t* sm = m.small.as<uint32_t>();
+    uint32_t* win_tot = sm;
+    uint32_t* win_base[2] = {sm + 1024, sm + 2080};
+    XYZZ* buckets = m.buckets.as<XYZZ>();
+    XYZZ* partials = m.partials.as<XYZZ>();
+    XYZZ* win_sums = m.win_sums.as<XYZZ>();
+    const uint32_t G = kCombineFan;
+    uint64_t tmax = ((uint64_t)m.h_max[0] + g.L - 1) / g.L;
     // lanes per fold group: latency mode for small problems, one lane per bucket for large ones
-    const uint32_t gs = (TBK >= (1u << 18) || c.tune_fold_group == 1) ? 1u : (tmax > 8 ? 16u : (tmax > 2 ? 4u : 1u));
+    const uint32_t gs = (g.TBK >= (1u << 18) || c.tune_fold_group == 1) ? 1u : (tmax > 8 ? 16u : (tmax > 2 ? 4u : 1u));
     int lvl = 0;
-    uint64_t bound_prev = bound0;
+    uint64_t bound_prev = g.bound0;
     while (tmax > G) {
         const int nx = (lvl + 1) & 1;
-        UZK_TRY(m.lvl_part[nx].reserve((size_t)part_cap * sizeof(XYZZ)));   // no-op for buffer 0
+        UZK_TRY(m.lvl_part[nx].reserve((size_t)g.part_cap * sizeof(XYZZ)));   // no-op for buffer 0
         uint32_t* cnt_nx = m.lvl_cnt[nx].as<uint32_t>();
         uint32_t* off_nx = m.lvl_off[nx].as<uint32_t>();
         uint32_t* base_nx = win_base[nx];
-        const uint64_t bound_nx = bound_prev / G + TBK;
+        const uint64_t bound_nx = bound_prev / G + g.TBK;
         XYZZ* part_nx = m.lvl_part[nx].as<XYZZ>();
         {
             KernelScope ks(c, "msm_scan_win");
-            hipLaunchKernelGGL(msm_scan_win_kernel, dim3(Wd), dim3(1024), 0, st, cnt_cur, G, cnt_nx, off_nx, win_tot,
-                               (uint32_t*)nullptr, NB);
-            hipLaunchKernelGGL(msm_win_base_kernel, dim3(1), dim3(1024), 0, st, win_tot, base_nx, Wd);
+            hipLaunchKernelGGL(msm_scan_win_kernel, dim3(g.Wd), dim3(1024), 0, st, g.cnt_cur, G, cnt_nx, off_nx, win_tot,
+                               (uint32_t*)nullptr, g.NB);
+            hipLaunchKernelGGL(msm_win_base_kernel, dim3(1), dim3(1024), 0, st, win_tot, base_nx, g.Wd);
         }
         {
             KernelScope ks(c, "msm_combine");
             const dim3 grid((unsigned)((bound_nx * gs + 255) / 256));
             if (gs == 16)
-                hipLaunchKernelGGL(msm_combine_kernel<16>, grid, dim3(256), 0, st, part_cur, cnt_cur, off_cur, base_cur,
-                                   off_nx, base_nx, part_nx, NB, Wd, G);
+                hipLaunchKernelGGL(msm_combine_kernel<16>, grid, dim3(256), 0, st, g.part_cur, g.cnt_cur, g.off_cur, g.base_cur,
+                                   off_nx, base_nx, part_nx, g.NB, g.Wd, G);
             else if (gs == 4)
-                hipLaunchKernelGGL(msm_combine_kernel<4>, grid, dim3(256), 0, st, part_cur, cnt_cur, off_cur, base_cur,
-                                   off_nx, base_nx, part_nx, NB, Wd, G);
+                hipLaunchKernelGGL(msm_combine_kernel<4>, grid, dim3(256), 0, st, g.part_cur, g.cnt_cur, g.off_cur, g.base_cur,
+                                   off_nx, base_nx, part_nx, g.NB, g.Wd, G);
             else
-                hipLaunchKernelGGL(msm_combine_kernel<1>, grid, dim3(256), 0, st, part_cur, cnt_cur, off_cur, base_cur,
-                                   off_nx, base_nx, part_nx, NB, Wd, G);
+                hipLaunchKernelGGL(msm_combine_kernel<1>, grid, dim3(256), 0, st, g.part_cur, g.cnt_cur, g.off_cur, g.base_cur,
+                                   off_nx, base_nx, part_nx, g.NB, g.Wd, G);
         }
-        cnt_cur = cnt_nx; off_cur = off_nx; base_cur = base_nx; part_cur = part_nx;
+        g.cnt_cur = cnt_nx; g.off_cur = off_nx; g.base_cur = base_nx; g.part_cur = part_nx;
         bound_prev = bound_nx;
         tmax = (tmax + G - 1) / G;
         lvl = nx;
     }
     {
         KernelScope ks(c, "msm_finalize");
-        const dim3 grid((unsigned)((TBK * gs + 255) / 256));
+        const dim3 grid((unsigned)((g.TBK * gs + 255) / 256));
         if (gs == 16)
-            hipLaunchKernelGGL(msm_finalize_kernel<16>, grid, dim3(256), 0, st, part_cur, cnt_cur, off_cur, base_cur,
-                               buckets, NB, Wd);
+            hipLaunchKernelGGL(msm_finalize_kernel<16>, grid, dim3(256), 0, st, g.part_cur, g.cnt_cur, g.off_cur, g.base_cur,
+                               buckets, g.NB, g.Wd);
         else if (gs == 4)
-            hipLaunchKernelGGL(msm_finalize_kernel<4>, grid, dim3(256), 0, st, part_cur, cnt_cur, off_cur, base_cur,
-                               buckets, NB, Wd);
+            hipLaunchKernelGGL(msm_finalize_kernel<4>, grid, dim3(256), 0, st, g.part_cur, g.cnt_cur, g.off_cur, g.base_cur,
+                               buckets, g.NB, g.Wd);
         else
-            hipLaunchKernelGGL(msm_finalize_kernel<1>, grid, dim3(256), 0, st, part_cur, cnt_cur, off_cur, base_cur,
-                               buckets, NB, Wd);
+            hipLaunchKernelGGL(msm_finalize_kernel<1>, grid, dim3(256), 0, st, g.part_cur, g.cnt_cur, g.off_cur, g.base_cur,
+                               buckets, g.NB, g.Wd);
     }
     {
         KernelScope ks(c, "msm_reduce");
-        hipLaunchKernelGGL(msm_reduce_kernel, dim3(groups, RW), dim3(256), 0, st, buckets, partials, NBL, groups, seg);
-        hipLaunchKernelGGL(msm_fold_partials_kernel, dim3(RW), dim3(256), 0, st, partials, win_sums, groups);
+        hipLaunchKernelGGL(msm_reduce_kernel, dim3(g.groups, g.RW), dim3(256), 0, st, buckets, partials, g.NBL, g.groups, g.seg);
+        hipLaunchKernelGGL(msm_fold_partials_kernel, dim3(g.RW), dim3(256), 0, st, partials, win_sums, g.groups);
     }
     UZK_HIP(hipGetLastError());
-    UZK_HIP(hipMemcpyAsync(m.h_sums, win_sums, (size_t)RW * sizeof(XYZZ), hipMemcpyDeviceToHost, st));
-    UZK_HIP(hipStreamSynchronize(st));
+    UZK_HIP(hipMemcpyAsync(m.h_sums, win_sums, (size_t)g.RW * sizeof(XYZZ), hipMemcpyDeviceToHost, st));
+    return UZK_OK;
+}
+
+// `points`: base array the sorted indices refer to (the SRS slice, or the window table).
+// Precomputed mode (pre_c > 0): `points` = table, entries of window j index pre_stride * j + pre_off + i.
+// `batch` scalar vectors of n elements each share the same bases; out_host[batch].
+int msm_run(Ctx& c, const Affine* points, const Fp* d_scalars, size_t n, uint32_t batch, Jac* out_host, int pre_c,
+            uint32_t pre_stride, uint32_t pre_off) {
+    if (batch == 0) return UZK_OK;
+    if (n == 0) { for (uint32_t b = 0; b < batch; ++b) out_host[b] = jac_inf(); return UZK_OK; }
+    if (n >= (1ull << 31)) { set_error("msm: n = %zu exceeds 2^31 - 1 points per call", n); return UZK_ERR_PARAMETER; }
+    if (!c.msm) c.msm = new MsmWork[2];
+    const bool pre = pre_c > 0;
+    const int cb = pre ? pre_c : choose_window_bits(n, c.msm_window_bits);
+    const uint32_t W = (uint32_t)msm_num_windows(cb);
+    // Optional: two overlapping groups (a quarter of the windows first).  Measured on MI355X it buys
+    // 0.2 ms of 26 at 2^24 and loses at 2^22 and below -- the sort's workgroups and the accumulation
+    // compete for the same CUs -- so it is off unless asked for (uzk_tune("msm_overlap", 1)).
+    const bool split = c.tune_overlap && !pre && batch == 1 && n >= (1u << 20) && W >= 4;
+    const int ngroups = split ? 2 : 1;
+    MsmGroup g[2];
+    const uint32_t wa = split ? std::max<uint32_t>(1, W / 4) : W;
+    if (split && !c.stream2) UZK_HIP(hipStreamCreateWithFlags(&c.stream2, hipStreamNonBlocking));
+    g[0].m = &c.msm[0]; g[0].st = c.stream;
+    UZK_TRY(msm_group_plan(c, g[0], n, batch, cb, pre, W, 0, wa));
+    if (split) {
+        g[1].m = &c.msm[1]; g[1].st = c.stream2;
+        UZK_TRY(msm_group_plan(c, g[1], n, batch, cb, pre, W, wa, W - wa));
+        // the second stream starts after whatever the caller queued on the library stream (scalar upload)
+        hipEvent_t ev = c.get_event();
+        UZK_HIP(hipEventRecord(ev, c.stream));
+        UZK_HIP(hipStreamWaitEvent(c.stream2, ev, 0));
+        c.event_pool.push_back(ev);
+    }
+    int rc = UZK_OK;
+    for (int k = 0; k < ngroups && rc == UZK_OK; ++k) rc = msm_group_phase1(c, g[k], points, d_scalars, pre_stride, pre_off);
+    for (int k = 0; k < ngroups && rc == UZK_OK; ++k) rc = msm_group_phase2(c, g[k]);
+    for (int k = 0; k < ngroups; ++k) (void)hipStreamSynchronize(g[k].st);
+    c.cur_stream = c.stream;
+    UZK_TRY(rc);
 
     // 7. host: per scalar vector, Horner over its logical windows (c doublings per step); one window
-    //    each when precomputed
+    //    each when precomputed.  Window w of vector b lives in the group that owns w.
     const uint32_t wpp = pre ? 1u : W;
+    auto window_sum = [&](uint32_t b, uint32_t w) -> const XYZZ& {
+        if (pre) return g[0].m->h_sums[b];
+        const int k = (split && w >= wa) ? 1 : 0;
+        return g[k].m->h_sums[(size_t)b * g[k].W + (w - g[k].w0)];
+    };
     auto horner = [&](uint32_t b) {
         XYZZ total = xyzz_inf();
         for (int w = (int)wpp - 1; w >= 0; --w) {
             if (w != (int)wpp - 1) for (int d = 0; d < cb; ++d) total = xyzz_dbl(total);
-            xyzz_add(total, m.h_sums[(size_t)b * wpp + w]);
+            xyzz_add(total, window_sum(b, (uint32_t)w));
         }
         out_host[b] = xyzz_to_jac(total);
     };
