@@ -4,6 +4,7 @@ normalisation (the Jacobian representative is not unique).  Mirrors the referenc
 coef_i * SRS_i) and `test_homomorphic_poly_com_elem` (:483-514)."""
 import numpy as np
 import pytest
+import torch
 
 import bn254_py as opy
 import oracle_c as oc
@@ -208,7 +209,6 @@ def test_precomputed_mode_matches_oracle(gpu, c):
 def test_experiment_switches_do_not_change_the_result(gpu):
     """uzk_tune knobs (canonical-arithmetic accumulate loop, two overlapping pipeline groups, forced
     one-lane folds) are speed experiments: the commitment must be identical with each of them."""
-    import torch
     n = 1 << 20
     pts = torch.empty((n, 8), dtype=torch.int64, device="cuda")
     sc = torch.empty((n, 4), dtype=torch.int64, device="cuda")

@@ -62,7 +62,28 @@ PROTOTYPES = {
 }
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """PyTorch-ROCm wheels bundle their own libamdhip64.  Two HIP runtimes in one process do not share
+    devices ("No HIP GPUs are available" in whichever initialises second), so when torch is installed
+    but not yet imported, load ITS runtime first: libuzkge_gpu.so then binds to the same copy torch
+    will use, whatever the import order.  Opt out with UZK_USE_SYSTEM_HIP=1."""
+    import sys
+    if os.environ.get("UZK_USE_SYSTEM_HIP") == "1" or "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+    except Exception:   # plumbing only: fall back to the system runtime
+        pass
+
+
 def load() -> ctypes.CDLL:
+    _share_hip_runtime_with_torch()
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
