@@ -93,3 +93,33 @@ def test_group_ops_match_oracle(gpu):
         assert aff(dbl[i]) == opy.g1_add(pa[i], pa[i]), i
         assert aff(msub[i]) == opy.g1_add(pa[i], opy.g1_neg(pb[i])), i
         assert aff(twice[i]) == opy.g1_add(s, s), i
+
+
+# ---- the 9 x 29-bit-limb representation used inside the hot loops (fp29.hpp) ---------------------
+@pytest.mark.parametrize("field,mod", [("fq", opy.P), ("fr", opy.R)])
+def test_l29_representation_matches_canonical_arithmetic(gpu, field, mod):
+    """Products, lazy additions/subtractions, carry normalisation, canonicalisation and the
+    2^256 <-> 2^261 Montgomery-form maps of the 29-bit-limb code agree word for word with the
+    canonical 32-bit-limb arithmetic (itself checked against the oracle above) -- on edge values
+    (0, 1, M-1, all-ones limbs, ...) in every combination and on 2^16 random pairs."""
+    n = 1 << 16
+    a = rand_fr_wire(n, 31)
+    b = rand_fr_wire(n, 32)
+    e = _edge_values(mod)
+    a = np.concatenate([np.repeat(e, len(e), axis=0), a])
+    b = np.concatenate([np.tile(e, (len(e), 1)), b])
+    assert np.array_equal(gpu.field_op(field, 10, a, b), gpu.field_op(field, 3, a, b))     # mul
+    assert np.array_equal(gpu.field_op(field, 11, a, b), gpu.field_op(field, 8, a, b))     # add
+    assert np.array_equal(gpu.field_op(field, 12, a, b), gpu.field_op(field, 9, a, b))     # sub, 4M offset
+    assert np.array_equal(gpu.field_op(field, 13, a, b), gpu.field_op(field, 9, a, b))     # sub, 12M offset
+    assert np.array_equal(gpu.field_op(field, 15, a, b), a if False else gpu.field_op(field, 1, a, np.zeros_like(a)))   # form round trip == a mod M
+    # lazy chain (op 14): t = 2*mul261(x - y, x + y) - mul261(x - y, y * 2^5), result t * 2^-5, where
+    # mul261(u, v) = u*v*2^-261 -- un-normalised operands at the documented limb bounds
+    got = gpu.field_op(field, 14, a, b)
+    to_int = lambda row: opy.limbs_to_int(row)
+    i261, i5 = pow(1 << 261, -1, mod), pow(32, -1, mod)
+    for i in list(range(len(e) * len(e))) + list(range(len(e) * len(e), len(a), 499)):
+        x, y = to_int(a[i]) % mod, to_int(b[i]) % mod
+        d = (x - y) % mod
+        want = (2 * d * (x + y) * i261 - d * (y * 32) * i261) * i5 % mod
+        assert to_int(got[i]) == want, (field, i)

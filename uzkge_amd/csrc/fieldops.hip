@@ -2,10 +2,11 @@
 // tests can compare them word-for-word with the oracle (Fq/Fr mont-mul/add/sub KATs, G1
 // add / double / mixed-add including P+P, P+(-P) and infinity; SURVEY.md 8c "golden vectors").
 #include "ctx.hpp"
+#include "fp29.hpp"
 
 namespace uzk {
 
-template <class F>
+template <class F, class F29>
 __global__ __launch_bounds__(256) void field_op_kernel(int op, const Fp* __restrict__ a, const Fp* __restrict__ b,
                                                        Fp* __restrict__ out, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -21,6 +22,21 @@ __global__ __launch_bounds__(256) void field_op_kernel(int op, const Fp* __restr
         case 6: r = F::from_mont(x); break;
         case 8: r = F::add_portable(x, y); break;
         case 9: r = F::sub_portable(x, y); break;
+        // ---- the 9 x 29-bit-limb representation (fp29.hpp), results mapped back to canonical words ----
+        case 10: r = F29::to_fp(F29::canon(F29::mul(F29::from_fp(x), F29::to_261(F29::from_fp(y))))); break;   // x*y (2^256-form)
+        case 11: r = F29::to_fp(F29::canon(F29::add(F29::from_fp(x), F29::from_fp(y)))); break;
+        case 12: r = F29::to_fp(F29::canon(F29::template sub<4>(F29::from_fp(x), F29::from_fp(y)))); break;
+        case 13: r = F29::to_fp(F29::canon(F29::template sub<12>(F29::from_fp(x), F29::from_fp(y)))); break;
+        case 14: {   // lazy chain at the documented limb bounds: ((x - y + 12M) * (x + y)) with un-normalized operands
+            L29 a = F29::from_fp(x), b = F29::from_fp(y);
+            L29 d = F29::template sub<12>(a, b);                 // limbs < 2^31
+            L29 sum = F29::add(a, b);                            // limbs < 2^30
+            L29 p = F29::mul(F29::norm(d), sum);                 // normalized x lazy sum
+            L29 q = F29::mul(d, F29::to_261(F29::from_fp(y)));   // lazy difference x normalized
+            L29 t = F29::template sub<4>(F29::add(p, p), q);     // 2p - q, lazy
+            r = F29::to_fp(F29::canon(F29::to_256(t)));
+        } break;
+        case 15: r = F29::to_fp(F29::canon(F29::to_256(F29::to_261(F29::from_fp(x))))); break;   // 256 -> 261 -> 256
         default: r = F::to_mont(x); break;
     }
     out[i] = r;
@@ -56,8 +72,8 @@ int field_op_device(Ctx& c, int field, int op, const Fp* a, const Fp* b, Fp* out
     UZK_HIP(hipMemcpyAsync(da, a, bytes, hipMemcpyHostToDevice, c.stream));
     UZK_HIP(hipMemcpyAsync(db, b, bytes, hipMemcpyHostToDevice, c.stream));
     const unsigned grid = (unsigned)((n + 255) / 256);
-    if (field == 0) hipLaunchKernelGGL(field_op_kernel<Fq>, dim3(grid), dim3(256), 0, c.stream, op, da, db, dout, n);
-    else hipLaunchKernelGGL(field_op_kernel<Fr>, dim3(grid), dim3(256), 0, c.stream, op, da, db, dout, n);
+    if (field == 0) hipLaunchKernelGGL((field_op_kernel<Fq, Fq29>), dim3(grid), dim3(256), 0, c.stream, op, da, db, dout, n);
+    else hipLaunchKernelGGL((field_op_kernel<Fr, Fr29>), dim3(grid), dim3(256), 0, c.stream, op, da, db, dout, n);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, c.stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c.stream);

@@ -1,0 +1,178 @@
+// "L29": the device-only representation used inside the two hot loops (bucket accumulation, NTT
+// passes).  A field element is 9 limbs of 29 bits, value = sum l_i 2^(29 i); limbs may temporarily
+// hold more than 29 bits (lazy carries) and values more than M (lazy reduction).
+//
+// Why (measured, tools/microbench/l29_rate.hip): with 29-bit limbs a column of the product scanning
+// Montgomery product -- up to 9 a_i*b_j plus 9 m_i*M_j partial products -- fits a 64-bit accumulator,
+// so every partial product is ONE v_mad_u64_u32 with no carry bookkeeping: 162 MADs instead of
+// 128 MADs + 128 v_addc through VCC.  981 vs 1173 cycles per wave-product at 4 waves/SIMD (-16 %),
+// and additions/subtractions become 9 independent 32-bit adds with no reduction at all.
+//
+// Contract of the operations (B = 2^29):
+//   mul(a, b)   limbs: max(a_i) * max(b_j) < 2^60.6 (e.g. both < 2^30.3, or < B and < 2^31.6);
+//               values: a < Va*M, b < Vb*M  ->  result limbs < B (normalized), value < M*(1 + Va*Vb/169).
+//               Montgomery radix is 2^261: mul(a, b) = a*b*2^-261 mod M (up to the lazy multiple of M).
+//   add(a, b)   limb-wise, no carry, no reduction (caller keeps limbs < 2^32 and values in range).
+//   sub(a, b, OFF)  a - b + OFF limb-wise, OFF = k*M with every low limb >= 2^30 - 2, so it never
+//               underflows when b's limbs are < 2^30 - 1 (a normalized value or a sum of two).
+//   norm(a)     carry propagation: limbs < B again, value unchanged.
+//   canon(a)    value < 16 M  ->  the unique representative in [0, M), normalized.
+// The external 4 x u64 Montgomery form has radix 2^256.  NTT data stays in 2^256-form (it is only ever
+// multiplied by twiddles, which the plan stores in 2^261-form); MSM bases are stored in 2^261-form
+// at registration and the bucket sums are mapped back with one product by 2^256.
+#pragma once
+#include "fp256.hpp"
+
+namespace uzk {
+
+#include "fp29_consts.inc"
+
+struct L29 {
+    uint32_t l[9];
+};
+
+#if defined(__HIPCC__)
+
+template <class C>
+struct Field29 {
+    static constexpr uint32_t MASK = (1u << 29) - 1;
+
+    __device__ __forceinline__ static L29 zero() { L29 r; for (int i = 0; i < 9; ++i) r.l[i] = 0; return r; }
+    __device__ __forceinline__ static L29 constant(const uint32_t (&c)[9]) { L29 r; for (int i = 0; i < 9; ++i) r.l[i] = c[i]; return r; }
+
+    // 8 x 32-bit words -> 9 x 29-bit limbs (pure repacking, value unchanged)
+    __device__ __forceinline__ static L29 from_fp(const Fp& a) {
+        L29 r;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int bit = 29 * k, w = bit >> 5, s = bit & 31;
+            uint32_t v = a.v[w] >> s;
+            if (s > 3) v |= a.v[w + 1] << (32 - s);     // the limb straddles two words
+            r.l[k] = v & MASK;
+        }
+        r.l[8] = a.v[7] >> 8;
+        return r;
+    }
+    // normalized limbs, value < 2^256 -> 8 x 32-bit words
+    __device__ __forceinline__ static Fp to_fp(const L29& a) {
+        Fp r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int bit = 32 * j, k = bit / 29, o = bit - 29 * k;
+            uint64_t t = (uint64_t)a.l[k] >> o;
+            t |= (uint64_t)a.l[k + 1] << (29 - o);
+            if (58 - o < 32 && k + 2 < 9) t |= (uint64_t)a.l[k + 2] << (58 - o);
+            r.v[j] = (uint32_t)t;
+        }
+        return r;
+    }
+
+    __device__ __forceinline__ static L29 add(const L29& a, const L29& b) {
+        L29 r;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] + b.l[i];
+        return r;
+    }
+    // a - b + OFF (OFF = 4M or 12M with borrowed limbs)
+    template <int K>
+    __device__ __forceinline__ static L29 sub(const L29& a, const L29& b) {
+        static_assert(K == 4 || K == 12, "offsets 4M and 12M are provided");
+        L29 r;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] - b.l[i] + (K == 4 ? C::OFF4[i] : C::OFF12[i]);
+        return r;
+    }
+    __device__ __forceinline__ static L29 norm(const L29& a) {
+        L29 r;
+        uint32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t t = a.l[i] + c;
+            r.l[i] = t & MASK;
+            c = t >> 29;
+        }
+        r.l[8] = a.l[8] + c;
+        return r;
+    }
+    // Montgomery product, radix 2^261 (contract in the header comment)
+    __device__ __forceinline__ static L29 mul(const L29& a, const L29& b) {
+        uint64_t acc = 0;
+        uint32_t m[9];
+        L29 r;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+#pragma unroll
+            for (int i = 0; i <= k; ++i) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+            for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * C::M[k - i];
+            m[k] = ((uint32_t)acc * C::INV) & MASK;
+            acc += (uint64_t)m[k] * C::M[0];
+            acc >>= 29;
+        }
+#pragma unroll
+        for (int k = 9; k < 17; ++k) {
+#pragma unroll
+            for (int i = k - 8; i < 9; ++i) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+            for (int i = k - 8; i < 9; ++i) acc += (uint64_t)m[i] * C::M[k - i];
+            r.l[k - 9] = (uint32_t)acc & MASK;
+            acc >>= 29;
+        }
+        r.l[8] = (uint32_t)acc;
+        return r;
+    }
+    __device__ __forceinline__ static L29 sqr(const L29& a) { return mul(a, a); }
+
+    // normalized a, value < 3M: is it 0 mod M?
+    __device__ __forceinline__ static bool is_zero_mod_small(const L29& a) {
+        uint32_t z = 0, m1 = 0, m2 = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { z |= a.l[i]; m1 |= a.l[i] ^ C::M[i]; m2 |= a.l[i] ^ C::M2[i]; }
+        return z == 0 || m1 == 0 || m2 == 0;
+    }
+    // r = a - k*M for the estimate k = floor(value / M) or one less; then one conditional subtraction.
+    // a: limbs < 2^32 - 2^3, value < 16 M.
+    __device__ __forceinline__ static L29 canon(const L29& a_in) {
+        const L29 a = norm(a_in);
+        // top 24+ bits: value >> 232 = l[8] (normalized low limbs contribute < 1)
+        const uint32_t q = (uint32_t)(((uint64_t)a.l[8] * C::MU) >> 32);
+        // d = a - q*M, limb-wise with signed carries
+        L29 r;
+        int64_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int64_t t = (int64_t)a.l[i] - (int64_t)((uint64_t)q * C::M[i]) + c;
+            r.l[i] = (uint32_t)t & MASK;
+            c = t >> 29;                       // arithmetic shift: floor division
+        }
+        r.l[8] = (uint32_t)((int64_t)a.l[8] - (int64_t)((uint64_t)q * C::M[8]) + c);
+        // now 0 <= r < 2M (q is the true quotient or one below it); subtract M once or twice if needed
+#pragma unroll
+        for (int round = 0; round < 2; ++round) {
+            L29 d;
+            int32_t br = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int32_t t = (int32_t)r.l[i] - (int32_t)C::M[i] + br;
+                d.l[i] = (uint32_t)t & MASK;
+                br = t >> 29;
+            }
+            const int32_t top = (int32_t)r.l[8] - (int32_t)C::M[8] + br;
+            d.l[8] = (uint32_t)top;
+            const bool ge = top >= 0;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) r.l[i] = ge ? d.l[i] : r.l[i];
+        }
+        return r;
+    }
+    // map between the external 2^256-form and the internal 2^261-form (one product each)
+    __device__ __forceinline__ static L29 to_261(const L29& a256) { return mul(a256, constant(C::R266)); }
+    __device__ __forceinline__ static L29 to_256(const L29& a261) { return mul(a261, constant(C::R256)); }
+};
+
+using Fq29 = Field29<Fq29Cfg>;
+using Fr29 = Field29<Fr29Cfg>;
+
+#endif   // __HIPCC__
+
+}  // namespace uzk
