@@ -113,6 +113,10 @@ def test_l29_representation_matches_canonical_arithmetic(gpu, field, mod):
     assert np.array_equal(gpu.field_op(field, 12, a, b), gpu.field_op(field, 9, a, b))     # sub, 4M offset
     assert np.array_equal(gpu.field_op(field, 13, a, b), gpu.field_op(field, 9, a, b))     # sub, 12M offset
     assert np.array_equal(gpu.field_op(field, 15, a, b), a if False else gpu.field_op(field, 1, a, np.zeros_like(a)))   # form round trip == a mod M
+    assert np.array_equal(gpu.field_op(field, 16, a, b), gpu.field_op(field, 17, a, b))    # sqr == mul(t, t), lazy t
+    three_b = gpu.field_op(field, 8, b, gpu.field_op(field, 8, b, b))
+    assert np.array_equal(gpu.field_op(field, 18, a, b), gpu.field_op(field, 9, a, three_b))   # x - 3y, offset 4M/T3
+    assert np.array_equal(gpu.field_op(field, 19, a, b), gpu.field_op(field, 9, a, b))     # x - y, offset 2M/T1
     # lazy chain (op 14): t = 2*mul261(x - y, x + y) - mul261(x - y, y * 2^5), result t * 2^-5, where
     # mul261(u, v) = u*v*2^-261 -- un-normalised operands at the documented limb bounds
     got = gpu.field_op(field, 14, a, b)

@@ -37,6 +37,14 @@ __global__ __launch_bounds__(256) void field_op_kernel(int op, const Fp* __restr
             r = F29::to_fp(F29::canon(F29::to_256(t)));
         } break;
         case 15: r = F29::to_fp(F29::canon(F29::to_256(F29::to_261(F29::from_fp(x))))); break;   // 256 -> 261 -> 256
+        case 16: { L29 t = F29::add(F29::from_fp(x), F29::from_fp(y)); r = F29::to_fp(F29::canon(F29::sqr(t))); } break;      // dedicated squaring, lazy operand
+        case 17: { L29 t = F29::add(F29::from_fp(x), F29::from_fp(y)); r = F29::to_fp(F29::canon(F29::mul(t, t))); } break;   // ... against the general product
+        case 18: {   // x - 3y through the three-subtrahend offset (the -X3 step of ec29.hpp)
+            L29 a = F29::from_fp(x), b = F29::from_fp(y), t;
+            for (int k = 0; k < 9; ++k) t.l[k] = a.l[k] + F29::Cfg::OFF4T3[k] - 2 * b.l[k] - b.l[k];
+            r = F29::to_fp(F29::canon(t));
+        } break;
+        case 19: r = F29::to_fp(F29::canon(F29::sub_off(F29::from_fp(x), F29::from_fp(y), F29::Cfg::OFF2T1))); break;
         default: r = F::to_mont(x); break;
     }
     out[i] = r;

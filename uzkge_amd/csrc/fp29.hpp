@@ -16,6 +16,7 @@
 //   sub(a, b, OFF)  a - b + OFF limb-wise, OFF = k*M with every low limb >= 2^30 - 2, so it never
 //               underflows when b's limbs are < 2^30 - 1 (a normalized value or a sum of two).
 //   norm(a)     carry propagation: limbs < B again, value unchanged.
+//   reduce(a)   value < 16 M  ->  normalized, value < 2M.
 //   canon(a)    value < 16 M  ->  the unique representative in [0, M), normalized.
 // The external 4 x u64 Montgomery form has radix 2^256.  NTT data stays in 2^256-form (it is only ever
 // multiplied by twiddles, which the plan stores in 2^261-form); MSM bases are stored in 2^261-form
@@ -35,6 +36,7 @@ struct L29 {
 
 template <class C>
 struct Field29 {
+    using Cfg = C;
     static constexpr uint32_t MASK = (1u << 29) - 1;
 
     __device__ __forceinline__ static L29 zero() { L29 r; for (int i = 0; i < 9; ++i) r.l[i] = 0; return r; }
@@ -121,7 +123,52 @@ struct Field29 {
         r.l[8] = (uint32_t)acc;
         return r;
     }
-    __device__ __forceinline__ static L29 sqr(const L29& a) { return mul(a, a); }
+    // a*a*2^-261: the 36 cross products are taken once against the doubled operand (45 + 81 MADs
+    // instead of 162).  Same contract as mul(a, a); limbs of a must also be < 2^31.
+    __device__ __forceinline__ static L29 sqr(const L29& a) {
+        uint32_t d[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) d[i] = a.l[i] << 1;
+        uint64_t acc = 0;
+        uint32_t m[9];
+        L29 r;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+#pragma unroll
+            for (int i = 0; 2 * i < k; ++i) acc += (uint64_t)a.l[i] * d[k - i];
+            if ((k & 1) == 0) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
+#pragma unroll
+            for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * C::M[k - i];
+            m[k] = ((uint32_t)acc * C::INV) & MASK;
+            acc += (uint64_t)m[k] * C::M[0];
+            acc >>= 29;
+        }
+#pragma unroll
+        for (int k = 9; k < 17; ++k) {
+#pragma unroll
+            for (int i = k - 8; 2 * i < k; ++i) acc += (uint64_t)a.l[i] * d[k - i];
+            if ((k & 1) == 0) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
+#pragma unroll
+            for (int i = k - 8; i < 9; ++i) acc += (uint64_t)m[i] * C::M[k - i];
+            r.l[k - 9] = (uint32_t)acc & MASK;
+            acc >>= 29;
+        }
+        r.l[8] = (uint32_t)acc;
+        return r;
+    }
+    // a - b + OFF for any of the offset constants (the caller matches OFF to b's limb / value bounds)
+    __device__ __forceinline__ static L29 sub_off(const L29& a, const L29& b, const uint32_t (&off)[9]) {
+        L29 r;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] - b.l[i] + off[i];
+        return r;
+    }
+    __device__ __forceinline__ static bool all_zero(const L29& a) {
+        uint32_t z = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) z |= a.l[i];
+        return z == 0;
+    }
 
     // normalized a, value < 3M: is it 0 mod M?
     __device__ __forceinline__ static bool is_zero_mod_small(const L29& a) {
@@ -130,13 +177,12 @@ struct Field29 {
         for (int i = 0; i < 9; ++i) { z |= a.l[i]; m1 |= a.l[i] ^ C::M[i]; m2 |= a.l[i] ^ C::M2[i]; }
         return z == 0 || m1 == 0 || m2 == 0;
     }
-    // r = a - k*M for the estimate k = floor(value / M) or one less; then one conditional subtraction.
-    // a: limbs < 2^32 - 2^3, value < 16 M.
-    __device__ __forceinline__ static L29 canon(const L29& a_in) {
+    // a: limbs < 2^32 - 2^3, value < 16 M  ->  normalized, value < 2M, same residue.
+    // r = a - q*M with q = floor(value / M) or one less, estimated from the top limb.
+    __device__ __forceinline__ static L29 reduce(const L29& a_in) {
         const L29 a = norm(a_in);
-        // top 24+ bits: value >> 232 = l[8] (normalized low limbs contribute < 1)
+        // value >> 232 = l[8] (the normalized low limbs contribute < 1)
         const uint32_t q = (uint32_t)(((uint64_t)a.l[8] * C::MU) >> 32);
-        // d = a - q*M, limb-wise with signed carries
         L29 r;
         int64_t c = 0;
 #pragma unroll
@@ -146,23 +192,24 @@ struct Field29 {
             c = t >> 29;                       // arithmetic shift: floor division
         }
         r.l[8] = (uint32_t)((int64_t)a.l[8] - (int64_t)((uint64_t)q * C::M[8]) + c);
-        // now 0 <= r < 2M (q is the true quotient or one below it); subtract M once or twice if needed
+        return r;
+    }
+    // a as for reduce()  ->  the unique representative in [0, M), normalized.
+    __device__ __forceinline__ static L29 canon(const L29& a_in) {
+        L29 r = reduce(a_in);
+        L29 d;
+        int32_t br = 0;
 #pragma unroll
-        for (int round = 0; round < 2; ++round) {
-            L29 d;
-            int32_t br = 0;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int32_t t = (int32_t)r.l[i] - (int32_t)C::M[i] + br;
-                d.l[i] = (uint32_t)t & MASK;
-                br = t >> 29;
-            }
-            const int32_t top = (int32_t)r.l[8] - (int32_t)C::M[8] + br;
-            d.l[8] = (uint32_t)top;
-            const bool ge = top >= 0;
-#pragma unroll
-            for (int i = 0; i < 9; ++i) r.l[i] = ge ? d.l[i] : r.l[i];
+        for (int i = 0; i < 8; ++i) {
+            const int32_t t = (int32_t)r.l[i] - (int32_t)C::M[i] + br;
+            d.l[i] = (uint32_t)t & MASK;
+            br = t >> 29;
         }
+        const int32_t top = (int32_t)r.l[8] - (int32_t)C::M[8] + br;
+        d.l[8] = (uint32_t)top;
+        const bool ge = top >= 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) r.l[i] = ge ? d.l[i] : r.l[i];
         return r;
     }
     // map between the external 2^256-form and the internal 2^261-form (one product each)

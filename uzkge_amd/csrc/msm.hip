@@ -32,6 +32,7 @@
 #include <vector>
 
 #include "ctx.hpp"
+#include "ec29.hpp"
 #include "host_math.hpp"
 
 namespace uzk {
@@ -494,6 +495,35 @@ __global__ __launch_bounds__(256, MINW) void msm_accumulate_kernel(const Affine*
     partials[d.task] = acc;
 }
 
+// The same loop on the 29-bit-limb accumulator (ec29.hpp).
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void msm_accumulate29_kernel(const Affine* __restrict__ points,
+                                                               const uint32_t* __restrict__ sorted,
+                                                               const TaskDesc* __restrict__ desc,
+                                                               const uint32_t* __restrict__ win_base,
+                                                               XYZZ* __restrict__ partials, uint32_t W) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= win_base[W]) return;
+    const TaskDesc d = desc[slot];
+    const uint32_t cnt = d.cnt;
+    const uint32_t* run = sorted + d.start;
+    Acc29 acc = acc29_inf();
+    uint32_t e = run[0];
+    Affine p = load_point(points, e & ~kSignBit);
+    for (uint32_t k = 0; k < cnt; ++k) {
+        const Affine cur = p;
+        const bool neg = (e & kSignBit) != 0;
+        if (k + 1 < cnt) {
+            e = run[k + 1];
+            p = load_point(points, e & ~kSignBit);
+        }
+        acc29_madd(acc, cur, neg);
+    }
+    partials[d.task] = acc29_to_xyzz(acc);
+#endif
+}
+
 // Folding partial sums.  GS lanes of one wave cooperate on one output: lane `sub` adds the partials
 // sub, sub + GS, ... and a shuffle tree adds the GS lane sums, so the dependent chain is
 // ceil(cnt / GS) + log2(GS) additions instead of cnt (GS = 1 for large problems, where throughput
@@ -933,10 +963,16 @@ static int msm_group_phase1(Ctx& c, MsmGroup& g, const Affine* points, const Fp*
     {
         KernelScope ks(c, "msm_accumulate");
         const dim3 grid((unsigned)((g.bound0 + 255) / 256));
-        if (c.tune_acc_variant == 1)        // canonical arithmetic throughout (cross-check of the relaxed loop)
+        if (c.tune_acc_variant == 1)        // canonical arithmetic throughout (cross-check of the other loops)
             hipLaunchKernelGGL((msm_accumulate_kernel<1, false>), grid, dim3(256), 0, st, points, sorted, desc, g.base_cur,
                                g.part_cur, g.Wd);
-        else
+        else if (c.tune_acc_variant == 0)   // default: 29-bit-limb accumulator
+            hipLaunchKernelGGL(msm_accumulate29_kernel<1>, grid, dim3(256), 0, st, points, sorted, desc, g.base_cur,
+                               g.part_cur, g.Wd);
+        else if (c.tune_acc_variant == 3)   // experiment: the same at 4 waves/SIMD (128 VGPRs, spills)
+            hipLaunchKernelGGL(msm_accumulate29_kernel<4>, grid, dim3(256), 0, st, points, sorted, desc, g.base_cur,
+                               g.part_cur, g.Wd);
+        else                                // 2: 8 x 32-bit relaxed Montgomery
             hipLaunchKernelGGL((msm_accumulate_kernel<1, true>), grid, dim3(256), 0, st, points, sorted, desc, g.base_cur,
                                g.part_cur, g.Wd);
     }

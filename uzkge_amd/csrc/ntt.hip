@@ -21,6 +21,7 @@
 #include <cstring>
 
 #include "ctx.hpp"
+#include "fp29.hpp"
 #include "host_math.hpp"
 
 namespace uzk {
@@ -33,6 +34,7 @@ struct NttPlan {
     int log_n = 0;
     bool inverse = false;
     bool scaled = false;     // inverse only: fold 1/n in
+    bool l29 = false;        // twiddle tables in 2^261-form for the 29-bit-limb pass kernels
     int npass = 0;
     int bits[4] = {0, 0, 0, 0};
     Fp* d_tw256 = nullptr;        // omega_256^e (direction-specific), e < 256   (n >= 4096)
@@ -60,7 +62,7 @@ static void host_pow_tables(const Fp& w, std::vector<Fp>& tab) {
 __global__ __launch_bounds__(256) void ntt_gen_pass_tw_kernel(Fp* __restrict__ out, uint64_t count,
                                                               int log_S, int B,
                                                               const Fp* __restrict__ pw, Fp scale,
-                                                              int use_scale) {
+                                                              int use_scale, int dbl_count) {
     uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= count) return;
     uint64_t mp = idx >> B, sg = idx & ((1u << B) - 1);
@@ -68,6 +70,7 @@ __global__ __launch_bounds__(256) void ntt_gen_pass_tw_kernel(Fp* __restrict__ o
     Fp v = Fr::mul(pw[e & 1023], pw[1024 + ((e >> 10) & 1023)]);
     v = Fr::mul(v, pw[2048 + (e >> 20)]);
     if (use_scale) v = Fr::mul(v, scale);
+    for (int d = 0; d < dbl_count; ++d) v = Fr::add(v, v);   // 2^256-form -> 2^261-form
     out[idx] = v;
 }
 
@@ -268,6 +271,144 @@ __global__ __launch_bounds__(512) void ntt_pass_kernel(const Fp* __restrict__ in
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same pass on the 29-bit-limb representation (fp29.hpp): data stays in 2^256-form, every
+// twiddle table is in 2^261-form, so a twiddle product is one carry-free 9x9 product.  Additions and
+// subtractions are 9 independent 32-bit adds; the bounds below (limb size / multiple of M) are what
+// keeps every product inside its contract (limb product < 2^60.6):
+//   loaded / exchanged values        limbs < 2^29     value < 2M
+//   radix-4 outputs                  limbs < 2^31.5   value < 10M   -> twiddle product or reduce()
+//   radix-2 outputs                  limbs < 2^31     value < 6M
+// The sigma = 0 output of a butterfly has no twiddle; it is brought back with reduce() (a 9-MAD
+// quotient-estimate subtraction, about a fifth of a product).
+// ---------------------------------------------------------------------------------------------
+using F9 = Fr29;
+
+__device__ __forceinline__ void bf2_l(L29& a, L29& b) {
+    L29 s = F9::add(a, b);
+    b = F9::sub<4>(a, b);
+    a = s;
+}
+__device__ __forceinline__ void radix4_l(L29& x0, L29& x1, L29& x2, L29& x3, const L29& w4) {
+    bf2_l(x0, x2);
+    bf2_l(x1, x3); x3 = F9::mul(x3, w4);
+    bf2_l(x0, x1);
+    bf2_l(x2, x3);
+    L29 t = x1; x1 = x2; x2 = t;
+}
+
+constexpr int kLds29Words = 9 * kPlane;   // two uint4 planes + one u32 plane per element slot
+
+__device__ __forceinline__ void lds_put29(uint4* lds, int idx, const L29& v) {
+    lds[idx] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    lds[kPlane + idx] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+    reinterpret_cast<uint32_t*>(lds + 2 * kPlane)[idx] = v.l[8];
+}
+__device__ __forceinline__ L29 lds_get29(const uint4* lds, int idx) {
+    const uint4 a = lds[idx], b = lds[kPlane + idx];
+    L29 v;
+    v.l[0] = a.x; v.l[1] = a.y; v.l[2] = a.z; v.l[3] = a.w;
+    v.l[4] = b.x; v.l[5] = b.y; v.l[6] = b.z; v.l[7] = b.w;
+    v.l[8] = reinterpret_cast<const uint32_t*>(lds + 2 * kPlane)[idx];
+    return v;
+}
+
+template <int B, bool FIRST>
+__global__ __launch_bounds__(512, 4) void ntt_pass29_kernel(const Fp* __restrict__ in, Fp* __restrict__ out,
+                                                         PassArgs a) {
+    constexpr int R = 1 << B, T = 2048 / R, Q = R / 4, SH = 8 - B;
+    constexpr int N4 = B / 2;
+    constexpr bool TAIL2 = (B & 1) != 0;
+    __shared__ uint4 lds[(kLds29Words + 3) / 4];
+    const int tid = threadIdx.x;
+    const int col = tid % T, q = tid / T;
+    const uint64_t i0 = (uint64_t)blockIdx.x * T;
+    const uint64_t i = i0 + col;
+    in += (uint64_t)blockIdx.y * a.batch_stride;
+    out += (uint64_t)blockIdx.y * a.batch_stride;
+
+    const L29 w4 = F9::from_fp(a.tw256[64]);
+    L29 x[4];
+    int rows[4];
+
+    // ---- sub-pass 0: radix 4 straight from global memory
+#pragma unroll
+    for (int t = 0; t < 4; ++t) x[t] = F9::from_fp(in[i + (uint64_t)(q + t * Q) * a.stride]);
+    radix4_l(x[0], x[1], x[2], x[3], w4);
+    if constexpr (N4 > 1 || TAIL2) {
+        x[0] = F9::reduce(x[0]);
+#pragma unroll
+        for (int s = 1; s < 4; ++s) x[s] = F9::mul(x[s], F9::from_fp(a.tw256[(q * s) << SH]));
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) rows[s] = q * 4 + s;
+
+    // ---- radix-4 sub-passes 1 .. N4-1
+#pragma unroll
+    for (int k = 1; k < N4; ++k) {
+        const int S = 1 << (2 * k);
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) lds_put29(lds, rows[s] * T + col, x[s]);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) x[t] = lds_get29(lds, (q + t * Q) * T + col);
+        radix4_l(x[0], x[1], x[2], x[3], w4);
+        const int mp = q >> (2 * k), sl = q & (S - 1);
+        const bool more = (R >> (2 * k + 2)) > 1;
+        if (more) {
+            x[0] = F9::reduce(x[0]);
+#pragma unroll
+            for (int s = 1; s < 4; ++s) x[s] = F9::mul(x[s], F9::from_fp(a.tw256[((S * mp * s)) << SH]));
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) rows[s] = (mp << (2 * k + 2)) + s * S + sl;
+    }
+    // ---- final radix-2 sub-pass (B odd)
+    if constexpr (TAIL2) {
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) lds_put29(lds, rows[s] * T + col, x[s]);
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int ib = q + u * Q;
+            x[2 * u] = lds_get29(lds, ib * T + col);
+            x[2 * u + 1] = lds_get29(lds, (ib + R / 2) * T + col);
+            bf2_l(x[2 * u], x[2 * u + 1]);
+            rows[2 * u] = ib;
+            rows[2 * u + 1] = ib + R / 2;
+        }
+    }
+
+    // ---- write back (lazy limbs: < 2^31.5, value < 10M)
+    if constexpr (FIRST) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds_put29(lds, col * (R + 1) + rows[j], x[j]);
+        __syncthreads();
+        const uint64_t base = i0 * R;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = tid + j * 512;
+            const int ce = e / R, re = e % R;
+            L29 v = lds_get29(lds, ce * (R + 1) + re);
+            v = F9::mul(v, F9::from_fp(a.twp[base + e]));      // normalized, < 2M: fits 8 words
+            out[base + e] = F9::to_fp(v);
+        }
+    } else {
+        const uint64_t mp = i >> a.log_S, sp = i & ((1ull << a.log_S) - 1);
+        const uint64_t base = (mp << (a.log_S + B)) + sp;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            L29 v = x[j];
+            if (a.twp != nullptr) v = F9::mul(v, F9::from_fp(a.twp[(mp << B) + rows[j]]));
+            else v = F9::canon(v);                 // last pass: back to [0, M)
+            out[base + ((uint64_t)rows[j] << a.log_S)] = F9::to_fp(v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // helpers for coset scaling and the 3 * 2^k domain
 // ---------------------------------------------------------------------------------------------
 // out[j] = in[j] * g^j, powers from a three-level table of g.
@@ -317,13 +458,15 @@ static int upload(Fp** dst, const std::vector<Fp>& src, hipStream_t st) {
 }
 
 static int get_plan(Ctx& c, uint64_t n, bool inverse, bool scaled, NttPlan** out) {
-    const uint64_t key = (n << 2) | (inverse ? 1u : 0u) | (scaled ? 2u : 0u);
+    const bool l29 = c.tune_ntt_l29 != 0;
+    const uint64_t key = (n << 3) | (inverse ? 1u : 0u) | (scaled ? 2u : 0u) | (l29 ? 4u : 0u);
     auto it = c.ntt_plans.find(key);
     if (it != c.ntt_plans.end()) { *out = it->second; return UZK_OK; }
     NttPlan* p = new NttPlan();
     p->n = n;
     p->inverse = inverse;
     p->scaled = scaled;
+    p->l29 = l29;
     int k = 0;
     while ((1ull << k) < n) ++k;
     p->log_n = k;
@@ -336,9 +479,30 @@ static int get_plan(Ctx& c, uint64_t n, bool inverse, bool scaled, NttPlan** out
         for (size_t e = 0; e < tw.size(); ++e) { tw[e] = cur; cur = Fr::mul(cur, w); }
         UZK_TRY(upload(&p->d_small_tw, tw, c.stream));
     } else {
+        // Split k into P = ceil(k/8) radices 2^b, b in 5..8, minimising the products per element:
+        // a pass of radix 2^b costs floor(b/2) radix-4 sub-passes of one product per element each,
+        // except that the last sub-pass of an even b carries no twiddles (a quarter of a product).
         p->npass = (k + 7) / 8;
-        int base = k / p->npass, extra = k % p->npass;
-        for (int j = 0; j < p->npass; ++j) p->bits[j] = base + (j < extra ? 1 : 0);
+        {
+            int best_cost = 1 << 30, cur[4] = {0, 0, 0, 0};
+            const int P = p->npass;
+            // enumerate non-increasing b_0 >= b_1 >= ... (order does not change the cost), smallest
+            // b_0 first so that ties go to the more balanced split
+            auto cost_of = [&](const int* b) {
+                int c4 = 0;
+                for (int j = 0; j < P; ++j) c4 += 4 * (b[j] / 2) - ((b[j] & 1) ? 0 : 3);
+                return c4;
+            };
+            for (cur[0] = 5; cur[0] <= 8; ++cur[0])
+                for (cur[1] = (P > 1 ? cur[0] : 0); cur[1] >= (P > 1 ? 5 : 0); --cur[1])
+                    for (cur[2] = (P > 2 ? cur[1] : 0); cur[2] >= (P > 2 ? 5 : 0); --cur[2])
+                        for (cur[3] = (P > 3 ? cur[2] : 0); cur[3] >= (P > 3 ? 5 : 0); --cur[3]) {
+                            if (cur[0] + cur[1] + cur[2] + cur[3] != k) continue;
+                            const int cst = cost_of(cur);
+                            if (cst < best_cost) { best_cost = cst; for (int j = 0; j < 4; ++j) p->bits[j] = cur[j]; }
+                        }
+            if (best_cost == (1 << 30)) { delete p; set_error("ntt: no radix split for 2^%d", k); return UZK_ERR_FFT; }
+        }
         std::vector<Fp> pw;
         host_pow_tables(w, pw);
         UZK_TRY(upload(&p->d_pow, pw, c.stream));
@@ -346,6 +510,9 @@ static int get_plan(Ctx& c, uint64_t n, bool inverse, bool scaled, NttPlan** out
         std::vector<Fp> t256(256);
         Fp w256 = f_pow_u64<Fr>(w, n / 256), cur = Fr::one();
         for (int e = 0; e < 256; ++e) { t256[e] = cur; cur = Fr::mul(cur, w256); }
+        if (l29)
+            for (auto& t : t256)
+                for (int d = 0; d < 5; ++d) t = Fr::add(t, t);     // 2^261-form
         UZK_TRY(upload(&p->d_tw256, t256, c.stream));
         int log_S = 0;
         for (int j = 0; j + 1 < p->npass; ++j) {
@@ -356,7 +523,7 @@ static int get_plan(Ctx& c, uint64_t n, bool inverse, bool scaled, NttPlan** out
                 KernelScope ks(c, "ntt_gen_pass_tw");
                 hipLaunchKernelGGL(ntt_gen_pass_tw_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0,
                                    c.stream, p->d_tw_pass[j], count, log_S, p->bits[j], p->d_pow, p->scale,
-                                   fold ? 1 : 0);
+                                   fold ? 1 : 0, l29 ? 5 : 0);
             }
             log_S += p->bits[j];
         }
@@ -382,10 +549,14 @@ void ntt_free_plans(Ctx& c) {
 }
 
 template <int B>
-static void launch_pass(Ctx& c, bool first, const Fp* in, Fp* out, const PassArgs& a, uint64_t n, uint32_t batch) {
+static void launch_pass(Ctx& c, bool l29, bool first, const Fp* in, Fp* out, const PassArgs& a, uint64_t n, uint32_t batch) {
     constexpr int R = 1 << B, T = 2048 / R;
     const unsigned grid = (unsigned)((n / R) / T);
-    if (first) {
+    if (l29) {
+        KernelScope ks(c, first ? "ntt_pass_first" : "ntt_pass");
+        if (first) hipLaunchKernelGGL((ntt_pass29_kernel<B, true>), dim3(grid, batch), dim3(512), 0, c.stream, in, out, a);
+        else hipLaunchKernelGGL((ntt_pass29_kernel<B, false>), dim3(grid, batch), dim3(512), 0, c.stream, in, out, a);
+    } else if (first) {
         KernelScope ks(c, "ntt_pass_first");
         hipLaunchKernelGGL((ntt_pass_kernel<B, true>), dim3(grid, batch), dim3(512), 0, c.stream, in, out, a);
     } else {
@@ -432,10 +603,10 @@ static int ntt_pow2(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse,
         a.twp = p->d_tw_pass[j];
         const bool first = (j == 0);
         switch (p->bits[j]) {
-            case 5: launch_pass<5>(c, first, src, dst, a, n, batch); break;
-            case 6: launch_pass<6>(c, first, src, dst, a, n, batch); break;
-            case 7: launch_pass<7>(c, first, src, dst, a, n, batch); break;
-            case 8: launch_pass<8>(c, first, src, dst, a, n, batch); break;
+            case 5: launch_pass<5>(c, p->l29, first, src, dst, a, n, batch); break;
+            case 6: launch_pass<6>(c, p->l29, first, src, dst, a, n, batch); break;
+            case 7: launch_pass<7>(c, p->l29, first, src, dst, a, n, batch); break;
+            case 8: launch_pass<8>(c, p->l29, first, src, dst, a, n, batch); break;
             default: set_error("ntt: bad radix bits %d", p->bits[j]); return UZK_ERR_FFT;
         }
         UZK_HIP(hipGetLastError());
