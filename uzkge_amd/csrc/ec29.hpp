@@ -1,14 +1,15 @@
 // Bucket accumulator on the 29-bit-limb representation (fp29.hpp): the mixed addition of the
 // accumulation loop (same XYZZ formulas as ec.hpp's xyzz_madd, EFD madd-2008-s) arranged so that
 //   * the SRS points are used as they arrive (8 x 32-bit words, 2^256-form, canonical): no converted
-//     copy of the SRS exists;
-//   * the accumulator keeps  nx = -X * 2^261,  ny = -Y * 2^261  (normalized limbs, value < 6M) and
-//     zz = ZZ * 2^266, zzz = ZZZ * 2^266  (products: normalized, < 1.3M).  With these exponents
-//     every product below lands in the right form by itself: mul(p.x 2^256, ZZ 2^266) = U2 2^261, ...
-//     (a * b * 2^-261 per product), and keeping X, Y negated turns the two differences
-//     P = U2 - X and R = S2 - Y into plain limb-wise additions whose limbs stay < 2^30 -- small
-//     enough to be squared without a carry pass.
-// Per addition: 8 products + 2 squarings, two carry passes, about 90 limb additions.
+//     copy of the SRS exists.  The accumulator keeps x = X * 2^261, y = Y * 2^261 and
+//     zz = ZZ * 2^266, z3 = +-ZZZ * 2^266; with these exponents every product lands in the right
+//     form by itself (a * b * 2^-261 per product): mul(p.x 2^256, ZZ 2^266) = U2 2^261, ...
+//   * -P = X - U2 is formed as a limb-wise ADDITION (the point's x is negated on load), so its limbs
+//     stay < 2^30 and it can be squared without a carry pass;
+//   * Y3 = R (Q - X3) - Y PPP is ONE dual product R*D + Y*(-PPP) with a single reduction; -PPP comes
+//     for free from -P, and the sign it leaves on ZZZ' = ZZZ * (-PPP) is tracked in one bit and undone
+//     by flipping the sign of the next point's y.
+// Per addition: 6 products, 2 squarings, 1 dual product (1467 multiply-adds), two carry passes.
 // Doubling / cancellation (P = 0) are detected on PP = P^2 (normalized: 0 or M) and handled by the
 // canonical code of ec.hpp.
 #pragma once
@@ -20,43 +21,50 @@ namespace uzk {
 #if defined(__HIP_DEVICE_COMPILE__)
 
 struct Acc29 {
-    L29 nx, ny, zz, zzz;
+    L29 x, y, zz, z3;   // x, y: normalized, value < 7M / 2M; zz, z3: products (normalized, < 1.1M)
     bool inf;
+    bool zneg;          // true ZZZ = -z3
 };
 
 __device__ __forceinline__ Acc29 acc29_inf() {
     Acc29 a;
-    a.nx = Fq29::zero(); a.ny = Fq29::zero(); a.zz = Fq29::zero(); a.zzz = Fq29::zero();
+    a.x = Fq29::zero(); a.y = Fq29::zero(); a.zz = Fq29::zero(); a.z3 = Fq29::zero();
     a.inf = true;
+    a.zneg = false;
     return a;
 }
 // canonical XYZZ in 2^256-form -> accumulator forms (ZZ = ZZZ = 1 for an affine point)
 __device__ __forceinline__ void acc29_set(Acc29& a, const Fp& x, const Fp& y, const Fp* zz, const Fp* zzz) {
-    a.nx = Fq29::to_261(Fq29::from_fp(Fq::neg(x)));
-    a.ny = Fq29::to_261(Fq29::from_fp(Fq::neg(y)));
+    a.x = Fq29::to_261(Fq29::from_fp(x));
+    a.y = Fq29::to_261(Fq29::from_fp(y));
     if (zz == nullptr) {
         a.zz = Fq29::constant(Fq29Cfg::R266);
-        a.zzz = a.zz;
+        a.z3 = a.zz;
     } else {
         a.zz = Fq29::mul(Fq29::from_fp(*zz), Fq29::constant(Fq29Cfg::R271));
-        a.zzz = Fq29::mul(Fq29::from_fp(*zzz), Fq29::constant(Fq29Cfg::R271));
+        a.z3 = Fq29::mul(Fq29::from_fp(*zzz), Fq29::constant(Fq29Cfg::R271));
     }
     a.inf = false;
+    a.zneg = false;
 }
 __device__ __forceinline__ void acc29_madd(Acc29& a, const Affine& p_in, bool negate) {
     using F = Fq29;
     if (affine_is_inf(p_in)) return;
-    Affine p = p_in;
-    if (negate) p.y = Fq::neg(p.y);
-    if (a.inf) { acc29_set(a, p.x, p.y, nullptr, nullptr); return; }
-    // (statement order keeps few temporaries alive: at most four besides the accumulator)
-    const L29 Pd = F::add(F::mul(F::from_fp(p.x), a.zz), a.nx);       // limbs < 2^30, value < 7M
-    const L29 PP = F::sqr(Pd);                                        // normalized, < 1.3M
+    if (a.inf) {
+        acc29_set(a, p_in.x, negate ? Fq::neg(p_in.y) : p_in.y, nullptr, nullptr);
+        return;
+    }
+    const Fp py_eff = (negate != a.zneg) ? Fq::neg(p_in.y) : p_in.y;          // sign of z3 folded into y
+    const L29 nPd = F::add(F::mul(F::from_fp(Fq::neg(p_in.x)), a.zz), a.x);   // -P: limbs < 2^30, value < 8.2M
+    const L29 PP = F::sqr(nPd);                                               // normalized, < 1.4M
+    const L29 S2 = F::mul(F::from_fp(py_eff), a.z3);
+    const L29 Rd = F::norm(F::sub_off(S2, a.y, Fq29Cfg::OFF2T1));             // R: normalized, value < 3.1M
     {
         const uint32_t t = PP.l[0];
-        if ((t == 0 || t == Fq29Cfg::M[0]) && F::is_zero_mod_small(PP)) {   // same x: double or cancel
-            const L29 Rd = F::add(F::mul(F::from_fp(p.y), a.zzz), a.ny);
+        if ((t == 0 || t == Fq29Cfg::M[0]) && F::is_zero_mod_small(PP)) {     // same x: double or cancel
             if (F::all_zero(F::canon(Rd))) {
+                Affine p = p_in;
+                if (negate) p.y = Fq::neg(p.y);
                 const XYZZ d = xyzz_dbl_affine(p);
                 acc29_set(a, d.x, d.y, &d.zz, &d.zzz);
             } else {
@@ -66,35 +74,30 @@ __device__ __forceinline__ void acc29_madd(Acc29& a, const Affine& p_in, bool ne
         }
     }
     a.zz = F::mul(a.zz, PP);
-    const L29 nQ = F::mul(a.nx, PP);                                  // -Q
-    const L29 PPP = F::mul(Pd, PP);
-    const L29 Rd = F::add(F::mul(F::from_fp(p.y), a.zzz), a.ny);
-    a.zzz = F::mul(a.zzz, PPP);
-    const L29 nB = F::mul(a.ny, PPP);                                 // -Y * PPP
+    const L29 Q = F::mul(a.x, PP);
+    const L29 nPPP = F::mul(nPd, PP);                                         // -PPP
+    a.z3 = F::mul(a.z3, nPPP);
+    a.zneg = !a.zneg;
     const L29 RR = F::sqr(Rd);
-    // -X3 = PPP + 2Q - RR = PPP - 2 nQ - RR (+ 4M)
-    L29 nx;
+    // X3 = RR - PPP - 2Q (+ 4M)
+    L29 x3;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) nx.l[i] = PPP.l[i] + Fq29Cfg::OFF4T3[i] - 2 * nQ.l[i] - RR.l[i];
-    nx = F::norm(nx);                                                 // value < 5.1M
-    a.nx = nx;
-    const L29 D = F::sub_off(nx, nQ, Fq29Cfg::OFF2T1);                // Q - X3: limbs < 1.45 * 2^30, value < 7.1M
-    const L29 A = F::mul(Rd, D);
-    // -Y3 = Y PPP - R (Q - X3) = -nB - A (+ 4M)
-    L29 ny;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) ny.l[i] = Fq29Cfg::OFF4[i] - nB.l[i] - A.l[i];
-    a.ny = F::norm(ny);                                               // value < 4M
+    for (int i = 0; i < 9; ++i) x3.l[i] = RR.l[i] + nPPP.l[i] + Fq29Cfg::OFF4[i] - 2 * Q.l[i];
+    x3 = F::norm(x3);                                                         // value < 6.2M
+    const L29 D = F::sub_off(Q, x3, Fq29Cfg::OFF8T1);                         // Q - X3: limbs < 1.5 * 2^30, value < 9.1M
+    a.y = F::mul2(Rd, D, a.y, nPPP);                                          // Y3 = R D - Y PPP: normalized, < 1.2M
+    a.x = x3;
 }
 // -> canonical XYZZ in 2^256-form
 __device__ __forceinline__ XYZZ acc29_to_xyzz(const Acc29& a) {
     using F = Fq29;
     if (a.inf) return xyzz_inf();
     XYZZ r;
-    r.x = Fq::neg(F::to_fp(F::canon(F::to_256(a.nx))));
-    r.y = Fq::neg(F::to_fp(F::canon(F::to_256(a.ny))));
+    r.x = F::to_fp(F::canon(F::to_256(a.x)));
+    r.y = F::to_fp(F::canon(F::to_256(a.y)));
     r.zz = F::to_fp(F::canon(F::mul(a.zz, F::constant(Fq29Cfg::R251))));
-    r.zzz = F::to_fp(F::canon(F::mul(a.zzz, F::constant(Fq29Cfg::R251))));
+    r.zzz = F::to_fp(F::canon(F::mul(a.z3, F::constant(Fq29Cfg::R251))));
+    if (a.zneg) r.zzz = Fq::neg(r.zzz);
     return r;
 }
 

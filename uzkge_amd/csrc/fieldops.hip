@@ -45,6 +45,10 @@ __global__ __launch_bounds__(256) void field_op_kernel(int op, const Fp* __restr
             r = F29::to_fp(F29::canon(t));
         } break;
         case 19: r = F29::to_fp(F29::canon(F29::sub_off(F29::from_fp(x), F29::from_fp(y), F29::Cfg::OFF2T1))); break;
+        case 20: {   // dual product with one reduction: x*y + (x + y)*x (2^256-form), second pair lazy
+            L29 a = F29::from_fp(x), b = F29::from_fp(y);
+            r = F29::to_fp(F29::canon(F29::mul2(a, F29::to_261(b), F29::add(a, b), F29::to_261(a))));
+        } break;
         default: r = F::to_mont(x); break;
     }
     out[i] = r;

@@ -156,6 +156,38 @@ struct Field29 {
         r.l[8] = (uint32_t)acc;
         return r;
     }
+    // (a*b + c*d) * 2^-261 with ONE reduction: max(a_i) max(b_j) + max(c_i) max(d_j) < 2^60.6;
+    // result normalized, value < M (1 + (Va Vb + Vc Vd) / 169).
+    __device__ __forceinline__ static L29 mul2(const L29& a, const L29& b, const L29& c, const L29& d) {
+        uint64_t acc = 0;
+        uint32_t m[9];
+        L29 r;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+#pragma unroll
+            for (int i = 0; i <= k; ++i) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+            for (int i = 0; i <= k; ++i) acc += (uint64_t)c.l[i] * d.l[k - i];
+#pragma unroll
+            for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * C::M[k - i];
+            m[k] = ((uint32_t)acc * C::INV) & MASK;
+            acc += (uint64_t)m[k] * C::M[0];
+            acc >>= 29;
+        }
+#pragma unroll
+        for (int k = 9; k < 17; ++k) {
+#pragma unroll
+            for (int i = k - 8; i < 9; ++i) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+            for (int i = k - 8; i < 9; ++i) acc += (uint64_t)c.l[i] * d.l[k - i];
+#pragma unroll
+            for (int i = k - 8; i < 9; ++i) acc += (uint64_t)m[i] * C::M[k - i];
+            r.l[k - 9] = (uint32_t)acc & MASK;
+            acc >>= 29;
+        }
+        r.l[8] = (uint32_t)acc;
+        return r;
+    }
     // a - b + OFF for any of the offset constants (the caller matches OFF to b's limb / value bounds)
     __device__ __forceinline__ static L29 sub_off(const L29& a, const L29& b, const uint32_t (&off)[9]) {
         L29 r;
