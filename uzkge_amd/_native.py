@@ -58,6 +58,7 @@ PROTOTYPES = {
     "uzk_sync": (_I, []),
     "uzk_stream": (_P, []),
     "uzk_msm_set_window_bits": (_I, [_I]),
+    "uzk_msm_plan_info": (_I, [ctypes.c_size_t, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "uzk_tune": (_I, [ctypes.c_char_p, _I]),
 }
 

@@ -4,7 +4,7 @@ Jacobian results [12]."""
 from __future__ import annotations
 
 import ctypes
-from typing import Optional
+from typing import Optional, Tuple
 
 import numpy as np
 
@@ -250,6 +250,13 @@ def profile_table() -> dict:
 
 def set_msm_window_bits(c: int) -> None:
     check(lib.uzk_msm_set_window_bits(c))
+
+
+def msm_plan_info(n: int) -> Tuple[int, int]:
+    """(window bits, windows) a general-mode MSM over n points will use."""
+    cb, w = ctypes.c_int(0), ctypes.c_int(0)
+    check(lib.uzk_msm_plan_info(n, ctypes.byref(cb), ctypes.byref(w)))
+    return cb.value, w.value
 
 
 def tune(key: str, value: int) -> None:

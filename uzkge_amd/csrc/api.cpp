@@ -578,6 +578,13 @@ int uzk_msm_set_window_bits(int c) {
     return UZK_OK;
 }
 
+int uzk_msm_plan_info(size_t n, int* window_bits, int* windows) {
+    API_LOCK;
+    if (!window_bits || !windows || n == 0) { set_error("uzk_msm_plan_info: bad arguments"); return UZK_ERR_PARAMETER; }
+    msm_plan_info(ctx(), n, window_bits, windows);
+    return UZK_OK;
+}
+
 int uzk_tune(const char* key, int value) {
     API_LOCK;
     if (!key) { set_error("uzk_tune: null key"); return UZK_ERR_PARAMETER; }

@@ -108,6 +108,7 @@ struct KernelScope {
 // entry points implemented in the .hip files
 int ntt_run(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse, const Fp* coset_shift_host, uint32_t batch);
 void ntt_free_plans(Ctx& c);
+void msm_plan_info(Ctx& c, size_t n, int* window_bits, int* windows);
 int msm_run(Ctx& c, const Affine* points, const Fp* d_scalars, size_t n, uint32_t batch, Jac* out_host, int pre_c,
             uint32_t pre_stride, uint32_t pre_off);
 int msm_build_table(Ctx& c, const Affine* d_points, size_t n, int cb, Affine** table_out, uint32_t* W_out);

@@ -1055,6 +1055,12 @@ static int msm_group_phase2(Ctx& c, MsmGroup& g) {
     return UZK_OK;
 }
 
+void msm_plan_info(Ctx& c, size_t n, int* window_bits, int* windows) {
+    const int cb = choose_window_bits(n, c.msm_window_bits);
+    *window_bits = cb;
+    *windows = msm_num_windows(cb);
+}
+
 // `points`: base array the sorted indices refer to (the SRS slice, or the window table).
 // Precomputed mode (pre_c > 0): `points` = table, entries of window j index pre_stride * j + pre_off + i.
 // `batch` scalar vectors of n elements each share the same bases; out_host[batch].
