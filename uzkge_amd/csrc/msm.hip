@@ -103,7 +103,18 @@ struct RadixArgs {
     uint32_t* bin_count;         // [seg][bins]
     uint2* out_entries;          // !OUT_VAL
     uint32_t* out_vals;          // OUT_VAL
+    // Packed 4-byte intermediate entries (two-pass sorts whose fields fit 32 bits): the remaining low
+    // key bits above the point index and its sign,  e = key_low << (idx_bits + 1) | sign << idx_bits | idx.
+    // 0 = 8-byte {key, val} entries.
+    uint32_t pk_in_bits, pk_out_bits;   // idx_bits of the input / output entry format (0 = unpacked)
 };
+__device__ __forceinline__ uint32_t pk_key(uint32_t e, uint32_t idx_bits) { return e >> (idx_bits + 1); }
+__device__ __forceinline__ uint32_t pk_val(uint32_t e, uint32_t idx_bits) {
+    return (e & ((1u << idx_bits) - 1)) | (((e >> idx_bits) & 1u) << 31);
+}
+__device__ __forceinline__ uint32_t pk_make(uint32_t key_low, uint32_t val, uint32_t idx_bits) {
+    return (key_low << (idx_bits + 1)) | ((val >> 31) << idx_bits) | (val & ~kSignBit);
+}
 
 // Which (segment, chunk) does this workgroup own, where are its counters, and which entries?
 // Pass 0 (FROM_DIGITS): equal segments, grid (nch, nseg).  Later passes: segment lengths are data
@@ -138,7 +149,7 @@ __device__ __forceinline__ bool radix_work(const RadixArgs& a, uint32_t& seg, si
         return true;
     }
 }
-template <bool FROM_DIGITS>
+template <bool FROM_DIGITS, bool PK_IN>
 __device__ __forceinline__ bool radix_load(const RadixArgs& a, uint32_t seg, uint32_t base, uint32_t k, uint32_t& key,
                                            uint32_t& val) {
     if constexpr (FROM_DIGITS) {
@@ -149,6 +160,11 @@ __device__ __forceinline__ bool radix_load(const RadixArgs& a, uint32_t seg, uin
         if (a.remap_cnt) idx = (k / a.remap_cnt) * a.remap_stride + a.remap_off + (k % a.remap_cnt);
         val = idx | (d & kSignBit);
         return mag != 0;
+    } else if constexpr (PK_IN) {
+        const uint32_t e = reinterpret_cast<const uint32_t*>(a.in_entries)[(size_t)base + k];
+        key = pk_key(e, a.pk_in_bits);
+        val = pk_val(e, a.pk_in_bits);
+        return true;
     } else {
         const uint2 e = a.in_entries[(size_t)base + k];
         key = e.x;
@@ -157,7 +173,7 @@ __device__ __forceinline__ bool radix_load(const RadixArgs& a, uint32_t seg, uin
     }
 }
 
-template <bool FROM_DIGITS>
+template <bool FROM_DIGITS, bool PK_IN>
 __global__ __launch_bounds__(1024) void msm_radix_hist_kernel(RadixArgs a) {
     __shared__ uint32_t cnt[512];
     uint32_t seg, base, lo, hi;
@@ -169,6 +185,9 @@ __global__ __launch_bounds__(1024) void msm_radix_hist_kernel(RadixArgs a) {
         if constexpr (FROM_DIGITS) {
             const uint32_t mag = a.digits[(size_t)seg * a.n + k] & ~kSignBit;
             if (mag) atomicAdd(&cnt[((mag - 1) >> a.shift) & a.mask], 1u);
+        } else if constexpr (PK_IN) {
+            const uint32_t e = reinterpret_cast<const uint32_t*>(a.in_entries)[(size_t)base + k];
+            atomicAdd(&cnt[(pk_key(e, a.pk_in_bits) >> a.shift) & a.mask], 1u);
         } else {
             atomicAdd(&cnt[(a.in_entries[(size_t)base + k].x >> a.shift) & a.mask], 1u);
         }
@@ -236,7 +255,7 @@ __global__ __launch_bounds__(1024) void msm_radix_items_kernel(const uint32_t* _
 }
 
 // block TB, tile = TB * E entries sorted in LDS before they are written out
-template <int TB, int E, bool FROM_DIGITS, bool OUT_VAL>
+template <int TB, int E, bool FROM_DIGITS, bool OUT_VAL, bool PK_IN>
 __global__ __launch_bounds__(TB) void msm_radix_scatter_kernel(RadixArgs a) {
     constexpr int TILE = TB * E;
     __shared__ uint2 buf[TILE];
@@ -255,7 +274,7 @@ __global__ __launch_bounds__(TB) void msm_radix_scatter_kernel(RadixArgs a) {
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const uint32_t k = t0 + tid + e * TB;
-            ok[e] = (k < hi) && radix_load<FROM_DIGITS>(a, seg, base, k, key[e], val[e]);
+            ok[e] = (k < hi) && radix_load<FROM_DIGITS, PK_IN>(a, seg, base, k, key[e], val[e]);
             if (ok[e]) rank[e] = atomicAdd(&tcnt[(key[e] >> a.shift) & a.mask], 1u);
         }
         __syncthreads();
@@ -293,6 +312,8 @@ __global__ __launch_bounds__(TB) void msm_radix_scatter_kernel(RadixArgs a) {
             const uint32_t bin = (en.x >> a.shift) & a.mask;
             const uint32_t pos = gcur[bin] + (k - toff[bin]);
             if constexpr (OUT_VAL) a.out_vals[pos] = en.y;
+            else if (a.pk_out_bits)
+                reinterpret_cast<uint32_t*>(a.out_entries)[pos] = pk_make(en.x & ((1u << a.shift) - 1), en.y, a.pk_out_bits);
             else a.out_entries[pos] = en;
         }
         __syncthreads();
@@ -790,6 +811,7 @@ struct MsmGroup {
     uint64_t per_poly = 0, entries = 0, TBK = 0, bound0 = 0, part_cap = 0;
     uint32_t kb = 0, NBL = 0, S0 = 0, seg_n = 0, NB = 0, Wd = 0, RW = 0, seg = 0, groups = 0, L = 0;
     int P = 0;
+    uint32_t pk_bits = 0;   // > 0: 4-byte packed entries between the two sort passes (index bits)
     SortPass sp[kMaxPasses];
     // state carried from phase 1 to phase 2
     uint32_t *cnt_cur = nullptr, *off_cur = nullptr, *base_cur = nullptr;
@@ -819,9 +841,19 @@ static int msm_group_plan(Ctx& c, MsmGroup& g, size_t n, uint32_t batch, int cb,
     g.bound0 = g.entries / g.L + g.TBK;                     // upper bound on level-0 tasks
     g.part_cap = g.bound0 + 2 * g.TBK;                      // every later level fits too
     g.P = g.kb <= 9 ? 1 : (g.kb <= 18 ? 2 : 3);             // radix passes of <= 9 bits, high bits first
+    // Two-pass sorts: take 9 bits first when that lets {remaining key bits, sign, index} fit 32 bits --
+    // the entries between the passes are then 4 bytes instead of 8 (a third of the sort's traffic less).
+    g.pk_bits = 0;
+    if (g.P == 2 && !pre && c.tune_sort_packed) {
+        uint32_t ib = 1;
+        while ((1ull << ib) < g.seg_n) ++ib;
+        const uint32_t first_bits = std::min<uint32_t>(9, g.kb - 1);
+        if (ib + 1 + (g.kb - first_bits) <= 32) g.pk_bits = ib;
+    }
     uint32_t rem = g.kb, nseg = g.S0;
     for (int p = 0; p < g.P; ++p) {
-        const uint32_t bits = (rem + (uint32_t)(g.P - p) - 1) / (uint32_t)(g.P - p);
+        uint32_t bits = (rem + (uint32_t)(g.P - p) - 1) / (uint32_t)(g.P - p);
+        if (g.pk_bits && p == 0) bits = std::min<uint32_t>(9, g.kb - 1);
         rem -= bits;
         g.sp[p].shift = rem;
         g.sp[p].bins = 1u << bits;
@@ -904,6 +936,7 @@ static int msm_group_phase1(Ctx& c, MsmGroup& g, const Affine* points, const Fp*
             a.seg_start = m.segs_start[p - 1].as<uint32_t>();
             a.seg_len = m.segs_len[p - 1].as<uint32_t>();
         }
+        if (g.pk_bits) { if (first) a.pk_out_bits = g.pk_bits; else a.pk_in_bits = g.pk_bits; }
         if (last) { a.bin_base = bstart; a.bin_count = bcount; a.out_vals = sorted; }
         else {
             a.bin_base = m.segs_start[p].as<uint32_t>(); a.bin_count = m.segs_len[p].as<uint32_t>();
@@ -920,8 +953,9 @@ static int msm_group_phase1(Ctx& c, MsmGroup& g, const Affine* points, const Fp*
         const dim3 grid = first ? dim3(sp.nch, sp.nseg) : dim3(sp.items_bound);
         {
             KernelScope ks(c, "msm_sort_hist");
-            if (first) hipLaunchKernelGGL(msm_radix_hist_kernel<true>, grid, dim3(1024), 0, st, a);
-            else hipLaunchKernelGGL(msm_radix_hist_kernel<false>, grid, dim3(256), 0, st, a);
+            if (first) hipLaunchKernelGGL((msm_radix_hist_kernel<true, false>), grid, dim3(1024), 0, st, a);
+            else if (a.pk_in_bits) hipLaunchKernelGGL((msm_radix_hist_kernel<false, true>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((msm_radix_hist_kernel<false, false>), grid, dim3(256), 0, st, a);
         }
         {
             KernelScope ks(c, "msm_sort_scan");
@@ -930,10 +964,11 @@ static int msm_group_phase1(Ctx& c, MsmGroup& g, const Affine* points, const Fp*
         }
         {
             KernelScope ks(c, "msm_sort_scatter");
-            if (first && last) hipLaunchKernelGGL((msm_radix_scatter_kernel<1024, 8, true, true>), grid, dim3(1024), 0, st, a);
-            else if (first) hipLaunchKernelGGL((msm_radix_scatter_kernel<1024, 8, true, false>), grid, dim3(1024), 0, st, a);
-            else if (last) hipLaunchKernelGGL((msm_radix_scatter_kernel<256, 16, false, true>), grid, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((msm_radix_scatter_kernel<1024, 8, false, false>), grid, dim3(1024), 0, st, a);
+            if (first && last) hipLaunchKernelGGL((msm_radix_scatter_kernel<1024, 8, true, true, false>), grid, dim3(1024), 0, st, a);
+            else if (first) hipLaunchKernelGGL((msm_radix_scatter_kernel<1024, 8, true, false, false>), grid, dim3(1024), 0, st, a);
+            else if (last && a.pk_in_bits) hipLaunchKernelGGL((msm_radix_scatter_kernel<256, 16, false, true, true>), grid, dim3(256), 0, st, a);
+            else if (last) hipLaunchKernelGGL((msm_radix_scatter_kernel<256, 16, false, true, false>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((msm_radix_scatter_kernel<1024, 8, false, false, false>), grid, dim3(1024), 0, st, a);
         }
     }
     // ---- level-0 tasks (runs of <= L indices), longest first
