@@ -134,6 +134,40 @@ int uzk_poly_eval_batch_device(const void* d_coefs, uint64_t n, uint32_t batch, 
 int uzk_z_poly(const uint64_t* w, const uint32_t* perm, const uint64_t* group, const uint64_t* k,
                const uint64_t* beta_mont, const uint64_t* gamma_mont, uint32_t n, uint32_t n_wires, uint64_t* z_out);
 
+/* The quotient evaluations of t_poly on the coset k[1]*<g_m> (uzkge/src/plonk/helpers.rs:284-656 with
+ * the "shuffle" feature; gate function turbo/mod.rs:193-222): for every point of the m = factor*n
+ * domain, the 18 terms (gate, permutation, L1, booleanity, Anemoi round, shuffle/ECC selectors) are
+ * combined with the powers of alpha and multiplied by z_h_inv[point % factor] -- the body of the
+ * reference's cfg_into_iter!(0..m) loop, one lane per point.  The caller produces the inputs with the
+ * coset transforms above (uzk_ntt_fr_batch_device with coset_shift = k[1]) and finishes with the
+ * inverse coset transform, exactly as the reference does around that loop.
+ * vec[slot]: DEVICE pointers to vectors of m elements (Montgomery form); "next" values (z, w0..w2 at
+ * (point + factor) % m) are read from the same vectors. */
+enum {
+    UZK_TQ_W = 0,               /* 5: wire polynomials w[0..4] */
+    UZK_TQ_WSEL = 5,            /* 3: wire selectors w_sel[0..2] */
+    UZK_TQ_PI = 8,              /* public-input polynomial */
+    UZK_TQ_Z = 9,               /* permutation grand product */
+    UZK_TQ_Q = 10,              /* 9: selectors q_coset_evals (turbo/mod.rs:197-210 order) */
+    UZK_TQ_S = 19,              /* 5: s_coset_evals */
+    UZK_TQ_L1 = 24,
+    UZK_TQ_QB = 25,
+    UZK_TQ_QPRK = 26,           /* 4: q_prk1..4 */
+    UZK_TQ_COSET_QUOTIENT = 30, /* prover_params.coset_quotient */
+    UZK_TQ_QPK = 31,            /* 12: q_shuffle_public_key: x_00,x_01,x_10,x_11, y_.., dxy_.. */
+    UZK_TQ_QG = 43,             /* 12: q_shuffle_generator, same order */
+    UZK_TQ_QECC = 55,
+    UZK_TQ_NVEC = 56
+};
+typedef struct {
+    uint32_t n, factor;                 /* constraint-system size, m / n (6, or 16 for n <= 8); factor <= 16 */
+    const void* vec[UZK_TQ_NVEC];
+    uint64_t alpha[4], beta[4], gamma[4], k[5][4], anemoi_g[4], anemoi_g_inv[4], edwards_a[4];
+    uint64_t z_h_inv[16][4];            /* 1 / (k[1]^n * g_m^(n*i) - 1), i < factor (helpers.rs:242-252) */
+} uzk_quotient_args;
+/* d_out: m elements on the device (must not alias an input). */
+int uzk_t_quotient_device(const uzk_quotient_args* args, void* d_out, int sync);
+
 /* ---- synthetic workloads (bench / tests; generated on device, nothing uploaded) -------- */
 /* d_points[i] = (i + 1) * Q with Q = seed_scalar * G: n distinct valid G1 points whose discrete
  * logs relative to Q are known, so MSM(points, s) == (sum_i s_i (i+1)) * Q for any size. */

@@ -429,3 +429,167 @@ void oracle_z_poly(const uint64_t *w_, const uint32_t *perm, const uint64_t *gro
     for (uint32_t i = 0; i < m; ++i) { fe t; f_mul(&FR, &t, &num[i], &den[i]); f_mul(&FR, &prev, &prev, &t); z[i + 1] = prev; }
     free(num); free(den); free(pre);
 }
+
+/* t_poly's quotient evaluations on the coset (uzkge/src/plonk/helpers.rs:284-656, feature "shuffle"),
+ * restated term by term in the reference's own order; the gate function is
+ * uzkge/src/plonk/constraint_system/turbo/mod.rs:193-222.  vec[] = 56 vectors of m = factor * n
+ * elements in the slot order of include/uzkge_gpu.h (UZK_TQ_*); out[point] = numerator * z_h_inv[point % factor].
+ * No fixture of the reference pins these intermediate values: parity for this row is unpinned. */
+typedef struct {
+    uint32_t n, factor;
+    const uint64_t *vec[56];
+    uint64_t alpha[4], beta[4], gamma[4], k[5][4], anemoi_g[4], anemoi_g_inv[4], edwards_a[4];
+    uint64_t z_h_inv[16][4];
+} oracle_quotient_args;
+
+static void f_pow5(const field *F, fe *r, const fe *a) { fe a2, a4; f_sqr(F, &a2, a); f_sqr(F, &a4, &a2); f_mul(F, r, &a4, a); }
+
+void oracle_t_quotient(const oracle_quotient_args *A, uint64_t *out_) {
+    const field *F = &FR;
+    const size_t m = (size_t)A->n * A->factor, factor = A->factor;
+    fe *out = (fe *)out_;
+#define V(slot, p) ((const fe *)A->vec[slot] + (p))
+    const fe *alpha = (const fe *)A->alpha, *beta = (const fe *)A->beta, *gamma = (const fe *)A->gamma;
+    const fe *g = (const fe *)A->anemoi_g, *g_inv = (const fe *)A->anemoi_g_inv, *ea = (const fe *)A->edwards_a;
+    fe ap[17];                      /* alpha^1 .. alpha^16 */
+    ap[1] = *alpha;
+    for (int i = 2; i <= 16; ++i) f_mul(F, &ap[i], &ap[i - 1], alpha);
+    const fe one = F->r;
+    fe g2p1; f_sqr(F, &g2p1, g); f_add(F, &g2p1, &g2p1, &one);
+    for (size_t point = 0; point < m; ++point) {
+        const size_t nxt = (point + factor) % m;
+        fe w[5], ws[3];
+        for (int j = 0; j < 5; ++j) w[j] = *V(0 + j, point);
+        for (int j = 0; j < 3; ++j) ws[j] = *V(5 + j, point);
+        const fe pi = *V(8, point), z = *V(9, point), zn = *V(9, nxt);
+        const fe w0n = *V(0, nxt), w1n = *V(1, nxt), w2n = *V(2, nxt);
+        fe t, u, v;
+        /* term1: gate function (turbo/mod.rs:197-221) */
+        fe term1, acc;
+        f_mul(F, &term1, V(10, point), &w[0]);
+        f_mul(F, &t, V(11, point), &w[1]); f_add(F, &term1, &term1, &t);
+        f_mul(F, &t, V(12, point), &w[2]); f_add(F, &term1, &term1, &t);
+        f_mul(F, &t, V(13, point), &w[3]); f_add(F, &term1, &term1, &t);
+        f_mul(F, &u, &w[0], &w[1]); f_mul(F, &t, V(14, point), &u); f_add(F, &term1, &term1, &t);
+        f_mul(F, &u, &w[2], &w[3]); f_mul(F, &t, V(15, point), &u); f_add(F, &term1, &term1, &t);
+        f_add(F, &t, V(16, point), &pi); f_add(F, &term1, &term1, &t);
+        f_mul(F, &t, V(17, point), &w[0]); f_mul(F, &t, &t, &w[1]); f_mul(F, &t, &t, &w[2]); f_mul(F, &t, &t, &w[3]);
+        f_mul(F, &t, &t, &w[4]); f_add(F, &term1, &term1, &t);
+        f_mul(F, &t, V(18, point), &w[4]); f_sub(F, &term1, &term1, &t);
+        /* term2 (helpers.rs:300-307) */
+        fe term2; f_mul(F, &term2, alpha, &z);
+        for (int j = 0; j < 5; ++j) {
+            f_mul(F, &t, (const fe *)A->k[j], V(30, point)); f_mul(F, &t, beta, &t);
+            f_add(F, &u, &w[j], gamma); f_add(F, &u, &u, &t);
+            f_mul(F, &term2, &term2, &u);
+        }
+        /* term3 (:310-319) */
+        fe term3; f_mul(F, &term3, alpha, &zn);
+        for (int j = 0; j < 5; ++j) {
+            f_mul(F, &t, beta, V(19 + j, point));
+            f_add(F, &u, &w[j], gamma); f_add(F, &u, &u, &t);
+            f_mul(F, &term3, &term3, &u);
+        }
+        /* term4 (:322-324) */
+        fe term4; f_mul(F, &term4, &ap[2], V(24, point)); f_sub(F, &t, &z, &one); f_mul(F, &term4, &term4, &t);
+        /* term5..7 (:328-350) */
+        fe term5, term6, term7;
+        const fe qb = *V(25, point);
+        f_mul(F, &term5, &ap[3], &qb); f_mul(F, &term5, &term5, &w[1]); f_sub(F, &t, &w[1], &one); f_mul(F, &term5, &term5, &t);
+        f_mul(F, &term6, &ap[4], &qb); f_mul(F, &term6, &term6, &w[2]); f_sub(F, &t, &w[2], &one); f_mul(F, &term6, &term6, &t);
+        f_mul(F, &term7, &ap[5], &qb); f_mul(F, &term7, &term7, &w[3]); f_sub(F, &t, &w[3], &one); f_mul(F, &term7, &term7, &t);
+        /* Anemoi terms 8..11 (:352-417) */
+        const fe prk1 = *V(26, point), prk2 = *V(27, point), prk3 = *V(28, point), prk4 = *V(29, point);
+        fe w3w0, w2w1, w3_2w0, w2_2w1, tmp, d5, sq, rhs;
+        f_add(F, &w3w0, &w[0], &w[3]); f_add(F, &w2w1, &w[1], &w[2]);
+        f_add(F, &w3_2w0, &w[0], &w3w0); f_add(F, &w2_2w1, &w[1], &w2w1);
+        f_mul(F, &t, g, &w2w1); f_add(F, &tmp, &w3w0, &t); f_add(F, &tmp, &tmp, &prk3);
+        fe term8, term9, term10, term11;
+        f_sub(F, &t, &tmp, &w2n); f_pow5(F, &d5, &t);
+        f_sqr(F, &sq, &tmp); f_mul(F, &sq, g, &sq);
+        f_mul(F, &t, g, &w2_2w1); f_add(F, &rhs, &w3_2w0, &t); f_add(F, &rhs, &rhs, &prk1);
+        f_add(F, &u, &d5, &sq); f_sub(F, &u, &u, &rhs);
+        f_mul(F, &term8, &ap[6], &prk3); f_mul(F, &term8, &term8, &u);
+        f_sqr(F, &sq, &w2n); f_mul(F, &sq, g, &sq);
+        f_add(F, &u, &d5, &sq); f_add(F, &u, &u, g_inv); f_sub(F, &u, &u, &w0n);
+        f_mul(F, &term10, &ap[8], &prk3); f_mul(F, &term10, &term10, &u);
+        f_mul(F, &t, g, &w3w0); f_mul(F, &u, &g2p1, &w2w1); f_add(F, &tmp, &t, &u); f_add(F, &tmp, &tmp, &prk4);
+        f_sub(F, &t, &tmp, &w[4]); f_pow5(F, &d5, &t);
+        f_sqr(F, &sq, &tmp); f_mul(F, &sq, g, &sq);
+        f_mul(F, &t, g, &w3_2w0); f_mul(F, &u, &g2p1, &w2_2w1); f_add(F, &rhs, &t, &u); f_add(F, &rhs, &rhs, &prk2);
+        f_add(F, &u, &d5, &sq); f_sub(F, &u, &u, &rhs);
+        f_mul(F, &term9, &ap[7], &prk3); f_mul(F, &term9, &term9, &u);
+        f_sqr(F, &sq, &w[4]); f_mul(F, &sq, g, &sq);
+        f_add(F, &u, &d5, &sq); f_add(F, &u, &u, g_inv); f_sub(F, &u, &u, &w1n);
+        f_mul(F, &term11, &ap[9], &prk3); f_mul(F, &term11, &term11, &u);
+        /* shuffle terms 12..18 (:419-627) */
+        const fe qecc = *V(55, point);
+        fe sel[4], om0, om1;
+        f_sub(F, &om0, &one, &ws[0]); f_sub(F, &om1, &one, &ws[1]);
+        f_mul(F, &sel[0], &om0, &om1); f_add(F, &sel[0], &sel[0], &qecc); f_sub(F, &sel[0], &sel[0], &one);
+        f_mul(F, &sel[1], &ws[0], &om1);
+        f_mul(F, &sel[2], &om0, &ws[1]);
+        f_mul(F, &sel[3], &ws[0], &ws[1]);
+        fe term12 = {{0, 0, 0, 0}}, term13 = term12, term14 = term12, term15 = term12;
+        for (int ab = 0; ab < 4; ++ab) {
+            const fe pkx = *V(31 + ab, point), pky = *V(35 + ab, point), pkd = *V(39 + ab, point);
+            const fe gx = *V(43 + ab, point), gy = *V(47 + ab, point), gd = *V(51 + ab, point);
+            fe e;
+            /* 12: ws2*w0n - ws2*w0*pky - w1*pkx + w0*w1*w0n*pkd */
+            f_mul(F, &e, &ws[2], &w0n);
+            f_mul(F, &t, &ws[2], &w[0]); f_mul(F, &t, &t, &pky); f_sub(F, &e, &e, &t);
+            f_mul(F, &t, &w[1], &pkx); f_sub(F, &e, &e, &t);
+            f_mul(F, &t, &w[0], &w[1]); f_mul(F, &t, &t, &w0n); f_mul(F, &t, &t, &pkd); f_add(F, &e, &e, &t);
+            f_mul(F, &e, &sel[ab], &e); f_add(F, &term12, &term12, &e);
+            /* 13: ws2*w1n + w0*a*pkx - ws2*w1*pky - w0*w1*w1n*pkd */
+            f_mul(F, &e, &ws[2], &w1n);
+            f_mul(F, &t, &w[0], ea); f_mul(F, &t, &t, &pkx); f_add(F, &e, &e, &t);
+            f_mul(F, &t, &ws[2], &w[1]); f_mul(F, &t, &t, &pky); f_sub(F, &e, &e, &t);
+            f_mul(F, &t, &w[0], &w[1]); f_mul(F, &t, &t, &w1n); f_mul(F, &t, &t, &pkd); f_sub(F, &e, &e, &t);
+            f_mul(F, &e, &sel[ab], &e); f_add(F, &term13, &term13, &e);
+            /* 14: ws2*w2n - ws2*w2*gy - w3*gx + w2*w3*w2n*gd */
+            f_mul(F, &e, &ws[2], &w2n);
+            f_mul(F, &t, &ws[2], &w[2]); f_mul(F, &t, &t, &gy); f_sub(F, &e, &e, &t);
+            f_mul(F, &t, &w[3], &gx); f_sub(F, &e, &e, &t);
+            f_mul(F, &t, &w[2], &w[3]); f_mul(F, &t, &t, &w2n); f_mul(F, &t, &t, &gd); f_add(F, &e, &e, &t);
+            f_mul(F, &e, &sel[ab], &e); f_add(F, &term14, &term14, &e);
+            /* 15: ws2*w4 + w2*a*gx - ws2*w3*gy - w2*w3*w4*gd */
+            f_mul(F, &e, &ws[2], &w[4]);
+            f_mul(F, &t, &w[2], ea); f_mul(F, &t, &t, &gx); f_add(F, &e, &e, &t);
+            f_mul(F, &t, &ws[2], &w[3]); f_mul(F, &t, &t, &gy); f_sub(F, &e, &e, &t);
+            f_mul(F, &t, &w[2], &w[3]); f_mul(F, &t, &t, &w[4]); f_mul(F, &t, &t, &gd); f_sub(F, &e, &e, &t);
+            f_mul(F, &e, &sel[ab], &e); f_add(F, &term15, &term15, &e);
+        }
+        f_mul(F, &term12, &ap[10], &term12); f_mul(F, &term13, &ap[11], &term13);
+        f_mul(F, &term14, &ap[12], &term14); f_mul(F, &term15, &ap[13], &term15);
+        fe term16, term17, term18, omq;
+        f_sub(F, &omq, &one, &qecc);
+        f_mul(F, &t, &qecc, &ws[0]); f_mul(F, &t, &t, &om0); f_mul(F, &u, &omq, &ws[0]); f_add(F, &t, &t, &u); f_mul(F, &term16, &ap[14], &t);
+        f_mul(F, &t, &qecc, &ws[1]); f_mul(F, &t, &t, &om1); f_mul(F, &u, &omq, &ws[1]); f_add(F, &t, &t, &u); f_mul(F, &term17, &ap[15], &t);
+        f_add(F, &t, &one, &ws[2]); f_sub(F, &u, &one, &ws[2]); f_mul(F, &v, &qecc, &t); f_mul(F, &v, &v, &u); f_mul(F, &term18, &ap[16], &v);
+        /* numerator (:629-652) */
+        acc = term1;
+        f_add(F, &acc, &acc, &term2);
+        f_sub(F, &t, &term4, &term3); f_add(F, &acc, &acc, &t);
+        f_add(F, &acc, &acc, &term5); f_add(F, &acc, &acc, &term6); f_add(F, &acc, &acc, &term7);
+        f_sub(F, &acc, &acc, &term8); f_sub(F, &acc, &acc, &term9); f_sub(F, &acc, &acc, &term10); f_sub(F, &acc, &acc, &term11);
+        f_add(F, &acc, &acc, &term12); f_add(F, &acc, &acc, &term13); f_add(F, &acc, &acc, &term14); f_add(F, &acc, &acc, &term15);
+        f_add(F, &acc, &acc, &term16); f_add(F, &acc, &acc, &term17); f_add(F, &acc, &acc, &term18);
+        f_mul(F, &out[point], &acc, (const fe *)A->z_h_inv[point % factor]);
+    }
+#undef V
+}
+
+/* z_h_inv_coset_evals (helpers.rs:242-252): 1 / (k1^n * (g_m^n)^i - 1), i < factor */
+void oracle_z_h_inv(const uint64_t *k1_mont, uint32_t n, uint32_t factor, uint64_t *out) {
+    const field *F = &FR;
+    fe gm; fr_root_of_unity(&gm, (uint64_t)n * factor);
+    fe e = {{n, 0, 0, 0}}, gn, mult;
+    f_pow(F, &gn, &gm, &e);
+    f_pow(F, &mult, (const fe *)k1_mont, &e);
+    for (uint32_t i = 0; i < factor; ++i) {
+        fe t; f_sub(F, &t, &mult, &F->r);
+        f_inv(F, (fe *)out + i, &t);
+        f_mul(F, &mult, &mult, &gn);
+    }
+}

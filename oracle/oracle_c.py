@@ -43,6 +43,10 @@ def _load():
         getattr(lib, name).restype = None
     lib.oracle_z_poly.argtypes = [P, P, P, P, P, P, ctypes.c_uint32, ctypes.c_uint32, P]
     lib.oracle_z_poly.restype = None
+    lib.oracle_t_quotient.argtypes = [P, P]
+    lib.oracle_t_quotient.restype = None
+    lib.oracle_z_h_inv.argtypes = [P, ctypes.c_uint32, ctypes.c_uint32, P]
+    lib.oracle_z_h_inv.restype = None
     lib.oracle_ntt.argtypes = [P, ctypes.c_uint64, ctypes.c_int, ctypes.c_int]
     lib.oracle_ntt.restype = ctypes.c_int
     lib.oracle_domain_supported.argtypes = [ctypes.c_uint64]
@@ -138,6 +142,50 @@ def z_poly(w: np.ndarray, perm: np.ndarray, group: np.ndarray, k: np.ndarray, be
     out = np.zeros((n, 4), dtype=np.uint64)
     lib.oracle_z_poly(_p(wv), pm.ctypes.data_as(ctypes.c_void_p), _p(np.ascontiguousarray(group)), _p(np.ascontiguousarray(k)),
                       _p(np.ascontiguousarray(beta)), _p(np.ascontiguousarray(gamma)), n, n_wires, _p(out))
+    return out
+
+
+class _QuotientArgs(ctypes.Structure):
+    _fields_ = [
+        ("n", ctypes.c_uint32), ("factor", ctypes.c_uint32),
+        ("vec", ctypes.c_void_p * 56),
+        ("alpha", ctypes.c_uint64 * 4), ("beta", ctypes.c_uint64 * 4), ("gamma", ctypes.c_uint64 * 4),
+        ("k", (ctypes.c_uint64 * 4) * 5),
+        ("anemoi_g", ctypes.c_uint64 * 4), ("anemoi_g_inv", ctypes.c_uint64 * 4), ("edwards_a", ctypes.c_uint64 * 4),
+        ("z_h_inv", (ctypes.c_uint64 * 4) * 16),
+    ]
+
+
+def t_quotient(n: int, factor: int, vecs: np.ndarray, alpha, beta, gamma, k, anemoi_g, anemoi_g_inv, edwards_a, z_h_inv) -> np.ndarray:
+    """helpers.rs:284-656 on the CPU.  vecs [56, n*factor, 4] in UZK_TQ_* slot order."""
+    v = np.ascontiguousarray(vecs, dtype=np.uint64)
+    m = n * factor
+    assert v.shape == (56, m, 4)
+    a = _QuotientArgs()
+    a.n, a.factor = n, factor
+    for i in range(56):
+        a.vec[i] = v[i].ctypes.data
+    def put(dst, src):
+        s = np.ascontiguousarray(src, dtype=np.uint64).reshape(4)
+        for j in range(4):
+            dst[j] = int(s[j])
+    put(a.alpha, alpha); put(a.beta, beta); put(a.gamma, gamma)
+    put(a.anemoi_g, anemoi_g); put(a.anemoi_g_inv, anemoi_g_inv); put(a.edwards_a, edwards_a)
+    kk = np.ascontiguousarray(k, dtype=np.uint64).reshape(5, 4)
+    for j in range(5):
+        put(a.k[j], kk[j])
+    zz = np.ascontiguousarray(z_h_inv, dtype=np.uint64).reshape(-1, 4)
+    for j in range(zz.shape[0]):
+        put(a.z_h_inv[j], zz[j])
+    out = np.zeros((m, 4), dtype=np.uint64)
+    lib.oracle_t_quotient(ctypes.byref(a), _p(out))
+    return out
+
+
+def z_h_inv(k1: np.ndarray, n: int, factor: int) -> np.ndarray:
+    """helpers.rs:242-252: 1 / (k1^n g_m^(n i) - 1), i < factor."""
+    out = np.zeros((factor, 4), dtype=np.uint64)
+    lib.oracle_z_h_inv(_p(np.ascontiguousarray(k1, dtype=np.uint64).reshape(4)), n, factor, _p(out))
     return out
 
 

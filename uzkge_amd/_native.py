@@ -46,6 +46,7 @@ PROTOTYPES = {
     "uzk_poly_eval_batch": (_I, [_P, _U64, ctypes.c_uint32, _P, _P]),
     "uzk_poly_eval_batch_device": (_I, [_P, _U64, ctypes.c_uint32, _P, _P]),
     "uzk_z_poly": (_I, [_P, _P, _P, _P, _P, _P, ctypes.c_uint32, ctypes.c_uint32, _P]),
+    "uzk_t_quotient_device": (_I, [_P, _P, _I]),
     "uzk_synth_points_arith": (_I, [_P, _SZ, _P]),
     "uzk_synth_points_random": (_I, [_P, _SZ, _U64]),
     "uzk_synth_scalars": (_I, [_P, _SZ, _U64]),
@@ -99,3 +100,18 @@ def load() -> ctypes.CDLL:
 
 
 lib = load()
+
+
+TQ_NVEC = 56
+
+
+class QuotientArgs(ctypes.Structure):
+    """uzk_quotient_args (include/uzkge_gpu.h)."""
+    _fields_ = [
+        ("n", ctypes.c_uint32), ("factor", ctypes.c_uint32),
+        ("vec", ctypes.c_void_p * TQ_NVEC),
+        ("alpha", ctypes.c_uint64 * 4), ("beta", ctypes.c_uint64 * 4), ("gamma", ctypes.c_uint64 * 4),
+        ("k", (ctypes.c_uint64 * 4) * 5),
+        ("anemoi_g", ctypes.c_uint64 * 4), ("anemoi_g_inv", ctypes.c_uint64 * 4), ("edwards_a", ctypes.c_uint64 * 4),
+        ("z_h_inv", (ctypes.c_uint64 * 4) * 16),
+    ]

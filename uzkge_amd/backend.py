@@ -193,6 +193,32 @@ def z_poly(w: np.ndarray, perm: np.ndarray, group: np.ndarray, k: np.ndarray, be
     return out
 
 
+def t_quotient_device(n: int, factor: int, vec_ptrs, alpha, beta, gamma, k, anemoi_g, anemoi_g_inv, edwards_a,
+                      z_h_inv, d_out: int, sync: bool = True) -> None:
+    """The quotient evaluations of t_poly (helpers.rs:284-656) on device-resident coset evaluations.
+    vec_ptrs: 56 device pointers in UZK_TQ_* slot order; scalars as [4] uint64 Montgomery limbs,
+    k [5, 4], z_h_inv [factor, 4]; d_out: n * factor elements."""
+    from ._native import QuotientArgs, TQ_NVEC
+    assert len(vec_ptrs) == TQ_NVEC
+    a = QuotientArgs()
+    a.n, a.factor = n, factor
+    for i, p in enumerate(vec_ptrs):
+        a.vec[i] = p
+    def put(dst, src):
+        v = np.ascontiguousarray(src, dtype=np.uint64).reshape(4)
+        for j in range(4):
+            dst[j] = int(v[j])
+    put(a.alpha, alpha); put(a.beta, beta); put(a.gamma, gamma)
+    put(a.anemoi_g, anemoi_g); put(a.anemoi_g_inv, anemoi_g_inv); put(a.edwards_a, edwards_a)
+    kk = np.ascontiguousarray(k, dtype=np.uint64).reshape(5, 4)
+    for j in range(5):
+        put(a.k[j], kk[j])
+    zz = np.ascontiguousarray(z_h_inv, dtype=np.uint64).reshape(-1, 4)
+    for j in range(min(16, zz.shape[0])):
+        put(a.z_h_inv[j], zz[j])
+    check(lib.uzk_t_quotient_device(ctypes.byref(a), ctypes.c_void_p(d_out), int(sync)))
+
+
 def synth_points_arith(d_points: int, n: int, seed_scalar_mont: np.ndarray) -> None:
     s = np.ascontiguousarray(seed_scalar_mont, dtype=np.uint64).reshape(4)
     check(lib.uzk_synth_points_arith(ctypes.c_void_p(d_points), n, _ptr(s)))

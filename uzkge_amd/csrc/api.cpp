@@ -468,6 +468,16 @@ int uzk_poly_eval_batch_device(const void* d_coefs, uint64_t n, uint32_t batch, 
     UZK_TRY(require_ready());
     return poly_eval_batch(ctx(), static_cast<const Fp*>(d_coefs), n, batch, *as_fp(x_mont), reinterpret_cast<Fp*>(out));
 }
+int uzk_t_quotient_device(const uzk_quotient_args* args, void* d_out, int sync) {
+    API_LOCK;
+    if (!args || !d_out) { set_error("uzk_t_quotient_device: null pointer"); return UZK_ERR_PARAMETER; }
+    UZK_TRY(require_ready());
+    static_assert(sizeof(uzk_quotient_args) == 8 + 56 * sizeof(void*) + (3 + 5 + 3 + 16) * 32, "ABI layout");
+    UZK_TRY(t_quotient_run(ctx(), args, static_cast<Fp*>(d_out)));
+    if (sync) UZK_HIP(hipStreamSynchronize(ctx().stream));
+    return UZK_OK;
+}
+
 int uzk_z_poly(const uint64_t* w, const uint32_t* perm, const uint64_t* group, const uint64_t* k, const uint64_t* beta_mont,
                const uint64_t* gamma_mont, uint32_t n, uint32_t n_wires, uint64_t* z_out) {
     API_LOCK;
