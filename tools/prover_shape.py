@@ -38,6 +38,15 @@ def run(reps=5, precompute=False):
         b.ntt_device(big.data_ptr(), outb.data_ptr(), m, inverse=True)
         for cnt, off in ((8, 0), (1, 8), (5, 9), (2, 14)):
             b.msm_batch_device(srs, sc.data_ptr() + off * n * 32, n, cnt)
+    # the fused quotient kernel over the 6n domain (56 input vectors; 46 are per-circuit tables)
+    qv = torch.empty((56 * m, 4), dtype=torch.int64, device="cuda")
+    b.synth_scalars(qv.data_ptr(), 56 * m, 10)
+    sca = torch.empty((32, 4), dtype=torch.int64, device="cuda"); b.synth_scalars(sca.data_ptr(), 32, 11)
+    sh = sca.cpu().numpy().view(np.uint64)
+    ptrs = [qv.data_ptr() + i * m * 32 for i in range(56)]
+    def quotient():
+        b.t_quotient_device(n, 6, ptrs, sh[0], sh[1], sh[2], sh[3:8], sh[8], sh[9], sh[10], sh[11:17], outb.data_ptr(), sync=False)
+    timed("t_quotient_ms", quotient)
     timed("single_calls_ms", single)
     timed("batched_calls_ms", batched)
     timed("msm_16_single_ms", lambda: [b.msm_device(srs, sc.data_ptr() + k * n * 32, n) for k in range(16)])
