@@ -10,8 +10,8 @@
 //     for free from -P, and the sign it leaves on ZZZ' = ZZZ * (-PPP) is tracked in one bit and undone
 //     by flipping the sign of the next point's y.
 // Per addition: 6 products, 2 squarings, 1 dual product (1467 multiply-adds), two carry passes.
-// Doubling / cancellation (P = 0) are detected on PP = P^2 (normalized: 0 or M) and handled by the
-// canonical code of ec.hpp.
+// Doubling / cancellation (P = 0) are detected on PP = P^2 (normalized: 0 or M); such a task is
+// redone from its first point by the canonical code of ec.hpp in a second, normally empty, kernel.
 #pragma once
 #include "ec.hpp"
 #include "fp29.hpp"
@@ -47,32 +47,26 @@ __device__ __forceinline__ void acc29_set(Acc29& a, const Fp& x, const Fp& y, co
     a.inf = false;
     a.zneg = false;
 }
-__device__ __forceinline__ void acc29_madd(Acc29& a, const Affine& p_in, bool negate) {
+// Adds p (negated if `negate`) into a.  Returns false -- leaving `a` unusable -- when the addition
+// degenerates (p = +-acc: P = 0): the caller hands the whole task to the canonical code
+// (msm_accumulate_exc_kernel).  Keeping that branch out of this loop is what keeps the kernel at
+// 110 VGPRs = 4 waves per SIMD (with it inline: 164 and 3).
+__device__ __forceinline__ bool acc29_madd(Acc29& a, const Affine& p_in, bool negate) {
     using F = Fq29;
-    if (affine_is_inf(p_in)) return;
+    if (affine_is_inf(p_in)) return true;
     if (a.inf) {
         acc29_set(a, p_in.x, negate ? Fq::neg(p_in.y) : p_in.y, nullptr, nullptr);
-        return;
+        return true;
     }
     const Fp py_eff = (negate != a.zneg) ? Fq::neg(p_in.y) : p_in.y;          // sign of z3 folded into y
     const L29 nPd = F::add(F::mul(F::from_fp(Fq::neg(p_in.x)), a.zz), a.x);   // -P: limbs < 2^30, value < 8.2M
     const L29 PP = F::sqr(nPd);                                               // normalized, < 1.4M
-    const L29 S2 = F::mul(F::from_fp(py_eff), a.z3);
-    const L29 Rd = F::norm(F::sub_off(S2, a.y, Fq29Cfg::OFF2T1));             // R: normalized, value < 3.1M
     {
         const uint32_t t = PP.l[0];
-        if ((t == 0 || t == Fq29Cfg::M[0]) && F::is_zero_mod_small(PP)) {     // same x: double or cancel
-            if (F::all_zero(F::canon(Rd))) {
-                Affine p = p_in;
-                if (negate) p.y = Fq::neg(p.y);
-                const XYZZ d = xyzz_dbl_affine(p);
-                acc29_set(a, d.x, d.y, &d.zz, &d.zzz);
-            } else {
-                a.inf = true;
-            }
-            return;
-        }
+        if ((t == 0 || t == Fq29Cfg::M[0]) && F::is_zero_mod_small(PP)) return false;   // same x: double or cancel
     }
+    const L29 S2 = F::mul(F::from_fp(py_eff), a.z3);
+    const L29 Rd = F::norm(F::sub_off(S2, a.y, Fq29Cfg::OFF2T1));             // R: normalized, value < 3.1M
     a.zz = F::mul(a.zz, PP);
     const L29 Q = F::mul(a.x, PP);
     const L29 nPPP = F::mul(nPd, PP);                                         // -PPP
@@ -87,6 +81,7 @@ __device__ __forceinline__ void acc29_madd(Acc29& a, const Affine& p_in, bool ne
     const L29 D = F::sub_off(Q, x3, Fq29Cfg::OFF8T1);                         // Q - X3: limbs < 1.5 * 2^30, value < 9.1M
     a.y = F::mul2(Rd, D, a.y, nPPP);                                          // Y3 = R D - Y PPP: normalized, < 1.2M
     a.x = x3;
+    return true;
 }
 // -> canonical XYZZ in 2^256-form
 __device__ __forceinline__ XYZZ acc29_to_xyzz(const Acc29& a) {

@@ -46,7 +46,7 @@ struct MsmWork {
     DevBuf digits, bucket_count, bucket_start, sorted, buckets, partials, win_sums;
     DevBuf ent[2];                           // radix ping-pong ({key, val} entries)
     DevBuf counts[kMaxPasses], segs_start[kMaxPasses], segs_len[kMaxPasses], items[kMaxPasses];
-    DevBuf lvl_cnt[2], lvl_off[2], lvl_part[2], small, task_desc;
+    DevBuf lvl_cnt[2], lvl_off[2], lvl_part[2], small, task_desc, exc;
     XYZZ* h_sums = nullptr;                  // pinned
     size_t h_sums_cap = 0;
     uint32_t* h_max = nullptr;               // pinned: largest bucket population of the current call
@@ -516,13 +516,16 @@ __global__ __launch_bounds__(256, MINW) void msm_accumulate_kernel(const Affine*
     partials[d.task] = acc;
 }
 
-// The same loop on the 29-bit-limb accumulator (ec29.hpp).
-template <int MINW>
-__global__ __launch_bounds__(256, MINW) void msm_accumulate29_kernel(const Affine* __restrict__ points,
-                                                               const uint32_t* __restrict__ sorted,
-                                                               const TaskDesc* __restrict__ desc,
-                                                               const uint32_t* __restrict__ win_base,
-                                                               XYZZ* __restrict__ partials, uint32_t W) {
+// The same loop on the 29-bit-limb accumulator (ec29.hpp).  A task whose additions degenerate
+// (the next point equals +-the running sum) is appended to exc_list and left to
+// msm_accumulate_exc_kernel; for SRS-like inputs that list is empty.
+__global__ __launch_bounds__(256, 4) void msm_accumulate29_kernel(const Affine* __restrict__ points,
+                                                                  const uint32_t* __restrict__ sorted,
+                                                                  const TaskDesc* __restrict__ desc,
+                                                                  const uint32_t* __restrict__ win_base,
+                                                                  XYZZ* __restrict__ partials, uint32_t W,
+                                                                  uint32_t* __restrict__ exc_count,
+                                                                  uint32_t* __restrict__ exc_list) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= win_base[W]) return;
@@ -539,10 +542,31 @@ __global__ __launch_bounds__(256, MINW) void msm_accumulate29_kernel(const Affin
             e = run[k + 1];
             p = load_point(points, e & ~kSignBit);
         }
-        acc29_madd(acc, cur, neg);
+        if (!acc29_madd(acc, cur, neg)) {
+            exc_list[atomicAdd(exc_count, 1u)] = slot;
+            return;
+        }
     }
     partials[d.task] = acc29_to_xyzz(acc);
 #endif
+}
+// Tasks the fast kernel gave up on, redone from scratch with the complete canonical group law.
+__global__ __launch_bounds__(256) void msm_accumulate_exc_kernel(const Affine* __restrict__ points,
+                                                                 const uint32_t* __restrict__ sorted,
+                                                                 const TaskDesc* __restrict__ desc,
+                                                                 XYZZ* __restrict__ partials,
+                                                                 const uint32_t* __restrict__ exc_count,
+                                                                 const uint32_t* __restrict__ exc_list) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *exc_count) return;
+    const TaskDesc d = desc[exc_list[i]];
+    const uint32_t* run = sorted + d.start;
+    XYZZ acc = xyzz_inf();
+    for (uint32_t k = 0; k < d.cnt; ++k) {
+        const uint32_t e = run[k];
+        xyzz_madd(acc, load_point(points, e & ~kSignBit), (e & kSignBit) != 0);
+    }
+    partials[d.task] = acc;
 }
 
 // Folding partial sums.  GS lanes of one wave cooperate on one output: lane `sub` adds the partials
@@ -746,7 +770,7 @@ void msm_free(Ctx& c) {
     for (int q = 0; q < 2; ++q) {
         MsmWork* m = &c.msm[q];
         m->digits.release(); m->bucket_count.release(); m->bucket_start.release(); m->sorted.release();
-        m->buckets.release(); m->partials.release(); m->win_sums.release(); m->small.release(); m->task_desc.release();
+        m->buckets.release(); m->partials.release(); m->win_sums.release(); m->small.release(); m->task_desc.release(); m->exc.release();
         for (int k = 0; k < 2; ++k) {
             m->ent[k].release(); m->lvl_cnt[k].release(); m->lvl_off[k].release(); m->lvl_part[k].release();
         }
@@ -833,7 +857,7 @@ static int msm_group_plan(Ctx& c, MsmGroup& g, size_t n, uint32_t batch, int cb,
     g.TBK = (uint64_t)g.Wd * g.NB;
     if (g.Wd > 1024) { set_error("msm: too many bucket windows (%u): lower the batch", g.Wd); return UZK_ERR_PARAMETER; }
     g.RW = pre ? batch : batch * W;                         // logical windows in the reduction
-    g.seg = std::max<uint32_t>(1, std::min<uint32_t>(kSeg, g.NBL / 256));
+    g.seg = std::max<uint32_t>(1, std::min<uint32_t>(c.tune_reduce_seg > 0 ? (uint32_t)c.tune_reduce_seg : kSeg, g.NBL / 256));
     g.groups = (g.NBL + g.seg * 256 - 1) / (g.seg * 256);
     const uint64_t all_entries = (uint64_t)W_total * n * batch;
     g.L = c.tune_task_len > 0 ? (uint32_t)c.tune_task_len
@@ -888,6 +912,7 @@ static int msm_group_plan(Ctx& c, MsmGroup& g, size_t n, uint32_t batch, int cb,
     UZK_TRY(m.lvl_part[0].reserve((size_t)g.part_cap * sizeof(XYZZ)));
     UZK_TRY(m.small.reserve(16384));
     UZK_TRY(m.task_desc.reserve((size_t)g.bound0 * sizeof(TaskDesc)));
+    UZK_TRY(m.exc.reserve((size_t)g.bound0 * 4));
     if (m.h_sums_cap < g.RW) {
         if (m.h_sums) (void)hipHostFree(m.h_sums);
         UZK_HIP(hipHostMalloc(reinterpret_cast<void**>(&m.h_sums), (size_t)g.RW * sizeof(XYZZ), hipHostMallocDefault));
@@ -1001,12 +1026,15 @@ static int msm_group_phase1(Ctx& c, MsmGroup& g, const Affine* points, const Fp*
         if (c.tune_acc_variant == 1)        // canonical arithmetic throughout (cross-check of the other loops)
             hipLaunchKernelGGL((msm_accumulate_kernel<1, false>), grid, dim3(256), 0, st, points, sorted, desc, g.base_cur,
                                g.part_cur, g.Wd);
-        else if (c.tune_acc_variant == 0)   // default: 29-bit-limb accumulator
-            hipLaunchKernelGGL(msm_accumulate29_kernel<1>, grid, dim3(256), 0, st, points, sorted, desc, g.base_cur,
-                               g.part_cur, g.Wd);
-        else if (c.tune_acc_variant == 3)   // experiment: the same at 4 waves/SIMD (128 VGPRs, spills)
-            hipLaunchKernelGGL(msm_accumulate29_kernel<4>, grid, dim3(256), 0, st, points, sorted, desc, g.base_cur,
-                               g.part_cur, g.Wd);
+        else if (c.tune_acc_variant == 0) { // default: 29-bit-limb accumulator + (normally empty) exception pass
+            uint32_t* exc_count = sm + 3900;
+            uint32_t* exc_list = m.exc.as<uint32_t>();
+            UZK_HIP(hipMemsetAsync(exc_count, 0, 4, st));
+            hipLaunchKernelGGL(msm_accumulate29_kernel, grid, dim3(256), 0, st, points, sorted, desc, g.base_cur, g.part_cur,
+                               g.Wd, exc_count, exc_list);
+            hipLaunchKernelGGL(msm_accumulate_exc_kernel, grid, dim3(256), 0, st, points, sorted, desc, g.part_cur,
+                               exc_count, exc_list);
+        }
         else                                // 2: 8 x 32-bit relaxed Montgomery
             hipLaunchKernelGGL((msm_accumulate_kernel<1, true>), grid, dim3(256), 0, st, points, sorted, desc, g.base_cur,
                                g.part_cur, g.Wd);
