@@ -10,14 +10,14 @@ pts = torch.empty((nmax, 8), dtype=torch.int64, device="cuda"); sc = torch.empty
 torch.cuda.synchronize()
 b.synth_points_random(pts.data_ptr(), nmax, 1); b.synth_scalars(sc.data_ptr(), nmax, 2)
 srs = b.Srs.from_device(pts.data_ptr(), nmax)
-for lg in (10, 12, 14, 16, 18, 20, 22):
+for lg in (10, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22):
     n = 1 << lg
     res = {}
-    for c in range(6, 17):
+    for c in range(6, 19):
         b.set_msm_window_bits(c)
         b.msm_device(srs, sc.data_ptr(), n)
     for rd in range(3):
-        for c in range(6, 17):
+        for c in range(6, 19):
             b.set_msm_window_bits(c); b.sync(); t = time.perf_counter()
             b.msm_device(srs, sc.data_ptr(), n); b.sync()
             res.setdefault(c, []).append((time.perf_counter() - t) * 1e3)

@@ -74,6 +74,7 @@ struct Ctx {
     int tune_no_precompute = 0;
     int tune_fold_group = 0;
     int tune_reduce_seg = 0;  // experiment: buckets per lane in the bucket reduction (0 = default)
+    int tune_fused_hist = 1;  // 1: the digit kernel also produces the first sort pass's histograms (large n)
     int tune_sort_packed = 1; // 1: 4-byte entries between the two sort passes when the fields fit
     int tune_ntt_l29 = 1;     // 1: NTT passes on the 29-bit-limb representation (0: 8x32-bit relaxed Montgomery)
     int tune_overlap = 0;     // 1: run large MSMs as two overlapping pipeline instances (experiment)  // 1: force one lane per bucket in the fold kernels

@@ -82,6 +82,44 @@ __global__ __launch_bounds__(256) void msm_digits_kernel(const Fp* __restrict__ 
     }
 }
 
+// The same, one workgroup per pass-0 sort chunk (grid (nch, batch), scalars [ch*cs, (ch+1)*cs) of a
+// vector): besides the digits it leaves the chunk's pass-0 histograms counts[seg][ch][bins] for all
+// windows, so the sort's first histogram kernel (a 4-byte read of every entry) is not needed.
+// General mode, large n only (a chunk must be big enough to keep 1024 lanes busy).
+__global__ __launch_bounds__(1024) void msm_digits_hist_kernel(const Fp* __restrict__ scalars, uint32_t* __restrict__ digits,
+                                                               uint32_t n, int c, int W, uint32_t shift, uint32_t bins,
+                                                               uint32_t* __restrict__ counts) {
+    extern __shared__ uint32_t hist[];       // [W][bins]
+    const uint32_t ch = blockIdx.x, nch = gridDim.x, b = blockIdx.y;
+    const uint32_t cs = (n + nch - 1) / nch;
+    const uint32_t lo = min(n, ch * cs), hi = min(n, lo + cs);
+    for (uint32_t k = threadIdx.x; k < (uint32_t)W * bins; k += blockDim.x) hist[k] = 0;
+    __syncthreads();
+    const uint32_t mask = (1u << c) - 1, half = 1u << (c - 1), bmask = bins - 1;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        Fp k = Fr::from_mont(scalars[(size_t)b * n + i]);
+        uint32_t carry = 0;
+        uint32_t* dst = digits + (size_t)b * W * n + i;
+        for (int w = 0; w < W; ++w) {
+            uint32_t d = (k.v[0] & mask) + carry;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) k.v[j] = __funnelshift_r(k.v[j], k.v[j + 1], c);
+            k.v[7] >>= c;
+            uint32_t out;
+            if (d > half) { out = ((1u << c) - d) | kSignBit; carry = 1; }
+            else { out = d; carry = 0; }
+            dst[(size_t)w * n] = out;
+            const uint32_t mag = out & ~kSignBit;
+            if (mag) atomicAdd(&hist[(uint32_t)w * bins + (((mag - 1) >> shift) & bmask)], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < (uint32_t)W * bins; k += blockDim.x) {
+        const uint32_t w = k / bins, bin = k % bins;
+        counts[(((size_t)b * W + w) * nch + ch) * bins + bin] = hist[k];
+    }
+}
+
 // ---- 2. counting sort --------------------------------------------------------------------------
 // Bucket key = |digit| - 1 in [0, 2^(c-1)); zero digits are dropped.  A pass sorts every segment on
 // one bit field of the key.  Pass 0 reads the digit array (FROM_DIGITS), later passes read 8-byte
@@ -749,13 +787,14 @@ __global__ __launch_bounds__(64) void msm_precompute_kernel(const Affine* __rest
 // Besides the W*n additions what matters is the population of the TOP window (254 mod c bits): a
 // narrow top window piles n / 2^bits points into each of its few buckets and both the sort and the
 // fold levels pay for it, so only sizes with a wide top window are used
-// (c = 8: 6 bits, c = 16: 14 bits, c = 17: 16 bits and only 15 windows).
+// (c = 8: 6 bits, c = 15: 14 bits, c = 16: 14 bits, c = 17: 16 bits and only 15 windows).
 static int choose_window_bits(size_t n, int forced) {
     if (forced >= 4 && forced <= 22) return forced;
     int lg = 0;
     while ((1ull << (lg + 1)) <= n) ++lg;
-    if (lg <= 18) return 8;
-    if (lg <= 21) return 16;
+    if (lg <= 17) return 8;
+    if (lg == 18) return 15;
+    if (lg == 19) return 16;
     return 17;
 }
 int msm_precompute_window_bits(size_t n, int forced) {
@@ -939,7 +978,14 @@ static int msm_group_phase1(Ctx& c, MsmGroup& g, const Affine* points, const Fp*
     uint32_t* win_tot = sm;
     uint32_t* d_max = sm + 3200;
     UZK_HIP(hipMemsetAsync(d_max, 0, 4, st));
-    {
+    // general mode, whole window range, chunks of >= 32768 scalars: digits and pass-0 histograms in one kernel
+    const bool fused_hist = !g.pre && g.w0 == 0 && g.W == g.W_total && g.sp[0].nch >= 256 && c.tune_fused_hist &&
+                            (size_t)g.W * g.sp[0].bins * 4 <= 64 * 1024;
+    if (fused_hist) {
+        KernelScope ks(c, "msm_digits");
+        hipLaunchKernelGGL(msm_digits_hist_kernel, dim3(g.sp[0].nch, g.batch), dim3(1024), (size_t)g.W * g.sp[0].bins * 4, st,
+                           d_scalars, digits, g.n32, g.cb, (int)g.W, g.sp[0].shift, g.sp[0].bins, m.counts[0].as<uint32_t>());
+    } else {
         KernelScope ks(c, "msm_digits");
         const uint64_t tot = (uint64_t)g.n32 * g.batch;
         hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_scalars, digits, g.n32,
@@ -976,7 +1022,7 @@ static int msm_group_phase1(Ctx& c, MsmGroup& g, const Affine* points, const Fp*
                                m.items[p].as<uint32_t>());
         }
         const dim3 grid = first ? dim3(sp.nch, sp.nseg) : dim3(sp.items_bound);
-        {
+        if (!(first && fused_hist)) {
             KernelScope ks(c, "msm_sort_hist");
             if (first) hipLaunchKernelGGL((msm_radix_hist_kernel<true, false>), grid, dim3(1024), 0, st, a);
             else if (a.pk_in_bits) hipLaunchKernelGGL((msm_radix_hist_kernel<false, true>), grid, dim3(256), 0, st, a);
