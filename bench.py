@@ -28,6 +28,46 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 MAD_PEAK_T = 30.4        # T lane-MAD/s, measured (tools/microbench/int_rates.hip, profiles/r01i_microbench.txt)
 MADS_PER_MIXED_ADD = 1467
+CYC_PER_MAD = 5.17        # issue cycles per wave instruction at 4 waves/SIMD (int_rates.hip)
+CYC_PER_SIMPLE_VALU = 2.72
+OTHER_VALU_PER_MIXED_ADD = 830
+NUM_SIMDS = 1024
+MAD_PEAK_SCLK_MHZ = 2390  # shader clock during that sub-millisecond microbenchmark (rocm-smi: 2388-2393 MHz)
+
+
+def _sample_clocks(work, sync, seconds: float = 2.0):
+    """Median sclk (MHz) and socket power (W) from rocm-smi while `work` repeats; None if unavailable."""
+    import re
+    import shutil
+    import subprocess
+    import threading
+    if not shutil.which("rocm-smi"):
+        return None
+    samples, stop = [], [False]
+
+    def sampler():
+        while not stop[0]:
+            out = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True).stdout
+            m = re.search(r"sclk clock level:\s*\d+:\s*\((\d+)Mhz\)", out)
+            pw = re.search(r"Power \(W\):\s*([0-9.]+)", out)
+            if m:
+                samples.append((int(m.group(1)), float(pw.group(1)) if pw else None))
+
+    th = threading.Thread(target=sampler)
+    t0 = time.perf_counter()
+    work(); sync()
+    th.start()
+    while time.perf_counter() - t0 < seconds:
+        work()
+    sync()
+    stop[0] = True
+    th.join()
+    samples = samples[1:] if len(samples) > 2 else samples      # the first one may predate the ramp
+    if not samples:
+        return None
+    sclk = sorted(x[0] for x in samples)[len(samples) // 2]
+    pws = sorted(x[1] for x in samples if x[1] is not None)
+    return {"sclk_mhz": sclk, "power_w": pws[len(pws) // 2] if pws else None, "samples": len(samples)}
 
 
 def main() -> None:
@@ -206,6 +246,28 @@ def main() -> None:
                          "traffic": ntt_traffic},
             "kernels": {k: {"launches": v[0], "avg_ms": round(v[1] / max(v[0], 1), 4)} for k, v in sorted(p2.items())},
         }
+
+    # ---- sustained shader clock under this workload (rank 0, N = 1 only) --------------------------
+    # The MAD peak above was measured with sub-millisecond kernels at the boost clock; the 18 ms
+    # accumulation kernel runs the package into its power limit and the clock drops.  Sample
+    # rocm-smi while the same MSM repeats for ~2 s and restate the ALU fraction at that clock.
+    if rank == 0 and world == 1 and not args.no_extras:
+        try:
+            clk = _sample_clocks(lambda: b.msm_device(srs, sc.data_ptr(), n), b.sync)
+            if clk:
+                roofline["alu"]["sustained_sclk_mhz"] = clk["sclk_mhz"]
+                roofline["alu"]["sustained_power_w"] = clk["power_w"]
+                roofline["alu"]["boost_sclk_mhz"] = MAD_PEAK_SCLK_MHZ
+                peak_s = MAD_PEAK_T * clk["sclk_mhz"] / MAD_PEAK_SCLK_MHZ
+                roofline["alu"]["peak_at_sustained_clock"] = round(peak_s, 2)
+                roofline["alu"]["frac_at_sustained_clock"] = round(alu_achieved / peak_s, 4) if peak_s else None
+                # whole instruction stream of the loop (ISA count: 1467 MADs + ~830 other VALU instructions per
+                # addition) priced at the measured issue costs, against the SIMD cycles the launch had
+                need = (MADS_PER_MIXED_ADD * CYC_PER_MAD + OTHER_VALU_PER_MIXED_ADD * CYC_PER_SIMPLE_VALU) * (n * nwin / 64.0)
+                have = acc_avg_ms * 1e-3 * NUM_SIMDS * clk["sclk_mhz"] * 1e6
+                roofline["alu"]["valu_issue_frac_at_sustained_clock"] = round(need / have, 4) if have else None
+        except Exception as e:
+            roofline["alu"]["clock_probe_error"] = str(e)
 
     # ---- opt-in window-table mode and the real prover's call mix (rank 0, N = 1 only) ----------
     if rank == 0 and world == 1 and not args.no_extras:
