@@ -134,6 +134,16 @@ int uzk_poly_eval_batch_device(const void* d_coefs, uint64_t n, uint32_t batch, 
 int uzk_z_poly(const uint64_t* w, const uint32_t* perm, const uint64_t* group, const uint64_t* k,
                const uint64_t* beta_mont, const uint64_t* gamma_mont, uint32_t n, uint32_t n_wires, uint64_t* z_out);
 
+/* batch_prove's polynomial work (uzkge/src/poly_commit/pcs.rs:119-135 with div_rem,
+ * field_polynomial.rs:519-550): evals_out[k] = p_k(z);  h = sum_k alpha^k (p_k - p_k(z));
+ * q = h / (X - z)  (the remainder is zero by construction).
+ * d_polys: batch polynomials of n coefficients each (device, zero-padded to the common n);
+ * d_q: n elements on the device, q's n - 1 coefficients followed by a zero; evals_out: batch x 4 words
+ * (host).  n <= 2^20, batch <= 4096.  The caller commits q (or folds it for the Lagrange path,
+ * pcs.rs:137-166) exactly as the reference does. */
+int uzk_open_quotient_device(const void* d_polys, uint64_t n, uint32_t batch, const uint64_t* z_mont,
+                             const uint64_t* alpha_mont, void* d_q, uint64_t* evals_out);
+
 /* The quotient evaluations of t_poly on the coset k[1]*<g_m> (uzkge/src/plonk/helpers.rs:284-656 with
  * the "shuffle" feature; gate function turbo/mod.rs:193-222): for every point of the m = factor*n
  * domain, the 18 terms (gate, permutation, L1, booleanity, Anemoi round, shuffle/ECC selectors) are

@@ -593,3 +593,43 @@ void oracle_z_h_inv(const uint64_t *k1_mont, uint32_t n, uint32_t factor, uint64
         f_mul(F, &mult, &mult, &gn);
     }
 }
+
+/* batch_prove's polynomial work (uzkge/src/poly_commit/pcs.rs:119-135), restated literally:
+ * for each poly: eval at the point (Horner, field_polynomial.rs:198-209), subtract the value, scale by
+ * the running power of alpha, accumulate into h; then div_rem by X - z (field_polynomial.rs:519-550,
+ * general long division specialised to the two-coefficient divisor {-z, 1}).
+ * polys: batch x n coefficients; q_out: n elements (n - 1 quotient coefficients, then zero);
+ * evals_out: batch elements.  Returns 1 if the remainder is zero (PCSProveEvalError otherwise). */
+int oracle_open_quotient(const uint64_t *polys_, uint64_t n, uint32_t batch, const uint64_t *z_, const uint64_t *alpha_,
+                         uint64_t *q_out, uint64_t *evals_out) {
+    const field *F = &FR;
+    const fe *polys = (const fe *)polys_, *z = (const fe *)z_, *alpha = (const fe *)alpha_;
+    fe *q = (fe *)q_out, *ev = (fe *)evals_out;
+    fe *h = (fe *)calloc(n, sizeof(fe));
+    fe mult = F->r;
+    for (uint32_t k = 0; k < batch; ++k) {
+        const fe *p = polys + (size_t)k * n;
+        fe e = {{0, 0, 0, 0}};
+        for (uint64_t j = n; j-- > 0;) { f_mul(F, &e, &e, z); f_add(F, &e, &e, &p[j]); }
+        ev[k] = e;
+        for (uint64_t j = 0; j < n; ++j) {
+            fe c = p[j];
+            if (j == 0) f_sub(F, &c, &c, &e);
+            f_mul(F, &c, &c, &mult);
+            f_add(F, &h[j], &h[j], &c);
+        }
+        f_mul(F, &mult, &mult, alpha);
+    }
+    /* div_rem with divisor coefs d = {-z, 1}: bl_inv = 1; for i = k-l .. 0: qi = rem[i+1]; rem[i] -= qi*(-z); rem[i+1] -= qi */
+    fe nz; f_neg(F, &nz, z);
+    for (uint64_t i = 0; i < n; ++i) q[i] = (fe){{0, 0, 0, 0}};
+    for (uint64_t i = n - 1; i-- > 0;) {
+        fe qi = h[i + 1], a;
+        f_mul(F, &a, &qi, &nz); f_sub(F, &h[i], &h[i], &a);
+        f_sub(F, &h[i + 1], &h[i + 1], &qi);
+        q[i] = qi;
+    }
+    int ok = fe_is_zero(&h[0]);
+    free(h);
+    return ok;
+}

@@ -43,6 +43,8 @@ def _load():
         getattr(lib, name).restype = None
     lib.oracle_z_poly.argtypes = [P, P, P, P, P, P, ctypes.c_uint32, ctypes.c_uint32, P]
     lib.oracle_z_poly.restype = None
+    lib.oracle_open_quotient.argtypes = [P, ctypes.c_uint64, ctypes.c_uint32, P, P, P, P]
+    lib.oracle_open_quotient.restype = ctypes.c_int
     lib.oracle_t_quotient.argtypes = [P, P]
     lib.oracle_t_quotient.restype = None
     lib.oracle_z_h_inv.argtypes = [P, ctypes.c_uint32, ctypes.c_uint32, P]
@@ -180,6 +182,16 @@ def t_quotient(n: int, factor: int, vecs: np.ndarray, alpha, beta, gamma, k, ane
     out = np.zeros((m, 4), dtype=np.uint64)
     lib.oracle_t_quotient(ctypes.byref(a), _p(out))
     return out
+
+
+def open_quotient(polys: np.ndarray, z: np.ndarray, alpha: np.ndarray):
+    """pcs.rs:119-135 on the CPU.  polys [batch, n, 4] -> (q [n, 4] with q[n-1] = 0, evals [batch, 4], remainder_is_zero)."""
+    p = np.ascontiguousarray(polys, dtype=np.uint64)
+    batch, n = p.shape[0], p.shape[1]
+    q = np.zeros((n, 4), dtype=np.uint64); ev = np.zeros((batch, 4), dtype=np.uint64)
+    ok = lib.oracle_open_quotient(_p(p), n, batch, _p(np.ascontiguousarray(z, dtype=np.uint64).reshape(4)),
+                                  _p(np.ascontiguousarray(alpha, dtype=np.uint64).reshape(4)), _p(q), _p(ev))
+    return q, ev, bool(ok)
 
 
 def z_h_inv(k1: np.ndarray, n: int, factor: int) -> np.ndarray:

@@ -193,6 +193,17 @@ def z_poly(w: np.ndarray, perm: np.ndarray, group: np.ndarray, k: np.ndarray, be
     return out
 
 
+def open_quotient_device(d_polys: int, n: int, batch: int, z: np.ndarray, alpha: np.ndarray, d_q: int) -> np.ndarray:
+    """batch_prove's polynomial work (pcs.rs:119-135): writes q = sum_k alpha^k (p_k - p_k(z)) / (X - z) to d_q
+    (n elements, the last one zero) and returns the evaluations p_k(z) [batch, 4]."""
+    ev = np.zeros((batch, 4), dtype=np.uint64)
+    check(lib.uzk_open_quotient_device(ctypes.c_void_p(d_polys), n, batch,
+                                       _ptr(np.ascontiguousarray(z, dtype=np.uint64).reshape(4)),
+                                       _ptr(np.ascontiguousarray(alpha, dtype=np.uint64).reshape(4)),
+                                       ctypes.c_void_p(d_q), _ptr(ev)))
+    return ev
+
+
 def t_quotient_device(n: int, factor: int, vec_ptrs, alpha, beta, gamma, k, anemoi_g, anemoi_g_inv, edwards_a,
                       z_h_inv, d_out: int, sync: bool = True) -> None:
     """The quotient evaluations of t_poly (helpers.rs:284-656) on device-resident coset evaluations.

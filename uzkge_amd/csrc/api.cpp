@@ -468,6 +468,16 @@ int uzk_poly_eval_batch_device(const void* d_coefs, uint64_t n, uint32_t batch, 
     UZK_TRY(require_ready());
     return poly_eval_batch(ctx(), static_cast<const Fp*>(d_coefs), n, batch, *as_fp(x_mont), reinterpret_cast<Fp*>(out));
 }
+int uzk_open_quotient_device(const void* d_polys, uint64_t n, uint32_t batch, const uint64_t* z_mont,
+                             const uint64_t* alpha_mont, void* d_q, uint64_t* evals_out) {
+    API_LOCK;
+    if (!d_polys || !z_mont || !alpha_mont || !d_q || !evals_out) { set_error("uzk_open_quotient_device: null pointer"); return UZK_ERR_PARAMETER; }
+    if (d_q == d_polys) { set_error("uzk_open_quotient_device: output aliases the input"); return UZK_ERR_PARAMETER; }
+    UZK_TRY(require_ready());
+    return open_quotient_run(ctx(), static_cast<const Fp*>(d_polys), n, batch, *as_fp(z_mont), *as_fp(alpha_mont),
+                             static_cast<Fp*>(d_q), reinterpret_cast<Fp*>(evals_out));
+}
+
 int uzk_t_quotient_device(const uzk_quotient_args* args, void* d_out, int sync) {
     API_LOCK;
     if (!args || !d_out) { set_error("uzk_t_quotient_device: null pointer"); return UZK_ERR_PARAMETER; }

@@ -122,6 +122,8 @@ int synth_points_random(Ctx& c, Affine* d_points, size_t n, uint64_t seed);
 int synth_scalars(Ctx& c, Fp* d_scalars, size_t n, uint64_t seed);
 int poly_eval_batch(Ctx& c, const Fp* d_coefs, uint64_t n, uint32_t batch, const Fp& x, Fp* out_host);
 int poly_eval_batch_host(Ctx& c, const Fp* coefs_host, uint64_t n, uint32_t batch, const Fp& x, Fp* out_host);
+int open_quotient_run(Ctx& c, const Fp* d_polys, uint64_t n, uint32_t batch, const Fp& z, const Fp& alpha, Fp* d_q,
+                      Fp* evals_host);
 struct QuotientDev;
 int t_quotient_run(Ctx& c, const void* args_c_abi, Fp* d_out);
 int z_poly_run(Ctx& c, const Fp* w_host, const uint32_t* perm_host, const Fp* group_host, const Fp* k_host,

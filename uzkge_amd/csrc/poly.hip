@@ -11,6 +11,7 @@
 //                    here two product scans and ONE inversion)
 // All values are exact field elements, so any evaluation order gives the reference's bytes.
 #include <cstring>
+#include <vector>
 
 #include "ctx.hpp"
 #include "host_math.hpp"
@@ -402,6 +403,149 @@ int t_quotient_run(Ctx& c, const void* args_c_abi, Fp* d_out) {
     return UZK_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Opening quotient (uzk_open_quotient_device): batch_prove's polynomial work,
+// uzkge/src/poly_commit/pcs.rs:119-135:  h = sum_k alpha^k (p_k - p_k(z)),  q = h / (X - z)
+// (div_rem, field_polynomial.rs:519-550, with the monic divisor X - z: synthetic division
+//  q_{i-1} = h_i + z q_i, a linear recurrence from the top coefficient down).
+// The recurrence is evaluated as a blocked scan: 16 coefficients per lane by Horner, the carries
+// between lanes and between 4096-coefficient blocks by Hillis-Steele steps whose multipliers are
+// the same for every lane (x_t += z^(16 * 2^k) x_(t + 2^k)).  n <= 2^20 coefficients per polynomial.
+// ---------------------------------------------------------------------------------------------
+constexpr int kDivPer = 16;
+constexpr int kDivBlock = 256 * kDivPer;
+
+// h[j] = sum_k apow[k] * polys[k*n + j]  - (j == 0 ? E : 0)
+__global__ __launch_bounds__(256) void open_lincomb_kernel(const Fp* __restrict__ polys, uint64_t n, uint32_t batch,
+                                                           const Fp* __restrict__ apow, Fp E, Fp* __restrict__ h) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    Fp acc = polys[j];                                  // alpha^0 = 1
+    for (uint32_t k = 1; k < batch; ++k) acc = Fr::add(acc, Fr::mul(apow[k], polys[(uint64_t)k * n + j]));
+    if (j == 0) acc = Fr::sub(acc, E);
+    h[j] = acc;
+}
+// s_i = h_i + z s_(i+1) within each 4096-block, carry-in 0; block_first[b] = s at the block's lowest index.
+// zp[k] = z^(16 * 2^k), k < 8.
+struct DivPows { Fp z; Fp zp[8]; };
+__global__ __launch_bounds__(256) void open_div_block_kernel(const Fp* __restrict__ h, uint64_t n, DivPows pw,
+                                                             Fp* __restrict__ s_out, Fp* __restrict__ block_first) {
+    __shared__ Fp sh[256];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t lo = (uint64_t)blockIdx.x * kDivBlock + (uint64_t)tid * kDivPer;
+    Fp v[kDivPer];
+    Fp run = Fr::zero();
+#pragma unroll
+    for (int e = kDivPer - 1; e >= 0; --e) {             // local Horner, top index first
+        const uint64_t i = lo + e;
+        run = Fr::mul(run, pw.z);
+        if (i < n) run = Fr::add(run, h[i]);
+        v[e] = run;
+    }
+    // x_t = local value at the lane's lowest index; carry from the lanes above: x_t += z^16 x_(t+1) ...
+    sh[tid] = run;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t off = 1u << k;
+        Fp t = (tid + off < 256) ? sh[tid + off] : Fr::zero();
+        __syncthreads();
+        if (tid + off < 256) sh[tid] = Fr::add(sh[tid], Fr::mul(pw.zp[k], t));
+        __syncthreads();
+    }
+    // carry into this lane = full value at the lowest index of the lane above
+    Fp carry = (tid + 1 < 256) ? sh[tid + 1] : Fr::zero();
+    Fp zp = pw.z;                                        // z^(hi - i) for i = hi-1 .. lo
+#pragma unroll
+    for (int e = kDivPer - 1; e >= 0; --e) {
+        const uint64_t i = lo + e;
+        if (i < n) s_out[i] = Fr::add(v[e], Fr::mul(zp, carry));
+        zp = Fr::mul(zp, pw.z);
+    }
+    if (tid == 0) block_first[blockIdx.x] = sh[0];
+}
+// carries between blocks (nblocks <= 256): c_b = sum_{b' > b} first[b'] z^(4096 (b' - b - 1)); zb[k] = z^(4096 * 2^k)
+__global__ __launch_bounds__(256) void open_div_carry_kernel(const Fp* __restrict__ block_first, uint32_t nblocks, DivPows pb,
+                                                             Fp* __restrict__ carry) {
+    __shared__ Fp sh[256];
+    const uint32_t tid = threadIdx.x;
+    sh[tid] = tid < nblocks ? block_first[tid] : Fr::zero();
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t off = 1u << k;
+        Fp t = (tid + off < 256) ? sh[tid + off] : Fr::zero();
+        __syncthreads();
+        if (tid + off < 256) sh[tid] = Fr::add(sh[tid], Fr::mul(pb.zp[k], t));
+        __syncthreads();
+    }
+    if (tid < nblocks) carry[tid] = (tid + 1 < 256) ? sh[tid + 1] : Fr::zero();
+}
+// q[i-1] = s_i + z^(block_hi - i) carry[block]  for 1 <= i < n ;  q[n-1] = 0 ; ztab[t] = z^t, t <= 4096
+__global__ __launch_bounds__(256) void open_div_apply_kernel(const Fp* __restrict__ s, const Fp* __restrict__ carry,
+                                                             const Fp* __restrict__ ztab16, Fp z, uint64_t n,
+                                                             Fp* __restrict__ q) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (i == 0) { q[n - 1] = Fr::zero(); return; }
+    const uint64_t blk = i / kDivBlock;
+    const uint32_t dist = (uint32_t)((blk + 1) * kDivBlock - i);      // 1 .. 4096
+    Fp v = s[i];
+    const Fp cb = carry[blk];
+    if (!Fr::is_zero(cb)) {
+        // z^dist = ztab16[dist / 16] * z^(dist % 16)
+        Fp zp = ztab16[dist / kDivPer];
+        for (uint32_t r = 0; r < dist % kDivPer; ++r) zp = Fr::mul(zp, z);
+        v = Fr::add(v, Fr::mul(zp, cb));
+    }
+    q[i - 1] = v;
+}
+
+static DevBuf g_open_tmp;
+
+int open_quotient_run(Ctx& c, const Fp* d_polys, uint64_t n, uint32_t batch, const Fp& z, const Fp& alpha, Fp* d_q,
+                      Fp* evals_host) {
+    if (batch == 0 || n == 0) { set_error("open_quotient: need batch > 0 and n > 0"); return UZK_ERR_PARAMETER; }
+    if (n > (1ull << 20)) { set_error("open_quotient: n = %llu exceeds 2^20 coefficients", (unsigned long long)n); return UZK_ERR_PARAMETER; }
+    if (batch > 4096) { set_error("open_quotient: batch %u exceeds 4096", batch); return UZK_ERR_PARAMETER; }
+    UZK_TRY(poly_eval_batch(c, d_polys, n, batch, z, evals_host));          // p_k(z), also returned to the caller
+    std::vector<Fp> apow(batch);
+    Fp E = Fr::zero(), a = Fr::one();
+    for (uint32_t k = 0; k < batch; ++k) { apow[k] = a; E = Fr::add(E, Fr::mul(a, evals_host[k])); a = Fr::mul(a, alpha); }
+    const uint32_t nblocks = (uint32_t)((n + kDivBlock - 1) / kDivBlock);
+    // layout: apow[batch] | h[n] | s[n] | block_first[256] | carry[256] | ztab16[257]
+    UZK_TRY(g_open_tmp.reserve(((size_t)batch + 2 * n + 256 + 256 + 257) * sizeof(Fp)));
+    Fp* d_apow = g_open_tmp.as<Fp>();
+    Fp* d_h = d_apow + batch;
+    Fp* d_s = d_h + n;
+    Fp* d_first = d_s + n;
+    Fp* d_carry = d_first + 256;
+    Fp* d_ztab = d_carry + 256;
+    std::vector<Fp> ztab(257);
+    DivPows pw, pb;
+    pw.z = z; pb.z = z;
+    {
+        Fp z16 = z;
+        for (int i = 0; i < 4; ++i) z16 = Fr::sqr(z16);                     // z^16
+        Fp cur = Fr::one();
+        for (int t = 0; t <= 256; ++t) { ztab[t] = cur; cur = Fr::mul(cur, z16); }   // z^(16 t)
+        Fp p = z16;
+        for (int k = 0; k < 8; ++k) { pw.zp[k] = p; p = Fr::sqr(p); }       // z^(16 * 2^k)
+        p = ztab[256];                                                      // z^4096
+        for (int k = 0; k < 8; ++k) { pb.zp[k] = p; p = Fr::sqr(p); }
+    }
+    UZK_HIP(hipMemcpyAsync(d_apow, apow.data(), batch * sizeof(Fp), hipMemcpyHostToDevice, c.stream));
+    UZK_HIP(hipMemcpyAsync(d_ztab, ztab.data(), ztab.size() * sizeof(Fp), hipMemcpyHostToDevice, c.stream));
+    KernelScope ks(c, "open_quotient");
+    hipLaunchKernelGGL(open_lincomb_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, d_polys, n, batch, d_apow, E, d_h);
+    hipLaunchKernelGGL(open_div_block_kernel, dim3(nblocks), dim3(256), 0, c.stream, d_h, n, pw, d_s, d_first);
+    hipLaunchKernelGGL(open_div_carry_kernel, dim3(1), dim3(256), 0, c.stream, d_first, nblocks, pb, d_carry);
+    hipLaunchKernelGGL(open_div_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, d_s, d_carry, d_ztab, z, n, d_q);
+    UZK_HIP(hipGetLastError());
+    UZK_HIP(hipStreamSynchronize(c.stream));     // apow / ztab are host vectors of this call
+    return UZK_OK;
+}
+
 int poly_eval_batch_host(Ctx& c, const Fp* coefs_host, uint64_t n, uint32_t batch, const Fp& x, Fp* out_host) {
     if (batch == 0) return UZK_OK;
     const size_t bytes = (size_t)n * batch * sizeof(Fp);
@@ -416,6 +560,7 @@ void poly_free(Ctx&) {
     g_poly_tmp.release();
     g_poly_tmp2.release();
     g_poly_io.release();
+    g_open_tmp.release();
 }
 
 }  // namespace uzk
