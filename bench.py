@@ -47,7 +47,10 @@ def _sample_clocks(work, sync, seconds: float = 2.0):
 
     def sampler():
         while not stop[0]:
-            out = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True).stdout
+            try:
+                out = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=10).stdout
+            except Exception:
+                return
             m = re.search(r"sclk clock level:\s*\d+:\s*\((\d+)Mhz\)", out)
             pw = re.search(r"Power \(W\):\s*([0-9.]+)", out)
             if m:
