@@ -220,15 +220,21 @@ def main() -> None:
         b.ntt_device(x.data_ptr(), y.data_ptr(), nn, sync=True)          # warm-up (builds the plan)
         b.ntt_device(y.data_ptr(), y.data_ptr(), nn, inverse=True, sync=True)
         roundtrip_ok = bool(torch.equal(x, y))
+        # throughput: back-to-back transforms, no per-kernel events (they add bubbles between the three
+        # short passes); then a short profiled loop for the per-kernel durations
+        reps_t = 200
+        b.sync()
+        t1 = time.perf_counter()
+        for _ in range(reps_t):
+            b.ntt_device(x.data_ptr(), y.data_ptr(), nn)
+        b.sync()
+        ntt_s = (time.perf_counter() - t1) / reps_t
         b.profile_reset()
         b.profile_enable(True)
         reps = 20
-        b.sync()
-        t1 = time.perf_counter()
         for _ in range(reps):
             b.ntt_device(x.data_ptr(), y.data_ptr(), nn)
         b.sync()
-        ntt_s = (time.perf_counter() - t1) / reps
         b.profile_enable(False)
         p2 = b.profile_table()
         kern_ms = sum(v[1] for k, v in p2.items() if k.startswith("ntt_pass")) / reps
@@ -242,10 +248,12 @@ def main() -> None:
             "metric": "bn254_fr_ntt_elements_per_sec", "log_n": args.ntt_log_n,
             "value": nn / ntt_s, "ms_per_transform": round(ntt_s * 1e3, 4),
             "kernel_ms_per_transform": round(kern_ms, 4), "roundtrip_bit_exact": roundtrip_ok,
-            "roofline": {"bound": "hbm", "achieved": round(64.0 * nn / (kern_ms * 1e-3) / 1e9, 2) if kern_ms else 0.0,
+            # per transform = three back-to-back pass kernels: priced on the un-instrumented wall time per
+            # transform (the event-bracketed kernel durations below do not overlap their ramps and sum to more)
+            "roofline": {"bound": "hbm", "achieved": round(64.0 * nn / ntt_s / 1e9, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(64.0 * nn / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if kern_ms else 0.0,
-                         "hbm_read_frac": round((32.0 * nn / (HBM_PEAK_GBS * 1e9)) / (kern_ms * 1e-3), 5) if kern_ms else 0.0,
+                         "frac": round(64.0 * nn / ntt_s / 1e9 / HBM_PEAK_GBS, 5),
+                         "hbm_read_frac": round((32.0 * nn / (HBM_PEAK_GBS * 1e9)) / ntt_s, 5),
                          "traffic": ntt_traffic},
             "kernels": {k: {"launches": v[0], "avg_ms": round(v[1] / max(v[0], 1), 4)} for k, v in sorted(p2.items())},
         }

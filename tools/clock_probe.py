@@ -28,3 +28,17 @@ while time.perf_counter() - t0 < 6.0:
 b.sync(); dt = time.perf_counter() - t0
 stop = True; th.join()
 print(f"{reps} MSMs in {dt:.2f} s = {dt/reps*1e3:.2f} ms each")
+# the same for back-to-back 2^22 NTTs
+nn = 1 << 22
+x = sc[:nn]; y = torch.empty((nn, 4), dtype=torch.int64, device="cuda")
+b.ntt_device(x.data_ptr(), y.data_ptr(), nn, sync=True)
+time.sleep(2.0); smi("idle:")
+stop = False
+th = threading.Thread(target=sampler); th.start()
+t0 = time.perf_counter(); reps = 0
+while time.perf_counter() - t0 < 4.0:
+    for _ in range(50): b.ntt_device(x.data_ptr(), y.data_ptr(), nn)
+    b.sync(); reps += 50
+dt = time.perf_counter() - t0
+stop = True; th.join()
+print(f"{reps} NTTs 2^22 in {dt:.2f} s = {dt/reps*1e3:.4f} ms each")
