@@ -2,10 +2,10 @@
 // accumulation loop (same XYZZ formulas as ec.hpp's xyzz_madd, EFD madd-2008-s) arranged so that
 //   * the SRS points are used as they arrive (8 x 32-bit words, 2^256-form, canonical): no converted
 //     copy of the SRS exists.  The accumulator keeps x = X * 2^261, y = Y * 2^261 and
-//     zz = ZZ * 2^266, z3 = +-ZZZ * 2^266; with these exponents every product lands in the right
-//     form by itself (a * b * 2^-261 per product): mul(p.x 2^256, ZZ 2^266) = U2 2^261, ...
-//   * -P = X - U2 is formed as a limb-wise ADDITION (the point's x is negated on load), so its limbs
-//     stay < 2^30 and it can be squared without a carry pass;
+//     nzz = -ZZ * 2^266, z3 = +-ZZZ * 2^266; with these exponents every product lands in the right
+//     form by itself (a * b * 2^-261 per product): mul(p.x 2^256, -ZZ 2^266) = -U2 2^261, ...
+//   * -P = X - U2 is formed as a limb-wise ADDITION (ZZ is kept negated: -ZZ' = -ZZ * PP stays
+//     negative by itself), so its limbs stay < 2^30 and it can be squared without a carry pass;
 //   * Y3 = R (Q - X3) - Y PPP is ONE dual product R*D + Y*(-PPP) with a single reduction; -PPP comes
 //     for free from -P, and the sign it leaves on ZZZ' = ZZZ * (-PPP) is tracked in one bit and undone
 //     by flipping the sign of the next point's y.
@@ -21,29 +21,24 @@ namespace uzk {
 #if defined(__HIP_DEVICE_COMPILE__)
 
 struct Acc29 {
-    L29 x, y, zz, z3;   // x, y: normalized, value < 7M / 2M; zz, z3: products (normalized, < 1.1M)
+    L29 x, y, nzz, z3;  // x, y: normalized, value < 7M / 2M; nzz = -ZZ, z3 = +-ZZZ: products (normalized, < 1.1M)
     bool inf;
     bool zneg;          // true ZZZ = -z3
 };
 
 __device__ __forceinline__ Acc29 acc29_inf() {
     Acc29 a;
-    a.x = Fq29::zero(); a.y = Fq29::zero(); a.zz = Fq29::zero(); a.z3 = Fq29::zero();
+    a.x = Fq29::zero(); a.y = Fq29::zero(); a.nzz = Fq29::zero(); a.z3 = Fq29::zero();
     a.inf = true;
     a.zneg = false;
     return a;
 }
-// canonical XYZZ in 2^256-form -> accumulator forms (ZZ = ZZZ = 1 for an affine point)
-__device__ __forceinline__ void acc29_set(Acc29& a, const Fp& x, const Fp& y, const Fp* zz, const Fp* zzz) {
+// affine point (canonical, 2^256-form; ZZ = ZZZ = 1) -> accumulator forms
+__device__ __forceinline__ void acc29_set(Acc29& a, const Fp& x, const Fp& y) {
     a.x = Fq29::to_261(Fq29::from_fp(x));
     a.y = Fq29::to_261(Fq29::from_fp(y));
-    if (zz == nullptr) {
-        a.zz = Fq29::constant(Fq29Cfg::R266);
-        a.z3 = a.zz;
-    } else {
-        a.zz = Fq29::mul(Fq29::from_fp(*zz), Fq29::constant(Fq29Cfg::R271));
-        a.z3 = Fq29::mul(Fq29::from_fp(*zzz), Fq29::constant(Fq29Cfg::R271));
-    }
+    a.nzz = Fq29::constant(Fq29Cfg::NR266);
+    a.z3 = Fq29::constant(Fq29Cfg::R266);
     a.inf = false;
     a.zneg = false;
 }
@@ -53,13 +48,13 @@ __device__ __forceinline__ void acc29_set(Acc29& a, const Fp& x, const Fp& y, co
 // 110 VGPRs = 4 waves per SIMD (with it inline: 164 and 3).
 __device__ __forceinline__ bool acc29_madd(Acc29& a, const Affine& p_in, bool negate) {
     using F = Fq29;
-    if (affine_is_inf(p_in)) return true;
+    if (Fq::is_zero(p_in.y)) return true;          // infinity is (0, 0); no point of G1 has y = 0 (odd prime order)
     if (a.inf) {
-        acc29_set(a, p_in.x, negate ? Fq::neg(p_in.y) : p_in.y, nullptr, nullptr);
+        acc29_set(a, p_in.x, negate ? Fq::neg(p_in.y) : p_in.y);
         return true;
     }
     const Fp py_eff = (negate != a.zneg) ? Fq::neg(p_in.y) : p_in.y;          // sign of z3 folded into y
-    const L29 nPd = F::add(F::mul(F::from_fp(Fq::neg(p_in.x)), a.zz), a.x);   // -P: limbs < 2^30, value < 8.2M
+    const L29 nPd = F::add(F::mul(F::from_fp(p_in.x), a.nzz), a.x);           // -P = X - U2: limbs < 2^30, value < 8.2M
     const L29 PP = F::sqr(nPd);                                               // normalized, < 1.4M
     {
         const uint32_t t = PP.l[0];
@@ -67,7 +62,7 @@ __device__ __forceinline__ bool acc29_madd(Acc29& a, const Affine& p_in, bool ne
     }
     const L29 S2 = F::mul(F::from_fp(py_eff), a.z3);
     const L29 Rd = F::norm(F::sub_off(S2, a.y, Fq29Cfg::OFF2T1));             // R: normalized, value < 3.1M
-    a.zz = F::mul(a.zz, PP);
+    a.nzz = F::mul(a.nzz, PP);
     const L29 Q = F::mul(a.x, PP);
     const L29 nPPP = F::mul(nPd, PP);                                         // -PPP
     a.z3 = F::mul(a.z3, nPPP);
@@ -90,7 +85,7 @@ __device__ __forceinline__ XYZZ acc29_to_xyzz(const Acc29& a) {
     XYZZ r;
     r.x = F::to_fp(F::canon(F::to_256(a.x)));
     r.y = F::to_fp(F::canon(F::to_256(a.y)));
-    r.zz = F::to_fp(F::canon(F::mul(a.zz, F::constant(Fq29Cfg::R251))));
+    r.zz = Fq::neg(F::to_fp(F::canon(F::mul(a.nzz, F::constant(Fq29Cfg::R251)))));
     r.zzz = F::to_fp(F::canon(F::mul(a.z3, F::constant(Fq29Cfg::R251))));
     if (a.zneg) r.zzz = Fq::neg(r.zzz);
     return r;
