@@ -190,10 +190,11 @@ int uzk_synth_scalars(void* d_scalars, size_t n, uint64_t seed);
 
 /* ---- known-answer entry points (tests): the DEVICE primitives applied element-wise -------- */
 /* field: 0 = Fq, 1 = Fr.  op: 0 mul (assembly FIPS), 1 add, 2 sub, 3 mul (portable CIOS), 4 sqr,
- * 5 neg, 6 from_mont, 7 to_mont, 8 add (portable), 9 sub (portable); 10..20 exercise the 9 x 29-bit
+ * 5 neg, 6 from_mont, 7 to_mont, 8 add (portable), 9 sub (portable); 10..23 exercise the 9 x 29-bit
  * limb representation of the hot loops (fp29.hpp): 10 mul, 11 add, 12/13 sub with 4M / 12M offsets,
  * 14 a lazy-carry chain, 15 form round trip, 16/17 squaring vs product of a lazy operand, 18/19 the
- * multi-subtrahend offsets of ec29.hpp, 20 the dual product.  a, b, out: n elements (host memory). */
+ * multi-subtrahend offsets of ec29.hpp, 20 the dual product, 21..23 the C++ forms of the
+ * assembly products 10 / 16 / 20.  a, b, out: n elements (host memory). */
 int uzk_field_op_device(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 /* op: 0 a + b (mixed add), 1 a + b (full XYZZ add), 2 2a, 3 a - b, 4 2(a + b).  Inputs affine
  * (infinity = zeros), outputs Jacobian. */

@@ -119,6 +119,8 @@ def test_l29_representation_matches_canonical_arithmetic(gpu, field, mod):
     assert np.array_equal(gpu.field_op(field, 19, a, b), gpu.field_op(field, 9, a, b))     # x - y, offset 2M/T1
     dual = gpu.field_op(field, 8, gpu.field_op(field, 3, a, b), gpu.field_op(field, 3, gpu.field_op(field, 8, a, b), a))
     assert np.array_equal(gpu.field_op(field, 20, a, b), dual)                             # x*y + (x+y)*x, one reduction
+    for asm_op, cpp_op in ((10, 21), (16, 22), (20, 23)):                                   # assembly chains == C++ forms
+        assert np.array_equal(gpu.field_op(field, asm_op, a, b), gpu.field_op(field, cpp_op, a, b))
     # lazy chain (op 14): t = 2*mul261(x - y, x + y) - mul261(x - y, y * 2^5), result t * 2^-5, where
     # mul261(u, v) = u*v*2^-261 -- un-normalised operands at the documented limb bounds
     got = gpu.field_op(field, 14, a, b)

@@ -42,6 +42,14 @@ __global__ __launch_bounds__(256) void rate_kernel(uint64_t* out, uint32_t seed)
                 uint32_t x = (uint32_t)acc[k]; x = (uint32_t)(((uint64_t)(x & 0xffffffu) * (b & 0xffffffu)) >> 32) + a; acc[k] = x;
             } else if constexpr (OP == 8) {   // v_mul_f64
                 dacc[k] = dacc[k] * db;
+            } else if constexpr (OP == 10) {  // v_lshrrev_b64 (the column shift of the 29-bit-limb product)
+                asm volatile("v_lshrrev_b64 %0, 3, %0" : "+v"(acc[k]));
+            } else if constexpr (OP == 11) {  // v_lshl_add_u64 (64-bit add joining two column chains)
+                asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(acc[k]) : "v"(acc[(k + 1) % ILP]));
+            } else if constexpr (OP == 12) {  // v_alignbit_b32
+                uint32_t x = (uint32_t)acc[k]; asm volatile("v_alignbit_b32 %0, %0, %1, 29" : "+v"(x) : "v"(b)); acc[k] = x;
+            } else if constexpr (OP == 13) {  // v_and_b32
+                uint32_t x = (uint32_t)acc[k]; asm volatile("v_and_b32 %0, %1, %0" : "+v"(x) : "v"(b)); acc[k] = x;
             } else if constexpr (OP == 9) {   // v_mad_u64_u32 with carry-out consumed
                 unsigned __int128 t = (unsigned __int128)((uint64_t)(uint32_t)acc[k] * b) + acc[k];
                 acc[k] = (uint64_t)t + (uint64_t)(t >> 64);
@@ -89,6 +97,10 @@ int main() {
         run<6>("v_add_u32", w);
         run<5>("v_fma_f64", w);
         run<8>("v_mul_f64", w);
+        run<10>("v_lshrrev_b64", w);
+        run<11>("v_lshl_add_u64", w);
+        run<12>("v_alignbit_b32", w);
+        run<13>("v_and_b32", w);
     }
     return 0;
 }

@@ -3,9 +3,8 @@
 // FIPS product.  Question: is the extra 27 % of MACs cheaper than 128 v_addc + VCC chains?
 #include <hip/hip_runtime.h>
 #include <cstdio>
-#include "fp256.hpp"
+#include "fp29.hpp"
 using namespace uzk;
-struct L29 { uint32_t l[9]; };
 __device__ __constant__ uint32_t kM29[9];
 __device__ __forceinline__ L29 mul29(const L29& a, const L29& b, const uint32_t (&M)[9], uint32_t inv) {
     constexpr uint32_t MASK = (1u << 29) - 1;
@@ -34,6 +33,41 @@ __device__ __forceinline__ L29 mul29(const L29& a, const L29& b, const uint32_t 
     r.l[8] = (uint32_t)acc;
     return r;
 }
+__device__ __forceinline__ void madv(uint64_t& acc, uint32_t a, uint32_t b) {
+    uint64_t c;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mads(uint64_t& acc, uint32_t a, uint32_t b) {
+    uint64_t c;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(c) : "v"(a), "s"(b));
+}
+__device__ __forceinline__ L29 mul29a(const L29& a, const L29& b, const uint32_t (&M)[9], uint32_t inv) {
+    constexpr uint32_t MASK = (1u << 29) - 1;
+    uint64_t acc = 0;
+    uint32_t m[9];
+    L29 r;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+#pragma unroll
+        for (int i = 0; i <= k; ++i) madv(acc, a.l[i], b.l[k - i]);
+#pragma unroll
+        for (int i = 0; i < k; ++i) mads(acc, m[i], M[k - i]);
+        m[k] = ((uint32_t)acc * inv) & MASK;
+        mads(acc, m[k], M[0]);
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; ++k) {
+#pragma unroll
+        for (int i = k - 8; i < 9; ++i) madv(acc, a.l[i], b.l[k - i]);
+#pragma unroll
+        for (int i = k - 8; i < 9; ++i) mads(acc, m[i], M[k - i]);
+        r.l[k - 9] = (uint32_t)acc & MASK;
+        acc >>= 29;
+    }
+    r.l[8] = (uint32_t)acc;
+    return r;
+}
 constexpr int ITERS = 512;
 template <int MODE>
 __global__ __launch_bounds__(256) void k(uint32_t* io, uint32_t inv) {
@@ -43,6 +77,11 @@ __global__ __launch_bounds__(256) void k(uint32_t* io, uint32_t inv) {
         L29 x, y;
         for (int i = 0; i < 9; ++i) { x.l[i] = io[t * 9 + i] & 0x1fffffff; y.l[i] = (io[t * 9 + i] >> 3) & 0x1fffffff; }
         for (int i = 0; i < ITERS; ++i) x = mul29(x, y, M, inv);
+        for (int i = 0; i < 9; ++i) io[t * 9 + i] = x.l[i];
+    } else if constexpr (MODE == 2) {
+        L29 x, y;
+        for (int i = 0; i < 9; ++i) { x.l[i] = io[t * 9 + i] & 0x1fffffff; y.l[i] = (io[t * 9 + i] >> 3) & 0x1fffffff; }
+        for (int i = 0; i < ITERS; ++i) x = Fq29::mul(x, y);
         for (int i = 0; i < 9; ++i) io[t * 9 + i] = x.l[i];
     } else {
         Fp x, y;
@@ -64,4 +103,4 @@ void run(const char* name, int wps) {
     printf("%-10s waves/SIMD=%d  %.3f ms  %.3e op/s  %.0f cycles(@2.4GHz)/wave-op/SIMD\n", name, wps, best, ops / (best * 1e-3), best * 1e-3 * 2.4e9 / ((double)wps * ITERS));
     hipFree(d);
 }
-int main() { for (int w : {2, 4, 8}) { run<0>("l29_cpp", w); run<1>("fips32_rx", w); } }
+int main() { for (int w : {2, 3, 4, 8}) { run<0>("l29_cpp", w); run<2>("l29_asm_columns", w); run<1>("fips32_rx", w); } }

@@ -526,7 +526,7 @@ int uzk_synth_scalars(void* d_scalars, size_t n, uint64_t seed) {
 int uzk_field_op_device(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
     API_LOCK;
     if (n > 0 && (!a || !b || !out)) { set_error("uzk_field_op_device: null pointer"); return UZK_ERR_PARAMETER; }
-    if (field < 0 || field > 1 || op < 0 || op > 20) { set_error("uzk_field_op_device: bad field/op"); return UZK_ERR_PARAMETER; }
+    if (field < 0 || field > 1 || op < 0 || op > 23) { set_error("uzk_field_op_device: bad field/op"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
     return field_op_device(ctx(), field, op, as_fp(a), as_fp(b), reinterpret_cast<Fp*>(out), n);
 }

@@ -49,6 +49,13 @@ __global__ __launch_bounds__(256) void field_op_kernel(int op, const Fp* __restr
             L29 a = F29::from_fp(x), b = F29::from_fp(y);
             r = F29::to_fp(F29::canon(F29::mul2(a, F29::to_261(b), F29::add(a, b), F29::to_261(a))));
         } break;
+        // 21..23: the plain C++ products (ops 10, 16, 20 run the generated assembly chains)
+        case 21: r = F29::to_fp(F29::canon(F29::mul_cpp(F29::from_fp(x), F29::to_261(F29::from_fp(y))))); break;
+        case 22: { L29 t = F29::add(F29::from_fp(x), F29::from_fp(y)); r = F29::to_fp(F29::canon(F29::sqr_cpp(t))); } break;
+        case 23: {
+            L29 a = F29::from_fp(x), b = F29::from_fp(y);
+            r = F29::to_fp(F29::canon(F29::mul2_cpp(a, F29::to_261(b), F29::add(a, b), F29::to_261(a))));
+        } break;
         default: r = F::to_mont(x); break;
     }
     out[i] = r;

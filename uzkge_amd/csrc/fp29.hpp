@@ -34,6 +34,8 @@ struct L29 {
 
 #if defined(__HIPCC__)
 
+#include "mul29_gfx950.inc"   // l29_mul_asm / l29_sqr_asm / l29_mul2_asm: the column MADs as single asm chains
+
 template <class C>
 struct Field29 {
     using Cfg = C;
@@ -97,7 +99,11 @@ struct Field29 {
         return r;
     }
     // Montgomery product, radix 2^261 (contract in the header comment)
-    __device__ __forceinline__ static L29 mul(const L29& a, const L29& b) {
+    __device__ __forceinline__ static L29 mul(const L29& a, const L29& b) { return l29_mul_asm<C>(a, b); }
+    __device__ __forceinline__ static L29 sqr(const L29& a) { return l29_sqr_asm<C>(a); }
+    __device__ __forceinline__ static L29 mul2(const L29& a, const L29& b, const L29& c, const L29& d) { return l29_mul2_asm<C>(a, b, c, d); }
+    // the same three in plain C++ (reference for the generated assembly; KAT ops compare them)
+    __device__ __forceinline__ static L29 mul_cpp(const L29& a, const L29& b) {
         uint64_t acc = 0;
         uint32_t m[9];
         L29 r;
@@ -125,7 +131,7 @@ struct Field29 {
     }
     // a*a*2^-261: the 36 cross products are taken once against the doubled operand (45 + 81 MADs
     // instead of 162).  Same contract as mul(a, a); limbs of a must also be < 2^31.
-    __device__ __forceinline__ static L29 sqr(const L29& a) {
+    __device__ __forceinline__ static L29 sqr_cpp(const L29& a) {
         uint32_t d[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i) d[i] = a.l[i] << 1;
@@ -158,7 +164,7 @@ struct Field29 {
     }
     // (a*b + c*d) * 2^-261 with ONE reduction: max(a_i) max(b_j) + max(c_i) max(d_j) < 2^60.6;
     // result normalized, value < M (1 + (Va Vb + Vc Vd) / 169).
-    __device__ __forceinline__ static L29 mul2(const L29& a, const L29& b, const L29& c, const L29& d) {
+    __device__ __forceinline__ static L29 mul2_cpp(const L29& a, const L29& b, const L29& c, const L29& d) {
         uint64_t acc = 0;
         uint32_t m[9];
         L29 r;
