@@ -29,8 +29,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured
 MAD_PEAK_T = 30.4        # T lane-MAD/s, measured (tools/microbench/int_rates.hip, profiles/r01i_microbench.txt)
 MADS_PER_MIXED_ADD = 1467
 CYC_PER_MAD = 5.17        # issue cycles per wave instruction at 4 waves/SIMD (int_rates.hip)
-CYC_PER_SIMPLE_VALU = 2.72
-OTHER_VALU_PER_MIXED_ADD = 830
+CYC_PER_OTHER_VALU = 3.4   # mean over the loop's other VALU instructions (v_and 2.7, v_lshrrev_b64 4.25, v_mul_lo 4.46, ...)
+OTHER_VALU_PER_MIXED_ADD = 586   # tools/isa_hist.py on the accumulation loop; plus 176 s_nop after asm statements
 NUM_SIMDS = 1024
 MAD_PEAK_SCLK_MHZ = 2390  # shader clock during that sub-millisecond microbenchmark (rocm-smi: 2388-2393 MHz)
 
@@ -272,9 +272,9 @@ def main() -> None:
                 peak_s = MAD_PEAK_T * clk["sclk_mhz"] / MAD_PEAK_SCLK_MHZ
                 roofline["alu"]["peak_at_sustained_clock"] = round(peak_s, 2)
                 roofline["alu"]["frac_at_sustained_clock"] = round(alu_achieved / peak_s, 4) if peak_s else None
-                # whole instruction stream of the loop (ISA count: 1467 MADs + ~830 other VALU instructions per
-                # addition) priced at the measured issue costs, against the SIMD cycles the launch had
-                need = (MADS_PER_MIXED_ADD * CYC_PER_MAD + OTHER_VALU_PER_MIXED_ADD * CYC_PER_SIMPLE_VALU) * (n * nwin / 64.0)
+                # whole instruction stream of the loop (ISA count: 1467 MADs + 586 other VALU instructions + 176
+                # s_nop per addition) priced at the measured issue costs, against the SIMD cycles the launch had
+                need = (MADS_PER_MIXED_ADD * CYC_PER_MAD + OTHER_VALU_PER_MIXED_ADD * CYC_PER_OTHER_VALU + 176) * (n * nwin / 64.0)
                 have = acc_avg_ms * 1e-3 * NUM_SIMDS * clk["sclk_mhz"] * 1e6
                 roofline["alu"]["valu_issue_frac_at_sustained_clock"] = round(need / have, 4) if have else None
         except Exception as e:
