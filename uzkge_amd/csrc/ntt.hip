@@ -39,6 +39,7 @@ struct NttPlan {
     int bits[4] = {0, 0, 0, 0};
     Fp* d_tw256 = nullptr;        // omega_256^e (direction-specific), e < 256   (n >= 4096)
     Fp* d_tw_pass[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint64_t tw_count[4] = {0, 0, 0, 0};   // entries per pass table
     Fp* d_small_tw = nullptr;     // omega_n^e, e < n/2                          (n <= 2048)
     Fp scale;                     // 1/n (Montgomery) when scaled, else one
     // three-level power tables of omega (device): A[j]=w^j, B[j]=w^(1024 j), C[j]=w^(2^20 j)
@@ -151,6 +152,7 @@ struct PassArgs {
     int log_S;             // log2 of the product of earlier radices
     const Fp* tw256;       // omega_256^e, direction-specific
     const Fp* twp;         // pass table [m'][sigma] (nullptr on the last pass)
+    uint64_t twp_count;    // entries of twp (29-bit-limb kernels: tables are limb planes, see tw29_load)
 };
 
 constexpr int kPlane = 2048 + 64;   // uint4 slots per LDS plane (transposed layout needs T*(R+1))
@@ -283,6 +285,33 @@ __global__ __launch_bounds__(512) void ntt_pass_kernel(const Fp* __restrict__ in
 // ---------------------------------------------------------------------------------------------
 using F9 = Fr29;
 
+// Twiddle tables of the 29-bit-limb kernels are stored already repacked, as three planes over the
+// table's `count` entries: limbs 0-3 (uint4), limbs 4-7 (uint4), limb 8 (u32) -- 36 bytes per entry
+// instead of 32, and no shifting/masking per twiddle in the butterflies.
+__device__ __forceinline__ L29 tw29_load(const Fp* base, uint64_t count, uint64_t idx) {
+    const uint4* p0 = reinterpret_cast<const uint4*>(base);
+    const uint4* p1 = p0 + count;
+    const uint32_t* p2 = reinterpret_cast<const uint32_t*>(p1 + count);
+    const uint4 a = p0[idx], b = p1[idx];
+    L29 v;
+    v.l[0] = a.x; v.l[1] = a.y; v.l[2] = a.z; v.l[3] = a.w;
+    v.l[4] = b.x; v.l[5] = b.y; v.l[6] = b.z; v.l[7] = b.w;
+    v.l[8] = p2[idx];
+    return v;
+}
+__global__ __launch_bounds__(256) void ntt_repack_tw_kernel(const Fp* __restrict__ src, Fp* __restrict__ dst_base,
+                                                            uint64_t count) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const L29 v = F9::from_fp(src[i]);
+    uint4* p0 = reinterpret_cast<uint4*>(dst_base);
+    uint4* p1 = p0 + count;
+    uint32_t* p2 = reinterpret_cast<uint32_t*>(p1 + count);
+    p0[i] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    p1[i] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+    p2[i] = v.l[8];
+}
+
 __device__ __forceinline__ void bf2_l(L29& a, L29& b) {
     L29 s = F9::add(a, b);
     b = F9::sub<4>(a, b);
@@ -326,7 +355,7 @@ __global__ __launch_bounds__(512, 4) void ntt_pass29_kernel(const Fp* __restrict
     in += (uint64_t)blockIdx.y * a.batch_stride;
     out += (uint64_t)blockIdx.y * a.batch_stride;
 
-    const L29 w4 = F9::from_fp(a.tw256[64]);
+    const L29 w4 = tw29_load(a.tw256, 256, 64);
     L29 x[4];
     int rows[4];
 
@@ -337,7 +366,7 @@ __global__ __launch_bounds__(512, 4) void ntt_pass29_kernel(const Fp* __restrict
     if constexpr (N4 > 1 || TAIL2) {
         x[0] = F9::reduce(x[0]);
 #pragma unroll
-        for (int s = 1; s < 4; ++s) x[s] = F9::mul(x[s], F9::from_fp(a.tw256[(q * s) << SH]));
+        for (int s = 1; s < 4; ++s) x[s] = F9::mul(x[s], tw29_load(a.tw256, 256, (q * s) << SH));
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s) rows[s] = q * 4 + s;
@@ -358,7 +387,7 @@ __global__ __launch_bounds__(512, 4) void ntt_pass29_kernel(const Fp* __restrict
         if (more) {
             x[0] = F9::reduce(x[0]);
 #pragma unroll
-            for (int s = 1; s < 4; ++s) x[s] = F9::mul(x[s], F9::from_fp(a.tw256[((S * mp * s)) << SH]));
+            for (int s = 1; s < 4; ++s) x[s] = F9::mul(x[s], tw29_load(a.tw256, 256, (S * mp * s) << SH));
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) rows[s] = (mp << (2 * k + 2)) + s * S + sl;
@@ -392,7 +421,7 @@ __global__ __launch_bounds__(512, 4) void ntt_pass29_kernel(const Fp* __restrict
             const int e = tid + j * 512;
             const int ce = e / R, re = e % R;
             L29 v = lds_get29(lds, ce * (R + 1) + re);
-            v = F9::mul(v, F9::from_fp(a.twp[base + e]));      // normalized, < 2M: fits 8 words
+            v = F9::mul(v, tw29_load(a.twp, a.twp_count, base + e));      // normalized, < 2M: fits 8 words
             out[base + e] = F9::to_fp(v);
         }
     } else {
@@ -401,7 +430,7 @@ __global__ __launch_bounds__(512, 4) void ntt_pass29_kernel(const Fp* __restrict
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             L29 v = x[j];
-            if (a.twp != nullptr) v = F9::mul(v, F9::from_fp(a.twp[(mp << B) + rows[j]]));
+            if (a.twp != nullptr) v = F9::mul(v, tw29_load(a.twp, a.twp_count, (mp << B) + rows[j]));
             else v = F9::canon(v);                 // last pass: back to [0, M)
             out[base + ((uint64_t)rows[j] << a.log_S)] = F9::to_fp(v);
         }
@@ -514,6 +543,19 @@ static int get_plan(Ctx& c, uint64_t n, bool inverse, bool scaled, NttPlan** out
             for (auto& t : t256)
                 for (int d = 0; d < 5; ++d) t = Fr::add(t, t);     // 2^261-form
         UZK_TRY(upload(&p->d_tw256, t256, c.stream));
+        // 29-bit-limb kernels read their twiddles as limb planes (36 B per entry): repack a table in place of
+        // the 8 x 32-bit one
+        auto to_planes = [&](Fp** tab, uint64_t count) -> int {
+            Fp* planes = nullptr;
+            UZK_HIP(hipMalloc(reinterpret_cast<void**>(&planes), count * 36 + 64));
+            hipLaunchKernelGGL(ntt_repack_tw_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c.stream, *tab,
+                               planes, count);
+            UZK_HIP(hipStreamSynchronize(c.stream));
+            UZK_HIP(hipFree(*tab));
+            *tab = planes;
+            return UZK_OK;
+        };
+        if (l29) UZK_TRY(to_planes(&p->d_tw256, 256));
         int log_S = 0;
         for (int j = 0; j + 1 < p->npass; ++j) {
             const uint64_t count = n >> log_S;   // (N / (S R)) * R
@@ -525,6 +567,8 @@ static int get_plan(Ctx& c, uint64_t n, bool inverse, bool scaled, NttPlan** out
                                    c.stream, p->d_tw_pass[j], count, log_S, p->bits[j], p->d_pow, p->scale,
                                    fold ? 1 : 0, l29 ? 5 : 0);
             }
+            p->tw_count[j] = count;
+            if (l29) UZK_TRY(to_planes(&p->d_tw_pass[j], count));
             log_S += p->bits[j];
         }
         UZK_HIP(hipStreamSynchronize(c.stream));
@@ -601,6 +645,7 @@ static int ntt_pow2(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse,
         a.log_S = log_S;
         a.tw256 = p->d_tw256;
         a.twp = p->d_tw_pass[j];
+        a.twp_count = p->tw_count[j];
         const bool first = (j == 0);
         switch (p->bits[j]) {
             case 5: launch_pass<5>(c, p->l29, first, src, dst, a, n, batch); break;
