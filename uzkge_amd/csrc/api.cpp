@@ -618,6 +618,7 @@ int uzk_tune(const char* key, int value) {
     else if (!std::strcmp(key, "msm_sort_packed")) c.tune_sort_packed = value;
     else if (!std::strcmp(key, "msm_fused_hist")) c.tune_fused_hist = value;
     else if (!std::strcmp(key, "msm_reduce_seg")) c.tune_reduce_seg = value;
+    else if (!std::strcmp(key, "msm_scan_reduce")) c.tune_scan_reduce = value;
     else { set_error("uzk_tune: unknown key %s", key); return UZK_ERR_PARAMETER; }
     return UZK_OK;
 }

@@ -731,6 +731,89 @@ __global__ __launch_bounds__(256) void msm_fold_partials_kernel(const XYZZ* __re
     if (tid == 0) out[w] = sh[0];
 }
 
+// The same reduction without the per-lane double-and-add.  With t the lane's index in its workgroup and
+// G the workgroup's index in its window, a bucket's weight is  b = (G*256 + t)*seg + j,  j = 1..seg, so
+//   sum b*B_b = sum_t acc_t  +  seg * sum_t t*run_t  +  256*seg * G * sum_t run_t
+// and  sum_t t*run_t = sum_{t >= 1} Suffix_t  (Suffix_t = run_t + run_(t+1) + ...): an 8-step suffix scan
+// of the run_t through LDS, log2(seg) doublings per lane and one tree sum give the first two terms
+// (P1); the third is left to the fold kernel, which applies the same identity to the workgroup totals
+// R_G.  Every lane does the same work (no data-dependent double-and-add), so short segments -- many
+// lanes, short dependent chains -- become affordable.  grid (groups, windows).
+__device__ __forceinline__ void wg_suffix_scan(XYZZ* sh, uint32_t tid, XYZZ& mine) {
+    sh[tid] = mine;
+    __syncthreads();
+    for (uint32_t off = 1; off < 256; off <<= 1) {
+        XYZZ v = (tid + off < 256) ? sh[tid + off] : xyzz_inf();
+        __syncthreads();
+        xyzz_add(mine, v);
+        sh[tid] = mine;
+        __syncthreads();
+    }
+}
+__device__ __forceinline__ void wg_tree_sum(XYZZ* sh, uint32_t tid, const XYZZ& mine) {
+    sh[tid] = mine;
+    __syncthreads();
+    for (uint32_t s = 128; s > 0; s >>= 1) {
+        if (tid < s) {
+            XYZZ a = sh[tid];
+            XYZZ b2 = sh[tid + s];
+            xyzz_add(a, b2);
+            sh[tid] = a;
+        }
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void msm_reduce_scan_kernel(const XYZZ* __restrict__ buckets, XYZZ* __restrict__ part_p1,
+                                                              XYZZ* __restrict__ part_r, uint32_t nbk,
+                                                              uint32_t groups_per_window, uint32_t seg, uint32_t log_seg) {
+    __shared__ XYZZ sh[256];
+    const uint32_t w = blockIdx.y, tid = threadIdx.x;
+    const uint32_t g = blockIdx.x * blockDim.x + tid;
+    const XYZZ* bw = buckets + (size_t)w * nbk;
+    XYZZ run = xyzz_inf(), acc = xyzz_inf();
+    const uint64_t lo64 = (uint64_t)g * seg;   // bucket ids lo+1 .. lo+seg  (array index = id - 1)
+    if (lo64 < nbk) {
+        const uint32_t lo = (uint32_t)lo64;
+        const uint32_t hi = min(nbk, lo + seg);
+        for (uint32_t idx = hi; idx-- > lo;) {
+            XYZZ bk = bw[idx];
+            xyzz_add(run, bk);
+            xyzz_add(acc, run);
+        }
+    }
+    XYZZ suf = run;
+    wg_suffix_scan(sh, tid, suf);                 // sh[t] = Suffix_t (inclusive)
+    XYZZ above = (tid + 1 < 256) ? sh[tid + 1] : xyzz_inf();
+    const XYZZ total = sh[0];
+    __syncthreads();
+    for (uint32_t d = 0; d < log_seg; ++d) above = xyzz_dbl(above);
+    xyzz_add(acc, above);                         // acc_t + seg * Suffix_(t+1)
+    wg_tree_sum(sh, tid, acc);
+    if (tid == 0) {
+        part_p1[(size_t)w * groups_per_window + blockIdx.x] = sh[0];
+        part_r[(size_t)w * groups_per_window + blockIdx.x] = total;
+    }
+}
+// out[w] = sum_G P1_G + 256*seg * sum_{G >= 1} SuffixR_G   (one workgroup per window, groups <= 256)
+__global__ __launch_bounds__(256) void msm_fold_scan_kernel(const XYZZ* __restrict__ part_p1, const XYZZ* __restrict__ part_r,
+                                                            XYZZ* __restrict__ out, uint32_t groups, uint32_t log_shift) {
+    __shared__ XYZZ sh[256];
+    const uint32_t w = blockIdx.x, tid = threadIdx.x;
+    XYZZ r = tid < groups ? part_r[(size_t)w * groups + tid] : xyzz_inf();
+    XYZZ p1 = tid < groups ? part_p1[(size_t)w * groups + tid] : xyzz_inf();
+    if (groups > 1) {
+        wg_suffix_scan(sh, tid, r);
+        XYZZ above = (tid + 1 < 256) ? sh[tid + 1] : xyzz_inf();
+        __syncthreads();
+        if (!xyzz_is_inf(above)) {
+            for (uint32_t d = 0; d < log_shift; ++d) above = xyzz_dbl(above);
+            xyzz_add(p1, above);
+        }
+    }
+    wg_tree_sum(sh, tid, p1);
+    if (tid == 0) out[w] = sh[0];
+}
+
 // ---- precomputation: T[j][i] = 2^c * T[j-1][i], affine --------------------------------------------
 __device__ inline Fp fq_inv_pow(const Fp& a) {   // a^(p-2)
     const uint32_t e[8] = {0xd87cfd45u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u,
@@ -874,6 +957,7 @@ struct MsmGroup {
     uint64_t per_poly = 0, entries = 0, TBK = 0, bound0 = 0, part_cap = 0;
     uint32_t kb = 0, NBL = 0, S0 = 0, seg_n = 0, NB = 0, Wd = 0, RW = 0, seg = 0, groups = 0, L = 0;
     int P = 0;
+    bool scan_reduce = false;
     uint32_t pk_bits = 0;   // > 0: 4-byte packed entries between the two sort passes (index bits)
     SortPass sp[kMaxPasses];
     // state carried from phase 1 to phase 2
@@ -896,11 +980,26 @@ static int msm_group_plan(Ctx& c, MsmGroup& g, size_t n, uint32_t batch, int cb,
     g.TBK = (uint64_t)g.Wd * g.NB;
     if (g.Wd > 1024) { set_error("msm: too many bucket windows (%u): lower the batch", g.Wd); return UZK_ERR_PARAMETER; }
     g.RW = pre ? batch : batch * W;                         // logical windows in the reduction
-    g.seg = std::max<uint32_t>(1, std::min<uint32_t>(c.tune_reduce_seg > 0 ? (uint32_t)c.tune_reduce_seg : kSeg, g.NBL / 256));
+    // scan-based reduction: segments of 8 buckets per lane (power of two), at most 256 workgroups per window
+    // (measured: the scan form wins for windows of <= 2^14 buckets, the double-and-add form above that)
+    g.scan_reduce = c.tune_scan_reduce == 2 || (c.tune_scan_reduce == 1 && g.NBL <= (1u << 14));
+    if (g.scan_reduce) {
+        uint32_t sg = c.tune_reduce_seg > 0 ? (uint32_t)c.tune_reduce_seg : 8u;
+        while (sg & (sg - 1)) sg &= sg - 1;                                  // power of two
+        sg = std::max<uint32_t>(1, std::min<uint32_t>(sg, g.NBL / 256));
+        while ((g.NBL + sg * 256 - 1) / (sg * 256) > 256) sg <<= 1;
+        g.seg = sg;
+    } else {
+        g.seg = std::max<uint32_t>(1, std::min<uint32_t>(c.tune_reduce_seg > 0 ? (uint32_t)c.tune_reduce_seg : kSeg, g.NBL / 256));
+    }
     g.groups = (g.NBL + g.seg * 256 - 1) / (g.seg * 256);
     const uint64_t all_entries = (uint64_t)W_total * n * batch;
+    // Task length: long enough that a typical bucket (4x the mean population) is ONE task -- its partial
+    // sum then needs no folding -- but short enough that there are >= ~200k tasks to fill the chip
+    // (measured, tools/ab_msm.py msm_task_len sweeps at 2^14 .. 2^24).  Larger buckets are split evenly.
+    const uint64_t mean_pop = (pre ? (uint64_t)W_total * n : (uint64_t)n) >> g.kb;
     g.L = c.tune_task_len > 0 ? (uint32_t)c.tune_task_len
-                              : (uint32_t)std::max<uint64_t>(16, std::min<uint64_t>(96, all_entries >> 21));
+                              : (uint32_t)std::max<uint64_t>(16, std::min<uint64_t>(256, std::min<uint64_t>(4 * mean_pop, all_entries / 200000)));
     g.bound0 = g.entries / g.L + g.TBK;                     // upper bound on level-0 tasks
     g.part_cap = g.bound0 + 2 * g.TBK;                      // every later level fits too
     g.P = g.kb <= 9 ? 1 : (g.kb <= 18 ? 2 : 3);             // radix passes of <= 9 bits, high bits first
@@ -933,7 +1032,7 @@ static int msm_group_plan(Ctx& c, MsmGroup& g, size_t n, uint32_t batch, int cb,
     UZK_TRY(m.bucket_count.reserve((size_t)g.TBK * 4));
     UZK_TRY(m.bucket_start.reserve((size_t)g.TBK * 4));
     UZK_TRY(m.buckets.reserve((size_t)g.TBK * sizeof(XYZZ)));
-    UZK_TRY(m.partials.reserve((size_t)g.RW * g.groups * sizeof(XYZZ)));
+    UZK_TRY(m.partials.reserve((size_t)2 * g.RW * g.groups * sizeof(XYZZ)));
     UZK_TRY(m.win_sums.reserve((size_t)g.RW * sizeof(XYZZ)));
     for (int p = 0; p < g.P; ++p) {
         UZK_TRY(m.counts[p].reserve((size_t)(p == 0 ? g.sp[p].nseg * g.sp[p].nch : g.sp[p].items_bound) * g.sp[p].bins * 4));
@@ -1156,8 +1255,18 @@ static int msm_group_phase2(Ctx& c, MsmGroup& g) {
     }
     {
         KernelScope ks(c, "msm_reduce");
-        hipLaunchKernelGGL(msm_reduce_kernel, dim3(g.groups, g.RW), dim3(256), 0, st, buckets, partials, g.NBL, g.groups, g.seg);
-        hipLaunchKernelGGL(msm_fold_partials_kernel, dim3(g.RW), dim3(256), 0, st, partials, win_sums, g.groups);
+        if (g.scan_reduce) {
+            XYZZ* part_r = partials + (size_t)g.RW * g.groups;
+            uint32_t log_seg = 0;
+            while ((1u << log_seg) < g.seg) ++log_seg;
+            hipLaunchKernelGGL(msm_reduce_scan_kernel, dim3(g.groups, g.RW), dim3(256), 0, st, buckets, partials, part_r, g.NBL,
+                               g.groups, g.seg, log_seg);
+            hipLaunchKernelGGL(msm_fold_scan_kernel, dim3(g.RW), dim3(256), 0, st, partials, part_r, win_sums, g.groups,
+                               8 + log_seg);
+        } else {
+            hipLaunchKernelGGL(msm_reduce_kernel, dim3(g.groups, g.RW), dim3(256), 0, st, buckets, partials, g.NBL, g.groups, g.seg);
+            hipLaunchKernelGGL(msm_fold_partials_kernel, dim3(g.RW), dim3(256), 0, st, partials, win_sums, g.groups);
+        }
     }
     UZK_HIP(hipGetLastError());
     UZK_HIP(hipMemcpyAsync(m.h_sums, win_sums, (size_t)g.RW * sizeof(XYZZ), hipMemcpyDeviceToHost, st));
