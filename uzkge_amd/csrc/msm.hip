@@ -1135,6 +1135,8 @@ static int msm_group_phase1(Ctx& c, MsmGroup& g, const Affine* points, const Fp*
         {
             KernelScope ks(c, "msm_sort_scatter");
             if (first && last) hipLaunchKernelGGL((msm_radix_scatter_kernel<1024, 8, true, true, false>), grid, dim3(1024), 0, st, a);
+            else if (first && g.entries >= (1ull << 26))   // large sorts: 512 lanes, 4096-entry tiles (measured)
+                hipLaunchKernelGGL((msm_radix_scatter_kernel<512, 8, true, false, false>), grid, dim3(512), 0, st, a);
             else if (first) hipLaunchKernelGGL((msm_radix_scatter_kernel<1024, 8, true, false, false>), grid, dim3(1024), 0, st, a);
             else if (last && a.pk_in_bits) hipLaunchKernelGGL((msm_radix_scatter_kernel<512, 8, false, true, true>), grid, dim3(512), 0, st, a);
             else if (last) hipLaunchKernelGGL((msm_radix_scatter_kernel<256, 16, false, true, false>), grid, dim3(256), 0, st, a);
