@@ -5,22 +5,27 @@
 // Why (measured, tools/microbench/l29_rate.hip): with 29-bit limbs a column of the product scanning
 // Montgomery product -- up to 9 a_i*b_j plus 9 m_i*M_j partial products -- fits a 64-bit accumulator,
 // so every partial product is ONE v_mad_u64_u32 with no carry bookkeeping: 162 MADs instead of
-// 128 MADs + 128 v_addc through VCC.  981 vs 1173 cycles per wave-product at 4 waves/SIMD (-16 %),
-// and additions/subtractions become 9 independent 32-bit adds with no reduction at all.
+// 128 MADs + 128 v_addc through VCC.  900 vs 1131 cycles per wave-product at 4 waves/SIMD (-20 %; the
+// three products are generated assembly column chains, mul29_gfx950.inc, with the C++ forms kept as
+// *_cpp), and additions/subtractions become 9 independent 32-bit adds with no reduction at all.
 //
 // Contract of the operations (B = 2^29):
 //   mul(a, b)   limbs: max(a_i) * max(b_j) < 2^60.6 (e.g. both < 2^30.3, or < B and < 2^31.6);
 //               values: a < Va*M, b < Vb*M  ->  result limbs < B (normalized), value < M*(1 + Va*Vb/169).
 //               Montgomery radix is 2^261: mul(a, b) = a*b*2^-261 mod M (up to the lazy multiple of M).
 //   add(a, b)   limb-wise, no carry, no reduction (caller keeps limbs < 2^32 and values in range).
-//   sub(a, b, OFF)  a - b + OFF limb-wise, OFF = k*M with every low limb >= 2^30 - 2, so it never
-//               underflows when b's limbs are < 2^30 - 1 (a normalized value or a sum of two).
+//   sub(a, b, OFF)  a - b + OFF limb-wise, OFF = k*M with limbs pre-borrowed so that no limb underflows:
+//               OFF4 / OFF12 (low limbs >= 2^30 - 2: b normalized or a sum of two), OFF4T3 (three
+//               normalized subtrahends), OFF2T1 / OFF8T1 (one).  The caller keeps b's VALUE <= k*M.
+//   sqr(a), mul2(a, b, c, d)  a*a and a*b + c*d with one reduction; same contracts (sum of the limb
+//               bound products < 2^60.6).
 //   norm(a)     carry propagation: limbs < B again, value unchanged.
 //   reduce(a)   value < 16 M  ->  normalized, value < 2M.
 //   canon(a)    value < 16 M  ->  the unique representative in [0, M), normalized.
 // The external 4 x u64 Montgomery form has radix 2^256.  NTT data stays in 2^256-form (it is only ever
-// multiplied by twiddles, which the plan stores in 2^261-form); MSM bases are stored in 2^261-form
-// at registration and the bucket sums are mapped back with one product by 2^256.
+// multiplied by twiddles, which the plan stores in 2^261-form); MSM bases are used as they arrive
+// (2^256-form): the accumulator keeps X, Y in 2^261-form and ZZ, ZZZ in 2^266-form so that every
+// product lands in the right form (ec29.hpp), and the bucket sums are mapped back once per task.
 #pragma once
 #include "fp256.hpp"
 
