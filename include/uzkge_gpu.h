@@ -134,6 +134,11 @@ int uzk_poly_eval_batch_device(const void* d_coefs, uint64_t n, uint32_t batch, 
 int uzk_z_poly(const uint64_t* w, const uint32_t* perm, const uint64_t* group, const uint64_t* k,
                const uint64_t* beta_mont, const uint64_t* gamma_mont, uint32_t n, uint32_t n_wires, uint64_t* z_out);
 
+/* The same on device-resident inputs (w, group: device Fr vectors; perm: device u32; k and the challenges on the
+ * host), z written to d_z (n elements, device). */
+int uzk_z_poly_device(const void* d_w, const uint32_t* d_perm, const void* d_group, const uint64_t* k,
+                      const uint64_t* beta_mont, const uint64_t* gamma_mont, uint32_t n, uint32_t n_wires, void* d_z);
+
 /* batch_prove's polynomial work (uzkge/src/poly_commit/pcs.rs:119-135 with div_rem,
  * field_polynomial.rs:519-550): evals_out[k] = p_k(z);  h = sum_k alpha^k (p_k - p_k(z));
  * q = h / (X - z)  (the remainder is zero by construction).

@@ -54,6 +54,25 @@ def test_z_poly_matches_restatement(gpu, n, n_wires):
     assert oc.fr_to_ints(got[:1]) == [1]
 
 
+def test_z_poly_device_entry_point(gpu):
+    """uzk_z_poly_device on device-resident inputs gives the same bytes as the host-pointer entry point."""
+    import torch
+    n, n_wires = 5000, 5
+    rng = np.random.default_rng(7)
+    w = rand_fr_wire(n * n_wires, 31).reshape(n_wires, n, 4)
+    perm = rng.integers(0, n * n_wires, size=(n_wires, n), dtype=np.uint32)
+    group = rand_fr_wire(n, 32)
+    k = oc.fr_from_ints([1, 7, 13, 17, 23])
+    beta, gamma = rand_fr_wire(2, 33)
+    dw = torch.from_numpy(w.view(np.int64)).to("cuda")
+    dp = torch.from_numpy(perm.view(np.int32)).to("cuda")
+    dg = torch.from_numpy(group.view(np.int64)).to("cuda")
+    dz = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+    gpu.z_poly_device(dw.data_ptr(), dp.data_ptr(), dg.data_ptr(), k, beta, gamma, n, n_wires, dz.data_ptr())
+    gpu.sync()
+    assert np.array_equal(dz.cpu().numpy().view(np.uint64), oc.z_poly(w, perm, group, k, beta, gamma))
+
+
 def test_z_poly_closes_for_a_satisfied_permutation(gpu):
     """Protocol property: when the wire values respect the copy constraints (w at position p equals
     w at perm[p]), the grand product over the WHOLE domain is 1, i.e. z[n-1] times the last row's

@@ -46,6 +46,7 @@ PROTOTYPES = {
     "uzk_poly_eval_batch": (_I, [_P, _U64, ctypes.c_uint32, _P, _P]),
     "uzk_poly_eval_batch_device": (_I, [_P, _U64, ctypes.c_uint32, _P, _P]),
     "uzk_z_poly": (_I, [_P, _P, _P, _P, _P, _P, ctypes.c_uint32, ctypes.c_uint32, _P]),
+    "uzk_z_poly_device": (_I, [_P, _P, _P, _P, _P, _P, ctypes.c_uint32, ctypes.c_uint32, _P]),
     "uzk_t_quotient_device": (_I, [_P, _P, _I]),
     "uzk_open_quotient_device": (_I, [_P, ctypes.c_uint64, ctypes.c_uint32, _P, _P, _P, _P]),
     "uzk_synth_points_arith": (_I, [_P, _SZ, _P]),

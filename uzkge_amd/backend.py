@@ -193,6 +193,16 @@ def z_poly(w: np.ndarray, perm: np.ndarray, group: np.ndarray, k: np.ndarray, be
     return out
 
 
+def z_poly_device(d_w: int, d_perm: int, d_group: int, k: np.ndarray, beta: np.ndarray, gamma: np.ndarray, n: int,
+                  n_wires: int, d_z: int) -> None:
+    """z_poly on device-resident wires / permutation / domain (helpers.rs:160-220); z -> d_z (n elements)."""
+    kk = np.ascontiguousarray(k, dtype=np.uint64).reshape(n_wires, 4)
+    check(lib.uzk_z_poly_device(ctypes.c_void_p(d_w), ctypes.c_void_p(d_perm), ctypes.c_void_p(d_group), _ptr(kk),
+                                _ptr(np.ascontiguousarray(beta, dtype=np.uint64).reshape(4)),
+                                _ptr(np.ascontiguousarray(gamma, dtype=np.uint64).reshape(4)), n, n_wires,
+                                ctypes.c_void_p(d_z)))
+
+
 def open_quotient_device(d_polys: int, n: int, batch: int, z: np.ndarray, alpha: np.ndarray, d_q: int) -> np.ndarray:
     """batch_prove's polynomial work (pcs.rs:119-135): writes q = sum_k alpha^k (p_k - p_k(z)) / (X - z) to d_q
     (n elements, the last one zero) and returns the evaluations p_k(z) [batch, 4]."""

@@ -468,6 +468,15 @@ int uzk_poly_eval_batch_device(const void* d_coefs, uint64_t n, uint32_t batch, 
     UZK_TRY(require_ready());
     return poly_eval_batch(ctx(), static_cast<const Fp*>(d_coefs), n, batch, *as_fp(x_mont), reinterpret_cast<Fp*>(out));
 }
+int uzk_z_poly_device(const void* d_w, const uint32_t* d_perm, const void* d_group, const uint64_t* k, const uint64_t* beta_mont,
+                      const uint64_t* gamma_mont, uint32_t n, uint32_t n_wires, void* d_z) {
+    API_LOCK;
+    if (n > 0 && (!d_w || !d_perm || !d_group || !k || !beta_mont || !gamma_mont || !d_z)) { set_error("uzk_z_poly_device: null pointer"); return UZK_ERR_PARAMETER; }
+    UZK_TRY(require_ready());
+    return z_poly_device(ctx(), static_cast<const Fp*>(d_w), d_perm, static_cast<const Fp*>(d_group), as_fp(k), *as_fp(beta_mont),
+                         *as_fp(gamma_mont), n, n_wires, static_cast<Fp*>(d_z));
+}
+
 int uzk_open_quotient_device(const void* d_polys, uint64_t n, uint32_t batch, const uint64_t* z_mont,
                              const uint64_t* alpha_mont, void* d_q, uint64_t* evals_out) {
     API_LOCK;

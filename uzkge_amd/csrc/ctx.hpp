@@ -127,6 +127,8 @@ int open_quotient_run(Ctx& c, const Fp* d_polys, uint64_t n, uint32_t batch, con
                       Fp* evals_host);
 struct QuotientDev;
 int t_quotient_run(Ctx& c, const void* args_c_abi, Fp* d_out);
+int z_poly_device(Ctx& c, const Fp* d_w, const uint32_t* d_perm, const Fp* d_group, const Fp* k_host, const Fp& beta,
+                  const Fp& gamma, uint32_t n, uint32_t n_wires, Fp* d_z);
 int z_poly_run(Ctx& c, const Fp* w_host, const uint32_t* perm_host, const Fp* group_host, const Fp* k_host,
                const Fp& beta, const Fp& gamma, uint32_t n, uint32_t n_wires, Fp* z_host);
 void poly_free(Ctx& c);

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(64) void poly_eval_finish_kernel(const Fp* __restri
     out[b] = acc;
 }
 
-static DevBuf g_poly_tmp, g_poly_tmp2, g_poly_io;
+static DevBuf g_poly_tmp, g_poly_tmp2, g_poly_io, g_zpoly_tmp;
 
 int poly_eval_batch(Ctx& c, const Fp* d_coefs, uint64_t n, uint32_t batch, const Fp& x, Fp* out_host) {
     if (batch == 0) return UZK_OK;
@@ -193,25 +193,23 @@ __global__ __launch_bounds__(256) void z_poly_combine_kernel(const Fp* __restric
     z[i] = v;
 }
 
-int z_poly_run(Ctx& c, const Fp* w_host, const uint32_t* perm_host, const Fp* group_host, const Fp* k_host,
-               const Fp& beta, const Fp& gamma, uint32_t n, uint32_t n_wires, Fp* z_host) {
+// Device-resident core: d_w [n_wires][n], d_perm [n_wires][n], d_group [n]  ->  d_z [n].
+int z_poly_device(Ctx& c, const Fp* d_w, const uint32_t* d_perm, const Fp* d_group, const Fp* k_host, const Fp& beta,
+                  const Fp& gamma, uint32_t n, uint32_t n_wires, Fp* d_z) {
     if (n == 0) return UZK_OK;
     if (n_wires == 0 || n_wires > 8) { set_error("z_poly: n_wires must be 1..8"); return UZK_ERR_PARAMETER; }
-    if (n == 1) { z_host[0] = Fr::one(); return UZK_OK; }
-    const size_t wn = (size_t)n_wires * n;
-    // staging: w | group | num | den | P | S | z   (Fp), perm (u32)
-    UZK_TRY(g_poly_io.reserve((wn + 6 * (size_t)n) * sizeof(Fp) + wn * sizeof(uint32_t)));
-    Fp* d_w = g_poly_io.as<Fp>();
-    Fp* d_group = d_w + wn;
-    Fp* d_num = d_group + n;
+    if (n == 1) {
+        const Fp one = Fr::one();
+        UZK_HIP(hipMemcpyAsync(d_z, &one, sizeof(Fp), hipMemcpyHostToDevice, c.stream));
+        UZK_HIP(hipStreamSynchronize(c.stream));
+        return UZK_OK;
+    }
+    // workspace: num | den | P | S
+    UZK_TRY(g_zpoly_tmp.reserve(4 * (size_t)n * sizeof(Fp)));
+    Fp* d_num = g_zpoly_tmp.as<Fp>();
     Fp* d_den = d_num + n;
     Fp* d_P = d_den + n;
     Fp* d_S = d_P + n;
-    Fp* d_z = d_S + n;
-    uint32_t* d_perm = reinterpret_cast<uint32_t*>(d_z + n);
-    UZK_HIP(hipMemcpyAsync(d_w, w_host, wn * sizeof(Fp), hipMemcpyHostToDevice, c.stream));
-    UZK_HIP(hipMemcpyAsync(d_group, group_host, (size_t)n * sizeof(Fp), hipMemcpyHostToDevice, c.stream));
-    UZK_HIP(hipMemcpyAsync(d_perm, perm_host, wn * sizeof(uint32_t), hipMemcpyHostToDevice, c.stream));
     ZPolyArgs a;
     a.w = d_w; a.perm = d_perm; a.group = d_group;
     for (uint32_t j = 0; j < 8; ++j) a.k[j] = j < n_wires ? k_host[j] : Fr::zero();
@@ -238,6 +236,24 @@ int z_poly_run(Ctx& c, const Fp* w_host, const uint32_t* perm_host, const Fp* gr
         hipLaunchKernelGGL(z_poly_combine_kernel, dim3((n + 255) / 256), dim3(256), 0, c.stream, d_P, d_S, inv_total, n, d_z);
     }
     UZK_HIP(hipGetLastError());
+    return UZK_OK;
+}
+
+int z_poly_run(Ctx& c, const Fp* w_host, const uint32_t* perm_host, const Fp* group_host, const Fp* k_host,
+               const Fp& beta, const Fp& gamma, uint32_t n, uint32_t n_wires, Fp* z_host) {
+    if (n == 0) return UZK_OK;
+    if (n_wires == 0 || n_wires > 8) { set_error("z_poly: n_wires must be 1..8"); return UZK_ERR_PARAMETER; }
+    const size_t wn = (size_t)n_wires * n;
+    // staging: w | group | z (Fp), perm (u32)
+    UZK_TRY(g_poly_io.reserve((wn + 2 * (size_t)n) * sizeof(Fp) + wn * sizeof(uint32_t)));
+    Fp* d_w = g_poly_io.as<Fp>();
+    Fp* d_group = d_w + wn;
+    Fp* d_z = d_group + n;
+    uint32_t* d_perm = reinterpret_cast<uint32_t*>(d_z + n);
+    UZK_HIP(hipMemcpyAsync(d_w, w_host, wn * sizeof(Fp), hipMemcpyHostToDevice, c.stream));
+    UZK_HIP(hipMemcpyAsync(d_group, group_host, (size_t)n * sizeof(Fp), hipMemcpyHostToDevice, c.stream));
+    UZK_HIP(hipMemcpyAsync(d_perm, perm_host, wn * sizeof(uint32_t), hipMemcpyHostToDevice, c.stream));
+    UZK_TRY(z_poly_device(c, d_w, d_perm, d_group, k_host, beta, gamma, n, n_wires, d_z));
     UZK_HIP(hipMemcpyAsync(z_host, d_z, (size_t)n * sizeof(Fp), hipMemcpyDeviceToHost, c.stream));
     UZK_HIP(hipStreamSynchronize(c.stream));
     return UZK_OK;
@@ -560,6 +576,7 @@ void poly_free(Ctx&) {
     g_poly_tmp.release();
     g_poly_tmp2.release();
     g_poly_io.release();
+    g_zpoly_tmp.release();
     g_open_tmp.release();
 }
 
