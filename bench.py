@@ -206,6 +206,7 @@ def main() -> None:
         "note": "integer-ALU bound (254-bit modular arithmetic on v_mad_u64_u32), not HBM bound: `alu` is the "
                 "binding roofline, `frac` the HBM one the contract asks for; see DESIGN.md 3.1",
     }
+    # device kernels (HIP events) and, prefixed host_, the host-side sections of the call (wall clock)
     kernels = {k: {"launches": v[0], "avg_ms": round(v[1] / max(v[0], 1), 4)} for k, v in sorted(prof.items())}
 
     extra = {"msm_kernels": kernels}

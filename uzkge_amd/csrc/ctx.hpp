@@ -6,6 +6,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <string>
@@ -103,6 +104,20 @@ std::mutex& ctx_mutex();
 int require_ready();
 
 // RAII kernel-launch bracket:  { KernelScope ks(c, "name"); kernel<<<...>>>(...); }
+// host-side section timer feeding the same profile table (entries named host_*)
+struct HostScope {
+    Ctx& c;
+    const char* name;
+    std::chrono::steady_clock::time_point t0;
+    HostScope(Ctx& c_, const char* n) : c(c_), name(n), t0(std::chrono::steady_clock::now()) {}
+    ~HostScope() {
+        if (!c.prof_on) return;
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        auto& e = c.prof_totals[name];
+        e.first += ms; e.second += 1;
+    }
+};
+
 struct KernelScope {
     Ctx& c;
     KernelScope(Ctx& c_, const char* name) : c(c_) { if (c.prof_on) c.prof_begin(name); }

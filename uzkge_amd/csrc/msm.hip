@@ -27,6 +27,10 @@
 //                larger c, ~25 % fewer additions, no per-window reduction and no host Horner.
 // No MFMA anywhere: the work is 254-bit modular integer arithmetic on v_mad_u64_u32.
 #include <algorithm>
+#include <mutex>
+#include <functional>
+#include <condition_variable>
+#include <atomic>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -887,6 +891,7 @@ int msm_precompute_window_bits(size_t n, int forced) {
     return std::max(8, std::min(22, lg - 2));
 }
 
+static void horner_pool_shutdown();
 void msm_free(Ctx& c) {
     if (!c.msm) return;
     for (int q = 0; q < 2; ++q) {
@@ -904,6 +909,7 @@ void msm_free(Ctx& c) {
     }
     delete[] c.msm;
     c.msm = nullptr;
+    horner_pool_shutdown();
     if (c.stream2) { (void)hipStreamDestroy(c.stream2); c.stream2 = nullptr; }
 }
 
@@ -1207,7 +1213,9 @@ static int msm_group_phase2(Ctx& c, MsmGroup& g) {
     const uint32_t G = kCombineFan;
     uint64_t tmax = ((uint64_t)m.h_max[0] + g.L - 1) / g.L;
     // lanes per fold group: latency mode for small problems, one lane per bucket for large ones
-    const uint32_t gs = (g.TBK >= (1u << 18) || c.tune_fold_group == 1) ? 1u : (tmax > 8 ? 16u : (tmax > 2 ? 4u : 1u));
+    // (measured at n = 2^14, batch 1..8: four lanes per bucket beat sixteen by 2..20 %)
+    const uint32_t gs = (c.tune_fold_group == 4 || c.tune_fold_group == 16) ? (uint32_t)c.tune_fold_group
+                      : (g.TBK >= (1u << 18) || c.tune_fold_group == 1) ? 1u : (tmax > 2 ? 4u : 1u);
     int lvl = 0;
     uint64_t bound_prev = g.bound0;
     while (tmax > G) {
@@ -1275,6 +1283,65 @@ static int msm_group_phase2(Ctx& c, MsmGroup& g) {
     return UZK_OK;
 }
 
+// A few persistent host threads for the per-vector Horner sums of a batched call (spawning
+// std::threads per call cost 0.2 ms for 8 vectors -- more than the arithmetic).
+namespace {
+class HornerPool {
+public:
+    explicit HornerPool(unsigned nthreads) {
+        for (unsigned t = 0; t < nthreads; ++t) workers_.emplace_back([this] { loop(); });
+    }
+    ~HornerPool() {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; ++gen_; }
+        cv_.notify_all();
+        for (auto& w : workers_) w.join();
+    }
+    // runs fn(i) for i in [0, count), the caller included; returns when all are done
+    void run(uint32_t count, const std::function<void(uint32_t)>& fn) {
+        { std::lock_guard<std::mutex> lk(mu_); fn_ = &fn; count_ = count; next_.store(0); done_.store(0); ++gen_; }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_done_.wait(lk, [this] { return done_.load() >= count_; });
+        fn_ = nullptr;
+    }
+private:
+    void work() {
+        for (;;) {
+            const uint32_t i = next_.fetch_add(1);
+            if (i >= count_) break;
+            (*fn_)(i);
+            if (done_.fetch_add(1) + 1 >= count_) { std::lock_guard<std::mutex> lk(mu_); cv_done_.notify_all(); }
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+            }
+            work();
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex mu_;
+    std::condition_variable cv_, cv_done_;
+    const std::function<void(uint32_t)>* fn_ = nullptr;
+    uint32_t count_ = 0;
+    std::atomic<uint32_t> next_{0}, done_{0};
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
+HornerPool* g_horner_pool = nullptr;
+}  // namespace
+static void horner_pool_shutdown() {
+    delete g_horner_pool;
+    g_horner_pool = nullptr;
+}
+
 void msm_plan_info(Ctx& c, size_t n, int* window_bits, int* windows) {
     const int cb = choose_window_bits(n, c.msm_window_bits);
     *window_bits = cb;
@@ -1313,9 +1380,12 @@ int msm_run(Ctx& c, const Affine* points, const Fp* d_scalars, size_t n, uint32_
         c.event_pool.push_back(ev);
     }
     int rc = UZK_OK;
-    for (int k = 0; k < ngroups && rc == UZK_OK; ++k) rc = msm_group_phase1(c, g[k], points, d_scalars, pre_stride, pre_off);
-    for (int k = 0; k < ngroups && rc == UZK_OK; ++k) rc = msm_group_phase2(c, g[k]);
-    for (int k = 0; k < ngroups; ++k) (void)hipStreamSynchronize(g[k].st);
+    { HostScope hs(c, "host_msm_enqueue1");
+      for (int k = 0; k < ngroups && rc == UZK_OK; ++k) rc = msm_group_phase1(c, g[k], points, d_scalars, pre_stride, pre_off); }
+    { HostScope hs(c, "host_msm_wait1_enqueue2");
+      for (int k = 0; k < ngroups && rc == UZK_OK; ++k) rc = msm_group_phase2(c, g[k]); }
+    { HostScope hs(c, "host_msm_wait2");
+      for (int k = 0; k < ngroups; ++k) (void)hipStreamSynchronize(g[k].st); }
     c.cur_stream = c.stream;
     UZK_TRY(rc);
 
@@ -1335,13 +1405,12 @@ int msm_run(Ctx& c, const Affine* points, const Fp* d_scalars, size_t n, uint32_
         }
         out_host[b] = xyzz_to_jac(total);
     };
+    HostScope hs_horner(c, "host_msm_horner");
     if (batch > 1 && wpp > 1) {
-        // 254 dependent doublings per vector: ~0.1 ms each on one core, so spread the vectors over threads
-        const uint32_t nt = std::min<uint32_t>(batch, 8);
-        std::vector<std::thread> th;
-        for (uint32_t t = 0; t < nt; ++t)
-            th.emplace_back([&, t] { for (uint32_t b = t; b < batch; b += nt) horner(b); });
-        for (auto& x : th) x.join();
+        // 254 dependent doublings per vector: ~0.06 ms each on one core, so spread the vectors over the pool
+        if (!g_horner_pool) g_horner_pool = new HornerPool(7);
+        const std::function<void(uint32_t)> job = [&](uint32_t b) { horner(b); };
+        g_horner_pool->run(batch, job);
     } else {
         for (uint32_t b = 0; b < batch; ++b) horner(b);
     }
