@@ -743,10 +743,11 @@ __global__ __launch_bounds__(256) void msm_fold_partials_kernel(const XYZZ* __re
 // (P1); the third is left to the fold kernel, which applies the same identity to the workgroup totals
 // R_G.  Every lane does the same work (no data-dependent double-and-add), so short segments -- many
 // lanes, short dependent chains -- become affordable.  grid (groups, windows).
-__device__ __forceinline__ void wg_suffix_scan(XYZZ* sh, uint32_t tid, XYZZ& mine) {
+// `width` = power of two >= the number of lanes that hold anything (lanes beyond it hold infinity)
+__device__ __forceinline__ void wg_suffix_scan(XYZZ* sh, uint32_t tid, XYZZ& mine, uint32_t width) {
     sh[tid] = mine;
     __syncthreads();
-    for (uint32_t off = 1; off < 256; off <<= 1) {
+    for (uint32_t off = 1; off < width; off <<= 1) {
         XYZZ v = (tid + off < 256) ? sh[tid + off] : xyzz_inf();
         __syncthreads();
         xyzz_add(mine, v);
@@ -754,10 +755,10 @@ __device__ __forceinline__ void wg_suffix_scan(XYZZ* sh, uint32_t tid, XYZZ& min
         __syncthreads();
     }
 }
-__device__ __forceinline__ void wg_tree_sum(XYZZ* sh, uint32_t tid, const XYZZ& mine) {
+__device__ __forceinline__ void wg_tree_sum(XYZZ* sh, uint32_t tid, const XYZZ& mine, uint32_t width) {
     sh[tid] = mine;
     __syncthreads();
-    for (uint32_t s = 128; s > 0; s >>= 1) {
+    for (uint32_t s = width >> 1; s > 0; s >>= 1) {
         if (tid < s) {
             XYZZ a = sh[tid];
             XYZZ b2 = sh[tid + s];
@@ -785,14 +786,20 @@ __global__ __launch_bounds__(256) void msm_reduce_scan_kernel(const XYZZ* __rest
             xyzz_add(acc, run);
         }
     }
+    // lanes of this workgroup that own buckets (rounded up to a power of two)
+    const uint64_t lanes_w = ((uint64_t)nbk + seg - 1) / seg;
+    const uint64_t mine_first = (uint64_t)blockIdx.x * 256;
+    uint32_t active = lanes_w > mine_first ? (uint32_t)min((uint64_t)256, lanes_w - mine_first) : 1u;
+    uint32_t width = 1;
+    while (width < active) width <<= 1;
     XYZZ suf = run;
-    wg_suffix_scan(sh, tid, suf);                 // sh[t] = Suffix_t (inclusive)
+    wg_suffix_scan(sh, tid, suf, width);          // sh[t] = Suffix_t (inclusive)
     XYZZ above = (tid + 1 < 256) ? sh[tid + 1] : xyzz_inf();
     const XYZZ total = sh[0];
     __syncthreads();
     for (uint32_t d = 0; d < log_seg; ++d) above = xyzz_dbl(above);
     xyzz_add(acc, above);                         // acc_t + seg * Suffix_(t+1)
-    wg_tree_sum(sh, tid, acc);
+    wg_tree_sum(sh, tid, acc, width);
     if (tid == 0) {
         part_p1[(size_t)w * groups_per_window + blockIdx.x] = sh[0];
         part_r[(size_t)w * groups_per_window + blockIdx.x] = total;
@@ -805,8 +812,10 @@ __global__ __launch_bounds__(256) void msm_fold_scan_kernel(const XYZZ* __restri
     const uint32_t w = blockIdx.x, tid = threadIdx.x;
     XYZZ r = tid < groups ? part_r[(size_t)w * groups + tid] : xyzz_inf();
     XYZZ p1 = tid < groups ? part_p1[(size_t)w * groups + tid] : xyzz_inf();
+    uint32_t width = 1;
+    while (width < groups) width <<= 1;
     if (groups > 1) {
-        wg_suffix_scan(sh, tid, r);
+        wg_suffix_scan(sh, tid, r, width);
         XYZZ above = (tid + 1 < 256) ? sh[tid + 1] : xyzz_inf();
         __syncthreads();
         if (!xyzz_is_inf(above)) {
@@ -814,7 +823,7 @@ __global__ __launch_bounds__(256) void msm_fold_scan_kernel(const XYZZ* __restri
             xyzz_add(p1, above);
         }
     }
-    wg_tree_sum(sh, tid, p1);
+    wg_tree_sum(sh, tid, p1, width);
     if (tid == 0) out[w] = sh[0];
 }
 
