@@ -8,6 +8,11 @@ N > 1 ranks (one process per GPU, torch.distributed / RCCL) every rank owns its 
 (weak scaling, a 2^24*N-point MSM in total), the 96-byte partial sums are all-gathered and folded
 on every rank -- EC addition is not an RCCL reduce op.
 
+`python bench.py --gpus N` starts the N ranks ITSELF (N child processes, one per GPU, launched before this
+process touches HIP or torch; RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in their environment); under an
+external launcher (torchrun sets RANK) the process is a rank straight away.  `--total-log-n K` is
+the strong-scaling mode of BASELINE config #5: 2^K points in total, 2^K / N per rank.
+
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (msm_accumulate):
 achieved = 96 B/point (32 B scalar + 64 B affine base) x points per launch / the
 kernel's mean duration, measured live with HIP events on the library stream during the timed
@@ -73,9 +78,53 @@ def _sample_clocks(work, sync, seconds: float = 2.0):
     return {"sclk_mhz": sclk, "power_w": pws[len(pws) // 2] if pws else None, "samples": len(samples)}
 
 
+def _free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n_ranks: int, argv) -> int:
+    """Start `n_ranks` copies of this script as rank processes and wait for them.  Runs in a parent
+    that has not imported torch or the backend (no HIP call), so nothing GPU-initialised is ever
+    forked or exec'd.  Returns the first non-zero exit code (the other ranks are then terminated)."""
+    import subprocess
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n_ranks), "LOCAL_WORLD_SIZE": str(n_ranks),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": port, "UZK_BENCH_LAUNCHED": "1"})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    pending = set(range(n_ranks))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print(f"bench.py: rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr)
+                for q in pending:
+                    procs[q].terminate()
+        if pending:
+            time.sleep(0.05)
+    return rc
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--total-log-n", type=int, default=0,
+                    help="strong scaling: log2 of the TOTAL point count, split evenly over the ranks (config #5: 26)")
+    ap.add_argument("--scalars", choices=["uniform", "mix"], default="uniform",
+                    help="scalar set of the headline loop: (A) uniform or (B) the prover-like mix of BASELINE.md section 4")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU work: every rank contributes (rank + 1) * G; exercises the launcher, the collective and the fold")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log-n", type=int, default=24, help="log2 MSM points per GPU")
@@ -87,6 +136,62 @@ def main() -> None:
     ap.add_argument("--no-extras", action="store_true", help="skip the window-table and prover-shape extras")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # parent: no torch, no HIP -- only children touch the GPU
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    run_rank(args)
+
+
+def _kernel_sources_sha() -> str:
+    """sha256 over the sources of the two hot kernels: ties committed counter files to the code they measured."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("msm.hip", "ec29.hpp", "fp29.hpp", "mul29_gfx950.inc", "ntt.hip"):
+        with open(os.path.join(ROOT, "uzkge_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def _load_counters(name: str):
+    """profiles/<name> if it was measured on the kernel sources of this tree, else (None, reason)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None, "no counter file"
+    if d.get("kernel_sources_sha") != _kernel_sources_sha():
+        return None, f"stale: {name} was measured on other kernel sources ({d.get('kernel_sources_sha')})"
+    return d, None
+
+
+def dry_run_rank(args, rank, world, dist, np) -> None:
+    """--dry-run: the launcher, the rendezvous, the all-gather of 96-byte partials and the fold, with no GPU:
+    rank r contributes (r + 1) * G (built with the host-side fold of the C ABI)."""
+    import torch
+    from uzkge_amd import backend as b
+    one_q = np.array([0xd35d438dc58f0d9d, 0x0a78eb28f5c70b3d, 0x666ea36f7879462c, 0x0e0a77c19a07df2f], dtype=np.uint64)
+    two_q = np.array([0xa6ba871b8b1e1b3a, 0x14f1d651eb8e167b, 0xccdd46def0f28c58, 0x1c14ef83340fbe5e], dtype=np.uint64)
+    g = np.concatenate([one_q, two_q, one_q])                      # G = (1, 2, 1) in Montgomery form
+    part = b.g1_fold(np.stack([g] * (rank + 1)))
+    send = torch.from_numpy(part.view(np.uint8).copy())
+    recv = torch.zeros(96 * world, dtype=torch.uint8)
+    if world > 1:
+        dist.all_gather_into_tensor(recv, send)
+    else:
+        recv.copy_(send)
+    total = b.g1_fold(recv.numpy().view(np.uint64).reshape(world, 12))
+    aff = b.g1_to_affine(total)
+    if rank == 0:
+        print(json.dumps({"metric": "bn254_g1_msm_points_per_sec", "value": 0.0, "unit": "points/s", "n_gpus": world,
+                          "dry_run": True, "dist_world_size": dist.get_world_size() if world > 1 else 1,
+                          "fold_of_rank_partials_affine": [int(x) for x in aff],
+                          "expect": f"{world * (world + 1) // 2} * G"}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_rank(args) -> None:
     import numpy as np
     import torch
 
@@ -97,7 +202,14 @@ def main() -> None:
     # UZK_BENCH_BACKEND=gloo rehearses the multi-rank control flow on a box with fewer GPUs than ranks
     # (ranks then share a device and exchange their partials through host memory); the driver's runs
     # use the default: one rank per GPU over RCCL.
-    backend = os.environ.get("UZK_BENCH_BACKEND", "nccl")
+    backend = os.environ.get("UZK_BENCH_BACKEND", "gloo" if args.dry_run else "nccl")
+    if args.dry_run:
+        if world > 1:
+            import torch.distributed as dist  # type: ignore
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")
+        dry_run_rank(args, rank, world, dist, np)
+        return
     ndev = max(torch.cuda.device_count(), 1)
     dev_index = local_rank if backend == "nccl" else local_rank % ndev
     torch.cuda.set_device(dev_index)
@@ -117,7 +229,14 @@ def main() -> None:
     if args.window_bits:
         b.set_msm_window_bits(args.window_bits)
 
-    n = 1 << args.log_n
+    strong = args.total_log_n > 0
+    if strong:
+        total = 1 << args.total_log_n
+        if total % world:
+            raise SystemExit(f"--total-log-n {args.total_log_n}: 2^{args.total_log_n} points do not split over {world} ranks")
+        n = total // world
+    else:
+        n = 1 << args.log_n
     seed = 0x755A6B67655F6D73 + rank   # documented SplitMix64 seed, per-rank chunk
     pts = torch.empty((n, 8), dtype=torch.int64, device=dev)
     sc = torch.empty((n, 4), dtype=torch.int64, device=dev)
@@ -125,15 +244,19 @@ def main() -> None:
     if args.points == "random":
         b.synth_points_random(pts.data_ptr(), n, seed)
     else:
-        import ctypes  # noqa: F401
         k = np.array([seed & 0xFFFFFFFFFFFFFFFF, 1, 0, 0], dtype=np.uint64)
         b.synth_points_arith(pts.data_ptr(), n, k)
-    b.synth_scalars(sc.data_ptr(), n, seed ^ 0x5CA1AB1E)
+    if args.scalars == "mix":
+        b.synth_scalars_mix(sc.data_ptr(), n, seed ^ 0x5CA1AB1E)
+    else:
+        b.synth_scalars(sc.data_ptr(), n, seed ^ 0x5CA1AB1E)
     srs = b.Srs.from_device(pts.data_ptr(), n)
     gather_in = torch.zeros(96, dtype=torch.uint8, device=coll_dev)
     gather_out = torch.zeros(96 * world, dtype=torch.uint8, device=coll_dev)
 
     def step():
+        # the rank's partial sum arrives in host memory (the window sums are combined there); the exchange is
+        # the 96-byte all-gather over RCCL / xGMI and every rank folds the N partials
         part = b.msm_device(srs, sc.data_ptr(), n)
         if world == 1:
             return part
@@ -150,41 +273,55 @@ def main() -> None:
         b.sync()
         torch.cuda.synchronize()
 
+    def timed_steps(fn, steps):
+        fence()
+        t0 = time.perf_counter()
+        res = None
+        for _ in range(steps):
+            res = fn()
+        fence()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, res
+
     for _ in range(args.warmup):
         step()
     b.profile_reset()
     b.profile_enable(True)
-    fence()
-    t0 = time.perf_counter()
-    result = None
-    for _ in range(args.steps):
-        result = step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    elapsed, result = timed_steps(step, args.steps)
     b.profile_enable(False)
     prof = b.profile_table()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
     ms_per_step = elapsed / args.steps * 1e3
     value = world * n * args.steps / elapsed
 
+    # which devices the ranks really ran on (so the record shows N distinct GPUs behind the collective)
+    dev_ids = [dev_index]
+    dev_uuids = [str(getattr(torch.cuda.get_device_properties(dev_index), "uuid", ""))]
+    if world > 1:
+        objs = [None] * world
+        dist.all_gather_object(objs, (dev_index, dev_uuids[0]))
+        dev_ids = [o[0] for o in objs]
+        dev_uuids = [o[1] for o in objs]
+
     acc_cnt, acc_ms = prof.get("msm_accumulate", (0, 0.0))
     acc_avg_ms = acc_ms / max(acc_cnt, 1)
     achieved = (96.0 * n) / (acc_avg_ms * 1e-3) / 1e9 if acc_cnt else 0.0
-    # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json), valid for
-    # the configuration they were collected on (same kernel, same log_n, default window bits)
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            pmc = json.load(f)
-        ent = pmc.get("msm_accumulate", {}).get(str(args.log_n))
-        if ent and args.points == "random" and not args.window_bits:
+    # HBM bytes per launch: rocprofv3 PMC passes summarised in profiles/pmc_traffic.json, used only when that file
+    # was measured on the kernel sources of this tree (it records their hash) and on this configuration
+    traffic, traffic_note = None, None
+    pmc, why = _load_counters("pmc_traffic.json")
+    if pmc is None:
+        traffic_note = why
+    else:
+        ent = pmc.get("msm_accumulate", {}).get(str(n.bit_length() - 1))
+        if ent and args.points == "random" and not args.window_bits and args.scalars == "uniform" and n & (n - 1) == 0:
             traffic = ent["traffic_bytes"]
-    except (OSError, ValueError, KeyError):
-        traffic = None
+        else:
+            traffic_note = "no PMC pass for this configuration"
     # The kernel's real bound is the 64-bit multiply-add pipe: every mixed addition is 1467
     # v_mad_u64_u32 per lane (ec29.hpp: 6 products, 2 squarings, 1 dual product on 9 x 29-bit limbs)
     # against the measured issue peak of that instruction (tools/microbench/int_rates.hip:
@@ -206,10 +343,37 @@ def main() -> None:
         "note": "integer-ALU bound (254-bit modular arithmetic on v_mad_u64_u32), not HBM bound: `alu` is the "
                 "binding roofline, `frac` the HBM one the contract asks for; see DESIGN.md 3.1",
     }
+    if traffic_note:
+        roofline["traffic_note"] = traffic_note
+    # SQ counters of the same kernel (separate rocprofv3 --pmc passes, profiles/sq_counters.json): measured issue
+    # utilisation instead of a cost model
+    sq, why = _load_counters("sq_counters.json")
+    if sq is not None and "msm_accumulate" in sq:
+        roofline["alu"]["sq_counters"] = sq["msm_accumulate"]
+    elif why:
+        roofline["alu"]["sq_counters_note"] = why
     # device kernels (HIP events) and, prefixed host_, the host-side sections of the call (wall clock)
     kernels = {k: {"launches": v[0], "avg_ms": round(v[1] / max(v[0], 1), 4)} for k, v in sorted(prof.items())}
 
     extra = {"msm_kernels": kernels}
+    solo = rank == 0 and world == 1 and not args.no_extras
+
+    # ---- BASELINE config #5 next to the weak-scaling headline: 2^26 points in total, split over the ranks ------
+    if world > 1 and not strong and not args.no_extras and  (1 << 26) // world <= n:
+        m5 = (1 << 26) // world
+
+        def step5():
+            part = b.msm_device(srs, sc.data_ptr(), m5)
+            gather_in.copy_(torch.from_numpy(part.view(np.uint8)))
+            dist.all_gather_into_tensor(gather_out, gather_in)
+            return b.g1_fold(gather_out.cpu().numpy().view(np.uint64).reshape(world, 12))
+        step5()
+        el5, _ = timed_steps(step5, max(3, args.steps // 2))
+        extra["strong_2p26"] = {"what": "BASELINE config #5: 2^26 points in total, point-chunk sharded over the ranks, "
+                                        "RCCL all-gather of the partial sums, fold on every rank",
+                                "points_per_gpu": m5, "total_points": m5 * world, "steps": max(3, args.steps // 2),
+                                "ms_per_step": round(el5 / max(3, args.steps // 2) * 1e3, 4),
+                                "value": m5 * world * max(3, args.steps // 2) / el5, "unit": "points/s", "scaling": "strong"}
 
     # ---- NTT 2^22 (single GPU path; replicas only under N > 1) --------------------------------
     if not args.no_ntt and rank == 0:
@@ -230,6 +394,13 @@ def main() -> None:
             b.ntt_device(x.data_ptr(), y.data_ptr(), nn)
         b.sync()
         ntt_s = (time.perf_counter() - t1) / reps_t
+        b.sync()
+        t1 = time.perf_counter()
+        for _ in range(reps_t // 2):
+            b.ntt_device(x.data_ptr(), y.data_ptr(), nn)
+            b.ntt_device(y.data_ptr(), y.data_ptr(), nn, inverse=True)
+        b.sync()
+        rt_s = (time.perf_counter() - t1) / (reps_t // 2)
         b.profile_reset()
         b.profile_enable(True)
         reps = 20
@@ -240,16 +411,14 @@ def main() -> None:
         p2 = b.profile_table()
         kern_ms = sum(v[1] for k, v in p2.items() if k.startswith("ntt_pass")) / reps
         ntt_traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                ntt_traffic = json.load(f).get("ntt_pass", {}).get(str(args.ntt_log_n), {}).get("traffic_bytes_per_transform")
-        except (OSError, ValueError):
-            ntt_traffic = None
+        if pmc is not None:
+            ntt_traffic = pmc.get("ntt_pass", {}).get(str(args.ntt_log_n), {}).get("traffic_bytes_per_transform")
         extra["ntt"] = {
             "metric": "bn254_fr_ntt_elements_per_sec", "log_n": args.ntt_log_n,
             "value": nn / ntt_s, "ms_per_transform": round(ntt_s * 1e3, 4),
+            "forward_plus_inverse_ms": round(rt_s * 1e3, 4),
             "kernel_ms_per_transform": round(kern_ms, 4), "roundtrip_bit_exact": roundtrip_ok,
-            # per transform = three back-to-back pass kernels: priced on the un-instrumented wall time per
+            # per transform = back-to-back pass kernels: priced on the un-instrumented wall time per
             # transform (the event-bracketed kernel durations below do not overlap their ramps and sum to more)
             "roofline": {"bound": "hbm", "achieved": round(64.0 * nn / ntt_s / 1e9, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -258,12 +427,14 @@ def main() -> None:
                          "traffic": ntt_traffic},
             "kernels": {k: {"launches": v[0], "avg_ms": round(v[1] / max(v[0], 1), 4)} for k, v in sorted(p2.items())},
         }
+        if sq is not None and "ntt_pass" in sq:
+            extra["ntt"]["sq_counters"] = sq["ntt_pass"]
 
     # ---- sustained shader clock under this workload (rank 0, N = 1 only) --------------------------
     # The MAD peak above was measured with sub-millisecond kernels at the boost clock; the 18 ms
     # accumulation kernel runs the package into its power limit and the clock drops.  Sample
     # rocm-smi while the same MSM repeats for ~2 s and restate the ALU fraction at that clock.
-    if rank == 0 and world == 1 and not args.no_extras:
+    if solo:
         try:
             clk = _sample_clocks(lambda: b.msm_device(srs, sc.data_ptr(), n), b.sync)
             if clk:
@@ -273,18 +444,59 @@ def main() -> None:
                 peak_s = MAD_PEAK_T * clk["sclk_mhz"] / MAD_PEAK_SCLK_MHZ
                 roofline["alu"]["peak_at_sustained_clock"] = round(peak_s, 2)
                 roofline["alu"]["frac_at_sustained_clock"] = round(alu_achieved / peak_s, 4) if peak_s else None
-                # whole instruction stream of the loop (ISA count: 1467 MADs + 586 other VALU instructions + 176
-                # s_nop per addition) priced at the measured issue costs, against the SIMD cycles the launch had
-                need = (MADS_PER_MIXED_ADD * CYC_PER_MAD + OTHER_VALU_PER_MIXED_ADD * CYC_PER_OTHER_VALU + 176) * (n * nwin / 64.0)
-                have = acc_avg_ms * 1e-3 * NUM_SIMDS * clk["sclk_mhz"] * 1e6
-                roofline["alu"]["valu_issue_frac_at_sustained_clock"] = round(need / have, 4) if have else None
         except Exception as e:
             roofline["alu"]["clock_probe_error"] = str(e)
 
+    # ---- the other rows of BASELINE.md section 5 and section 4's set (B), end-to-end timings (rank 0, N = 1 only) ----
+    if solo:
+        def time_msm(handle, d_sc, m, reps=5):
+            b.msm_device(handle, d_sc, m)
+            b.sync()
+            t = time.perf_counter()
+            for _ in range(reps):
+                r = b.msm_device(handle, d_sc, m)
+            b.sync()
+            return (time.perf_counter() - t) / reps, r
+        try:     # scalar set (B): the prover-like mix, same points, same size
+            sc_mix = torch.empty((n, 4), dtype=torch.int64, device=dev)
+            b.synth_scalars_mix(sc_mix.data_ptr(), n, seed ^ 0x5CA1AB1E)
+            s_mix, _ = time_msm(srs, sc_mix.data_ptr(), n)
+            extra["msm_prover_mix"] = {"what": "scalar set (B): 50 % zero, 20 % one, 10 % r-1, 10 % < 2^16, 10 % uniform (placeholder proportions)",
+                                       "log_n": n.bit_length() - 1, "ms_per_msm": round(s_mix * 1e3, 4), "points_per_sec": n / s_mix}
+            del sc_mix
+        except Exception as e:
+            extra["msm_prover_mix"] = {"error": str(e)}
+        try:     # 2^20 (config #2's size): a prefix of the same workload
+            if n >= (1 << 20):
+                s20, _ = time_msm(srs, sc.data_ptr(), 1 << 20, reps=10)
+                extra["msm_2p20"] = {"ms_per_msm": round(s20 * 1e3, 4), "points_per_sec": (1 << 20) / s20}
+        except Exception as e:
+            extra["msm_2p20"] = {"error": str(e)}
+        try:     # PCIe-inclusive: the host-pointer entry points (scalars / vector cross PCIe inside the call)
+            hs = sc.cpu().numpy().view(np.uint64).reshape(-1, 4)
+            b.msm(srs, hs[: 1 << 10])
+            t = time.perf_counter()
+            for _ in range(2):
+                b.msm(srs, hs)
+            pc_s = (time.perf_counter() - t) / 2
+            ent = {"msm_host_scalars_ms": round(pc_s * 1e3, 3), "msm_points_per_sec": n / pc_s,
+                   "what": "uzk_msm_g1 / uzk_ntt_fr with pageable host buffers: upload + compute + download inside the call"}
+            if "ntt" in extra:
+                hx = x.cpu().numpy().view(np.uint64).reshape(-1, 4)
+                b.ntt(hx[:4096])
+                t = time.perf_counter()
+                b.ntt(hx)
+                ent["ntt_host_vector_ms"] = round((time.perf_counter() - t) * 1e3, 3)
+                del hx
+            extra["pcie_inclusive"] = ent
+            del hs
+        except Exception as e:
+            extra["pcie_inclusive"] = {"error": str(e)}
+
     # ---- opt-in window-table mode and the real prover's call mix (rank 0, N = 1 only) ----------
-    if rank == 0 and world == 1 and not args.no_extras:
+    if solo:
         try:
-            srs.precompute(20 if args.log_n >= 22 else 0)
+            srs.precompute(20 if n >= (1 << 22) else 0)
             b.msm_device(srs, sc.data_ptr(), n)
             b.sync()
             t2 = time.perf_counter()
@@ -294,7 +506,7 @@ def main() -> None:
             pre_s = (time.perf_counter() - t2) / 3
             same = bool(np.array_equal(b.g1_to_affine(pre_res), b.g1_to_affine(result)))
             extra["msm_precomputed"] = {"ms_per_msm": round(pre_s * 1e3, 4), "points_per_sec": n / pre_s,
-                                        "window_bits": 20 if args.log_n >= 22 else "auto",
+                                        "window_bits": 20 if n >= (1 << 22) else "auto",
                                         "same_commitment_as_general_mode": same,
                                         "note": "uzk_srs_precompute: window table resident in HBM (opt-in; not the headline)"}
         except Exception as e:   # e.g. not enough HBM for the table at a larger --log-n
@@ -316,10 +528,10 @@ def main() -> None:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle_c as oc   # checker / reported baseline only
 
-        m = min(n, 1 << 24)   # the whole default workload: about 6 s on 16 host threads
+        m = min(n, 1 << 24)   # the whole default workload: a few seconds on the node's host cores
         hp = pts[:m].cpu().numpy().view(np.uint64).reshape(-1, 8)
         hs = sc[:m].cpu().numpy().view(np.uint64).reshape(-1, 4)
-        cores = min(16, os.cpu_count() or 1)
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         tc = time.perf_counter()
         ref = oc.msm_pippenger(hp, hs, 0, cores)
         cpu_s = time.perf_counter() - tc
@@ -328,8 +540,8 @@ def main() -> None:
         cpu_baseline = {
             "value": m / cpu_s, "unit": "points/s", "cores": cores, "kind": "port",
             "sample": f"first 2^{m.bit_length() - 1} points/scalars of the same workload, Pippenger in oracle/bn254_oracle.c "
-                      f"(own CPU restatement, not arkworks)", "seconds": round(cpu_s, 3),
-            "gpu_matches_cpu_on_sample": parity,
+                      f"(own CPU restatement, not arkworks), one thread per host core this process may use",
+            "seconds": round(cpu_s, 3), "gpu_matches_cpu_on_sample": parity,
         }
         if "ntt" in extra:
             nn = 1 << args.ntt_log_n
@@ -345,14 +557,21 @@ def main() -> None:
             }
 
     if rank == 0:
+        lg = n.bit_length() - 1 if n & (n - 1) == 0 else None
+        per = f"2^{lg}" if lg is not None else str(n)
         line = {
             "metric": "bn254_g1_msm_points_per_sec", "value": value, "unit": "points/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u256 (8 x u32 Montgomery limbs)", "data": "synthetic",
-            "config": {"workload": f"BN254 G1 MSM, 2^{args.log_n} {args.points} points + uniform scalars per GPU, "
-                                   f"bases resident in HBM", "points_per_gpu": n, "total_points": n * world,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "dtype": "u256 (254-bit modular integers: 8 x u32 Montgomery limbs in HBM, 9 x 29-bit limbs in the two hot loops)",
+            "data": "synthetic",
+            "config": {"workload": f"BN254 G1 MSM, {per} {args.points} points + {args.scalars} scalars per GPU, "
+                                   f"bases resident in HBM" + (f" (2^{args.total_log_n} points in total)" if strong else ""),
+                       "points_per_gpu": n, "total_points": n * world,
                        "sharding": "point-chunk per rank, all-gather of 96-byte partial sums, host fold" if world > 1 else "single GPU"},
+            "dist_world_size": dist.get_world_size() if world > 1 else 1,
+            "collective_backend": (dist.get_backend() if world > 1 else None),
+            "device_ids": dev_ids, "device_uuids": dev_uuids,
             "roofline": roofline, "cpu_baseline": cpu_baseline, "extra": extra,
             "result_is_infinity": bool(not result[8:12].any()),
         }

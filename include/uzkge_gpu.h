@@ -192,6 +192,9 @@ int uzk_synth_points_arith(void* d_points, size_t n, const uint64_t* seed_scalar
 int uzk_synth_points_random(void* d_points, size_t n, uint64_t seed);
 /* Uniform Fr elements (Montgomery form) from a SplitMix64 counter stream. */
 int uzk_synth_scalars(void* d_scalars, size_t n, uint64_t seed);
+/* The illustrative prover-like mix (SURVEY.md 8d set B): by a hash of the index 50 % zero, 20 % one,
+ * 10 % r - 1, 10 % below 2^16, 10 % uniform. */
+int uzk_synth_scalars_mix(void* d_scalars, size_t n, uint64_t seed);
 
 /* ---- known-answer entry points (tests): the DEVICE primitives applied element-wise -------- */
 /* field: 0 = Fq, 1 = Fr.  op: 0 mul (assembly FIPS), 1 add, 2 sub, 3 mul (portable CIOS), 4 sqr,

@@ -238,9 +238,12 @@ void oracle_msm_naive(const uint64_t *points, const uint64_t *scalars_mont, size
     *(g1j *)out_jac = acc;
 }
 
+/* One job = one window over one contiguous range of points; jobs are handed out through a shared
+ * counter so any thread count (up to windows x parts) keeps every core busy. */
 typedef struct {
-    const g1a *P; const fe *K; size_t n; int c; int w_begin, w_end; g1j *win_out;
-} msm_job;
+    const g1a *P; fe *K; const fe *S; size_t n; int c, nwin, parts; g1j *win_part;   /* [nwin][parts] */
+    volatile long next_job, next_conv;
+} msm_shared;
 
 static inline uint32_t get_bits(const fe *k, int lo, int c) {
     int limb = lo >> 6, sh = lo & 63;
@@ -249,51 +252,71 @@ static inline uint32_t get_bits(const fe *k, int lo, int c) {
     if (sh + c > 64 && limb + 1 < 4) v |= k->l[limb + 1] << (64 - sh);
     return (uint32_t)(v & ((1ULL << c) - 1));
 }
+static void *msm_conv_worker(void *arg) {        /* scalars out of Montgomery form, 4096 at a time */
+    msm_shared *sh = (msm_shared *)arg;
+    for (;;) {
+        long blk = __sync_fetch_and_add(&sh->next_conv, 1);
+        size_t lo = (size_t)blk * 4096, hi = lo + 4096;
+        if (lo >= sh->n) break;
+        if (hi > sh->n) hi = sh->n;
+        for (size_t i = lo; i < hi; ++i) f_from_mont(&FR, &sh->K[i], &sh->S[i]);
+    }
+    return NULL;
+}
 static void *msm_worker(void *arg) {
-    msm_job *j = (msm_job *)arg;
-    size_t nb = (size_t)1 << j->c;
+    msm_shared *sh = (msm_shared *)arg;
+    size_t nb = (size_t)1 << sh->c;
     g1j *buckets = (g1j *)malloc(nb * sizeof(g1j));
-    for (int w = j->w_begin; w < j->w_end; ++w) {
+    for (;;) {
+        long job = __sync_fetch_and_add(&sh->next_job, 1);
+        if (job >= (long)sh->nwin * sh->parts) break;
+        int w = (int)(job / sh->parts), part = (int)(job % sh->parts);
+        size_t lo = sh->n * (size_t)part / sh->parts, hi = sh->n * (size_t)(part + 1) / sh->parts;
         for (size_t b = 0; b < nb; ++b) j_set_inf(&buckets[b]);
-        for (size_t i = 0; i < j->n; ++i) {
-            uint32_t d = get_bits(&j->K[i], w * j->c, j->c);
-            if (d) j_add_affine(&buckets[d], &buckets[d], &j->P[i], 0);
+        for (size_t i = lo; i < hi; ++i) {
+            uint32_t d = get_bits(&sh->K[i], w * sh->c, sh->c);
+            if (d) j_add_affine(&buckets[d], &buckets[d], &sh->P[i], 0);
         }
         g1j run, acc; j_set_inf(&run); j_set_inf(&acc);
         for (size_t b = nb - 1; b >= 1; --b) { j_add(&run, &run, &buckets[b]); j_add(&acc, &acc, &run); }
-        j->win_out[w] = acc;
+        sh->win_part[(size_t)w * sh->parts + part] = acc;
     }
     free(buckets);
     return NULL;
 }
-/* Pippenger bucket method, plain (unsigned) windows of c bits, threads over windows.
- * This is the timed "port" CPU baseline in bench.py. */
+/* Pippenger bucket method, plain (unsigned) windows of c bits, threads over (window, point range)
+ * jobs.  This is the timed "port" CPU baseline in bench.py. */
 void oracle_msm_pippenger(const uint64_t *points, const uint64_t *scalars_mont, size_t n,
                           int c, int threads, uint64_t *out_jac) {
     if (c < 1) {
         c = 3; while ((1ULL << (c + 3)) < n && c < 16) ++c;     /* ~ log2(n) - 3 */
     }
     int nwin = (254 + c - 1) / c;
-    fe *K = (fe *)malloc((n ? n : 1) * sizeof(fe));
-    for (size_t i = 0; i < n; ++i) f_from_mont(&FR, &K[i], &((const fe *)scalars_mont)[i]);
-    g1j *win = (g1j *)malloc(nwin * sizeof(g1j));
     if (threads < 1) threads = 1;
-    if (threads > nwin) threads = nwin;
+    if (threads > 1024) threads = 1024;
+    /* point ranges per window: enough jobs for every thread, none shorter than 8 buckets' worth */
+    int parts = (threads + nwin - 1) / nwin;
+    if (threads > 1 && parts < 2 && (threads % nwin)) parts = 2;
+    while (parts > 1 && n / (size_t)parts < ((size_t)8 << c)) --parts;
+    msm_shared sh;
+    sh.P = (const g1a *)points; sh.S = (const fe *)scalars_mont; sh.n = n; sh.c = c; sh.nwin = nwin; sh.parts = parts;
+    sh.K = (fe *)malloc((n ? n : 1) * sizeof(fe));
+    sh.win_part = (g1j *)malloc((size_t)nwin * parts * sizeof(g1j));
+    sh.next_job = 0; sh.next_conv = 0;
     pthread_t *th = (pthread_t *)malloc(threads * sizeof(pthread_t));
-    msm_job *jobs = (msm_job *)malloc(threads * sizeof(msm_job));
-    for (int t = 0; t < threads; ++t) {
-        jobs[t] = (msm_job){(const g1a *)points, K, n, c, (int)((long)nwin * t / threads),
-                            (int)((long)nwin * (t + 1) / threads), win};
-        pthread_create(&th[t], NULL, msm_worker, &jobs[t]);
-    }
-    for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);
+    for (int t = 1; t < threads; ++t) pthread_create(&th[t], NULL, msm_conv_worker, &sh);
+    msm_conv_worker(&sh);
+    for (int t = 1; t < threads; ++t) pthread_join(th[t], NULL);
+    for (int t = 1; t < threads; ++t) pthread_create(&th[t], NULL, msm_worker, &sh);
+    msm_worker(&sh);
+    for (int t = 1; t < threads; ++t) pthread_join(th[t], NULL);
     g1j total; j_set_inf(&total);
     for (int w = nwin - 1; w >= 0; --w) {
         for (int b = 0; b < c; ++b) j_double(&total, &total);
-        j_add(&total, &total, &win[w]);
+        for (int part = 0; part < parts; ++part) j_add(&total, &total, &sh.win_part[(size_t)w * parts + part]);
     }
     *(g1j *)out_jac = total;
-    free(K); free(win); free(th); free(jobs);
+    free(sh.K); free(sh.win_part); free(th);
 }
 
 /* ------------------------------------------------------------------ NTT */

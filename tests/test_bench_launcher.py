@@ -1,0 +1,55 @@
+"""`python bench.py --gpus N` must start its N ranks itself (the driver's command has no torchrun).
+CPU rehearsal: `--dry-run` keeps the launcher, the environment hand-over, the gloo rendezvous, the
+all-gather of the 96-byte partials and the fold through the C ABI, and replaces the GPU MSM of rank r by
+(r + 1) * G, so the folded result is known: N (N + 1) / 2 * G."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import bn254_py as opy
+import oracle_c as oc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env_extra=None, timeout=240):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gpus_flag_spawns_that_many_ranks(world):
+    r = _run(["--gpus", str(world), "--dry-run"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == world and out["dist_world_size"] == world
+    aff = np.array(out["fold_of_rank_partials_affine"], dtype=np.uint64)
+    want = opy.g1_mul(opy.G1_GEN, world * (world + 1) // 2)
+    assert opy.wire_to_affine(aff.tobytes()) == want
+
+
+def test_a_failing_rank_fails_the_launcher():
+    # rank processes cannot initialise a GPU here: without --dry-run every rank fails, and so must the parent
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--log-n", "10", "--no-extras", "--no-cpu-baseline"],
+             env_extra={"UZK_BENCH_BACKEND": "gloo"})
+    from uzkge_amd import backend as b
+    if b.device_count() > 0:
+        pytest.skip("GPU present: the ranks succeed")
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_external_launcher_env_is_respected():
+    # under torchrun RANK is already set: the process must act as that rank, not spawn again
+    r = _run(["--gpus", "1", "--dry-run"], env_extra={"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 1

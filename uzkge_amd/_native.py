@@ -52,6 +52,7 @@ PROTOTYPES = {
     "uzk_synth_points_arith": (_I, [_P, _SZ, _P]),
     "uzk_synth_points_random": (_I, [_P, _SZ, _U64]),
     "uzk_synth_scalars": (_I, [_P, _SZ, _U64]),
+    "uzk_synth_scalars_mix": (_I, [_P, _SZ, _U64]),
     "uzk_field_op_device": (_I, [_I, _I, _P, _P, _P, _SZ]),
     "uzk_g1_op_device": (_I, [_I, _P, _P, _P, _SZ]),
     "uzk_profile_enable": (_I, [_I]),

@@ -253,6 +253,11 @@ def synth_scalars(d_scalars: int, n: int, seed: int) -> None:
     check(lib.uzk_synth_scalars(ctypes.c_void_p(d_scalars), n, seed))
 
 
+def synth_scalars_mix(d_scalars: int, n: int, seed: int) -> None:
+    """Prover-like scalar mix (50 % zero, 20 % one, 10 % r-1, 10 % < 2^16, 10 % uniform)."""
+    check(lib.uzk_synth_scalars_mix(ctypes.c_void_p(d_scalars), n, seed))
+
+
 def field_op(field: str, op: int, a: np.ndarray, b: np.ndarray) -> np.ndarray:
     """Device field primitive applied element-wise (KATs).  field: 'fq' | 'fr'."""
     x = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)

@@ -91,23 +91,37 @@ int Ctx::prof_collect() {
     return UZK_OK;
 }
 
+// The device this process was last bound to by uzk_init: a lazy re-initialisation after uzk_shutdown
+// returns to it instead of silently moving to device 0.
+static int g_last_device = 0;
+
+static int bind_device(Ctx& c, int device) {
+    UZK_HIP(hipSetDevice(device));
+    UZK_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    hipDeviceProp_t prop;
+    UZK_HIP(hipGetDeviceProperties(&prop, device));
+    c.num_cus = prop.multiProcessorCount;
+    c.device = device;
+    c.ready = true;
+    g_last_device = device;
+    return UZK_OK;
+}
+
 int require_ready() {
     Ctx& c = ctx();
-    if (c.ready) return UZK_OK;
-    // lazy init on device 0 so a plain library user need not call uzk_init
+    if (c.ready) {
+        // HIP's current device is per thread: a prover thread that never called uzk_init would otherwise
+        // allocate and launch on device 0 while the stream and the SRS live on c.device
+        UZK_HIP(hipSetDevice(c.device));
+        return UZK_OK;
+    }
+    // lazy init (device 0, or the one uzk_init bound before a shutdown) so a plain library user need not call uzk_init
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
         set_error("no HIP device visible: the MI355X backend has no CPU fallback");
         return UZK_ERR_DEVICE;
     }
-    UZK_HIP(hipSetDevice(0));
-    UZK_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-    hipDeviceProp_t prop;
-    UZK_HIP(hipGetDeviceProperties(&prop, 0));
-    c.num_cus = prop.multiProcessorCount;
-    c.device = 0;
-    c.ready = true;
-    return UZK_OK;
+    return bind_device(c, g_last_device < n ? g_last_device : 0);
 }
 
 static const Fp* as_fp(const uint64_t* p) { return reinterpret_cast<const Fp*>(p); }
@@ -133,7 +147,7 @@ int uzk_init(int device) {
     API_LOCK;
     Ctx& c = ctx();
     if (c.ready) {
-        if (c.device == device) return UZK_OK;
+        if (c.device == device) { UZK_HIP(hipSetDevice(device)); return UZK_OK; }
         set_error("uzk_init(%d): already bound to device %d (one process per GPU)", device, c.device);
         return UZK_ERR_PARAMETER;
     }
@@ -146,20 +160,14 @@ int uzk_init(int device) {
         set_error("uzk_init(%d): %d device(s) visible", device, n);
         return UZK_ERR_PARAMETER;
     }
-    UZK_HIP(hipSetDevice(device));
-    UZK_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-    hipDeviceProp_t prop;
-    UZK_HIP(hipGetDeviceProperties(&prop, device));
-    c.num_cus = prop.multiProcessorCount;
-    c.device = device;
-    c.ready = true;
-    return UZK_OK;
+    return bind_device(c, device);
 }
 
 int uzk_shutdown(void) {
     API_LOCK;
     Ctx& c = ctx();
     if (!c.ready) return UZK_OK;
+    (void)hipSetDevice(c.device);
     (void)hipStreamSynchronize(c.stream);
     ntt_free_plans(c);
     msm_free(c);
@@ -222,6 +230,7 @@ int uzk_srs_release(uint64_t handle) {
     Ctx& c = ctx();
     auto it = c.srs.find(handle);
     if (it == c.srs.end()) { set_error("uzk_srs_release: unknown handle %llu", (unsigned long long)handle); return UZK_ERR_PARAMETER; }
+    if (c.ready) (void)hipSetDevice(c.device);
     (void)hipStreamSynchronize(c.stream);
     if (it->second.owned && it->second.d_points) (void)hipFree(it->second.d_points);
     if (it->second.d_table) (void)hipFree(it->second.d_table);
@@ -527,6 +536,15 @@ int uzk_synth_scalars(void* d_scalars, size_t n, uint64_t seed) {
     if (n > 0 && !d_scalars) { set_error("uzk_synth_scalars: null pointer"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
     UZK_TRY(synth_scalars(ctx(), static_cast<Fp*>(d_scalars), n, seed));
+    UZK_HIP(hipStreamSynchronize(ctx().stream));
+    return UZK_OK;
+}
+
+int uzk_synth_scalars_mix(void* d_scalars, size_t n, uint64_t seed) {
+    API_LOCK;
+    if (n > 0 && !d_scalars) { set_error("uzk_synth_scalars_mix: null pointer"); return UZK_ERR_PARAMETER; }
+    UZK_TRY(require_ready());
+    UZK_TRY(synth_scalars_mix(ctx(), static_cast<Fp*>(d_scalars), n, seed));
     UZK_HIP(hipStreamSynchronize(ctx().stream));
     return UZK_OK;
 }

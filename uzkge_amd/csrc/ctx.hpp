@@ -136,6 +136,7 @@ void msm_free(Ctx& c);
 int synth_points_arith(Ctx& c, Affine* d_points, size_t n, const Fp& seed_scalar_mont);
 int synth_points_random(Ctx& c, Affine* d_points, size_t n, uint64_t seed);
 int synth_scalars(Ctx& c, Fp* d_scalars, size_t n, uint64_t seed);
+int synth_scalars_mix(Ctx& c, Fp* d_scalars, size_t n, uint64_t seed);
 int poly_eval_batch(Ctx& c, const Fp* d_coefs, uint64_t n, uint32_t batch, const Fp& x, Fp* out_host);
 int poly_eval_batch_host(Ctx& c, const Fp* coefs_host, uint64_t n, uint32_t batch, const Fp& x, Fp* out_host);
 int open_quotient_run(Ctx& c, const Fp* d_polys, uint64_t n, uint32_t batch, const Fp& z, const Fp& alpha, Fp* d_q,

@@ -29,6 +29,7 @@
 #include <algorithm>
 #include <mutex>
 #include <functional>
+#include <memory>
 #include <condition_variable>
 #include <atomic>
 #include <cstring>
@@ -1307,40 +1308,50 @@ public:
     }
     // runs fn(i) for i in [0, count), the caller included; returns when all are done
     void run(uint32_t count, const std::function<void(uint32_t)>& fn) {
-        { std::lock_guard<std::mutex> lk(mu_); fn_ = &fn; count_ = count; next_.store(0); done_.store(0); ++gen_; }
+        // every call owns its counters: a worker that wakes late still holds the job it saw under the
+        // lock and can only find that job exhausted, never the next call's indices
+        auto job = std::make_shared<Job>();
+        job->fn = &fn;
+        job->count = count;
+        { std::lock_guard<std::mutex> lk(mu_); job_ = job; ++gen_; }
         cv_.notify_all();
-        work();
+        work(*job);
         std::unique_lock<std::mutex> lk(mu_);
-        cv_done_.wait(lk, [this] { return done_.load() >= count_; });
-        fn_ = nullptr;
+        cv_done_.wait(lk, [&] { return job->done.load() >= count; });
+        job_.reset();
     }
 private:
-    void work() {
+    struct Job {
+        const std::function<void(uint32_t)>* fn = nullptr;
+        uint32_t count = 0;
+        std::atomic<uint32_t> next{0}, done{0};
+    };
+    void work(Job& j) {
         for (;;) {
-            const uint32_t i = next_.fetch_add(1);
-            if (i >= count_) break;
-            (*fn_)(i);
-            if (done_.fetch_add(1) + 1 >= count_) { std::lock_guard<std::mutex> lk(mu_); cv_done_.notify_all(); }
+            const uint32_t i = j.next.fetch_add(1);
+            if (i >= j.count) break;
+            (*j.fn)(i);
+            if (j.done.fetch_add(1) + 1 >= j.count) { std::lock_guard<std::mutex> lk(mu_); cv_done_.notify_all(); }
         }
     }
     void loop() {
         uint64_t seen = 0;
         for (;;) {
+            std::shared_ptr<Job> j;
             {
                 std::unique_lock<std::mutex> lk(mu_);
                 cv_.wait(lk, [&] { return gen_ != seen; });
                 seen = gen_;
                 if (stop_) return;
+                j = job_;
             }
-            work();
+            if (j) work(*j);
         }
     }
     std::vector<std::thread> workers_;
     std::mutex mu_;
     std::condition_variable cv_, cv_done_;
-    const std::function<void(uint32_t)>* fn_ = nullptr;
-    uint32_t count_ = 0;
-    std::atomic<uint32_t> next_{0}, done_{0};
+    std::shared_ptr<Job> job_;
     uint64_t gen_ = 0;
     bool stop_ = false;
 };

@@ -33,6 +33,23 @@ __global__ __launch_bounds__(256) void synth_scalars_kernel(Fp* __restrict__ out
     out[i] = random_fe<Fr>(seed, i);
 }
 
+// The illustrative "prover-like" scalar mix of BASELINE.md section 4 / SURVEY.md 8d set (B): by a hash of the
+// index 50 % zero, 20 % one, 10 % r - 1, 10 % below 2^16, 10 % uniform (the value classes the witness
+// vectors of the real prover hold; the proportions are a placeholder).
+__global__ __launch_bounds__(256) void synth_scalars_mix_kernel(Fp* __restrict__ out, uint64_t n, uint64_t seed) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t h = splitmix64(seed ^ 0x6D69785F736574ull ^ splitmix64(i));
+    const uint32_t cls = (uint32_t)(((h >> 32) * 100) >> 32);
+    Fp r;
+    if (cls < 50) r = Fr::zero();
+    else if (cls < 70) r = Fr::one();
+    else if (cls < 80) r = Fr::neg(Fr::one());
+    else if (cls < 90) { Fp v = Fr::zero(); v.v[0] = (uint32_t)(h & 0xFFFF); r = Fr::to_mont(v); }
+    else r = random_fe<Fr>(seed, i);
+    out[i] = r;
+}
+
 // a^((p+1)/4) for the BN254 base field (p = 3 mod 4): square root candidate
 __device__ inline Fp fq_sqrt_candidate(const Fp& a) {
     // (p+1)/4, little-endian 32-bit words
@@ -122,6 +139,15 @@ int synth_scalars(Ctx& c, Fp* d_scalars, size_t n, uint64_t seed) {
     if (n == 0) return UZK_OK;
     KernelScope ks(c, "synth_scalars");
     hipLaunchKernelGGL(synth_scalars_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, d_scalars,
+                       (uint64_t)n, seed);
+    UZK_HIP(hipGetLastError());
+    return UZK_OK;
+}
+
+int synth_scalars_mix(Ctx& c, Fp* d_scalars, size_t n, uint64_t seed) {
+    if (n == 0) return UZK_OK;
+    KernelScope ks(c, "synth_scalars_mix");
+    hipLaunchKernelGGL(synth_scalars_mix_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, d_scalars,
                        (uint64_t)n, seed);
     UZK_HIP(hipGetLastError());
     return UZK_OK;
