@@ -142,6 +142,20 @@ def main() -> None:
     run_rank(args)
 
 
+def _host_cores() -> int:
+    """Host threads this process can really run at once: the affinity mask capped by the cgroup CPU quota
+    (the GPU box shows 256 logical CPUs but grants 16 CPUs' worth of time -- more threads than that only contend)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def _kernel_sources_sha() -> str:
     """sha256 over the sources of the two hot kernels: ties committed counter files to the code they measured."""
     import hashlib
@@ -531,7 +545,7 @@ def run_rank(args) -> None:
         m = min(n, 1 << 24)   # the whole default workload: a few seconds on the node's host cores
         hp = pts[:m].cpu().numpy().view(np.uint64).reshape(-1, 8)
         hs = sc[:m].cpu().numpy().view(np.uint64).reshape(-1, 4)
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        cores = _host_cores()
         tc = time.perf_counter()
         ref = oc.msm_pippenger(hp, hs, 0, cores)
         cpu_s = time.perf_counter() - tc
@@ -540,7 +554,7 @@ def run_rank(args) -> None:
         cpu_baseline = {
             "value": m / cpu_s, "unit": "points/s", "cores": cores, "kind": "port",
             "sample": f"first 2^{m.bit_length() - 1} points/scalars of the same workload, Pippenger in oracle/bn254_oracle.c "
-                      f"(own CPU restatement, not arkworks), one thread per host core this process may use",
+                      f"(own CPU restatement, not arkworks), one thread per host CPU this process may use (affinity mask capped by the cgroup quota)",
             "seconds": round(cpu_s, 3), "gpu_matches_cpu_on_sample": parity,
         }
         if "ntt" in extra:

@@ -149,6 +149,18 @@ int uzk_z_poly_device(const void* d_w, const uint32_t* d_perm, const void* d_gro
 int uzk_open_quotient_device(const void* d_polys, uint64_t n, uint32_t batch, const uint64_t* z_mont,
                              const uint64_t* alpha_mont, void* d_q, uint64_t* evals_out);
 
+/* The same on host arrays (polys: batch * n elements; q_out: n elements; evals_out: batch elements). */
+int uzk_open_quotient(const uint64_t* polys, uint64_t n, uint32_t batch, const uint64_t* z_mont, const uint64_t* alpha_mont,
+                      uint64_t* q_out, uint64_t* evals_out);
+
+/* The fold modulo X^N - 1 in front of every Lagrange-basis commit of a polynomial with len > N coefficients
+ * (batch_prove, uzkge/src/poly_commit/pcs.rs:137-156; split_t_and_commit, uzkge/src/plonk/helpers.rs:1366-1383):
+ *   blinds_out[i] = -coefs[N + i]  (i < len - N, host memory),
+ *   d_out[i] = coefs[i] + coefs[N + i] for i < len - N, coefs[i] for len - N <= i < min(len, N), 0 beyond  (N elements, device).
+ * len <= 2N.  The caller continues exactly as the reference: fft(N) of d_out, commit over the Lagrange SRS,
+ * apply_blind_factors(blinds, N).  d_out may alias d_coefs. */
+int uzk_fold_blinds_device(const void* d_coefs, uint64_t len, uint64_t n_fold, void* d_out, uint64_t* blinds_out);
+
 /* The quotient evaluations of t_poly on the coset k[1]*<g_m> (uzkge/src/plonk/helpers.rs:284-656 with
  * the "shuffle" feature; gate function turbo/mod.rs:193-222): for every point of the m = factor*n
  * domain, the 18 terms (gate, permutation, L1, booleanity, Anemoi round, shuffle/ECC selectors) are
@@ -226,7 +238,8 @@ int uzk_msm_set_window_bits(int c);
  * point is added into one bucket per window: n * windows mixed additions). */
 int uzk_msm_plan_info(size_t n, int* window_bits, int* windows);
 /* Experiment switches for A/B measurements in one process (keys: "msm_acc_variant",
- * "msm_task_len", "msm_no_precompute", "msm_fold_group", "msm_overlap", "msm_sort_packed", "msm_fused_hist", "msm_reduce_seg", "ntt_l29"); never needed for correctness. */
+ * "msm_task_len", "msm_no_precompute", "msm_fold_group", "msm_overlap", "msm_sort_packed", "msm_fused_hist", "msm_reduce_seg", "msm_scan_reduce",
+ * "msm_chunk_log", "ntt_l29"); never needed for correctness. */
 int uzk_tune(const char* key, int value);
 
 #ifdef __cplusplus

@@ -6,6 +6,7 @@
 // What lives here is what stays on the host in the Rust integration: trimming,
 // zero-padding, domain choice, length checks.  All arithmetic runs on the GPU.
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <optional>
@@ -139,10 +140,95 @@ class KZGCommitmentSchemeBN254 {
         check(uzk_msm_g1(handle_, 0, reinterpret_cast<const uint64_t*>(polynomial.get_coefs_ref().data()), degree + 1, &out));
         return out;
     }
+    // C += sum_i b_i * (SRS[i] - SRS[zeroing_degree + i])  (kzg_poly_commitment.rs:299-313)
+    G1Projective apply_blind_factors(const G1Projective& commitment, const std::vector<Fr>& blinds, size_t zeroing_degree) const {
+        if (blinds.empty()) return commitment;
+        G1Projective parts[3] = {commitment, {}, {}};
+        std::vector<Fr> neg = fr_neg(blinds);
+        check(uzk_msm_g1(handle_, 0, reinterpret_cast<const uint64_t*>(blinds.data()), blinds.size(), &parts[1]));
+        check(uzk_msm_g1(handle_, zeroing_degree, reinterpret_cast<const uint64_t*>(neg.data()), neg.size(), &parts[2]));
+        G1Projective out;
+        check(uzk_g1_fold(parts, 3, &out));
+        return out;
+    }
     uint64_t handle() const { return handle_; }
 
+    // element-wise field helpers of the host mirrors (device primitives through the KAT entry point)
+    static std::vector<Fr> fr_neg(const std::vector<Fr>& a) { return fr_op(5, a, a); }
+    static std::vector<Fr> fr_add(const std::vector<Fr>& a, const std::vector<Fr>& b) { return fr_op(1, a, b); }
+    static std::vector<Fr> fr_sub(const std::vector<Fr>& a, const std::vector<Fr>& b) { return fr_op(2, a, b); }
+
   private:
+    static std::vector<Fr> fr_op(int op, const std::vector<Fr>& a, const std::vector<Fr>& b) {
+        std::vector<Fr> out(a.size());
+        if (!a.empty())
+            check(uzk_field_op_device(/*Fr*/ 1, op, reinterpret_cast<const uint64_t*>(a.data()),
+                                      reinterpret_cast<const uint64_t*>(b.data()), reinterpret_cast<uint64_t*>(out.data()), a.size()));
+        return out;
+    }
     uint64_t handle_ = 0;
+};
+
+// uzkge/src/gen_params/mod.rs:151-183: the monomial SRS of a size-`size` circuit from the embedded blob -- powers
+// 0..2050, the identity up to `size`, then the three padding powers size, size + 1, size + 2.
+inline KZGCommitmentSchemeBN254* load_srs_params(const std::vector<uint8_t>& srs_blob, size_t size) {
+    if (size > 16384) throw UzkgeException(UzkgeError::ParameterError, "size exceeds the embedded SRS");
+    std::vector<G1Affine> g1;
+    {
+        auto full = KZGCommitmentSchemeBN254::from_unchecked_bytes(srs_blob);
+        g1 = full.public_parameter_group_1;
+    }
+    std::vector<G1Affine> out(std::max<size_t>(size + 3, 2051));
+    std::memset(out.data(), 0, out.size() * sizeof(G1Affine));
+    std::copy(g1.begin(), g1.begin() + 2051, out.begin());
+    const size_t pad = size == 4096 ? 2051 : size == 8192 ? 2054 : size == 16384 ? 2057 : 0;
+    if (pad) std::copy(g1.begin() + pad, g1.begin() + pad + 3, out.begin() + size);
+    return new KZGCommitmentSchemeBN254(std::move(out));
+}
+
+// The reference's `for i in (0..=degree).rev() { if (i & (i - 1)) == 0 { .. break } }` (pcs.rs:139-145,
+// helpers.rs:1367-1373): the largest power of two <= degree.
+inline size_t max_power_of_2(size_t degree) {
+    size_t p = 1;
+    while (p * 2 <= degree) p *= 2;
+    return p;
+}
+
+// The tail shared by batch_prove (pcs.rs:137-166, degree = q.degree()) and split_t_and_commit
+// (helpers.rs:1366-1394, degree = coefs.len()): fold the coefficients from max_power_of_2 on back onto the low
+// ones, fft(N), commit the evaluations over the Lagrange SRS, undo the fold with blind factors.
+inline G1Projective commit_folded_lagrange(const KZGCommitmentSchemeBN254& pcs, const KZGCommitmentSchemeBN254& lagrange_pcs,
+                                           const std::vector<Fr>& coefs, size_t degree) {
+    const size_t N = max_power_of_2(degree);
+    std::vector<Fr> hi(coefs.begin() + std::min(N, coefs.size()), coefs.end());
+    std::vector<Fr> blinds = KZGCommitmentSchemeBN254::fr_neg(hi);
+    std::vector<Fr> new_coefs(coefs.begin(), coefs.begin() + std::min(N, coefs.size()));
+    if (!hi.empty()) {
+        std::vector<Fr> low(new_coefs.begin(), new_coefs.begin() + hi.size());
+        std::vector<Fr> sum = KZGCommitmentSchemeBN254::fr_sub(low, blinds);            // coefs[i] - blinds[i]
+        std::copy(sum.begin(), sum.end(), new_coefs.begin());
+    }
+    auto sub_q = FpPolynomial::from_coefs(new_coefs);
+    auto q_eval = sub_q.fft(N);
+    if (!q_eval) throw UzkgeException(UzkgeError::FFTError, "no evaluation domain for the folded polynomial");
+    auto cm = lagrange_pcs.commit(FpPolynomial::from_coefs(*q_eval));
+    return pcs.apply_blind_factors(cm, blinds, N);
+}
+
+// The commit closure of prover_with_lagrange (prover.rs:125-149; twin in indexer.rs:284-299).
+struct ProverCommit {
+    const KZGCommitmentSchemeBN254& pcs;
+    const KZGCommitmentSchemeBN254* lagrange_pcs;      // null unless it has exactly n_constraints bases
+    size_t n_constraints;
+    ProverCommit(const KZGCommitmentSchemeBN254& p, const KZGCommitmentSchemeBN254* l, size_t n)
+        : pcs(p), lagrange_pcs((l && l->max_degree() + 1 == n) ? l : nullptr), n_constraints(n) {}
+    G1Projective operator()(const std::vector<Fr>& evals, const FpPolynomial& coef_polynomial, const std::vector<Fr>& blinds) const {
+        if (lagrange_pcs) {
+            auto cm = lagrange_pcs->commit(FpPolynomial::from_coefs(evals));
+            return pcs.apply_blind_factors(cm, blinds, n_constraints);
+        }
+        return pcs.commit(coef_polynomial);
+    }
 };
 
 }  // namespace uzkge

@@ -5,6 +5,8 @@
 // The naive side of each check uses the CPU oracle (test infrastructure).
 #include <cstdio>
 #include <fstream>
+#include <iterator>
+#include <memory>
 #include <random>
 #include "../../include/uzkge_poly_commit.hpp"
 
@@ -101,6 +103,30 @@ int main(int argc, char** argv) {
     try { std::vector<uint64_t> x(20, 0); check(uzk_ntt_fr(x.data(), 5, 0, nullptr)); }
     catch (const UzkgeException& e) { threw = e.kind == UzkgeError::FFTError; }
     EXPECT(threw);
+
+    // Lagrange path == monomial commit, pinned on the reference's parameter files (pcs.rs:137-166,
+    // gen_params/mod.rs:151-183): q has non-zero coefficients only where the monomial SRS holds real powers.
+    if (argc >= 3) {
+        std::ifstream fl(argv[2], std::ios::binary);
+        std::vector<uint8_t> lblob((std::istreambuf_iterator<char>(fl)), std::istreambuf_iterator<char>());
+        auto lag = KZGCommitmentSchemeBN254::from_unchecked_bytes(lblob);
+        const size_t N = lag.max_degree() + 1;
+        std::unique_ptr<KZGCommitmentSchemeBN254> mono(load_srs_params(blob, N));
+        EXPECT(mono->max_degree() + 1 == N + 3);
+        std::vector<Fr> q(N + 3);
+        for (size_t i = 0; i < 2051; ++i) q[i] = rand_fr(g);
+        for (size_t i = N; i < N + 3; ++i) q[i] = rand_fr(g);
+        auto direct = mono->commit(FpPolynomial::from_coefs(q));
+        auto folded = commit_folded_lagrange(*mono, lag, q, N + 2);
+        EXPECT(same_point(direct, folded));
+        // the prover's closure: Lagrange branch iff the sizes match, both branches commit to the same polynomial
+        std::vector<Fr> low(q.begin(), q.begin() + 2051);
+        auto p_low = FpPolynomial::from_coefs(low);
+        auto evals = *p_low.fft(N);
+        ProverCommit with(*mono, &lag, N), without(*mono, nullptr, N), wrong(*mono, &lag, N / 2);
+        EXPECT(with.lagrange_pcs == &lag && without.lagrange_pcs == nullptr && wrong.lagrange_pcs == nullptr);
+        EXPECT(same_point(with(evals, p_low, {}), without(evals, p_low, {})));
+    }
 
     std::printf(failures ? "FAILED (%d)\n" : "OK\n", failures);
     return failures ? 1 : 0;

@@ -30,5 +30,6 @@ def test_cpp_mirror_compiles_and_links():
 @pytest.mark.gpu
 def test_cpp_mirror_reference_tests(gpu):
     exe = _build()
-    r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "srs-padding.bin")], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "srs-padding.bin"),
+                        os.path.join(ROOT, "tests", "golden", "lagrange-srs-4096.bin")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr

@@ -1,0 +1,159 @@
+"""the Lagrange-basis commit path the real prover always takes (n >= 4096).
+
+  batch_prove tail          uzkge/src/poly_commit/pcs.rs:137-166
+  split_t_and_commit        uzkge/src/plonk/helpers.rs:1323-1408
+  prover commit closure     uzkge/src/plonk/prover.rs:125-149
+  load_srs_params           uzkge/src/gen_params/mod.rs:151-183
+
+PINNED ON REFERENCE DATA: for a polynomial whose non-zero coefficients sit where the reference's monomial SRS
+(`srs-padding.bin`: powers 0..2050 and the three padding powers N, N+1, N+2) is not the identity, the
+Lagrange path -- fold mod X^N - 1, fft(N), MSM over `lagrange-srs-N.bin`, blind factors -- must produce the same
+group element as the direct monomial commit: both sides are built from the reference's own parameter files,
+and the check exercises NTT + MSM + the fold together."""
+import os
+
+import numpy as np
+import pytest
+
+import bn254_py as opy
+import oracle_c as oc
+from util import GOLDEN, affine_of, rand_fr_wire
+
+pytestmark = pytest.mark.gpu
+
+
+def _blob(name):
+    return open(os.path.join(GOLDEN, name), "rb").read()
+
+
+@pytest.fixture(scope="module", params=[4096, 16384])
+def schemes(request, gpu):
+    from uzkge_amd.poly_commit import KZGCommitmentSchemeBN254, load_srs_params
+    n = request.param
+    pcs = load_srs_params(_blob("srs-padding.bin"), n)
+    lag = KZGCommitmentSchemeBN254.from_unchecked_bytes(_blob(f"lagrange-srs-{n}.bin"))
+    yield n, pcs, lag
+    pcs.release()
+    lag.release()
+
+
+def _sparse_poly(n, seed, top=3):
+    """n + top coefficients, non-zero only at 0..2050 and n..n+top-1 (where the monomial SRS has real powers)."""
+    c = np.zeros((n + top, 4), dtype=np.uint64)
+    c[:2051] = rand_fr_wire(2051, seed)
+    c[n:] = rand_fr_wire(top, seed + 1)
+    return c
+
+
+def test_load_srs_params_layout(schemes):
+    n, pcs, _ = schemes
+    g1 = pcs.public_parameter_group_1
+    file_pts = opy.parse_srs_g1(_blob("srs-padding.bin"))
+    assert g1.shape[0] == n + 3
+    assert np.array_equal(g1[:2051], oc.points_from_affine(file_pts[:2051]))
+    assert not g1[2051:n].any()                                     # identity between the powers and the padding
+    pad = {4096: 2051, 16384: 2057}[n]
+    assert np.array_equal(g1[n:], oc.points_from_affine(file_pts[pad:pad + 3]))
+
+
+def test_lagrange_path_equals_monomial_commit(schemes):
+    from uzkge_amd.poly_commit import FpPolynomial, commit_folded_lagrange
+    n, pcs, lag = schemes
+    q = _sparse_poly(n, 100 + n)
+    direct = affine_of(pcs.commit(FpPolynomial.from_coefs(q)))                       # MSM over the monomial SRS
+    via_lagrange = affine_of(commit_folded_lagrange(pcs, lag, q, n + 2))             # pcs.rs:137-166 with degree n + 2
+    assert direct is not None and via_lagrange == direct
+    # and the oracle agrees with the monomial side (MSM definition over the same reference points)
+    assert affine_of(oc.msm_pippenger(pcs.public_parameter_group_1, q, 0, 4)) == direct
+
+
+def test_prover_commit_closure_dispatch(schemes):
+    """prover.rs:125-149: the Lagrange SRS is used iff it has exactly n bases; both branches commit to the same
+    polynomial (evaluations + blinds on one side, hidden coefficient polynomial on the other)."""
+    from uzkge_amd.poly_commit import FpPolynomial, ProverCommit, hide_polynomial
+    n, pcs, lag = schemes
+    evals = rand_fr_wire(n, 7)
+    # the polynomial must stay inside the monomial SRS's real powers for the monomial branch: degree <= 2050
+    coefs = np.zeros((n, 4), dtype=np.uint64)
+    coefs[:2051] = rand_fr_wire(2051, 8)
+    evals = oc.ntt(coefs)                                                            # its evaluations over the size-n domain
+    blinds = rand_fr_wire(3, 9)
+    hidden = hide_polynomial(FpPolynomial.from_coefs(coefs), blinds, n)              # helpers.rs:139-158
+    with_lagrange = ProverCommit(pcs, lag, n)
+    without = ProverCommit(pcs, None, n)
+    wrong_size = ProverCommit(pcs, lag, n // 2)                                      # size mismatch -> monomial branch
+    assert with_lagrange.lagrange_pcs is lag and without.lagrange_pcs is None and wrong_size.lagrange_pcs is None
+    a = affine_of(with_lagrange(evals, hidden, blinds))
+    b = affine_of(without(evals, hidden, blinds))
+    assert a is not None and a == b
+
+
+def test_split_t_and_commit_five_chunks(schemes):
+    from uzkge_amd.poly_commit import FpPolynomial, split_t_and_commit
+    n, pcs, lag = schemes
+    t = np.zeros((4 * n + n + 2, 4), dtype=np.uint64)
+    for i in range(5):
+        t[i * n:i * n + 2051] = rand_fr_wire(2051, 40 + i)
+    t[5 * n:] = rand_fr_wire(2, 50)                       # the last chunk has n + 2 coefficients (helpers.rs:1337-1341)
+    rands = rand_fr_wire(5, 60)
+    cms_l, polys_l = split_t_and_commit(pcs, lag, FpPolynomial(t), 5, n, rands)
+    cms_m, polys_m = split_t_and_commit(pcs, None, FpPolynomial(t), 5, n, rands)
+    assert cms_l.shape == (5, 12)
+    for i in range(5):
+        assert polys_l[i] == polys_m[i]
+        a, b = affine_of(cms_l[i]), affine_of(cms_m[i])
+        assert a is not None and a == b
+    # the chunks recombine to t: sum_i X^(i (n+... )) is not needed -- the blinds telescope: chunk_i(X) carries
+    # + rand_i X^n and chunk_(i+1) carries - rand_i, so sum_i X^(i n) chunk_i(X) == t(X)
+    total = np.zeros(5 * n + n + 2 + 1, dtype=object)
+    for i, p in enumerate(polys_l):
+        for j, v in enumerate(oc.fr_to_ints(p.coefs)):
+            total[i * n + j] = (total[i * n + j] + v) % opy.R
+    want = oc.fr_to_ints(t)
+    assert [int(x) for x in total[: len(want)]] == want and not any(total[len(want):])
+
+
+def test_fold_blinds_device_matches_definition(gpu):
+    import torch
+    b = gpu
+    N = 4096
+    for length in (N + 3, N, N - 5, 2 * N, N + 1):
+        c = rand_fr_wire(length, 70 + length)
+        d_c = torch.from_numpy(c.view(np.int64)).cuda()
+        d_o = torch.empty((N, 4), dtype=torch.int64, device="cuda")
+        blinds = b.fold_blinds_device(d_c.data_ptr(), length, N, d_o.data_ptr())
+        b.sync()
+        ci = oc.fr_to_ints(c)
+        want = [(ci[i] if i < length else 0) for i in range(N)]
+        for i in range(max(0, length - N)):
+            want[i] = (want[i] + ci[N + i]) % opy.R
+        assert oc.fr_to_ints(d_o.cpu().numpy().view(np.uint64)) == want
+        assert oc.fr_to_ints(blinds) == [(-x) % opy.R for x in ci[N:]]
+
+
+def test_batch_prove_lagrange_chain_matches_oracle_chain(schemes):
+    """batch_prove with the Lagrange path on dense polynomials of degree n + 2 (16 of them at zeta in the prover,
+    prover.rs:329-347).  The quotient is dense, so the monomial SRS cannot check it; the comparison is against the
+    same chain on the CPU oracle (open_quotient restatement, NTT, MSM over the reference's Lagrange SRS, blinds)."""
+    from uzkge_amd.poly_commit import FpPolynomial, batch_prove
+    n, pcs, lag = schemes
+    batch = 4
+    polys = [FpPolynomial(rand_fr_wire(n + 3, 200 + k)) for k in range(batch)]
+    z, alpha = rand_fr_wire(1, 300)[0], rand_fr_wire(1, 301)[0]
+    cm, evals = batch_prove(pcs, lag, polys, z, alpha)
+    stack = np.stack([p.coefs for p in polys])
+    q, ev, rem_zero = oc.open_quotient(stack, z, alpha)
+    assert rem_zero and np.array_equal(evals, ev)
+    qi = oc.fr_to_ints(q)
+    assert qi[n + 2] == 0 and qi[n + 1] != 0                      # degree n + 1 -> max_power_of_2 = n, two blinds
+    folded = list(qi[:n])
+    for i in range(2):
+        folded[i] = (folded[i] + qi[n + i]) % opy.R
+    ev_q = oc.ntt(oc.fr_from_ints(folded))
+    want = affine_of(oc.msm_pippenger(lag.public_parameter_group_1, ev_q, 0, 4))
+    srs = [opy.wire_to_affine(pcs.public_parameter_group_1[i].tobytes()) for i in (0, 1, n, n + 1)]
+    for i in range(2):
+        blind = (-qi[n + i]) % opy.R
+        want = opy.g1_add(want, opy.g1_mul(srs[i], blind))
+        want = opy.g1_add(want, opy.g1_mul(srs[2 + i], (-blind) % opy.R))
+    assert affine_of(cm) == want

@@ -62,3 +62,35 @@ def test_shutdown_and_reinit(gpu):
         assert np.array_equal(gpu.ntt(x), oc.ntt(x))
     finally:
         srs2.release()
+
+
+def test_calls_from_a_fresh_thread_use_the_bound_device(gpu):
+    """HIP's current device is per thread: every entry point rebinds the calling thread to the device uzk_init
+    chose.  A thread that has never touched HIP registers an SRS, runs an MSM and an NTT."""
+    wire, _ = load_srs("lagrange-srs-4096.bin")
+    out = {}
+
+    def worker():
+        try:
+            srs = gpu.Srs.from_host(wire[:777])
+            s = rand_fr_wire(777, 21)
+            out["msm"] = affine_of(gpu.msm(srs, s)) == affine_of(oc.msm_pippenger(wire[:777], s, 0, 1))
+            x = rand_fr_wire(4096, 22)
+            out["ntt"] = bool(np.array_equal(gpu.ntt(x), oc.ntt(x)))
+            srs.release()
+        except Exception as e:   # noqa: BLE001
+            out["err"] = e
+
+    t = threading.Thread(target=worker)
+    t.start()
+    t.join()
+    assert out == {"msm": True, "ntt": True}, out
+
+
+def test_reinit_returns_to_the_last_bound_device(gpu):
+    """After uzk_shutdown a lazy re-initialisation (a compute call without uzk_init) goes back to the device the
+    process was bound to, not silently to device 0."""
+    gpu.shutdown()
+    x = rand_fr_wire(2048, 5)
+    assert np.array_equal(gpu.ntt(x), oc.ntt(x))       # lazy init
+    gpu.init(0)                                         # same ordinal: idempotent

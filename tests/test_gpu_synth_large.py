@@ -133,3 +133,68 @@ def test_maximum_size_chunked_closed_form(gpu):
     del pts, sc
     torch.cuda.empty_cache()
     assert got == opy.g1_mul(opy.g1_mul(opy.G1_GEN, seed_int), k)
+
+
+def test_random_2p20_points_vs_oracle(gpu):
+    """BASELINE config #2 literally: 2^20 random points and uniform scalars, the GPU result against the CPU
+    oracle's Pippenger over the same inputs."""
+    n = 1 << 20
+    pts = torch.empty((n, 8), dtype=torch.int64, device="cuda")
+    sc = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    gpu.synth_points_random(pts.data_ptr(), n, 0x755A6B67655F6D73)
+    gpu.synth_scalars(sc.data_ptr(), n, 0x5CA1AB1E)
+    srs = gpu.Srs.from_device(pts.data_ptr(), n)
+    try:
+        got = affine_of(gpu.msm_device(srs, sc.data_ptr(), n))
+    finally:
+        srs.release()
+    hp = pts.cpu().numpy().view(np.uint64).reshape(-1, 8)
+    hs = sc.cpu().numpy().view(np.uint64).reshape(-1, 4)
+    assert got is not None and got == affine_of(oc.msm_pippenger(hp, hs, 0, 16))
+
+
+def test_headline_paths_2p23_variants_agree(gpu):
+    """The code paths only the large configurations reach -- digits + first histogram in one kernel (needs >= 256
+    sort chunks, i.e. n >= 2^23), the 512-lane scatter of sorts with >= 2^26 entries -- against the separate
+    kernels and the canonical accumulator, on the same device-generated input."""
+    n = 1 << 23
+    pts = torch.empty((n, 8), dtype=torch.int64, device="cuda")
+    sc = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    gpu.synth_points_random(pts.data_ptr(), n, 77)
+    gpu.synth_scalars(sc.data_ptr(), n, 78)
+    srs = gpu.Srs.from_device(pts.data_ptr(), n)
+    try:
+        ref = affine_of(gpu.msm_device(srs, sc.data_ptr(), n))
+        for key, val in (("msm_fused_hist", 0), ("msm_acc_variant", 2), ("msm_sort_packed", 0)):
+            gpu.tune(key, val)
+            try:
+                assert affine_of(gpu.msm_device(srs, sc.data_ptr(), n)) == ref, key
+            finally:
+                gpu.tune(key, {"msm_fused_hist": 1, "msm_acc_variant": 0, "msm_sort_packed": 1}[key])
+        # split property ties the value to smaller, oracle-checked sizes
+        h1 = gpu.msm_device(srs, sc.data_ptr(), n // 2)
+        h2 = gpu.msm_device(srs, sc.data_ptr() + (n // 2) * 32, n // 2, offset=n // 2)
+        assert affine_of(gpu.g1_fold(np.stack([h1, h2]))) == ref
+    finally:
+        srs.release()
+
+
+def test_point_chunk_loop_small(gpu):
+    """The > 2^26-point chunk loop of the dispatcher (api.cpp msm_dispatch) with the chunk size lowered to 2^10:
+    3000 points run as three chunks whose partial sums are folded; same commitment as the single pass and the oracle."""
+    from util import load_srs, rand_fr_wire
+    wire, _ = load_srs("lagrange-srs-4096.bin")
+    s = rand_fr_wire(3000, 31)
+    srs = gpu.Srs.from_host(wire)
+    try:
+        one = affine_of(gpu.msm(srs, s))
+        gpu.tune("msm_chunk_log", 10)
+        try:
+            chunked = affine_of(gpu.msm(srs, s))
+        finally:
+            gpu.tune("msm_chunk_log", 26)
+    finally:
+        srs.release()
+    assert chunked == one == affine_of(oc.msm_pippenger(wire[:3000], s, 0, 2))

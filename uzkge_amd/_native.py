@@ -49,6 +49,8 @@ PROTOTYPES = {
     "uzk_z_poly_device": (_I, [_P, _P, _P, _P, _P, _P, ctypes.c_uint32, ctypes.c_uint32, _P]),
     "uzk_t_quotient_device": (_I, [_P, _P, _I]),
     "uzk_open_quotient_device": (_I, [_P, ctypes.c_uint64, ctypes.c_uint32, _P, _P, _P, _P]),
+    "uzk_open_quotient": (_I, [_P, ctypes.c_uint64, ctypes.c_uint32, _P, _P, _P, _P]),
+    "uzk_fold_blinds_device": (_I, [_P, ctypes.c_uint64, ctypes.c_uint64, _P, _P]),
     "uzk_synth_points_arith": (_I, [_P, _SZ, _P]),
     "uzk_synth_points_random": (_I, [_P, _SZ, _U64]),
     "uzk_synth_scalars": (_I, [_P, _SZ, _U64]),

@@ -214,6 +214,26 @@ def open_quotient_device(d_polys: int, n: int, batch: int, z: np.ndarray, alpha:
     return ev
 
 
+def open_quotient(polys: np.ndarray, z: np.ndarray, alpha: np.ndarray):
+    """Host-array form of open_quotient_device: polys [batch, n, 4] -> (q [n, 4] with a trailing zero, evals [batch, 4])."""
+    p = np.ascontiguousarray(polys, dtype=np.uint64)
+    assert p.ndim == 3 and p.shape[2] == 4
+    batch, n = p.shape[0], p.shape[1]
+    q = np.zeros((n, 4), dtype=np.uint64)
+    ev = np.zeros((batch, 4), dtype=np.uint64)
+    check(lib.uzk_open_quotient(_ptr(p), n, batch, _ptr(np.ascontiguousarray(z, dtype=np.uint64).reshape(4)),
+                                _ptr(np.ascontiguousarray(alpha, dtype=np.uint64).reshape(4)), _ptr(q), _ptr(ev)))
+    return q, ev
+
+
+def fold_blinds_device(d_coefs: int, length: int, n_fold: int, d_out: int) -> np.ndarray:
+    """Fold modulo X^N - 1 on the device (pcs.rs:137-156 / helpers.rs:1366-1383); returns blinds [len - N, 4]."""
+    nb = max(0, length - n_fold)
+    blinds = np.zeros((max(nb, 1), 4), dtype=np.uint64)
+    check(lib.uzk_fold_blinds_device(ctypes.c_void_p(d_coefs), length, n_fold, ctypes.c_void_p(d_out), _ptr(blinds)))
+    return blinds[:nb]
+
+
 def t_quotient_device(n: int, factor: int, vec_ptrs, alpha, beta, gamma, k, anemoi_g, anemoi_g_inv, edwards_a,
                       z_h_inv, d_out: int, sync: bool = True) -> None:
     """The quotient evaluations of t_poly (helpers.rs:284-656) on device-resident coset evaluations.

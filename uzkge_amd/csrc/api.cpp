@@ -295,7 +295,7 @@ static int msm_dispatch_one(const Ctx::Srs& s, size_t offset, const Fp* d_scalar
 // scalar vector (2^26 * 16 windows); longer inputs are cut into point chunks whose partial sums are
 // folded on the host -- the same decomposition the multi-GPU path uses across ranks.
 static int msm_dispatch(const Ctx::Srs& s, size_t offset, const Fp* d_scalars, size_t n, uint32_t batch, Jac* out) {
-    const size_t kChunk = (size_t)1 << 26;
+    const size_t kChunk = (size_t)1 << ctx().tune_chunk_log;
     if (n <= kChunk || batch != 1) return msm_dispatch_one(s, offset, d_scalars, n, batch, out);
     XYZZ acc = xyzz_inf();
     for (size_t lo = 0; lo < n; lo += kChunk) {
@@ -496,6 +496,31 @@ int uzk_open_quotient_device(const void* d_polys, uint64_t n, uint32_t batch, co
                              static_cast<Fp*>(d_q), reinterpret_cast<Fp*>(evals_out));
 }
 
+int uzk_open_quotient(const uint64_t* polys, uint64_t n, uint32_t batch, const uint64_t* z_mont, const uint64_t* alpha_mont,
+                      uint64_t* q_out, uint64_t* evals_out) {
+    API_LOCK;
+    if (!polys || !z_mont || !alpha_mont || !q_out || !evals_out) { set_error("uzk_open_quotient: null pointer"); return UZK_ERR_PARAMETER; }
+    if (n == 0 || batch == 0) { set_error("uzk_open_quotient: need batch > 0 and n > 0"); return UZK_ERR_PARAMETER; }
+    UZK_TRY(require_ready());
+    Ctx& c = ctx();
+    const size_t in_bytes = (size_t)n * batch * sizeof(Fp);
+    UZK_TRY(c.poly_io.reserve(in_bytes + (size_t)n * sizeof(Fp)));
+    Fp* d_p = c.poly_io.as<Fp>();
+    Fp* d_q = d_p + (size_t)n * batch;
+    UZK_HIP(hipMemcpyAsync(d_p, polys, in_bytes, hipMemcpyHostToDevice, c.stream));
+    UZK_TRY(open_quotient_run(c, d_p, n, batch, *as_fp(z_mont), *as_fp(alpha_mont), d_q, reinterpret_cast<Fp*>(evals_out)));
+    UZK_HIP(hipMemcpyAsync(q_out, d_q, (size_t)n * sizeof(Fp), hipMemcpyDeviceToHost, c.stream));
+    UZK_HIP(hipStreamSynchronize(c.stream));
+    return UZK_OK;
+}
+
+int uzk_fold_blinds_device(const void* d_coefs, uint64_t len, uint64_t n_fold, void* d_out, uint64_t* blinds_out) {
+    API_LOCK;
+    if (!d_coefs || !d_out || (len > n_fold && !blinds_out)) { set_error("uzk_fold_blinds_device: null pointer"); return UZK_ERR_PARAMETER; }
+    UZK_TRY(require_ready());
+    return fold_blinds_run(ctx(), static_cast<const Fp*>(d_coefs), len, n_fold, static_cast<Fp*>(d_out), reinterpret_cast<Fp*>(blinds_out));
+}
+
 int uzk_t_quotient_device(const uzk_quotient_args* args, void* d_out, int sync) {
     API_LOCK;
     if (!args || !d_out) { set_error("uzk_t_quotient_device: null pointer"); return UZK_ERR_PARAMETER; }
@@ -646,6 +671,7 @@ int uzk_tune(const char* key, int value) {
     else if (!std::strcmp(key, "msm_fused_hist")) c.tune_fused_hist = value;
     else if (!std::strcmp(key, "msm_reduce_seg")) c.tune_reduce_seg = value;
     else if (!std::strcmp(key, "msm_scan_reduce")) c.tune_scan_reduce = value;
+    else if (!std::strcmp(key, "msm_chunk_log")) c.tune_chunk_log = (value >= 8 && value <= 26) ? value : 26;
     else { set_error("uzk_tune: unknown key %s", key); return UZK_ERR_PARAMETER; }
     return UZK_OK;
 }

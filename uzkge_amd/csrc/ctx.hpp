@@ -79,7 +79,16 @@ struct Ctx {
     int tune_fused_hist = 1;  // 1: the digit kernel also produces the first sort pass's histograms (large n)
     int tune_sort_packed = 1; // 1: 4-byte entries between the two sort passes when the fields fit
     int tune_ntt_l29 = 1;     // 1: NTT passes on the 29-bit-limb representation (0: 8x32-bit relaxed Montgomery)
+    int tune_chunk_log = 26;  // point-chunk size of one sort pass (tests lower it to reach the chunk loop at small n)
     int tune_overlap = 0;     // 1: run large MSMs as two overlapping pipeline instances (experiment)  // 1: force one lane per bucket in the fold kernels
+    // poly.hip workspaces (grow-only)
+    DevBuf poly_tmp, poly_tmp2, poly_io, zpoly_tmp, open_tmp;
+    // ntt.hip: decimated sub-vectors of the small 3 * 2^k path; three-level power tables of arbitrary
+    // elements (coset shifts, mixed-radix roots) cached by VALUE, least recently used entry replaced
+    DevBuf ntt_sub;
+    struct PowCache { Fp key; bool valid = false; uint64_t stamp = 0; DevBuf buf; };
+    PowCache pow_cache[8];
+    uint64_t pow_stamp = 0;
     // SRS registry
     struct Srs {
         Affine* d_points = nullptr;
@@ -141,6 +150,7 @@ int poly_eval_batch(Ctx& c, const Fp* d_coefs, uint64_t n, uint32_t batch, const
 int poly_eval_batch_host(Ctx& c, const Fp* coefs_host, uint64_t n, uint32_t batch, const Fp& x, Fp* out_host);
 int open_quotient_run(Ctx& c, const Fp* d_polys, uint64_t n, uint32_t batch, const Fp& z, const Fp& alpha, Fp* d_q,
                       Fp* evals_host);
+int fold_blinds_run(Ctx& c, const Fp* d_coefs, uint64_t len, uint64_t N, Fp* d_out, Fp* blinds_host);
 struct QuotientDev;
 int t_quotient_run(Ctx& c, const void* args_c_abi, Fp* d_out);
 int z_poly_device(Ctx& c, const Fp* d_w, const uint32_t* d_perm, const Fp* d_group, const Fp* k_host, const Fp& beta,

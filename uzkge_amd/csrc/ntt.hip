@@ -578,7 +578,7 @@ static int get_plan(Ctx& c, uint64_t n, bool inverse, bool scaled, NttPlan** out
     return UZK_OK;
 }
 
-static void release_ntt_caches();
+static void release_ntt_caches(Ctx& c);
 void ntt_free_plans(Ctx& c) {
     for (auto& kv : c.ntt_plans) {
         NttPlan* p = kv.second;
@@ -589,7 +589,7 @@ void ntt_free_plans(Ctx& c) {
         delete p;
     }
     c.ntt_plans.clear();
-    release_ntt_caches();
+    release_ntt_caches(c);
 }
 
 template <int B>
@@ -662,32 +662,31 @@ static int ntt_pow2(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse,
     return UZK_OK;
 }
 
-// three-level power table of an arbitrary element, cached on the last value
-struct PowCache {
-    Fp key;
-    bool valid = false;
-    DevBuf buf;
-};
-static PowCache g_coset_cache, g_mixed_cache[2];
-static DevBuf g_sub;   // decimated sub-vectors of the 3 * 2^k path
-
-static void release_ntt_caches() {
-    g_coset_cache.buf.release(); g_coset_cache.valid = false;
-    for (auto& m : g_mixed_cache) { m.buf.release(); m.valid = false; }
-    g_sub.release();
+// three-level power table of an arbitrary element, cached by value (a proof alternates between k and 1/k and
+// between the forward and inverse mixed-radix roots: all of them stay resident, a hit costs nothing)
+static void release_ntt_caches(Ctx& c) {
+    for (auto& pc : c.pow_cache) { pc.buf.release(); pc.valid = false; }
+    c.ntt_sub.release();
 }
 
-static int pow_table_device(Ctx& c, PowCache& pc, const Fp& g, const Fp** out) {
-    if (!pc.valid || !Fr::eq(pc.key, g)) {
-        std::vector<Fp> pw;
-        host_pow_tables(g, pw);
-        UZK_TRY(pc.buf.reserve(pw.size() * sizeof(Fp)));
-        UZK_HIP(hipMemcpyAsync(pc.buf.p, pw.data(), pw.size() * sizeof(Fp), hipMemcpyHostToDevice, c.stream));
-        UZK_HIP(hipStreamSynchronize(c.stream));
-        pc.key = g;
-        pc.valid = true;
+static int pow_table_device(Ctx& c, const Fp& g, const Fp** out) {
+    for (auto& pc : c.pow_cache)
+        if (pc.valid && Fr::eq(pc.key, g)) { pc.stamp = ++c.pow_stamp; *out = pc.buf.as<Fp>(); return UZK_OK; }
+    Ctx::PowCache* slot = &c.pow_cache[0];          // first free entry, else the least recently used one
+    for (auto& pc : c.pow_cache) {
+        if (!pc.valid) { slot = &pc; break; }
+        if (pc.stamp < slot->stamp) slot = &pc;
     }
-    *out = pc.buf.as<Fp>();
+    std::vector<Fp> pw;
+    host_pow_tables(g, pw);
+    UZK_TRY(slot->buf.reserve(pw.size() * sizeof(Fp)));
+    // the slot being replaced may still be read by kernels in flight on this stream; the copy is ordered after them
+    UZK_HIP(hipMemcpyAsync(slot->buf.p, pw.data(), pw.size() * sizeof(Fp), hipMemcpyHostToDevice, c.stream));
+    UZK_HIP(hipStreamSynchronize(c.stream));      // pw is a host vector of this call
+    slot->key = g;
+    slot->valid = true;
+    slot->stamp = ++c.pow_stamp;
+    *out = slot->buf.as<Fp>();
     return UZK_OK;
 }
 
@@ -703,7 +702,7 @@ int ntt_run(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse, const F
     const Fp* src = d_in;
     if (coset_shift_host != nullptr && !inverse) {
         const Fp* pw = nullptr;
-        UZK_TRY(pow_table_device(c, g_coset_cache, *coset_shift_host, &pw));
+        UZK_TRY(pow_table_device(c, *coset_shift_host, &pw));
         KernelScope ks(c, "ntt_scale_pows");
         hipLaunchKernelGGL(ntt_scale_pows_kernel, egrid, dim3(256), 0, c.stream, src, d_out, n, pw);
         src = d_out;
@@ -713,8 +712,8 @@ int ntt_run(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse, const F
     } else {
         // decimation in time by 3: per vector, sub[k][j] = x[3j + k]; 3*batch transforms of size m
         const uint64_t m = n / 3;
-        UZK_TRY(g_sub.reserve((size_t)n * batch * sizeof(Fp)));
-        Fp* s = g_sub.as<Fp>();
+        UZK_TRY(c.ntt_sub.reserve((size_t)n * batch * sizeof(Fp)));
+        Fp* s = c.ntt_sub.as<Fp>();
         {
             KernelScope ks(c, "ntt_decimate3");
             hipLaunchKernelGGL(ntt_decimate3_kernel, egrid, dim3(256), 0, c.stream, src, s, m);
@@ -723,14 +722,14 @@ int ntt_run(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse, const F
         Fp w = fr_root_of_unity(n);
         if (inverse) w = fr_inv(w);
         const Fp* pw = nullptr;
-        UZK_TRY(pow_table_device(c, g_mixed_cache[inverse ? 1 : 0], w, &pw));
+        UZK_TRY(pow_table_device(c, w, &pw));
         Fp scale = inverse ? fr_inv(fr_from_u64(n)) : Fr::one();
         KernelScope ks(c, "ntt_combine3");
         hipLaunchKernelGGL(ntt_combine3_kernel, egrid, dim3(256), 0, c.stream, s, d_out, m, pw, scale, inverse ? 1 : 0);
     }
     if (coset_shift_host != nullptr && inverse) {
         const Fp* pw = nullptr;
-        UZK_TRY(pow_table_device(c, g_coset_cache, *coset_shift_host, &pw));
+        UZK_TRY(pow_table_device(c, *coset_shift_host, &pw));
         KernelScope ks(c, "ntt_scale_pows");
         hipLaunchKernelGGL(ntt_scale_pows_kernel, egrid, dim3(256), 0, c.stream, d_out, d_out, n, pw);
     }

@@ -132,15 +132,14 @@ __global__ __launch_bounds__(64) void poly_eval_finish_kernel(const Fp* __restri
     out[b] = acc;
 }
 
-static DevBuf g_poly_tmp, g_poly_tmp2, g_poly_io, g_zpoly_tmp;
 
 int poly_eval_batch(Ctx& c, const Fp* d_coefs, uint64_t n, uint32_t batch, const Fp& x, Fp* out_host) {
     if (batch == 0) return UZK_OK;
     if (n == 0) { for (uint32_t b = 0; b < batch; ++b) out_host[b] = Fr::zero(); return UZK_OK; }
     if (batch > 65535) { set_error("poly_eval: batch %u exceeds 65535", batch); return UZK_ERR_PARAMETER; }
     const uint32_t nblocks = (uint32_t)((n + kEvalBlock - 1) / kEvalBlock);
-    UZK_TRY(g_poly_tmp.reserve(((size_t)256 + nblocks + (size_t)batch * nblocks + batch) * sizeof(Fp)));
-    Fp* tab = g_poly_tmp.as<Fp>();
+    UZK_TRY(c.poly_tmp.reserve(((size_t)256 + nblocks + (size_t)batch * nblocks + batch) * sizeof(Fp)));
+    Fp* tab = c.poly_tmp.as<Fp>();
     Fp* partial = tab + 256 + nblocks;
     Fp* d_out = partial + (size_t)batch * nblocks;
     {
@@ -205,8 +204,8 @@ int z_poly_device(Ctx& c, const Fp* d_w, const uint32_t* d_perm, const Fp* d_gro
         return UZK_OK;
     }
     // workspace: num | den | P | S
-    UZK_TRY(g_zpoly_tmp.reserve(4 * (size_t)n * sizeof(Fp)));
-    Fp* d_num = g_zpoly_tmp.as<Fp>();
+    UZK_TRY(c.zpoly_tmp.reserve(4 * (size_t)n * sizeof(Fp)));
+    Fp* d_num = c.zpoly_tmp.as<Fp>();
     Fp* d_den = d_num + n;
     Fp* d_P = d_den + n;
     Fp* d_S = d_P + n;
@@ -219,8 +218,8 @@ int z_poly_device(Ctx& c, const Fp* d_w, const uint32_t* d_perm, const Fp* d_gro
         KernelScope ks(c, "z_poly_terms");
         hipLaunchKernelGGL(z_poly_terms_kernel, dim3((m + 255) / 256), dim3(256), 0, c.stream, a, d_num, d_den);
     }
-    UZK_TRY(fr_scan_mul(c, d_num, d_P, m, false, g_poly_tmp));
-    UZK_TRY(fr_scan_mul(c, d_den, d_S, m, true, g_poly_tmp2));
+    UZK_TRY(fr_scan_mul(c, d_num, d_P, m, false, c.poly_tmp));
+    UZK_TRY(fr_scan_mul(c, d_den, d_S, m, true, c.poly_tmp2));
     Fp total;
     UZK_HIP(hipMemcpyAsync(&total, d_S, sizeof(Fp), hipMemcpyDeviceToHost, c.stream));
     UZK_HIP(hipStreamSynchronize(c.stream));
@@ -245,8 +244,8 @@ int z_poly_run(Ctx& c, const Fp* w_host, const uint32_t* perm_host, const Fp* gr
     if (n_wires == 0 || n_wires > 8) { set_error("z_poly: n_wires must be 1..8"); return UZK_ERR_PARAMETER; }
     const size_t wn = (size_t)n_wires * n;
     // staging: w | group | z (Fp), perm (u32)
-    UZK_TRY(g_poly_io.reserve((wn + 2 * (size_t)n) * sizeof(Fp) + wn * sizeof(uint32_t)));
-    Fp* d_w = g_poly_io.as<Fp>();
+    UZK_TRY(c.poly_io.reserve((wn + 2 * (size_t)n) * sizeof(Fp) + wn * sizeof(uint32_t)));
+    Fp* d_w = c.poly_io.as<Fp>();
     Fp* d_group = d_w + wn;
     Fp* d_z = d_group + n;
     uint32_t* d_perm = reinterpret_cast<uint32_t*>(d_z + n);
@@ -517,7 +516,6 @@ __global__ __launch_bounds__(256) void open_div_apply_kernel(const Fp* __restric
     q[i - 1] = v;
 }
 
-static DevBuf g_open_tmp;
 
 int open_quotient_run(Ctx& c, const Fp* d_polys, uint64_t n, uint32_t batch, const Fp& z, const Fp& alpha, Fp* d_q,
                       Fp* evals_host) {
@@ -530,8 +528,8 @@ int open_quotient_run(Ctx& c, const Fp* d_polys, uint64_t n, uint32_t batch, con
     for (uint32_t k = 0; k < batch; ++k) { apow[k] = a; E = Fr::add(E, Fr::mul(a, evals_host[k])); a = Fr::mul(a, alpha); }
     const uint32_t nblocks = (uint32_t)((n + kDivBlock - 1) / kDivBlock);
     // layout: apow[batch] | h[n] | s[n] | block_first[256] | carry[256] | ztab16[257]
-    UZK_TRY(g_open_tmp.reserve(((size_t)batch + 2 * n + 256 + 256 + 257) * sizeof(Fp)));
-    Fp* d_apow = g_open_tmp.as<Fp>();
+    UZK_TRY(c.open_tmp.reserve(((size_t)batch + 2 * n + 256 + 256 + 257) * sizeof(Fp)));
+    Fp* d_apow = c.open_tmp.as<Fp>();
     Fp* d_h = d_apow + batch;
     Fp* d_s = d_h + n;
     Fp* d_first = d_s + n;
@@ -562,22 +560,58 @@ int open_quotient_run(Ctx& c, const Fp* d_polys, uint64_t n, uint32_t batch, con
     return UZK_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The fold modulo X^N - 1 that precedes every Lagrange-basis commit of a polynomial with more than N
+// coefficients (batch_prove, uzkge/src/poly_commit/pcs.rs:137-156; split_t_and_commit,
+// uzkge/src/plonk/helpers.rs:1366-1383):  blinds[i] = -coefs[N + i];  out[i] = coefs[i] - blinds[i] for
+// i < len - N, out[i] = coefs[i] otherwise.  out has N elements (zero beyond len when len < N).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fold_blinds_kernel(const Fp* __restrict__ coefs, uint64_t len, uint64_t N,
+                                                          Fp* __restrict__ out, Fp* __restrict__ blinds) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    Fp v = i < len ? coefs[i] : Fr::zero();
+    if (N + i < len) {
+        const Fp hi = coefs[N + i];
+        blinds[i] = Fr::neg(hi);
+        v = Fr::add(v, hi);
+    }
+    out[i] = v;
+}
+
+int fold_blinds_run(Ctx& c, const Fp* d_coefs, uint64_t len, uint64_t N, Fp* d_out, Fp* blinds_host) {
+    if (N == 0 || len > 2 * N) { set_error("fold_blinds: need N > 0 and len <= 2N (len %llu, N %llu)", (unsigned long long)len, (unsigned long long)N); return UZK_ERR_PARAMETER; }
+    const uint64_t nb = len > N ? len - N : 0;
+    UZK_TRY(c.poly_tmp2.reserve((size_t)(nb ? nb : 1) * sizeof(Fp)));
+    {
+        KernelScope ks(c, "fold_blinds");
+        hipLaunchKernelGGL(fold_blinds_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c.stream, d_coefs, len, N, d_out,
+                           c.poly_tmp2.as<Fp>());
+    }
+    UZK_HIP(hipGetLastError());
+    if (nb) {
+        UZK_HIP(hipMemcpyAsync(blinds_host, c.poly_tmp2.p, nb * sizeof(Fp), hipMemcpyDeviceToHost, c.stream));
+        UZK_HIP(hipStreamSynchronize(c.stream));
+    }
+    return UZK_OK;
+}
+
 int poly_eval_batch_host(Ctx& c, const Fp* coefs_host, uint64_t n, uint32_t batch, const Fp& x, Fp* out_host) {
     if (batch == 0) return UZK_OK;
     const size_t bytes = (size_t)n * batch * sizeof(Fp);
     if (bytes) {
-        UZK_TRY(g_poly_io.reserve(bytes));
-        UZK_HIP(hipMemcpyAsync(g_poly_io.p, coefs_host, bytes, hipMemcpyHostToDevice, c.stream));
+        UZK_TRY(c.poly_io.reserve(bytes));
+        UZK_HIP(hipMemcpyAsync(c.poly_io.p, coefs_host, bytes, hipMemcpyHostToDevice, c.stream));
     }
-    return poly_eval_batch(c, g_poly_io.as<Fp>(), n, batch, x, out_host);
+    return poly_eval_batch(c, c.poly_io.as<Fp>(), n, batch, x, out_host);
 }
 
-void poly_free(Ctx&) {
-    g_poly_tmp.release();
-    g_poly_tmp2.release();
-    g_poly_io.release();
-    g_zpoly_tmp.release();
-    g_open_tmp.release();
+void poly_free(Ctx& c) {
+    c.poly_tmp.release();
+    c.poly_tmp2.release();
+    c.poly_io.release();
+    c.zpoly_tmp.release();
+    c.open_tmp.release();
 }
 
 }  // namespace uzk

@@ -203,3 +203,144 @@ class KZGCommitmentSchemeBN254:
 
     def release(self) -> None:
         self._srs.release()
+
+
+# ---------------------------------------------------------------------------------------------------
+# The callers of the two primitives inside the prover: the Lagrange-basis commit path.
+#   prover commit closure        uzkge/src/plonk/prover.rs:125-149
+#   PolyComScheme::batch_prove   uzkge/src/poly_commit/pcs.rs:107-168
+#   split_t_and_commit           uzkge/src/plonk/helpers.rs:1323-1408
+# Fiat-Shamir (Keccak transcript) and the prover's RNG are out of scope: the
+# challenge `alpha` and the random blinds are arguments here, where the Rust draws them.
+# ---------------------------------------------------------------------------------------------------
+def fr_add_rows(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """a + b on wire-format rows (Montgomery form is linear)."""
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+    b = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 4)
+    out = np.zeros_like(a)
+    for i in range(a.shape[0]):
+        v = (_wire_int(a[i]) + _wire_int(b[i])) % FR_MODULUS
+        out[i] = [(v >> (64 * k)) & _MASK64 for k in range(4)]
+    return out
+
+
+def max_power_of_2(degree: int) -> int:
+    """The reference's loop `for i in (0..=degree).rev() { if (i & (i - 1)) == 0 {..break} }`
+    (pcs.rs:139-145, helpers.rs:1367-1373): the largest power of two <= degree (degree >= 1)."""
+    assert degree >= 1
+    return 1 << (degree.bit_length() - 1)
+
+
+def commit_folded_lagrange(pcs: KZGCommitmentSchemeBN254, lagrange_pcs: KZGCommitmentSchemeBN254, coefs: np.ndarray,
+                           degree: int) -> np.ndarray:
+    """The tail shared by batch_prove (pcs.rs:137-166, `degree` = q.degree()) and split_t_and_commit
+    (helpers.rs:1366-1394, `degree` = coefs.len()): fold the coefficients from max_power_of_2 on back onto
+    the low ones, fft(N), commit the evaluations over the Lagrange SRS, undo the fold with blind factors."""
+    c = np.ascontiguousarray(coefs, dtype=np.uint64).reshape(-1, 4)
+    npow = max_power_of_2(degree)
+    blinds = fr_neg(c[npow:])
+    new_coefs = c[:npow].copy()
+    if blinds.shape[0]:
+        new_coefs[: blinds.shape[0]] = fr_add_rows(new_coefs[: blinds.shape[0]], c[npow:])    # coefs[i] - blinds[i]
+    sub_q = FpPolynomial.from_coefs(new_coefs)
+    q_eval = sub_q.fft(npow)
+    if q_eval is None:
+        raise UzkgeError(N.UZK_ERR_FFT, "no evaluation domain for the folded polynomial")
+    cm = lagrange_pcs.commit(FpPolynomial.from_coefs(q_eval))
+    return pcs.apply_blind_factors(cm, blinds, npow)
+
+
+def batch_prove(pcs: KZGCommitmentSchemeBN254, lagrange_pcs: Optional[KZGCommitmentSchemeBN254],
+                polys: Sequence[FpPolynomial], point: np.ndarray, alpha: np.ndarray):
+    """PolyComScheme::batch_prove's default body (pcs.rs:107-168) with `alpha` given instead of drawn from the
+    transcript.  Returns (commitment of q, evaluations p_k(point) [len(polys), 4]).  The evaluations, the linear
+    combination and the division by X - point run on the device (uzk_open_quotient)."""
+    assert len(polys) > 0
+    n = max(p.coefs.shape[0] for p in polys)
+    stack = np.zeros((len(polys), n, 4), dtype=np.uint64)
+    for k, p in enumerate(polys):
+        stack[k, : p.coefs.shape[0]] = p.coefs
+    q_rows, evals = B.open_quotient(stack, point, alpha)
+    q = FpPolynomial.from_coefs(q_rows)
+    if lagrange_pcs is not None:
+        return commit_folded_lagrange(pcs, lagrange_pcs, q.coefs, q.degree()), evals
+    return pcs.commit(q), evals
+
+
+def split_t_and_commit(pcs: KZGCommitmentSchemeBN254, lagrange_pcs: Optional[KZGCommitmentSchemeBN254], t: FpPolynomial,
+                       n_wires_per_gate: int, n: int, rands: np.ndarray):
+    """helpers.rs:1323-1408 with the prover's random blinds `rands` [n_wires_per_gate, 4] given: chunk i of t gets
+    + rand_i * X^n and - rand_(i-1); every chunk is committed (Lagrange path: fold, fft, commit, blinds).
+    Returns (commitments [n_wires_per_gate, 12], chunk polynomials)."""
+    coefs_all = t.get_coefs_ref()
+    coefs_len = coefs_all.shape[0]
+    rands = np.ascontiguousarray(rands, dtype=np.uint64).reshape(n_wires_per_gate, 4)
+    prev = np.zeros((1, 4), dtype=np.uint64)
+    cms, polys = [], []
+    for i in range(n_wires_per_gate):
+        start = i * n
+        end = coefs_len if i == n_wires_per_gate - 1 else (i + 1) * n
+        coefs = coefs_all[start:min(coefs_len, end)].copy() if start < coefs_len else np.zeros((0, 4), np.uint64)
+        if i != n_wires_per_gate - 1:
+            padded = np.zeros((n + 1, 4), dtype=np.uint64)
+            padded[: coefs.shape[0]] = coefs
+            coefs = padded
+            coefs[n] = fr_add_rows(coefs[n:n + 1], rands[i:i + 1])[0]
+            coefs[0] = fr_add_rows(coefs[0:1], fr_neg(prev))[0]
+        elif coefs.shape[0] == 0:
+            coefs = fr_neg(prev)
+        else:
+            coefs[0] = fr_add_rows(coefs[0:1], fr_neg(prev))[0]
+        prev = rands[i:i + 1]
+        if lagrange_pcs is not None:
+            cm = commit_folded_lagrange(pcs, lagrange_pcs, coefs, coefs.shape[0])
+        else:
+            cm = pcs.commit(FpPolynomial.from_coefs(coefs))
+        cms.append(cm)
+        polys.append(FpPolynomial.from_coefs(coefs))
+    return np.stack(cms), polys
+
+
+class ProverCommit:
+    """The commit closure of prover_with_lagrange (prover.rs:125-149; twin in indexer.rs:284-299): the Lagrange
+    SRS is used iff it has exactly n_constraints bases; then C = MSM(lagrange, evals) + blind factors, else the
+    monomial commit of the coefficient polynomial."""
+
+    def __init__(self, pcs: KZGCommitmentSchemeBN254, lagrange_pcs: Optional[KZGCommitmentSchemeBN254], n_constraints: int):
+        self.pcs = pcs
+        self.n_constraints = n_constraints
+        self.lagrange_pcs = lagrange_pcs if (lagrange_pcs is not None and lagrange_pcs.max_degree() + 1 == n_constraints) else None
+
+    def __call__(self, evals: np.ndarray, coef_polynomial: FpPolynomial, blinds: np.ndarray) -> np.ndarray:
+        if self.lagrange_pcs is not None:
+            cm = self.lagrange_pcs.commit(FpPolynomial.from_coefs(evals))
+            return self.pcs.apply_blind_factors(cm, blinds, self.n_constraints)
+        return self.pcs.commit(coef_polynomial)
+
+
+def hide_polynomial(polynomial: FpPolynomial, blinds: np.ndarray, zeroing_degree: int) -> FpPolynomial:
+    """helpers.rs:139-158 with the random blinds given: adds (b_0 + b_1 X + ...) * (X^zeroing_degree - 1)."""
+    b = np.ascontiguousarray(blinds, dtype=np.uint64).reshape(-1, 4)
+    size = max(polynomial.coefs.shape[0], zeroing_degree + b.shape[0])
+    c = np.zeros((size, 4), dtype=np.uint64)
+    c[: polynomial.coefs.shape[0]] = polynomial.coefs
+    for i in range(b.shape[0]):
+        c[i] = fr_add_rows(c[i:i + 1], b[i:i + 1])[0]
+        c[zeroing_degree + i] = fr_add_rows(c[zeroing_degree + i:zeroing_degree + i + 1], fr_neg(b[i:i + 1]))[0]
+    return FpPolynomial.from_coefs(c)
+
+
+def load_srs_params(srs_blob: bytes, size: int) -> KZGCommitmentSchemeBN254:
+    """uzkge/src/gen_params/mod.rs:151-183: the monomial SRS of a size-`size` circuit from the embedded blob --
+    powers 0..2050, the identity up to `size`, then the three padding powers size, size+1, size+2."""
+    full = KZGCommitmentSchemeBN254.from_unchecked_bytes(srs_blob)
+    g1 = full.public_parameter_group_1
+    full.release()
+    if size > 16384:
+        raise UzkgeError(N.UZK_ERR_PARAMETER, "ParameterError: size exceeds the embedded SRS")
+    out = np.zeros((max(size + 3, 2051), 8), dtype=np.uint64)
+    out[:2051] = g1[:2051]
+    pad = {4096: 2051, 8192: 2054, 16384: 2057}.get(size)
+    if pad is not None:
+        out[size:size + 3] = g1[pad:pad + 3]
+    return KZGCommitmentSchemeBN254(out)
