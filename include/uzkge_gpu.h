@@ -216,7 +216,8 @@ int uzk_synth_scalars_mix(void* d_scalars, size_t n, uint64_t seed);
  * multi-subtrahend offsets of ec29.hpp, 20 the dual product, 21..23 the C++ forms of the
  * assembly products 10 / 16 / 20.  a, b, out: n elements (host memory). */
 int uzk_field_op_device(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
-/* op: 0 a + b (mixed add), 1 a + b (full XYZZ add), 2 2a, 3 a - b, 4 2(a + b).  Inputs affine
+/* op: 0 a + b (mixed add), 1 a + b (full XYZZ add), 2 2a, 3 a - b, 4 2(a + b); 5..7 the four-lane addition of the
+ * small-MSM folds (ecquad.hpp): 5 a + b, 6 2(a + b) (its doubling branch), 7 (a + b) + (a - b).  Inputs affine
  * (infinity = zeros), outputs Jacobian. */
 int uzk_g1_op_device(int op, const uzk_g1_affine* a, const uzk_g1_affine* b, uzk_g1_jac* out, size_t n);
 
@@ -239,7 +240,7 @@ int uzk_msm_set_window_bits(int c);
 int uzk_msm_plan_info(size_t n, int* window_bits, int* windows);
 /* Experiment switches for A/B measurements in one process (keys: "msm_acc_variant",
  * "msm_task_len", "msm_no_precompute", "msm_fold_group", "msm_overlap", "msm_sort_packed", "msm_fused_hist", "msm_reduce_seg", "msm_scan_reduce",
- * "msm_chunk_log", "ntt_l29"); never needed for correctness. */
+ * "msm_chunk_log", "msm_small", "msm_fold_mode", "ntt_l29"); never needed for correctness. */
 int uzk_tune(const char* key, int value);
 
 #ifdef __cplusplus

@@ -86,8 +86,12 @@ def test_group_ops_match_oracle(gpu):
     dbl = gpu.g1_op(2, a, b)
     msub = gpu.g1_op(3, a, b)
     twice = gpu.g1_op(4, a, b)
+    qadd, qtwice, qmix = gpu.g1_op(5, a, b), gpu.g1_op(6, a, b), gpu.g1_op(7, a, b)     # four-lane addition (ecquad.hpp)
     for i in range(n):
         s = opy.g1_add(pa[i], pb[i])
+        assert aff(qadd[i]) == s, i
+        assert aff(qtwice[i]) == opy.g1_add(s, s), i
+        assert aff(qmix[i]) == opy.g1_add(s, opy.g1_add(pa[i], opy.g1_neg(pb[i]))), i
         assert aff(madd[i]) == s, i
         assert aff(full[i]) == s, i
         assert aff(dbl[i]) == opy.g1_add(pa[i], pa[i]), i

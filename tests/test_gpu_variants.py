@@ -16,7 +16,7 @@ KNOBS = [
     {"msm_scan_reduce": 0}, {"msm_scan_reduce": 2}, {"msm_reduce_seg": 4}, {"msm_task_len": 5}, {"msm_task_len": 300},
     {"msm_fold_group": 1}, {"msm_fold_group": 16}, {"window_bits": 9}, {"window_bits": 12}, {"window_bits": 16}, {"window_bits": 17},
 ]
-DEFAULTS = {"msm_acc_variant": 0, "msm_sort_packed": 1, "msm_fused_hist": 1, "msm_scan_reduce": 1, "msm_reduce_seg": 0,
+DEFAULTS = {"msm_small": 1, "msm_fold_mode": 0, "msm_acc_variant": 0, "msm_sort_packed": 1, "msm_fused_hist": 1, "msm_scan_reduce": 1, "msm_reduce_seg": 0,
             "msm_task_len": 0, "msm_fold_group": 0, "window_bits": 0}
 
 
@@ -66,3 +66,53 @@ def test_ntt_variants_agree(gpu, n):
             assert torch.equal(a, b_)
     finally:
         gpu.tune("ntt_l29", 1)
+
+
+@pytest.mark.parametrize("n", [1, 2, 33, 1000, 4096, 16384, 32768])
+def test_small_pipeline_agrees_with_general(gpu, n):
+    """n <= 2^15 takes the one-workgroup-per-slot pipeline (msm_small_*): same commitments as the general
+    pipeline for uniform, prover-mix, all-equal and all-zero scalar vectors, single and batched, at every
+    window size the small path accepts, and for forced task lengths on both sides of the automatic one."""
+    B = 3
+    pts = torch.empty((n, 8), dtype=torch.int64, device="cuda")
+    sc = torch.empty((4 * B * n, 4), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    gpu.synth_points_random(pts.data_ptr(), n, 11)
+    gpu.synth_scalars(sc.data_ptr(), B * n, 12)
+    gpu.synth_scalars_mix(sc.data_ptr() + B * n * 32, B * n, 13)
+    sc[2 * B * n:3 * B * n] = sc[0:1].expand(B * n, 4)         # one value everywhere: a single bucket per window
+    sc[3 * B * n:] = 0
+    srs = gpu.Srs.from_device(pts.data_ptr(), n)
+    try:
+        def run():
+            out = []
+            for k in range(4):
+                base = sc.data_ptr() + k * B * n * 32
+                out.append(affine_of(gpu.msm_device(srs, base, n)))
+                out += [affine_of(x) for x in gpu.msm_batch_device(srs, base, n, B)]
+            return out
+        gpu.tune("msm_small", 0)
+        want = run()
+        if n <= 4096:      # anchor the general path on the oracle
+            hp = pts.cpu().numpy().view(np.uint64); hs = sc[:n].cpu().numpy().view(np.uint64)
+            assert want[0] == oc.jac_to_affine_ints(oc.msm_pippenger(hp, hs, 0, 8))
+        assert want[-1] is None and want[-2] is None               # all-zero scalars commit to infinity
+        gpu.tune("msm_small", 1)
+        for cfg in ({}, {"window_bits": 5}, {"window_bits": 9}, {"window_bits": 10}, {"msm_task_len": 2}, {"msm_task_len": 3}, {"msm_task_len": 200},
+                    {"msm_acc_variant": 1}, {"msm_acc_variant": 2}, {"msm_fold_mode": 1 + 16 + 8}, {"msm_fold_mode": 1 + 16 + 2},
+                    {"msm_fold_mode": 1 + 8}, {"msm_fold_mode": 1 + 4}, {"msm_fold_mode": 1 + 2}, {"msm_fold_mode": 1 + 1}):
+            _apply(gpu, cfg)
+            gpu.tune("msm_small", 1)
+            assert run() == want, cfg
+        _apply(gpu, {})
+        # window table (uzk_srs_precompute) on the small pipeline: per-window rows, window sums added without doublings
+        gpu.tune("msm_no_precompute", 0)
+        for c in (0, 6, 9):
+            srs.precompute(c)
+            assert run() == want, ("precompute", c)
+        gpu.tune("msm_small", 2)                                   # one lane per addition in the folds and scans
+        assert run() == want
+    finally:
+        _apply(gpu, {})
+        gpu.tune("msm_small", 1)
+        srs.release()

@@ -79,6 +79,8 @@ struct Ctx {
     int tune_fused_hist = 1;  // 1: the digit kernel also produces the first sort pass's histograms (large n)
     int tune_sort_packed = 1; // 1: 4-byte entries between the two sort passes when the fields fit
     int tune_ntt_l29 = 1;     // 1: NTT passes on the 29-bit-limb representation (0: 8x32-bit relaxed Montgomery)
+    int tune_small = 1;       // 1: n <= 2^15 takes the one-workgroup-per-slot pipeline (msm_small_*)
+    int tune_fold_mode = 0;   // experiment: level-1 fold of the small pipeline = 1 + 16 * quad + lanes per chunk
     int tune_chunk_log = 26;  // point-chunk size of one sort pass (tests lower it to reach the chunk loop at small n)
     int tune_overlap = 0;     // 1: run large MSMs as two overlapping pipeline instances (experiment)  // 1: force one lane per bucket in the fold kernels
     // poly.hip workspaces (grow-only)

@@ -1,0 +1,61 @@
+// Group addition computed by the four lanes of a quad (used by the latency-bound folds and scans of small MSMs).
+#pragma once
+#include "ec.hpp"
+
+namespace uzk {
+
+// The folds and scans of a small problem are chains of DEPENDENT full additions on a nearly idle chip, so
+// what counts is the latency of one addition, 14 products back to back in one lane.  Here the four lanes
+// of a quad hold identical copies of both operands and each computes one product per stage,
+//   stage 1: U1 = X1 ZZ2 | U2 = X2 ZZ1 | S1 = Y1 ZZZ2 | S2 = Y2 ZZZ1        P = U2 - U1, R = S2 - S1
+//   stage 2: PP = P^2    | RR = R^2    | ZZ1 ZZ2      | ZZZ1 ZZZ2
+//   stage 3: PPP = P PP  | Q = U1 PP   | ZZ3 = (ZZ1 ZZ2) PP | -                X3 = RR - PPP - 2Q
+//   stage 4: R (Q - X3)  | S1 PPP      | -            | ZZZ3 = (ZZZ1 ZZZ2) PPP   Y3 = R (Q - X3) - S1 PPP
+// exchanging results with DPP quad_perm moves (one v_mov per word, no LDS): four product latencies
+// instead of fourteen.  Same formulas and the same canonical arithmetic as xyzz_add (add-2008-s).
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int S>
+__device__ __forceinline__ Fp quad_bcast(const Fp& v) {
+    Fp r;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r.v[k] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.v[k], S * 0x55, 0xf, 0xf, false);
+    return r;
+}
+__device__ __forceinline__ Fp quad_sel(uint32_t q, const Fp& a0, const Fp& a1, const Fp& a2, const Fp& a3) {
+    Fp r;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t lo = (q & 1) ? a1.v[k] : a0.v[k], hi = (q & 1) ? a3.v[k] : a2.v[k];
+        r.v[k] = (q & 2) ? hi : lo;
+    }
+    return r;
+}
+// acc += p; every lane of the quad passes the same acc and p and leaves with the same acc.  q = lane & 3.
+__device__ __forceinline__ void xyzz_add_quad(XYZZ& acc, const XYZZ& p, uint32_t q) {
+    if (xyzz_is_inf(p)) return;
+    if (xyzz_is_inf(acc)) { acc = p; return; }
+    const Fp r1 = Fq::mul(quad_sel(q, acc.x, p.x, acc.y, p.y), quad_sel(q, p.zz, acc.zz, p.zzz, acc.zzz));
+    const Fp U1 = quad_bcast<0>(r1), U2 = quad_bcast<1>(r1), S1 = quad_bcast<2>(r1), S2 = quad_bcast<3>(r1);
+    const Fp Pd = Fq::sub(U2, U1), Rd = Fq::sub(S2, S1);
+    if (Fq::is_zero(Pd)) {                             // same x: doubling or cancellation (uniform over the quad)
+        if (Fq::is_zero(Rd)) acc = xyzz_dbl(acc);
+        else acc = xyzz_inf();
+        return;
+    }
+    const Fp r2 = Fq::mul(quad_sel(q, Pd, Rd, acc.zz, acc.zzz), quad_sel(q, Pd, Rd, p.zz, p.zzz));
+    const Fp PP = quad_bcast<0>(r2), RR = quad_bcast<1>(r2);
+    const Fp r3 = Fq::mul(quad_sel(q, Pd, U1, r2, PP), PP);                  // PPP | Q | ZZ3 | unused
+    const Fp PPP = quad_bcast<0>(r3), Q = quad_bcast<1>(r3);
+    const Fp X3 = Fq::sub(Fq::sub(RR, PPP), Fq::dbl(Q));
+    const Fp r4 = Fq::mul(quad_sel(q, Rd, S1, PPP, r2), quad_sel(q, Fq::sub(Q, X3), PPP, PPP, PPP));   // T1 | T2 | unused | ZZZ3
+    acc.x = X3;
+    acc.y = Fq::sub(quad_bcast<0>(r4), quad_bcast<1>(r4));
+    acc.zz = quad_bcast<2>(r3);
+    acc.zzz = quad_bcast<3>(r4);
+}
+#else
+__device__ void xyzz_add_quad(XYZZ& acc, const XYZZ& p, uint32_t q);
+#endif
+
+
+}  // namespace uzk

@@ -2,6 +2,7 @@
 // tests can compare them word-for-word with the oracle (Fq/Fr mont-mul/add/sub KATs, G1
 // add / double / mixed-add including P+P, P+(-P) and infinity; SURVEY.md 8c "golden vectors").
 #include "ctx.hpp"
+#include "ecquad.hpp"
 #include "fp29.hpp"
 
 namespace uzk {
@@ -81,6 +82,31 @@ __global__ __launch_bounds__(256) void g1_op_kernel(int op, const Affine* __rest
     out[i] = xyzz_to_jac(acc);
 }
 
+// ops 5..7: the quad addition (ecquad.hpp), four lanes per element
+__global__ __launch_bounds__(256) void g1_quad_op_kernel(int op, const Affine* __restrict__ a, const Affine* __restrict__ b,
+                                                         Jac* __restrict__ out, size_t n) {
+    const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t i = gt >> 2;
+    const uint32_t q = (uint32_t)(gt & 3);
+    if (i >= n) return;
+    const Affine p = a[i], r = b[i];
+    XYZZ acc = xyzz_from_affine(p);
+    if (op == 5) {                                   // p + r, trivial ZZ on both sides
+        const XYZZ t = xyzz_from_affine(r);
+        xyzz_add_quad(acc, t, q);
+    } else if (op == 6) {                            // (p + r) + (p + r): the doubling branch through non-trivial ZZ
+        xyzz_madd(acc, r, false);
+        const XYZZ t = acc;
+        xyzz_add_quad(acc, t, q);
+    } else {                                         // (p + r) + (p - r) = 2p: general case, non-trivial ZZ on both sides
+        XYZZ t = acc;
+        xyzz_madd(acc, r, false);
+        xyzz_madd(t, r, true);
+        xyzz_add_quad(acc, t, q);
+    }
+    if (q == 0) out[i] = xyzz_to_jac(acc);
+}
+
 int field_op_device(Ctx& c, int field, int op, const Fp* a, const Fp* b, Fp* out, size_t n) {
     if (n == 0) return UZK_OK;
     Fp *da = nullptr, *db = nullptr, *dout = nullptr;
@@ -110,7 +136,8 @@ int g1_op_device(Ctx& c, int op, const Affine* a, const Affine* b, Jac* out, siz
     UZK_HIP(hipMalloc(reinterpret_cast<void**>(&dout), n * sizeof(Jac)));
     UZK_HIP(hipMemcpyAsync(da, a, n * sizeof(Affine), hipMemcpyHostToDevice, c.stream));
     UZK_HIP(hipMemcpyAsync(db, b, n * sizeof(Affine), hipMemcpyHostToDevice, c.stream));
-    hipLaunchKernelGGL(g1_op_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, op, da, db, dout, n);
+    if (op >= 5) hipLaunchKernelGGL(g1_quad_op_kernel, dim3((unsigned)((4 * n + 255) / 256)), dim3(256), 0, c.stream, op, da, db, dout, n);
+    else hipLaunchKernelGGL(g1_op_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, op, da, db, dout, n);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out, dout, n * sizeof(Jac), hipMemcpyDeviceToHost, c.stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c.stream);

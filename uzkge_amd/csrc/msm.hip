@@ -38,6 +38,7 @@
 
 #include "ctx.hpp"
 #include "ec29.hpp"
+#include "ecquad.hpp"
 #include "host_math.hpp"
 
 namespace uzk {
@@ -600,16 +601,17 @@ __global__ __launch_bounds__(256) void msm_accumulate_exc_kernel(const Affine* _
                                                                  XYZZ* __restrict__ partials,
                                                                  const uint32_t* __restrict__ exc_count,
                                                                  const uint32_t* __restrict__ exc_list) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= *exc_count) return;
-    const TaskDesc d = desc[exc_list[i]];
-    const uint32_t* run = sorted + d.start;
-    XYZZ acc = xyzz_inf();
-    for (uint32_t k = 0; k < d.cnt; ++k) {
-        const uint32_t e = run[k];
-        xyzz_madd(acc, load_point(points, e & ~kSignBit), (e & kSignBit) != 0);
+    const uint32_t total = *exc_count;                      // grid-stride: any grid size covers the whole list
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const TaskDesc d = desc[exc_list[i]];
+        const uint32_t* run = sorted + d.start;
+        XYZZ acc = xyzz_inf();
+        for (uint32_t k = 0; k < d.cnt; ++k) {
+            const uint32_t e = run[k];
+            xyzz_madd(acc, load_point(points, e & ~kSignBit), (e & kSignBit) != 0);
+        }
+        partials[d.task] = acc;
     }
-    partials[d.task] = acc;
 }
 
 // Folding partial sums.  GS lanes of one wave cooperate on one output: lane `sub` adds the partials
@@ -630,7 +632,9 @@ __device__ __forceinline__ XYZZ fold_partials(const XYZZ* __restrict__ src, uint
     for (uint32_t k = sub; k < cnt; k += GS) { XYZZ q = src[k]; xyzz_add(acc, q); }
     for (int o = GS / 2; o > 0; o >>= 1) {
         XYZZ q = xyzz_shfl_down(acc, o);
-        xyzz_add(acc, q);
+        // lanes whose partner lies outside the group hold nothing lane 0 will use; adding there would feed a lane
+        // its own value at the end of the wave and send the whole wave through the doubling branch
+        if (sub + (uint32_t)o < (uint32_t)GS) xyzz_add(acc, q);
     }
     return acc;   // valid in lane sub == 0
 }
@@ -828,6 +832,234 @@ __global__ __launch_bounds__(256) void msm_fold_scan_kernel(const XYZZ* __restri
     if (tid == 0) out[w] = sh[0];
 }
 
+// ---- small problems (n <= 2^15): one workgroup per (vector, window) slot ---------------------------
+// The prover's real size is n = 2^14: the general pipeline above spends 17 launches and a
+// host round trip on it.  Here a slot's whole sort -- histogram, prefixes, scatter, the task table and the
+// tables of every fold level -- happens inside one workgroup's LDS, and nothing is read back before the
+// window sums:
+//   msm_digits -> msm_small_sort -> msm_accumulate29 (+ exceptions) -> msm_small_fold x levels -> msm_small_reduce
+// Tasks are runs of <= L sorted entries of one bucket (balanced split, as above).  Their partial sums are folded
+// 16 to 1 per level until every bucket holds one sum -- ceil(log16(n / L)) levels sized on the host, so the depth
+// is bounded whatever the skew, and a bucket that is down to one sum takes no part in later levels (the uniform
+// case: one level).  All sums live in one array P: level 0 = task partials, level k = the sums of level k's chunks.
+// The slot's reduction workgroup finishes with sum_b b*B_b as a suffix scan + tree over its 2^(c-1) buckets in LDS.
+struct SmallChunk { uint32_t first, cnt; };          // sums P[first .. first + cnt) of one bucket
+constexpr uint32_t kSmallFan = 16;                   // sums folded per chunk
+constexpr int kSmallMaxLevels = 4;                   // 16^4 >= 2^15 / 2 tasks of one bucket
+constexpr uint32_t kSmallNone = 0xFFFFFFFFu;
+struct SmallLevels {
+    uint32_t nl;                                     // fold levels 1 .. nl
+    uint32_t pbase[kSmallMaxLevels + 1];             // first sum of each level's region in P (pbase[0] = 0)
+    uint32_t dbase[kSmallMaxLevels + 1];             // first chunk descriptor of each level
+};
+
+// exclusive prefix of v over the workgroup (all threads call; wsum: LDS[17]); total = sum over the workgroup
+__device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t* wsum, uint32_t tid, uint32_t nthreads,
+                                                       uint32_t& total) {
+    const uint32_t lane = tid & 63;
+    uint32_t incl = v;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)incl, o);
+        if ((int)lane >= o) incl += t;
+    }
+    __syncthreads();                                  // wsum may still be read from the previous call
+    if (lane == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t pre = 0, tot = 0;
+    for (uint32_t w = 0; w < nthreads / 64; ++w) {
+        const uint32_t x = wsum[w];
+        if (w < (tid >> 6)) pre += x;
+        tot += x;
+    }
+    total = tot;
+    return pre + incl - v;
+}
+// largest b in [0, nb) with off[b] <= t   (off: exclusive prefix, non-decreasing; picks the non-empty bucket)
+__device__ __forceinline__ uint32_t small_find(const uint32_t* off, uint32_t nb, uint32_t t) {
+    uint32_t lo = 0, hi = nb;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (off[mid] <= t) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// grid (slots), block 1024, dynamic LDS (5 NBL + 32 + n) words.  digits: [slot][n].
+// counters[k]: running total over all slots of the tasks (k = 0) / the chunks of level k (dense packing of the tables).
+__global__ __launch_bounds__(1024) void msm_small_sort_kernel(const uint32_t* __restrict__ digits, uint32_t n, uint32_t NBL,
+                                                              uint32_t L, uint32_t* __restrict__ sorted,
+                                                              TaskDesc* __restrict__ desc, SmallChunk* __restrict__ cdesc,
+                                                              uint32_t* __restrict__ bucket_ref, uint2* __restrict__ slot_chunks,
+                                                              uint32_t* __restrict__ counters, SmallLevels lv, uint32_t W,
+                                                              uint32_t pre_stride, uint32_t pre_off) {
+    extern __shared__ uint32_t sm_small[];
+    uint32_t* cnt = sm_small;                 // [NBL]    bucket populations
+    uint32_t* start = cnt + NBL;              // [NBL+1]  exclusive entry prefix
+    uint32_t* toff = start + NBL + 1;         // [NBL+1]  exclusive task prefix
+    uint32_t* coff = toff + NBL + 1;          // [NBL+1]  exclusive chunk prefix of the level being built
+    uint32_t* cur = coff + NBL + 1;           // [NBL]    scatter cursors, then the buckets' current first sum
+    uint32_t* misc = cur + NBL;               // [4]      table bases of this slot
+    uint32_t* wsum = misc + 4;                // [17]
+    uint32_t* stage = wsum + 17;              // [n]      the slot's sorted entries
+    const uint32_t slot = blockIdx.x, tid = threadIdx.x;
+    const uint32_t* dg = digits + (size_t)slot * n;
+    for (uint32_t b = tid; b < NBL; b += 1024) { cnt[b] = 0; cur[b] = 0; }
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += 1024) {
+        const uint32_t mag = dg[i] & ~kSignBit;
+        if (mag) atomicAdd(&cnt[mag - 1], 1u);
+    }
+    __syncthreads();
+    const uint32_t e = tid < NBL ? cnt[tid] : 0u;
+    const uint32_t tk = (e + L - 1) / L;
+    uint32_t tot_e, tot_t;
+    const uint32_t es = block_excl_scan_u32(e, wsum, tid, 1024, tot_e);
+    const uint32_t ts = block_excl_scan_u32(tk, wsum, tid, 1024, tot_t);
+    if (tid < NBL) { start[tid] = es; toff[tid] = ts; }
+    if (tid == 0) {
+        start[NBL] = tot_e; toff[NBL] = tot_t;
+        misc[0] = atomicAdd(&counters[0], tot_t);
+    }
+    __syncthreads();
+    const uint32_t tbase = misc[0];
+    // window table (uzk_srs_precompute): window w of every vector reads row w of T[w][i] = 2^(c w) P_i
+    const uint32_t idx_base = pre_stride ? (slot % W) * pre_stride + pre_off : 0u;
+    for (uint32_t i = tid; i < n; i += 1024) {
+        const uint32_t d = dg[i], mag = d & ~kSignBit;
+        if (mag) stage[start[mag - 1] + atomicAdd(&cur[mag - 1], 1u)] = (idx_base + i) | (d & kSignBit);
+    }
+    __syncthreads();
+    uint32_t* so = sorted + (size_t)slot * n;
+    for (uint32_t k = tid; k < tot_e; k += 1024) so[k] = stage[k];
+    for (uint32_t t = tid; t < tot_t; t += 1024) {
+        const uint32_t b = small_find(toff, NBL, t), j = t - toff[b];
+        const uint32_t total = cnt[b], T = toff[b + 1] - toff[b];
+        const uint32_t q = total / T, r = total - q * T;
+        TaskDesc d;
+        d.start = slot * n + start[b] + j * q + min(j, r);
+        d.cnt = q + (j < r ? 1u : 0u);
+        d.task = tbase + t;
+        d.pad = 0;
+        desc[tbase + t] = d;
+    }
+    // fold levels: thread b < NBL carries its bucket's (number of sums, index of the first one in P)
+    uint32_t have = tk, first = tbase + ts;
+    for (uint32_t lvl = 1; lvl <= lv.nl; ++lvl) {
+        const uint32_t ck = have > 1 ? (have + kSmallFan - 1) / kSmallFan : 0u;     // a single sum is final
+        uint32_t tot_c;
+        const uint32_t cs = block_excl_scan_u32(ck, wsum, tid, 1024, tot_c);       // (starts with a barrier)
+        if (tid < NBL) { coff[tid] = cs; cnt[tid] = have; cur[tid] = first; }
+        if (tid == 0) {
+            coff[NBL] = tot_c;
+            misc[1] = atomicAdd(&counters[lvl], tot_c);
+            slot_chunks[(size_t)slot * kSmallMaxLevels + (lvl - 1)] = make_uint2(misc[1], tot_c);   // this slot's chunks of the level
+        }
+        __syncthreads();
+        const uint32_t cbase = misc[1];
+        for (uint32_t ch = tid; ch < tot_c; ch += 1024) {
+            const uint32_t b = small_find(coff, NBL, ch), j = ch - coff[b];
+            SmallChunk cd;
+            cd.first = cur[b] + j * kSmallFan;
+            cd.cnt = min(kSmallFan, cnt[b] - j * kSmallFan);
+            cdesc[lv.dbase[lvl] + cbase + ch] = cd;
+        }
+        if (ck) { have = ck; first = lv.pbase[lvl] + cbase + cs; }
+    }
+    if (tid < NBL) bucket_ref[(size_t)slot * NBL + tid] = have ? first : kSmallNone;
+}
+
+// One fold level: out[chunk] = sum of the chunk's <= 16 sums.  GS logical lanes per chunk (lane `sub` adds the sums
+// sub, sub + GS, ..., a shuffle tree adds the GS lane sums); QUAD: every logical lane is a quad (ecquad.hpp) --
+// 2.5x shorter dependent chains for 1.6x the work, for launches that cannot fill the chip anyway.
+template <bool QUAD, int GS>
+__global__ __launch_bounds__(256) void msm_small_fold_kernel(XYZZ* __restrict__ P, const SmallChunk* __restrict__ cdesc,
+                                                             const uint32_t* __restrict__ count, uint32_t out_base) {
+    constexpr uint32_t LPL = QUAD ? 4 : 1;         // lanes per logical lane
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t group = gt / (LPL * GS), sub = (gt / LPL) % GS, q = gt & 3;
+    if (group >= *count) return;               // whole groups leave together
+    const SmallChunk cd = cdesc[group];
+    XYZZ acc = xyzz_inf();
+    for (uint32_t k = sub; k < cd.cnt; k += GS) {
+        const XYZZ v = P[cd.first + k];
+        if constexpr (QUAD) xyzz_add_quad(acc, v, q); else xyzz_add(acc, v);
+    }
+#pragma unroll
+    for (int o = GS / 2; o > 0; o >>= 1) {
+        const XYZZ v = xyzz_shfl_down(acc, (int)LPL * o);
+        if (sub + (uint32_t)o < (uint32_t)GS) {        // see fold_partials
+            if constexpr (QUAD) xyzz_add_quad(acc, v, q); else xyzz_add(acc, v);
+        }
+    }
+    if (sub == 0 && (!QUAD || q == 0)) P[out_base + group] = acc;
+}
+
+// grid (slots).  First the slot's chunks of the fold levels >= 2 (they exist only where one bucket holds more than 16
+// task sums -- skewed scalars; four quads per chunk), then B_b = the bucket's one remaining sum and
+// window sum = sum_{b >= 1} b * B_b = sum over t of the inclusive suffix sums Suffix_t = B_(t+1) + B_(t+2) + ... (t = b - 1):
+// log2(NBL) scan steps, then a tree over the NBL suffixes.
+// QUAD: one quad per bucket (block 4 * NBL, NBL <= 256); else one lane per bucket (block NBL).  Dynamic LDS NBL * 128 B.
+template <bool QUAD, int MAXT>
+__global__ __launch_bounds__(MAXT) void msm_small_reduce_kernel(XYZZ* __restrict__ P, const uint32_t* __restrict__ bucket_ref,
+                                                                const SmallChunk* __restrict__ cdesc,
+                                                                const uint2* __restrict__ slot_chunks, SmallLevels lv,
+                                                                XYZZ* __restrict__ win_sums, uint32_t NBL) {
+    extern __shared__ uint4 sm_red[];
+    XYZZ* sh = reinterpret_cast<XYZZ*>(sm_red);
+    const uint32_t slot = blockIdx.x, tid = threadIdx.x;
+    const uint32_t t = QUAD ? tid >> 2 : tid, q = tid & 3;
+    const bool writer = !QUAD || q == 0;
+    for (uint32_t lvl = 2; lvl <= lv.nl; ++lvl) {
+        const uint2 rng = slot_chunks[(size_t)slot * kSmallMaxLevels + (lvl - 1)];
+        if (rng.y) {                                           // uniform over the workgroup
+            constexpr uint32_t LPL = QUAD ? 4 : 1, GS = 4;     // lanes per logical lane, logical lanes per chunk
+            const uint32_t sub = (tid / LPL) % GS, per_round = blockDim.x / (LPL * GS);
+            for (uint32_t ch = tid / (LPL * GS); ch < rng.y; ch += per_round) {
+                const SmallChunk cd = cdesc[lv.dbase[lvl] + rng.x + ch];
+                XYZZ acc = xyzz_inf();
+                for (uint32_t k = sub; k < cd.cnt; k += GS) {
+                    const XYZZ v = P[cd.first + k];
+                    if constexpr (QUAD) xyzz_add_quad(acc, v, q); else xyzz_add(acc, v);
+                }
+#pragma unroll
+                for (int o = GS / 2; o > 0; o >>= 1) {
+                    const XYZZ v = xyzz_shfl_down(acc, (int)LPL * o);
+                    if (sub + (uint32_t)o < GS) {
+                        if constexpr (QUAD) xyzz_add_quad(acc, v, q); else xyzz_add(acc, v);
+                    }
+                }
+                if (sub == 0 && writer) P[lv.pbase[lvl] + rng.x + ch] = acc;
+            }
+            __threadfence();                                   // the sums are read by other waves of this workgroup
+        }
+        __syncthreads();
+    }
+    const uint32_t ref = bucket_ref[(size_t)slot * NBL + t];
+    XYZZ mine = ref == kSmallNone ? xyzz_inf() : P[ref];
+    if (writer) sh[t] = mine;
+    __syncthreads();
+    for (uint32_t off = 1; off < NBL; off <<= 1) {
+        const bool has = t + off < NBL;
+        XYZZ v;
+        if (has) v = sh[t + off];
+        __syncthreads();
+        if (has) {
+            if constexpr (QUAD) xyzz_add_quad(mine, v, q); else xyzz_add(mine, v);
+            if (writer) sh[t] = mine;
+        }
+        __syncthreads();
+    }
+    for (uint32_t s2 = NBL >> 1; s2 > 0; s2 >>= 1) {
+        if (t < s2) {
+            const XYZZ v = sh[t + s2];
+            if constexpr (QUAD) xyzz_add_quad(mine, v, q); else xyzz_add(mine, v);
+            if (writer) sh[t] = mine;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) win_sums[slot] = mine;
+}
+
 // ---- precomputation: T[j][i] = 2^c * T[j-1][i], affine --------------------------------------------
 __device__ inline Fp fq_inv_pow(const Fp& a) {   // a^(p-2)
     const uint32_t e[8] = {0xd87cfd45u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u,
@@ -896,6 +1128,7 @@ static int choose_window_bits(size_t n, int forced) {
 }
 int msm_precompute_window_bits(size_t n, int forced) {
     if (forced >= 4 && forced <= 24) return forced;
+    if (n <= (1u << 15)) return n <= 256 ? 5 : n <= 2048 ? 7 : 8;   // the small pipeline's window (small_window_bits)
     int lg = 0;
     while ((1ull << (lg + 1)) <= n) ++lg;
     return std::max(8, std::min(22, lg - 2));
@@ -1362,8 +1595,188 @@ static void horner_pool_shutdown() {
     g_horner_pool = nullptr;
 }
 
+// Host: per scalar vector, Horner over its W window sums (c doublings per step).
+template <class WindowSum>
+static void msm_horner_host(Ctx& c, uint32_t batch, uint32_t wpp, int cb, const WindowSum& window_sum, Jac* out_host) {
+    auto horner = [&](uint32_t b) {
+        XYZZ total = xyzz_inf();
+        for (int w = (int)wpp - 1; w >= 0; --w) {
+            if (w != (int)wpp - 1) for (int d = 0; d < cb; ++d) total = xyzz_dbl(total);
+            xyzz_add(total, window_sum(b, (uint32_t)w));
+        }
+        out_host[b] = xyzz_to_jac(total);
+    };
+    HostScope hs_horner(c, "host_msm_horner");
+    if (batch > 1 && wpp > 1) {
+        // 254 dependent doublings per vector: ~0.06 ms each on one core, so spread the vectors over the pool
+        if (!g_horner_pool) g_horner_pool = new HornerPool(7);
+        const std::function<void(uint32_t)> job = [&](uint32_t b) { horner(b); };
+        g_horner_pool->run(batch, job);
+    } else {
+        for (uint32_t b = 0; b < batch; ++b) horner(b);
+    }
+}
+
+// ---- the small-problem pipeline (kernels above: msm_small_*) ------------------------------------------
+static int small_window_bits(Ctx& c, size_t n, uint32_t batch) {
+    if (c.msm_window_bits >= 4 && c.msm_window_bits <= 10) return c.msm_window_bits;
+    (void)batch;
+    if (n <= 256) return 5;
+    if (n <= 2048) return 7;
+    return 8;
+}
+bool msm_small_applies(Ctx& c, size_t n, uint32_t batch, int pre_c = 0) {
+    if (!c.tune_small || n == 0 || n > (1u << 15)) return false;
+    if (pre_c > 10 || (pre_c == 0 && c.msm_window_bits > 10)) return false;   // larger windows: the general pipeline
+    const int cb = pre_c > 0 ? pre_c : small_window_bits(c, n, batch);
+    const uint64_t S = (uint64_t)batch * (uint64_t)msm_num_windows(cb);
+    return S <= 65535 && S * n < (1ull << 31);
+}
+
+// General mode: `points` are the bases, the host combines the W window sums by Horner.  Window-table mode (pre_c > 0):
+// `points` is T[w][i] = 2^(pre_c w) P_i (row stride pre_stride, first column pre_off), every window keeps its own bucket
+// set but reads its own row, and the window sums just add up -- no doublings on the host.
+static int msm_run_small(Ctx& c, const Affine* points, const Fp* d_scalars, size_t n, uint32_t batch, Jac* out_host, int pre_c,
+                         uint32_t pre_stride, uint32_t pre_off) {
+    MsmWork& m = c.msm[0];
+    hipStream_t st = c.stream;
+    c.cur_stream = st;
+    const int cb = pre_c > 0 ? pre_c : small_window_bits(c, n, batch);
+    const uint32_t W = (uint32_t)msm_num_windows(cb), S = batch * W, NBL = 1u << (cb - 1), n32 = (uint32_t)n;
+    const uint64_t entries = (uint64_t)S * n;
+    // Task length: the accumulation is issue-bound from one wave per SIMD on (a wave alone already keeps its
+    // SIMD's 64-bit multiplier busy), so the shortest dependent chain comes from filling k = 1..4 waves per
+    // SIMD almost exactly: L = entries / (0.93 * 65536 * k) for the smallest k that keeps L <= 12.
+    uint32_t L = 0;
+    if (c.tune_task_len > 0) L = (uint32_t)c.tune_task_len;
+    else {
+        const double lanes = 0.93 * 64.0 * 4.0 * (double)c.num_cus;
+        for (int k = 1; k <= 4; ++k) {
+            L = (uint32_t)((double)entries / (lanes * k)) + 1;
+            if (L <= 12) break;
+        }
+        L = std::max<uint32_t>(L, 2);
+    }
+    const uint64_t task_cap = entries / L + (uint64_t)S * NBL;       // sum_b ceil(cnt_b / L) over non-empty buckets
+    // fold levels (16 to 1): as many as the fullest possible bucket (all n entries of a slot) needs
+    SmallLevels lv{};
+    uint64_t cap[kSmallMaxLevels + 1];                               // capacity of each level's region (sums = chunks)
+    cap[0] = task_cap;
+    {
+        uint64_t worst = (n + L - 1) / L;
+        while (worst > 1 && lv.nl < (uint32_t)kSmallMaxLevels) { worst = (worst + kSmallFan - 1) / kSmallFan; ++lv.nl; }
+        if (worst > 1) { set_error("msm: small pipeline: %u fold levels do not cover n = %zu at task length %u", lv.nl, n, L); return UZK_ERR_PARAMETER; }
+    }
+    uint64_t p_total = 0, d_total = 0;
+    for (uint32_t k = 0; k <= lv.nl; ++k) {
+        if (k > 0) cap[k] = cap[k - 1] / kSmallFan + (uint64_t)S * NBL;   // a chunk per 16 sums, plus one ragged chunk per bucket
+        lv.pbase[k] = (uint32_t)p_total;
+        lv.dbase[k] = (uint32_t)d_total;                                  // level k's descriptors follow level k - 1's
+        p_total += cap[k];
+        if (k > 0) d_total += cap[k];
+    }
+    if (p_total >= (1ull << 32)) { set_error("msm: small pipeline: too many partial sums"); return UZK_ERR_PARAMETER; }
+    UZK_TRY(m.digits.reserve((size_t)entries * 4));
+    UZK_TRY(m.sorted.reserve((size_t)entries * 4));
+    UZK_TRY(m.task_desc.reserve((size_t)task_cap * sizeof(TaskDesc)));
+    UZK_TRY(m.lvl_part[0].reserve((size_t)p_total * sizeof(XYZZ)));
+    UZK_TRY(m.exc.reserve((size_t)task_cap * 4));
+    UZK_TRY(m.partials.reserve((size_t)(d_total + 1) * sizeof(SmallChunk)));
+    UZK_TRY(m.bucket_count.reserve((size_t)S * NBL * 4));
+    UZK_TRY(m.bucket_start.reserve((size_t)S * kSmallMaxLevels * sizeof(uint2)));
+    UZK_TRY(m.win_sums.reserve((size_t)S * sizeof(XYZZ)));
+    UZK_TRY(m.small.reserve(16384));
+    if (m.h_sums_cap < S) {
+        if (m.h_sums) (void)hipHostFree(m.h_sums);
+        UZK_HIP(hipHostMalloc(reinterpret_cast<void**>(&m.h_sums), (size_t)S * sizeof(XYZZ), hipHostMallocDefault));
+        m.h_sums_cap = S;
+    }
+    uint32_t* digits = m.digits.as<uint32_t>();
+    uint32_t* sorted = m.sorted.as<uint32_t>();
+    TaskDesc* desc = m.task_desc.as<TaskDesc>();
+    XYZZ* P = m.lvl_part[0].as<XYZZ>();
+    SmallChunk* cdesc = m.partials.as<SmallChunk>();
+    uint32_t* bucket_ref = m.bucket_count.as<uint32_t>();
+    uint2* slot_chunks = m.bucket_start.as<uint2>();
+    XYZZ* win_sums = m.win_sums.as<XYZZ>();
+    uint32_t* counters = m.small.as<uint32_t>() + 3960;               // [0] tasks, [1..4] chunks per level, [6] exceptions
+    const size_t sort_lds = ((size_t)5 * NBL + 32 + n32) * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        UZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_small_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (5 * 512 + 32 + 32768) * 4));
+        attr_done = true;
+    }
+    {
+        HostScope hs(c, "host_msm_enqueue1");
+        UZK_HIP(hipMemsetAsync(counters, 0, 32, st));
+        {
+            KernelScope ks(c, "msm_digits");
+            const uint64_t tot = (uint64_t)n32 * batch;
+            hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_scalars, digits, n32, batch,
+                               cb, (int)W, 0, (int)W);
+        }
+        {
+            KernelScope ks(c, "msm_small_sort");
+            hipLaunchKernelGGL(msm_small_sort_kernel, dim3(S), dim3(1024), sort_lds, st, digits, n32, NBL, L, sorted, desc, cdesc,
+                               bucket_ref, slot_chunks, counters, lv, W, pre_c > 0 ? pre_stride : 0u, pre_off);
+        }
+        {
+            KernelScope ks(c, "msm_accumulate");
+            const dim3 grid((unsigned)((task_cap + 255) / 256));
+            if (c.tune_acc_variant == 1)
+                hipLaunchKernelGGL((msm_accumulate_kernel<1, false>), grid, dim3(256), 0, st, points, sorted, desc, counters, P, 0u);
+            else if (c.tune_acc_variant == 0) {
+                hipLaunchKernelGGL(msm_accumulate29_kernel, grid, dim3(256), 0, st, points, sorted, desc, counters, P, 0u,
+                                   counters + 6, m.exc.as<uint32_t>());
+                hipLaunchKernelGGL(msm_accumulate_exc_kernel, dim3(256), dim3(256), 0, st, points, sorted, desc, P, counters + 6,
+                                   m.exc.as<uint32_t>());
+            } else
+                hipLaunchKernelGGL((msm_accumulate_kernel<1, true>), grid, dim3(256), 0, st, points, sorted, desc, counters, P, 0u);
+        }
+        // Fold mode per level: quads (four lanes per addition) while a level is latency-bound -- about one chunk per
+        // non-empty bucket at level 1, far fewer later -- plain lanes once the chunks alone fill the chip.
+        // uzk_tune("msm_fold_mode", 1 + 16 * quad + lanes): experiment override for level 1.
+        const uint64_t lanes_chip = (uint64_t)c.num_cus * 4 * 64;
+        for (uint32_t k = 1; k <= std::min<uint32_t>(lv.nl, 1); ++k) {     // later levels: inside the reduction kernel
+            KernelScope ks(c, "msm_small_fold");
+            const uint64_t est = k == 1 ? (uint64_t)S * NBL : (uint64_t)S * 2;      // chunks that really exist (estimate)
+            bool quad = est * 16 <= 2 * lanes_chip;
+            int gs = quad ? 4 : (est * 4 <= 2 * lanes_chip ? 4 : 2);
+            if (k == 1 && c.tune_fold_mode > 0) { quad = ((c.tune_fold_mode - 1) & 16) != 0; gs = (c.tune_fold_mode - 1) & 15; }
+            if (c.tune_small == 2) quad = false;
+            const uint64_t lanes = cap[k] * (uint64_t)gs * (quad ? 4 : 1);
+            const dim3 grid((unsigned)((lanes + 255) / 256));
+            const SmallChunk* cd = cdesc + lv.dbase[k];
+#define UZK_FOLD(QD, G) hipLaunchKernelGGL((msm_small_fold_kernel<QD, G>), grid, dim3(256), 0, st, P, cd, counters + k, lv.pbase[k])
+            if (quad) { if (gs >= 8) UZK_FOLD(true, 8); else if (gs >= 4) UZK_FOLD(true, 4); else UZK_FOLD(true, 2); }
+            else { if (gs >= 8) UZK_FOLD(false, 8); else if (gs >= 4) UZK_FOLD(false, 4); else if (gs >= 2) UZK_FOLD(false, 2); else UZK_FOLD(false, 1); }
+#undef UZK_FOLD
+        }
+        {
+            KernelScope ks(c, "msm_small_reduce");
+            const size_t lds = (size_t)NBL * sizeof(XYZZ);
+            if (NBL <= 128 && c.tune_small != 2)
+                hipLaunchKernelGGL((msm_small_reduce_kernel<true, 512>), dim3(S), dim3(4 * NBL), lds, st, P, bucket_ref, cdesc, slot_chunks, lv, win_sums, NBL);
+            else if (NBL <= 256 && c.tune_small != 2)
+                hipLaunchKernelGGL((msm_small_reduce_kernel<true, 1024>), dim3(S), dim3(4 * NBL), lds, st, P, bucket_ref, cdesc, slot_chunks, lv, win_sums, NBL);
+            else
+                hipLaunchKernelGGL((msm_small_reduce_kernel<false, 512>), dim3(S), dim3(NBL), lds, st, P, bucket_ref, cdesc, slot_chunks, lv, win_sums, NBL);
+        }
+        UZK_HIP(hipGetLastError());
+        UZK_HIP(hipMemcpyAsync(m.h_sums, win_sums, (size_t)S * sizeof(XYZZ), hipMemcpyDeviceToHost, st));
+    }
+    {
+        HostScope hs(c, "host_msm_wait2");
+        UZK_HIP(hipStreamSynchronize(st));
+    }
+    auto window_sum = [&](uint32_t b, uint32_t w) -> const XYZZ& { return m.h_sums[(size_t)b * W + w]; };
+    msm_horner_host(c, batch, W, pre_c > 0 ? 0 : cb, window_sum, out_host);
+    return UZK_OK;
+}
+
 void msm_plan_info(Ctx& c, size_t n, int* window_bits, int* windows) {
-    const int cb = choose_window_bits(n, c.msm_window_bits);
+    const int cb = msm_small_applies(c, n, 1) ? small_window_bits(c, n, 1) : choose_window_bits(n, c.msm_window_bits);
     *window_bits = cb;
     *windows = msm_num_windows(cb);
 }
@@ -1378,6 +1791,7 @@ int msm_run(Ctx& c, const Affine* points, const Fp* d_scalars, size_t n, uint32_
     if (n >= (1ull << 31)) { set_error("msm: n = %zu exceeds 2^31 - 1 points per call", n); return UZK_ERR_PARAMETER; }
     if (!c.msm) c.msm = new MsmWork[2];
     const bool pre = pre_c > 0;
+    if (msm_small_applies(c, n, batch, pre_c)) return msm_run_small(c, points, d_scalars, n, batch, out_host, pre_c, pre_stride, pre_off);
     const int cb = pre ? pre_c : choose_window_bits(n, c.msm_window_bits);
     const uint32_t W = (uint32_t)msm_num_windows(cb);
     // Optional: two overlapping groups (a quarter of the windows first).  Measured on MI355X it buys
@@ -1417,23 +1831,7 @@ int msm_run(Ctx& c, const Affine* points, const Fp* d_scalars, size_t n, uint32_
         const int k = (split && w >= wa) ? 1 : 0;
         return g[k].m->h_sums[(size_t)b * g[k].W + (w - g[k].w0)];
     };
-    auto horner = [&](uint32_t b) {
-        XYZZ total = xyzz_inf();
-        for (int w = (int)wpp - 1; w >= 0; --w) {
-            if (w != (int)wpp - 1) for (int d = 0; d < cb; ++d) total = xyzz_dbl(total);
-            xyzz_add(total, window_sum(b, (uint32_t)w));
-        }
-        out_host[b] = xyzz_to_jac(total);
-    };
-    HostScope hs_horner(c, "host_msm_horner");
-    if (batch > 1 && wpp > 1) {
-        // 254 dependent doublings per vector: ~0.06 ms each on one core, so spread the vectors over the pool
-        if (!g_horner_pool) g_horner_pool = new HornerPool(7);
-        const std::function<void(uint32_t)> job = [&](uint32_t b) { horner(b); };
-        g_horner_pool->run(batch, job);
-    } else {
-        for (uint32_t b = 0; b < batch; ++b) horner(b);
-    }
+    msm_horner_host(c, batch, wpp, cb, window_sum, out_host);
     return UZK_OK;
 }
 
