@@ -116,3 +116,38 @@ def test_small_pipeline_agrees_with_general(gpu, n):
         _apply(gpu, {})
         gpu.tune("msm_small", 1)
         srs.release()
+
+
+@pytest.mark.parametrize("n", [4096, 1 << 14, 3 << 12, 3 << 13, 98304, 1 << 17, 3 << 16])
+def test_ntt_fused_stages_agree_with_separate_kernels(gpu, n):
+    """Coset scaling and the radix-3 stage of 3 * 2^k domains run inside the first / last Stockham pass
+    (uzk_tune("ntt_fused", 1), the default); the separate scaling / decimation / combination kernels remain behind
+    ntt_fused = 0.  Same bytes for forward and inverse, with and without a coset shift, single and batched, in place
+    and out of place -- and the small sizes are anchored on the oracle."""
+    B = 3
+    x = torch.empty((B * n, 4), dtype=torch.int64, device="cuda")
+    a = torch.empty((B * n, 4), dtype=torch.int64, device="cuda")
+    b_ = torch.empty((B * n, 4), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    gpu.synth_scalars(x.data_ptr(), B * n, 90 + n % 7)
+    shift = oc.fr_from_ints([7, 12345678901234567890123])      # two different coset shifts
+    try:
+        for inv in (False, True):
+            for cs in (None, shift[0], shift[1]):
+                for batch in (1, B):
+                    gpu.tune("ntt_fused", 0)
+                    gpu.ntt_batch_device(x.data_ptr(), a.data_ptr(), n, batch, inverse=inv, coset_shift=cs, sync=True)
+                    gpu.tune("ntt_fused", 1)
+                    gpu.ntt_batch_device(x.data_ptr(), b_.data_ptr(), n, batch, inverse=inv, coset_shift=cs, sync=True)
+                    assert torch.equal(a[:batch * n], b_[:batch * n]), (inv, cs is not None, batch)
+                    b_[:batch * n] = x[:batch * n]                           # in place
+                    torch.cuda.synchronize()                                 # torch's copy runs on torch's stream, the library on its own
+                    gpu.ntt_batch_device(b_.data_ptr(), b_.data_ptr(), n, batch, inverse=inv, coset_shift=cs, sync=True)
+                    assert torch.equal(a[:batch * n], b_[:batch * n]), ("in place", inv, cs is not None, batch)
+        if n <= 98304:
+            hx = x[:n].cpu().numpy().view(np.uint64).reshape(-1, 4)
+            gpu.ntt_device(x.data_ptr(), a.data_ptr(), n, coset_shift=shift[0], sync=True)
+            want = oc.ntt(oc.mul_var(hx, shift[0]))
+            assert np.array_equal(a[:n].cpu().numpy().view(np.uint64).reshape(-1, 4), want)
+    finally:
+        gpu.tune("ntt_fused", 1)

@@ -78,6 +78,7 @@ struct Ctx {
     int tune_reduce_seg = 0;  // experiment: buckets per lane in the bucket reduction (0 = default)
     int tune_fused_hist = 1;  // 1: the digit kernel also produces the first sort pass's histograms (large n)
     int tune_sort_packed = 1; // 1: 4-byte entries between the two sort passes when the fields fit
+    int tune_ntt_fused = 1;   // 1: coset scaling and the radix-3 stage inside the first / last pass (0: separate kernels)
     int tune_ntt_l29 = 1;     // 1: NTT passes on the 29-bit-limb representation (0: 8x32-bit relaxed Montgomery)
     int tune_small = 1;       // 1: n <= 2^15 takes the one-workgroup-per-slot pipeline (msm_small_*)
     int tune_fold_mode = 0;   // experiment: level-1 fold of the small pipeline = 1 + 16 * quad + lanes per chunk
@@ -91,6 +92,7 @@ struct Ctx {
     struct PowCache { Fp key; bool valid = false; uint64_t stamp = 0; DevBuf buf; };
     PowCache pow_cache[8];
     uint64_t pow_stamp = 0;
+    std::vector<void*> ntt_fused;   // NttFused* (ntt.hip): tables of the fused coset / radix-3 transforms
     // SRS registry
     struct Srs {
         Affine* d_points = nullptr;

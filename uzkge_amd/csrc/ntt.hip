@@ -153,6 +153,19 @@ struct PassArgs {
     const Fp* tw256;       // omega_256^e, direction-specific
     const Fp* twp;         // pass table [m'][sigma] (nullptr on the last pass)
     uint64_t twp_count;    // entries of twp (29-bit-limb kernels: tables are limb planes, see tw29_load)
+    // ---- fused coset scaling and radix-3 stage (29-bit-limb kernels only; all zero = plain transform) ----
+    // First pass, m3 != 0: the launch runs 3 * batch sub-transforms of size m3 of batch vectors of 3 * m3 elements
+    // (blockIdx.y = 3 * vector + r).  Sub-transform r loads a = x[j], b = x[j + m3], c = x[j + 2 m3] and starts from
+    //   y_j = (a + alpha[r] b + beta[r] c) * in_tw[r][j]       (decimation in frequency by 3; r = 0 without tables: a + b + c)
+    // First pass, m3 == 0, in_tw[0] != null: y_j = x[j] * in_tw[0][j]  (coset pre-scaling k^j of a 2^k transform).
+    // Last pass: element i' of sub-transform r goes to out[out_mul * i' + r] (out_mul = 3 with m3, else 1), times
+    // out_tw[r][i'] when given (coset post-scaling of the inverse transforms).
+    uint64_t m3;
+    const Fp* in_tw[3];    // limb planes of N (or m3) entries each
+    Fp alpha[3], beta[3];  // 2^261-form
+    uint32_t use_ab;       // alpha / beta present (else plain sums for every r is NOT implied: r != 0 always needs them)
+    const Fp* out_tw[3];
+    uint32_t out_mul;      // 0 / 1: contiguous
 };
 
 constexpr int kPlane = 2048 + 64;   // uint4 slots per LDS plane (transposed layout needs T*(R+1))
@@ -312,6 +325,25 @@ __global__ __launch_bounds__(256) void ntt_repack_tw_kernel(const Fp* __restrict
     p2[i] = v.l[8];
 }
 
+// planes[j] = g^j * scale in 2^261-form (three-level power table of g), j < count: the coset / radix-3 input and
+// output tables of the fused transforms
+__global__ __launch_bounds__(256) void ntt_gen_pow_planes_kernel(Fp* __restrict__ dst_base, uint64_t count,
+                                                                 const Fp* __restrict__ pw, Fp scale) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    Fp g = Fr::mul(pw[j & 1023], pw[1024 + ((j >> 10) & 1023)]);
+    g = Fr::mul(g, pw[2048 + (j >> 20)]);
+    g = Fr::mul(g, scale);
+    for (int d = 0; d < 5; ++d) g = Fr::add(g, g);          // 2^256-form -> 2^261-form
+    const L29 v = F9::from_fp(g);
+    uint4* p0 = reinterpret_cast<uint4*>(dst_base);
+    uint4* p1 = p0 + count;
+    uint32_t* p2 = reinterpret_cast<uint32_t*>(p1 + count);
+    p0[j] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    p1[j] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+    p2[j] = v.l[8];
+}
+
 __device__ __forceinline__ void bf2_l(L29& a, L29& b) {
     L29 s = F9::add(a, b);
     b = F9::sub<4>(a, b);
@@ -352,6 +384,8 @@ __global__ __launch_bounds__(512, 4) void ntt_pass29_kernel(const Fp* __restrict
     const int col = tid % T, q = tid / T;
     const uint64_t i0 = (uint64_t)blockIdx.x * T;
     const uint64_t i = i0 + col;
+    const Fp* in_base = in;
+    Fp* out_base = out;
     in += (uint64_t)blockIdx.y * a.batch_stride;
     out += (uint64_t)blockIdx.y * a.batch_stride;
 
@@ -360,8 +394,38 @@ __global__ __launch_bounds__(512, 4) void ntt_pass29_kernel(const Fp* __restrict
     int rows[4];
 
     // ---- sub-pass 0: radix 4 straight from global memory
+    if constexpr (FIRST) {
+        if (a.m3 != 0) {
+            // decimation in frequency by 3 in front of sub-transform r of vector blockIdx.y / 3 (see PassArgs)
+            const uint32_t r = blockIdx.y % 3;
+            const Fp* vec = in_base + (uint64_t)(blockIdx.y / 3) * (3 * a.m3);
+            const bool tabled = a.in_tw[r] != nullptr;
+            L29 al, be;
+            if (r != 0) { al = F9::from_fp(a.alpha[r]); be = F9::from_fp(a.beta[r]); }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) x[t] = F9::from_fp(in[i + (uint64_t)(q + t * Q) * a.stride]);
+            for (int t = 0; t < 4; ++t) {
+                const uint64_t j = i + (uint64_t)(q + t * Q) * a.stride;
+                const L29 xa = F9::from_fp(vec[j]), xb = F9::from_fp(vec[j + a.m3]), xc = F9::from_fp(vec[j + 2 * a.m3]);
+                L29 y;
+                if (r == 0 && !a.use_ab) y = F9::add(F9::add(xa, xb), xc);                  // limbs < 3 * 2^29, value < 3M
+                else if (r == 0) y = F9::add(xa, F9::mul2(xb, F9::from_fp(a.alpha[0]), xc, F9::from_fp(a.beta[0])));
+                else y = F9::add(xa, F9::mul2(xb, al, xc, be));                            // limbs < 2^30, value < 2.1M
+                x[t] = tabled ? F9::mul(y, tw29_load(a.in_tw[r], a.m3, j)) : F9::reduce(y);  // normalized, value < 2M
+            }
+        } else if (a.in_tw[0] != nullptr) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const uint64_t j = i + (uint64_t)(q + t * Q) * a.stride;
+                x[t] = F9::mul(F9::from_fp(in[j]), tw29_load(a.in_tw[0], a.batch_stride, j));
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) x[t] = F9::from_fp(in[i + (uint64_t)(q + t * Q) * a.stride]);
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) x[t] = F9::from_fp(in[i + (uint64_t)(q + t * Q) * a.stride]);
+    }
     radix4_l(x[0], x[1], x[2], x[3], w4);
     if constexpr (N4 > 1 || TAIL2) {
         x[0] = F9::reduce(x[0]);
@@ -427,12 +491,28 @@ __global__ __launch_bounds__(512, 4) void ntt_pass29_kernel(const Fp* __restrict
     } else {
         const uint64_t mp = i >> a.log_S, sp = i & ((1ull << a.log_S) - 1);
         const uint64_t base = (mp << (a.log_S + B)) + sp;
+        if (a.twp == nullptr && (a.out_mul > 1 || a.out_tw[0] != nullptr)) {
+            // last pass of a fused transform: interleaved store (radix-3 outputs 3 i' + r) and / or coset post-scaling
+            const uint32_t mul = a.out_mul > 1 ? a.out_mul : 1u;
+            const uint32_t r = mul > 1 ? blockIdx.y % mul : 0u;
+            Fp* dst = mul > 1 ? out_base + (uint64_t)(blockIdx.y / mul) * (mul * a.batch_stride) : out;
+            const Fp* otw = a.out_tw[r];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint64_t pos = base + ((uint64_t)rows[j] << a.log_S);
+                L29 v = x[j];
+                if (otw != nullptr) v = F9::mul(v, tw29_load(otw, a.batch_stride, pos));   // lazy v: limbs < 2^31.5, value < 10M
+                v = F9::canon(v);
+                dst[(uint64_t)mul * pos + r] = F9::to_fp(v);
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             L29 v = x[j];
             if (a.twp != nullptr) v = F9::mul(v, tw29_load(a.twp, a.twp_count, (mp << B) + rows[j]));
             else v = F9::canon(v);                 // last pass: back to [0, M)
             out[base + ((uint64_t)rows[j] << a.log_S)] = F9::to_fp(v);
+        }
         }
     }
 }
@@ -611,7 +691,10 @@ static void launch_pass(Ctx& c, bool l29, bool first, const Fp* in, Fp* out, con
 
 // power-of-two transform d_in -> d_out (may alias)
 // `batch` contiguous vectors of n elements each, d_in -> d_out (may alias)
-static int ntt_pow2(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse, bool scaled, uint32_t batch) {
+// `fx` (optional): the fused stages of PassArgs -- first-pass input tables / radix-3 load, last-pass interleaved store
+// and output tables; batch then counts sub-transforms (3 per vector when fx->m3 != 0).
+static int ntt_pow2(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse, bool scaled, uint32_t batch,
+                    const PassArgs* fx = nullptr) {
     NttPlan* p = nullptr;
     UZK_TRY(get_plan(c, n, inverse, scaled, &p));
     if (p->log_n <= 11) {
@@ -639,7 +722,11 @@ static int ntt_pow2(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse,
         const int remaining = p->npass - 1 - j;
         Fp* dst = (remaining % 2 == 0) ? d_out : s0;
         if (dst == src) dst = s1;   // only when in_place and npass is odd, at j == 0
-        PassArgs a;
+        PassArgs a{};
+        if (fx != nullptr) {
+            if (j == 0) { a.m3 = fx->m3; a.use_ab = fx->use_ab; for (int k = 0; k < 3; ++k) { a.in_tw[k] = fx->in_tw[k]; a.alpha[k] = fx->alpha[k]; a.beta[k] = fx->beta[k]; } }
+            if (j == p->npass - 1) { a.out_mul = fx->out_mul; for (int k = 0; k < 3; ++k) a.out_tw[k] = fx->out_tw[k]; }
+        }
         a.batch_stride = n;
         a.stride = n >> p->bits[j];
         a.log_S = log_S;
@@ -664,9 +751,11 @@ static int ntt_pow2(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse,
 
 // three-level power table of an arbitrary element, cached by value (a proof alternates between k and 1/k and
 // between the forward and inverse mixed-radix roots: all of them stay resident, a hit costs nothing)
+static void release_fused(Ctx& c);
 static void release_ntt_caches(Ctx& c) {
     for (auto& pc : c.pow_cache) { pc.buf.release(); pc.valid = false; }
     c.ntt_sub.release();
+    release_fused(c);
 }
 
 static int pow_table_device(Ctx& c, const Fp& g, const Fp** out) {
@@ -690,6 +779,104 @@ static int pow_table_device(Ctx& c, const Fp& g, const Fp** out) {
     return UZK_OK;
 }
 
+// ---- fused transforms: coset scaling and the radix-3 stage inside the first / last pass -----------------------
+// Device tables of one (n, direction, coset shift): built once, kept (a proof uses a handful: k and 1/k on the 6n
+// domain, nothing else), all dropped together when the cache is full or on shutdown.
+struct NttFused {
+    uint64_t n = 0;
+    bool inverse = false, has_shift = false;
+    Fp shift;
+    PassArgs fx{};            // the fused fields of PassArgs, ready to copy
+    Fp* tables[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+static void release_fused(Ctx& c) {
+    for (void* v : c.ntt_fused) {
+        NttFused* f = static_cast<NttFused*>(v);
+        for (Fp* t : f->tables) if (t) (void)hipFree(t);
+        delete f;
+    }
+    c.ntt_fused.clear();
+}
+// planes of count entries: base^j * scale (2^261-form)
+static int gen_pow_planes(Ctx& c, const Fp& base, const Fp& scale, uint64_t count, Fp** out) {
+    const Fp* pw = nullptr;
+    UZK_TRY(pow_table_device(c, base, &pw));
+    Fp* planes = nullptr;
+    UZK_HIP(hipMalloc(reinterpret_cast<void**>(&planes), count * 36 + 64));
+    KernelScope ks(c, "ntt_gen_tables");
+    hipLaunchKernelGGL(ntt_gen_pow_planes_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c.stream, planes, count, pw, scale);
+    UZK_HIP(hipGetLastError());
+    *out = planes;
+    return UZK_OK;
+}
+static Fp to_261(Fp v) { for (int d = 0; d < 5; ++d) v = Fr::add(v, v); return v; }
+
+static int get_fused(Ctx& c, uint64_t n, bool inverse, const Fp* shift, NttFused** out) {
+    for (void* v : c.ntt_fused) {
+        NttFused* f = static_cast<NttFused*>(v);
+        if (f->n == n && f->inverse == inverse && f->has_shift == (shift != nullptr) && (!shift || Fr::eq(f->shift, *shift))) { *out = f; return UZK_OK; }
+    }
+    if (c.ntt_fused.size() >= 16) { UZK_HIP(hipStreamSynchronize(c.stream)); release_fused(c); }
+    NttFused* f = new NttFused();
+    f->n = n; f->inverse = inverse; f->has_shift = shift != nullptr;
+    if (shift) f->shift = *shift;
+    int nt = 0;
+    auto fail = [&](int rc) { for (Fp* t : f->tables) if (t) (void)hipFree(t); delete f; return rc; };
+    const Fp one = Fr::one();
+    if (n % 3 != 0) {
+        // 2^k coset: forward pre-scales by shift^j in the first pass, inverse post-scales by shift^i in the last
+        Fp* t = nullptr;
+        int rc = gen_pow_planes(c, *shift, one, n, &t);
+        if (rc != UZK_OK) return fail(rc);
+        f->tables[nt++] = t;
+        if (!inverse) f->fx.in_tw[0] = t; else f->fx.out_tw[0] = t;
+    } else {
+        // n = 3m.  X[3i' + r] = NTT_m( w^(rj) k^j (x_j + zeta^r k^m x_(j+m) + zeta^(2r) k^(2m) x_(j+2m)) )[i'],
+        // w = group_gen(n) (inverted for the inverse transform), zeta = w^m, k = the forward coset shift (1 otherwise);
+        // the inverse carries 1/n in its input tables and post-scales by shift^(3i' + r).
+        const uint64_t m = n / 3;
+        Fp w = fr_root_of_unity(n);
+        if (inverse) w = fr_inv(w);
+        const Fp zeta = f_pow_u64<Fr>(w, m);
+        const Fp k = (!inverse && shift) ? *shift : one;
+        const Fp km = f_pow_u64<Fr>(k, m), k2m = Fr::sqr(km);
+        const Fp ninv = inverse ? fr_inv(fr_from_u64(n)) : one;
+        f->fx.m3 = m;
+        f->fx.out_mul = 3;
+        f->fx.use_ab = (!inverse && shift) ? 1u : 0u;
+        Fp zr = one, wr = one;                                   // zeta^r, w^r
+        for (int r = 0; r < 3; ++r) {
+            f->fx.alpha[r] = to_261(Fr::mul(zr, km));
+            f->fx.beta[r] = to_261(Fr::mul(Fr::sqr(zr), k2m));
+            const bool need_table = r != 0 || inverse || shift != nullptr;     // r = 0 plain forward: a + b + c, no products
+            if (need_table) {
+                Fp* t = nullptr;
+                int rc = gen_pow_planes(c, Fr::mul(wr, k), ninv, m, &t);        // (w^r k)^j / n
+                if (rc != UZK_OK) return fail(rc);
+                f->tables[nt++] = t;
+                f->fx.in_tw[r] = t;
+            }
+            zr = Fr::mul(zr, zeta);
+            wr = Fr::mul(wr, w);
+        }
+        if (inverse && shift) {
+            const Fp s3 = Fr::mul(Fr::sqr(*shift), *shift);
+            Fp sr = one;
+            for (int r = 0; r < 3; ++r) {
+                Fp* t = nullptr;
+                int rc = gen_pow_planes(c, s3, sr, m, &t);                      // shift^(3i' + r)
+                if (rc != UZK_OK) return fail(rc);
+                f->tables[nt++] = t;
+                f->fx.out_tw[r] = t;
+                sr = Fr::mul(sr, *shift);
+            }
+        }
+    }
+    c.ntt_fused.push_back(f);
+    *out = f;
+    return UZK_OK;
+}
+
 // `batch` independent transforms over contiguous vectors of n elements (d_in -> d_out, may alias).
 int ntt_run(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse, const Fp* coset_shift_host, uint32_t batch) {
     if (!domain_supported(n)) {
@@ -698,6 +885,15 @@ int ntt_run(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse, const F
     }
     if (batch == 0) return UZK_OK;
     if (batch > 65535) { set_error("ntt: batch %u exceeds 65535", batch); return UZK_ERR_PARAMETER; }
+    // 29-bit-limb pass kernels: coset scaling and the radix-3 stage of 3 * 2^k domains run inside the first / last pass
+    // (no separate scaling, decimation or combination kernels; 2 launches for the prover's 98304-point coset FFTs)
+    const uint64_t sub_n = n % 3 == 0 ? n / 3 : n;
+    if (c.tune_ntt_l29 && c.tune_ntt_fused && sub_n >= 4096 && (n % 3 == 0 || coset_shift_host != nullptr)) {
+        NttFused* f = nullptr;
+        UZK_TRY(get_fused(c, n, inverse, coset_shift_host, &f));
+        if (n % 3 == 0) return ntt_pow2(c, d_in, d_out, sub_n, inverse, false, 3 * batch, &f->fx);
+        return ntt_pow2(c, d_in, d_out, n, inverse, inverse, batch, &f->fx);
+    }
     const dim3 egrid((unsigned)((n + 255) / 256), batch);
     const Fp* src = d_in;
     if (coset_shift_host != nullptr && !inverse) {
