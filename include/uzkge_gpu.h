@@ -161,6 +161,15 @@ int uzk_open_quotient(const uint64_t* polys, uint64_t n, uint32_t batch, const u
  * apply_blind_factors(blinds, N).  d_out may alias d_coefs. */
 int uzk_fold_blinds_device(const void* d_coefs, uint64_t len, uint64_t n_fold, void* d_out, uint64_t* blinds_out);
 
+/* d_out[j] = sum_k scalars[k] * d_polys[k][j] for j < out_len (a polynomial contributes zero beyond lens[k]): the shape of
+ * r_poly (uzkge/src/plonk/helpers.rs:681-999, 1030-1090) -- about 43 device-resident polynomials times scalars that the
+ * caller builds from the evaluations and challenges exactly as the reference does.  count <= 64; d_out aliases no input. */
+int uzk_poly_lincomb_device(const void* const* d_polys, const uint64_t* lens, const uint64_t* scalars_mont, uint32_t count,
+                            void* d_out, uint64_t out_len);
+/* hide_polynomial (uzkge/src/plonk/helpers.rs:139-158) on device-resident coefficients (len >= zeroing_degree +
+ * hiding_degree, zero-padded by the caller): coefs[i] += blinds[i], coefs[zeroing_degree + i] -= blinds[i]. */
+int uzk_hide_polynomial_device(void* d_coefs, uint64_t len, const uint64_t* blinds_mont, uint32_t hiding_degree, uint64_t zeroing_degree);
+
 /* The quotient evaluations of t_poly on the coset k[1]*<g_m> (uzkge/src/plonk/helpers.rs:284-656 with
  * the "shuffle" feature; gate function turbo/mod.rs:193-222): for every point of the m = factor*n
  * domain, the 18 terms (gate, permutation, L1, booleanity, Anemoi round, shuffle/ECC selectors) are
@@ -192,7 +201,9 @@ typedef struct {
     uint64_t alpha[4], beta[4], gamma[4], k[5][4], anemoi_g[4], anemoi_g_inv[4], edwards_a[4];
     uint64_t z_h_inv[16][4];            /* 1 / (k[1]^n * g_m^(n*i) - 1), i < factor (helpers.rs:242-252) */
 } uzk_quotient_args;
-/* d_out: m elements on the device (must not alias an input). */
+/* d_out: m elements on the device (must not alias an input).  A circuit built without the "shuffle" feature (zmatchmaking)
+ * passes NULL in all 28 slots of UZK_TQ_WSEL, UZK_TQ_QPK, UZK_TQ_QG and UZK_TQ_QECC: terms 12..18 (helpers.rs:437-655,
+ * #[cfg(feature = "shuffle")]) are then not evaluated. */
 int uzk_t_quotient_device(const uzk_quotient_args* args, void* d_out, int sync);
 
 /* ---- synthetic workloads (bench / tests; generated on device, nothing uploaded) -------- */

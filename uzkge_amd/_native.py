@@ -51,6 +51,8 @@ PROTOTYPES = {
     "uzk_open_quotient_device": (_I, [_P, ctypes.c_uint64, ctypes.c_uint32, _P, _P, _P, _P]),
     "uzk_open_quotient": (_I, [_P, ctypes.c_uint64, ctypes.c_uint32, _P, _P, _P, _P]),
     "uzk_fold_blinds_device": (_I, [_P, ctypes.c_uint64, ctypes.c_uint64, _P, _P]),
+    "uzk_poly_lincomb_device": (_I, [_P, _P, _P, ctypes.c_uint32, _P, ctypes.c_uint64]),
+    "uzk_hide_polynomial_device": (_I, [_P, ctypes.c_uint64, _P, ctypes.c_uint32, ctypes.c_uint64]),
     "uzk_synth_points_arith": (_I, [_P, _SZ, _P]),
     "uzk_synth_points_random": (_I, [_P, _SZ, _U64]),
     "uzk_synth_scalars": (_I, [_P, _SZ, _U64]),

@@ -179,6 +179,14 @@ def poly_eval_batch(coefs: np.ndarray, x_mont: np.ndarray) -> np.ndarray:
     return out
 
 
+def poly_eval_batch_device(d_coefs: int, n: int, batch: int, x_mont: np.ndarray) -> np.ndarray:
+    """batch device-resident polynomials of n coefficients each (contiguous) evaluated at one point -> [batch, 4]."""
+    x = np.ascontiguousarray(x_mont, dtype=np.uint64).reshape(4)
+    out = np.zeros((batch, 4), dtype=np.uint64)
+    check(lib.uzk_poly_eval_batch_device(ctypes.c_void_p(d_coefs), n, batch, _ptr(x), _ptr(out)))
+    return out
+
+
 def z_poly(w: np.ndarray, perm: np.ndarray, group: np.ndarray, k: np.ndarray, beta: np.ndarray, gamma: np.ndarray) -> np.ndarray:
     """Permutation grand product evaluations (helpers.rs:160-220).  w [n_wires, n, 4], perm [n_wires, n] uint32."""
     wv = np.ascontiguousarray(w, dtype=np.uint64)
@@ -232,6 +240,21 @@ def fold_blinds_device(d_coefs: int, length: int, n_fold: int, d_out: int) -> np
     blinds = np.zeros((max(nb, 1), 4), dtype=np.uint64)
     check(lib.uzk_fold_blinds_device(ctypes.c_void_p(d_coefs), length, n_fold, ctypes.c_void_p(d_out), _ptr(blinds)))
     return blinds[:nb]
+
+
+def poly_lincomb_device(d_polys, lens, scalars: np.ndarray, d_out: int, out_len: int) -> None:
+    """d_out[j] = sum_k scalars[k] * poly_k[j] (r_poly's shape, helpers.rs:681-999); d_polys: device pointers, lens: lengths."""
+    cnt = len(d_polys)
+    ptrs = (ctypes.c_void_p * cnt)(*[ctypes.c_void_p(p) for p in d_polys])
+    ln = np.ascontiguousarray(lens, dtype=np.uint64)
+    sc = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(cnt, 4)
+    check(lib.uzk_poly_lincomb_device(ptrs, _ptr(ln), _ptr(sc), cnt, ctypes.c_void_p(d_out), out_len))
+
+
+def hide_polynomial_device(d_coefs: int, length: int, blinds: np.ndarray, zeroing_degree: int) -> None:
+    """hide_polynomial (helpers.rs:139-158) on device-resident coefficients."""
+    bl = np.ascontiguousarray(blinds, dtype=np.uint64).reshape(-1, 4)
+    check(lib.uzk_hide_polynomial_device(ctypes.c_void_p(d_coefs), length, _ptr(bl) if bl.shape[0] else None, bl.shape[0], zeroing_degree))
 
 
 def t_quotient_device(n: int, factor: int, vec_ptrs, alpha, beta, gamma, k, anemoi_g, anemoi_g_inv, edwards_a,

@@ -521,6 +521,21 @@ int uzk_fold_blinds_device(const void* d_coefs, uint64_t len, uint64_t n_fold, v
     return fold_blinds_run(ctx(), static_cast<const Fp*>(d_coefs), len, n_fold, static_cast<Fp*>(d_out), reinterpret_cast<Fp*>(blinds_out));
 }
 
+int uzk_poly_lincomb_device(const void* const* d_polys, const uint64_t* lens, const uint64_t* scalars_mont, uint32_t count,
+                            void* d_out, uint64_t out_len) {
+    API_LOCK;
+    if (!d_polys || !lens || !scalars_mont || (out_len > 0 && !d_out)) { set_error("uzk_poly_lincomb_device: null pointer"); return UZK_ERR_PARAMETER; }
+    UZK_TRY(require_ready());
+    return poly_lincomb_run(ctx(), d_polys, lens, as_fp(scalars_mont), count, static_cast<Fp*>(d_out), out_len);
+}
+
+int uzk_hide_polynomial_device(void* d_coefs, uint64_t len, const uint64_t* blinds_mont, uint32_t hiding_degree, uint64_t zeroing_degree) {
+    API_LOCK;
+    if (!d_coefs || (hiding_degree > 0 && !blinds_mont)) { set_error("uzk_hide_polynomial_device: null pointer"); return UZK_ERR_PARAMETER; }
+    UZK_TRY(require_ready());
+    return poly_hide_run(ctx(), static_cast<Fp*>(d_coefs), len, as_fp(blinds_mont), hiding_degree, zeroing_degree);
+}
+
 int uzk_t_quotient_device(const uzk_quotient_args* args, void* d_out, int sync) {
     API_LOCK;
     if (!args || !d_out) { set_error("uzk_t_quotient_device: null pointer"); return UZK_ERR_PARAMETER; }

@@ -155,6 +155,9 @@ int poly_eval_batch_host(Ctx& c, const Fp* coefs_host, uint64_t n, uint32_t batc
 int open_quotient_run(Ctx& c, const Fp* d_polys, uint64_t n, uint32_t batch, const Fp& z, const Fp& alpha, Fp* d_q,
                       Fp* evals_host);
 int fold_blinds_run(Ctx& c, const Fp* d_coefs, uint64_t len, uint64_t N, Fp* d_out, Fp* blinds_host);
+int poly_lincomb_run(Ctx& c, const void* const* d_polys, const uint64_t* lens, const Fp* scalars_host, uint32_t count, Fp* d_out,
+                     uint64_t out_len);
+int poly_hide_run(Ctx& c, Fp* d_coefs, uint64_t len, const Fp* blinds_host, uint32_t hiding_degree, uint64_t zeroing_degree);
 struct QuotientDev;
 int t_quotient_run(Ctx& c, const void* args_c_abi, Fp* d_out);
 int z_poly_device(Ctx& c, const Fp* d_w, const uint32_t* d_perm, const Fp* d_group, const Fp* k_host, const Fp& beta,

@@ -274,6 +274,9 @@ struct QuotientDev {
     Fp zhi[16];
 };
 
+// SHUFFLE = false: the circuit has no shuffle / ECC selectors (uzkge built without the "shuffle" feature, e.g.
+// zmatchmaking): terms 12..18 of helpers.rs:437-655 do not exist and their 28 vectors are not read.
+template <bool SHUFFLE>
 __global__ __launch_bounds__(256) void t_quotient_kernel(QuotientDev a, Fp* __restrict__ out) {
     const uint32_t point = blockIdx.x * blockDim.x + threadIdx.x;
     if (point >= a.m) return;
@@ -339,7 +342,7 @@ __global__ __launch_bounds__(256) void t_quotient_kernel(QuotientDev a, Fp* __re
         acc = Fr::sub(acc, Fr::mul(prk3, s));
     }
     // terms 12..18: shuffle / ECC
-    {
+    if constexpr (SHUFFLE) {
         const Fp ws0 = L(5), ws1 = L(6), ws2 = L(7), qecc = L(55);
         const Fp om0 = Fr::sub(one, ws0), om1 = Fr::sub(one, ws1);
         Fp sel[4];
@@ -398,9 +401,18 @@ int t_quotient_run(Ctx& c, const void* args_c_abi, Fp* d_out) {
     QuotientDev d;
     d.m = A.n * A.factor;
     d.factor = A.factor;
+    // the 28 vectors of the "shuffle" feature (w_sel, q_shuffle_public_key, q_shuffle_generator, q_ecc) are either all
+    // given or all null (a circuit without them: terms 12..18 vanish)
+    auto is_shuffle_slot = [](int i) { return (i >= UZK_TQ_WSEL && i < UZK_TQ_PI) || i >= UZK_TQ_QPK; };
+    int shuffle_present = 0;
+    for (int i = 0; i < 56; ++i) if (is_shuffle_slot(i) && A.vec[i]) ++shuffle_present;
+    if (shuffle_present != 0 && shuffle_present != 28) {
+        set_error("t_quotient: the shuffle-feature vectors (w_sel, q_pk, q_g, q_ecc) must be all present or all null (%d of 28 given)", shuffle_present);
+        return UZK_ERR_PARAMETER;
+    }
     for (int i = 0; i < 56; ++i) {
-        if (!A.vec[i]) { set_error("t_quotient: vec[%d] is null", i); return UZK_ERR_PARAMETER; }
-        if (A.vec[i] == d_out) { set_error("t_quotient: output aliases vec[%d]", i); return UZK_ERR_PARAMETER; }
+        if (!A.vec[i] && !(is_shuffle_slot(i) && shuffle_present == 0)) { set_error("t_quotient: vec[%d] is null", i); return UZK_ERR_PARAMETER; }
+        if (A.vec[i] && A.vec[i] == d_out) { set_error("t_quotient: output aliases vec[%d]", i); return UZK_ERR_PARAMETER; }
         d.vec[i] = static_cast<const Fp*>(A.vec[i]);
     }
     const Fp alpha = fp_from_words(A.alpha), beta = fp_from_words(A.beta), g = fp_from_words(A.anemoi_g);
@@ -413,7 +425,8 @@ int t_quotient_run(Ctx& c, const void* args_c_abi, Fp* d_out) {
     d.g2p1 = Fr::add(Fr::sqr(g), Fr::one());
     for (int i = 0; i < 16; ++i) d.zhi[i] = fp_from_words(A.z_h_inv[i]);
     KernelScope ks(c, "t_quotient");
-    hipLaunchKernelGGL(t_quotient_kernel, dim3((d.m + 255) / 256), dim3(256), 0, c.stream, d, d_out);
+    if (shuffle_present) hipLaunchKernelGGL(t_quotient_kernel<true>, dim3((d.m + 255) / 256), dim3(256), 0, c.stream, d, d_out);
+    else hipLaunchKernelGGL(t_quotient_kernel<false>, dim3((d.m + 255) / 256), dim3(256), 0, c.stream, d, d_out);
     UZK_HIP(hipGetLastError());
     return UZK_OK;
 }
@@ -593,6 +606,73 @@ int fold_blinds_run(Ctx& c, const Fp* d_coefs, uint64_t len, uint64_t N, Fp* d_o
         UZK_HIP(hipMemcpyAsync(blinds_host, c.poly_tmp2.p, nb * sizeof(Fp), hipMemcpyDeviceToHost, c.stream));
         UZK_HIP(hipStreamSynchronize(c.stream));
     }
+    return UZK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// out[j] = sum_k scalar_k * p_k[j]  (p_k[j] = 0 beyond its length): the shape of r_poly
+// (uzkge/src/plonk/helpers.rs:681-999: ~43 polynomials times scalars built from the evaluations and challenges --
+// those O(1) scalar formulas stay with the caller, exactly where the reference computes them).
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kLincombMax = 64;
+struct LincombArgs {
+    const Fp* p[kLincombMax];
+    uint32_t len[kLincombMax];
+    uint32_t count;
+};
+__global__ __launch_bounds__(256) void poly_lincomb_kernel(LincombArgs a, const Fp* __restrict__ scalars, Fp* __restrict__ out,
+                                                           uint64_t out_len) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= out_len) return;
+    Fp acc = Fr::zero();
+    for (uint32_t k = 0; k < a.count; ++k)
+        if (j < a.len[k]) acc = Fr::add(acc, Fr::mul(scalars[k], a.p[k][j]));
+    out[j] = acc;
+}
+int poly_lincomb_run(Ctx& c, const void* const* d_polys, const uint64_t* lens, const Fp* scalars_host, uint32_t count, Fp* d_out,
+                     uint64_t out_len) {
+    if (count == 0 || count > kLincombMax) { set_error("poly_lincomb: 1 <= count <= %u", kLincombMax); return UZK_ERR_PARAMETER; }
+    LincombArgs a;
+    a.count = count;
+    for (uint32_t k = 0; k < count; ++k) {
+        if (!d_polys[k] && lens[k]) { set_error("poly_lincomb: polynomial %u is null", k); return UZK_ERR_PARAMETER; }
+        if (d_polys[k] == d_out) { set_error("poly_lincomb: output aliases polynomial %u", k); return UZK_ERR_PARAMETER; }
+        if (lens[k] >= (1ull << 32)) { set_error("poly_lincomb: polynomial %u too long", k); return UZK_ERR_PARAMETER; }
+        a.p[k] = static_cast<const Fp*>(d_polys[k]);
+        a.len[k] = (uint32_t)lens[k];
+    }
+    if (out_len == 0) return UZK_OK;
+    UZK_TRY(c.poly_tmp2.reserve((size_t)kLincombMax * sizeof(Fp)));
+    UZK_HIP(hipMemcpyAsync(c.poly_tmp2.p, scalars_host, (size_t)count * sizeof(Fp), hipMemcpyHostToDevice, c.stream));
+    {
+        KernelScope ks(c, "poly_lincomb");
+        hipLaunchKernelGGL(poly_lincomb_kernel, dim3((unsigned)((out_len + 255) / 256)), dim3(256), 0, c.stream, a, c.poly_tmp2.as<Fp>(),
+                           d_out, out_len);
+    }
+    UZK_HIP(hipGetLastError());
+    UZK_HIP(hipStreamSynchronize(c.stream));      // scalars_host belongs to the caller
+    return UZK_OK;
+}
+
+// hide_polynomial (uzkge/src/plonk/helpers.rs:139-158) on device-resident coefficients:
+// coefs[i] += blind_i, coefs[zeroing_degree + i] -= blind_i  (adds (b_0 + b_1 X + ..)(X^zeroing_degree - 1)).
+__global__ void poly_hide_kernel(Fp* __restrict__ coefs, uint64_t zeroing_degree, const Fp* __restrict__ blinds, uint32_t count) {
+    const uint32_t i = threadIdx.x;
+    if (i >= count) return;
+    coefs[i] = Fr::add(coefs[i], blinds[i]);
+    coefs[zeroing_degree + i] = Fr::sub(coefs[zeroing_degree + i], blinds[i]);
+}
+int poly_hide_run(Ctx& c, Fp* d_coefs, uint64_t len, const Fp* blinds_host, uint32_t hiding_degree, uint64_t zeroing_degree) {
+    if (hiding_degree == 0) return UZK_OK;
+    if (hiding_degree > 64 || hiding_degree > zeroing_degree || zeroing_degree + hiding_degree > len) {
+        set_error("hide_polynomial: need hiding_degree <= min(64, zeroing_degree) and zeroing_degree + hiding_degree <= len");
+        return UZK_ERR_PARAMETER;
+    }
+    UZK_TRY(c.poly_tmp2.reserve((size_t)kLincombMax * sizeof(Fp)));
+    UZK_HIP(hipMemcpyAsync(c.poly_tmp2.p, blinds_host, (size_t)hiding_degree * sizeof(Fp), hipMemcpyHostToDevice, c.stream));
+    hipLaunchKernelGGL(poly_hide_kernel, dim3(1), dim3(64), 0, c.stream, d_coefs, zeroing_degree, c.poly_tmp2.as<Fp>(), hiding_degree);
+    UZK_HIP(hipGetLastError());
+    UZK_HIP(hipStreamSynchronize(c.stream));
     return UZK_OK;
 }
 
