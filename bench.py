@@ -31,13 +31,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-MAD_PEAK_T = 30.4        # T lane-MAD/s, measured (tools/microbench/int_rates.hip, profiles/r01i_microbench.txt)
-MADS_PER_MIXED_ADD = 1467
-CYC_PER_MAD = 5.17        # issue cycles per wave instruction at 4 waves/SIMD (int_rates.hip)
-CYC_PER_OTHER_VALU = 3.4   # mean over the loop's other VALU instructions (v_and 2.7, v_lshrrev_b64 4.25, v_mul_lo 4.46, ...)
-OTHER_VALU_PER_MIXED_ADD = 586   # tools/isa_hist.py on the accumulation loop; plus 176 s_nop after asm statements
+MADS_PER_MIXED_ADD = 1467   # v_mad_u64_u32 per mixed addition (ec29.hpp: 6 products, 2 squarings, 1 dual product)
 NUM_SIMDS = 1024
-MAD_PEAK_SCLK_MHZ = 2390  # shader clock during that sub-millisecond microbenchmark (rocm-smi: 2388-2393 MHz)
+LANES = 64
+BOOST_SCLK_MHZ = 2390
+# The roofline that binds both hot loops is vector-instruction ISSUE: a SIMD issues at most one vector instruction per
+# quad-cycle (4 cycles), whatever the instruction (the SQ counters show SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU for these
+# kernels, v_mad_u64_u32 included: profiles/sq_counters.json).  Peak = 1024 SIMDs x 64 lanes x sclk / 4 lane-instructions/s.
+
+
+def _issue_peak_t(sclk_mhz: float) -> float:
+    return NUM_SIMDS * LANES * sclk_mhz * 1e6 / 4.0 / 1e12
 
 
 def _sample_clocks(work, sync, seconds: float = 2.0):
@@ -336,36 +340,43 @@ def run_rank(args) -> None:
             traffic = ent["traffic_bytes"]
         else:
             traffic_note = "no PMC pass for this configuration"
-    # The kernel's real bound is the 64-bit multiply-add pipe: every mixed addition is 1467
-    # v_mad_u64_u32 per lane (ec29.hpp: 6 products, 2 squarings, 1 dual product on 9 x 29-bit limbs)
-    # against the measured issue peak of that instruction (tools/microbench/int_rates.hip:
-    # 5.17 cycles per wave instruction per SIMD at 4 waves/SIMD = 30.4 T lane-MAD/s chip-wide).
+    # The kernel's real bound is vector-instruction issue (see _issue_peak_t): every mixed addition is ~2090 vector
+    # instructions per lane, 1467 of them v_mad_u64_u32 (ec29.hpp); the count per addition and the measured issue
+    # utilisation come from the SQ counter pass of the same kernel (profiles/sq_counters.json, separate rocprofv3 --pmc
+    # runs), the achieved rate from the kernel's mean duration in THIS run.
     cbits, nwin = (args.window_bits, 0)
     try:
         cbits, nwin = b.msm_plan_info(n)
     except Exception:
         pass
-    mads = float(MADS_PER_MIXED_ADD) * n * nwin
-    alu_achieved = mads / (acc_avg_ms * 1e-3) / 1e12 if acc_cnt and nwin else 0.0
+    adds = float(n) * nwin
+    sq, why = _load_counters("sq_counters.json")
+    insts_per_add = None
+    if sq is not None and "msm_accumulate" in sq and n == (1 << 24) and args.scalars == "uniform" and not args.window_bits:
+        ent = sq["msm_accumulate"]
+        insts_per_add = ent["SQ_INSTS_VALU"] * LANES / adds        # wave instructions x 64 lanes / lane-additions
+    alu = {"unit": "T lane vector-instructions/s (issue: one per SIMD per 4 cycles)", "mixed_adds_per_launch": int(adds),
+           "window_bits": cbits, "windows": nwin, "mads_per_mixed_add": MADS_PER_MIXED_ADD,
+           "peak_at_boost_clock": round(_issue_peak_t(BOOST_SCLK_MHZ), 2), "boost_sclk_mhz": BOOST_SCLK_MHZ}
+    if insts_per_add:
+        alu_achieved = adds * insts_per_add / (acc_avg_ms * 1e-3) / 1e12 if acc_cnt else 0.0
+        alu.update({"valu_insts_per_mixed_add": round(insts_per_add, 1), "achieved": round(alu_achieved, 3),
+                    "frac_at_boost_clock": round(alu_achieved / _issue_peak_t(BOOST_SCLK_MHZ), 4),
+                    "mad_share_of_instructions": round(MADS_PER_MIXED_ADD / insts_per_add, 4),
+                    "sq_counters": sq["msm_accumulate"]})
+    else:
+        alu_achieved = 0.0
+        alu["sq_counters_note"] = why or "no SQ counter pass for this configuration"
     roofline = {
         "bound": "hbm", "kernel": "msm_accumulate", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
         "avg_launch_ms": round(acc_avg_ms, 4), "algorithmic_bytes_per_launch": 96 * n,
-        "alu": {"unit": "T lane-MAD/s (v_mad_u64_u32)", "achieved": round(alu_achieved, 3), "peak": MAD_PEAK_T,
-                "frac": round(alu_achieved / MAD_PEAK_T, 4), "mads_per_mixed_add": MADS_PER_MIXED_ADD,
-                "mixed_adds_per_launch": n * nwin, "window_bits": cbits, "windows": nwin},
-        "note": "integer-ALU bound (254-bit modular arithmetic on v_mad_u64_u32), not HBM bound: `alu` is the "
+        "alu": alu,
+        "note": "vector-issue bound (254-bit modular arithmetic, ~2090 instructions per mixed addition), not HBM bound: `alu` is the "
                 "binding roofline, `frac` the HBM one the contract asks for; see DESIGN.md 3.1",
     }
     if traffic_note:
         roofline["traffic_note"] = traffic_note
-    # SQ counters of the same kernel (separate rocprofv3 --pmc passes, profiles/sq_counters.json): measured issue
-    # utilisation instead of a cost model
-    sq, why = _load_counters("sq_counters.json")
-    if sq is not None and "msm_accumulate" in sq:
-        roofline["alu"]["sq_counters"] = sq["msm_accumulate"]
-    elif why:
-        roofline["alu"]["sq_counters_note"] = why
     # device kernels (HIP events) and, prefixed host_, the host-side sections of the call (wall clock)
     kernels = {k: {"launches": v[0], "avg_ms": round(v[1] / max(v[0], 1), 4)} for k, v in sorted(prof.items())}
 
@@ -454,10 +465,10 @@ def run_rank(args) -> None:
             if clk:
                 roofline["alu"]["sustained_sclk_mhz"] = clk["sclk_mhz"]
                 roofline["alu"]["sustained_power_w"] = clk["power_w"]
-                roofline["alu"]["boost_sclk_mhz"] = MAD_PEAK_SCLK_MHZ
-                peak_s = MAD_PEAK_T * clk["sclk_mhz"] / MAD_PEAK_SCLK_MHZ
+                peak_s = _issue_peak_t(clk["sclk_mhz"])
                 roofline["alu"]["peak_at_sustained_clock"] = round(peak_s, 2)
-                roofline["alu"]["frac_at_sustained_clock"] = round(alu_achieved / peak_s, 4) if peak_s else None
+                if alu_achieved:
+                    roofline["alu"]["frac_at_sustained_clock"] = round(alu_achieved / peak_s, 4)
         except Exception as e:
             roofline["alu"]["clock_probe_error"] = str(e)
 
@@ -531,10 +542,31 @@ def run_rank(args) -> None:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import prover_shape
             extra["prover_shape"] = prover_shape.run(reps=3)
+            extra["prover_shape"]["with_window_table"] = prover_shape.run(reps=3, precompute=True)
             extra["prover_shape"]["what"] = ("one 52-card proof's hot-path calls (n = 2^14: 16 MSM, 17 NTT(n), 11 NTT(6n)), "
-                                             "device-resident data: call by call vs batched entry points, ms")
+                                             "device-resident data: call by call vs batched entry points, ms; with_window_table = "
+                                             "the same after uzk_srs_precompute (static SRS)")
         except Exception as e:
             extra["prover_shape"] = {"error": str(e)}
+        try:     # the checked chain of tests/test_gpu_prover_chain.py, timed (stand-in for config #4's prove time)
+            import prover_chain
+            ch = prover_chain.ProverChain()
+            ch.run(); b.sync()
+            t3 = time.perf_counter()
+            for _ in range(3):
+                ch.run()
+            b.sync()
+            chain_ms = (time.perf_counter() - t3) / 3 * 1e3
+            b.profile_reset(); b.profile_enable(True); ch.run(); b.sync(); b.profile_enable(False)
+            ktab = b.profile_table()
+            ch.release()
+            extra["prover_chain"] = {"what": "every device-resident step of one 52-card proof chained (tools/prover_chain.py: 9+1 iFFT, 8+1+5+2 "
+                                             "commits with blinds, z_poly, 10 coset FFT(6n), quotient kernel, coset iFFT, split, evaluations, "
+                                             "r_poly-shaped combination, 2 openings), synthetic circuit tables, Python/torch glue included",
+                                     "ms_per_chain": round(chain_ms, 3),
+                                     "device_kernel_ms": round(sum(ms for k, (cnt, ms) in ktab.items() if not k.startswith("host_")), 3)}
+        except Exception as e:
+            extra["prover_chain"] = {"error": str(e)}
 
     # ---- CPU baseline + parity on a bounded sample (rank 0, N = 1 only) -----------------------
     cpu_baseline = None

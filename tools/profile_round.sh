@@ -1,10 +1,14 @@
 #!/bin/bash
 # Round-end measurement set, run on the GPU box from the repo root:
-#   bash tools/profile_round.sh r01i
+#   bash tools/profile_round.sh r02a
 # 1. bench.py (default flags)                         -> gpurun_out/<tag>_bench.json
 # 2. rocprofv3 --kernel-trace --stats of bench.py     -> gpurun_out/<tag>_kernel_stats.csv
 # 3. rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE    -> gpurun_out/<tag>_pmc_{fetch,write}_size.csv
+# 4. rocprofv3 --pmc <8 SQ counters> / GRBM           -> gpurun_out/<tag>_pmc_sq.csv, _pmc_grbm.csv
 #    (separate passes, counters only, program directly after `--`)
+# 5. tools/make_counter_files.py                      -> gpurun_out/<tag>_pmc_traffic.json, <tag>_sq_counters.json
+#    (stamped with the hash of the kernel sources they were measured on; copy to profiles/pmc_traffic.json and
+#     profiles/sq_counters.json -- bench.py refuses them when the sources have changed since)
 set -o pipefail
 tag=${1:-rXX}
 out=gpurun_out
@@ -17,11 +21,16 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_stats -- pytho
 cp "$(find $out/prof_stats -name '*kernel_stats.csv' | head -1)" $out/${tag}_kernel_stats.csv
 rm -rf $out/prof_stats
 echo "kernel stats done"
-for ctr in FETCH_SIZE WRITE_SIZE; do
-    lc=$(echo $ctr | tr 'A-Z' 'a-z')
+pmc_pass() {   # name, counters...
+    local name=$1; shift
     rm -rf $out/prof_pmc
-    rocprofv3 --pmc $ctr --output-format csv -d $out/prof_pmc -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras > /dev/null 2> $out/${tag}_pmc_${lc}.err || { tail -5 $out/${tag}_pmc_${lc}.err; exit 1; }
-    python3 tools/pmc_summary.py "$(find $out/prof_pmc -name '*counter_collection.csv' | head -1)" > $out/${tag}_pmc_${lc}.csv
+    rocprofv3 --pmc "$@" --output-format csv -d $out/prof_pmc -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras > /dev/null 2> $out/${tag}_pmc_${name}.err || { tail -5 $out/${tag}_pmc_${name}.err; return 1; }
+    python3 tools/pmc_summary.py "$(find $out/prof_pmc -name '*counter_collection.csv' | head -1)" > $out/${tag}_pmc_${name}.csv
     rm -rf $out/prof_pmc
-    echo "pmc $ctr done"
-done
+    echo "pmc $name done"
+}
+pmc_pass fetch_size FETCH_SIZE || exit 1
+pmc_pass write_size WRITE_SIZE || exit 1
+pmc_pass sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY || echo "SQ pass failed (see $out/${tag}_pmc_sq.err)"
+pmc_pass grbm GRBM_GUI_ACTIVE GRBM_COUNT || echo "GRBM pass failed"
+python3 tools/make_counter_files.py $tag && echo "counter files written"
