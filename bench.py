@@ -537,7 +537,7 @@ def run_rank(args) -> None:
         except Exception as e:   # e.g. not enough HBM for the table at a larger --log-n
             extra["msm_precomputed"] = {"error": str(e)}
         finally:
-            b.tune("msm_no_precompute", 1)
+            b.tune("msm_no_precompute", 1)      # the parity sample below runs the general mode again
         try:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import prover_shape

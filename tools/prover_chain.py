@@ -63,6 +63,7 @@ class ProverChain:
         lag.release(); mono.release()
         self.bases = np.concatenate([self.lagrange_wire, self.mono_wire[:3], self.mono_wire[n:n + 3]])      # n + 6 points
         self.srs = b.Srs.from_host(self.bases)
+        b.tune("msm_no_precompute", 0)
         if precompute:
             self.srs.precompute(0)            # static SRS: window table (same commitments, shorter calls)
         # ---- synthetic circuit: witness evaluations, wire selectors, public input, permutation, tables

@@ -21,6 +21,7 @@ def run(reps=5, precompute=False):
     torch.cuda.synchronize()
     b.synth_points_random(pts.data_ptr(), n, 7); b.synth_scalars(sc.data_ptr(), 16 * n, 8); b.synth_scalars(big.data_ptr(), 11 * m, 9)
     srs = b.Srs.from_device(pts.data_ptr(), n)
+    b.tune("msm_no_precompute", 0 if precompute else 1)
     if precompute: srs.precompute(0)
     res = {}
     def timed(name, fn):
@@ -52,6 +53,7 @@ def run(reps=5, precompute=False):
     timed("msm_16_single_ms", lambda: [b.msm_device(srs, sc.data_ptr() + k * n * 32, n) for k in range(16)])
     timed("msm_16_in_4_batches_ms", lambda: [b.msm_batch_device(srs, sc.data_ptr() + off * n * 32, n, cnt) for cnt, off in ((8, 0), (1, 8), (5, 9), (2, 14))])
     srs.release()
+    b.tune("msm_no_precompute", 0)
     return {k: round(v, 3) for k, v in res.items()}
 
 

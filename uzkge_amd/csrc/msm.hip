@@ -1370,6 +1370,21 @@ static int msm_group_phase1(Ctx& c, MsmGroup& g, const Affine* points, const Fp*
                                m.items[p].as<uint32_t>());
         }
         const dim3 grid = first ? dim3(sp.nch, sp.nseg) : dim3(sp.items_bound);
+        // Workspace guard (the round-1 fault -- a write past a sort counter array while the two-pass sort was being
+        // written, DESIGN.md 3.1 -- must fail here, on the host, not on the device): every workgroup of this pass
+        // owns `bins` counters, every segment `bins` entries of bin_base / bin_count, and both output arrays hold
+        // all entries.
+        {
+            const size_t wgs = (size_t)grid.x * grid.y;
+            const size_t ent_bytes = g.pk_bits ? 4 : sizeof(uint2);
+            const bool ok = m.counts[p].cap >= wgs * sp.bins * 4 &&
+                            (last ? (m.bucket_start.cap >= (size_t)sp.nseg * sp.bins * 4 && m.bucket_count.cap >= (size_t)sp.nseg * sp.bins * 4 &&
+                                     m.sorted.cap >= (size_t)g.entries * 4)
+                                  : (m.segs_start[p].cap >= (size_t)sp.nseg * sp.bins * 4 && m.segs_len[p].cap >= (size_t)sp.nseg * sp.bins * 4 &&
+                                     m.ent[p & 1].cap >= (size_t)g.entries * ent_bytes)) &&
+                            (first || m.items[p].cap >= ((size_t)sp.nseg + 1) * 4);
+            if (!ok) { set_error("msm: sort pass %d: a workspace is smaller than its launch needs (internal error)", p); return UZK_ERR_DEVICE; }
+        }
         if (!(first && fused_hist)) {
             KernelScope ks(c, "msm_sort_hist");
             if (first) hipLaunchKernelGGL((msm_radix_hist_kernel<true, false>), grid, dim3(1024), 0, st, a);
