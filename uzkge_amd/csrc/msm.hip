@@ -65,6 +65,23 @@ __host__ __device__ inline int msm_num_windows(int c) {
 }
 
 // ---- 1. digits -------------------------------------------------------------------------------
+// Scalars above (r - 1) / 2 are replaced by r - k with every digit's sign flipped: k P = -(r - k) P.  Uniform scalars
+// gain nothing, but the values a real witness is full of -- -1 = r - 1 (wire selectors, uzkge turbo/mod.rs:171-185),
+// small negatives -- then populate one or two low windows instead of all of them.
+__device__ __forceinline__ uint32_t msm_fold_scalar_sign(Fp& k) {
+    // k > (r - 1) / 2  <=>  2k >= r + 1  <=>  2k > r
+    bool gt = false, decided = false;
+#pragma unroll
+    for (int j = 7; j >= 0; --j) {
+        const uint32_t two_k = (k.v[j] << 1) | (j ? (k.v[j - 1] >> 31) : 0u);      // canonical k < r < 2^254: no bit 256
+        if (!decided && two_k != FrCfg::M[j]) { gt = two_k > FrCfg::M[j]; decided = true; }
+    }
+    if (!gt) return 0u;
+    k = Fr::neg(k);            // r - k (k != 0 here)
+    return kSignBit;
+}
+
+
 // scalars: [batch][n]; digits: [batch][wcnt][n] for the windows w0 .. w0 + wcnt of the W-window recoding
 __global__ __launch_bounds__(256) void msm_digits_kernel(const Fp* __restrict__ scalars, uint32_t* __restrict__ digits,
                                                          uint32_t n, uint32_t batch, int c, int W, int w0, int wcnt) {
@@ -72,6 +89,7 @@ __global__ __launch_bounds__(256) void msm_digits_kernel(const Fp* __restrict__ 
     if (t >= (uint64_t)n * batch) return;
     const uint32_t b = (uint32_t)(t / n), i = (uint32_t)(t % n);
     Fp k = Fr::from_mont(scalars[t]);
+    const uint32_t flip = msm_fold_scalar_sign(k);
     const uint32_t mask = (1u << c) - 1, half = 1u << (c - 1);
     uint32_t carry = 0;
     uint32_t* dst = digits + (size_t)b * wcnt * n + i;
@@ -84,6 +102,7 @@ __global__ __launch_bounds__(256) void msm_digits_kernel(const Fp* __restrict__ 
         uint32_t out;
         if (d > half) { out = ((1u << c) - d) | kSignBit; carry = 1; }
         else { out = d; carry = 0; }
+        if (out & ~kSignBit) out ^= flip;                // a zero digit stays zero
         if (w >= w0) dst[(size_t)(w - w0) * n] = out;
     }
 }
@@ -104,6 +123,7 @@ __global__ __launch_bounds__(1024) void msm_digits_hist_kernel(const Fp* __restr
     const uint32_t mask = (1u << c) - 1, half = 1u << (c - 1), bmask = bins - 1;
     for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         Fp k = Fr::from_mont(scalars[(size_t)b * n + i]);
+        const uint32_t flip = msm_fold_scalar_sign(k);
         uint32_t carry = 0;
         uint32_t* dst = digits + (size_t)b * W * n + i;
         for (int w = 0; w < W; ++w) {
@@ -114,6 +134,7 @@ __global__ __launch_bounds__(1024) void msm_digits_hist_kernel(const Fp* __restr
             uint32_t out;
             if (d > half) { out = ((1u << c) - d) | kSignBit; carry = 1; }
             else { out = d; carry = 0; }
+            if (out & ~kSignBit) out ^= flip;
             dst[(size_t)w * n] = out;
             const uint32_t mag = out & ~kSignBit;
             if (mag) atomicAdd(&hist[(uint32_t)w * bins + (((mag - 1) >> shift) & bmask)], 1u);
