@@ -18,7 +18,7 @@
  *
  * Ownership: every pointer is caller-owned for the duration of the call; the library keeps no
  * reference except data explicitly copied (or adopted) by uzk_srs_register*.  Outputs go to
- * caller memory.  All functions are thread-safe (one internal lock); none panics or aborts.
+ * caller memory.  All functions are thread-safe (one lock per context, see uzk_ctx_create); none panics or aborts.
  *
  * Error codes map onto `UzkgeError` (uzkge/src/errors.rs:5-44):
  *   UZK_ERR_DEGREE     -> UzkgeError::DegreeError      (commit: len > SRS len, kzg_poly_commitment.rs:283-285)
@@ -58,6 +58,18 @@ int uzk_device_count(void);
 /* Thread-local description of the last non-OK return on this thread. */
 const char* uzk_last_error(void);
 const char* uzk_version(void);
+
+/* ---- contexts (optional) ---------------------------------------------------------------- */
+/* A context = one stream, one set of workspaces, one lock.  Every entry point works on the calling thread's current
+ * context; threads that never set one share the default context (and serialise on its lock).  Giving each prover
+ * thread its own context lets independent proofs overlap on the GPU -- at the real circuit size (n = 2^14) a single
+ * proof leaves most of the chip idle.  SRS handles are process-wide and may be used from every context; register and
+ * precompute them before the contexts start sharing them. */
+int uzk_ctx_create(uint64_t* ctx_out);
+/* Makes `ctx` (0 = the default context) the calling thread's current context. */
+int uzk_ctx_set_current(uint64_t ctx);
+/* Frees the context's stream, plans and workspaces; no thread may still be using it. */
+int uzk_ctx_destroy(uint64_t ctx);
 
 /* ---- SRS (the static bases of KZG commit) --------------------------------------------- */
 /* Copy `n` affine points to HBM once; replaces the per-commit `normalize_batch` of

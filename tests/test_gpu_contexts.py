@@ -1,0 +1,71 @@
+"""Contexts (uzk_ctx_create / uzk_ctx_set_current): every prover thread can own a stream, workspaces and a lock, so
+independent proofs overlap on one GPU; SRS handles are process-wide.  Results must be what the default context gives."""
+import threading
+
+import numpy as np
+import pytest
+
+import oracle_c as oc
+from util import affine_of, load_srs, rand_fr_wire
+
+pytestmark = pytest.mark.gpu
+
+
+def test_threads_with_their_own_contexts(gpu):
+    wire, _ = load_srs("lagrange-srs-4096.bin")
+    srs = gpu.Srs.from_host(wire)                       # registered in the default context, used by all
+    srs.precompute(0)
+    scal = [rand_fr_wire(4096, 900 + i) for i in range(4)]
+    vecs = [rand_fr_wire(3 << 12, 950 + i) for i in range(4)]
+    want_msm = [affine_of(oc.msm_pippenger(wire, s, 0, 4)) for s in scal]
+    want_ntt = [oc.ntt(v) for v in vecs]
+    errors, ctxs = [], []
+
+    def worker(i):
+        try:
+            h = gpu.ctx_create()
+            ctxs.append(h)
+            gpu.ctx_set_current(h)
+            for rep in range(5):
+                assert affine_of(gpu.msm(srs, scal[i])) == want_msm[i]
+                assert np.array_equal(gpu.ntt(vecs[i]), want_ntt[i])
+                b3 = gpu.msm_batch(srs, np.stack([scal[i], scal[(i + 1) % 4], scal[i]]))
+                assert [affine_of(x) for x in b3] == [want_msm[i], want_msm[(i + 1) % 4], want_msm[i]]
+            gpu.ctx_set_current(0)
+        except Exception as e:   # noqa: BLE001
+            errors.append((i, e))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    # the default context still works, and the contexts can be destroyed
+    assert affine_of(gpu.msm(srs, scal[0])) == want_msm[0]
+    for h in ctxs:
+        gpu.ctx_destroy(h)
+    from uzkge_amd import UzkgeError
+    with pytest.raises(UzkgeError):
+        gpu.ctx_set_current(ctxs[0])
+    srs.release()
+
+
+def test_profile_tables_are_per_context(gpu):
+    wire, _ = load_srs("lagrange-srs-4096.bin")
+    srs = gpu.Srs.from_host(wire)
+    s = rand_fr_wire(1000, 5)
+    h = gpu.ctx_create()
+    try:
+        gpu.profile_reset()
+        gpu.ctx_set_current(h)
+        gpu.profile_reset(); gpu.profile_enable(True)
+        gpu.msm(srs, s)
+        gpu.profile_enable(False)
+        assert gpu.profile_table().get("msm_accumulate", (0, 0))[0] >= 1
+        gpu.ctx_set_current(0)
+        assert "msm_accumulate" not in gpu.profile_table()
+    finally:
+        gpu.ctx_set_current(0)
+        gpu.ctx_destroy(h)
+        srs.release()

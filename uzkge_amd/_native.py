@@ -25,6 +25,9 @@ PROTOTYPES = {
     "uzk_device_count": (_I, []),
     "uzk_last_error": (ctypes.c_char_p, []),
     "uzk_version": (ctypes.c_char_p, []),
+    "uzk_ctx_create": (_I, [ctypes.POINTER(_U64)]),
+    "uzk_ctx_set_current": (_I, [_U64]),
+    "uzk_ctx_destroy": (_I, [_U64]),
     "uzk_srs_register": (_I, [_P, _SZ, ctypes.POINTER(_U64)]),
     "uzk_srs_register_device": (_I, [_P, _SZ, ctypes.POINTER(_U64)]),
     "uzk_srs_release": (_I, [_U64]),

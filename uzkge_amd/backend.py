@@ -35,6 +35,22 @@ def sync() -> None:
     check(lib.uzk_sync())
 
 
+def ctx_create() -> int:
+    """A new context (stream + workspaces + lock) on the bound device; see uzk_ctx_create."""
+    h = ctypes.c_uint64(0)
+    check(lib.uzk_ctx_create(ctypes.byref(h)))
+    return h.value
+
+
+def ctx_set_current(ctx: int) -> None:
+    """Make `ctx` (0 = default) the calling thread's current context."""
+    check(lib.uzk_ctx_set_current(ctx))
+
+
+def ctx_destroy(ctx: int) -> None:
+    check(lib.uzk_ctx_destroy(ctx))
+
+
 class Srs:
     """Device-resident SRS (static bases of KZG commit)."""
 

@@ -20,14 +20,29 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-Ctx& ctx() {
+// Process-wide state: the device this process is bound to, the SRS registry (bases are read-only and shared by
+// every context), the contexts.  Lock order: a context's own mutex first, then Shared::mu (held briefly).
+struct Shared {
+    std::mutex mu;
+    bool bound = false;
+    int device = -1, num_cus = 256;
+    std::map<uint64_t, Ctx::Srs> srs;
+    uint64_t next_handle = 1;
+    std::map<uint64_t, Ctx*> contexts;
+    uint64_t next_ctx = 1;
+};
+static Shared& shared() {
+    static Shared s;
+    return s;
+}
+static Ctx& default_ctx() {
     static Ctx c;
     return c;
 }
-std::mutex& ctx_mutex() {
-    static std::mutex m;
-    return m;
-}
+static thread_local Ctx* t_current = nullptr;      // the calling thread's context (null: the default one)
+
+Ctx& ctx() { return t_current ? *t_current : default_ctx(); }
+std::mutex& ctx_mutex() { return ctx().mu; }
 
 int DevBuf::reserve(size_t bytes) {
     if (bytes <= cap) return UZK_OK;
@@ -95,33 +110,66 @@ int Ctx::prof_collect() {
 // returns to it instead of silently moving to device 0.
 static int g_last_device = 0;
 
-static int bind_device(Ctx& c, int device) {
+// binds the process to `device` (Shared::mu held by the caller)
+static int bind_device_locked(Shared& s, int device) {
     UZK_HIP(hipSetDevice(device));
-    UZK_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     hipDeviceProp_t prop;
     UZK_HIP(hipGetDeviceProperties(&prop, device));
-    c.num_cus = prop.multiProcessorCount;
-    c.device = device;
-    c.ready = true;
+    s.num_cus = prop.multiProcessorCount;
+    s.device = device;
+    s.bound = true;
     g_last_device = device;
     return UZK_OK;
 }
 
+// Makes the calling thread's context usable: process bound to a device, HIP's per-thread current device set to it,
+// the context's stream created.  Called with the context's mutex held.
 int require_ready() {
+    Shared& s = shared();
     Ctx& c = ctx();
-    if (c.ready) {
-        // HIP's current device is per thread: a prover thread that never called uzk_init would otherwise
-        // allocate and launch on device 0 while the stream and the SRS live on c.device
-        UZK_HIP(hipSetDevice(c.device));
-        return UZK_OK;
+    int device;
+    {
+        std::lock_guard<std::mutex> lk(s.mu);
+        if (!s.bound) {
+            // lazy init (device 0, or the one uzk_init bound before a shutdown) so a plain library user need not call uzk_init
+            int n = 0;
+            if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+                set_error("no HIP device visible: the MI355X backend has no CPU fallback");
+                return UZK_ERR_DEVICE;
+            }
+            UZK_TRY(bind_device_locked(s, g_last_device < n ? g_last_device : 0));
+        }
+        device = s.device;
+        c.num_cus = s.num_cus;
     }
-    // lazy init (device 0, or the one uzk_init bound before a shutdown) so a plain library user need not call uzk_init
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
-        set_error("no HIP device visible: the MI355X backend has no CPU fallback");
-        return UZK_ERR_DEVICE;
+    // HIP's current device is per thread: a prover thread that never called uzk_init would otherwise
+    // allocate and launch on device 0 while the streams and the SRS live on the bound device
+    UZK_HIP(hipSetDevice(device));
+    if (!c.ready) {
+        UZK_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+        c.device = device;
+        c.ready = true;
     }
-    return bind_device(c, g_last_device < n ? g_last_device : 0);
+    return UZK_OK;
+}
+
+// frees everything a context owns (its mutex held, or no other user left)
+static void ctx_release(Ctx& c) {
+    if (!c.ready) return;
+    (void)hipStreamSynchronize(c.stream);
+    ntt_free_plans(c);
+    msm_free(c);
+    poly_free(c);
+    c.ntt_scratch[0].release(); c.ntt_scratch[1].release(); c.ntt_io.release(); c.msm_scalars.release();
+    for (auto& pe : c.prof_pending) { (void)hipEventDestroy(pe.e0); (void)hipEventDestroy(pe.e1); }
+    c.prof_pending.clear();
+    for (auto e : c.event_pool) (void)hipEventDestroy(e);
+    c.event_pool.clear();
+    (void)hipStreamDestroy(c.stream);
+    c.stream = nullptr;
+    c.cur_stream = nullptr;
+    c.ready = false;
+    c.device = -1;
 }
 
 static const Fp* as_fp(const uint64_t* p) { return reinterpret_cast<const Fp*>(p); }
@@ -145,52 +193,106 @@ int uzk_device_count(void) {
 
 int uzk_init(int device) {
     API_LOCK;
-    Ctx& c = ctx();
-    if (c.ready) {
-        if (c.device == device) { UZK_HIP(hipSetDevice(device)); return UZK_OK; }
-        set_error("uzk_init(%d): already bound to device %d (one process per GPU)", device, c.device);
-        return UZK_ERR_PARAMETER;
+    Shared& s = shared();
+    {
+        std::lock_guard<std::mutex> lk(s.mu);
+        if (s.bound && s.device != device) {
+            set_error("uzk_init(%d): already bound to device %d (one process per GPU)", device, s.device);
+            return UZK_ERR_PARAMETER;
+        }
+        if (!s.bound) {
+            int n = 0;
+            if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+                set_error("no HIP device visible: the MI355X backend has no CPU fallback");
+                return UZK_ERR_DEVICE;
+            }
+            if (device < 0 || device >= n) {
+                set_error("uzk_init(%d): %d device(s) visible", device, n);
+                return UZK_ERR_PARAMETER;
+            }
+            UZK_TRY(bind_device_locked(s, device));
+        }
     }
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
-        set_error("no HIP device visible: the MI355X backend has no CPU fallback");
-        return UZK_ERR_DEVICE;
-    }
-    if (device < 0 || device >= n) {
-        set_error("uzk_init(%d): %d device(s) visible", device, n);
-        return UZK_ERR_PARAMETER;
-    }
-    return bind_device(c, device);
+    return require_ready();
 }
 
+// Frees every context (the default one and those of uzk_ctx_create), every SRS and table, and unbinds the device.
+// No other thread may be inside the library.
 int uzk_shutdown(void) {
-    API_LOCK;
-    Ctx& c = ctx();
-    if (!c.ready) return UZK_OK;
-    (void)hipSetDevice(c.device);
-    (void)hipStreamSynchronize(c.stream);
-    ntt_free_plans(c);
-    msm_free(c);
-    poly_free(c);
-    for (auto& kv : c.srs) {
+    Shared& s = shared();
+    std::lock_guard<std::mutex> lk(s.mu);
+    if (!s.bound) return UZK_OK;
+    (void)hipSetDevice(s.device);
+    ctx_release(default_ctx());
+    for (auto& kv : s.contexts) { ctx_release(*kv.second); delete kv.second; }
+    s.contexts.clear();
+    t_current = nullptr;
+    for (auto& kv : s.srs) {
         if (kv.second.owned && kv.second.d_points) (void)hipFree(kv.second.d_points);
         if (kv.second.d_table) (void)hipFree(kv.second.d_table);
     }
-    c.srs.clear();
-    c.ntt_scratch[0].release(); c.ntt_scratch[1].release(); c.ntt_io.release(); c.msm_scalars.release();
-    for (auto& pe : c.prof_pending) { (void)hipEventDestroy(pe.e0); (void)hipEventDestroy(pe.e1); }
-    c.prof_pending.clear();
-    for (auto e : c.event_pool) (void)hipEventDestroy(e);
-    c.event_pool.clear();
-    (void)hipStreamDestroy(c.stream);
-    c.stream = nullptr;
-    c.cur_stream = nullptr;
-    c.ready = false;
-    c.device = -1;
+    s.srs.clear();
+    s.bound = false;
+    s.device = -1;
     return UZK_OK;
 }
 
-/* ---- SRS ---------------------------------------------------------------------------------- */
+/* ---- contexts ------------------------------------------------------------------------------- */
+int uzk_ctx_create(uint64_t* ctx_out) {
+    if (!ctx_out) { set_error("uzk_ctx_create: null pointer"); return UZK_ERR_PARAMETER; }
+    { API_LOCK; UZK_TRY(require_ready()); }            // binds the device through the caller's current context
+    Ctx* c = new Ctx();
+    Shared& s = shared();
+    std::lock_guard<std::mutex> lk(s.mu);
+    const uint64_t h = s.next_ctx++;
+    s.contexts[h] = c;
+    *ctx_out = h;
+    return UZK_OK;
+}
+int uzk_ctx_set_current(uint64_t handle) {
+    if (handle == 0) { t_current = nullptr; return UZK_OK; }
+    Shared& s = shared();
+    std::lock_guard<std::mutex> lk(s.mu);
+    auto it = s.contexts.find(handle);
+    if (it == s.contexts.end()) { set_error("uzk_ctx_set_current: unknown context %llu", (unsigned long long)handle); return UZK_ERR_PARAMETER; }
+    t_current = it->second;
+    return UZK_OK;
+}
+int uzk_ctx_destroy(uint64_t handle) {
+    Shared& s = shared();
+    Ctx* c = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(s.mu);
+        auto it = s.contexts.find(handle);
+        if (it == s.contexts.end()) { set_error("uzk_ctx_destroy: unknown context %llu", (unsigned long long)handle); return UZK_ERR_PARAMETER; }
+        c = it->second;
+        s.contexts.erase(it);
+        if (s.bound) (void)hipSetDevice(s.device);
+    }
+    if (t_current == c) t_current = nullptr;
+    { std::lock_guard<std::mutex> lk(c->mu); ctx_release(*c); }
+    delete c;
+    return UZK_OK;
+}
+
+/* ---- SRS (process-wide registry: the bases are read-only and shared by every context) ------------ */
+static uint64_t srs_insert(const Ctx::Srs& e) {
+    Shared& s = shared();
+    std::lock_guard<std::mutex> lk(s.mu);
+    const uint64_t h = s.next_handle++;
+    s.srs[h] = e;
+    return h;
+}
+// copy of the registry entry (the pointers stay valid until uzk_srs_release / uzk_srs_precompute on that handle)
+static bool srs_lookup(uint64_t handle, Ctx::Srs* out) {
+    Shared& s = shared();
+    std::lock_guard<std::mutex> lk(s.mu);
+    auto it = s.srs.find(handle);
+    if (it == s.srs.end()) return false;
+    *out = it->second;
+    return true;
+}
+
 int uzk_srs_register(const uzk_g1_affine* points, size_t n, uint64_t* handle_out) {
     API_LOCK;
     if (!handle_out || (n > 0 && !points)) { set_error("uzk_srs_register: null pointer"); return UZK_ERR_PARAMETER; }
@@ -204,9 +306,7 @@ int uzk_srs_register(const uzk_g1_affine* points, size_t n, uint64_t* handle_out
         UZK_HIP(hipMemcpyAsync(s.d_points, points, n * sizeof(Affine), hipMemcpyHostToDevice, c.stream));
         UZK_HIP(hipStreamSynchronize(c.stream));
     }
-    const uint64_t h = c.next_handle++;
-    c.srs[h] = s;
-    *handle_out = h;
+    *handle_out = srs_insert(s);
     return UZK_OK;
 }
 
@@ -214,74 +314,80 @@ int uzk_srs_register_device(const void* d_points, size_t n, uint64_t* handle_out
     API_LOCK;
     if (!handle_out || (n > 0 && !d_points)) { set_error("uzk_srs_register_device: null pointer"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
-    Ctx& c = ctx();
     Ctx::Srs s;
     s.n = n;
     s.owned = false;
     s.d_points = const_cast<Affine*>(static_cast<const Affine*>(d_points));
-    const uint64_t h = c.next_handle++;
-    c.srs[h] = s;
-    *handle_out = h;
+    *handle_out = srs_insert(s);
     return UZK_OK;
 }
 
+// The caller makes sure no context still runs an MSM over this handle.
 int uzk_srs_release(uint64_t handle) {
     API_LOCK;
     Ctx& c = ctx();
-    auto it = c.srs.find(handle);
-    if (it == c.srs.end()) { set_error("uzk_srs_release: unknown handle %llu", (unsigned long long)handle); return UZK_ERR_PARAMETER; }
-    if (c.ready) (void)hipSetDevice(c.device);
-    (void)hipStreamSynchronize(c.stream);
-    if (it->second.owned && it->second.d_points) (void)hipFree(it->second.d_points);
-    if (it->second.d_table) (void)hipFree(it->second.d_table);
-    c.srs.erase(it);
+    Shared& sh = shared();
+    Ctx::Srs e;
+    {
+        std::lock_guard<std::mutex> lk(sh.mu);
+        auto it = sh.srs.find(handle);
+        if (it == sh.srs.end()) { set_error("uzk_srs_release: unknown handle %llu", (unsigned long long)handle); return UZK_ERR_PARAMETER; }
+        e = it->second;
+        sh.srs.erase(it);
+        if (sh.bound) (void)hipSetDevice(sh.device);
+    }
+    if (c.ready) (void)hipStreamSynchronize(c.stream);
+    if (e.owned && e.d_points) (void)hipFree(e.d_points);
+    if (e.d_table) (void)hipFree(e.d_table);
     return UZK_OK;
 }
 
+// Build the table before contexts start using the handle concurrently (the entry is replaced, not versioned).
 int uzk_srs_precompute(uint64_t handle, int window_bits) {
     API_LOCK;
     UZK_TRY(require_ready());
     Ctx& c = ctx();
-    auto it = c.srs.find(handle);
-    if (it == c.srs.end()) { set_error("uzk_srs_precompute: unknown handle"); return UZK_ERR_PARAMETER; }
+    Ctx::Srs s;
+    if (!srs_lookup(handle, &s)) { set_error("uzk_srs_precompute: unknown handle"); return UZK_ERR_PARAMETER; }
     if (window_bits != 0 && (window_bits < 4 || window_bits > 24)) {
         set_error("uzk_srs_precompute: window bits must be 0 (auto) or 4..24");
         return UZK_ERR_PARAMETER;
     }
-    Ctx::Srs& s = it->second;
     if (s.n == 0) return UZK_OK;
     const int cb = msm_precompute_window_bits(s.n, window_bits);
     if (s.d_table && s.pre_c == cb) return UZK_OK;
-    if (s.d_table) { (void)hipStreamSynchronize(c.stream); (void)hipFree(s.d_table); s.d_table = nullptr; s.pre_c = 0; }
+    Affine* old_table = s.d_table;
     Affine* table = nullptr;
     uint32_t W = 0;
     UZK_TRY(msm_build_table(c, s.d_points, s.n, cb, &table, &W));
-    s.d_table = table;
-    s.pre_c = cb;
-    s.pre_W = W;
+    {
+        Shared& sh = shared();
+        std::lock_guard<std::mutex> lk(sh.mu);
+        auto it = sh.srs.find(handle);
+        if (it == sh.srs.end()) { (void)hipFree(table); set_error("uzk_srs_precompute: handle released meanwhile"); return UZK_ERR_PARAMETER; }
+        it->second.d_table = table;
+        it->second.pre_c = cb;
+        it->second.pre_W = W;
+    }
+    if (old_table) { (void)hipStreamSynchronize(c.stream); (void)hipFree(old_table); }
     return UZK_OK;
 }
 
 int uzk_srs_len(uint64_t handle, size_t* n_out) {
-    API_LOCK;
-    Ctx& c = ctx();
-    auto it = c.srs.find(handle);
-    if (it == c.srs.end() || !n_out) { set_error("uzk_srs_len: unknown handle"); return UZK_ERR_PARAMETER; }
-    *n_out = it->second.n;
+    Ctx::Srs s;
+    if (!n_out || !srs_lookup(handle, &s)) { set_error("uzk_srs_len: unknown handle"); return UZK_ERR_PARAMETER; }
+    *n_out = s.n;
     return UZK_OK;
 }
 
 /* ---- MSM ---------------------------------------------------------------------------------- */
-static int msm_checked(uint64_t srs_handle, size_t offset, size_t n, const Ctx::Srs** srs_out) {
-    Ctx& c = ctx();
-    auto it = c.srs.find(srs_handle);
-    if (it == c.srs.end()) { set_error("msm: unknown SRS handle %llu", (unsigned long long)srs_handle); return UZK_ERR_PARAMETER; }
-    if (offset > it->second.n || n > it->second.n - offset) {
+static int msm_checked(uint64_t srs_handle, size_t offset, size_t n, Ctx::Srs* srs_out) {
+    if (!srs_lookup(srs_handle, srs_out)) { set_error("msm: unknown SRS handle %llu", (unsigned long long)srs_handle); return UZK_ERR_PARAMETER; }
+    if (offset > srs_out->n || n > srs_out->n - offset) {
         // KZG commit: degree + 1 > SRS length (kzg_poly_commitment.rs:283-285)
-        set_error("msm: offset %zu + n %zu exceeds SRS length %zu", offset, n, it->second.n);
+        set_error("msm: offset %zu + n %zu exceeds SRS length %zu", offset, n, srs_out->n);
         return UZK_ERR_DEGREE;
     }
-    *srs_out = &it->second;
     return UZK_OK;
 }
 // general mode unless the handle carries a window table
@@ -313,10 +419,10 @@ int uzk_msm_g1_device(uint64_t srs_handle, size_t offset, const void* d_scalars_
     API_LOCK;
     if (!out || (n > 0 && !d_scalars_mont)) { set_error("uzk_msm_g1_device: null pointer"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
-    const Ctx::Srs* srs = nullptr;
+    Ctx::Srs srs;
     UZK_TRY(msm_checked(srs_handle, offset, n, &srs));
     Jac r;
-    UZK_TRY(msm_dispatch(*srs, offset, static_cast<const Fp*>(d_scalars_mont), n, 1, &r));
+    UZK_TRY(msm_dispatch(srs, offset, static_cast<const Fp*>(d_scalars_mont), n, 1, &r));
     std::memcpy(out, &r, sizeof r);
     return UZK_OK;
 }
@@ -326,13 +432,13 @@ int uzk_msm_g1(uint64_t srs_handle, size_t offset, const uint64_t* scalars_mont,
     if (!out || (n > 0 && !scalars_mont)) { set_error("uzk_msm_g1: null pointer"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
     Ctx& c = ctx();
-    const Ctx::Srs* srs = nullptr;
+    Ctx::Srs srs;
     UZK_TRY(msm_checked(srs_handle, offset, n, &srs));
     Jac r = jac_inf();
     if (n > 0) {
         UZK_TRY(c.msm_scalars.reserve(n * sizeof(Fp)));
         UZK_HIP(hipMemcpyAsync(c.msm_scalars.p, scalars_mont, n * sizeof(Fp), hipMemcpyHostToDevice, c.stream));
-        UZK_TRY(msm_dispatch(*srs, offset, c.msm_scalars.as<Fp>(), n, 1, &r));
+        UZK_TRY(msm_dispatch(srs, offset, c.msm_scalars.as<Fp>(), n, 1, &r));
     }
     std::memcpy(out, &r, sizeof r);
     return UZK_OK;
@@ -343,10 +449,10 @@ int uzk_msm_g1_batch_device(uint64_t srs_handle, size_t offset, const void* d_sc
     API_LOCK;
     if (batch > 0 && (!out || (n > 0 && !d_scalars_mont))) { set_error("uzk_msm_g1_batch_device: null pointer"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
-    const Ctx::Srs* srs = nullptr;
+    Ctx::Srs srs;
     UZK_TRY(msm_checked(srs_handle, offset, n, &srs));
     std::vector<Jac> r(batch);
-    UZK_TRY(msm_dispatch(*srs, offset, static_cast<const Fp*>(d_scalars_mont), n, batch, r.data()));
+    UZK_TRY(msm_dispatch(srs, offset, static_cast<const Fp*>(d_scalars_mont), n, batch, r.data()));
     if (batch) std::memcpy(out, r.data(), (size_t)batch * sizeof(Jac));
     return UZK_OK;
 }
@@ -357,14 +463,14 @@ int uzk_msm_g1_batch(uint64_t srs_handle, size_t offset, const uint64_t* scalars
     if (batch > 0 && (!out || (n > 0 && !scalars_mont))) { set_error("uzk_msm_g1_batch: null pointer"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
     Ctx& c = ctx();
-    const Ctx::Srs* srs = nullptr;
+    Ctx::Srs srs;
     UZK_TRY(msm_checked(srs_handle, offset, n, &srs));
     std::vector<Jac> r(batch, jac_inf());
     if (n > 0 && batch > 0) {
         const size_t bytes = (size_t)n * batch * sizeof(Fp);
         UZK_TRY(c.msm_scalars.reserve(bytes));
         UZK_HIP(hipMemcpyAsync(c.msm_scalars.p, scalars_mont, bytes, hipMemcpyHostToDevice, c.stream));
-        UZK_TRY(msm_dispatch(*srs, offset, c.msm_scalars.as<Fp>(), n, batch, r.data()));
+        UZK_TRY(msm_dispatch(srs, offset, c.msm_scalars.as<Fp>(), n, batch, r.data()));
     }
     if (batch) std::memcpy(out, r.data(), (size_t)batch * sizeof(Jac));
     return UZK_OK;

@@ -50,7 +50,12 @@ struct ProfEntry {
 struct NttPlan;   // ntt.hip
 struct MsmWork;   // msm.hip
 
+// One context = one stream, one set of grow-only workspaces, one lock.  The default context serves callers that
+// never ask for another; uzk_ctx_create / uzk_ctx_set_current give every prover thread its own, so independent
+// proofs overlap on the GPU (at n = 2^14 a single proof leaves most of the chip idle).  The device binding and the
+// SRS registry are process-wide (Shared, api.cpp).
 struct Ctx {
+    std::mutex mu;
     bool ready = false;
     int device = -1;
     hipStream_t stream = nullptr;
@@ -93,7 +98,7 @@ struct Ctx {
     PowCache pow_cache[8];
     uint64_t pow_stamp = 0;
     std::vector<void*> ntt_fused;   // NttFused* (ntt.hip): tables of the fused coset / radix-3 transforms
-    // SRS registry
+    // an entry of the process-wide SRS registry
     struct Srs {
         Affine* d_points = nullptr;
         size_t n = 0;
@@ -103,8 +108,6 @@ struct Ctx {
         int pre_c = 0;
         uint32_t pre_W = 0;
     };
-    std::map<uint64_t, Srs> srs;
-    uint64_t next_handle = 1;
 
     hipEvent_t get_event();
     void prof_begin(const char* name);

@@ -1155,7 +1155,6 @@ int msm_precompute_window_bits(size_t n, int forced) {
     return std::max(8, std::min(22, lg - 2));
 }
 
-static void horner_pool_shutdown();
 void msm_free(Ctx& c) {
     if (!c.msm) return;
     for (int q = 0; q < 2; ++q) {
@@ -1173,7 +1172,6 @@ void msm_free(Ctx& c) {
     }
     delete[] c.msm;
     c.msm = nullptr;
-    horner_pool_shutdown();
     if (c.stream2) { (void)hipStreamDestroy(c.stream2); c.stream2 = nullptr; }
 }
 
@@ -1577,6 +1575,9 @@ public:
     }
     // runs fn(i) for i in [0, count), the caller included; returns when all are done
     void run(uint32_t count, const std::function<void(uint32_t)>& fn) {
+        // one batch at a time: a second context that arrives while the pool is busy does its own sums in its own thread
+        std::unique_lock<std::mutex> busy(run_mu_, std::try_to_lock);
+        if (!busy.owns_lock()) { for (uint32_t i = 0; i < count; ++i) fn(i); return; }
         // every call owns its counters: a worker that wakes late still holds the job it saw under the
         // lock and can only find that job exhausted, never the next call's indices
         auto job = std::make_shared<Job>();
@@ -1618,18 +1619,18 @@ private:
         }
     }
     std::vector<std::thread> workers_;
-    std::mutex mu_;
+    std::mutex mu_, run_mu_;
     std::condition_variable cv_, cv_done_;
     std::shared_ptr<Job> job_;
     uint64_t gen_ = 0;
     bool stop_ = false;
 };
-HornerPool* g_horner_pool = nullptr;
-}  // namespace
-static void horner_pool_shutdown() {
-    delete g_horner_pool;
-    g_horner_pool = nullptr;
+// process-wide, shared by every context, created on first use and joined at process exit
+HornerPool& horner_pool() {
+    static HornerPool pool(7);
+    return pool;
 }
+}  // namespace
 
 // Host: per scalar vector, Horner over its W window sums (c doublings per step).
 template <class WindowSum>
@@ -1645,9 +1646,8 @@ static void msm_horner_host(Ctx& c, uint32_t batch, uint32_t wpp, int cb, const 
     HostScope hs_horner(c, "host_msm_horner");
     if (batch > 1 && wpp > 1) {
         // 254 dependent doublings per vector: ~0.06 ms each on one core, so spread the vectors over the pool
-        if (!g_horner_pool) g_horner_pool = new HornerPool(7);
         const std::function<void(uint32_t)> job = [&](uint32_t b) { horner(b); };
-        g_horner_pool->run(batch, job);
+        horner_pool().run(batch, job);
     } else {
         for (uint32_t b = 0; b < batch; ++b) horner(b);
     }
@@ -1737,11 +1737,14 @@ static int msm_run_small(Ctx& c, const Affine* points, const Fp* d_scalars, size
     XYZZ* win_sums = m.win_sums.as<XYZZ>();
     uint32_t* counters = m.small.as<uint32_t>() + 3960;               // [0] tasks, [1..4] chunks per level, [6] exceptions
     const size_t sort_lds = ((size_t)5 * NBL + 32 + n32) * 4;
-    static bool attr_done = false;
-    if (!attr_done) {
-        UZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_small_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (5 * 512 + 32 + 32768) * 4));
-        attr_done = true;
+    {
+        static std::once_flag attr_once;
+        hipError_t attr_err = hipSuccess;
+        std::call_once(attr_once, [&] {
+            attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(msm_small_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (5 * 512 + 32 + 32768) * 4);
+        });
+        UZK_HIP(attr_err);
     }
     {
         HostScope hs(c, "host_msm_enqueue1");
