@@ -15,7 +15,7 @@ def _wire(t):
     return t.cpu().numpy().view(np.uint64).reshape(-1, 4)
 
 
-@pytest.mark.parametrize("log_n", [10, 16, 20, 22])   # 22: packed sort entries
+@pytest.mark.parametrize("log_n", [10, 16, 20, 22, 24])   # 22: packed sort entries; 24: BASELINE's headline size
 def test_arith_points_closed_form(gpu, log_n):
     n = 1 << log_n
     pts = torch.empty((n, 8), dtype=torch.int64, device="cuda")

@@ -39,13 +39,22 @@ for t in range(cases):
     elif smode == 2: sc[nrng.integers(0, 3, n) == 1] = rm1
     elif smode == 3: sc[:] = sc[0]                                  # identical scalars (with repeated points: doublings)
     elif smode == 4: sc[nrng.integers(0, 2, n) == 1] = 0
-    c = rng.choice([0, 0, 0, 4, 7, 8, 11, 13, 16, 17])
+    c = rng.choice([0, 0, 0, 4, 5, 7, 8, 9, 10, 11, 13, 16, 17])
     b.set_msm_window_bits(c)
-    got = b.msm_raw(pts, sc)
+    b.tune("msm_small", rng.choice([1, 1, 1, 2, 0]))               # small pipeline (quads / plain lanes) or the general one
+    b.tune("msm_task_len", rng.choice([0, 0, 2, 3, 40]))
+    if rng.random() < 0.3:                                           # batched entry point: the same vector three times over
+        h = b.Srs.from_host(pts)
+        if rng.random() < 0.5: h.precompute(rng.choice([0, 5, 8, 10]))
+        outs = b.msm_batch(h, np.stack([sc, sc, sc]))
+        h.release()
+        got = outs[rng.randrange(3)]
+    else:
+        got = b.msm_raw(pts, sc)
     want = oc.msm_pippenger(pts, sc, 0, 8)
     if oc.jac_to_affine_ints(got) != oc.jac_to_affine_ints(want):
         bad += 1
         print(f"MISMATCH case {t}: n={n} mode={mode} smode={smode} c={c}", flush=True)
-b.set_msm_window_bits(0)
+b.set_msm_window_bits(0); b.tune("msm_small", 1); b.tune("msm_task_len", 0)
 print(f"{cases} cases, {bad} mismatches")
 sys.exit(1 if bad else 0)
