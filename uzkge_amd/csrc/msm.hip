@@ -1734,7 +1734,7 @@ static int msm_run_small(Ctx& c, const Affine* points, const Fp* d_scalars, size
     SmallChunk* cdesc = m.partials.as<SmallChunk>();
     uint32_t* bucket_ref = m.bucket_count.as<uint32_t>();
     uint2* slot_chunks = m.bucket_start.as<uint2>();
-    XYZZ* win_sums = m.win_sums.as<XYZZ>();
+    XYZZ* win_sums = m.h_sums;        // pinned, device-visible host memory: one 128-byte store per slot, no copy kernel afterwards
     uint32_t* counters = m.small.as<uint32_t>() + 3960;               // [0] tasks, [1..4] chunks per level, [6] exceptions
     const size_t sort_lds = ((size_t)5 * NBL + 32 + n32) * 4;
     {
@@ -1803,11 +1803,10 @@ static int msm_run_small(Ctx& c, const Affine* points, const Fp* d_scalars, size
                 hipLaunchKernelGGL((msm_small_reduce_kernel<false, 512>), dim3(S), dim3(NBL), lds, st, P, bucket_ref, cdesc, slot_chunks, lv, win_sums, NBL);
         }
         UZK_HIP(hipGetLastError());
-        UZK_HIP(hipMemcpyAsync(m.h_sums, win_sums, (size_t)S * sizeof(XYZZ), hipMemcpyDeviceToHost, st));
     }
     {
         HostScope hs(c, "host_msm_wait2");
-        UZK_HIP(hipStreamSynchronize(st));
+        UZK_HIP(hipStreamSynchronize(st));      // the reduction kernel stored the window sums straight into pinned host memory
     }
     auto window_sum = [&](uint32_t b, uint32_t w) -> const XYZZ& { return m.h_sums[(size_t)b * W + w]; };
     msm_horner_host(c, batch, W, pre_c > 0 ? 0 : cb, window_sum, out_host);
