@@ -22,119 +22,56 @@ def _host(t):
 
 
 def _add_blinds(coefs, blinds, n):
-    """hide_polynomial on canonical ints (helpers.rs:139-158)."""
-    c = list(coefs) + [0] * (n + len(blinds) - len(coefs))
-    for i, bl in enumerate(blinds):
-        c[i] = (c[i] + bl) % opy.R
-        c[n + i] = (c[n + i] - bl) % opy.R
-    return c
+    from chain_oracle import add_blinds
+    return add_blinds(coefs, blinds, n)
 
 
-def _commit_with_blinds(lagrange_wire, mono_pts, evals_wire, blinds_ints, n):
-    """prover.rs:136-142: lagrange_pcs.commit(evals) then apply_blind_factors(blinds, n) (kzg_poly_commitment.rs:299-313)."""
-    cm = affine_of(oc.msm_pippenger(lagrange_wire, evals_wire, 0, 8))
-    for i, bl in enumerate(blinds_ints):
-        cm = opy.g1_add(cm, opy.g1_mul(mono_pts[i], bl))
-        cm = opy.g1_add(cm, opy.g1_mul(mono_pts[n + i], (-bl) % opy.R))
-    return cm
-
-
-def _pad(wire, length):
-    out = np.zeros((length, 4), dtype=np.uint64)
-    out[: wire.shape[0]] = wire
-    return out
+def _check_chain_against(c, o, want):
+    """c: ProverChain after run(), o: its outputs, want: chain_oracle.oracle_chain(inputs)."""
+    n, m = c.n, c.m
+    dev_coefs = _host(c.d_coefs).reshape(10, m, 4)
+    assert np.array_equal(dev_coefs[:, : n + 3], want["coefs"]) and not dev_coefs[:, n + 3:].any()     # hidden coefficient polynomials
+    for key in ("cm_w_wsel", "cm_z", "cm_t", "cm_q"):
+        got = oc.points_from_affine([affine_of(j) for j in o[key]])
+        assert np.array_equal(got, want[key]), key
+    assert np.array_equal(_host(c.d_z), want["z_evals"])
+    assert np.array_equal(_host(c.d_coset).reshape(10, m, 4), want["coset_evals"])
+    assert np.array_equal(_host(c.d_tq), want["t_quotient"])
+    assert np.array_equal(_host(c.d_t), want["t"])
+    for i in range(5):
+        assert np.array_equal(o["t_blinds"][i], want["t_blinds"][i]), i
+    for i in range(2):
+        assert np.array_equal(o["q_blinds"][i], want["q_blinds"][i]), i
+    for key in ("evals_zeta", "z_eval_zeta_omega", "open_evals_zeta", "open_evals_zeta_omega"):
+        assert np.array_equal(o[key], want[key]), key
+    assert np.array_equal(_host(c.d_r)[: n + 3], want["r"])
 
 
 def test_prover_round_chain_matches_oracle_chain(gpu):
-    from prover_chain import HIDE, ProverChain
-    c = ProverChain(n=1 << 14, seed=11)
+    from chain_oracle import oracle_chain
+    from prover_chain import ChainInputs, ProverChain
+    inp = ChainInputs(1 << 14, 11)
+    c = ProverChain(inputs=inp)
     try:
-        o = c.run()
-        n, m = c.n, c.m
-        mono_pts = {i: opy.wire_to_affine(c.mono_wire[i].tobytes()) for i in list(range(3)) + list(range(n, n + 3))}
-        ints = oc.fr_to_ints
-        # ---- round 1: coefficient polynomials (hidden) and the eight commitments
-        evals9 = [c.w_evals[i] for i in range(5)] + [c.wsel_evals[i] for i in range(3)] + [c.pi_evals]
-        blinds9 = [ints(c.blinds_w[i]) for i in range(5)] + [ints(c.blinds_wsel[i]) for i in range(3)] + [[]]
-        polys = []                                              # hidden coefficient polynomials, canonical ints
-        dev_coefs = _host(c.d_coefs).reshape(10, m, 4)
-        for i in range(9):
-            co = _add_blinds(ints(oc.ntt(evals9[i], inverse=True)), blinds9[i], n)
-            polys.append(co)
-            assert ints(dev_coefs[i, : n + 3]) == (co + [0] * 3)[: n + 3], f"polynomial {i}"
-            assert not dev_coefs[i, n + 3:].any()
-        for i in range(8):
-            assert affine_of(o["cm_w_wsel"][i]) == _commit_with_blinds(c.lagrange_wire, mono_pts, evals9[i], blinds9[i], n), f"commitment {i}"
-        # ---- round 2: z
-        group = oc.fr_from_ints([pow(pc_int(c.group_gen), i, opy.R) for i in range(n)])
-        z_evals = oc.z_poly(c.w_evals, c.perm, group, c.k, c.beta, c.gamma)
-        assert np.array_equal(_host(c.d_z), z_evals)
-        z_co = _add_blinds(ints(oc.ntt(z_evals, inverse=True)), ints(c.blinds_z), n)
-        polys.append(z_co)
-        assert ints(dev_coefs[9, : n + 3]) == z_co[: n + 3]
-        assert affine_of(o["cm_z"][0]) == _commit_with_blinds(c.lagrange_wire, mono_pts, z_evals, ints(c.blinds_z), n)
-        # ---- round 3: coset evaluations, quotient, t
-        cos = np.stack([oc.ntt(oc.mul_var(_pad(oc.fr_from_ints(p), m), c.k[1])) for p in polys])
-        assert np.array_equal(_host(c.d_coset).reshape(10, m, 4), cos)
-        vecs = np.concatenate([cos, c.tables])                  # slot order UZK_TQ_*: 10 fresh vectors then the 46 tables
-        want_tq = oc.t_quotient(n, 6, vecs, c.alpha, c.beta, c.gamma, c.k, c.anemoi_g, c.anemoi_g_inv, c.edwards_a, c.z_h_inv)
-        assert np.array_equal(_host(c.d_tq), want_tq)
-        t = oc.mul_var(oc.ntt(want_tq, inverse=True), c.k1_inv)
-        assert np.array_equal(_host(c.d_t), t)
-        t_int = ints(t)
-        prev, rands = 0, ints(c.t_rands)
-        for i in range(5):
-            chunk = t_int[i * n:(i + 1) * n] + [rands[i]] if i < 4 else t_int[4 * n:5 * n + 2]
-            chunk[0] = (chunk[0] - prev) % opy.R
-            prev = rands[i]
-            fold = chunk[:n]
-            blinds = [(-x) % opy.R for x in chunk[n:]]
-            for j, bl in enumerate(blinds):
-                fold[j] = (fold[j] - bl) % opy.R
-            assert ints(o["t_blinds"][i]) == blinds
-            ev = oc.ntt(oc.fr_from_ints(fold))
-            assert affine_of(o["cm_t"][i]) == _commit_with_blinds(c.lagrange_wire, mono_pts, ev, blinds, n), f"t chunk {i}"
-            polys.append(chunk)
-        # ---- round 4: evaluations
-        for j in range(10):
-            assert np.array_equal(o["evals_zeta"][j], oc.poly_eval(oc.fr_from_ints(polys[j]), c.zeta)), f"evaluation {j}"
-        assert np.array_equal(o["z_eval_zeta_omega"][0], oc.poly_eval(oc.fr_from_ints(polys[9]), c.zeta_omega))
-        # ---- round 5: r(X), openings
-        order = [9, 10, 11, 12, 13, 14, 0, 1, 2, 3, 4, 5]
-        rs = ints(c.r_scalars)
-        r = [0] * (n + 3)
-        for s_k, idx in zip(rs, order):
-            for j, v in enumerate(polys[idx][: n + 3]):
-                r[j] = (r[j] + s_k * v) % opy.R
-        assert ints(_host(c.d_r)[: n + 3]) == r
-        stack = np.stack([_pad(oc.fr_from_ints(p), n + 8) for p in polys] + [_pad(oc.fr_from_ints(r), n + 8)])
-        for which, (pset, point) in enumerate(((stack, c.zeta), (stack[9:10], c.zeta_omega))):
-            q, ev, rem_zero = oc.open_quotient(pset, point, c.alpha_open)
-            assert rem_zero
-            assert np.array_equal(o["open_evals_zeta" if which == 0 else "open_evals_zeta_omega"], ev)
-            qi = ints(q)
-            assert not any(qi[n + 2:]) and qi[n + 1] != 0
-            blinds = [(-x) % opy.R for x in qi[n:n + 2]]
-            fold = qi[:n]
-            for j, bl in enumerate(blinds):
-                fold[j] = (fold[j] - bl) % opy.R
-            assert ints(o["q_blinds"][which]) == blinds
-            ev_q = oc.ntt(oc.fr_from_ints(fold))
-            assert affine_of(o["cm_q"][which]) == _commit_with_blinds(c.lagrange_wire, mono_pts, ev_q, blinds, n), f"opening {which}"
+        _check_chain_against(c, c.run(), oracle_chain(inp))
+        # the general pipeline (no window table) commits to the same points
+        c2 = ProverChain(inputs=inp, precompute=False)
+        try:
+            o2 = c2.run()
+            for key in ("cm_w_wsel", "cm_z", "cm_t", "cm_q"):
+                assert [affine_of(j) for j in o2[key]] == [affine_of(j) for j in c.out[key]], key
+        finally:
+            c2.release()
     finally:
         c.release()
-
-
-def pc_int(row):
-    from uzkge_amd.poly_commit import fr_to_int
-    return fr_to_int(row)
 
 
 def test_quotient_without_shuffle_vectors(gpu):
     """A circuit without the "shuffle" feature (zmatchmaking, helpers.rs:437 #[cfg(feature = "shuffle")]): the 28 vectors
     of terms 12..18 are passed as NULL; the result equals the full formula with those vectors zero."""
-    from prover_chain import ProverChain
-    c = ProverChain(n=4096, seed=5, shuffle=False, precompute=False)
+    from prover_chain import ChainInputs, ProverChain
+    inp = ChainInputs(4096, 5)
+    c = ProverChain(inputs=inp, shuffle=False, precompute=False)
     try:
         c.run()
         n, m = c.n, c.m

@@ -24,7 +24,10 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-import torch
+try:
+    import torch
+except ImportError:      # ChainInputs alone needs no torch
+    torch = None
 
 from uzkge_amd import backend as b
 from uzkge_amd import poly_commit as pc
@@ -42,38 +45,30 @@ def _host(t: torch.Tensor) -> np.ndarray:
     return t.cpu().numpy().view(np.uint64)
 
 
-class ProverChain:
-    def __init__(self, n: int = 1 << 14, seed: int = 2024, shuffle: bool = True, precompute: bool = True):
-        b.init(0)
-        self.n, self.m, self.shuffle = n, 6 * n, shuffle
-        n, m = self.n, self.m
+class ChainInputs:
+    """Everything a chain run consumes, as host arrays (no GPU needed): the reference's SRS files, the synthetic circuit
+    and witness, the seeded challenges and blinds.  tests/chain_oracle.py computes the expected outputs from the same object."""
+
+    def __init__(self, n: int = 1 << 14, seed: int = 2024):
+        self.n, self.m, self.seed = n, 6 * n, seed
+        m = self.m
         rng = np.random.default_rng(seed)
-        self.rng = rng
 
         def fr(*shape):
             a = rng.integers(0, 1 << 63, size=shape + (4,), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=shape + (4,), dtype=np.uint64)
             a[..., 3] &= np.uint64(0x0FFFFFFFFFFFFFFF)
             return a
-        self.fr = fr
         # ---- parameters (reference files) and the combined commit bases
-        lag = pc.KZGCommitmentSchemeBN254.from_unchecked_bytes(open(os.path.join(GOLDEN, f"lagrange-srs-{n}.bin"), "rb").read())
-        mono = pc.load_srs_params(open(os.path.join(GOLDEN, "srs-padding.bin"), "rb").read(), n)
-        self.lagrange_wire = lag.public_parameter_group_1
-        self.mono_wire = mono.public_parameter_group_1
-        lag.release(); mono.release()
+        self.lagrange_wire = pc.parse_srs_g1_wire(open(os.path.join(GOLDEN, f"lagrange-srs-{n}.bin"), "rb").read())
+        self.mono_wire = pc.srs_params_wire(open(os.path.join(GOLDEN, "srs-padding.bin"), "rb").read(), n)
         self.bases = np.concatenate([self.lagrange_wire, self.mono_wire[:3], self.mono_wire[n:n + 3]])      # n + 6 points
-        self.srs = b.Srs.from_host(self.bases)
-        b.tune("msm_no_precompute", 0)
-        if precompute:
-            self.srs.precompute(0)            # static SRS: window table (same commitments, shorter calls)
         # ---- synthetic circuit: witness evaluations, wire selectors, public input, permutation, tables
         self.w_evals = fr(N_WIRES, n)
         self.wsel_evals = fr(N_WSEL, n)
         self.pi_evals = np.zeros((n, 4), dtype=np.uint64); self.pi_evals[:8] = fr(8)
         self.perm = rng.permutation(N_WIRES * n).astype(np.uint32).reshape(N_WIRES, n)
         self.k = fr(N_WIRES)
-        g = b.domain_group_gen(n)
-        self.group_gen = g
+        self.group_gen = b.domain_group_gen(n)
         self.tables = fr(N_TABLES, m)          # q (9), s (5), l1, qb, q_prk (4), coset_quotient, q_pk (12), q_g (12), q_ecc
         # challenges / blinds (seeded stand-ins for the transcript and the prover's rng)
         sc = fr(16)
@@ -82,6 +77,25 @@ class ProverChain:
         self.blinds_w = fr(N_WIRES, HIDE["w"]); self.blinds_wsel = fr(N_WSEL, HIDE["wsel"]); self.blinds_z = fr(HIDE["z"])
         self.t_rands = fr(5)
         self.r_scalars = fr(12)
+        # 1 / Z_H on the coset: 1 / (k1^n * g_m^(n i) - 1), i < 6 (helpers.rs:242-252) -- O(1) host arithmetic
+        k1 = pc.fr_to_int(self.k[1]); gm = pc.fr_to_int(b.domain_group_gen(m)); R = pc.FR_MODULUS
+        self.z_h_inv = np.stack([pc.fr_from_int(pow((pow(k1, n, R) * pow(gm, n * i, R) - 1) % R, -1, R)) for i in range(6)])
+        self.k1_inv = pc.fr_from_int(pow(k1, -1, R))
+        self.anemoi_g_inv = pc.fr_from_int(pow(pc.fr_to_int(self.anemoi_g), -1, R))
+        self.zeta_omega = pc.fr_from_int(pc.fr_to_int(self.zeta) * pc.fr_to_int(self.group_gen) % R)
+
+
+class ProverChain:
+    def __init__(self, n: int = 1 << 14, seed: int = 2024, shuffle: bool = True, precompute: bool = True, inputs: ChainInputs = None):
+        b.init(0)
+        inp = inputs if inputs is not None else ChainInputs(n, seed)
+        self.__dict__.update(inp.__dict__)               # the inputs' fields are read as attributes of the chain
+        self.inputs, self.shuffle = inp, shuffle
+        n, m = self.n, self.m
+        self.srs = b.Srs.from_host(self.bases)
+        b.tune("msm_no_precompute", 0)
+        if precompute:
+            self.srs.precompute(0)            # static SRS: window table (same commitments, shorter calls)
         # ---- device residency
         self.d_evals = _dev(np.concatenate([self.w_evals.reshape(-1, 4), self.wsel_evals.reshape(-1, 4), self.pi_evals]))   # [9n]
         self.d_perm = torch.from_numpy(self.perm.view(np.int32)).cuda()
@@ -104,12 +118,6 @@ class ProverChain:
         self.d_group = torch.empty((n, 4), dtype=torch.int64, device="cuda")
         torch.cuda.synchronize()
         b.ntt_device(x.data_ptr(), self.d_group.data_ptr(), n, sync=True)
-        # 1 / Z_H on the coset: 1 / (k1^n * g_m^(n i) - 1), i < 6 (helpers.rs:242-252) -- O(1) host arithmetic
-        k1 = pc.fr_to_int(self.k[1]); gm = pc.fr_to_int(b.domain_group_gen(m)); R = pc.FR_MODULUS
-        self.z_h_inv = np.stack([pc.fr_from_int(pow((pow(k1, n, R) * pow(gm, n * i, R) - 1) % R, -1, R)) for i in range(6)])
-        self.k1_inv = pc.fr_from_int(pow(k1, -1, R))
-        self.anemoi_g_inv = pc.fr_from_int(pow(pc.fr_to_int(self.anemoi_g), -1, R))
-        self.zeta_omega = pc.fr_from_int(pc.fr_to_int(self.zeta) * pc.fr_to_int(g) % R)
         self.out = {}
 
     # commit `count` evaluation vectors (device, n each, stride n) with their blinds: one batched MSM over n + 6 bases

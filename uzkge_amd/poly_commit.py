@@ -150,6 +150,43 @@ class FpPolynomial:
             FpPolynomial.from_coefs(self.coefs).coefs, FpPolynomial.from_coefs(other.coefs).coefs)
 
 
+def parse_srs_g1_wire(data: bytes) -> np.ndarray:
+    """The G1 section of a reference SRS blob as wire-format affine points [len, 8] (host only): u32 len_g1 | u32 len_g2 |
+    len_g1 x (x LE32 || y LE32, flags in the top two bits of the last byte) | G2 points (kzg_poly_commitment.rs:228-264)."""
+    if len(data) < 8:
+        raise UzkgeError(N.UZK_ERR_PARAMETER, "DeserializationError: short SRS blob")
+    len1, _len2 = struct.unpack_from("<II", data, 0)
+    if len(data) < 8 + 64 * len1:
+        raise UzkgeError(N.UZK_ERR_PARAMETER, "DeserializationError: truncated G1 section")
+    out = np.zeros((len1, 8), dtype=np.uint64)
+    for i in range(len1):
+        off = 8 + 64 * i
+        x = int.from_bytes(data[off:off + 32], "little")
+        yb = bytearray(data[off + 32:off + 64])
+        flags = yb[31] & 0xC0
+        yb[31] &= 0x3F
+        if flags & 0x40:
+            continue                       # infinity -> (0, 0)
+        y = int.from_bytes(bytes(yb), "little")
+        out[i, :4] = _to_wire(x, FQ_MODULUS)
+        out[i, 4:] = _to_wire(y, FQ_MODULUS)
+    return out
+
+
+def srs_params_wire(srs_blob: bytes, size: int) -> np.ndarray:
+    """load_srs_params (uzkge/src/gen_params/mod.rs:151-183) as a wire array (host only): powers 0..2050, the identity
+    up to `size`, then the three padding powers size, size + 1, size + 2."""
+    if size > 16384:
+        raise UzkgeError(N.UZK_ERR_PARAMETER, "ParameterError: size exceeds the embedded SRS")
+    g1 = parse_srs_g1_wire(srs_blob)
+    out = np.zeros((max(size + 3, 2051), 8), dtype=np.uint64)
+    out[:2051] = g1[:2051]
+    pad = {4096: 2051, 8192: 2054, 16384: 2057}.get(size)
+    if pad is not None:
+        out[size:size + 3] = g1[pad:pad + 3]
+    return out
+
+
 class KZGCommitmentSchemeBN254:
     """KZG over BN254 with the G1 powers resident on the GPU."""
 
@@ -162,24 +199,7 @@ class KZGCommitmentSchemeBN254:
         """Reference SRS blob: u32 len_g1 | u32 len_g2 | len_g1 x (x LE32 || y LE32, flags in the
         top two bits of the last byte) | G2 points (kzg_poly_commitment.rs:228-264).  The G2 part is
         only used by the verifier and is ignored here."""
-        if len(data) < 8:
-            raise UzkgeError(N.UZK_ERR_PARAMETER, "DeserializationError: short SRS blob")
-        len1, _len2 = struct.unpack_from("<II", data, 0)
-        if len(data) < 8 + 64 * len1:
-            raise UzkgeError(N.UZK_ERR_PARAMETER, "DeserializationError: truncated G1 section")
-        out = np.zeros((len1, 8), dtype=np.uint64)
-        for i in range(len1):
-            off = 8 + 64 * i
-            x = int.from_bytes(data[off:off + 32], "little")
-            yb = bytearray(data[off + 32:off + 64])
-            flags = yb[31] & 0xC0
-            yb[31] &= 0x3F
-            if flags & 0x40:
-                continue                       # infinity -> (0, 0)
-            y = int.from_bytes(bytes(yb), "little")
-            out[i, :4] = _to_wire(x, FQ_MODULUS)
-            out[i, 4:] = _to_wire(y, FQ_MODULUS)
-        return cls(out)
+        return cls(parse_srs_g1_wire(data))
 
     def max_degree(self) -> int:
         return self.public_parameter_group_1.shape[0] - 1
@@ -333,14 +353,4 @@ def hide_polynomial(polynomial: FpPolynomial, blinds: np.ndarray, zeroing_degree
 def load_srs_params(srs_blob: bytes, size: int) -> KZGCommitmentSchemeBN254:
     """uzkge/src/gen_params/mod.rs:151-183: the monomial SRS of a size-`size` circuit from the embedded blob --
     powers 0..2050, the identity up to `size`, then the three padding powers size, size+1, size+2."""
-    full = KZGCommitmentSchemeBN254.from_unchecked_bytes(srs_blob)
-    g1 = full.public_parameter_group_1
-    full.release()
-    if size > 16384:
-        raise UzkgeError(N.UZK_ERR_PARAMETER, "ParameterError: size exceeds the embedded SRS")
-    out = np.zeros((max(size + 3, 2051), 8), dtype=np.uint64)
-    out[:2051] = g1[:2051]
-    pad = {4096: 2051, 8192: 2054, 16384: 2057}.get(size)
-    if pad is not None:
-        out[size:size + 3] = g1[pad:pad + 3]
-    return KZGCommitmentSchemeBN254(out)
+    return KZGCommitmentSchemeBN254(srs_params_wire(srs_blob, size))
