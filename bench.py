@@ -567,6 +567,21 @@ def run_rank(args) -> None:
                                      "device_kernel_ms": round(sum(ms for k, (cnt, ms) in ktab.items() if not k.startswith("host_")), 3)}
         except Exception as e:
             extra["prover_chain"] = {"error": str(e)}
+        try:     # the same chain issued from compiled host code (tests/cpp/prover_rounds.cpp, built by __graft_entry__.build())
+            import subprocess
+            import tempfile
+            exe = os.path.join(ROOT, "tests", "cpp", "prover_rounds")
+            if os.path.exists(exe):
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                from test_gpu_cpp_mirror import _write_inputs
+                with tempfile.TemporaryDirectory() as td:
+                    _write_inputs(prover_chain.ChainInputs(1 << 14, 11), td, precompute=True)
+                    r = subprocess.run([exe, td, "10"], capture_output=True, text=True, timeout=300)
+                line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                extra["prover_rounds_cpp"] = dict(json.loads(line[0]), what="the chain above issued from C++ through the C ABI only "
+                                                  "(no interpreter between the calls), window table, ms per chain") if line else {"error": r.stderr[-300:]}
+        except Exception as e:
+            extra["prover_rounds_cpp"] = {"error": str(e)}
 
     # ---- CPU baseline + parity on a bounded sample (rank 0, N = 1 only) -----------------------
     cpu_baseline = None

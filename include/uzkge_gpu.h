@@ -175,11 +175,13 @@ int uzk_fold_blinds_device(const void* d_coefs, uint64_t len, uint64_t n_fold, v
 
 /* d_out[j] = sum_k scalars[k] * d_polys[k][j] for j < out_len (a polynomial contributes zero beyond lens[k]): the shape of
  * r_poly (uzkge/src/plonk/helpers.rs:681-999, 1030-1090) -- about 43 device-resident polynomials times scalars that the
- * caller builds from the evaluations and challenges exactly as the reference does.  count <= 64; d_out aliases no input. */
+ * caller builds from the evaluations and challenges exactly as the reference does.  count <= 64; d_out aliases no input.
+ * Asynchronous on the library stream (the scalars are copied before the call returns). */
 int uzk_poly_lincomb_device(const void* const* d_polys, const uint64_t* lens, const uint64_t* scalars_mont, uint32_t count,
                             void* d_out, uint64_t out_len);
 /* hide_polynomial (uzkge/src/plonk/helpers.rs:139-158) on device-resident coefficients (len >= zeroing_degree +
- * hiding_degree, zero-padded by the caller): coefs[i] += blinds[i], coefs[zeroing_degree + i] -= blinds[i]. */
+ * hiding_degree, zero-padded by the caller): coefs[i] += blinds[i], coefs[zeroing_degree + i] -= blinds[i].
+ * hiding_degree <= 16.  Asynchronous on the library stream. */
 int uzk_hide_polynomial_device(void* d_coefs, uint64_t len, const uint64_t* blinds_mont, uint32_t hiding_degree, uint64_t zeroing_degree);
 
 /* The quotient evaluations of t_poly on the coset k[1]*<g_m> (uzkge/src/plonk/helpers.rs:284-656 with

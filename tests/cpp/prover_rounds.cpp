@@ -1,0 +1,226 @@
+// prover_rounds -- the hot-path work of one PlonK proof issued from compiled host code through the C ABI only
+// (include/uzkge_gpu.h) plus the HIP runtime for device buffers: what a GPU-resident `prover_with_lagrange`
+// (uzkge/src/plonk/prover.rs:88-394) would issue, in its order, with no interpreter between the calls.
+//
+//   round 1   iFFT(n) x9 (5 wires, 3 wire selectors, pi), hide_polynomial, 8 commits       prover.rs:151-192
+//   round 2   z_poly, iFFT(n), hide, commit                                                 prover.rs:199-209
+//   round 3   coset FFT(6n) x10, quotient kernel, coset iFFT(6n); split t: fold, FFT(n), commit     helpers.rs:223-678, 1323-1408
+//   round 4   evaluations at zeta and zeta * omega                                         prover.rs:246-273
+//   round 5   r(X) = sum scalar_k p_k, two batch_prove openings                             helpers.rs:1030, pcs.rs:107-168
+//
+// Every commit is MSM(lagrange SRS, evaluations) + blind factors (prover.rs:132-149); the blinds ride in the same MSM:
+// bases = lagrange[0..n) || srs[0..3) || srs[n..n+3), scalars = evals || b || -b.  Challenges and blinds are inputs
+// (transcript / rng are out of scope).  Inputs and outputs are raw little-endian files in a directory written / read by
+// tests/test_gpu_cpp_mirror.py, which compares the outputs with the oracle chain (tests/chain_oracle.py).
+//
+// usage: prover_rounds <dir> [reps]      (reps > 0: also time `reps` chains and print ms per chain)
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "../../include/uzkge_gpu.h"
+
+#define CK(x) do { int rc_ = (x); if (rc_ != UZK_OK) { std::fprintf(stderr, "%s -> %d: %s\n", #x, rc_, uzk_last_error()); std::exit(1); } } while (0)
+#define HK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); std::exit(1); } } while (0)
+
+struct Fr { uint64_t l[4]; };
+static const uint64_t R_MOD[4] = {0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
+
+static Fr fr_sub(const Fr& a, const Fr& b) {            // Montgomery form is linear: plain modular subtraction
+    Fr r; unsigned __int128 br = 0;
+    for (int i = 0; i < 4; ++i) { unsigned __int128 t = (unsigned __int128)a.l[i] - b.l[i] - (uint64_t)br; r.l[i] = (uint64_t)t; br = (t >> 64) & 1; }
+    if (br) { unsigned __int128 c = 0; for (int i = 0; i < 4; ++i) { c += (unsigned __int128)r.l[i] + R_MOD[i]; r.l[i] = (uint64_t)c; c >>= 64; } }
+    return r;
+}
+static Fr fr_neg(const Fr& a) { Fr z{}; return (a.l[0] | a.l[1] | a.l[2] | a.l[3]) ? fr_sub(z, a) : z; }
+
+static std::string g_dir;
+template <class T> static std::vector<T> rd(const char* name) {
+    std::ifstream f(g_dir + "/" + name + ".bin", std::ios::binary | std::ios::ate);
+    if (!f) { std::fprintf(stderr, "missing input %s\n", name); std::exit(2); }
+    const size_t bytes = (size_t)f.tellg();
+    std::vector<T> v(bytes / sizeof(T));
+    f.seekg(0); f.read(reinterpret_cast<char*>(v.data()), bytes);
+    return v;
+}
+static void wr(const char* name, const void* p, size_t bytes) {
+    std::ofstream f(g_dir + "/out_" + name + ".bin", std::ios::binary);
+    f.write(static_cast<const char*>(p), bytes);
+}
+template <class T> static T* dmalloc(size_t count) { void* p; HK(hipMalloc(&p, count * sizeof(T))); return static_cast<T*>(p); }
+
+int main(int argc, char** argv) {
+    if (argc < 2) { std::printf("usage: prover_rounds <dir> [reps]\n"); return 2; }
+    g_dir = argv[1];
+    const int reps = argc > 2 ? std::atoi(argv[2]) : 0;
+    CK(uzk_init(0));
+    hipStream_t st = static_cast<hipStream_t>(uzk_stream());     // all copies go on the library stream: ordered with its kernels
+
+    // ---- inputs
+    const auto meta = rd<uint64_t>("meta");                       // n, shuffle
+    const size_t n = meta[0], m = 6 * n;
+    const bool shuffle = meta[1] != 0;
+    const auto bases = rd<uzk_g1_affine>("bases");                // n + 6 points
+    const auto evals9 = rd<Fr>("evals9");                         // w0..w4, wsel0..2, pi  (9 n)
+    const auto perm = rd<uint32_t>("perm");
+    const auto tables = rd<Fr>("tables");                         // 46 m
+    const auto k = rd<Fr>("k");                                   // 5
+    const auto sc = rd<Fr>("scalars");     // beta gamma alpha zeta alpha_open anemoi_g anemoi_g_inv edwards_a k1_inv zeta_omega
+    const Fr beta = sc[0], gamma = sc[1], alpha = sc[2], zeta = sc[3], alpha_open = sc[4], anemoi_g = sc[5], anemoi_g_inv = sc[6],
+             edwards_a = sc[7], k1_inv = sc[8], zeta_omega = sc[9];
+    const auto z_h_inv = rd<Fr>("z_h_inv");                       // 6
+    const auto blinds_w = rd<Fr>("blinds_w"), blinds_wsel = rd<Fr>("blinds_wsel"), blinds_z = rd<Fr>("blinds_z");   // 5x2, 3x2, 3
+    const auto t_rands = rd<Fr>("t_rands"), r_scalars = rd<Fr>("r_scalars");                                       // 5, 12
+
+    // ---- device residency
+    uint64_t srs = 0;
+    CK(uzk_srs_register(bases.data(), bases.size(), &srs));
+    if (meta.size() > 2 && meta[2]) CK(uzk_srs_precompute(srs, 0));
+    Fr* d_evals = dmalloc<Fr>(9 * n);   HK(hipMemcpy(d_evals, evals9.data(), 9 * n * sizeof(Fr), hipMemcpyHostToDevice));
+    uint32_t* d_perm = dmalloc<uint32_t>(5 * n); HK(hipMemcpy(d_perm, perm.data(), 5 * n * 4, hipMemcpyHostToDevice));
+    Fr* d_tables = dmalloc<Fr>(46 * m); HK(hipMemcpy(d_tables, tables.data(), 46 * m * sizeof(Fr), hipMemcpyHostToDevice));
+    Fr *d_coefs = dmalloc<Fr>(10 * m), *d_tmp = dmalloc<Fr>(10 * n), *d_coset = dmalloc<Fr>(10 * m), *d_tq = dmalloc<Fr>(m), *d_t = dmalloc<Fr>(m),
+       *d_z = dmalloc<Fr>(n), *d_sc = dmalloc<Fr>(8 * (n + 6)), *d_chunks = dmalloc<Fr>(5 * (n + 8)), *d_fold = dmalloc<Fr>(5 * n),
+       *d_q = dmalloc<Fr>(2 * (n + 8)), *d_r = dmalloc<Fr>(n + 8), *d_open = dmalloc<Fr>(16 * (n + 8)), *d_group = dmalloc<Fr>(n);
+    HK(hipMemset(d_coefs, 0, 10 * m * sizeof(Fr)));               // coefficient slots: 6n each, zero beyond n + 3
+    {   // group[i] = omega^i: forward NTT of X
+        std::vector<Fr> x(n);
+        std::memset(x.data(), 0, n * sizeof(Fr));
+        const uint64_t one[4] = {0xac96341c4ffffffbull, 0x36fc76959f60cd29ull, 0x666ea36f7879462eull, 0x0e0a77c19a07df2full};   // R mod r
+        std::memcpy(x[1].l, one, 32);
+        HK(hipMemcpy(d_tmp, x.data(), n * sizeof(Fr), hipMemcpyHostToDevice));
+        CK(uzk_ntt_fr_device(d_tmp, d_group, n, 0, nullptr, 1));
+    }
+
+    // commit `count` evaluation vectors (device, stride n) with their blinds: one batched MSM over n + 6 bases.  The
+    // blind tails go through pinned host memory (one slot per commit of the chain), so nothing waits for the upload.
+    Fr* h_tails = nullptr;
+    HK(hipHostMalloc(reinterpret_cast<void**>(&h_tails), 4 * 8 * 6 * sizeof(Fr), hipHostMallocDefault));
+    int commit_no = 0;
+    auto commit = [&](const Fr* d_ev, uint32_t count, const std::vector<std::vector<Fr>>& blinds, uzk_g1_jac* out) {
+        HK(hipMemcpy2DAsync(d_sc, (n + 6) * sizeof(Fr), d_ev, n * sizeof(Fr), n * sizeof(Fr), count, hipMemcpyDeviceToDevice, st));
+        Fr* tail = h_tails + (commit_no++ % 4) * 8 * 6;
+        std::memset(tail, 0, count * 6 * sizeof(Fr));
+        for (uint32_t i = 0; i < count; ++i)
+            for (size_t j = 0; j < blinds[i].size(); ++j) { tail[i * 6 + j] = blinds[i][j]; tail[i * 6 + 3 + j] = fr_neg(blinds[i][j]); }
+        HK(hipMemcpy2DAsync(d_sc + n, (n + 6) * sizeof(Fr), tail, 6 * sizeof(Fr), 6 * sizeof(Fr), count, hipMemcpyHostToDevice, st));
+        CK(uzk_msm_g1_batch_device(srs, 0, d_sc, n + 6, count, out));      // returns after the window sums have arrived
+    };
+
+    uzk_g1_jac cm_w_wsel[8], cm_z[1], cm_t[5], cm_q[2];
+    std::vector<Fr> evals_zeta(10), z_eval_zo(1), open_ev_zeta(16), open_ev_zo(1);
+    std::vector<std::vector<Fr>> t_blinds(5), q_blinds(2);
+    void* tq_ptrs[UZK_TQ_NVEC];
+
+    auto chain = [&]() {
+        // ---- round 1
+        HK(hipMemset2DAsync(d_coefs + n, m * sizeof(Fr), 0, 8 * sizeof(Fr), 10, st));     // the slots the blinds are added into
+        CK(uzk_ntt_fr_batch_device(d_evals, d_tmp, n, 9, 1, nullptr, 0));
+        HK(hipMemcpy2DAsync(d_coefs, m * sizeof(Fr), d_tmp, n * sizeof(Fr), n * sizeof(Fr), 9, hipMemcpyDeviceToDevice, st));
+        std::vector<std::vector<Fr>> bl8(8);
+        for (int i = 0; i < 5; ++i) { bl8[i] = {blinds_w[2 * i], blinds_w[2 * i + 1]}; CK(uzk_hide_polynomial_device(d_coefs + i * m, m, bl8[i][0].l, 2, n)); }
+        for (int i = 0; i < 3; ++i) { bl8[5 + i] = {blinds_wsel[2 * i], blinds_wsel[2 * i + 1]}; CK(uzk_hide_polynomial_device(d_coefs + (5 + i) * m, m, bl8[5 + i][0].l, 2, n)); }
+        commit(d_evals, 8, bl8, cm_w_wsel);
+        // ---- round 2
+        CK(uzk_z_poly_device(d_evals, d_perm, d_group, k[0].l, beta.l, gamma.l, (uint32_t)n, 5, d_z));
+        CK(uzk_ntt_fr_device(d_z, d_tmp, n, 1, nullptr, 0));
+        HK(hipMemcpyAsync(d_coefs + 9 * m, d_tmp, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+        CK(uzk_hide_polynomial_device(d_coefs + 9 * m, m, blinds_z[0].l, 3, n));
+        commit(d_z, 1, {{blinds_z[0], blinds_z[1], blinds_z[2]}}, cm_z);
+        // ---- round 3
+        CK(uzk_ntt_fr_batch_device(d_coefs, d_coset, m, 10, 0, k[1].l, 0));
+        uzk_quotient_args qa;
+        std::memset(&qa, 0, sizeof qa);
+        qa.n = (uint32_t)n; qa.factor = 6;
+        for (int i = 0; i < 5; ++i) qa.vec[UZK_TQ_W + i] = d_coset + i * m;
+        for (int i = 0; i < 3; ++i) qa.vec[UZK_TQ_WSEL + i] = shuffle ? d_coset + (5 + i) * m : nullptr;
+        qa.vec[UZK_TQ_PI] = d_coset + 8 * m; qa.vec[UZK_TQ_Z] = d_coset + 9 * m;
+        for (int i = 0; i < 21; ++i) qa.vec[UZK_TQ_Q + i] = d_tables + i * m;
+        for (int i = 0; i < 25; ++i) qa.vec[UZK_TQ_QPK + i] = shuffle ? d_tables + (21 + i) * m : nullptr;
+        for (int i = 0; i < UZK_TQ_NVEC; ++i) tq_ptrs[i] = const_cast<void*>(qa.vec[i]);
+        std::memcpy(qa.alpha, alpha.l, 32); std::memcpy(qa.beta, beta.l, 32); std::memcpy(qa.gamma, gamma.l, 32);
+        std::memcpy(qa.k, k.data(), 5 * 32);
+        std::memcpy(qa.anemoi_g, anemoi_g.l, 32); std::memcpy(qa.anemoi_g_inv, anemoi_g_inv.l, 32); std::memcpy(qa.edwards_a, edwards_a.l, 32);
+        std::memcpy(qa.z_h_inv, z_h_inv.data(), 6 * 32);
+        CK(uzk_t_quotient_device(&qa, d_tq, 0));
+        CK(uzk_ntt_fr_device(d_tq, d_t, m, 1, k1_inv.l, 0));
+        // split t (taken as 5n + 2 coefficients): chunk i gets + rand_i X^n and - rand_(i-1)  (helpers.rs:1353-1363)
+        HK(hipMemsetAsync(d_chunks, 0, 5 * (n + 8) * sizeof(Fr), st));
+        HK(hipMemcpy2DAsync(d_chunks, (n + 8) * sizeof(Fr), d_t, n * sizeof(Fr), n * sizeof(Fr), 5, hipMemcpyDeviceToDevice, st));
+        HK(hipMemcpyAsync(d_chunks + 4 * (n + 8) + n, d_t + 5 * n, 2 * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+        Fr heads[5];
+        HK(hipMemcpy2DAsync(heads, sizeof(Fr), d_t, n * sizeof(Fr), sizeof(Fr), 5, hipMemcpyDeviceToHost, st));
+        HK(hipStreamSynchronize(st));
+        Fr prev{}, fix[5];
+        for (int i = 0; i < 5; ++i) {
+            fix[i] = fr_sub(heads[i], prev);                                  // coefs[0] -= rand_(i-1)
+            HK(hipMemcpyAsync(d_chunks + i * (n + 8), &fix[i], sizeof(Fr), hipMemcpyHostToDevice, st));
+            if (i < 4) HK(hipMemcpyAsync(d_chunks + i * (n + 8) + n, &t_rands[i], sizeof(Fr), hipMemcpyHostToDevice, st));   // coefs[n] += rand_i
+            prev = t_rands[i];
+        }
+        HK(hipStreamSynchronize(st));                                         // `fix` is a local array
+        for (int i = 0; i < 5; ++i) {
+            const size_t len = i < 4 ? n + 1 : n + 2;
+            t_blinds[i].assign(len - n, Fr{});
+            CK(uzk_fold_blinds_device(d_chunks + i * (n + 8), len, n, d_fold + i * n, t_blinds[i][0].l));
+        }
+        CK(uzk_ntt_fr_batch_device(d_fold, d_fold, n, 5, 0, nullptr, 0));
+        commit(d_fold, 5, t_blinds, cm_t);
+        // ---- round 4
+        CK(uzk_poly_eval_batch_device(d_coefs, m, 10, zeta.l, evals_zeta[0].l));
+        CK(uzk_poly_eval_batch_device(d_coefs + 9 * m, m, 1, zeta_omega.l, z_eval_zo[0].l));
+        // ---- round 5
+        const void* polys[12];
+        uint64_t lens[12];
+        polys[0] = d_coefs + 9 * m; lens[0] = n + 3;
+        for (int i = 0; i < 5; ++i) { polys[1 + i] = d_chunks + i * (n + 8); lens[1 + i] = n + 2; }
+        for (int i = 0; i < 6; ++i) { polys[6 + i] = d_coefs + i * m; lens[6 + i] = n + 3; }
+        CK(uzk_poly_lincomb_device(polys, lens, r_scalars[0].l, 12, d_r, n + 3));
+        HK(hipMemsetAsync(d_open, 0, 16 * (n + 8) * sizeof(Fr), st));
+        HK(hipMemcpy2DAsync(d_open, (n + 8) * sizeof(Fr), d_coefs, m * sizeof(Fr), (n + 3) * sizeof(Fr), 10, hipMemcpyDeviceToDevice, st));
+        HK(hipMemcpyAsync(d_open + 10 * (n + 8), d_chunks, 5 * (n + 8) * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+        HK(hipMemcpyAsync(d_open + 15 * (n + 8), d_r, (n + 3) * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+        CK(uzk_open_quotient_device(d_open, n + 8, 16, zeta.l, alpha_open.l, d_q, open_ev_zeta[0].l));
+        CK(uzk_open_quotient_device(d_open + 9 * (n + 8), n + 8, 1, zeta_omega.l, alpha_open.l, d_q + (n + 8), open_ev_zo[0].l));
+        for (int j = 0; j < 2; ++j) {      // q has degree n + 1: max_power_of_2 = n, two blinds (pcs.rs:137-156)
+            q_blinds[j].assign(2, Fr{});
+            CK(uzk_fold_blinds_device(d_q + j * (n + 8), n + 2, n, d_fold + j * n, q_blinds[j][0].l));
+        }
+        CK(uzk_ntt_fr_batch_device(d_fold, d_fold, n, 2, 0, nullptr, 0));
+        commit(d_fold, 2, q_blinds, cm_q);
+    };
+
+    chain();
+    CK(uzk_sync());
+    // ---- outputs
+    wr("cm_w_wsel", cm_w_wsel, sizeof cm_w_wsel); wr("cm_z", cm_z, sizeof cm_z); wr("cm_t", cm_t, sizeof cm_t); wr("cm_q", cm_q, sizeof cm_q);
+    wr("evals_zeta", evals_zeta.data(), 10 * 32); wr("z_eval_zeta_omega", z_eval_zo.data(), 32);
+    wr("open_evals_zeta", open_ev_zeta.data(), 16 * 32); wr("open_evals_zeta_omega", open_ev_zo.data(), 32);
+    { std::vector<Fr> flat; for (auto& v : t_blinds) flat.insert(flat.end(), v.begin(), v.end()); wr("t_blinds", flat.data(), flat.size() * 32); }
+    { std::vector<Fr> flat; for (auto& v : q_blinds) flat.insert(flat.end(), v.begin(), v.end()); wr("q_blinds", flat.data(), flat.size() * 32); }
+    auto dump = [&](const char* name, const Fr* d, size_t count) {
+        std::vector<Fr> h(count);
+        HK(hipMemcpy(h.data(), d, count * sizeof(Fr), hipMemcpyDeviceToHost));
+        wr(name, h.data(), count * sizeof(Fr));
+    };
+    dump("coefs", d_coefs, 10 * m); dump("coset_evals", d_coset, 10 * m); dump("t_quotient", d_tq, m); dump("t", d_t, m);
+    dump("z_evals", d_z, n); dump("r", d_r, n + 3);
+    { uint64_t nulls = 0; for (int i = 0; i < UZK_TQ_NVEC; ++i) nulls += tq_ptrs[i] == nullptr; wr("tq_null_slots", &nulls, 8); }
+
+    if (reps > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int r = 0; r < reps; ++r) chain();
+        CK(uzk_sync());
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / reps;
+        std::printf("{\"ms_per_chain\": %.4f, \"reps\": %d, \"n\": %zu}\n", ms, reps, n);
+    }
+    std::printf("OK\n");
+    CK(uzk_srs_release(srs));
+    return 0;
+}

@@ -33,3 +33,68 @@ def test_cpp_mirror_reference_tests(gpu):
     r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "srs-padding.bin"),
                         os.path.join(ROOT, "tests", "golden", "lagrange-srs-4096.bin")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+
+
+def _build_rounds():
+    """tests/cpp/prover_rounds.cpp: one proof's hot-path sequence issued from C++ through the C ABI (hipcc: it also uses
+    the HIP runtime for its device buffers)."""
+    out = os.path.join(ROOT, "tests", "cpp", "prover_rounds")
+    src = os.path.join(ROOT, "tests", "cpp", "prover_rounds.cpp")
+    subprocess.check_call([
+        "/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-o", out, src,
+        "-L" + os.path.join(ROOT, "uzkge_amd"), "-luzkge_gpu", "-Wl,-rpath," + os.path.join(ROOT, "uzkge_amd"),
+    ])
+    return out
+
+
+def test_cpp_prover_rounds_compiles_and_links():
+    assert os.path.exists(_build_rounds())
+
+
+def _write_inputs(inp, d, shuffle=True, precompute=True):
+    import numpy as np
+    def put(name, a, dtype=np.uint64):
+        np.ascontiguousarray(a, dtype=dtype).tofile(os.path.join(d, name + ".bin"))
+    put("meta", [inp.n, int(shuffle), int(precompute)])
+    put("bases", inp.bases)
+    put("evals9", np.concatenate([inp.w_evals.reshape(-1, 4), inp.wsel_evals.reshape(-1, 4), inp.pi_evals]))
+    put("perm", inp.perm, np.uint32)
+    put("tables", inp.tables)
+    put("k", inp.k)
+    put("scalars", np.stack([inp.beta, inp.gamma, inp.alpha, inp.zeta, inp.alpha_open, inp.anemoi_g, inp.anemoi_g_inv, inp.edwards_a,
+                             inp.k1_inv, inp.zeta_omega]))
+    put("z_h_inv", inp.z_h_inv)
+    put("blinds_w", inp.blinds_w); put("blinds_wsel", inp.blinds_wsel); put("blinds_z", inp.blinds_z)
+    put("t_rands", inp.t_rands); put("r_scalars", inp.r_scalars)
+
+
+@pytest.mark.gpu
+def test_cpp_prover_rounds_match_frozen_outputs(gpu, tmp_path):
+    """The C++ driver runs ChainInputs(4096, 7) and must reproduce tests/golden/vectors_v2.npz (commitments over the
+    reference's SRS files, evaluations, blinds, digests of the intermediates) -- the same fixture the Python chain is held to."""
+    import hashlib
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_c as oc
+    from prover_chain import ChainInputs
+    V2 = np.load(os.path.join(ROOT, "tests", "golden", "vectors_v2.npz"))
+    n = int(V2["n"][0])
+    inp = ChainInputs(n, int(V2["seed"][0]))
+    _write_inputs(inp, str(tmp_path))
+    exe = _build_rounds()
+    r = subprocess.run([exe, str(tmp_path), "3"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+    rd = lambda name, shape: np.fromfile(os.path.join(str(tmp_path), "out_" + name + ".bin"), dtype=np.uint64).reshape(shape)
+    for key, cnt in (("cm_w_wsel", 8), ("cm_z", 1), ("cm_t", 5), ("cm_q", 2)):
+        jac = rd(key, (cnt, 12))
+        assert np.array_equal(oc.points_from_affine([oc.jac_to_affine_ints(j) for j in jac]), V2[key]), key
+    for key in ("evals_zeta", "z_eval_zeta_omega", "open_evals_zeta", "open_evals_zeta_omega", "t_blinds", "q_blinds"):
+        assert np.array_equal(rd(key, (-1, 4)), V2[key]), key
+    m = 6 * n
+    big = {"coefs": rd("coefs", (10, m, 4))[:, : n + 3], "coset_evals": rd("coset_evals", (10, m, 4)), "t_quotient": rd("t_quotient", (m, 4)),
+           "t": rd("t", (m, 4)), "z_evals": rd("z_evals", (n, 4)), "r": rd("r", (n + 3, 4))}
+    for key, arr in big.items():
+        dig = np.frombuffer(hashlib.sha256(np.ascontiguousarray(arr).tobytes()).digest(), dtype=np.uint8)
+        assert np.array_equal(dig, V2["sha256_" + key]), key

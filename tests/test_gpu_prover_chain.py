@@ -102,6 +102,7 @@ def test_lincomb_and_hide_primitives(gpu):
     d = [torch.from_numpy(p.view(np.int64)).cuda() for p in polys]
     out = torch.empty((n + 5, 4), dtype=torch.int64, device="cuda")
     gpu.poly_lincomb_device([t.data_ptr() for t in d], [p.shape[0] for p in polys], scal, out.data_ptr(), n + 5)
+    gpu.sync()                                            # asynchronous on the library stream
     want = [0] * (n + 5)
     si = oc.fr_to_ints(scal)
     for s_k, p in zip(si, polys):
@@ -112,4 +113,5 @@ def test_lincomb_and_hide_primitives(gpu):
     bl = rand_fr_wire(3, 61)
     dco = torch.from_numpy(co.view(np.int64)).cuda()
     gpu.hide_polynomial_device(dco.data_ptr(), n + 3, bl, n)
+    gpu.sync()
     assert oc.fr_to_ints(_host(dco)) == _add_blinds(oc.fr_to_ints(co[:n]), oc.fr_to_ints(bl), n)

@@ -148,6 +148,7 @@ class ProverChain:
         coefs = self.d_coefs.view(10, m, 4)              # order = UZK_TQ slots: w0..w4, wsel0..2, pi, z
         # ---- round 1: iFFT of the nine evaluation vectors, hide, commit wires and wire selectors
         b.ntt_batch_device(self.d_evals.data_ptr(), self.d_tmp.data_ptr(), n, 9, inverse=True, sync=True)
+        coefs[:, n:n + 8] = 0                            # the slots the blinds are added into (a repeated run starts clean)
         coefs[:9, :n] = self.d_tmp[: 9 * n].view(9, n, 4)
         torch.cuda.synchronize()
         for i in range(N_WIRES):
@@ -210,6 +211,7 @@ class ProverChain:
         polys = [coefs[9].data_ptr()] + [ch[i].data_ptr() for i in range(5)] + [coefs[i].data_ptr() for i in range(6)]
         lens = [n + 3] + [n + 2] * 5 + [n + 3] * 6
         b.poly_lincomb_device(polys, lens, self.r_scalars, self.d_r.data_ptr(), n + 3)
+        b.sync()                                         # asynchronous call; torch copies below run on torch's stream
         op = self.d_open.view(16, n + 8, 4)
         op.zero_()
         for j in range(10):

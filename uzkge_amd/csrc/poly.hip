@@ -615,13 +615,14 @@ int fold_blinds_run(Ctx& c, const Fp* d_coefs, uint64_t len, uint64_t N, Fp* d_o
 // those O(1) scalar formulas stay with the caller, exactly where the reference computes them).
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t kLincombMax = 64;
-struct LincombArgs {
+struct LincombArgs {                      // by value: 2.8 KB of kernel arguments, no staging copy and no synchronisation
     const Fp* p[kLincombMax];
     uint32_t len[kLincombMax];
+    Fp scalars[kLincombMax];
     uint32_t count;
 };
-__global__ __launch_bounds__(256) void poly_lincomb_kernel(LincombArgs a, const Fp* __restrict__ scalars, Fp* __restrict__ out,
-                                                           uint64_t out_len) {
+__global__ __launch_bounds__(256) void poly_lincomb_kernel(LincombArgs a, Fp* __restrict__ out, uint64_t out_len) {
+    const Fp* scalars = a.scalars;
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= out_len) return;
     Fp acc = Fr::zero();
@@ -642,37 +643,34 @@ int poly_lincomb_run(Ctx& c, const void* const* d_polys, const uint64_t* lens, c
         a.len[k] = (uint32_t)lens[k];
     }
     if (out_len == 0) return UZK_OK;
-    UZK_TRY(c.poly_tmp2.reserve((size_t)kLincombMax * sizeof(Fp)));
-    UZK_HIP(hipMemcpyAsync(c.poly_tmp2.p, scalars_host, (size_t)count * sizeof(Fp), hipMemcpyHostToDevice, c.stream));
+    for (uint32_t k = 0; k < count; ++k) a.scalars[k] = scalars_host[k];
     {
         KernelScope ks(c, "poly_lincomb");
-        hipLaunchKernelGGL(poly_lincomb_kernel, dim3((unsigned)((out_len + 255) / 256)), dim3(256), 0, c.stream, a, c.poly_tmp2.as<Fp>(),
-                           d_out, out_len);
+        hipLaunchKernelGGL(poly_lincomb_kernel, dim3((unsigned)((out_len + 255) / 256)), dim3(256), 0, c.stream, a, d_out, out_len);
     }
     UZK_HIP(hipGetLastError());
-    UZK_HIP(hipStreamSynchronize(c.stream));      // scalars_host belongs to the caller
-    return UZK_OK;
+    return UZK_OK;                                 // asynchronous on the library stream
 }
 
 // hide_polynomial (uzkge/src/plonk/helpers.rs:139-158) on device-resident coefficients:
 // coefs[i] += blind_i, coefs[zeroing_degree + i] -= blind_i  (adds (b_0 + b_1 X + ..)(X^zeroing_degree - 1)).
-__global__ void poly_hide_kernel(Fp* __restrict__ coefs, uint64_t zeroing_degree, const Fp* __restrict__ blinds, uint32_t count) {
+struct HideArgs { Fp blinds[16]; };
+__global__ void poly_hide_kernel(Fp* __restrict__ coefs, uint64_t zeroing_degree, HideArgs h, uint32_t count) {
     const uint32_t i = threadIdx.x;
     if (i >= count) return;
-    coefs[i] = Fr::add(coefs[i], blinds[i]);
-    coefs[zeroing_degree + i] = Fr::sub(coefs[zeroing_degree + i], blinds[i]);
+    coefs[i] = Fr::add(coefs[i], h.blinds[i]);
+    coefs[zeroing_degree + i] = Fr::sub(coefs[zeroing_degree + i], h.blinds[i]);
 }
 int poly_hide_run(Ctx& c, Fp* d_coefs, uint64_t len, const Fp* blinds_host, uint32_t hiding_degree, uint64_t zeroing_degree) {
     if (hiding_degree == 0) return UZK_OK;
-    if (hiding_degree > 64 || hiding_degree > zeroing_degree || zeroing_degree + hiding_degree > len) {
-        set_error("hide_polynomial: need hiding_degree <= min(64, zeroing_degree) and zeroing_degree + hiding_degree <= len");
+    if (hiding_degree > 16 || hiding_degree > zeroing_degree || zeroing_degree + hiding_degree > len) {
+        set_error("hide_polynomial: need hiding_degree <= min(16, zeroing_degree) and zeroing_degree + hiding_degree <= len");
         return UZK_ERR_PARAMETER;
     }
-    UZK_TRY(c.poly_tmp2.reserve((size_t)kLincombMax * sizeof(Fp)));
-    UZK_HIP(hipMemcpyAsync(c.poly_tmp2.p, blinds_host, (size_t)hiding_degree * sizeof(Fp), hipMemcpyHostToDevice, c.stream));
-    hipLaunchKernelGGL(poly_hide_kernel, dim3(1), dim3(64), 0, c.stream, d_coefs, zeroing_degree, c.poly_tmp2.as<Fp>(), hiding_degree);
+    HideArgs h;                                    // the blinds travel as kernel arguments: no staging copy, no synchronisation
+    for (uint32_t i = 0; i < 16; ++i) h.blinds[i] = i < hiding_degree ? blinds_host[i] : Fr::zero();
+    hipLaunchKernelGGL(poly_hide_kernel, dim3(1), dim3(64), 0, c.stream, d_coefs, zeroing_degree, h, hiding_degree);
     UZK_HIP(hipGetLastError());
-    UZK_HIP(hipStreamSynchronize(c.stream));
     return UZK_OK;
 }
 
