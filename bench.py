@@ -551,12 +551,14 @@ def run_rank(args) -> None:
         try:     # the checked chain of tests/test_gpu_prover_chain.py, timed (stand-in for config #4's prove time)
             import prover_chain
             ch = prover_chain.ProverChain()
-            ch.run(); b.sync()
-            t3 = time.perf_counter()
             for _ in range(3):
                 ch.run()
             b.sync()
-            chain_ms = (time.perf_counter() - t3) / 3 * 1e3
+            t3 = time.perf_counter()
+            for _ in range(5):
+                ch.run()
+            b.sync()
+            chain_ms = (time.perf_counter() - t3) / 5 * 1e3
             b.profile_reset(); b.profile_enable(True); ch.run(); b.sync(); b.profile_enable(False)
             ktab = b.profile_table()
             ch.release()
@@ -576,7 +578,7 @@ def run_rank(args) -> None:
                 from test_gpu_cpp_mirror import _write_inputs
                 with tempfile.TemporaryDirectory() as td:
                     _write_inputs(prover_chain.ChainInputs(1 << 14, 11), td, precompute=True)
-                    r = subprocess.run([exe, td, "10"], capture_output=True, text=True, timeout=300)
+                    r = subprocess.run([exe, td, "20"], capture_output=True, text=True, timeout=300)
                 line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
                 extra["prover_rounds_cpp"] = dict(json.loads(line[0]), what="the chain above issued from C++ through the C ABI only "
                                                   "(no interpreter between the calls), window table, ms per chain") if line else {"error": r.stderr[-300:]}

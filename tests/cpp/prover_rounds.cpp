@@ -214,6 +214,8 @@ int main(int argc, char** argv) {
     { uint64_t nulls = 0; for (int i = 0; i < UZK_TQ_NVEC; ++i) nulls += tq_ptrs[i] == nullptr; wr("tq_null_slots", &nulls, 8); }
 
     if (reps > 0) {
+        for (int r = 0; r < 3; ++r) chain();        // settle workspaces, plans and clocks before timing
+        CK(uzk_sync());
         const auto t0 = std::chrono::steady_clock::now();
         for (int r = 0; r < reps; ++r) chain();
         CK(uzk_sync());

@@ -1780,8 +1780,10 @@ static int msm_run_small(Ctx& c, const Affine* points, const Fp* d_scalars, size
         for (uint32_t k = 1; k <= std::min<uint32_t>(lv.nl, 1); ++k) {     // later levels: inside the reduction kernel
             KernelScope ks(c, "msm_small_fold");
             const uint64_t est = k == 1 ? (uint64_t)S * NBL : (uint64_t)S * 2;      // chunks that really exist (estimate)
-            bool quad = est * 16 <= 2 * lanes_chip;
-            int gs = quad ? 4 : (est * 4 <= 2 * lanes_chip ? 4 : 2);
+            // measured (tools/small_msm.py, msm_fold_mode sweep, n = 2^14): quads of 4 logical lanes match or beat plain lanes up
+            // to batch 8 (uniform: 75-89 vs 77-96 us, skewed scalars: 27-38 vs 62-63 us); beyond, plain lanes fill the chip
+            bool quad = est * 16 <= 10 * lanes_chip;
+            int gs = quad ? 4 : (est * 4 <= 4 * lanes_chip ? 4 : 2);
             if (k == 1 && c.tune_fold_mode > 0) { quad = ((c.tune_fold_mode - 1) & 16) != 0; gs = (c.tune_fold_mode - 1) & 15; }
             if (c.tune_small == 2) quad = false;
             const uint64_t lanes = cap[k] * (uint64_t)gs * (quad ? 4 : 1);
