@@ -1130,6 +1130,41 @@ __global__ __launch_bounds__(64) void msm_precompute_kernel(const Affine* __rest
     }
 }
 
+// The same table for a small SRS in ONE launch: lane i walks point i through all W - 1 levels (c doublings each),
+// leaves the Jacobian-like values and their Z in place, and normalises its whole column with a single inversion.
+// The level-by-level kernel above needs one inversion per lane and LEVEL and has n / 16 lanes: at the prover's
+// n = 2^14 that is 31 launches of 1 ms; this one is ~3 ms in all.
+__global__ __launch_bounds__(64) void msm_precompute_column_kernel(Affine* __restrict__ table, Fp* __restrict__ tmp_z,
+                                                                   Fp* __restrict__ tmp_p, uint32_t n, int c, uint32_t W) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    XYZZ a = xyzz_from_affine(table[i]);                 // level 0 = the SRS itself
+    Fp prod = Fq::one();
+    for (uint32_t j = 1; j < W; ++j) {
+        for (int d = 0; d < c; ++d) a = xyzz_dbl(a);
+        Affine xy;
+        Fp z;
+        if (xyzz_is_inf(a)) { xy.x = Fq::zero(); xy.y = Fq::zero(); z = Fq::one(); }      // an infinity base stays infinity
+        else { xy.x = Fq::mul(a.x, a.zz); xy.y = Fq::mul(a.y, a.zzz); z = a.zz; }          // (X ZZ, Y ZZZ, Z = ZZ)
+        const size_t at = (size_t)j * n + i;
+        table[at] = xy;
+        tmp_z[at] = z;
+        tmp_p[at] = prod;                                // product of the z's of the earlier levels
+        prod = Fq::mul(prod, z);
+    }
+    Fp inv = fq_inv_pow(prod);
+    for (uint32_t j = W - 1; j >= 1; --j) {
+        const size_t at = (size_t)j * n + i;
+        const Fp zi = Fq::mul(inv, tmp_p[at]);           // 1 / z_j
+        inv = Fq::mul(inv, tmp_z[at]);
+        const Fp zi2 = Fq::sqr(zi);
+        Affine xy = table[at];
+        xy.x = Fq::mul(xy.x, zi2);
+        xy.y = Fq::mul(xy.y, Fq::mul(zi2, zi));
+        table[at] = xy;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host
 // ---------------------------------------------------------------------------------------------
@@ -1188,7 +1223,19 @@ int msm_build_table(Ctx& c, const Affine* d_points, size_t n, int cb, Affine** t
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&tz), n * sizeof(Fp));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&tp), n * sizeof(Fp));
     if (e == hipSuccess) e = hipMemcpyAsync(table, d_points, n * sizeof(Affine), hipMemcpyDeviceToDevice, c.stream);
-    if (e == hipSuccess) {
+    if (e == hipSuccess && n <= (1u << 16) && W > 1) {
+        // small SRS: whole columns in one launch (the scratch arrays then hold W * n elements each)
+        (void)hipFree(tz); (void)hipFree(tp); tz = tp = nullptr;
+        e = hipMalloc(reinterpret_cast<void**>(&tz), (size_t)W * n * sizeof(Fp));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&tp), (size_t)W * n * sizeof(Fp));
+        if (e == hipSuccess) {
+            KernelScope ks(c, "msm_precompute");
+            hipLaunchKernelGGL(msm_precompute_column_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c.stream, table, tz, tp,
+                               (uint32_t)n, cb, W);
+        }
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
+    } else if (e == hipSuccess) {
         const uint32_t threads = (uint32_t)((n + kPreRun - 1) / kPreRun);
         for (uint32_t j = 1; j < W; ++j) {
             KernelScope ks(c, "msm_precompute");
