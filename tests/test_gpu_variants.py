@@ -13,10 +13,11 @@ pytestmark = pytest.mark.gpu
 
 KNOBS = [
     {}, {"msm_acc_variant": 1}, {"msm_acc_variant": 2}, {"msm_sort_packed": 0}, {"msm_fused_hist": 0},
-    {"msm_scan_reduce": 0}, {"msm_scan_reduce": 2}, {"msm_reduce_seg": 4}, {"msm_task_len": 5}, {"msm_task_len": 300},
+    {"msm_quad_reduce": 0}, {"msm_scan_reduce": 0}, {"msm_scan_reduce": 2}, {"msm_scan_reduce": 3}, {"msm_scan_reduce": 3, "msm_reduce_seg": 16},
+    {"msm_scan_reduce": 3, "window_bits": 17}, {"msm_scan_reduce": 3, "window_bits": 9}, {"msm_reduce_seg": 4}, {"msm_task_len": 5}, {"msm_task_len": 300},
     {"msm_fold_group": 1}, {"msm_fold_group": 16}, {"window_bits": 9}, {"window_bits": 12}, {"window_bits": 16}, {"window_bits": 17},
 ]
-DEFAULTS = {"msm_small": 1, "msm_fold_mode": 0, "msm_acc_variant": 0, "msm_sort_packed": 1, "msm_fused_hist": 1, "msm_scan_reduce": 1, "msm_reduce_seg": 0,
+DEFAULTS = {"msm_small": 1, "msm_fold_mode": 0, "msm_acc_variant": 0, "msm_sort_packed": 1, "msm_fused_hist": 1, "msm_scan_reduce": 1, "msm_quad_reduce": 1, "msm_reduce_seg": 0,
             "msm_task_len": 0, "msm_fold_group": 0, "window_bits": 0}
 
 

@@ -53,8 +53,28 @@ __device__ __forceinline__ void xyzz_add_quad(XYZZ& acc, const XYZZ& p, uint32_t
     acc.zz = quad_bcast<2>(r3);
     acc.zzz = quad_bcast<3>(r4);
 }
+// 2 * a by the four lanes of a quad (dbl-2008-s-1), three product stages instead of nine products:
+//   stage 1: V = U^2 (U = 2Y) | X2 = X^2
+//   stage 2: W = U V | S = X V | MM = M^2 (M = 3 X2) | ZZ3 = V ZZ              X3 = MM - 2S
+//   stage 3: M (S - X3) | W Y | ZZZ3 = W ZZZ                                     Y3 = M (S - X3) - W Y
+__device__ __forceinline__ void xyzz_dbl_quad(XYZZ& a, uint32_t q) {
+    if (xyzz_is_inf(a)) return;
+    const Fp U = Fq::dbl(a.y);
+    const Fp r1 = Fq::mul(quad_sel(q, U, a.x, U, a.x), quad_sel(q, U, a.x, U, a.x));            // V | X2 | (V) | (X2)
+    const Fp V = quad_bcast<0>(r1), X2 = quad_bcast<1>(r1);
+    const Fp M = Fq::add(Fq::dbl(X2), X2);
+    const Fp r2 = Fq::mul(quad_sel(q, U, a.x, M, V), quad_sel(q, V, V, M, a.zz));                // W | S | MM | ZZ3
+    const Fp W = quad_bcast<0>(r2), S = quad_bcast<1>(r2), MM = quad_bcast<2>(r2);
+    const Fp X3 = Fq::sub(MM, Fq::dbl(S));
+    const Fp r3 = Fq::mul(quad_sel(q, M, W, W, W), quad_sel(q, Fq::sub(S, X3), a.y, a.zzz, a.zzz));   // T1 | T2 | ZZZ3 | (ZZZ3)
+    a.x = X3;
+    a.y = Fq::sub(quad_bcast<0>(r3), quad_bcast<1>(r3));
+    a.zz = quad_bcast<3>(r2);
+    a.zzz = quad_bcast<2>(r3);
+}
 #else
 __device__ void xyzz_add_quad(XYZZ& acc, const XYZZ& p, uint32_t q);
+__device__ void xyzz_dbl_quad(XYZZ& a, uint32_t q);
 #endif
 
 

@@ -853,6 +853,90 @@ __global__ __launch_bounds__(256) void msm_fold_scan_kernel(const XYZZ* __restri
     if (tid == 0) out[w] = sh[0];
 }
 
+// The two kernels above with one quad per lane-role (block 512 = 128 quads: no spills at 256 VGPRs, ecquad.hpp): the same identity, every
+// dependent addition / doubling at a quarter of its latency.  t = quad index in the workgroup.
+constexpr uint32_t kQuadLanes = 128;
+__device__ __forceinline__ void wgq_suffix_scan(XYZZ* sh, uint32_t t, uint32_t q, XYZZ& mine, uint32_t width) {
+    if (q == 0) sh[t] = mine;
+    __syncthreads();
+    for (uint32_t off = 1; off < width; off <<= 1) {
+        const bool has = t + off < kQuadLanes;
+        XYZZ v;
+        if (has) v = sh[t + off];
+        __syncthreads();
+        if (has) { xyzz_add_quad(mine, v, q); if (q == 0) sh[t] = mine; }
+        __syncthreads();
+    }
+}
+__device__ __forceinline__ void wgq_tree_sum(XYZZ* sh, uint32_t t, uint32_t q, XYZZ mine, uint32_t width) {
+    if (q == 0) sh[t] = mine;
+    __syncthreads();
+    for (uint32_t s = width >> 1; s > 0; s >>= 1) {
+        if (t < s) {
+            const XYZZ v = sh[t + s];
+            xyzz_add_quad(mine, v, q);
+            if (q == 0) sh[t] = mine;
+        }
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(kQuadLanes * 4) void msm_reduce_scan_quad_kernel(const XYZZ* __restrict__ buckets, XYZZ* __restrict__ part_p1,
+                                                                    XYZZ* __restrict__ part_r, uint32_t nbk,
+                                                                    uint32_t groups_per_window, uint32_t seg, uint32_t log_seg) {
+    __shared__ XYZZ sh[kQuadLanes];
+    const uint32_t w = blockIdx.y, t = threadIdx.x >> 2, q = threadIdx.x & 3;
+    const uint32_t g = blockIdx.x * kQuadLanes + t;
+    const XYZZ* bw = buckets + (size_t)w * nbk;
+    XYZZ run = xyzz_inf(), acc = xyzz_inf();
+    const uint64_t lo64 = (uint64_t)g * seg;
+    if (lo64 < nbk) {
+        const uint32_t lo = (uint32_t)lo64;
+        const uint32_t hi = min(nbk, lo + seg);
+        for (uint32_t idx = hi; idx-- > lo;) {
+            const XYZZ bk = bw[idx];
+            xyzz_add_quad(run, bk, q);
+            xyzz_add_quad(acc, run, q);
+        }
+    }
+    const uint64_t lanes_w = ((uint64_t)nbk + seg - 1) / seg;
+    const uint64_t mine_first = (uint64_t)blockIdx.x * kQuadLanes;
+    const uint32_t active = lanes_w > mine_first ? (uint32_t)min((uint64_t)kQuadLanes, lanes_w - mine_first) : 1u;
+    uint32_t width = 1;
+    while (width < active) width <<= 1;
+    XYZZ suf = run;
+    wgq_suffix_scan(sh, t, q, suf, width);
+    XYZZ above = (t + 1 < kQuadLanes) ? sh[t + 1] : xyzz_inf();
+    const XYZZ total = sh[0];
+    __syncthreads();
+    for (uint32_t d = 0; d < log_seg; ++d) xyzz_dbl_quad(above, q);
+    xyzz_add_quad(acc, above, q);
+    wgq_tree_sum(sh, t, q, acc, width);
+    if (threadIdx.x == 0) {
+        part_p1[(size_t)w * groups_per_window + blockIdx.x] = sh[0];
+        part_r[(size_t)w * groups_per_window + blockIdx.x] = total;
+    }
+}
+__global__ __launch_bounds__(kQuadLanes * 4) void msm_fold_scan_quad_kernel(const XYZZ* __restrict__ part_p1, const XYZZ* __restrict__ part_r,
+                                                                  XYZZ* __restrict__ out, uint32_t groups, uint32_t log_shift) {
+    __shared__ XYZZ sh[kQuadLanes];
+    const uint32_t w = blockIdx.x, t = threadIdx.x >> 2, q = threadIdx.x & 3;
+    XYZZ r = t < groups ? part_r[(size_t)w * groups + t] : xyzz_inf();
+    XYZZ p1 = t < groups ? part_p1[(size_t)w * groups + t] : xyzz_inf();
+    uint32_t width = 1;
+    while (width < groups) width <<= 1;
+    if (groups > 1) {
+        wgq_suffix_scan(sh, t, q, r, width);
+        XYZZ above = (t + 1 < kQuadLanes) ? sh[t + 1] : xyzz_inf();
+        __syncthreads();
+        if (!xyzz_is_inf(above)) {
+            for (uint32_t d = 0; d < log_shift; ++d) xyzz_dbl_quad(above, q);
+            xyzz_add_quad(p1, above, q);
+        }
+    }
+    wgq_tree_sum(sh, t, q, p1, width);
+    if (threadIdx.x == 0) out[w] = sh[0];
+}
+
 // ---- small problems (n <= 2^15): one workgroup per (vector, window) slot ---------------------------
 // The prover's real size is n = 2^14: the general pipeline above spends 17 launches and a
 // host round trip on it.  Here a slot's whole sort -- histogram, prefixes, scatter, the task table and the
@@ -1272,7 +1356,8 @@ struct MsmGroup {
     uint64_t per_poly = 0, entries = 0, TBK = 0, bound0 = 0, part_cap = 0;
     uint32_t kb = 0, NBL = 0, S0 = 0, seg_n = 0, NB = 0, Wd = 0, RW = 0, seg = 0, groups = 0, L = 0;
     int P = 0;
-    bool scan_reduce = false;
+    bool scan_reduce = false, quad_reduce = false;
+    uint32_t rl = 256;                                      // reduction lanes (quads) per workgroup
     uint32_t pk_bits = 0;   // > 0: 4-byte packed entries between the two sort passes (index bits)
     SortPass sp[kMaxPasses];
     // state carried from phase 1 to phase 2
@@ -1296,18 +1381,30 @@ static int msm_group_plan(Ctx& c, MsmGroup& g, size_t n, uint32_t batch, int cb,
     if (g.Wd > 1024) { set_error("msm: too many bucket windows (%u): lower the batch", g.Wd); return UZK_ERR_PARAMETER; }
     g.RW = pre ? batch : batch * W;                         // logical windows in the reduction
     // scan-based reduction: segments of 8 buckets per lane (power of two), at most 256 workgroups per window
-    // (measured: the scan form wins for windows of <= 2^14 buckets, the double-and-add form above that)
-    g.scan_reduce = c.tune_scan_reduce == 2 || (c.tune_scan_reduce == 1 && g.NBL <= (1u << 14));
+    // (measured: the scan form wins for windows of <= 2^14 buckets, the double-and-add form above that).
+    // Up to 2^19 buckets in all, the scans run on quads (ecquad.hpp): segments of <= 16 buckets, one quad each, still
+    // fit the chip at two waves per SIMD (32768 quads), and every dependent addition takes half the time -- reduce
+    // 0.16 -> 0.09 ms at n = 2^16, 0.55 -> 0.35 ms at 2^19; beyond that the segments get long or the quads queue behind
+    // each other, and the lane form is as fast (measured at 2^20 and 2^24: 0.59 vs 0.61 ms at best).
+    const uint64_t total_buckets = (uint64_t)g.RW * g.NBL;
+    const bool auto_quad = c.tune_scan_reduce == 1 && c.tune_quad_reduce && total_buckets <= (1u << 19);
+    g.quad_reduce = c.tune_scan_reduce == 3 || auto_quad;
+    g.scan_reduce = c.tune_scan_reduce >= 2 || g.quad_reduce || (c.tune_scan_reduce == 1 && g.NBL <= (1u << 14));
     if (g.scan_reduce) {
         uint32_t sg = c.tune_reduce_seg > 0 ? (uint32_t)c.tune_reduce_seg : 8u;
+        if (g.quad_reduce && c.tune_reduce_seg <= 0) {
+            sg = 1;
+            while ((uint64_t)sg * 32768 < total_buckets) sg <<= 1;
+        }
         while (sg & (sg - 1)) sg &= sg - 1;                                  // power of two
-        sg = std::max<uint32_t>(1, std::min<uint32_t>(sg, g.NBL / 256));
-        while ((g.NBL + sg * 256 - 1) / (sg * 256) > 256) sg <<= 1;
+        g.rl = g.quad_reduce ? kQuadLanes : 256u;
+        sg = std::max<uint32_t>(1, std::min<uint32_t>(sg, g.NBL / g.rl));
+        while ((g.NBL + sg * g.rl - 1) / (sg * g.rl) > g.rl) sg <<= 1;
         g.seg = sg;
     } else {
         g.seg = std::max<uint32_t>(1, std::min<uint32_t>(c.tune_reduce_seg > 0 ? (uint32_t)c.tune_reduce_seg : kSeg, g.NBL / 256));
     }
-    g.groups = (g.NBL + g.seg * 256 - 1) / (g.seg * 256);
+    g.groups = (g.NBL + g.seg * g.rl - 1) / (g.seg * g.rl);
     const uint64_t all_entries = (uint64_t)W_total * n * batch;
     // Task length: long enough that a typical bucket (4x the mean population) is ONE task -- its partial
     // sum then needs no folding -- but short enough that there are >= ~200k tasks to fill the chip
@@ -1593,10 +1690,17 @@ static int msm_group_phase2(Ctx& c, MsmGroup& g) {
             XYZZ* part_r = partials + (size_t)g.RW * g.groups;
             uint32_t log_seg = 0;
             while ((1u << log_seg) < g.seg) ++log_seg;
-            hipLaunchKernelGGL(msm_reduce_scan_kernel, dim3(g.groups, g.RW), dim3(256), 0, st, buckets, partials, part_r, g.NBL,
-                               g.groups, g.seg, log_seg);
-            hipLaunchKernelGGL(msm_fold_scan_kernel, dim3(g.RW), dim3(256), 0, st, partials, part_r, win_sums, g.groups,
-                               8 + log_seg);
+            if (g.quad_reduce) {
+                hipLaunchKernelGGL(msm_reduce_scan_quad_kernel, dim3(g.groups, g.RW), dim3(kQuadLanes * 4), 0, st, buckets, partials, part_r,
+                                   g.NBL, g.groups, g.seg, log_seg);
+                hipLaunchKernelGGL(msm_fold_scan_quad_kernel, dim3(g.RW), dim3(kQuadLanes * 4), 0, st, partials, part_r, win_sums, g.groups,
+                                   7 + log_seg);
+            } else {
+                hipLaunchKernelGGL(msm_reduce_scan_kernel, dim3(g.groups, g.RW), dim3(256), 0, st, buckets, partials, part_r, g.NBL,
+                                   g.groups, g.seg, log_seg);
+                hipLaunchKernelGGL(msm_fold_scan_kernel, dim3(g.RW), dim3(256), 0, st, partials, part_r, win_sums, g.groups,
+                                   8 + log_seg);
+            }
         } else {
             hipLaunchKernelGGL(msm_reduce_kernel, dim3(g.groups, g.RW), dim3(256), 0, st, buckets, partials, g.NBL, g.groups, g.seg);
             hipLaunchKernelGGL(msm_fold_partials_kernel, dim3(g.RW), dim3(256), 0, st, partials, win_sums, g.groups);
