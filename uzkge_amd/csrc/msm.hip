@@ -1263,7 +1263,7 @@ static int choose_window_bits(size_t n, int forced) {
     while ((1ull << (lg + 1)) <= n) ++lg;
     if (lg <= 17) return 8;
     if (lg == 18) return 15;
-    if (lg == 19) return 16;
+    if (lg <= 21) return 16;                 // 2^19 buckets: the reduction still runs on quads (msm_group_plan)
     return 17;
 }
 int msm_precompute_window_bits(size_t n, int forced) {
