@@ -22,6 +22,7 @@ of the same workload on this node's host cores.
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -228,10 +229,16 @@ def run_rank(args) -> None:
             dist.init_process_group("gloo")
         dry_run_rank(args, rank, world, dist, np)
         return
+    # UZK_BENCH_FORCE_DIST=1: a single rank still joins a process group and runs the collective (RCCL world of one):
+    # the exchange path can be exercised on a one-GPU box
+    use_dist = world > 1 or os.environ.get("UZK_BENCH_FORCE_DIST") == "1"
+    if use_dist and world == 1:
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
     ndev = max(torch.cuda.device_count(), 1)
     dev_index = local_rank if backend == "nccl" else local_rank % ndev
     torch.cuda.set_device(dev_index)
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist  # type: ignore
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -276,7 +283,7 @@ def run_rank(args) -> None:
         # the rank's partial sum arrives in host memory (the window sums are combined there); the exchange is
         # the 96-byte all-gather over RCCL / xGMI and every rank folds the N partials
         part = b.msm_device(srs, sc.data_ptr(), n)
-        if world == 1:
+        if not use_dist:
             return part
         gather_in.copy_(torch.from_numpy(part.view(np.uint8)))
         dist.all_gather_into_tensor(gather_out, gather_in)
@@ -286,7 +293,7 @@ def run_rank(args) -> None:
     def fence():
         b.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         b.sync()
         torch.cuda.synchronize()
@@ -299,7 +306,7 @@ def run_rank(args) -> None:
             res = fn()
         fence()
         el = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             t = torch.tensor([el], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
@@ -319,7 +326,7 @@ def run_rank(args) -> None:
     # which devices the ranks really ran on (so the record shows N distinct GPUs behind the collective)
     dev_ids = [dev_index]
     dev_uuids = [str(getattr(torch.cuda.get_device_properties(dev_index), "uuid", ""))]
-    if world > 1:
+    if use_dist:
         objs = [None] * world
         dist.all_gather_object(objs, (dev_index, dev_uuids[0]))
         dev_ids = [o[0] for o in objs]
@@ -507,11 +514,12 @@ def run_rank(args) -> None:
             ent = {"msm_host_scalars_ms": round(pc_s * 1e3, 3), "msm_points_per_sec": n / pc_s,
                    "what": "uzk_msm_g1 / uzk_ntt_fr with pageable host buffers: upload + compute + download inside the call"}
             if "ntt" in extra:
-                hx = x.cpu().numpy().view(np.uint64).reshape(-1, 4)
-                b.ntt(hx[:4096])
+                hx = np.ascontiguousarray(x.cpu().numpy().view(np.uint64).reshape(-1, 4))
+                b.ntt_inplace(hx)                    # uzk_ntt_fr transforms the caller's vector in place
                 t = time.perf_counter()
-                b.ntt(hx)
-                ent["ntt_host_vector_ms"] = round((time.perf_counter() - t) * 1e3, 3)
+                b.ntt_inplace(hx, inverse=True)
+                b.ntt_inplace(hx)
+                ent["ntt_host_vector_ms"] = round((time.perf_counter() - t) * 1e3 / 2, 3)
                 del hx
             extra["pcie_inclusive"] = ent
             del hs
@@ -632,15 +640,16 @@ def run_rank(args) -> None:
                                    f"bases resident in HBM" + (f" (2^{args.total_log_n} points in total)" if strong else ""),
                        "points_per_gpu": n, "total_points": n * world,
                        "sharding": "point-chunk per rank, all-gather of 96-byte partial sums, host fold" if world > 1 else "single GPU"},
-            "dist_world_size": dist.get_world_size() if world > 1 else 1,
-            "collective_backend": (dist.get_backend() if world > 1 else None),
+            "dist_world_size": dist.get_world_size() if use_dist else 1,
+            "collective_backend": (dist.get_backend() if use_dist else None),
             "device_ids": dev_ids, "device_uuids": dev_uuids,
             "roofline": roofline, "cpu_baseline": cpu_baseline, "extra": extra,
             "result_is_infinity": bool(not result[8:12].any()),
+            "result_affine_sha256": hashlib.sha256(np.ascontiguousarray(b.g1_to_affine(result)).tobytes()).hexdigest()[:16],
         }
         print(json.dumps(line))
     srs.release()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -231,4 +231,44 @@ struct ProverCommit {
     }
 };
 
+// The per-table loop of the preprocessing -- indexer_with_lagrange (uzkge/src/plonk/indexer.rs:316-470) and
+// refresh_prover_params_public_key (shuffle/src/gen_params/params.rs:88-121): for each evaluation table
+//   coefs = ifft_with_domain(domain_n, evals), coset_evals = coefs.coset_fft_with_domain(domain_m, k[1]),
+//   cm = commit(evals, coefs)   (no blinds)
+// with all tables in one batched inverse transform, one batched coset transform and one batched MSM.
+struct PreprocessedTables {
+    std::vector<std::vector<Fr>> coefs;          // k x n   (untrimmed, as the quotient kernel wants them)
+    std::vector<std::vector<Fr>> coset_evals;    // k x m
+    std::vector<G1Projective> cms;               // k
+};
+inline PreprocessedTables preprocess_tables(const ProverCommit& commit, const std::vector<std::vector<Fr>>& evals, size_t m, const Fr& k1) {
+    PreprocessedTables out;
+    const size_t k = evals.size(), n = commit.n_constraints;
+    if (k == 0) return out;
+    if (m % n != 0) throw UzkgeException(UzkgeError::ParameterError, "the quotient domain must be a multiple of n");
+    if (!uzk_domain_supported(n) || !uzk_domain_supported(m)) throw UzkgeException(UzkgeError::FFTError, "no evaluation domain of that size");
+    std::vector<Fr> flat(k * n), wide(k * m);
+    for (size_t i = 0; i < k; ++i) {
+        if (evals[i].size() != n) throw UzkgeException(UzkgeError::ParameterError, "every table has n_constraints rows");
+        std::copy(evals[i].begin(), evals[i].end(), flat.begin() + i * n);
+    }
+    out.cms.resize(k);
+    if (commit.lagrange_pcs)
+        check(uzk_msm_g1_batch(commit.lagrange_pcs->handle(), 0, reinterpret_cast<const uint64_t*>(flat.data()), n, (uint32_t)k, out.cms.data()));
+    check(uzk_ntt_fr_batch(reinterpret_cast<uint64_t*>(flat.data()), n, (uint32_t)k, /*inverse*/ 1, nullptr));
+    if (!commit.lagrange_pcs) {
+        if (n > commit.pcs.public_parameter_group_1.size()) throw UzkgeException(UzkgeError::DegreeError, "degree exceeds the SRS");
+        check(uzk_msm_g1_batch(commit.pcs.handle(), 0, reinterpret_cast<const uint64_t*>(flat.data()), n, (uint32_t)k, out.cms.data()));
+    }
+    for (size_t i = 0; i < k; ++i) std::copy(flat.begin() + i * n, flat.begin() + (i + 1) * n, wide.begin() + i * m);
+    check(uzk_ntt_fr_batch(reinterpret_cast<uint64_t*>(wide.data()), m, (uint32_t)k, /*inverse*/ 0, k1.l));
+    out.coefs.resize(k);
+    out.coset_evals.resize(k);
+    for (size_t i = 0; i < k; ++i) {
+        out.coefs[i].assign(flat.begin() + i * n, flat.begin() + (i + 1) * n);
+        out.coset_evals[i].assign(wide.begin() + i * m, wide.begin() + (i + 1) * m);
+    }
+    return out;
+}
+
 }  // namespace uzkge

@@ -126,6 +126,29 @@ int main(int argc, char** argv) {
         ProverCommit with(*mono, &lag, N), without(*mono, nullptr, N), wrong(*mono, &lag, N / 2);
         EXPECT(with.lagrange_pcs == &lag && without.lagrange_pcs == nullptr && wrong.lagrange_pcs == nullptr);
         EXPECT(same_point(with(evals, p_low, {}), without(evals, p_low, {})));
+
+        // preprocessing loop (indexer.rs:316-470, params.rs:88-121): batched tables == the single calls, on both branches
+        std::vector<std::vector<Fr>> tables;
+        for (int t = 0; t < 3; ++t) {
+            std::vector<Fr> c(2051);
+            for (auto& x : c) x = rand_fr(g);
+            if (t == 2) std::fill(c.begin(), c.end(), Fr{});                 // an all-zero table (unused selector)
+            tables.push_back(*FpPolynomial::from_coefs(c).fft(N));
+        }
+        const Fr k1 = fr_from_u64(7);
+        const size_t M = 2 * N;
+        auto pre_l = preprocess_tables(with, tables, M, k1);
+        auto pre_m = preprocess_tables(without, tables, M, k1);
+        EXPECT(pre_l.cms.size() == 3 && pre_m.cms.size() == 3);
+        for (int t = 0; t < 3; ++t) {
+            auto coefs = FpPolynomial::ifft_with_domain(N, tables[t]);
+            std::vector<Fr> padded(coefs.coefs);
+            padded.resize(N, Fr{});
+            EXPECT(pre_l.coefs[t] == padded && pre_m.coefs[t] == padded);
+            EXPECT(pre_l.coset_evals[t] == coefs.coset_fft_with_domain(M, k1) && pre_m.coset_evals[t] == pre_l.coset_evals[t]);
+            EXPECT(same_point(pre_l.cms[t], with(tables[t], coefs, {})));
+            EXPECT(same_point(pre_m.cms[t], pre_l.cms[t]));                     // Lagrange commit == monomial commit (reference SRS files)
+        }
     }
 
     std::printf(failures ? "FAILED (%d)\n" : "OK\n", failures);

@@ -157,3 +157,39 @@ def test_batch_prove_lagrange_chain_matches_oracle_chain(schemes):
         want = opy.g1_add(want, opy.g1_mul(srs[i], blind))
         want = opy.g1_add(want, opy.g1_mul(srs[2 + i], (-blind) % opy.R))
     assert affine_of(cm) == want
+
+
+def test_preprocess_tables_matches_single_calls_and_oracle(schemes):
+    """indexer_with_lagrange's table loop (indexer.rs:316-470) / refresh_prover_params_public_key (params.rs:88-121):
+    the batched device-resident form gives, per table, the oracle's inverse transform, the oracle's coset evaluations
+    over the 6n domain, and on BOTH branches of the commit closure the same group element (Lagrange SRS file vs
+    monomial SRS file: pinned on reference data)."""
+    from uzkge_amd.poly_commit import ProverCommit, preprocess_tables
+    n, pcs, lag = schemes
+    m = 6 * n
+    k1 = rand_fr_wire(1, 77)[0]
+    coefs = np.zeros((4, n, 4), dtype=np.uint64)
+    coefs[0, :2051] = rand_fr_wire(2051, 31)
+    coefs[1, :5] = rand_fr_wire(5, 32)
+    coefs[3, :2051] = rand_fr_wire(2051, 33)                   # table 2 stays all-zero (an unused selector)
+    evals = np.stack([oc.ntt(c) for c in coefs])
+    with_l, without = ProverCommit(pcs, lag, n), ProverCommit(pcs, None, n)
+    p_l, c_l, cm_l = preprocess_tables(with_l, evals, m, k1)
+    p_m, c_m, cm_m = preprocess_tables(without, evals, m, k1)
+    assert np.array_equal(p_l, coefs) and np.array_equal(p_m, coefs)
+    for t in range(4):
+        wide = np.zeros((m, 4), dtype=np.uint64)
+        wide[:n] = oc.mul_var(coefs[t], k1)
+        want = oc.ntt(wide, threads=4)
+        assert np.array_equal(c_l[t], want) and np.array_equal(c_m[t], want)
+        a = affine_of(cm_l[t])
+        assert a == affine_of(cm_m[t])
+        assert a == affine_of(oc.msm_pippenger(pcs.public_parameter_group_1[:n], coefs[t], 0, 4))
+    assert affine_of(cm_l[2]) is None
+    # device-resident form: the same tables stay in HBM for the quotient kernel
+    dp, dc, cms = preprocess_tables(with_l, evals, m, k1, keep_on_device=True)
+    assert dp.is_cuda and dc.is_cuda and tuple(dc.shape) == (4, m, 4)
+    assert np.array_equal(dc.cpu().numpy().view(np.uint64), c_l)
+    assert [affine_of(x) for x in cms] == [affine_of(x) for x in cm_l]       # Jacobian coordinates depend on the addition order
+    with pytest.raises(Exception):
+        preprocess_tables(with_l, evals[:, : n // 2], m, k1)

@@ -156,6 +156,15 @@ def ntt(data: np.ndarray, inverse: bool = False, coset_shift: Optional[np.ndarra
     return a
 
 
+def ntt_inplace(a: np.ndarray, inverse: bool = False, coset_shift: Optional[np.ndarray] = None) -> None:
+    """uzk_ntt_fr as the C ABI defines it: `a` ([n,4] u64, C-contiguous) is transformed in place (no copy here)."""
+    assert a.dtype == np.uint64 and a.flags.c_contiguous and a.ndim == 2 and a.shape[1] == 4
+    cs = None
+    if coset_shift is not None:
+        cs = np.ascontiguousarray(coset_shift, dtype=np.uint64).reshape(4)
+    check(lib.uzk_ntt_fr(_ptr(a), a.shape[0], int(inverse), _ptr(cs) if cs is not None else None))
+
+
 def ntt_batch(data: np.ndarray, inverse: bool = False, coset_shift: Optional[np.ndarray] = None) -> np.ndarray:
     """`data` [batch, n, 4]: batch independent transforms of size n in one call."""
     a = np.ascontiguousarray(data, dtype=np.uint64).copy()

@@ -338,6 +338,45 @@ class ProverCommit:
         return self.pcs.commit(coef_polynomial)
 
 
+def preprocess_tables(commit: ProverCommit, evals: np.ndarray, m: int, k1: np.ndarray, keep_on_device: bool = False):
+    """The per-table loop of the preprocessing -- indexer_with_lagrange (uzkge/src/plonk/indexer.rs:316-470: the
+    permutation, selector, boolean, Anemoi, ecc and shuffle tables) and refresh_prover_params_public_key
+    (shuffle/src/gen_params/params.rs:88-121) -- for a stack `evals` [k, n, 4] of evaluation tables:
+        coefs_i      = FpPolynomial::ifft_with_domain(domain_n, evals_i)
+        coset_evals_i = coefs_i.coset_fft_with_domain(domain_m, k[1])
+        cm_i         = commit(evals_i, coefs_i)        (the closure without blinds, indexer.rs:284-299)
+    All k tables go through ONE batched inverse transform, ONE batched coset transform on the m-domain and ONE batched
+    MSM; the tables cross PCIe once.  Returns (coefs [k, n, 4], coset_evals [k, m, 4], cms [k, 12]); with
+    `keep_on_device` the first two are int64 CUDA tensors (the quotient kernel's resident inputs, uzk_t_quotient_device)
+    instead of host arrays."""
+    import torch
+    ev_h = np.ascontiguousarray(evals, dtype=np.uint64)
+    assert ev_h.ndim == 3 and ev_h.shape[2] == 4
+    k, n = ev_h.shape[0], ev_h.shape[1]
+    if n != commit.n_constraints or m % n != 0:
+        raise UzkgeError(N.UZK_ERR_PARAMETER, "tables must have n_constraints rows and the quotient domain must be a multiple of n")
+    if not (B.domain_supported(n) and B.domain_supported(m)):
+        raise UzkgeError(N.UZK_ERR_FFT, "no evaluation domain of that size")
+    ev = torch.from_numpy(ev_h.view(np.int64)).cuda()
+    coefs = torch.empty_like(ev)
+    coset = torch.zeros((k, m, 4), dtype=torch.int64, device=ev.device)
+    torch.cuda.synchronize()                       # the library runs on its own stream
+    B.ntt_batch_device(ev.data_ptr(), coefs.data_ptr(), n, k, inverse=True, sync=True)
+    coset[:, :n] = coefs
+    torch.cuda.synchronize()
+    B.ntt_batch_device(coset.data_ptr(), coset.data_ptr(), m, k, coset_shift=k1)
+    if commit.lagrange_pcs is not None:
+        cms = B.msm_batch_device(commit.lagrange_pcs._srs, ev.data_ptr(), n, k)
+    else:
+        if n > commit.pcs.public_parameter_group_1.shape[0]:
+            raise UzkgeError(N.UZK_ERR_DEGREE, "polynomial degree exceeds the SRS")
+        cms = B.msm_batch_device(commit.pcs._srs, coefs.data_ptr(), n, k)
+    B.sync()
+    if keep_on_device:
+        return coefs, coset, cms
+    return (coefs.cpu().numpy().view(np.uint64), coset.cpu().numpy().view(np.uint64), cms)
+
+
 def hide_polynomial(polynomial: FpPolynomial, blinds: np.ndarray, zeroing_degree: int) -> FpPolynomial:
     """helpers.rs:139-158 with the random blinds given: adds (b_0 + b_1 X + ...) * (X^zeroing_degree - 1)."""
     b = np.ascontiguousarray(blinds, dtype=np.uint64).reshape(-1, 4)
