@@ -19,9 +19,9 @@ cases = int(os.environ.get("CASES", "150"))
 one = oc.fr_from_ints([1])[0]; rm1 = oc.fr_from_ints([opy.R - 1])[0]
 bad = 0
 for t in range(cases):
-    n = rng.choice([1, 2, 3, 17, 64, 255, 1000, 4096, 9000, 16384])
-    n = min(n, 16384)
-    idx = nrng.integers(0, 16384, n)
+    n = rng.choice([1, 2, 3, 17, 64, 255, 1000, 4096, 9000, 16384, 16384, 40000, 1 << 16, 100000, 1 << 17, 1 << 18])
+    if int(os.environ.get("MAX_N", "0")): n = min(n, int(os.environ["MAX_N"]))
+    idx = nrng.integers(0, 16384, n)                                # sizes above 2^14 draw with repetition: the general pipeline with duplicate bases
     mode = rng.randrange(5)
     if mode == 1: idx[:] = idx[0]                                  # one point repeated
     elif mode == 2: idx = idx[nrng.integers(0, max(1, n // 8), n)]  # few distinct points
@@ -40,6 +40,7 @@ for t in range(cases):
     elif smode == 3: sc[:] = sc[0]                                  # identical scalars (with repeated points: doublings)
     elif smode == 4: sc[nrng.integers(0, 2, n) == 1] = 0
     c = rng.choice([0, 0, 0, 4, 5, 7, 8, 9, 10, 11, 13, 16, 17])
+    b.tune("msm_quad_reduce", rng.choice([1, 1, 0])); b.tune("msm_scan_reduce", rng.choice([1, 1, 1, 0, 2, 3]))
     b.set_msm_window_bits(c)
     b.tune("msm_small", rng.choice([1, 1, 1, 2, 0]))               # small pipeline (quads / plain lanes) or the general one
     b.tune("msm_task_len", rng.choice([0, 0, 2, 3, 40]))
@@ -55,6 +56,6 @@ for t in range(cases):
     if oc.jac_to_affine_ints(got) != oc.jac_to_affine_ints(want):
         bad += 1
         print(f"MISMATCH case {t}: n={n} mode={mode} smode={smode} c={c}", flush=True)
-b.set_msm_window_bits(0); b.tune("msm_small", 1); b.tune("msm_task_len", 0)
+b.set_msm_window_bits(0); b.tune("msm_small", 1); b.tune("msm_task_len", 0); b.tune("msm_quad_reduce", 1); b.tune("msm_scan_reduce", 1)
 print(f"{cases} cases, {bad} mismatches")
 sys.exit(1 if bad else 0)

@@ -1787,13 +1787,13 @@ HornerPool& horner_pool() {
 // Host: per scalar vector, Horner over its W window sums (c doublings per step).
 template <class WindowSum>
 static void msm_horner_host(Ctx& c, uint32_t batch, uint32_t wpp, int cb, const WindowSum& window_sum, Jac* out_host) {
-    // 4 x 64-bit host arithmetic, Jacobian doublings (host_ec64.hpp): 58 -> 28 us for the 32 windows of a 2^14-point commit
+    // 4 x 64-bit host arithmetic, Jacobian doublings (host_ec64.hpp): 57 -> 37 us for the 32 windows of a 2^14-point commit
     auto horner = [&](uint32_t b) {
         out_host[b] = h64::horner(wpp, cb, [&](uint32_t w) -> const XYZZ& { return window_sum(b, w); });
     };
     HostScope hs_horner(c, "host_msm_horner");
     if (batch > 1 && wpp > 1) {
-        // 254 dependent doublings per vector: ~0.06 ms each on one core, so spread the vectors over the pool
+        // 254 dependent doublings per vector: ~0.04 ms each on one core, so spread the vectors over the pool
         const std::function<void(uint32_t)> job = [&](uint32_t b) { horner(b); };
         horner_pool().run(batch, job);
     } else {
