@@ -45,6 +45,7 @@ int main() {
         const Fp a = rand_fq(g), b = rand_fq(g);
         const h64::F x = h64::from_fp(a), y = h64::from_fp(b);
         EXPECT(Fq::eq(h64::to_fp(h64::mul(x, y)), Fq::mul(a, b)));
+        EXPECT(Fq::eq(h64::to_fp(h64::mul_portable(x, y)), Fq::mul(a, b)));
         EXPECT(Fq::eq(h64::to_fp(h64::add(x, y)), Fq::add(a, b)));
         EXPECT(Fq::eq(h64::to_fp(h64::sub(x, y)), Fq::sub(a, b)));
         EXPECT(Fq::eq(h64::to_fp(h64::sub(y, x)), Fq::sub(b, a)));
@@ -57,6 +58,19 @@ int main() {
             EXPECT(Fq::eq(h64::to_fp(h64::sub(h64::from_fp(a), h64::from_fp(b))), Fq::sub(a, b)));
         }
     }
+#if defined(__x86_64__) && !defined(UZK_HOST_NO_ADX)
+    std::printf("mulx/adx product: %s\n", h64::cpu_has_adx() ? "in use" : "CPU lacks BMI2/ADX, portable product in use");
+    if (h64::cpu_has_adx()) {           // values near the modulus: the largest intermediate sums
+        Fp m1 = Fq::neg(Fq::one()), m2 = Fq::neg(Fq::dbl(Fq::one()));
+        for (const Fp& a : {m1, m2}) for (const Fp& b : {m1, m2})
+            EXPECT(Fq::eq(h64::to_fp(h64::mul_adx(h64::from_fp(a), h64::from_fp(b))), Fq::mul(a, b)));
+        for (int t = 0; t < 20000; ++t) {
+            Fp a = rand_fq(g), b = rand_fq(g);
+            if (t & 1) a = Fq::neg(a);
+            EXPECT(Fq::eq(h64::to_fp(h64::mul_adx(h64::from_fp(a), h64::from_fp(b))), Fq::mul(a, b)));
+        }
+    }
+#endif
     Affine G;
     G.x = Fq::one();
     G.y = Fq::dbl(Fq::one());                                   // (1, 2)

@@ -8,6 +8,9 @@
 // Host code only: nothing here is compiled for the device.
 #pragma once
 #include <cstring>
+#if defined(__x86_64__)
+#include <cpuid.h>
+#endif
 
 #include "ec.hpp"
 
@@ -69,8 +72,8 @@ inline F sub(const F& a, const F& b) {
     return d;
 }
 inline F dbl(const F& a) { return add(a, a); }
-// Montgomery product a b 2^-256 mod M (CIOS over 64-bit words)
-inline F mul(const F& a, const F& b) {
+// Montgomery product a b 2^-256 mod M (CIOS over 64-bit words), portable form
+inline F mul_portable(const F& a, const F& b) {
     constexpr uint64_t m[4] = {M0, M1, M2, M3};
     uint64_t t[6] = {0, 0, 0, 0, 0, 0};
     for (int i = 0; i < 4; ++i) {
@@ -84,6 +87,31 @@ inline F mul(const F& a, const F& b) {
     }
     return reduce_once(F{{t[0], t[1], t[2], t[3]}});
 }
+#if defined(__x86_64__) && !defined(UZK_HOST_NO_ADX)
+// The same product as one mulx / adcx / adox block (generated: host_mul_adx.inc), taken when the CPU has BMI2 and ADX.
+#include "host_mul_adx.inc"
+__attribute__((target("bmi2,adx"))) inline F mul_adx(const F& a, const F& b) {
+    static const uint64_t q[4] = {M0, M1, M2, M3};
+    static const uint64_t inv = INV64;
+    uint64_t z0, z1, z2, z3, z4, lo, hi;
+    asm(UZK_HOST_MUL_ADX_ASM
+        : [z0] "=&r"(z0), [z1] "=&r"(z1), [z2] "=&r"(z2), [z3] "=&r"(z3), [z4] "=&r"(z4), [lo] "=&r"(lo), [hi] "=&r"(hi)
+        : [a] "r"(a.l), [b] "r"(b.l), [q] "r"(q), [inv] "m"(inv), "m"(a), "m"(b), "m"(q)
+        : "rax", "rdx", "cc");
+    return reduce_once(F{{UZK_HOST_MUL_ADX_RESULT}});
+}
+inline bool cpu_has_adx() {
+    static const bool v = [] {
+        unsigned a = 0, b = 0, c = 0, d = 0;
+        if (!__get_cpuid_count(7, 0, &a, &b, &c, &d)) return false;
+        return ((b >> 8) & 1) != 0 && ((b >> 19) & 1) != 0;          // CPUID.(EAX=7,ECX=0):EBX bit 8 = BMI2, bit 19 = ADX
+    }();
+    return v;
+}
+inline F mul(const F& a, const F& b) { return cpu_has_adx() ? mul_adx(a, b) : mul_portable(a, b); }
+#else
+inline F mul(const F& a, const F& b) { return mul_portable(a, b); }
+#endif
 inline F sqr(const F& a) { return mul(a, a); }
 
 struct J {          // Jacobian (X/Z^2, Y/Z^3); infinity <=> Z == 0

@@ -1787,7 +1787,7 @@ HornerPool& horner_pool() {
 // Host: per scalar vector, Horner over its W window sums (c doublings per step).
 template <class WindowSum>
 static void msm_horner_host(Ctx& c, uint32_t batch, uint32_t wpp, int cb, const WindowSum& window_sum, Jac* out_host) {
-    // 4 x 64-bit host arithmetic, Jacobian doublings (host_ec64.hpp): 57 -> 37 us for the 32 windows of a 2^14-point commit
+    // 4 x 64-bit host arithmetic, Jacobian doublings (host_ec64.hpp): 57 -> 32 us for the 32 windows of a 2^14-point commit
     auto horner = [&](uint32_t b) {
         out_host[b] = h64::horner(wpp, cb, [&](uint32_t w) -> const XYZZ& { return window_sum(b, w); });
     };
