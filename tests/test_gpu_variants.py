@@ -65,8 +65,12 @@ def test_ntt_variants_agree(gpu, n):
             gpu.tune("ntt_l29", 0); gpu.ntt_device(x.data_ptr(), a.data_ptr(), n, inverse=inv, sync=True)
             gpu.tune("ntt_l29", 1); gpu.ntt_device(x.data_ptr(), b_.data_ptr(), n, inverse=inv, sync=True)
             assert torch.equal(a, b_)
+            for tile in (1024, 2048):      # both workgroup tile sizes of the pass kernels (0 = chosen by size)
+                gpu.tune("ntt_tile", tile); gpu.ntt_device(x.data_ptr(), a.data_ptr(), n, inverse=inv, sync=True)
+                assert torch.equal(a, b_), tile
+            gpu.tune("ntt_tile", 0)
     finally:
-        gpu.tune("ntt_l29", 1)
+        gpu.tune("ntt_l29", 1); gpu.tune("ntt_tile", 0)
 
 
 @pytest.mark.parametrize("n", [1, 2, 33, 1000, 4096, 16384, 32768])
@@ -136,11 +140,13 @@ def test_ntt_fused_stages_agree_with_separate_kernels(gpu, n):
         for inv in (False, True):
             for cs in (None, shift[0], shift[1]):
                 for batch in (1, B):
+                    gpu.tune("ntt_tile", 2048 if (n // 4096) % 2 else 1024)
                     gpu.tune("ntt_fused", 0)
                     gpu.ntt_batch_device(x.data_ptr(), a.data_ptr(), n, batch, inverse=inv, coset_shift=cs, sync=True)
-                    gpu.tune("ntt_fused", 1)
+                    gpu.tune("ntt_fused", 1); gpu.tune("ntt_tile", 1024 if (n // 4096) % 2 else 2048)      # the other tile size
                     gpu.ntt_batch_device(x.data_ptr(), b_.data_ptr(), n, batch, inverse=inv, coset_shift=cs, sync=True)
                     assert torch.equal(a[:batch * n], b_[:batch * n]), (inv, cs is not None, batch)
+                    gpu.tune("ntt_tile", 0)
                     b_[:batch * n] = x[:batch * n]                           # in place
                     torch.cuda.synchronize()                                 # torch's copy runs on torch's stream, the library on its own
                     gpu.ntt_batch_device(b_.data_ptr(), b_.data_ptr(), n, batch, inverse=inv, coset_shift=cs, sync=True)
@@ -151,4 +157,4 @@ def test_ntt_fused_stages_agree_with_separate_kernels(gpu, n):
             want = oc.ntt(oc.mul_var(hx, shift[0]))
             assert np.array_equal(a[:n].cpu().numpy().view(np.uint64).reshape(-1, 4), want)
     finally:
-        gpu.tune("ntt_fused", 1)
+        gpu.tune("ntt_fused", 1); gpu.tune("ntt_tile", 0)

@@ -789,6 +789,7 @@ int uzk_tune(const char* key, int value) {
     else if (!std::strcmp(key, "msm_overlap")) c.tune_overlap = value;
     else if (!std::strcmp(key, "ntt_l29")) c.tune_ntt_l29 = value;
     else if (!std::strcmp(key, "ntt_fused")) c.tune_ntt_fused = value;
+    else if (!std::strcmp(key, "ntt_tile")) c.tune_ntt_tile = value;
     else if (!std::strcmp(key, "msm_sort_packed")) c.tune_sort_packed = value;
     else if (!std::strcmp(key, "msm_fused_hist")) c.tune_fused_hist = value;
     else if (!std::strcmp(key, "msm_reduce_seg")) c.tune_reduce_seg = value;
