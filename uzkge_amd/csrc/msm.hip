@@ -391,25 +391,39 @@ __global__ __launch_bounds__(TB) void msm_radix_scatter_kernel(RadixArgs a) {
 // ---- 3. task scans -----------------------------------------------------------------------------
 // One workgroup per bucket window: v[b] = div ? ceil(cnt[b] / div) : cnt[b]; writes v (optional), the
 // exclusive prefix of v within the window, the window total, and folds max(cnt) into *max_out.
+// The window's counts are staged in LDS (dynamic, NB + NB/32 words: one pad word per 32 keeps a lane's run of
+// NB/1024 consecutive entries off its neighbours' banks) so that every global access is coalesced; with the lanes
+// walking their runs in global memory each instruction touched 64 cache lines and the kernel took 80 us at NB = 2^15.
 __global__ __launch_bounds__(1024) void msm_scan_win_kernel(const uint32_t* __restrict__ cnt_in, uint32_t div,
                                                             uint32_t* __restrict__ v_out,
                                                             uint32_t* __restrict__ off_out,
                                                             uint32_t* __restrict__ win_total,
                                                             uint32_t* __restrict__ max_out, uint32_t NB) {
     __shared__ uint32_t part[1024];
+    extern __shared__ uint32_t stage[];
     const uint32_t w = blockIdx.x, tid = threadIdx.x;
     const uint32_t per = (NB + 1023) / 1024;
     const uint32_t lo = min(NB, tid * per), hi = min(NB, lo + per);
     const uint32_t* cnt = cnt_in + (size_t)w * NB;
-    auto val = [&](uint32_t b) -> uint32_t {
-        const uint32_t c = cnt[b];
-        return div ? (c + div - 1) / div : c;
+    // ceil(c / div) by one multiplication: magic = ceil(2^40 / div); exact for c + div < 2^30 (the error term
+    // (magic div - 2^40) (c + div - 1) < div 2^30 <= 2^40 needs div <= 2^10, which the task and fold lengths are)
+    const uint64_t magic = div ? ((1ull << 40) + div - 1) / div : 0;
+    const bool fast = div && div <= 1024;
+    auto val = [&](uint32_t c) -> uint32_t {
+        if (!div) return c;
+        if (fast && c < (1u << 29)) return (uint32_t)(((uint64_t)(c + div - 1) * magic) >> 40);
+        return (c + div - 1) / div;
     };
-    uint32_t s = 0, mx = 0;
-    for (uint32_t b = lo; b < hi; ++b) {
-        s += val(b);
-        mx = max(mx, cnt[b]);
+    auto pad = [](uint32_t i) -> uint32_t { return i + (i >> 5); };
+    uint32_t mx = 0;
+    for (uint32_t i = tid; i < NB; i += 1024) {
+        const uint32_t c = cnt[i];
+        mx = max(mx, c);
+        stage[pad(i)] = val(c);
     }
+    __syncthreads();
+    uint32_t s = 0;
+    for (uint32_t b = lo; b < hi; ++b) s += stage[pad(b)];
     part[tid] = s;
     __syncthreads();
     for (uint32_t off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan
@@ -419,19 +433,32 @@ __global__ __launch_bounds__(1024) void msm_scan_win_kernel(const uint32_t* __re
         __syncthreads();
     }
     uint32_t run = part[tid] - s;
+    for (uint32_t b = lo; b < hi; ++b) {               // exclusive prefix in place
+        const uint32_t v = stage[pad(b)];
+        stage[pad(b)] = run;
+        run += v;
+    }
+    __syncthreads();
     uint32_t* off_o = off_out + (size_t)w * NB;
     uint32_t* v_o = v_out ? v_out + (size_t)w * NB : nullptr;
-    for (uint32_t b = lo; b < hi; ++b) {
-        const uint32_t v = val(b);
-        off_o[b] = run;
-        if (v_o) v_o[b] = v;
-        run += v;
+    for (uint32_t i = tid; i < NB; i += 1024) {
+        off_o[i] = stage[pad(i)];
+        if (v_o) v_o[i] = val(cnt[i]);
     }
     if (tid == 1023) win_total[w] = part[1023];
     if (max_out) {
         for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_down((int)mx, o));
         if ((tid & 63) == 0 && mx) atomicMax(max_out, mx);
     }
+}
+// dynamic LDS of msm_scan_win_kernel for windows of NB buckets (above 64 KiB the runtime wants to be told once)
+static size_t scan_win_lds(uint32_t NB) {
+    static const bool raised = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(msm_scan_win_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   ((1 << 15) + (1 << 10) + 1) * 4) == hipSuccess;
+    }();
+    (void)raised;
+    return ((size_t)NB + NB / 32 + 1) * 4;
 }
 // win_base[w] = sum of win_total[0..w), win_base[W] = grand total   (W <= 1024)
 __global__ __launch_bounds__(1024) void msm_win_base_kernel(const uint32_t* __restrict__ win_total,
@@ -1578,7 +1605,7 @@ static int msm_group_phase1(Ctx& c, MsmGroup& g, const Affine* points, const Fp*
     g.part_cur = m.lvl_part[0].as<XYZZ>();
     {
         KernelScope ks(c, "msm_scan_win");
-        hipLaunchKernelGGL(msm_scan_win_kernel, dim3(g.Wd), dim3(1024), 0, st, bcount, g.L, g.cnt_cur, g.off_cur, win_tot,
+        hipLaunchKernelGGL(msm_scan_win_kernel, dim3(g.Wd), dim3(1024), scan_win_lds(g.NB), st, bcount, g.L, g.cnt_cur, g.off_cur, win_tot,
                            d_max, g.NB);
         hipLaunchKernelGGL(msm_win_base_kernel, dim3(1), dim3(1024), 0, st, win_tot, g.base_cur, g.Wd);
     }
@@ -1650,7 +1677,7 @@ static int msm_group_phase2(Ctx& c, MsmGroup& g) {
         XYZZ* part_nx = m.lvl_part[nx].as<XYZZ>();
         {
             KernelScope ks(c, "msm_scan_win");
-            hipLaunchKernelGGL(msm_scan_win_kernel, dim3(g.Wd), dim3(1024), 0, st, g.cnt_cur, G, cnt_nx, off_nx, win_tot,
+            hipLaunchKernelGGL(msm_scan_win_kernel, dim3(g.Wd), dim3(1024), scan_win_lds(g.NB), st, g.cnt_cur, G, cnt_nx, off_nx, win_tot,
                                (uint32_t*)nullptr, g.NB);
             hipLaunchKernelGGL(msm_win_base_kernel, dim3(1), dim3(1024), 0, st, win_tot, base_nx, g.Wd);
         }
