@@ -1,0 +1,49 @@
+// Latency of dependent group additions for ONE wave (and for 2 / 4 waves per SIMD): lane-serial xyzz_add against the
+// four-lane xyzz_add_quad / xyzz_dbl_quad of ecquad.hpp.
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../uzkge_amd/csrc quad_latency.hip -o quad_latency
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include "ecquad.hpp"
+using namespace uzk;
+__global__ void chain_lane(XYZZ* io, int iters) {
+    XYZZ acc = io[0], p = io[1];
+    for (int i = 0; i < iters; ++i) xyzz_add(acc, p);
+    if (threadIdx.x == 0) io[2] = acc;
+}
+__global__ void chain_quad(XYZZ* io, int iters) {
+    XYZZ acc = io[0], p = io[1];
+    const uint32_t q = threadIdx.x & 3;
+    for (int i = 0; i < iters; ++i) xyzz_add_quad(acc, p, q);
+    if (threadIdx.x == 0) io[3] = acc;
+}
+__global__ void chain_dblq(XYZZ* io, int iters) {
+    XYZZ acc = io[0];
+    const uint32_t q = threadIdx.x & 3;
+    for (int i = 0; i < iters; ++i) xyzz_dbl_quad(acc, q);
+    if (threadIdx.x == 0) io[4] = acc;
+}
+template <typename K> static float run(K k, XYZZ* d, int iters, int waves) {
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    hipLaunchKernelGGL(k, dim3(1), dim3(64 * waves), 0, 0, d, 10);
+    hipEventRecord(a);
+    hipLaunchKernelGGL(k, dim3(1), dim3(64 * waves), 0, 0, d, iters);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    return ms * 1e3f / iters;   // us per operation
+}
+int main() {
+    XYZZ h[8] = {};
+    Affine G; G.x = Fq::one(); G.y = Fq::dbl(Fq::one());
+    XYZZ g1 = xyzz_from_affine(G);
+    h[0] = xyzz_dbl(g1);          // 2G
+    h[1] = g1;                    // G: acc runs through 3G, 4G, ...
+    XYZZ* d; hipMalloc(&d, sizeof h); hipMemcpy(d, h, sizeof h, hipMemcpyHostToDevice);
+    const int it = 2000;
+    for (int waves : {1, 4, 8, 16})
+        std::printf("waves/WG %2d: lane add %.2f us, quad add %.2f us, quad dbl %.2f us\n", waves, run(chain_lane, d, it, waves),
+                    run(chain_quad, d, it, waves), run(chain_dblq, d, it, waves));
+    hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
+    std::printf("lane and quad chains agree: %s\n", memcmp(&h[2], &h[3], sizeof(XYZZ)) == 0 ? "yes" : "NO");
+    return 0;
+}

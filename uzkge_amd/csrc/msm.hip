@@ -881,9 +881,11 @@ __global__ __launch_bounds__(256) void msm_fold_scan_kernel(const XYZZ* __restri
     if (tid == 0) out[w] = sh[0];
 }
 
-// The two kernels above with one quad per lane-role (block 512 = 128 quads: no spills at 256 VGPRs, ecquad.hpp): the same identity, every
+// The two kernels above with one quad per lane-role (block 256 = 64 quads, ecquad.hpp): the same identity, every
 // dependent addition / doubling at a quarter of its latency.  t = quad index in the workgroup.
-constexpr uint32_t kQuadLanes = 128;
+// 256 threads = one wave per SIMD: two waves share the SIMD's issue port and every dependent step takes twice as long
+// (tools/microbench/quad_latency.hip: quad addition 3.2 us alone, 5.9 us with a second wave on the SIMD)
+constexpr uint32_t kQuadLanes = 64, kLogQuadLanes = 6;
 __device__ __forceinline__ void wgq_suffix_scan(XYZZ* sh, uint32_t t, uint32_t q, XYZZ& mine, uint32_t width) {
     if (q == 0) sh[t] = mine;
     __syncthreads();
@@ -1131,7 +1133,7 @@ __global__ __launch_bounds__(256) void msm_small_fold_kernel(XYZZ* __restrict__ 
 // task sums -- skewed scalars; four quads per chunk), then B_b = the bucket's one remaining sum and
 // window sum = sum_{b >= 1} b * B_b = sum over t of the inclusive suffix sums Suffix_t = B_(t+1) + B_(t+2) + ... (t = b - 1):
 // log2(NBL) scan steps, then a tree over the NBL suffixes.
-// QUAD: one quad per bucket (block 4 * NBL, NBL <= 256); else one lane per bucket (block NBL).  Dynamic LDS NBL * 128 B.
+// QUAD: min(NBL, 64) quads (block 4 min(NBL, 64)); else one lane per bucket (block NBL).  Dynamic LDS 128 B per quad / lane.
 template <bool QUAD, int MAXT>
 __global__ __launch_bounds__(MAXT) void msm_small_reduce_kernel(XYZZ* __restrict__ P, const uint32_t* __restrict__ bucket_ref,
                                                                 const SmallChunk* __restrict__ cdesc,
@@ -1167,30 +1169,73 @@ __global__ __launch_bounds__(MAXT) void msm_small_reduce_kernel(XYZZ* __restrict
         }
         __syncthreads();
     }
-    const uint32_t ref = bucket_ref[(size_t)slot * NBL + t];
-    XYZZ mine = ref == kSmallNone ? xyzz_inf() : P[ref];
-    if (writer) sh[t] = mine;
-    __syncthreads();
-    for (uint32_t off = 1; off < NBL; off <<= 1) {
-        const bool has = t + off < NBL;
-        XYZZ v;
-        if (has) v = sh[t + off];
-        __syncthreads();
-        if (has) {
-            if constexpr (QUAD) xyzz_add_quad(mine, v, q); else xyzz_add(mine, v);
-            if (writer) sh[t] = mine;
+    if constexpr (QUAD) {
+        // Q = min(NBL, 64) quads -- 256 lanes, ONE wave per SIMD (a second wave on the SIMD doubles the time of every
+        // dependent step) -- quad t owns the r = NBL / Q consecutive buckets t r .. t r + r - 1 (array index i = b - 1):
+        //   run_t = sum_j B, acc_t = sum_j (j + 1) B            (running sums from the top bucket down: 2 (r - 1) additions)
+        //   sum_b b B_b = sum_t acc_t + r sum_{t >= 1} Suf_t,   Suf_t = run_t + run_(t+1) + ...   (log2 Q scan steps)
+        // then a tree over V_t = acc_t + r Suf_t (t >= 1), V_0 = acc_0.
+        const uint32_t Q = blockDim.x >> 2, r = NBL / Q;
+        XYZZ run = xyzz_inf(), acc = xyzz_inf();
+        for (uint32_t j = r; j-- > 0;) {
+            const uint32_t ref = bucket_ref[(size_t)slot * NBL + t * r + j];
+            if (ref != kSmallNone) { const XYZZ bk = P[ref]; xyzz_add_quad(run, bk, q); }
+            if (r > 1) xyzz_add_quad(acc, run, q); else acc = run;
         }
+        if (writer) sh[t] = run;
         __syncthreads();
-    }
-    for (uint32_t s2 = NBL >> 1; s2 > 0; s2 >>= 1) {
-        if (t < s2) {
-            const XYZZ v = sh[t + s2];
-            if constexpr (QUAD) xyzz_add_quad(mine, v, q); else xyzz_add(mine, v);
-            if (writer) sh[t] = mine;
+        for (uint32_t off = 1; off < Q; off <<= 1) {
+            const bool has = t + off < Q;
+            XYZZ v;
+            if (has) v = sh[t + off];
+            __syncthreads();
+            if (has) {
+                xyzz_add_quad(run, v, q);
+                if (writer) sh[t] = run;
+            }
+            __syncthreads();
         }
+        if (t >= 1) {
+            for (uint32_t d = 1; d < r; d <<= 1) xyzz_dbl_quad(run, q);
+            xyzz_add_quad(acc, run, q);
+        }
+        if (writer) sh[t] = acc;
         __syncthreads();
+        for (uint32_t s2 = Q >> 1; s2 > 0; s2 >>= 1) {
+            if (t < s2) {
+                const XYZZ v = sh[t + s2];
+                xyzz_add_quad(acc, v, q);
+                if (writer) sh[t] = acc;
+            }
+            __syncthreads();
+        }
+        if (tid == 0) win_sums[slot] = acc;
+    } else {
+        const uint32_t ref = bucket_ref[(size_t)slot * NBL + t];
+        XYZZ mine = ref == kSmallNone ? xyzz_inf() : P[ref];
+        sh[t] = mine;
+        __syncthreads();
+        for (uint32_t off = 1; off < NBL; off <<= 1) {
+            const bool has = t + off < NBL;
+            XYZZ v;
+            if (has) v = sh[t + off];
+            __syncthreads();
+            if (has) {
+                xyzz_add(mine, v);
+                sh[t] = mine;
+            }
+            __syncthreads();
+        }
+        for (uint32_t s2 = NBL >> 1; s2 > 0; s2 >>= 1) {
+            if (t < s2) {
+                const XYZZ v = sh[t + s2];
+                xyzz_add(mine, v);
+                sh[t] = mine;
+            }
+            __syncthreads();
+        }
+        if (tid == 0) win_sums[slot] = mine;
     }
-    if (tid == 0) win_sums[slot] = mine;
 }
 
 // ---- precomputation: T[j][i] = 2^c * T[j-1][i], affine --------------------------------------------
@@ -1426,6 +1471,8 @@ static int msm_group_plan(Ctx& c, MsmGroup& g, size_t n, uint32_t batch, int cb,
         }
         while (sg & (sg - 1)) sg &= sg - 1;                                  // power of two
         g.rl = g.quad_reduce ? kQuadLanes : 256u;
+        // small windows (c = 8: 128 buckets): one workgroup per window, its partial needs no folding (0.094 -> 0.071 ms)
+        if (g.quad_reduce && c.tune_reduce_seg <= 0 && g.NBL <= 4 * g.rl) sg = std::max<uint32_t>(sg, g.NBL / g.rl);
         sg = std::max<uint32_t>(1, std::min<uint32_t>(sg, g.NBL / g.rl));
         while ((g.NBL + sg * g.rl - 1) / (sg * g.rl) > g.rl) sg <<= 1;
         g.seg = sg;
@@ -1722,7 +1769,7 @@ static int msm_group_phase2(Ctx& c, MsmGroup& g) {
                 hipLaunchKernelGGL(msm_reduce_scan_quad_kernel, dim3(g.groups, g.RW), dim3(kQuadLanes * 4), 0, st, buckets, partials, part_r,
                                    g.NBL, g.groups, g.seg, log_seg);
                 hipLaunchKernelGGL(msm_fold_scan_quad_kernel, dim3(g.RW), dim3(kQuadLanes * 4), 0, st, partials, part_r, win_sums, g.groups,
-                                   7 + log_seg);
+                                   kLogQuadLanes + log_seg);
             } else {
                 hipLaunchKernelGGL(msm_reduce_scan_kernel, dim3(g.groups, g.RW), dim3(256), 0, st, buckets, partials, part_r, g.NBL,
                                    g.groups, g.seg, log_seg);
@@ -1971,13 +2018,13 @@ static int msm_run_small(Ctx& c, const Affine* points, const Fp* d_scalars, size
         }
         {
             KernelScope ks(c, "msm_small_reduce");
-            const size_t lds = (size_t)NBL * sizeof(XYZZ);
-            if (NBL <= 128 && c.tune_small != 2)
-                hipLaunchKernelGGL((msm_small_reduce_kernel<true, 512>), dim3(S), dim3(4 * NBL), lds, st, P, bucket_ref, cdesc, slot_chunks, lv, win_sums, NBL);
-            else if (NBL <= 256 && c.tune_small != 2)
-                hipLaunchKernelGGL((msm_small_reduce_kernel<true, 1024>), dim3(S), dim3(4 * NBL), lds, st, P, bucket_ref, cdesc, slot_chunks, lv, win_sums, NBL);
+            const uint32_t Q = std::min<uint32_t>(NBL, 64);
+            if (c.tune_small != 2)
+                hipLaunchKernelGGL((msm_small_reduce_kernel<true, 256>), dim3(S), dim3(4 * Q), (size_t)Q * sizeof(XYZZ), st, P, bucket_ref, cdesc,
+                                   slot_chunks, lv, win_sums, NBL);
             else
-                hipLaunchKernelGGL((msm_small_reduce_kernel<false, 512>), dim3(S), dim3(NBL), lds, st, P, bucket_ref, cdesc, slot_chunks, lv, win_sums, NBL);
+                hipLaunchKernelGGL((msm_small_reduce_kernel<false, 512>), dim3(S), dim3(NBL), (size_t)NBL * sizeof(XYZZ), st, P, bucket_ref, cdesc,
+                                   slot_chunks, lv, win_sums, NBL);
         }
         UZK_HIP(hipGetLastError());
     }
