@@ -797,6 +797,7 @@ int uzk_tune(const char* key, int value) {
     else if (!std::strcmp(key, "msm_small")) c.tune_small = value;
     else if (!std::strcmp(key, "msm_fold_mode")) c.tune_fold_mode = value;
     else if (!std::strcmp(key, "msm_quad_reduce")) c.tune_quad_reduce = value;
+    else if (!std::strcmp(key, "poly_small")) c.tune_poly_small = value;
     else if (!std::strcmp(key, "msm_chunk_log")) c.tune_chunk_log = (value >= 8 && value <= 26) ? value : 26;
     else { set_error("uzk_tune: unknown key %s", key); return UZK_ERR_PARAMETER; }
     return UZK_OK;

@@ -80,6 +80,7 @@ struct Ctx {
     int tune_no_precompute = 0;
     int tune_fold_group = 0;
     int tune_scan_reduce = 1; // bucket reduction by suffix scans: 1 = for windows of <= 2^14 buckets, 2 = always, 3 = always with quads, 0 = never
+    int tune_poly_small = 1;  // 1: one-launch kernels for small polynomials (evaluation)
     int tune_quad_reduce = 1; // 1: up to 2^19 buckets the scan reduction runs on quads (ecquad.hpp); 0: lanes only
     int tune_reduce_seg = 0;  // experiment: buckets per lane in the bucket reduction (0 = default)
     int tune_fused_hist = 1;  // 1: the digit kernel also produces the first sort pass's histograms (large n)
@@ -93,6 +94,9 @@ struct Ctx {
     int tune_overlap = 0;     // 1: run large MSMs as two overlapping pipeline instances (experiment)  // 1: force one lane per bucket in the fold kernels
     // poly.hip workspaces (grow-only)
     DevBuf poly_tmp, poly_tmp2, poly_io, zpoly_tmp, open_tmp;
+    DevBuf poly_cnt;                 // per-polynomial arrival counters of poly_eval_small (zero between calls)
+    void* poly_host = nullptr;       // pinned, device-visible: small results written by the kernels themselves
+    size_t poly_host_cap = 0;
     // ntt.hip: decimated sub-vectors of the small 3 * 2^k path; three-level power tables of arbitrary
     // elements (coset shifts, mixed-radix roots) cached by VALUE, least recently used entry replaced
     DevBuf ntt_sub;

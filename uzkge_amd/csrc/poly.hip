@@ -133,10 +133,98 @@ __global__ __launch_bounds__(64) void poly_eval_finish_kernel(const Fp* __restri
 }
 
 
+// Small polynomials (<= 64 blocks of 1024 coefficients: the prover's n = 2^14 and its 6n quotient pieces): ONE launch.
+// grid (nblocks, batch), 256 lanes = one wave per SIMD.  Each workgroup builds its own power table x^(4 t), t < 256, in
+// LDS by doubling (eight levels of one product and one squaring -- the separate table kernel's square-and-multiply per
+// lane took 16 us), evaluates its 1024 coefficients, weights the sum by x^(1024 blk), and the last workgroup of a
+// polynomial to arrive (a counter per polynomial, reset by that workgroup) adds the block sums and stores the value
+// straight into pinned host memory: no table kernel, no finish kernel, no copy kernel.
+constexpr int kEvalSmallPer = 4, kEvalSmallBlock = 256 * kEvalSmallPer, kEvalSmallMaxBlocks = 64;
+__global__ __launch_bounds__(256) void poly_eval_small_kernel(const Fp* __restrict__ coefs, uint64_t n, Fp x, Fp* __restrict__ partial,
+                                                              uint32_t* __restrict__ counters, Fp* __restrict__ out_host) {
+    __shared__ Fp pw[256];
+    __shared__ Fp sh[256];
+    __shared__ uint32_t last;
+    const uint32_t tid = threadIdx.x, blk = blockIdx.x, nblocks = gridDim.x, b = blockIdx.y;
+    const Fp* c = coefs + (uint64_t)b * n;
+    const uint64_t base = (uint64_t)blk * kEvalSmallBlock + (uint64_t)tid * kEvalSmallPer;
+    Fp h = Fr::zero();
+#pragma unroll
+    for (int e = kEvalSmallPer - 1; e >= 0; --e) {
+        const uint64_t j = base + e;
+        h = Fr::mul(h, x);
+        if (j < n) h = Fr::add(h, c[j]);
+    }
+    // pw[t] = x^(4 t): pw[2^k + i] = pw[i] * s_k with s_k = x^(4 2^k) kept by every lane
+    Fp s = Fr::sqr(Fr::sqr(x));
+    if (tid == 0) pw[0] = Fr::one();
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t half = 1u << k;
+        if (tid < half) pw[half + tid] = Fr::mul(pw[tid], s);
+        s = Fr::sqr(s);
+        __syncthreads();
+    }
+    // s = x^1024: the block's weight is s^blk (blk < 64)
+    Fp wblk = Fr::one(), sp = s;
+    for (uint32_t e = blk; e; e >>= 1) {
+        if (e & 1) wblk = Fr::mul(wblk, sp);
+        sp = Fr::sqr(sp);
+    }
+    sh[tid] = Fr::mul(h, pw[tid]);
+    __syncthreads();
+    for (uint32_t st = 128; st > 0; st >>= 1) {
+        if (tid < st) sh[tid] = Fr::add(sh[tid], sh[tid + st]);
+        __syncthreads();
+    }
+    if (tid == 0) {
+        partial[(uint64_t)b * nblocks + blk] = Fr::mul(sh[0], wblk);
+        __threadfence();
+        last = (atomicAdd(&counters[b], 1u) == nblocks - 1) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (last && tid == 0) {
+        __threadfence();
+        Fp acc = Fr::zero();
+        for (uint32_t k = 0; k < nblocks; ++k) acc = Fr::add(acc, partial[(uint64_t)b * nblocks + k]);
+        out_host[b] = acc;
+        counters[b] = 0;                       // ready for the next call on this stream
+    }
+}
+
+static int poly_host_reserve(Ctx& c, size_t bytes) {
+    if (c.poly_host_cap >= bytes) return UZK_OK;
+    if (c.poly_host) { UZK_HIP(hipStreamSynchronize(c.stream)); (void)hipHostFree(c.poly_host); c.poly_host = nullptr; c.poly_host_cap = 0; }
+    const size_t cap = std::max<size_t>(bytes, 1 << 16);
+    UZK_HIP(hipHostMalloc(&c.poly_host, cap, hipHostMallocDefault));
+    c.poly_host_cap = cap;
+    return UZK_OK;
+}
+
 int poly_eval_batch(Ctx& c, const Fp* d_coefs, uint64_t n, uint32_t batch, const Fp& x, Fp* out_host) {
     if (batch == 0) return UZK_OK;
     if (n == 0) { for (uint32_t b = 0; b < batch; ++b) out_host[b] = Fr::zero(); return UZK_OK; }
     if (batch > 65535) { set_error("poly_eval: batch %u exceeds 65535", batch); return UZK_ERR_PARAMETER; }
+    const uint64_t nb_small = (n + kEvalSmallBlock - 1) / kEvalSmallBlock;
+    if (nb_small <= (uint64_t)kEvalSmallMaxBlocks && c.tune_poly_small) {
+        const uint32_t nblocks = (uint32_t)nb_small;
+        UZK_TRY(c.poly_tmp.reserve((size_t)batch * nblocks * sizeof(Fp)));
+        if (c.poly_cnt.cap < (size_t)batch * 4) {
+            UZK_TRY(c.poly_cnt.reserve(std::max<size_t>((size_t)batch * 4, 4096)));
+            UZK_HIP(hipMemsetAsync(c.poly_cnt.p, 0, c.poly_cnt.cap, c.stream));
+        }
+        UZK_TRY(poly_host_reserve(c, (size_t)batch * sizeof(Fp)));
+        {
+            KernelScope ks(c, "poly_eval");
+            hipLaunchKernelGGL(poly_eval_small_kernel, dim3(nblocks, batch), dim3(256), 0, c.stream, d_coefs, n, x, c.poly_tmp.as<Fp>(),
+                               c.poly_cnt.as<uint32_t>(), static_cast<Fp*>(c.poly_host));
+        }
+        UZK_HIP(hipGetLastError());
+        UZK_HIP(hipStreamSynchronize(c.stream));
+        std::memcpy(out_host, c.poly_host, (size_t)batch * sizeof(Fp));
+        return UZK_OK;
+    }
     const uint32_t nblocks = (uint32_t)((n + kEvalBlock - 1) / kEvalBlock);
     UZK_TRY(c.poly_tmp.reserve(((size_t)256 + nblocks + (size_t)batch * nblocks + batch) * sizeof(Fp)));
     Fp* tab = c.poly_tmp.as<Fp>();
@@ -690,6 +778,8 @@ void poly_free(Ctx& c) {
     c.poly_io.release();
     c.zpoly_tmp.release();
     c.open_tmp.release();
+    c.poly_cnt.release();
+    if (c.poly_host) { (void)hipHostFree(c.poly_host); c.poly_host = nullptr; c.poly_host_cap = 0; }
 }
 
 }  // namespace uzk
