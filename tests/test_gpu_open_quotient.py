@@ -24,11 +24,16 @@ def _run(gpu, polys, z, alpha):
 def test_matches_reference_loop(gpu, n, batch):
     polys = rand_fr_wire(n * batch, 7 + n).reshape(batch, n, 4)
     s = rand_fr_wire(2, 8 + n)
-    q_gpu, ev_gpu = _run(gpu, polys, s[0], s[1])
     q, ev, ok = oc.open_quotient(polys, s[0], s[1])
     assert ok
-    assert np.array_equal(ev_gpu, ev)
-    assert np.array_equal(q_gpu, q)
+    try:
+        for small in (1, 0):          # 4 / 16 coefficients per lane in the division kernels (n <= 2^16), both evaluation kernels
+            gpu.tune("poly_small", small)
+            q_gpu, ev_gpu = _run(gpu, polys, s[0], s[1])
+            assert np.array_equal(ev_gpu, ev), small
+            assert np.array_equal(q_gpu, q), small
+    finally:
+        gpu.tune("poly_small", 1)
 
 
 def test_division_identity(gpu):

@@ -528,8 +528,6 @@ int t_quotient_run(Ctx& c, const void* args_c_abi, Fp* d_out) {
 // between lanes and between 4096-coefficient blocks by Hillis-Steele steps whose multipliers are
 // the same for every lane (x_t += z^(16 * 2^k) x_(t + 2^k)).  n <= 2^20 coefficients per polynomial.
 // ---------------------------------------------------------------------------------------------
-constexpr int kDivPer = 16;
-constexpr int kDivBlock = 256 * kDivPer;
 
 // h[j] = sum_k apow[k] * polys[k*n + j]  - (j == 0 ? E : 0)
 __global__ __launch_bounds__(256) void open_lincomb_kernel(const Fp* __restrict__ polys, uint64_t n, uint32_t batch,
@@ -541,11 +539,15 @@ __global__ __launch_bounds__(256) void open_lincomb_kernel(const Fp* __restrict_
     if (j == 0) acc = Fr::sub(acc, E);
     h[j] = acc;
 }
-// s_i = h_i + z s_(i+1) within each 4096-block, carry-in 0; block_first[b] = s at the block's lowest index.
-// zp[k] = z^(16 * 2^k), k < 8.
+// s_i = h_i + z s_(i+1) within each block of 256 PER coefficients, carry-in 0; block_first[b] = s at the block's lowest index.
+// zp[k] = z^(PER * 2^k), k < 8.
 struct DivPows { Fp z; Fp zp[8]; };
+// PER coefficients per lane (16; 4 for n <= 2^16: the prover's openings get 16 workgroups and a dependent chain of
+// 16 products instead of 40), 256 PER per block; the host builds zp / ztab for the same PER.
+template <int kDivPer>
 __global__ __launch_bounds__(256) void open_div_block_kernel(const Fp* __restrict__ h, uint64_t n, DivPows pw,
                                                              Fp* __restrict__ s_out, Fp* __restrict__ block_first) {
+    constexpr int kDivBlock = 256 * kDivPer;
     __shared__ Fp sh[256];
     const uint32_t tid = threadIdx.x;
     const uint64_t lo = (uint64_t)blockIdx.x * kDivBlock + (uint64_t)tid * kDivPer;
@@ -598,9 +600,11 @@ __global__ __launch_bounds__(256) void open_div_carry_kernel(const Fp* __restric
     if (tid < nblocks) carry[tid] = (tid + 1 < 256) ? sh[tid + 1] : Fr::zero();
 }
 // q[i-1] = s_i + z^(block_hi - i) carry[block]  for 1 <= i < n ;  q[n-1] = 0 ; ztab[t] = z^t, t <= 4096
+template <int kDivPer>
 __global__ __launch_bounds__(256) void open_div_apply_kernel(const Fp* __restrict__ s, const Fp* __restrict__ carry,
                                                              const Fp* __restrict__ ztab16, Fp z, uint64_t n,
                                                              Fp* __restrict__ q) {
+    constexpr int kDivBlock = 256 * kDivPer;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (i == 0) { q[n - 1] = Fr::zero(); return; }
@@ -627,8 +631,11 @@ int open_quotient_run(Ctx& c, const Fp* d_polys, uint64_t n, uint32_t batch, con
     std::vector<Fp> apow(batch);
     Fp E = Fr::zero(), a = Fr::one();
     for (uint32_t k = 0; k < batch; ++k) { apow[k] = a; E = Fr::add(E, Fr::mul(a, evals_host[k])); a = Fr::mul(a, alpha); }
-    const uint32_t nblocks = (uint32_t)((n + kDivBlock - 1) / kDivBlock);
-    // layout: apow[batch] | h[n] | s[n] | block_first[256] | carry[256] | ztab16[257]
+    const int per = (n <= (1ull << 16) && c.tune_poly_small) ? 4 : 16;       // coefficients per lane of the division kernels
+    const int log_per = per == 4 ? 2 : 4;
+    const uint64_t div_block = 256ull * per;
+    const uint32_t nblocks = (uint32_t)((n + div_block - 1) / div_block);
+    // layout: apow[batch] | h[n] | s[n] | block_first[256] | carry[256] | ztab[257]
     UZK_TRY(c.open_tmp.reserve(((size_t)batch + 2 * n + 256 + 256 + 257) * sizeof(Fp)));
     Fp* d_apow = c.open_tmp.as<Fp>();
     Fp* d_h = d_apow + batch;
@@ -641,21 +648,23 @@ int open_quotient_run(Ctx& c, const Fp* d_polys, uint64_t n, uint32_t batch, con
     pw.z = z; pb.z = z;
     {
         Fp z16 = z;
-        for (int i = 0; i < 4; ++i) z16 = Fr::sqr(z16);                     // z^16
+        for (int i = 0; i < log_per; ++i) z16 = Fr::sqr(z16);               // z^per
         Fp cur = Fr::one();
-        for (int t = 0; t <= 256; ++t) { ztab[t] = cur; cur = Fr::mul(cur, z16); }   // z^(16 t)
+        for (int t = 0; t <= 256; ++t) { ztab[t] = cur; cur = Fr::mul(cur, z16); }   // z^(per t)
         Fp p = z16;
-        for (int k = 0; k < 8; ++k) { pw.zp[k] = p; p = Fr::sqr(p); }       // z^(16 * 2^k)
-        p = ztab[256];                                                      // z^4096
+        for (int k = 0; k < 8; ++k) { pw.zp[k] = p; p = Fr::sqr(p); }       // z^(per * 2^k)
+        p = ztab[256];                                                      // z^(256 per): one block
         for (int k = 0; k < 8; ++k) { pb.zp[k] = p; p = Fr::sqr(p); }
     }
     UZK_HIP(hipMemcpyAsync(d_apow, apow.data(), batch * sizeof(Fp), hipMemcpyHostToDevice, c.stream));
     UZK_HIP(hipMemcpyAsync(d_ztab, ztab.data(), ztab.size() * sizeof(Fp), hipMemcpyHostToDevice, c.stream));
     KernelScope ks(c, "open_quotient");
     hipLaunchKernelGGL(open_lincomb_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, d_polys, n, batch, d_apow, E, d_h);
-    hipLaunchKernelGGL(open_div_block_kernel, dim3(nblocks), dim3(256), 0, c.stream, d_h, n, pw, d_s, d_first);
+    if (per == 4) hipLaunchKernelGGL(open_div_block_kernel<4>, dim3(nblocks), dim3(256), 0, c.stream, d_h, n, pw, d_s, d_first);
+    else hipLaunchKernelGGL(open_div_block_kernel<16>, dim3(nblocks), dim3(256), 0, c.stream, d_h, n, pw, d_s, d_first);
     hipLaunchKernelGGL(open_div_carry_kernel, dim3(1), dim3(256), 0, c.stream, d_first, nblocks, pb, d_carry);
-    hipLaunchKernelGGL(open_div_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, d_s, d_carry, d_ztab, z, n, d_q);
+    if (per == 4) hipLaunchKernelGGL(open_div_apply_kernel<4>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, d_s, d_carry, d_ztab, z, n, d_q);
+    else hipLaunchKernelGGL(open_div_apply_kernel<16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, d_s, d_carry, d_ztab, z, n, d_q);
     UZK_HIP(hipGetLastError());
     UZK_HIP(hipStreamSynchronize(c.stream));     // apow / ztab are host vectors of this call
     return UZK_OK;
