@@ -13,9 +13,9 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("n,batch", [(1, 1), (3, 2), (17, 5), (1024, 2), (1025, 2), (4096, 3), (16384, 9), (16387, 20), (65536, 3), (65537, 2),
-                                     (100000, 2)])
+                                     (98304, 6), (100000, 2), (262144, 1), (262145, 2)])
 def test_poly_eval_batch(gpu, n, batch):
-    """Both evaluation paths -- the one-launch kernel for <= 64 blocks of 1024 coefficients and the table-driven one -- against
+    """Both evaluation paths -- the one-launch kernel for <= 256 blocks of 1024 coefficients and the table-driven one -- against
     the oracle; repeated calls (the one-launch kernel's arrival counters must come back to zero) and the forced other path."""
     c = rand_fr_wire(n * batch, 10 + n).reshape(batch, n, 4)
     x = rand_fr_wire(1, 77)[0]

@@ -133,13 +133,13 @@ __global__ __launch_bounds__(64) void poly_eval_finish_kernel(const Fp* __restri
 }
 
 
-// Small polynomials (<= 64 blocks of 1024 coefficients: the prover's n = 2^14 and its 6n quotient pieces): ONE launch.
+// Small polynomials (<= 256 blocks of 1024 coefficients: the prover's n = 2^14 and its 6n = 98304 quotient domain): ONE launch.
 // grid (nblocks, batch), 256 lanes = one wave per SIMD.  Each workgroup builds its own power table x^(4 t), t < 256, in
 // LDS by doubling (eight levels of one product and one squaring -- the separate table kernel's square-and-multiply per
 // lane took 16 us), evaluates its 1024 coefficients, weights the sum by x^(1024 blk), and the last workgroup of a
 // polynomial to arrive (a counter per polynomial, reset by that workgroup) adds the block sums and stores the value
 // straight into pinned host memory: no table kernel, no finish kernel, no copy kernel.
-constexpr int kEvalSmallPer = 4, kEvalSmallBlock = 256 * kEvalSmallPer, kEvalSmallMaxBlocks = 64;
+constexpr int kEvalSmallPer = 4, kEvalSmallBlock = 256 * kEvalSmallPer, kEvalSmallMaxBlocks = 256;
 __global__ __launch_bounds__(256) void poly_eval_small_kernel(const Fp* __restrict__ coefs, uint64_t n, Fp x, Fp* __restrict__ partial,
                                                               uint32_t* __restrict__ counters, Fp* __restrict__ out_host) {
     __shared__ Fp pw[256];
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void poly_eval_small_kernel(const Fp* __restri
         s = Fr::sqr(s);
         __syncthreads();
     }
-    // s = x^1024: the block's weight is s^blk (blk < 64)
+    // s = x^1024: the block's weight is s^blk (blk < 256)
     Fp wblk = Fr::one(), sp = s;
     for (uint32_t e = blk; e; e >>= 1) {
         if (e & 1) wblk = Fr::mul(wblk, sp);
