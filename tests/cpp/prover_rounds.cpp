@@ -13,7 +13,11 @@
 // (transcript / rng are out of scope).  Inputs and outputs are raw little-endian files in a directory written / read by
 // tests/test_gpu_cpp_mirror.py, which compares the outputs with the oracle chain (tests/chain_oracle.py).
 //
-// usage: prover_rounds <dir> [reps]      (reps > 0: also time `reps` chains and print ms per chain)
+// usage: prover_rounds <dir> [reps] [threads]
+//   reps > 0: also time `reps` chains and print ms per chain;
+//   threads > 1: after the checked single chain, `threads` host threads -- each with its own context (uzk_ctx_create:
+//   own stream, workspaces and lock) and its own device buffers, all sharing the one registered SRS -- run `reps` chains
+//   each at the same time: proofs per second of one GPU serving several provers.
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -21,7 +25,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/uzkge_gpu.h"
@@ -55,18 +61,18 @@ static void wr(const char* name, const void* p, size_t bytes) {
 }
 template <class T> static T* dmalloc(size_t count) { void* p; HK(hipMalloc(&p, count * sizeof(T))); return static_cast<T*>(p); }
 
-int main(int argc, char** argv) {
-    if (argc < 2) { std::printf("usage: prover_rounds <dir> [reps]\n"); return 2; }
-    g_dir = argv[1];
-    const int reps = argc > 2 ? std::atoi(argv[2]) : 0;
-    CK(uzk_init(0));
+// One prover: reads the inputs, makes them resident, runs the chain (once for the outputs, then timed).  `gate`: workers
+// of a multi-threaded run meet there after their warm-up so that the timed loops overlap.
+static void worker(uint64_t srs, int reps, bool write_outputs, bool own_context, std::atomic<int>* gate, int gate_n, double* ms_out) {
+    HK(hipSetDevice(0));
+    uint64_t ctx = 0;
+    if (own_context) { CK(uzk_ctx_create(&ctx)); CK(uzk_ctx_set_current(ctx)); }
     hipStream_t st = static_cast<hipStream_t>(uzk_stream());     // all copies go on the library stream: ordered with its kernels
 
     // ---- inputs
     const auto meta = rd<uint64_t>("meta");                       // n, shuffle
     const size_t n = meta[0], m = 6 * n;
     const bool shuffle = meta[1] != 0;
-    const auto bases = rd<uzk_g1_affine>("bases");                // n + 6 points
     const auto evals9 = rd<Fr>("evals9");                         // w0..w4, wsel0..2, pi  (9 n)
     const auto perm = rd<uint32_t>("perm");
     const auto tables = rd<Fr>("tables");                         // 46 m
@@ -78,10 +84,7 @@ int main(int argc, char** argv) {
     const auto blinds_w = rd<Fr>("blinds_w"), blinds_wsel = rd<Fr>("blinds_wsel"), blinds_z = rd<Fr>("blinds_z");   // 5x2, 3x2, 3
     const auto t_rands = rd<Fr>("t_rands"), r_scalars = rd<Fr>("r_scalars");                                       // 5, 12
 
-    // ---- device residency
-    uint64_t srs = 0;
-    CK(uzk_srs_register(bases.data(), bases.size(), &srs));
-    if (meta.size() > 2 && meta[2]) CK(uzk_srs_precompute(srs, 0));
+    // ---- device residency (the SRS is registered once, by main)
     Fr* d_evals = dmalloc<Fr>(9 * n);   HK(hipMemcpy(d_evals, evals9.data(), 9 * n * sizeof(Fr), hipMemcpyHostToDevice));
     uint32_t* d_perm = dmalloc<uint32_t>(5 * n); HK(hipMemcpy(d_perm, perm.data(), 5 * n * 4, hipMemcpyHostToDevice));
     Fr* d_tables = dmalloc<Fr>(46 * m); HK(hipMemcpy(d_tables, tables.data(), 46 * m * sizeof(Fr), hipMemcpyHostToDevice));
@@ -198,6 +201,7 @@ int main(int argc, char** argv) {
 
     chain();
     CK(uzk_sync());
+    if (write_outputs) {
     // ---- outputs
     wr("cm_w_wsel", cm_w_wsel, sizeof cm_w_wsel); wr("cm_z", cm_z, sizeof cm_z); wr("cm_t", cm_t, sizeof cm_t); wr("cm_q", cm_q, sizeof cm_q);
     wr("evals_zeta", evals_zeta.data(), 10 * 32); wr("z_eval_zeta_omega", z_eval_zo.data(), 32);
@@ -212,15 +216,49 @@ int main(int argc, char** argv) {
     dump("coefs", d_coefs, 10 * m); dump("coset_evals", d_coset, 10 * m); dump("t_quotient", d_tq, m); dump("t", d_t, m);
     dump("z_evals", d_z, n); dump("r", d_r, n + 3);
     { uint64_t nulls = 0; for (int i = 0; i < UZK_TQ_NVEC; ++i) nulls += tq_ptrs[i] == nullptr; wr("tq_null_slots", &nulls, 8); }
+    }
 
     if (reps > 0) {
         for (int r = 0; r < 3; ++r) chain();        // settle workspaces, plans and clocks before timing
         CK(uzk_sync());
+        if (gate) { gate->fetch_add(1); while (gate->load() < gate_n) std::this_thread::yield(); }
         const auto t0 = std::chrono::steady_clock::now();
         for (int r = 0; r < reps; ++r) chain();
         CK(uzk_sync());
-        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / reps;
-        std::printf("{\"ms_per_chain\": %.4f, \"reps\": %d, \"n\": %zu}\n", ms, reps, n);
+        *ms_out = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / reps;
+    }
+    for (void* p : {(void*)d_evals, (void*)d_perm, (void*)d_tables, (void*)d_coefs, (void*)d_tmp, (void*)d_coset, (void*)d_tq, (void*)d_t, (void*)d_z,
+                    (void*)d_sc, (void*)d_chunks, (void*)d_fold, (void*)d_q, (void*)d_r, (void*)d_open, (void*)d_group}) HK(hipFree(p));
+    HK(hipHostFree(h_tails));
+    if (own_context) { CK(uzk_ctx_set_current(0)); CK(uzk_ctx_destroy(ctx)); }
+}
+
+int main(int argc, char** argv) {
+    if (argc < 2) { std::printf("usage: prover_rounds <dir> [reps] [threads]\n"); return 2; }
+    g_dir = argv[1];
+    const int reps = argc > 2 ? std::atoi(argv[2]) : 0;
+    const int threads = argc > 3 ? std::atoi(argv[3]) : 1;
+    CK(uzk_init(0));
+    const auto meta = rd<uint64_t>("meta");
+    const auto bases = rd<uzk_g1_affine>("bases");                // n + 6 points
+    uint64_t srs = 0;
+    CK(uzk_srs_register(bases.data(), bases.size(), &srs));
+    if (meta.size() > 2 && meta[2]) CK(uzk_srs_precompute(srs, 0));
+    double ms = 0;
+    worker(srs, reps, true, false, nullptr, 0, &ms);
+    if (reps > 0) std::printf("{\"ms_per_chain\": %.4f, \"reps\": %d, \"n\": %llu}\n", ms, reps, (unsigned long long)meta[0]);
+    if (threads > 1 && reps > 0) {
+        std::atomic<int> gate{0};
+        std::vector<double> per(threads, 0.0);
+        std::vector<std::thread> pool;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int t = 0; t < threads; ++t) pool.emplace_back(worker, srs, reps, false, true, &gate, threads, &per[t]);
+        for (auto& th : pool) th.join();
+        (void)t0;
+        double worst = 0;
+        for (double v : per) worst = v > worst ? v : worst;
+        std::printf("{\"threads\": %d, \"ms_per_chain_slowest_thread\": %.4f, \"proofs_per_s\": %.1f, \"single_thread_proofs_per_s\": %.1f}\n", threads, worst,
+                    threads * 1e3 / worst, 1e3 / ms);
     }
     std::printf("OK\n");
     CK(uzk_srs_release(srs));
