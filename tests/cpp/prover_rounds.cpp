@@ -63,7 +63,8 @@ template <class T> static T* dmalloc(size_t count) { void* p; HK(hipMalloc(&p, c
 
 // One prover: reads the inputs, makes them resident, runs the chain (once for the outputs, then timed).  `gate`: workers
 // of a multi-threaded run meet there after their warm-up so that the timed loops overlap.
-static void worker(uint64_t srs, int reps, bool write_outputs, bool own_context, std::atomic<int>* gate, int gate_n, double* ms_out) {
+static void worker(uint64_t srs, int reps, bool write_outputs, bool own_context, std::atomic<int>* gate, int gate_n, double* ms_out,
+                   std::vector<uint64_t>* digest_out) {
     HK(hipSetDevice(0));
     uint64_t ctx = 0;
     if (own_context) { CK(uzk_ctx_create(&ctx)); CK(uzk_ctx_set_current(ctx)); }
@@ -227,6 +228,13 @@ static void worker(uint64_t srs, int reps, bool write_outputs, bool own_context,
         CK(uzk_sync());
         *ms_out = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / reps;
     }
+    if (digest_out) {      // what this prover produced last: affine commitments and the evaluations (compared across threads)
+        auto put_points = [&](const uzk_g1_jac* j, int count) {
+            for (int i = 0; i < count; ++i) { uzk_g1_affine a; CK(uzk_g1_to_affine(&j[i], &a)); digest_out->insert(digest_out->end(), a.x, a.x + 4); digest_out->insert(digest_out->end(), a.y, a.y + 4); }
+        };
+        put_points(cm_w_wsel, 8); put_points(cm_z, 1); put_points(cm_t, 5); put_points(cm_q, 2);
+        for (const auto* v : {&evals_zeta, &z_eval_zo, &open_ev_zeta, &open_ev_zo}) for (const Fr& f : *v) digest_out->insert(digest_out->end(), f.l, f.l + 4);
+    }
     for (void* p : {(void*)d_evals, (void*)d_perm, (void*)d_tables, (void*)d_coefs, (void*)d_tmp, (void*)d_coset, (void*)d_tq, (void*)d_t, (void*)d_z,
                     (void*)d_sc, (void*)d_chunks, (void*)d_fold, (void*)d_q, (void*)d_r, (void*)d_open, (void*)d_group}) HK(hipFree(p));
     HK(hipHostFree(h_tails));
@@ -245,20 +253,22 @@ int main(int argc, char** argv) {
     CK(uzk_srs_register(bases.data(), bases.size(), &srs));
     if (meta.size() > 2 && meta[2]) CK(uzk_srs_precompute(srs, 0));
     double ms = 0;
-    worker(srs, reps, true, false, nullptr, 0, &ms);
+    std::vector<uint64_t> digest0;
+    worker(srs, reps, true, false, nullptr, 0, &ms, &digest0);
     if (reps > 0) std::printf("{\"ms_per_chain\": %.4f, \"reps\": %d, \"n\": %llu}\n", ms, reps, (unsigned long long)meta[0]);
     if (threads > 1 && reps > 0) {
         std::atomic<int> gate{0};
         std::vector<double> per(threads, 0.0);
+        std::vector<std::vector<uint64_t>> digests(threads);
         std::vector<std::thread> pool;
-        const auto t0 = std::chrono::steady_clock::now();
-        for (int t = 0; t < threads; ++t) pool.emplace_back(worker, srs, reps, false, true, &gate, threads, &per[t]);
+        for (int t = 0; t < threads; ++t) pool.emplace_back(worker, srs, reps, false, true, &gate, threads, &per[t], &digests[t]);
         for (auto& th : pool) th.join();
-        (void)t0;
         double worst = 0;
-        for (double v : per) worst = v > worst ? v : worst;
-        std::printf("{\"threads\": %d, \"ms_per_chain_slowest_thread\": %.4f, \"proofs_per_s\": %.1f, \"single_thread_proofs_per_s\": %.1f}\n", threads, worst,
-                    threads * 1e3 / worst, 1e3 / ms);
+        bool agree = true;
+        for (int t = 0; t < threads; ++t) { worst = per[t] > worst ? per[t] : worst; agree = agree && digests[t] == digest0 && !digest0.empty(); }
+        std::printf("{\"threads\": %d, \"ms_per_chain_slowest_thread\": %.4f, \"proofs_per_s\": %.1f, \"single_thread_proofs_per_s\": %.1f, "
+                    "\"threads_agree_with_single\": %s}\n", threads, worst, threads * 1e3 / worst, 1e3 / ms, agree ? "true" : "false");
+        if (!agree) { std::printf("FAILED: a thread's commitments / evaluations differ from the single-threaded chain\n"); return 1; }
     }
     std::printf("OK\n");
     CK(uzk_srs_release(srs));

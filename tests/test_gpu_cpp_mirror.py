@@ -84,8 +84,10 @@ def test_cpp_prover_rounds_match_frozen_outputs(gpu, tmp_path):
     inp = ChainInputs(n, int(V2["seed"][0]))
     _write_inputs(inp, str(tmp_path))
     exe = _build_rounds()
-    r = subprocess.run([exe, str(tmp_path), "3"], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+    # 3 timed chains, then 3 host threads (one context each, one shared SRS) running 3 chains each at the same time: every
+    # thread must end with the single-threaded chain's commitments and evaluations
+    r = subprocess.run([exe, str(tmp_path), "3", "3"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout and '"threads_agree_with_single": true' in r.stdout, r.stdout + r.stderr
     rd = lambda name, shape: np.fromfile(os.path.join(str(tmp_path), "out_" + name + ".bin"), dtype=np.uint64).reshape(shape)
     for key, cnt in (("cm_w_wsel", 8), ("cm_z", 1), ("cm_t", 5), ("cm_q", 2)):
         jac = rd(key, (cnt, 12))
