@@ -586,10 +586,13 @@ def run_rank(args) -> None:
                 from test_gpu_cpp_mirror import _write_inputs
                 with tempfile.TemporaryDirectory() as td:
                     _write_inputs(prover_chain.ChainInputs(1 << 14, 11), td, precompute=True)
-                    r = subprocess.run([exe, td, "20"], capture_output=True, text=True, timeout=300)
+                    r = subprocess.run([exe, td, "20", "4"], capture_output=True, text=True, timeout=300)
                 line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
                 extra["prover_rounds_cpp"] = dict(json.loads(line[0]), what="the chain above issued from C++ through the C ABI only "
-                                                  "(no interpreter between the calls), window table, ms per chain") if line else {"error": r.stderr[-300:]}
+                                                  "(no interpreter between the calls), window table, ms per chain; four_threads = four host "
+                                                  "threads with one context each running chains at the same time") if line else {"error": r.stderr[-300:]}
+                if len(line) > 1:
+                    extra["prover_rounds_cpp"]["four_threads"] = json.loads(line[1])
         except Exception as e:
             extra["prover_rounds_cpp"] = {"error": str(e)}
 
