@@ -1795,26 +1795,26 @@ public:
         for (unsigned t = 0; t < nthreads; ++t) workers_.emplace_back([this] { loop(); });
     }
     ~HornerPool() {
-        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; ++gen_; }
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
         cv_.notify_all();
         for (auto& w : workers_) w.join();
     }
-    // runs fn(i) for i in [0, count), the caller included; returns when all are done
+    // runs fn(i) for i in [0, count), the caller included; returns when all are done.  Several contexts may be inside at
+    // once: every call is a job of its own in the list the workers serve (a caller only works on its own job), so a
+    // second prover's batch neither waits for the first one's nor falls back to doing all its sums alone.
     void run(uint32_t count, const std::function<void(uint32_t)>& fn) {
-        // one batch at a time: a second context that arrives while the pool is busy does its own sums in its own thread
-        std::unique_lock<std::mutex> busy(run_mu_, std::try_to_lock);
-        if (!busy.owns_lock()) { for (uint32_t i = 0; i < count; ++i) fn(i); return; }
-        // every call owns its counters: a worker that wakes late still holds the job it saw under the
-        // lock and can only find that job exhausted, never the next call's indices
+        // every job owns its counters: a worker that wakes late still holds the job it saw under the lock and can only
+        // find that job exhausted, never another call's indices
         auto job = std::make_shared<Job>();
         job->fn = &fn;
         job->count = count;
-        { std::lock_guard<std::mutex> lk(mu_); job_ = job; ++gen_; }
+        { std::lock_guard<std::mutex> lk(mu_); active_.push_back(job); }
         cv_.notify_all();
         work(*job);
         std::unique_lock<std::mutex> lk(mu_);
         cv_done_.wait(lk, [&] { return job->done.load() >= count; });
-        job_.reset();
+        for (size_t i = 0; i < active_.size(); ++i)
+            if (active_[i] == job) { active_.erase(active_.begin() + (long)i); break; }
     }
 private:
     struct Job {
@@ -1830,25 +1830,26 @@ private:
             if (j.done.fetch_add(1) + 1 >= j.count) { std::lock_guard<std::mutex> lk(mu_); cv_done_.notify_all(); }
         }
     }
+    // a job that still has indices to hand out (mu_ held)
+    std::shared_ptr<Job> pending_locked() const {
+        for (const auto& j : active_) if (j->next.load() < j->count) return j;
+        return nullptr;
+    }
     void loop() {
-        uint64_t seen = 0;
         for (;;) {
             std::shared_ptr<Job> j;
             {
                 std::unique_lock<std::mutex> lk(mu_);
-                cv_.wait(lk, [&] { return gen_ != seen; });
-                seen = gen_;
+                cv_.wait(lk, [&] { return stop_ || (j = pending_locked()) != nullptr; });
                 if (stop_) return;
-                j = job_;
             }
-            if (j) work(*j);
+            work(*j);
         }
     }
     std::vector<std::thread> workers_;
-    std::mutex mu_, run_mu_;
+    std::mutex mu_;
     std::condition_variable cv_, cv_done_;
-    std::shared_ptr<Job> job_;
-    uint64_t gen_ = 0;
+    std::vector<std::shared_ptr<Job>> active_;
     bool stop_ = false;
 };
 // process-wide, shared by every context, created on first use and joined at process exit
