@@ -4,6 +4,7 @@
 // UZK_ERR_DEVICE.
 #include <algorithm>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
 
 #include "ctx.hpp"
@@ -112,6 +113,15 @@ int Ctx::prof_collect() {
 static int g_last_device = 0;
 
 // binds the process to `device` (Shared::mu held by the caller)
+// The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); contexts are one
+// stream each, and with more than four provers in a process their kernels queue behind each other.  Ask for 16 unless
+// the environment already says something -- effective when this library makes the process's first HIP call (a compiled
+// prover), harmless otherwise (the runtime has read its settings by then; set the variable outside in that case).
+static void prefer_more_hw_queues() {
+    static const bool once = [] { return setenv("GPU_MAX_HW_QUEUES", "16", /*overwrite*/ 0) == 0; }();
+    (void)once;
+}
+
 static int bind_device_locked(Shared& s, int device) {
     UZK_HIP(hipSetDevice(device));
     hipDeviceProp_t prop;
@@ -133,6 +143,7 @@ int require_ready() {
         std::lock_guard<std::mutex> lk(s.mu);
         if (!s.bound) {
             // lazy init (device 0, or the one uzk_init bound before a shutdown) so a plain library user need not call uzk_init
+            prefer_more_hw_queues();
             int n = 0;
             if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
                 set_error("no HIP device visible: the MI355X backend has no CPU fallback");
@@ -202,6 +213,7 @@ int uzk_init(int device) {
             return UZK_ERR_PARAMETER;
         }
         if (!s.bound) {
+            prefer_more_hw_queues();
             int n = 0;
             if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
                 set_error("no HIP device visible: the MI355X backend has no CPU fallback");
