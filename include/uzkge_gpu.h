@@ -50,7 +50,9 @@ typedef struct { uint64_t x[4], y[4], z[4]; } uzk_g1_jac;
 
 /* ---- lifecycle ------------------------------------------------------------------------ */
 /* Bind the calling process to HIP device `device` (one process per GPU); idempotent for the
- * same ordinal.  Creates the library stream and workspaces. */
+ * same ordinal.  Creates the library stream and workspaces.  Side effect: sets GPU_MAX_HW_QUEUES=16 in the process
+ * environment unless it is already set (contexts are one stream each; the HIP runtime's default of four hardware queues
+ * makes more than four provers queue behind each other) -- effective when this is the process's first HIP call. */
 int uzk_init(int device);
 int uzk_shutdown(void);
 /* Number of visible HIP devices (0 when none / no driver); never fails. */
