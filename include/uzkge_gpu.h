@@ -244,7 +244,8 @@ int uzk_synth_scalars_mix(void* d_scalars, size_t n, uint64_t seed);
  * assembly products 10 / 16 / 20.  a, b, out: n elements (host memory). */
 int uzk_field_op_device(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 /* op: 0 a + b (mixed add), 1 a + b (full XYZZ add), 2 2a, 3 a - b, 4 2(a + b); 5..7 the four-lane addition of the
- * small-MSM folds (ecquad.hpp): 5 a + b, 6 2(a + b) (its doubling branch), 7 (a + b) + (a - b).  Inputs affine
+ * small-MSM folds (ecquad.hpp): 5 a + b, 6 2(a + b) (its doubling branch), 7 (a + b) + (a - b); 8..10 the same three on the
+ * 29-bit-limb form (ecquad29.hpp), 11 4(a + b) by two quad doublings, 12 2(a + b) by one, 13 4a.  Inputs affine
  * (infinity = zeros), outputs Jacobian. */
 int uzk_g1_op_device(int op, const uzk_g1_affine* a, const uzk_g1_affine* b, uzk_g1_jac* out, size_t n);
 

@@ -87,11 +87,20 @@ def test_group_ops_match_oracle(gpu):
     msub = gpu.g1_op(3, a, b)
     twice = gpu.g1_op(4, a, b)
     qadd, qtwice, qmix = gpu.g1_op(5, a, b), gpu.g1_op(6, a, b), gpu.g1_op(7, a, b)     # four-lane addition (ecquad.hpp)
+    q29 = [gpu.g1_op(op, a, b) for op in (8, 9, 10, 11, 12, 13)]                                # ... on 29-bit limbs (ecquad29.hpp)
     for i in range(n):
         s = opy.g1_add(pa[i], pb[i])
         assert aff(qadd[i]) == s, i
         assert aff(qtwice[i]) == opy.g1_add(s, s), i
         assert aff(qmix[i]) == opy.g1_add(s, opy.g1_add(pa[i], opy.g1_neg(pb[i]))), i
+        assert aff(q29[0][i]) == s, i
+        assert aff(q29[1][i]) == opy.g1_add(s, s), i
+        assert aff(q29[2][i]) == opy.g1_add(s, opy.g1_add(pa[i], opy.g1_neg(pb[i]))), i
+        s2 = opy.g1_add(s, s)
+        assert aff(q29[3][i]) == opy.g1_add(s2, s2), i                # two doublings of an addition's (lazy) result
+        assert aff(q29[4][i]) == s2, i
+        a2 = opy.g1_add(pa[i], pa[i])
+        assert aff(q29[5][i]) == opy.g1_add(a2, a2), i                # a doubling of a doubling's result
         assert aff(madd[i]) == s, i
         assert aff(full[i]) == s, i
         assert aff(dbl[i]) == opy.g1_add(pa[i], pa[i]), i

@@ -718,7 +718,7 @@ int uzk_field_op_device(int field, int op, const uint64_t* a, const uint64_t* b,
 int uzk_g1_op_device(int op, const uzk_g1_affine* a, const uzk_g1_affine* b, uzk_g1_jac* out, size_t n) {
     API_LOCK;
     if (n > 0 && (!a || !b || !out)) { set_error("uzk_g1_op_device: null pointer"); return UZK_ERR_PARAMETER; }
-    if (op < 0 || op > 7) { set_error("uzk_g1_op_device: bad op"); return UZK_ERR_PARAMETER; }
+    if (op < 0 || op > 13) { set_error("uzk_g1_op_device: bad op"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
     return g1_op_device(ctx(), op, reinterpret_cast<const Affine*>(a), reinterpret_cast<const Affine*>(b),
                         reinterpret_cast<Jac*>(out), n);
@@ -809,6 +809,7 @@ int uzk_tune(const char* key, int value) {
     else if (!std::strcmp(key, "msm_small")) c.tune_small = value;
     else if (!std::strcmp(key, "msm_fold_mode")) c.tune_fold_mode = value;
     else if (!std::strcmp(key, "msm_quad_reduce")) c.tune_quad_reduce = value;
+    else if (!std::strcmp(key, "msm_x29")) c.tune_x29 = value;
     else if (!std::strcmp(key, "poly_small")) c.tune_poly_small = value;
     else if (!std::strcmp(key, "msm_chunk_log")) c.tune_chunk_log = (value >= 8 && value <= 26) ? value : 26;
     else { set_error("uzk_tune: unknown key %s", key); return UZK_ERR_PARAMETER; }

@@ -81,6 +81,7 @@ struct Ctx {
     int tune_fold_group = 0;
     int tune_scan_reduce = 1; // bucket reduction by suffix scans: 1 = for windows of <= 2^14 buckets, 2 = always, 3 = always with quads, 0 = never
     int tune_poly_small = 1;  // 1: one-launch kernels for small polynomials (evaluation)
+    int tune_x29 = 1;         // 1: quad reductions on the 29-bit-limb form (ecquad29.hpp), 0: on the 8 x 32-bit arithmetic
     int tune_quad_reduce = 1; // 1: up to 2^19 buckets the scan reduction runs on quads (ecquad.hpp); 0: lanes only
     int tune_reduce_seg = 0;  // experiment: buckets per lane in the bucket reduction (0 = default)
     int tune_fused_hist = 1;  // 1: the digit kernel also produces the first sort pass's histograms (large n)

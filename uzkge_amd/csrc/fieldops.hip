@@ -3,6 +3,7 @@
 // add / double / mixed-add including P+P, P+(-P) and infinity; SURVEY.md 8c "golden vectors").
 #include "ctx.hpp"
 #include "ecquad.hpp"
+#include "ecquad29.hpp"
 #include "fp29.hpp"
 
 namespace uzk {
@@ -107,6 +108,53 @@ __global__ __launch_bounds__(256) void g1_quad_op_kernel(int op, const Affine* _
     if (q == 0) out[i] = xyzz_to_jac(acc);
 }
 
+// ops 8..13: the same on the 29-bit-limb representation (ecquad29.hpp): 8 a + b, 9 2(a + b) through the addition's
+// doubling branch, 10 (a + b) + (a - b), 11 4(a + b) by two quad doublings, 12 2(a + b) by one, 13 4a
+__global__ __launch_bounds__(256) void g1_quad29_op_kernel(int op, const Affine* __restrict__ a, const Affine* __restrict__ b,
+                                                           Jac* __restrict__ out, size_t n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t i = gt >> 2;
+    const uint32_t q = (uint32_t)(gt & 3);
+    if (i >= n) return;
+    const Affine p = a[i], r = b[i];
+    XYZZ s = xyzz_from_affine(p), t = xyzz_from_affine(r);
+    X29 acc;
+    if (op == 8) {
+        acc = x29_from_xyzz_quad(s, q);
+        x29_add_quad(acc, x29_from_xyzz_quad(t, q), q);
+    } else if (op == 9) {
+        xyzz_madd(s, r, false);
+        acc = x29_from_xyzz_quad(s, q);
+        const X29 same = acc;
+        x29_add_quad(acc, same, q);
+    } else if (op == 10) {
+        XYZZ u = s;
+        xyzz_madd(s, r, false);
+        xyzz_madd(u, r, true);
+        acc = x29_from_xyzz_quad(s, q);
+        x29_add_quad(acc, x29_from_xyzz_quad(u, q), q);
+    } else if (op == 11) {
+        acc = x29_from_xyzz_quad(s, q);
+        x29_add_quad(acc, x29_from_xyzz_quad(t, q), q);
+        x29_dbl_quad(acc, q);
+        x29_dbl_quad(acc, q);
+    } else if (op == 12) {                           // 2(a + b): one doubling of an addition's result
+        acc = x29_from_xyzz_quad(s, q);
+        x29_add_quad(acc, x29_from_xyzz_quad(t, q), q);
+        x29_dbl_quad(acc, q);
+    } else {                                         // 4a: doubling of a doubling's result
+        acc = x29_from_xyzz_quad(s, q);
+        x29_dbl_quad(acc, q);
+        x29_dbl_quad(acc, q);
+    }
+    const Fp mine = x29_coord_to_fp(acc, q);
+    XYZZ o;
+    o.x = quad_bcast<0>(mine); o.y = quad_bcast<1>(mine); o.zz = quad_bcast<2>(mine); o.zzz = quad_bcast<3>(mine);
+    if (q == 0) out[i] = xyzz_to_jac(o);
+#endif
+}
+
 int field_op_device(Ctx& c, int field, int op, const Fp* a, const Fp* b, Fp* out, size_t n) {
     if (n == 0) return UZK_OK;
     Fp *da = nullptr, *db = nullptr, *dout = nullptr;
@@ -136,7 +184,8 @@ int g1_op_device(Ctx& c, int op, const Affine* a, const Affine* b, Jac* out, siz
     UZK_HIP(hipMalloc(reinterpret_cast<void**>(&dout), n * sizeof(Jac)));
     UZK_HIP(hipMemcpyAsync(da, a, n * sizeof(Affine), hipMemcpyHostToDevice, c.stream));
     UZK_HIP(hipMemcpyAsync(db, b, n * sizeof(Affine), hipMemcpyHostToDevice, c.stream));
-    if (op >= 5) hipLaunchKernelGGL(g1_quad_op_kernel, dim3((unsigned)((4 * n + 255) / 256)), dim3(256), 0, c.stream, op, da, db, dout, n);
+    if (op >= 8) hipLaunchKernelGGL(g1_quad29_op_kernel, dim3((unsigned)((4 * n + 255) / 256)), dim3(256), 0, c.stream, op, da, db, dout, n);
+    else if (op >= 5) hipLaunchKernelGGL(g1_quad_op_kernel, dim3((unsigned)((4 * n + 255) / 256)), dim3(256), 0, c.stream, op, da, db, dout, n);
     else hipLaunchKernelGGL(g1_op_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, op, da, db, dout, n);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out, dout, n * sizeof(Jac), hipMemcpyDeviceToHost, c.stream);

@@ -103,6 +103,17 @@ struct Field29 {
         r.l[8] = a.l[8] + c;
         return r;
     }
+    // One parallel carry step: every limb keeps its low 29 bits and receives its lower neighbour's excess.  Limbs < 2^32 in,
+    // limbs < 2^29 + 2^3 out (top limb: the rest), value unchanged -- enough for the products' limb contract, and unlike
+    // norm() not a serial chain through the eight limbs (what a lone wave pays for in the latency-bound quad operations).
+    __device__ __forceinline__ static L29 norm1(const L29& a) {
+        L29 r;
+        r.l[0] = a.l[0] & MASK;
+#pragma unroll
+        for (int i = 1; i < 8; ++i) r.l[i] = (a.l[i] & MASK) + (a.l[i - 1] >> 29);
+        r.l[8] = a.l[8] + (a.l[7] >> 29);
+        return r;
+    }
     // Montgomery product, radix 2^261 (contract in the header comment)
     __device__ __forceinline__ static L29 mul(const L29& a, const L29& b) { return l29_mul_asm<C>(a, b); }
     __device__ __forceinline__ static L29 sqr(const L29& a) { return l29_sqr_asm<C>(a); }

@@ -39,6 +39,7 @@
 #include "ctx.hpp"
 #include "ec29.hpp"
 #include "ecquad.hpp"
+#include "ecquad29.hpp"
 #include "host_ec64.hpp"
 #include "host_math.hpp"
 
@@ -1134,11 +1135,14 @@ __global__ __launch_bounds__(256) void msm_small_fold_kernel(XYZZ* __restrict__ 
 // window sum = sum_{b >= 1} b * B_b = sum over t of the inclusive suffix sums Suffix_t = B_(t+1) + B_(t+2) + ... (t = b - 1):
 // log2(NBL) scan steps, then a tree over the NBL suffixes.
 // QUAD: min(NBL, 64) quads (block 4 min(NBL, 64)); else one lane per bucket (block NBL).  Dynamic LDS 128 B per quad / lane.
-template <bool QUAD, int MAXT>
+// QMODE: 0 = one lane per bucket, 1 = quads on the 8 x 32-bit arithmetic (ecquad.hpp), 2 = quads on 29-bit limbs
+// (ecquad29.hpp: buckets converted as they are loaded, the window sum converted back by the four lanes of quad 0).
+template <int QMODE, int MAXT>
 __global__ __launch_bounds__(MAXT) void msm_small_reduce_kernel(XYZZ* __restrict__ P, const uint32_t* __restrict__ bucket_ref,
                                                                 const SmallChunk* __restrict__ cdesc,
                                                                 const uint2* __restrict__ slot_chunks, SmallLevels lv,
                                                                 XYZZ* __restrict__ win_sums, uint32_t NBL) {
+    constexpr bool QUAD = QMODE != 0;
     extern __shared__ uint4 sm_red[];
     XYZZ* sh = reinterpret_cast<XYZZ*>(sm_red);
     const uint32_t slot = blockIdx.x, tid = threadIdx.x;
@@ -1169,12 +1173,50 @@ __global__ __launch_bounds__(MAXT) void msm_small_reduce_kernel(XYZZ* __restrict
         }
         __syncthreads();
     }
-    if constexpr (QUAD) {
+    if constexpr (QMODE == 2) {
         // Q = min(NBL, 64) quads -- 256 lanes, ONE wave per SIMD (a second wave on the SIMD doubles the time of every
         // dependent step) -- quad t owns the r = NBL / Q consecutive buckets t r .. t r + r - 1 (array index i = b - 1):
         //   run_t = sum_j B, acc_t = sum_j (j + 1) B            (running sums from the top bucket down: 2 (r - 1) additions)
         //   sum_b b B_b = sum_t acc_t + r sum_{t >= 1} Suf_t,   Suf_t = run_t + run_(t+1) + ...   (log2 Q scan steps)
         // then a tree over V_t = acc_t + r Suf_t (t >= 1), V_0 = acc_0.
+        const uint32_t Q = blockDim.x >> 2, r = NBL / Q;
+        X29* sh29 = reinterpret_cast<X29*>(sm_red);
+        X29 run = x29_inf(), acc = x29_inf();
+        for (uint32_t j = r; j-- > 0;) {
+            const uint32_t ref = bucket_ref[(size_t)slot * NBL + t * r + j];
+            if (ref != kSmallNone) { const XYZZ bk = P[ref]; x29_add_quad(run, x29_from_xyzz_quad(bk, q), q); }
+            if (r > 1) x29_add_quad(acc, run, q); else acc = run;
+        }
+        if (writer) sh29[t] = run;
+        __syncthreads();
+        for (uint32_t off = 1; off < Q; off <<= 1) {
+            const bool has = t + off < Q;
+            X29 v;
+            if (has) v = sh29[t + off];
+            __syncthreads();
+            if (has) {
+                x29_add_quad(run, v, q);
+                if (writer) sh29[t] = run;
+            }
+            __syncthreads();
+        }
+        if (t >= 1) {
+            for (uint32_t d = 1; d < r; d <<= 1) x29_dbl_quad(run, q);
+            x29_add_quad(acc, run, q);
+        }
+        if (writer) sh29[t] = acc;
+        __syncthreads();
+        for (uint32_t s2 = Q >> 1; s2 > 0; s2 >>= 1) {
+            if (t < s2) {
+                const X29 v = sh29[t + s2];
+                x29_add_quad(acc, v, q);
+                if (writer) sh29[t] = acc;
+            }
+            __syncthreads();
+        }
+        if (t == 0) reinterpret_cast<Fp*>(&win_sums[slot])[q] = x29_coord_to_fp(acc, q);      // x | y | zz | zzz by the quad's four lanes
+    } else if constexpr (QMODE == 1) {
+        // the same on the 8 x 32-bit arithmetic
         const uint32_t Q = blockDim.x >> 2, r = NBL / Q;
         XYZZ run = xyzz_inf(), acc = xyzz_inf();
         for (uint32_t j = r; j-- > 0;) {
@@ -2020,11 +2062,14 @@ static int msm_run_small(Ctx& c, const Affine* points, const Fp* d_scalars, size
         {
             KernelScope ks(c, "msm_small_reduce");
             const uint32_t Q = std::min<uint32_t>(NBL, 64);
-            if (c.tune_small != 2)
-                hipLaunchKernelGGL((msm_small_reduce_kernel<true, 256>), dim3(S), dim3(4 * Q), (size_t)Q * sizeof(XYZZ), st, P, bucket_ref, cdesc,
+            if (c.tune_small != 2 && c.tune_x29)
+                hipLaunchKernelGGL((msm_small_reduce_kernel<2, 256>), dim3(S), dim3(4 * Q), (size_t)Q * 144, st, P, bucket_ref, cdesc,
+                                   slot_chunks, lv, win_sums, NBL);
+            else if (c.tune_small != 2)
+                hipLaunchKernelGGL((msm_small_reduce_kernel<1, 256>), dim3(S), dim3(4 * Q), (size_t)Q * sizeof(XYZZ), st, P, bucket_ref, cdesc,
                                    slot_chunks, lv, win_sums, NBL);
             else
-                hipLaunchKernelGGL((msm_small_reduce_kernel<false, 512>), dim3(S), dim3(NBL), (size_t)NBL * sizeof(XYZZ), st, P, bucket_ref, cdesc,
+                hipLaunchKernelGGL((msm_small_reduce_kernel<0, 512>), dim3(S), dim3(NBL), (size_t)NBL * sizeof(XYZZ), st, P, bucket_ref, cdesc,
                                    slot_chunks, lv, win_sums, NBL);
         }
         UZK_HIP(hipGetLastError());
