@@ -17,7 +17,7 @@ KNOBS = [
     {"msm_scan_reduce": 3, "window_bits": 17}, {"msm_scan_reduce": 3, "window_bits": 9}, {"msm_reduce_seg": 4}, {"msm_task_len": 5}, {"msm_task_len": 300},
     {"msm_fold_group": 1}, {"msm_fold_group": 16}, {"window_bits": 9}, {"window_bits": 12}, {"window_bits": 16}, {"window_bits": 17},
 ]
-DEFAULTS = {"msm_small": 1, "msm_fold_mode": 0, "msm_acc_variant": 0, "msm_sort_packed": 1, "msm_fused_hist": 1, "msm_scan_reduce": 1, "msm_quad_reduce": 1, "msm_reduce_seg": 0,
+DEFAULTS = {"msm_small": 1, "msm_fold_mode": 0, "msm_acc_variant": 0, "msm_sort_packed": 1, "msm_fused_hist": 1, "msm_scan_reduce": 1, "msm_quad_reduce": 1, "msm_x29": 1, "msm_reduce_seg": 0,
             "msm_task_len": 0, "msm_fold_group": 0, "window_bits": 0}
 
 
@@ -104,7 +104,7 @@ def test_small_pipeline_agrees_with_general(gpu, n):
         assert want[-1] is None and want[-2] is None               # all-zero scalars commit to infinity
         gpu.tune("msm_small", 1)
         for cfg in ({}, {"window_bits": 5}, {"window_bits": 9}, {"window_bits": 10}, {"msm_task_len": 2}, {"msm_task_len": 3}, {"msm_task_len": 200},
-                    {"msm_acc_variant": 1}, {"msm_acc_variant": 2}, {"msm_fold_mode": 1 + 16 + 8}, {"msm_fold_mode": 1 + 16 + 2},
+                    {"msm_acc_variant": 1}, {"msm_acc_variant": 2}, {"msm_x29": 0}, {"msm_x29": 0, "window_bits": 10}, {"msm_fold_mode": 1 + 16 + 8}, {"msm_fold_mode": 1 + 16 + 2},
                     {"msm_fold_mode": 1 + 8}, {"msm_fold_mode": 1 + 4}, {"msm_fold_mode": 1 + 2}, {"msm_fold_mode": 1 + 1}):
             _apply(gpu, cfg)
             gpu.tune("msm_small", 1)
