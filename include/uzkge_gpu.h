@@ -50,9 +50,9 @@ typedef struct { uint64_t x[4], y[4], z[4]; } uzk_g1_jac;
 
 /* ---- lifecycle ------------------------------------------------------------------------ */
 /* Bind the calling process to HIP device `device` (one process per GPU); idempotent for the
- * same ordinal.  Creates the library stream and workspaces.  Side effect: sets GPU_MAX_HW_QUEUES=16 in the process
- * environment unless it is already set (contexts are one stream each; the HIP runtime's default of four hardware queues
- * makes more than four provers queue behind each other) -- effective when this is the process's first HIP call. */
+ * same ordinal.  Creates the library stream and workspaces.  The library never edits the process environment: a host
+ * that runs more than four prover threads (one context each) should export GPU_MAX_HW_QUEUES=16 before the process
+ * makes its first HIP call -- the HIP runtime multiplexes streams onto four hardware queues by default. */
 int uzk_init(int device);
 int uzk_shutdown(void);
 /* Number of visible HIP devices (0 when none / no driver); never fails. */
@@ -67,11 +67,38 @@ const char* uzk_version(void);
  * thread its own context lets independent proofs overlap on the GPU -- at the real circuit size (n = 2^14) a single
  * proof leaves most of the chip idle.  SRS handles are process-wide and may be used from every context; register and
  * precompute them before the contexts start sharing them. */
+/* The new context starts with the creator's current tuning (uzk_tune, uzk_msm_set_window_bits). */
 int uzk_ctx_create(uint64_t* ctx_out);
 /* Makes `ctx` (0 = the default context) the calling thread's current context. */
 int uzk_ctx_set_current(uint64_t ctx);
-/* Frees the context's stream, plans and workspaces; no thread may still be using it. */
+/* Frees the context's stream, plans and workspaces; no thread may be inside a call on it.  A thread whose current
+ * context has been destroyed (here or by uzk_shutdown) works on the default context from its next call on. */
 int uzk_ctx_destroy(uint64_t ctx);
+
+/* ---- device memory ------------------------------------------------------------------------ */
+/* Everything a host language needs to keep data resident between the *_device entry points: with these it links
+ * libuzkge_gpu.so and nothing else (no HIP runtime, no hip headers).  The reference keeps every polynomial of a proof in
+ * Vec<Fr> between its steps (uzkge/src/plonk/prover.rs:151-372); these are the device-side Vecs.
+ * Copies and fills are ordered on the calling context's stream, i.e. with that context's kernels:
+ *   UZK_COPY_D2H  the data is in `dst` when the call returns;
+ *   UZK_COPY_H2D  `src` may be reused when the call returns -- except for memory of uzk_host_alloc (pinned), whose
+ *                 uploads are asynchronous: keep it unchanged until the next synchronising call (uzk_sync, a D2H copy, a
+ *                 commit);
+ *   UZK_COPY_D2D  asynchronous.
+ * uzk_dev_free / uzk_host_free wait for the calling context's stream first.  Allocations belong to the caller and
+ * survive uzk_shutdown. */
+#define UZK_COPY_H2D 0
+#define UZK_COPY_D2H 1
+#define UZK_COPY_D2D 2
+int uzk_dev_alloc(size_t bytes, void** d_out);
+int uzk_dev_free(void* d_ptr);
+int uzk_host_alloc(size_t bytes, void** h_out);
+int uzk_host_free(void* h_ptr);
+int uzk_dev_copy(void* dst, const void* src, size_t bytes, int kind);
+/* `rows` rows of `width` bytes; consecutive rows are dst_pitch / src_pitch bytes apart. */
+int uzk_dev_copy2d(void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t width, size_t rows, int kind);
+int uzk_dev_memset(void* d_dst, int byte, size_t bytes);
+int uzk_dev_memset2d(void* d_dst, size_t pitch, int byte, size_t width, size_t rows);
 
 /* ---- SRS (the static bases of KZG commit) --------------------------------------------- */
 /* Copy `n` affine points to HBM once; replaces the per-commit `normalize_batch` of
@@ -261,7 +288,8 @@ int uzk_profile_dump(char* buf, size_t cap);
 int uzk_sync(void);
 /* The library's hipStream_t (so callers can order their own work against it). */
 void* uzk_stream(void);
-/* Tuning knobs (0 = automatic): MSM window bits. */
+/* Tuning knobs (0 = automatic): MSM window bits.  Like uzk_tune, this sets the calling thread's CURRENT CONTEXT only;
+ * a context created afterwards inherits its creator's settings. */
 int uzk_msm_set_window_bits(int c);
 /* What a general-mode MSM over n points will use: signed window width and window count (every
  * point is added into one bucket per window: n * windows mixed additions). */

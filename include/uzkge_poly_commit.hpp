@@ -187,8 +187,10 @@ inline KZGCommitmentSchemeBN254* load_srs_params(const std::vector<uint8_t>& srs
 }
 
 // The reference's `for i in (0..=degree).rev() { if (i & (i - 1)) == 0 { .. break } }` (pcs.rs:139-145,
-// helpers.rs:1367-1373): the largest power of two <= degree.
+// helpers.rs:1367-1373): the largest power of two <= degree; 0 for degree 0 (the release-build value of the reference's
+// loop: 0 & usize::MAX == 0), which the caller turns into the reference's FFT / PCSProveEval error.
 inline size_t max_power_of_2(size_t degree) {
+    if (degree == 0) return 0;
     size_t p = 1;
     while (p * 2 <= degree) p *= 2;
     return p;
@@ -200,6 +202,7 @@ inline size_t max_power_of_2(size_t degree) {
 inline G1Projective commit_folded_lagrange(const KZGCommitmentSchemeBN254& pcs, const KZGCommitmentSchemeBN254& lagrange_pcs,
                                            const std::vector<Fr>& coefs, size_t degree) {
     const size_t N = max_power_of_2(degree);
+    if (N == 0) throw UzkgeException(UzkgeError::FFTError, "no evaluation domain for a degree-0 polynomial (max_power_of_2 = 0)");
     std::vector<Fr> hi(coefs.begin() + std::min(N, coefs.size()), coefs.end());
     std::vector<Fr> blinds = KZGCommitmentSchemeBN254::fr_neg(hi);
     std::vector<Fr> new_coefs(coefs.begin(), coefs.begin() + std::min(N, coefs.size()));

@@ -1,6 +1,8 @@
-// prover_rounds -- the hot-path work of one PlonK proof issued from compiled host code through the C ABI only
-// (include/uzkge_gpu.h) plus the HIP runtime for device buffers: what a GPU-resident `prover_with_lagrange`
-// (uzkge/src/plonk/prover.rs:88-394) would issue, in its order, with no interpreter between the calls.
+// prover_rounds -- the hot-path work of one PlonK proof issued from compiled host code through the C ABI ONLY
+// (include/uzkge_gpu.h; device buffers come from uzk_dev_alloc / uzk_dev_copy*): what a GPU-resident
+// `prover_with_lagrange` (uzkge/src/plonk/prover.rs:88-394) would issue, in its order, with no interpreter between the
+// calls.  Built with plain g++ -- no hip_runtime.h, no -lamdhip64 on the link line -- exactly what a Rust host has
+// (rust/uzkge-glue/gpu_prover.rs mirrors this file call for call).
 //
 //   round 1   iFFT(n) x9 (5 wires, 3 wire selectors, pi), hide_polynomial, 8 commits       prover.rs:151-192
 //   round 2   z_poly, iFFT(n), hide, commit                                                 prover.rs:199-209
@@ -18,8 +20,6 @@
 //   threads > 1: after the checked single chain, `threads` host threads -- each with its own context (uzk_ctx_create:
 //   own stream, workspaces and lock) and its own device buffers, all sharing the one registered SRS -- run `reps` chains
 //   each at the same time: proofs per second of one GPU serving several provers.
-#include <hip/hip_runtime.h>
-
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -33,7 +33,6 @@
 #include "../../include/uzkge_gpu.h"
 
 #define CK(x) do { int rc_ = (x); if (rc_ != UZK_OK) { std::fprintf(stderr, "%s -> %d: %s\n", #x, rc_, uzk_last_error()); std::exit(1); } } while (0)
-#define HK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); std::exit(1); } } while (0)
 
 struct Fr { uint64_t l[4]; };
 static const uint64_t R_MOD[4] = {0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
@@ -59,16 +58,15 @@ static void wr(const char* name, const void* p, size_t bytes) {
     std::ofstream f(g_dir + "/out_" + name + ".bin", std::ios::binary);
     f.write(static_cast<const char*>(p), bytes);
 }
-template <class T> static T* dmalloc(size_t count) { void* p; HK(hipMalloc(&p, count * sizeof(T))); return static_cast<T*>(p); }
+template <class T> static T* dmalloc(size_t count) { void* p = nullptr; CK(uzk_dev_alloc(count * sizeof(T), &p)); return static_cast<T*>(p); }
+template <class T> static void upload(T* d, const std::vector<T>& h) { CK(uzk_dev_copy(d, h.data(), h.size() * sizeof(T), UZK_COPY_H2D)); }
 
 // One prover: reads the inputs, makes them resident, runs the chain (once for the outputs, then timed).  `gate`: workers
 // of a multi-threaded run meet there after their warm-up so that the timed loops overlap.
 static void worker(uint64_t srs, int reps, bool write_outputs, bool own_context, std::atomic<int>* gate, int gate_n, double* ms_out,
                    std::vector<uint64_t>* digest_out) {
-    HK(hipSetDevice(0));
     uint64_t ctx = 0;
-    if (own_context) { CK(uzk_ctx_create(&ctx)); CK(uzk_ctx_set_current(ctx)); }
-    hipStream_t st = static_cast<hipStream_t>(uzk_stream());     // all copies go on the library stream: ordered with its kernels
+    if (own_context) { CK(uzk_ctx_create(&ctx)); CK(uzk_ctx_set_current(ctx)); }     // copies below are ordered on this context's stream
 
     // ---- inputs
     const auto meta = rd<uint64_t>("meta");                       // n, shuffle
@@ -86,34 +84,35 @@ static void worker(uint64_t srs, int reps, bool write_outputs, bool own_context,
     const auto t_rands = rd<Fr>("t_rands"), r_scalars = rd<Fr>("r_scalars");                                       // 5, 12
 
     // ---- device residency (the SRS is registered once, by main)
-    Fr* d_evals = dmalloc<Fr>(9 * n);   HK(hipMemcpy(d_evals, evals9.data(), 9 * n * sizeof(Fr), hipMemcpyHostToDevice));
-    uint32_t* d_perm = dmalloc<uint32_t>(5 * n); HK(hipMemcpy(d_perm, perm.data(), 5 * n * 4, hipMemcpyHostToDevice));
-    Fr* d_tables = dmalloc<Fr>(46 * m); HK(hipMemcpy(d_tables, tables.data(), 46 * m * sizeof(Fr), hipMemcpyHostToDevice));
+    Fr* d_evals = dmalloc<Fr>(9 * n);   upload(d_evals, evals9);
+    uint32_t* d_perm = dmalloc<uint32_t>(5 * n); upload(d_perm, perm);
+    Fr* d_tables = dmalloc<Fr>(46 * m); upload(d_tables, tables);
     Fr *d_coefs = dmalloc<Fr>(10 * m), *d_tmp = dmalloc<Fr>(10 * n), *d_coset = dmalloc<Fr>(10 * m), *d_tq = dmalloc<Fr>(m), *d_t = dmalloc<Fr>(m),
        *d_z = dmalloc<Fr>(n), *d_sc = dmalloc<Fr>(8 * (n + 6)), *d_chunks = dmalloc<Fr>(5 * (n + 8)), *d_fold = dmalloc<Fr>(5 * n),
        *d_q = dmalloc<Fr>(2 * (n + 8)), *d_r = dmalloc<Fr>(n + 8), *d_open = dmalloc<Fr>(16 * (n + 8)), *d_group = dmalloc<Fr>(n);
-    HK(hipMemset(d_coefs, 0, 10 * m * sizeof(Fr)));               // coefficient slots: 6n each, zero beyond n + 3
+    CK(uzk_dev_memset(d_coefs, 0, 10 * m * sizeof(Fr)));          // coefficient slots: 6n each, zero beyond n + 3
     {   // group[i] = omega^i: forward NTT of X
         std::vector<Fr> x(n);
         std::memset(x.data(), 0, n * sizeof(Fr));
         const uint64_t one[4] = {0xac96341c4ffffffbull, 0x36fc76959f60cd29ull, 0x666ea36f7879462eull, 0x0e0a77c19a07df2full};   // R mod r
         std::memcpy(x[1].l, one, 32);
-        HK(hipMemcpy(d_tmp, x.data(), n * sizeof(Fr), hipMemcpyHostToDevice));
+        upload(d_tmp, x);
         CK(uzk_ntt_fr_device(d_tmp, d_group, n, 0, nullptr, 1));
     }
 
     // commit `count` evaluation vectors (device, stride n) with their blinds: one batched MSM over n + 6 bases.  The
     // blind tails go through pinned host memory (one slot per commit of the chain), so nothing waits for the upload.
-    Fr* h_tails = nullptr;
-    HK(hipHostMalloc(reinterpret_cast<void**>(&h_tails), 4 * 8 * 6 * sizeof(Fr), hipHostMallocDefault));
+    Fr* h_tails = nullptr;                                        // pinned (uzk_host_alloc): uploads from it are asynchronous
+    { void* p = nullptr; CK(uzk_host_alloc((4 * 8 * 6 + 16) * sizeof(Fr), &p)); h_tails = static_cast<Fr*>(p); }
+    Fr* h_fix = h_tails + 4 * 8 * 6;                              // 16 more pinned elements for split_t's head / rand patches
     int commit_no = 0;
     auto commit = [&](const Fr* d_ev, uint32_t count, const std::vector<std::vector<Fr>>& blinds, uzk_g1_jac* out) {
-        HK(hipMemcpy2DAsync(d_sc, (n + 6) * sizeof(Fr), d_ev, n * sizeof(Fr), n * sizeof(Fr), count, hipMemcpyDeviceToDevice, st));
+        CK(uzk_dev_copy2d(d_sc, (n + 6) * sizeof(Fr), d_ev, n * sizeof(Fr), n * sizeof(Fr), count, UZK_COPY_D2D));
         Fr* tail = h_tails + (commit_no++ % 4) * 8 * 6;
         std::memset(tail, 0, count * 6 * sizeof(Fr));
         for (uint32_t i = 0; i < count; ++i)
             for (size_t j = 0; j < blinds[i].size(); ++j) { tail[i * 6 + j] = blinds[i][j]; tail[i * 6 + 3 + j] = fr_neg(blinds[i][j]); }
-        HK(hipMemcpy2DAsync(d_sc + n, (n + 6) * sizeof(Fr), tail, 6 * sizeof(Fr), 6 * sizeof(Fr), count, hipMemcpyHostToDevice, st));
+        CK(uzk_dev_copy2d(d_sc + n, (n + 6) * sizeof(Fr), tail, 6 * sizeof(Fr), 6 * sizeof(Fr), count, UZK_COPY_H2D));
         CK(uzk_msm_g1_batch_device(srs, 0, d_sc, n + 6, count, out));      // returns after the window sums have arrived
     };
 
@@ -124,9 +123,9 @@ static void worker(uint64_t srs, int reps, bool write_outputs, bool own_context,
 
     auto chain = [&]() {
         // ---- round 1
-        HK(hipMemset2DAsync(d_coefs + n, m * sizeof(Fr), 0, 8 * sizeof(Fr), 10, st));     // the slots the blinds are added into
+        CK(uzk_dev_memset2d(d_coefs + n, m * sizeof(Fr), 0, 8 * sizeof(Fr), 10));          // the slots the blinds are added into
         CK(uzk_ntt_fr_batch_device(d_evals, d_tmp, n, 9, 1, nullptr, 0));
-        HK(hipMemcpy2DAsync(d_coefs, m * sizeof(Fr), d_tmp, n * sizeof(Fr), n * sizeof(Fr), 9, hipMemcpyDeviceToDevice, st));
+        CK(uzk_dev_copy2d(d_coefs, m * sizeof(Fr), d_tmp, n * sizeof(Fr), n * sizeof(Fr), 9, UZK_COPY_D2D));
         std::vector<std::vector<Fr>> bl8(8);
         for (int i = 0; i < 5; ++i) { bl8[i] = {blinds_w[2 * i], blinds_w[2 * i + 1]}; CK(uzk_hide_polynomial_device(d_coefs + i * m, m, bl8[i][0].l, 2, n)); }
         for (int i = 0; i < 3; ++i) { bl8[5 + i] = {blinds_wsel[2 * i], blinds_wsel[2 * i + 1]}; CK(uzk_hide_polynomial_device(d_coefs + (5 + i) * m, m, bl8[5 + i][0].l, 2, n)); }
@@ -134,7 +133,7 @@ static void worker(uint64_t srs, int reps, bool write_outputs, bool own_context,
         // ---- round 2
         CK(uzk_z_poly_device(d_evals, d_perm, d_group, k[0].l, beta.l, gamma.l, (uint32_t)n, 5, d_z));
         CK(uzk_ntt_fr_device(d_z, d_tmp, n, 1, nullptr, 0));
-        HK(hipMemcpyAsync(d_coefs + 9 * m, d_tmp, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+        CK(uzk_dev_copy(d_coefs + 9 * m, d_tmp, n * sizeof(Fr), UZK_COPY_D2D));
         CK(uzk_hide_polynomial_device(d_coefs + 9 * m, m, blinds_z[0].l, 3, n));
         commit(d_z, 1, {{blinds_z[0], blinds_z[1], blinds_z[2]}}, cm_z);
         // ---- round 3
@@ -155,20 +154,18 @@ static void worker(uint64_t srs, int reps, bool write_outputs, bool own_context,
         CK(uzk_t_quotient_device(&qa, d_tq, 0));
         CK(uzk_ntt_fr_device(d_tq, d_t, m, 1, k1_inv.l, 0));
         // split t (taken as 5n + 2 coefficients): chunk i gets + rand_i X^n and - rand_(i-1)  (helpers.rs:1353-1363)
-        HK(hipMemsetAsync(d_chunks, 0, 5 * (n + 8) * sizeof(Fr), st));
-        HK(hipMemcpy2DAsync(d_chunks, (n + 8) * sizeof(Fr), d_t, n * sizeof(Fr), n * sizeof(Fr), 5, hipMemcpyDeviceToDevice, st));
-        HK(hipMemcpyAsync(d_chunks + 4 * (n + 8) + n, d_t + 5 * n, 2 * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+        CK(uzk_dev_memset(d_chunks, 0, 5 * (n + 8) * sizeof(Fr)));
+        CK(uzk_dev_copy2d(d_chunks, (n + 8) * sizeof(Fr), d_t, n * sizeof(Fr), n * sizeof(Fr), 5, UZK_COPY_D2D));
+        CK(uzk_dev_copy(d_chunks + 4 * (n + 8) + n, d_t + 5 * n, 2 * sizeof(Fr), UZK_COPY_D2D));
         Fr heads[5];
-        HK(hipMemcpy2DAsync(heads, sizeof(Fr), d_t, n * sizeof(Fr), sizeof(Fr), 5, hipMemcpyDeviceToHost, st));
-        HK(hipStreamSynchronize(st));
-        Fr prev{}, fix[5];
+        CK(uzk_dev_copy2d(heads, sizeof(Fr), d_t, n * sizeof(Fr), sizeof(Fr), 5, UZK_COPY_D2H));      // synchronises
+        Fr prev{};
         for (int i = 0; i < 5; ++i) {
-            fix[i] = fr_sub(heads[i], prev);                                  // coefs[0] -= rand_(i-1)
-            HK(hipMemcpyAsync(d_chunks + i * (n + 8), &fix[i], sizeof(Fr), hipMemcpyHostToDevice, st));
-            if (i < 4) HK(hipMemcpyAsync(d_chunks + i * (n + 8) + n, &t_rands[i], sizeof(Fr), hipMemcpyHostToDevice, st));   // coefs[n] += rand_i
+            h_fix[i] = fr_sub(heads[i], prev);                                // coefs[0] -= rand_(i-1)
+            CK(uzk_dev_copy(d_chunks + i * (n + 8), &h_fix[i], sizeof(Fr), UZK_COPY_H2D));
+            if (i < 4) { h_fix[8 + i] = t_rands[i]; CK(uzk_dev_copy(d_chunks + i * (n + 8) + n, &h_fix[8 + i], sizeof(Fr), UZK_COPY_H2D)); }   // coefs[n] += rand_i
             prev = t_rands[i];
         }
-        HK(hipStreamSynchronize(st));                                         // `fix` is a local array
         for (int i = 0; i < 5; ++i) {
             const size_t len = i < 4 ? n + 1 : n + 2;
             t_blinds[i].assign(len - n, Fr{});
@@ -186,10 +183,10 @@ static void worker(uint64_t srs, int reps, bool write_outputs, bool own_context,
         for (int i = 0; i < 5; ++i) { polys[1 + i] = d_chunks + i * (n + 8); lens[1 + i] = n + 2; }
         for (int i = 0; i < 6; ++i) { polys[6 + i] = d_coefs + i * m; lens[6 + i] = n + 3; }
         CK(uzk_poly_lincomb_device(polys, lens, r_scalars[0].l, 12, d_r, n + 3));
-        HK(hipMemsetAsync(d_open, 0, 16 * (n + 8) * sizeof(Fr), st));
-        HK(hipMemcpy2DAsync(d_open, (n + 8) * sizeof(Fr), d_coefs, m * sizeof(Fr), (n + 3) * sizeof(Fr), 10, hipMemcpyDeviceToDevice, st));
-        HK(hipMemcpyAsync(d_open + 10 * (n + 8), d_chunks, 5 * (n + 8) * sizeof(Fr), hipMemcpyDeviceToDevice, st));
-        HK(hipMemcpyAsync(d_open + 15 * (n + 8), d_r, (n + 3) * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+        CK(uzk_dev_memset(d_open, 0, 16 * (n + 8) * sizeof(Fr)));
+        CK(uzk_dev_copy2d(d_open, (n + 8) * sizeof(Fr), d_coefs, m * sizeof(Fr), (n + 3) * sizeof(Fr), 10, UZK_COPY_D2D));
+        CK(uzk_dev_copy(d_open + 10 * (n + 8), d_chunks, 5 * (n + 8) * sizeof(Fr), UZK_COPY_D2D));
+        CK(uzk_dev_copy(d_open + 15 * (n + 8), d_r, (n + 3) * sizeof(Fr), UZK_COPY_D2D));
         CK(uzk_open_quotient_device(d_open, n + 8, 16, zeta.l, alpha_open.l, d_q, open_ev_zeta[0].l));
         CK(uzk_open_quotient_device(d_open + 9 * (n + 8), n + 8, 1, zeta_omega.l, alpha_open.l, d_q + (n + 8), open_ev_zo[0].l));
         for (int j = 0; j < 2; ++j) {      // q has degree n + 1: max_power_of_2 = n, two blinds (pcs.rs:137-156)
@@ -211,7 +208,7 @@ static void worker(uint64_t srs, int reps, bool write_outputs, bool own_context,
     { std::vector<Fr> flat; for (auto& v : q_blinds) flat.insert(flat.end(), v.begin(), v.end()); wr("q_blinds", flat.data(), flat.size() * 32); }
     auto dump = [&](const char* name, const Fr* d, size_t count) {
         std::vector<Fr> h(count);
-        HK(hipMemcpy(h.data(), d, count * sizeof(Fr), hipMemcpyDeviceToHost));
+        CK(uzk_dev_copy(h.data(), d, count * sizeof(Fr), UZK_COPY_D2H));
         wr(name, h.data(), count * sizeof(Fr));
     };
     dump("coefs", d_coefs, 10 * m); dump("coset_evals", d_coset, 10 * m); dump("t_quotient", d_tq, m); dump("t", d_t, m);
@@ -236,8 +233,8 @@ static void worker(uint64_t srs, int reps, bool write_outputs, bool own_context,
         for (const auto* v : {&evals_zeta, &z_eval_zo, &open_ev_zeta, &open_ev_zo}) for (const Fr& f : *v) digest_out->insert(digest_out->end(), f.l, f.l + 4);
     }
     for (void* p : {(void*)d_evals, (void*)d_perm, (void*)d_tables, (void*)d_coefs, (void*)d_tmp, (void*)d_coset, (void*)d_tq, (void*)d_t, (void*)d_z,
-                    (void*)d_sc, (void*)d_chunks, (void*)d_fold, (void*)d_q, (void*)d_r, (void*)d_open, (void*)d_group}) HK(hipFree(p));
-    HK(hipHostFree(h_tails));
+                    (void*)d_sc, (void*)d_chunks, (void*)d_fold, (void*)d_q, (void*)d_r, (void*)d_open, (void*)d_group}) CK(uzk_dev_free(p));
+    CK(uzk_host_free(h_tails));
     if (own_context) { CK(uzk_ctx_set_current(0)); CK(uzk_ctx_destroy(ctx)); }
 }
 
@@ -246,6 +243,7 @@ int main(int argc, char** argv) {
     g_dir = argv[1];
     const int reps = argc > 2 ? std::atoi(argv[2]) : 0;
     const int threads = argc > 3 ? std::atoi(argv[3]) : 1;
+    setenv("GPU_MAX_HW_QUEUES", "16", /*overwrite*/ 0);   // one stream per prover thread; before the process's first HIP call
     CK(uzk_init(0));
     const auto meta = rd<uint64_t>("meta");
     const auto bases = rd<uzk_g1_affine>("bases");                // n + 6 points

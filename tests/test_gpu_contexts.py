@@ -69,3 +69,56 @@ def test_profile_tables_are_per_context(gpu):
         gpu.ctx_set_current(0)
         gpu.ctx_destroy(h)
         srs.release()
+
+
+def test_worker_thread_survives_shutdown_of_its_context(gpu):
+    """a pooled worker that made a context current, then lives through uzk_shutdown + re-initialisation (or a
+    uzk_ctx_destroy from another thread), must not touch the freed context: its handle no longer resolves and its next
+    call runs on the default context."""
+    x = rand_fr_wire(4096, 77)
+    want = oc.ntt(x)
+    go, done, out = threading.Event(), threading.Event(), {}
+
+    def worker():
+        try:
+            h = gpu.ctx_create()
+            gpu.ctx_set_current(h)
+            out["first"] = bool(np.array_equal(gpu.ntt(x), want))
+            done.set()
+            go.wait(60)                                   # the main thread shuts the library down meanwhile
+            out["after_shutdown"] = bool(np.array_equal(gpu.ntt(x), want))       # lazy re-init, default context
+            h2 = gpu.ctx_create()
+            gpu.ctx_set_current(h2)
+            out["h2"] = h2
+            out["own_again"] = bool(np.array_equal(gpu.ntt(x), want))
+        except Exception as e:   # noqa: BLE001
+            out["err"] = e
+        finally:
+            done.set()
+
+    t = threading.Thread(target=worker)
+    t.start()
+    assert done.wait(120) and out.get("first") is True, out
+    done.clear()
+    gpu.shutdown()
+    gpu.init(0)
+    go.set()
+    t.join(120)
+    assert out.get("after_shutdown") is True and out.get("own_again") is True and "err" not in out, out
+    gpu.ctx_destroy(out["h2"])                            # destroyed from ANOTHER thread than the one that uses it
+
+
+def test_new_contexts_inherit_the_creators_tuning(gpu):
+    """uzk_tune / uzk_msm_set_window_bits are per context; uzk_ctx_create copies the creator's current settings."""
+    gpu.set_msm_window_bits(7)
+    h = gpu.ctx_create()
+    try:
+        gpu.ctx_set_current(h)
+        assert gpu.msm_plan_info(4096)[0] == 7
+        gpu.set_msm_window_bits(0)
+        gpu.ctx_set_current(0)
+        assert gpu.msm_plan_info(4096)[0] == 7            # the default context keeps its own value
+    finally:
+        gpu.ctx_set_current(0)
+        gpu.set_msm_window_bits(0)
+        gpu.ctx_destroy(h)

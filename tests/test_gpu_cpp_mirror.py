@@ -36,19 +36,37 @@ def test_cpp_mirror_reference_tests(gpu):
 
 
 def _build_rounds():
-    """tests/cpp/prover_rounds.cpp: one proof's hot-path sequence issued from C++ through the C ABI (hipcc: it also uses
-    the HIP runtime for its device buffers)."""
-    out = os.path.join(ROOT, "tests", "cpp", "prover_rounds")
-    src = os.path.join(ROOT, "tests", "cpp", "prover_rounds.cpp")
-    subprocess.check_call([
-        "/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-o", out, src,
-        "-L" + os.path.join(ROOT, "uzkge_amd"), "-luzkge_gpu", "-Wl,-rpath," + os.path.join(ROOT, "uzkge_amd"),
-    ])
-    return out
+    """tests/cpp/prover_rounds.cpp: one proof's hot-path sequence issued from C++ through the C ABI ALONE -- compiled by plain
+    g++ against include/uzkge_gpu.h, linked against libuzkge_gpu.so and nothing else (the command lives in __graft_entry__)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from __graft_entry__ import rounds_build_command
+    cmd = rounds_build_command()
+    subprocess.check_call(cmd)
+    return cmd[cmd.index("-o") + 1]
 
 
 def test_cpp_prover_rounds_compiles_and_links():
     assert os.path.exists(_build_rounds())
+
+
+def test_cpp_prover_rounds_needs_only_the_c_abi():
+    """The device-resident flow is reachable from a host language through include/uzkge_gpu.h alone: the driver's source
+    names no HIP header or symbol, its compile line names no HIP compiler or library, and the binary's own NEEDED list holds
+    libuzkge_gpu.so but not the HIP runtime (which only the library itself depends on)."""
+    import re
+    import sys
+    sys.path.insert(0, ROOT)
+    from __graft_entry__ import rounds_build_command
+    src = open(os.path.join(ROOT, "tests", "cpp", "prover_rounds.cpp")).read()
+    code = re.sub(r"//.*", "", src)
+    assert not re.search(r"\bhip[A-Z_]\w*|hip_runtime|<hip/", code), "prover_rounds.cpp still uses the HIP runtime"
+    cmd = rounds_build_command()
+    assert cmd[0] == "g++" and not any("hip" in a.lower() or "rocm" in a.lower() for a in cmd[1:] if not a.startswith(ROOT) and not a.startswith("-L" + ROOT) and not a.startswith("-Wl,-rpath," + ROOT))
+    exe = _build_rounds()
+    needed = subprocess.run(["readelf", "-d", exe], capture_output=True, text=True).stdout
+    libs = re.findall(r"\(NEEDED\).*\[(.*?)\]", needed)
+    assert any("libuzkge_gpu" in l for l in libs) and not any("amdhip" in l or "hsa" in l for l in libs), libs
 
 
 def _write_inputs(inp, d, shuffle=True, precompute=True):

@@ -26,7 +26,7 @@ def _blob(name):
     return open(os.path.join(GOLDEN, name), "rb").read()
 
 
-@pytest.fixture(scope="module", params=[4096, 16384])
+@pytest.fixture(scope="module", params=[4096, 8192, 16384])
 def schemes(request, gpu):
     from uzkge_amd.poly_commit import KZGCommitmentSchemeBN254, load_srs_params
     n = request.param
@@ -52,7 +52,7 @@ def test_load_srs_params_layout(schemes):
     assert g1.shape[0] == n + 3
     assert np.array_equal(g1[:2051], oc.points_from_affine(file_pts[:2051]))
     assert not g1[2051:n].any()                                     # identity between the powers and the padding
-    pad = {4096: 2051, 16384: 2057}[n]
+    pad = {4096: 2051, 8192: 2054, 16384: 2057}[n]       # gen_params/mod.rs:163-173
     assert np.array_equal(g1[n:], oc.points_from_affine(file_pts[pad:pad + 3]))
 
 

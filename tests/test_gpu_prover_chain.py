@@ -66,15 +66,17 @@ def test_prover_round_chain_matches_oracle_chain(gpu):
         c.release()
 
 
-def test_quotient_without_shuffle_vectors(gpu):
-    """A circuit without the "shuffle" feature (zmatchmaking, helpers.rs:437 #[cfg(feature = "shuffle")]): the 28 vectors
-    of terms 12..18 are passed as NULL; the result equals the full formula with those vectors zero."""
+@pytest.mark.parametrize("n", [4096, 8192])
+def test_quotient_without_shuffle_vectors(gpu, n):
+    """A circuit without the "shuffle" feature (zmatchmaking, helpers.rs:437 #[cfg(feature = "shuffle")]; its circuit has
+    n = 8192 constraints, matchmaking/src/build_cs.rs:68-99): the 28 vectors of terms 12..18 are passed as NULL; the result
+    equals the full formula with those vectors zero."""
     from prover_chain import ChainInputs, ProverChain
-    inp = ChainInputs(4096, 5)
+    inp = ChainInputs(n, 5)
     c = ProverChain(inputs=inp, shuffle=False, precompute=False)
     try:
         c.run()
-        n, m = c.n, c.m
+        m = c.m
         assert sum(1 for p in c.tq_ptrs if not p) == 28
         cos = _host(c.d_coset).reshape(10, m, 4).copy()
         vecs = np.concatenate([cos, c.tables])
@@ -89,6 +91,19 @@ def test_quotient_without_shuffle_vectors(gpu):
         with pytest.raises(UzkgeError):
             gpu.t_quotient_device(n, 6, bad, c.alpha, c.beta, c.gamma, c.k, c.anemoi_g, c.anemoi_g_inv, c.edwards_a, c.z_h_inv,
                                   c.d_tq.data_ptr())
+    finally:
+        c.release()
+
+
+def test_zmatchmaking_sized_chain_without_shuffle_terms(gpu):
+    """The whole checked chain at zmatchmaking's size (n = 8192, commits over the reference's lagrange-srs-8192.bin and the
+    padding powers at index 2054 of srs-padding.bin) with the shuffle-feature terms absent."""
+    from chain_oracle import oracle_chain
+    from prover_chain import ChainInputs, ProverChain
+    inp = ChainInputs(8192, 23)
+    c = ProverChain(inputs=inp, shuffle=False)
+    try:
+        _check_chain_against(c, c.run(), oracle_chain(inp, shuffle=False))
     finally:
         c.release()
 

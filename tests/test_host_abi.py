@@ -79,3 +79,24 @@ def test_product_does_not_import_oracle():
                 if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h", ".inc", "Makefile")):
                     src = open(os.path.join(dirpath, f), errors="replace").read()
                     assert not banned.search(src), f"{top}/{f} references the oracle"
+
+
+def test_max_power_of_2_follows_the_reference_loop():
+    """pcs.rs:139-145 / helpers.rs:1367-1373 in release arithmetic (usize wraps): degree 0 leaves the loop with 0, and the
+    fold then fails with the reference's FFT error instead of an assertion."""
+    from uzkge_amd import UzkgeError
+    from uzkge_amd.poly_commit import commit_folded_lagrange, max_power_of_2
+
+    def reference_loop(degree):
+        mp = degree
+        for i in range(degree, -1, -1):
+            if (i & ((i - 1) & (2 ** 64 - 1))) == 0:
+                mp = i
+                break
+        return mp
+
+    for d in list(range(0, 70)) + [4095, 4096, 4097, 16386, 98304]:
+        assert max_power_of_2(d) == reference_loop(d), d
+    with pytest.raises(UzkgeError) as e:
+        commit_folded_lagrange(None, None, np.zeros((1, 4), dtype=np.uint64), 0)
+    assert e.value.kind == "FFTError"

@@ -4,7 +4,8 @@ data under tests/golden/ -- and cross-checks the two oracle implementations agai
 
 Known answers:
   * srs-padding.bin[0] == G = (1, 2)
-  * sum_i L_i == G                       over lagrange-srs-{4096,16384}.bin
+  * sum_i L_i == G                       over lagrange-srs-{4096,8192,16384}.bin (8192 = zmatchmaking's circuit size,
+                                         matchmaking/src/build_cs.rs:68-99)
   * sum_i omega^i L_i == [tau]G          == srs-padding.bin[1]   (pins omega and natural order)
   * MSM(lagrange_srs, NTT(c)) == MSM(monomial_srs, c)  for deg c <= 2050 (NTT + MSM together)
 """
@@ -23,7 +24,8 @@ def mono():
     return load_srs("srs-padding.bin")
 
 
-@pytest.mark.parametrize("name,n", [("lagrange-srs-4096.bin", 4096), ("lagrange-srs-16384.bin", 16384)])
+@pytest.mark.parametrize("name,n", [("lagrange-srs-4096.bin", 4096), ("lagrange-srs-8192.bin", 8192),
+                                    ("lagrange-srs-16384.bin", 16384)])
 def test_lagrange_identities(name, n, mono):
     wire, pts = load_srs(name)
     _, mono_pts = mono
@@ -52,7 +54,7 @@ def test_ntt_and_msm_against_reference_srs(mono):
 def test_srs_file_format(golden_dir):
     """u32 len_g1 | u32 len_g2 | len_g1 x 64 B | len_g2 x 128 B (kzg_poly_commitment.rs:206-264)."""
     import os, struct
-    for name, n in (("lagrange-srs-4096.bin", 4096), ("lagrange-srs-16384.bin", 16384)):
+    for name, n in (("lagrange-srs-4096.bin", 4096), ("lagrange-srs-8192.bin", 8192), ("lagrange-srs-16384.bin", 16384)):
         data = open(os.path.join(golden_dir, name), "rb").read()
         l1, l2 = struct.unpack_from("<II", data, 0)
         assert (l1, l2) == (n, 0) and len(data) == 8 + 64 * n

@@ -28,6 +28,14 @@ PROTOTYPES = {
     "uzk_ctx_create": (_I, [ctypes.POINTER(_U64)]),
     "uzk_ctx_set_current": (_I, [_U64]),
     "uzk_ctx_destroy": (_I, [_U64]),
+    "uzk_dev_alloc": (_I, [_SZ, ctypes.POINTER(_P)]),
+    "uzk_dev_free": (_I, [_P]),
+    "uzk_host_alloc": (_I, [_SZ, ctypes.POINTER(_P)]),
+    "uzk_host_free": (_I, [_P]),
+    "uzk_dev_copy": (_I, [_P, _P, _SZ, _I]),
+    "uzk_dev_copy2d": (_I, [_P, _SZ, _P, _SZ, _SZ, _SZ, _I]),
+    "uzk_dev_memset": (_I, [_P, _I, _SZ]),
+    "uzk_dev_memset2d": (_I, [_P, _SZ, _I, _SZ, _SZ]),
     "uzk_srs_register": (_I, [_P, _SZ, ctypes.POINTER(_U64)]),
     "uzk_srs_register_device": (_I, [_P, _SZ, ctypes.POINTER(_U64)]),
     "uzk_srs_release": (_I, [_U64]),

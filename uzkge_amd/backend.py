@@ -381,3 +381,55 @@ def msm_plan_info(n: int) -> Tuple[int, int]:
 
 def tune(key: str, value: int) -> None:
     check(lib.uzk_tune(key.encode(), value))
+
+
+# ---- device memory (uzk_dev_*): what a host language uses instead of a HIP binding ----------------------------
+COPY_H2D, COPY_D2H, COPY_D2D = 0, 1, 2
+
+
+def dev_alloc(nbytes: int) -> int:
+    p = ctypes.c_void_p(0)
+    check(lib.uzk_dev_alloc(nbytes, ctypes.byref(p)))
+    return p.value or 0
+
+
+def dev_free(d_ptr: int) -> None:
+    check(lib.uzk_dev_free(ctypes.c_void_p(d_ptr)))
+
+
+def host_alloc(nbytes: int) -> int:
+    """Pinned host memory (uploads from it are asynchronous); returns the address."""
+    p = ctypes.c_void_p(0)
+    check(lib.uzk_host_alloc(nbytes, ctypes.byref(p)))
+    return p.value or 0
+
+
+def host_free(h_ptr: int) -> None:
+    check(lib.uzk_host_free(ctypes.c_void_p(h_ptr)))
+
+
+def dev_upload(d_dst: int, a: np.ndarray) -> None:
+    a = np.ascontiguousarray(a)
+    check(lib.uzk_dev_copy(ctypes.c_void_p(d_dst), a.ctypes.data_as(ctypes.c_void_p), a.nbytes, COPY_H2D))
+
+
+def dev_download(d_src: int, shape, dtype=np.uint64) -> np.ndarray:
+    out = np.empty(shape, dtype=dtype)
+    check(lib.uzk_dev_copy(out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(d_src), out.nbytes, COPY_D2H))
+    return out
+
+
+def dev_copy(d_dst: int, d_src: int, nbytes: int) -> None:
+    check(lib.uzk_dev_copy(ctypes.c_void_p(d_dst), ctypes.c_void_p(d_src), nbytes, COPY_D2D))
+
+
+def dev_copy2d(dst: int, dst_pitch: int, src: int, src_pitch: int, width: int, rows: int, kind: int = COPY_D2D) -> None:
+    check(lib.uzk_dev_copy2d(ctypes.c_void_p(dst), dst_pitch, ctypes.c_void_p(src), src_pitch, width, rows, kind))
+
+
+def dev_memset(d_dst: int, byte: int, nbytes: int) -> None:
+    check(lib.uzk_dev_memset(ctypes.c_void_p(d_dst), byte, nbytes))
+
+
+def dev_memset2d(d_dst: int, pitch: int, byte: int, width: int, rows: int) -> None:
+    check(lib.uzk_dev_memset2d(ctypes.c_void_p(d_dst), pitch, byte, width, rows))

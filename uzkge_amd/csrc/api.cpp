@@ -3,6 +3,7 @@
 // There is deliberately no CPU fallback: without a gfx950 device every compute call fails with
 // UZK_ERR_DEVICE.
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdlib>
 #include <cstring>
@@ -31,7 +32,9 @@ struct Shared {
     std::map<uint64_t, Ctx::Srs> srs;
     uint64_t next_handle = 1;
     std::map<uint64_t, Ctx*> contexts;
-    uint64_t next_ctx = 1;
+    uint64_t next_ctx = 1;                 // never reused: a stale handle cannot name a later context
+    std::atomic<uint64_t> epoch{1};        // bumped whenever a context is destroyed (uzk_ctx_destroy, uzk_shutdown)
+    std::map<const void*, size_t> pinned;  // uzk_host_alloc blocks (base -> bytes): uploads from them are asynchronous
 };
 static Shared& shared() {
     static Shared s;
@@ -41,9 +44,24 @@ static Ctx& default_ctx() {
     static Ctx c;
     return c;
 }
-static thread_local Ctx* t_current = nullptr;      // the calling thread's context (null: the default one)
+// The calling thread's context is remembered by HANDLE; the pointer is only a cache, valid while no context has been
+// destroyed since it was looked up (Shared::epoch).  A worker thread that outlives uzk_shutdown / uzk_ctx_destroy of its
+// context therefore falls back to the default context instead of dereferencing a freed Ctx.
+static thread_local uint64_t t_handle = 0;          // 0: the default context
+static thread_local Ctx* t_cached = nullptr;
+static thread_local uint64_t t_epoch = 0;
 
-Ctx& ctx() { return t_current ? *t_current : default_ctx(); }
+Ctx& ctx() {
+    if (t_handle == 0) return default_ctx();
+    Shared& s = shared();
+    if (t_cached && t_epoch == s.epoch.load(std::memory_order_acquire)) return *t_cached;
+    std::lock_guard<std::mutex> lk(s.mu);
+    auto it = s.contexts.find(t_handle);
+    if (it == s.contexts.end()) { t_handle = 0; t_cached = nullptr; return default_ctx(); }
+    t_cached = it->second;
+    t_epoch = s.epoch.load(std::memory_order_acquire);
+    return *t_cached;
+}
 std::mutex& ctx_mutex() { return ctx().mu; }
 
 int DevBuf::reserve(size_t bytes) {
@@ -113,15 +131,6 @@ int Ctx::prof_collect() {
 static int g_last_device = 0;
 
 // binds the process to `device` (Shared::mu held by the caller)
-// The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); contexts are one
-// stream each, and with more than four provers in a process their kernels queue behind each other.  Ask for 16 unless
-// the environment already says something -- effective when this library makes the process's first HIP call (a compiled
-// prover), harmless otherwise (the runtime has read its settings by then; set the variable outside in that case).
-static void prefer_more_hw_queues() {
-    static const bool once = [] { return setenv("GPU_MAX_HW_QUEUES", "16", /*overwrite*/ 0) == 0; }();
-    (void)once;
-}
-
 static int bind_device_locked(Shared& s, int device) {
     UZK_HIP(hipSetDevice(device));
     hipDeviceProp_t prop;
@@ -143,7 +152,6 @@ int require_ready() {
         std::lock_guard<std::mutex> lk(s.mu);
         if (!s.bound) {
             // lazy init (device 0, or the one uzk_init bound before a shutdown) so a plain library user need not call uzk_init
-            prefer_more_hw_queues();
             int n = 0;
             if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
                 set_error("no HIP device visible: the MI355X backend has no CPU fallback");
@@ -194,7 +202,10 @@ using namespace uzk;
 
 extern "C" {
 
-const char* uzk_version(void) { return "uzkge-amd 0.1 (gfx950)"; }
+#ifndef UZK_SRC_HASH
+#define UZK_SRC_HASH "unstamped"
+#endif
+const char* uzk_version(void) { return "uzkge-amd 0.3 (gfx950) src:" UZK_SRC_HASH; }
 const char* uzk_last_error(void) { return g_err; }
 
 int uzk_device_count(void) {
@@ -213,7 +224,6 @@ int uzk_init(int device) {
             return UZK_ERR_PARAMETER;
         }
         if (!s.bound) {
-            prefer_more_hw_queues();
             int n = 0;
             if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
                 set_error("no HIP device visible: the MI355X backend has no CPU fallback");
@@ -230,7 +240,9 @@ int uzk_init(int device) {
 }
 
 // Frees every context (the default one and those of uzk_ctx_create), every SRS and table, and unbinds the device.
-// No other thread may be inside the library.
+// No other thread may be inside the library.  Threads that had made a destroyed context current fall back to the
+// default context on their next call (the handle no longer resolves).  Memory from uzk_dev_alloc / uzk_host_alloc
+// belongs to the caller and is not touched.
 int uzk_shutdown(void) {
     Shared& s = shared();
     std::lock_guard<std::mutex> lk(s.mu);
@@ -239,7 +251,9 @@ int uzk_shutdown(void) {
     ctx_release(default_ctx());
     for (auto& kv : s.contexts) { ctx_release(*kv.second); delete kv.second; }
     s.contexts.clear();
-    t_current = nullptr;
+    s.epoch.fetch_add(1, std::memory_order_acq_rel);
+    t_handle = 0;
+    t_cached = nullptr;
     for (auto& kv : s.srs) {
         if (kv.second.owned && kv.second.d_points) (void)hipFree(kv.second.d_points);
         if (kv.second.d_table) (void)hipFree(kv.second.d_table);
@@ -251,10 +265,26 @@ int uzk_shutdown(void) {
 }
 
 /* ---- contexts ------------------------------------------------------------------------------- */
+// the experiment switches and the forced window width travel with the creator: a tool that tunes the default context
+// and then starts prover threads measures what it configured
+static void copy_tuning(const Ctx& from, Ctx& to) {
+    to.msm_window_bits = from.msm_window_bits;
+    to.tune_acc_variant = from.tune_acc_variant; to.tune_task_len = from.tune_task_len; to.tune_no_precompute = from.tune_no_precompute;
+    to.tune_fold_group = from.tune_fold_group; to.tune_scan_reduce = from.tune_scan_reduce; to.tune_poly_small = from.tune_poly_small;
+    to.tune_x29 = from.tune_x29; to.tune_quad_reduce = from.tune_quad_reduce; to.tune_reduce_seg = from.tune_reduce_seg;
+    to.tune_fused_hist = from.tune_fused_hist; to.tune_sort_packed = from.tune_sort_packed; to.tune_ntt_fused = from.tune_ntt_fused;
+    to.tune_ntt_tile = from.tune_ntt_tile; to.tune_ntt_l29 = from.tune_ntt_l29; to.tune_small = from.tune_small;
+    to.tune_fold_mode = from.tune_fold_mode; to.tune_chunk_log = from.tune_chunk_log; to.tune_overlap = from.tune_overlap;
+}
 int uzk_ctx_create(uint64_t* ctx_out) {
     if (!ctx_out) { set_error("uzk_ctx_create: null pointer"); return UZK_ERR_PARAMETER; }
-    { API_LOCK; UZK_TRY(require_ready()); }            // binds the device through the caller's current context
     Ctx* c = new Ctx();
+    {
+        API_LOCK;                                      // binds the device through the caller's current context
+        int rc = require_ready();
+        if (rc != UZK_OK) { delete c; return rc; }
+        copy_tuning(ctx(), *c);
+    }
     Shared& s = shared();
     std::lock_guard<std::mutex> lk(s.mu);
     const uint64_t h = s.next_ctx++;
@@ -263,12 +293,14 @@ int uzk_ctx_create(uint64_t* ctx_out) {
     return UZK_OK;
 }
 int uzk_ctx_set_current(uint64_t handle) {
-    if (handle == 0) { t_current = nullptr; return UZK_OK; }
+    if (handle == 0) { t_handle = 0; t_cached = nullptr; return UZK_OK; }
     Shared& s = shared();
     std::lock_guard<std::mutex> lk(s.mu);
     auto it = s.contexts.find(handle);
     if (it == s.contexts.end()) { set_error("uzk_ctx_set_current: unknown context %llu", (unsigned long long)handle); return UZK_ERR_PARAMETER; }
-    t_current = it->second;
+    t_handle = handle;
+    t_cached = it->second;
+    t_epoch = s.epoch.load(std::memory_order_acquire);
     return UZK_OK;
 }
 int uzk_ctx_destroy(uint64_t handle) {
@@ -280,11 +312,115 @@ int uzk_ctx_destroy(uint64_t handle) {
         if (it == s.contexts.end()) { set_error("uzk_ctx_destroy: unknown context %llu", (unsigned long long)handle); return UZK_ERR_PARAMETER; }
         c = it->second;
         s.contexts.erase(it);
+        s.epoch.fetch_add(1, std::memory_order_acq_rel);   // every thread's cached pointer is looked up again
         if (s.bound) (void)hipSetDevice(s.device);
     }
-    if (t_current == c) t_current = nullptr;
+    if (t_handle == handle) { t_handle = 0; t_cached = nullptr; }
     { std::lock_guard<std::mutex> lk(c->mu); ctx_release(*c); }
     delete c;
+    return UZK_OK;
+}
+
+/* ---- device memory ----------------------------------------------------------------------------
+ * What a host language needs to keep data resident between the *_device entry points without linking the HIP runtime
+ * itself.  Copies and fills are ordered on the calling context's stream, i.e. with that context's kernels. */
+int uzk_dev_alloc(size_t bytes, void** d_out) {
+    API_LOCK;
+    if (!d_out) { set_error("uzk_dev_alloc: null pointer"); return UZK_ERR_PARAMETER; }
+    *d_out = nullptr;
+    UZK_TRY(require_ready());
+    if (bytes == 0) return UZK_OK;
+    hipError_t e = hipMalloc(d_out, bytes);
+    if (e != hipSuccess) { *d_out = nullptr; set_error("uzk_dev_alloc(%zu): %s", bytes, hipGetErrorString(e)); return UZK_ERR_DEVICE; }
+    return UZK_OK;
+}
+// Waits for the calling context's stream first: work queued on it may still use the block.
+int uzk_dev_free(void* d_ptr) {
+    API_LOCK;
+    if (!d_ptr) return UZK_OK;
+    UZK_TRY(require_ready());
+    UZK_HIP(hipStreamSynchronize(ctx().stream));
+    UZK_HIP(hipFree(d_ptr));
+    return UZK_OK;
+}
+int uzk_host_alloc(size_t bytes, void** h_out) {
+    API_LOCK;
+    if (!h_out) { set_error("uzk_host_alloc: null pointer"); return UZK_ERR_PARAMETER; }
+    *h_out = nullptr;
+    UZK_TRY(require_ready());
+    if (bytes == 0) return UZK_OK;
+    hipError_t e = hipHostMalloc(h_out, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) { *h_out = nullptr; set_error("uzk_host_alloc(%zu): %s", bytes, hipGetErrorString(e)); return UZK_ERR_DEVICE; }
+    Shared& s = shared();
+    std::lock_guard<std::mutex> lk(s.mu);
+    s.pinned[*h_out] = bytes;
+    return UZK_OK;
+}
+int uzk_host_free(void* h_ptr) {
+    API_LOCK;
+    if (!h_ptr) return UZK_OK;
+    UZK_TRY(require_ready());
+    {
+        Shared& s = shared();
+        std::lock_guard<std::mutex> lk(s.mu);
+        auto it = s.pinned.find(h_ptr);
+        if (it == s.pinned.end()) { set_error("uzk_host_free: %p is not a block of uzk_host_alloc", h_ptr); return UZK_ERR_PARAMETER; }
+        s.pinned.erase(it);
+    }
+    UZK_HIP(hipStreamSynchronize(ctx().stream));
+    UZK_HIP(hipHostFree(h_ptr));
+    return UZK_OK;
+}
+// true when [p, p + bytes) lies inside a block of uzk_host_alloc
+static bool is_pinned_block(const void* p, size_t bytes) {
+    Shared& s = shared();
+    std::lock_guard<std::mutex> lk(s.mu);
+    auto it = s.pinned.upper_bound(p);
+    if (it == s.pinned.begin()) return false;
+    --it;
+    const char* base = static_cast<const char*>(it->first);
+    const char* q = static_cast<const char*>(p);
+    return q >= base && q + bytes <= base + it->second;
+}
+static int dev_copy_common(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows, int kind, const char* who) {
+    if (kind != UZK_COPY_H2D && kind != UZK_COPY_D2H && kind != UZK_COPY_D2D) { set_error("%s: kind must be UZK_COPY_H2D / D2H / D2D", who); return UZK_ERR_PARAMETER; }
+    if (width == 0 || rows == 0) return UZK_OK;
+    if (!dst || !src) { set_error("%s: null pointer", who); return UZK_ERR_PARAMETER; }
+    if (rows > 1 && (dpitch < width || spitch < width)) { set_error("%s: a pitch is smaller than the row width", who); return UZK_ERR_PARAMETER; }
+    UZK_TRY(require_ready());
+    Ctx& c = ctx();
+    const hipMemcpyKind k = kind == UZK_COPY_H2D ? hipMemcpyHostToDevice : kind == UZK_COPY_D2H ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    if (rows == 1 || (dpitch == width && spitch == width)) UZK_HIP(hipMemcpyAsync(dst, src, width * rows, k, c.stream));
+    else UZK_HIP(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, k, c.stream));
+    // D2H: the data is in `dst` on return.  H2D: `src` may be reused on return -- unless it is pinned memory of
+    // uzk_host_alloc, whose uploads stay asynchronous (the caller keeps it unchanged until the next synchronising call).
+    const size_t span = rows > 1 ? (rows - 1) * spitch + width : width;
+    if (kind == UZK_COPY_D2H || (kind == UZK_COPY_H2D && !is_pinned_block(src, span))) UZK_HIP(hipStreamSynchronize(c.stream));
+    return UZK_OK;
+}
+int uzk_dev_copy(void* dst, const void* src, size_t bytes, int kind) {
+    API_LOCK;
+    return dev_copy_common(dst, bytes, src, bytes, bytes, 1, kind, "uzk_dev_copy");
+}
+int uzk_dev_copy2d(void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t width, size_t rows, int kind) {
+    API_LOCK;
+    return dev_copy_common(dst, dst_pitch, src, src_pitch, width, rows, kind, "uzk_dev_copy2d");
+}
+int uzk_dev_memset(void* d_dst, int byte, size_t bytes) {
+    API_LOCK;
+    if (bytes == 0) return UZK_OK;
+    if (!d_dst) { set_error("uzk_dev_memset: null pointer"); return UZK_ERR_PARAMETER; }
+    UZK_TRY(require_ready());
+    UZK_HIP(hipMemsetAsync(d_dst, byte, bytes, ctx().stream));
+    return UZK_OK;
+}
+int uzk_dev_memset2d(void* d_dst, size_t pitch, int byte, size_t width, size_t rows) {
+    API_LOCK;
+    if (width == 0 || rows == 0) return UZK_OK;
+    if (!d_dst) { set_error("uzk_dev_memset2d: null pointer"); return UZK_ERR_PARAMETER; }
+    if (rows > 1 && pitch < width) { set_error("uzk_dev_memset2d: pitch smaller than the row width"); return UZK_ERR_PARAMETER; }
+    UZK_TRY(require_ready());
+    UZK_HIP(hipMemset2DAsync(d_dst, pitch, byte, width, rows, ctx().stream));
     return UZK_OK;
 }
 

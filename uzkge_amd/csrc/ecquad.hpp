@@ -18,7 +18,15 @@ template <int S>
 __device__ __forceinline__ Fp quad_bcast(const Fp& v) {
     Fp r;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) r.v[k] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.v[k], S * 0x55, 0xf, 0xf, false);
+    for (int k = 0; k < 8; ++k) {
+        r.v[k] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.v[k], S * 0x55, 0xf, 0xf, false);
+        // keep the move a move (same fence as quad_bcast29, ecquad29.hpp): the compiler's DPP combine may fold a broadcast
+        // into the v_sub / v_add of the modular subtraction that follows; with bound_ctrl = 0 and these masks the folded
+        // form was observed to leave lanes 0, 2, 3 of a quad with wrong low limbs on gfx950 in the 29-bit code.  The 8 x 32
+        // form feeds carry chains (v_sub_co / v_subb_co), which today's combine does not fold -- the fence makes that
+        // independent of instruction selection; KAT ops 5-7 (tests/test_gpu_field_kat.py) guard it either way.
+        asm volatile("" : "+v"(r.v[k]));
+    }
     return r;
 }
 __device__ __forceinline__ Fp quad_sel(uint32_t q, const Fp& a0, const Fp& a1, const Fp& a2, const Fp& a3) {

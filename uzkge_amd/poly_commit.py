@@ -246,8 +246,11 @@ def fr_add_rows(a: np.ndarray, b: np.ndarray) -> np.ndarray:
 
 def max_power_of_2(degree: int) -> int:
     """The reference's loop `for i in (0..=degree).rev() { if (i & (i - 1)) == 0 {..break} }`
-    (pcs.rs:139-145, helpers.rs:1367-1373): the largest power of two <= degree (degree >= 1)."""
-    assert degree >= 1
+    (pcs.rs:139-145, helpers.rs:1367-1373): the largest power of two <= degree.  degree = 0 (a constant quotient) leaves
+    the loop with 0 in a release build (0 & usize::MAX == 0): the fold then has no domain and the caller's `fft(.., 0)`
+    fails -- PCSProveEvalError / FFTError in the reference, UzkgeError(FFT) here -- instead of an assertion."""
+    if degree <= 0:
+        return 0
     return 1 << (degree.bit_length() - 1)
 
 
@@ -258,6 +261,8 @@ def commit_folded_lagrange(pcs: KZGCommitmentSchemeBN254, lagrange_pcs: KZGCommi
     the low ones, fft(N), commit the evaluations over the Lagrange SRS, undo the fold with blind factors."""
     c = np.ascontiguousarray(coefs, dtype=np.uint64).reshape(-1, 4)
     npow = max_power_of_2(degree)
+    if npow == 0:
+        raise UzkgeError(N.UZK_ERR_FFT, "no evaluation domain for a degree-0 polynomial (max_power_of_2 = 0)")
     blinds = fr_neg(c[npow:])
     new_coefs = c[:npow].copy()
     if blinds.shape[0]:
