@@ -130,6 +130,16 @@ int uzk_msm_g1_batch(uint64_t srs_handle, size_t offset, const uint64_t* scalars
                      uzk_g1_jac* out);
 int uzk_msm_g1_batch_device(uint64_t srs_handle, size_t offset, const void* d_scalars_mont, size_t n,
                             uint32_t batch, uzk_g1_jac* out);
+/* The prover's commit closure on its Lagrange branch (uzkge/src/plonk/prover.rs:132-142) in ONE batched MSM: vector b has
+ * n scalars at d_scalars + b * stride (device) followed by tail_n "tail" scalars (tail + b * tail_n; host memory unless
+ * tail_on_device):
+ *   out[b] = sum_{i<n} scalars_b[i] * SRS[offset + i]  +  sum_{j<tail_n} tail_b[j] * SRS[offset + n + j].
+ * With the bases registered as  lagrange[0..n) || pcs[0..K) || pcs[zd..zd+K)  and the tail  blinds || -blinds  this is
+ * lagrange_pcs.commit(evals) followed by pcs.apply_blind_factors(cm, blinds, zd) (kzg_poly_commitment.rs:299-313): the blind
+ * terms ride in the commit's own MSM.  The stride lets the evaluation vectors stay where they are (no gather into a staging
+ * array); a device tail is what uzk_fold_blinds_batch_device leaves behind.  n + tail_n <= 2^26. */
+int uzk_msm_g1_batch_tail_device(uint64_t srs_handle, size_t offset, const void* d_scalars_mont, size_t stride, size_t n,
+                                 uint32_t batch, const void* tail_scalars_mont, uint32_t tail_n, int tail_on_device, uzk_g1_jac* out);
 /* One-shot, nothing cached: points and scalars are host arrays of the same length. */
 int uzk_msm_g1_raw(const uzk_g1_affine* points, const uint64_t* scalars_mont, size_t n,
                    uzk_g1_jac* out);
@@ -162,6 +172,12 @@ int uzk_ntt_fr_device(const void* d_in, void* d_out, uint64_t n, int inverse,
 int uzk_ntt_fr_batch(uint64_t* data, uint64_t n, uint32_t batch, int inverse, const uint64_t* coset_shift_mont);
 int uzk_ntt_fr_batch_device(const void* d_in, void* d_out, uint64_t n, uint32_t batch, int inverse,
                             const uint64_t* coset_shift_mont, int sync);
+
+/* The same with consecutive vectors in_stride / out_stride elements apart (>= n; d_in == d_out needs equal strides): a batch
+ * that reads or writes slots of a wider array -- the prover's iFFT results go straight into the 6n-element slots its coset
+ * FFTs read (uzkge/src/plonk/prover.rs:160-175 -> helpers.rs:256-266), no copy in between. */
+int uzk_ntt_fr_batch_strided_device(const void* d_in, uint64_t in_stride, void* d_out, uint64_t out_stride, uint64_t n,
+                                    uint32_t batch, int inverse, const uint64_t* coset_shift_mont, int sync);
 
 /* ---- polynomial helpers next to the hot path ------------------------ */
 /* out[b] = sum_j coefs[b*n + j] * x^j : FpPolynomial::eval (field_polynomial.rs:198-209) for a batch of
@@ -212,6 +228,40 @@ int uzk_poly_lincomb_device(const void* const* d_polys, const uint64_t* lens, co
  * hiding_degree, zero-padded by the caller): coefs[i] += blinds[i], coefs[zeroing_degree + i] -= blinds[i].
  * hiding_degree <= 16.  Asynchronous on the library stream. */
 int uzk_hide_polynomial_device(void* d_coefs, uint64_t len, const uint64_t* blinds_mont, uint32_t hiding_degree, uint64_t zeroing_degree);
+
+/* ---- batched / pointer-list forms: one launch per prover step instead of one per polynomial ---------------------------- */
+/* hide_polynomial (helpers.rs:139-158) for `count` polynomials `stride` elements apart holding len_in coefficients each:
+ * as the reference's `resize`, slots [len_in, zeroing_degree + hiding_degree) are written (zeros, then minus the blinds),
+ * not read.  blinds: count * hiding_degree elements (host), count * hiding_degree <= 64.  Asynchronous. */
+int uzk_hide_polynomial_batch_device(void* d_coefs, uint64_t stride, uint64_t len_in, uint32_t count, const uint64_t* blinds_mont,
+                                     uint32_t hiding_degree, uint64_t zeroing_degree);
+/* uzk_fold_blinds_device for `batch` <= 16 polynomials (lens[b] coefficients, in_stride apart), results out_stride apart, and
+ * the scalars of apply_blind_factors left on the device as the tail of the following commit:
+ *   d_tail[b * tail_n + i] = blind_i = -coefs_b[N + i],  d_tail[b * tail_n + tail_n / 2 + i] = -blind_i   (zero padded),
+ * so fold -> uzk_ntt_fr_batch_strided_device -> uzk_msm_g1_batch_tail_device(.., d_tail, tail_n, 1, ..) is the tail of
+ * batch_prove (pcs.rs:137-166) / split_t_and_commit (helpers.rs:1366-1394) without a host round trip.  blinds_out (optional,
+ * host, batch * tail_n / 2 elements): the blinds as the reference's Vec; asking for them synchronises. */
+int uzk_fold_blinds_batch_device(const void* d_polys, uint64_t in_stride, const uint64_t* lens, uint64_t n_fold, uint32_t batch,
+                                 void* d_out, uint64_t out_stride, void* d_tail, uint32_t tail_n, uint64_t* blinds_out);
+/* The split of t in split_t_and_commit (helpers.rs:1335-1363); `chunk` is the reference's `n` argument (n_constraints + 2):
+ * chunk i < last = t[i chunk .. (i+1) chunk) resized to chunk + 1 with coefs[chunk] += rands[i], coefs[0] -= rands[i-1];
+ * the last chunk = t[last chunk .. t_len) (or [-rands[last-1]] if empty) with coefs[0] -= rands[last-1].  Written to
+ * d_chunks + i * chunk_stride, zero padded to chunk_stride; lens_out[i] (optional, host) = the reference's coefs.len().
+ * n_chunks <= 8.  Asynchronous. */
+int uzk_split_t_device(const void* d_t, uint64_t t_len, uint64_t chunk, uint32_t n_chunks, const uint64_t* rands_mont,
+                       void* d_chunks, uint64_t chunk_stride, uint64_t* lens_out);
+/* out[k] = p_k(points[point_idx[k]]) for `count` device-resident polynomials of lens[k] coefficients: the prover's round 4
+ * (prover.rs:246-273: 15 polynomials at zeta, 4 at zeta * omega) in one launch (count <= 64, n_points <= 4, lens <= 2^18;
+ * beyond that one call per polynomial). */
+int uzk_poly_eval_ptrs_device(const void* const* d_polys, const uint64_t* lens, const uint32_t* point_idx, uint32_t count,
+                              const uint64_t* points_mont, uint32_t n_points, uint64_t* out);
+/* uzk_open_quotient_device over a pointer list (polynomials of different lengths, wherever they live):
+ * q = (sum_k alpha^k p_k) div (X - z) -> d_q: hlen - 1 coefficients (hlen = max lens[k]), zeros up to q_cap >= hlen.
+ * evals_out (optional, host, count elements) = p_k(z); without it nothing is evaluated -- the constant batch_prove subtracts
+ * (pcs.rs:124-130) only changes the remainder.  The division is queued on the context's stream and the call returns: d_q is
+ * complete after the next synchronising call (uzk_sync, a commit, a D2H copy). */
+int uzk_open_quotient_ptrs_device(const void* const* d_polys, const uint64_t* lens, uint32_t count, const uint64_t* z_mont,
+                                  const uint64_t* alpha_mont, void* d_q, uint64_t q_cap, uint64_t* evals_out);
 
 /* The quotient evaluations of t_poly on the coset k[1]*<g_m> (uzkge/src/plonk/helpers.rs:284-656 with
  * the "shuffle" feature; gate function turbo/mod.rs:193-222): for every point of the m = factor*n

@@ -45,6 +45,7 @@ PROTOTYPES = {
     "uzk_msm_g1_device": (_I, [_U64, _SZ, _P, _SZ, _P]),
     "uzk_msm_g1_batch": (_I, [_U64, _SZ, _P, _SZ, ctypes.c_uint32, _P]),
     "uzk_msm_g1_batch_device": (_I, [_U64, _SZ, _P, _SZ, ctypes.c_uint32, _P]),
+    "uzk_msm_g1_batch_tail_device": (_I, [_U64, _SZ, _P, _SZ, _SZ, ctypes.c_uint32, _P, ctypes.c_uint32, _I, _P]),
     "uzk_msm_g1_raw": (_I, [_P, _P, _SZ, _P]),
     "uzk_g1_fold": (_I, [_P, _SZ, _P]),
     "uzk_g1_to_affine": (_I, [_P, _P]),
@@ -54,6 +55,12 @@ PROTOTYPES = {
     "uzk_ntt_fr_device": (_I, [_P, _P, _U64, _I, _P, _I]),
     "uzk_ntt_fr_batch": (_I, [_P, _U64, ctypes.c_uint32, _I, _P]),
     "uzk_ntt_fr_batch_device": (_I, [_P, _P, _U64, ctypes.c_uint32, _I, _P, _I]),
+    "uzk_ntt_fr_batch_strided_device": (_I, [_P, _U64, _P, _U64, _U64, ctypes.c_uint32, _I, _P, _I]),
+    "uzk_hide_polynomial_batch_device": (_I, [_P, _U64, _U64, ctypes.c_uint32, _P, ctypes.c_uint32, _U64]),
+    "uzk_fold_blinds_batch_device": (_I, [_P, _U64, _P, _U64, ctypes.c_uint32, _P, _U64, _P, ctypes.c_uint32, _P]),
+    "uzk_split_t_device": (_I, [_P, _U64, _U64, ctypes.c_uint32, _P, _P, _U64, _P]),
+    "uzk_poly_eval_ptrs_device": (_I, [_P, _P, _P, ctypes.c_uint32, _P, ctypes.c_uint32, _P]),
+    "uzk_open_quotient_ptrs_device": (_I, [_P, _P, ctypes.c_uint32, _P, _P, _P, _U64, _P]),
     "uzk_poly_eval_batch": (_I, [_P, _U64, ctypes.c_uint32, _P, _P]),
     "uzk_poly_eval_batch_device": (_I, [_P, _U64, ctypes.c_uint32, _P, _P]),
     "uzk_z_poly": (_I, [_P, _P, _P, _P, _P, _P, ctypes.c_uint32, ctypes.c_uint32, _P]),

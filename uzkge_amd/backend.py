@@ -433,3 +433,76 @@ def dev_memset(d_dst: int, byte: int, nbytes: int) -> None:
 
 def dev_memset2d(d_dst: int, pitch: int, byte: int, width: int, rows: int) -> None:
     check(lib.uzk_dev_memset2d(ctypes.c_void_p(d_dst), pitch, byte, width, rows))
+
+
+# ---- batched / strided / pointer-list forms (one launch per prover step) -----------------------------------------
+def _fr4(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.uint64).reshape(4)
+
+
+def ntt_batch_strided_device(d_in: int, in_stride: int, d_out: int, out_stride: int, n: int, batch: int, inverse: bool = False,
+                             coset_shift: Optional[np.ndarray] = None, sync: bool = False) -> None:
+    cs = _fr4(coset_shift) if coset_shift is not None else None
+    check(lib.uzk_ntt_fr_batch_strided_device(ctypes.c_void_p(d_in), in_stride, ctypes.c_void_p(d_out), out_stride, n, batch,
+                                              int(inverse), _ptr(cs) if cs is not None else None, int(sync)))
+
+
+def msm_batch_tail_device(srs: Srs, d_scalars: int, stride: int, n: int, batch: int, tail, tail_n: int, offset: int = 0) -> np.ndarray:
+    """`tail`: a host array [batch, tail_n, 4] or a device address (int) of batch * tail_n elements."""
+    out = np.zeros((batch, 12), dtype=np.uint64)
+    if isinstance(tail, (int, np.integer)):
+        tp, on_dev = ctypes.c_void_p(int(tail)), 1
+    else:
+        t = np.ascontiguousarray(tail, dtype=np.uint64).reshape(batch * tail_n, 4) if tail_n else None
+        tp, on_dev = (_ptr(t) if t is not None else None), 0
+    check(lib.uzk_msm_g1_batch_tail_device(srs.handle, offset, ctypes.c_void_p(d_scalars), stride, n, batch, tp, tail_n, on_dev, _ptr(out)))
+    return out
+
+
+def hide_polynomial_batch_device(d_coefs: int, stride: int, len_in: int, blinds: np.ndarray, zeroing_degree: int) -> None:
+    """blinds [count, hiding_degree, 4]."""
+    bl = np.ascontiguousarray(blinds, dtype=np.uint64)
+    assert bl.ndim == 3 and bl.shape[2] == 4
+    check(lib.uzk_hide_polynomial_batch_device(ctypes.c_void_p(d_coefs), stride, len_in, bl.shape[0], _ptr(bl.reshape(-1, 4)), bl.shape[1],
+                                               zeroing_degree))
+
+
+def fold_blinds_batch_device(d_polys: int, in_stride: int, lens, n_fold: int, d_out: int, out_stride: int, d_tail: int, tail_n: int,
+                             want_blinds: bool = False):
+    ln = np.ascontiguousarray(lens, dtype=np.uint64)
+    batch = ln.shape[0]
+    bl = np.zeros((batch, max(tail_n // 2, 1), 4), dtype=np.uint64) if want_blinds else None
+    check(lib.uzk_fold_blinds_batch_device(ctypes.c_void_p(d_polys), in_stride, _ptr(ln), n_fold, batch, ctypes.c_void_p(d_out), out_stride,
+                                           ctypes.c_void_p(d_tail), tail_n, _ptr(bl.reshape(-1, 4)) if want_blinds else None))
+    return bl[:, : tail_n // 2] if want_blinds else None
+
+
+def split_t_device(d_t: int, t_len: int, chunk: int, rands: np.ndarray, d_chunks: int, chunk_stride: int) -> np.ndarray:
+    """Returns the chunk lengths (the reference's coefs.len())."""
+    r = np.ascontiguousarray(rands, dtype=np.uint64).reshape(-1, 4)
+    lens = np.zeros(r.shape[0], dtype=np.uint64)
+    check(lib.uzk_split_t_device(ctypes.c_void_p(d_t), t_len, chunk, r.shape[0], _ptr(r), ctypes.c_void_p(d_chunks), chunk_stride, _ptr(lens)))
+    return lens
+
+
+def _ptr_list(d_polys):
+    return (ctypes.c_void_p * len(d_polys))(*[ctypes.c_void_p(p) for p in d_polys])
+
+
+def poly_eval_ptrs_device(d_polys, lens, point_idx, points: np.ndarray) -> np.ndarray:
+    cnt = len(d_polys)
+    ln = np.ascontiguousarray(lens, dtype=np.uint64)
+    pi = np.ascontiguousarray(point_idx, dtype=np.uint32)
+    pts = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 4)
+    out = np.zeros((cnt, 4), dtype=np.uint64)
+    check(lib.uzk_poly_eval_ptrs_device(_ptr_list(d_polys), _ptr(ln), pi.ctypes.data_as(ctypes.c_void_p), cnt, _ptr(pts), pts.shape[0], _ptr(out)))
+    return out
+
+
+def open_quotient_ptrs_device(d_polys, lens, z: np.ndarray, alpha: np.ndarray, d_q: int, q_cap: int, want_evals: bool = False):
+    cnt = len(d_polys)
+    ln = np.ascontiguousarray(lens, dtype=np.uint64)
+    ev = np.zeros((cnt, 4), dtype=np.uint64) if want_evals else None
+    check(lib.uzk_open_quotient_ptrs_device(_ptr_list(d_polys), _ptr(ln), cnt, _ptr(_fr4(z)), _ptr(_fr4(alpha)), ctypes.c_void_p(d_q), q_cap,
+                                            _ptr(ev) if want_evals else None))
+    return ev

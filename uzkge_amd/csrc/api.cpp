@@ -70,10 +70,12 @@ int DevBuf::reserve(size_t bytes) {
     size_t want = bytes + (bytes >> 3);   // 12.5 % head-room against regrowth
     hipError_t e = hipMalloc(&p, want);
     if (e != hipSuccess) {
+        (void)hipGetLastError();
         want = bytes;
         e = hipMalloc(&p, want);
     }
     if (e != hipSuccess) {
+        (void)hipGetLastError();        // clear the runtime's sticky last error
         p = nullptr;
         set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
         return UZK_ERR_DEVICE;
@@ -181,6 +183,7 @@ static void ctx_release(Ctx& c) {
     msm_free(c);
     poly_free(c);
     c.ntt_scratch[0].release(); c.ntt_scratch[1].release(); c.ntt_io.release(); c.msm_scalars.release();
+    if (c.msm_tail_host) { (void)hipHostFree(c.msm_tail_host); c.msm_tail_host = nullptr; c.msm_tail_cap = 0; }
     for (auto& pe : c.prof_pending) { (void)hipEventDestroy(pe.e0); (void)hipEventDestroy(pe.e1); }
     c.prof_pending.clear();
     for (auto e : c.event_pool) (void)hipEventDestroy(e);
@@ -331,7 +334,12 @@ int uzk_dev_alloc(size_t bytes, void** d_out) {
     UZK_TRY(require_ready());
     if (bytes == 0) return UZK_OK;
     hipError_t e = hipMalloc(d_out, bytes);
-    if (e != hipSuccess) { *d_out = nullptr; set_error("uzk_dev_alloc(%zu): %s", bytes, hipGetErrorString(e)); return UZK_ERR_DEVICE; }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();        // the runtime keeps a failed call as its sticky "last error": the next launch check must not see it
+        *d_out = nullptr;
+        set_error("uzk_dev_alloc(%zu): %s", bytes, hipGetErrorString(e));
+        return UZK_ERR_DEVICE;
+    }
     return UZK_OK;
 }
 // Waits for the calling context's stream first: work queued on it may still use the block.
@@ -350,7 +358,7 @@ int uzk_host_alloc(size_t bytes, void** h_out) {
     UZK_TRY(require_ready());
     if (bytes == 0) return UZK_OK;
     hipError_t e = hipHostMalloc(h_out, bytes, hipHostMallocDefault);
-    if (e != hipSuccess) { *h_out = nullptr; set_error("uzk_host_alloc(%zu): %s", bytes, hipGetErrorString(e)); return UZK_ERR_DEVICE; }
+    if (e != hipSuccess) { (void)hipGetLastError(); *h_out = nullptr; set_error("uzk_host_alloc(%zu): %s", bytes, hipGetErrorString(e)); return UZK_ERR_DEVICE; }
     Shared& s = shared();
     std::lock_guard<std::mutex> lk(s.mu);
     s.pinned[*h_out] = bytes;
@@ -540,11 +548,14 @@ static int msm_checked(uint64_t srs_handle, size_t offset, size_t n, Ctx::Srs* s
     return UZK_OK;
 }
 // general mode unless the handle carries a window table
-static int msm_dispatch_one(const Ctx::Srs& s, size_t offset, const Fp* d_scalars, size_t n, uint32_t batch, Jac* out) {
+static int msm_dispatch_view(const Ctx::Srs& s, size_t offset, const ScalarView& sv, size_t n, uint32_t batch, Jac* out) {
     Ctx& c = ctx();
     if (s.d_table && !c.tune_no_precompute)
-        return msm_run(c, s.d_table, d_scalars, n, batch, out, s.pre_c, (uint32_t)s.n, (uint32_t)offset);
-    return msm_run(c, s.d_points + offset, d_scalars, n, batch, out, 0, 0, 0);
+        return msm_run(c, s.d_table, sv, n, batch, out, s.pre_c, (uint32_t)s.n, (uint32_t)offset);
+    return msm_run(c, s.d_points + offset, sv, n, batch, out, 0, 0, 0);
+}
+static int msm_dispatch_one(const Ctx::Srs& s, size_t offset, const Fp* d_scalars, size_t n, uint32_t batch, Jac* out) {
+    return msm_dispatch_view(s, offset, ScalarView::dense(d_scalars, n), n, batch, out);
 }
 // The sort indexes (point, window) pairs with 31 bits, so one pass handles at most 2^26 points per
 // scalar vector (2^26 * 16 windows); longer inputs are cut into point chunks whose partial sums are
@@ -622,6 +633,45 @@ int uzk_msm_g1_batch(uint64_t srs_handle, size_t offset, const uint64_t* scalars
         UZK_TRY(msm_dispatch(srs, offset, c.msm_scalars.as<Fp>(), n, batch, r.data()));
     }
     if (batch) std::memcpy(out, r.data(), (size_t)batch * sizeof(Jac));
+    return UZK_OK;
+}
+
+// out[b] = sum_{i<n} d_scalars[b*stride + i] * SRS[offset + i] + sum_{j<tail_n} tail[b*tail_n + j] * SRS[offset + n + j]
+int uzk_msm_g1_batch_tail_device(uint64_t srs_handle, size_t offset, const void* d_scalars_mont, size_t stride, size_t n, uint32_t batch,
+                                 const void* tail_scalars_mont, uint32_t tail_n, int tail_on_device, uzk_g1_jac* out) {
+    API_LOCK;
+    if (batch > 0 && (!out || (n > 0 && !d_scalars_mont) || (tail_n > 0 && !tail_scalars_mont))) { set_error("uzk_msm_g1_batch_tail_device: null pointer"); return UZK_ERR_PARAMETER; }
+    if (batch > 1 && stride < n) { set_error("uzk_msm_g1_batch_tail_device: stride %zu smaller than n %zu", stride, n); return UZK_ERR_PARAMETER; }
+    if (tail_n > 4096) { set_error("uzk_msm_g1_batch_tail_device: tail_n %u exceeds 4096", tail_n); return UZK_ERR_PARAMETER; }
+    UZK_TRY(require_ready());
+    Ctx& c = ctx();
+    const size_t total = n + tail_n;
+    Ctx::Srs srs;
+    UZK_TRY(msm_checked(srs_handle, offset, total, &srs));
+    if (total > ((size_t)1 << c.tune_chunk_log)) { set_error("uzk_msm_g1_batch_tail_device: n + tail_n = %zu exceeds one sort pass (2^%d points)", total, c.tune_chunk_log); return UZK_ERR_PARAMETER; }
+    if (batch == 0) return UZK_OK;
+    ScalarView sv;
+    sv.main = static_cast<const Fp*>(d_scalars_mont);
+    sv.stride = stride;
+    sv.n_main = (uint32_t)n;
+    sv.tail_n = tail_n;
+    if (tail_n && tail_on_device) sv.tail = static_cast<const Fp*>(tail_scalars_mont);
+    else if (tail_n) {
+        // a few dozen elements: copied into pinned, device-visible memory the digit kernel reads directly; the call returns
+        // after the window sums have arrived, so one slot per context is enough
+        const size_t bytes = (size_t)batch * tail_n * sizeof(Fp);
+        if (c.msm_tail_cap < bytes) {
+            if (c.msm_tail_host) { UZK_HIP(hipStreamSynchronize(c.stream)); (void)hipHostFree(c.msm_tail_host); c.msm_tail_host = nullptr; c.msm_tail_cap = 0; }
+            const size_t cap = std::max<size_t>(bytes, 1 << 14);
+            UZK_HIP(hipHostMalloc(reinterpret_cast<void**>(&c.msm_tail_host), cap, hipHostMallocDefault));
+            c.msm_tail_cap = cap;
+        }
+        std::memcpy(c.msm_tail_host, tail_scalars_mont, bytes);
+        sv.tail = c.msm_tail_host;
+    }
+    std::vector<Jac> r(batch);
+    UZK_TRY(msm_dispatch_view(srs, offset, sv, total, batch, r.data()));
+    std::memcpy(out, r.data(), (size_t)batch * sizeof(Jac));
     return UZK_OK;
 }
 
@@ -709,6 +759,21 @@ int uzk_ntt_fr_batch_device(const void* d_in, void* d_out, uint64_t n, uint32_t 
     API_LOCK;
     return ntt_device_common(d_in, d_out, n, batch, inverse, coset_shift_mont, sync);
 }
+int uzk_ntt_fr_batch_strided_device(const void* d_in, uint64_t in_stride, void* d_out, uint64_t out_stride, uint64_t n, uint32_t batch,
+                                    int inverse, const uint64_t* coset_shift_mont, int sync) {
+    API_LOCK;
+    if (!domain_supported(n)) {
+        set_error("no evaluation domain of size %llu (need 2^k, k<=28, or 3*2^k)", (unsigned long long)n);
+        return UZK_ERR_FFT;
+    }
+    if (!d_in || !d_out) { set_error("uzk_ntt_fr_batch_strided_device: null pointer"); return UZK_ERR_PARAMETER; }
+    UZK_TRY(require_ready());
+    Ctx& c = ctx();
+    UZK_TRY(ntt_run(c, static_cast<const Fp*>(d_in), static_cast<Fp*>(d_out), n, inverse != 0,
+                    coset_shift_mont ? as_fp(coset_shift_mont) : nullptr, batch, in_stride, out_stride));
+    if (sync) UZK_HIP(hipStreamSynchronize(c.stream));
+    return UZK_OK;
+}
 int uzk_ntt_fr(uint64_t* data, uint64_t n, int inverse, const uint64_t* coset_shift_mont) {
     API_LOCK;
     return ntt_host_common(data, n, 1, inverse, coset_shift_mont);
@@ -788,6 +853,49 @@ int uzk_hide_polynomial_device(void* d_coefs, uint64_t len, const uint64_t* blin
     if (!d_coefs || (hiding_degree > 0 && !blinds_mont)) { set_error("uzk_hide_polynomial_device: null pointer"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
     return poly_hide_run(ctx(), static_cast<Fp*>(d_coefs), len, as_fp(blinds_mont), hiding_degree, zeroing_degree);
+}
+
+int uzk_hide_polynomial_batch_device(void* d_coefs, uint64_t stride, uint64_t len_in, uint32_t count, const uint64_t* blinds_mont,
+                                     uint32_t hiding_degree, uint64_t zeroing_degree) {
+    API_LOCK;
+    if (count > 0 && hiding_degree > 0 && (!d_coefs || !blinds_mont)) { set_error("uzk_hide_polynomial_batch_device: null pointer"); return UZK_ERR_PARAMETER; }
+    UZK_TRY(require_ready());
+    return poly_hide_batch_run(ctx(), static_cast<Fp*>(d_coefs), stride, len_in, count, as_fp(blinds_mont), hiding_degree, zeroing_degree);
+}
+
+int uzk_fold_blinds_batch_device(const void* d_polys, uint64_t in_stride, const uint64_t* lens, uint64_t n_fold, uint32_t batch, void* d_out,
+                                 uint64_t out_stride, void* d_tail, uint32_t tail_n, uint64_t* blinds_out) {
+    API_LOCK;
+    if (batch > 0 && (!d_polys || !lens || !d_out || (tail_n > 0 && !d_tail))) { set_error("uzk_fold_blinds_batch_device: null pointer"); return UZK_ERR_PARAMETER; }
+    UZK_TRY(require_ready());
+    return fold_blinds_batch_run(ctx(), static_cast<const Fp*>(d_polys), in_stride, lens, n_fold, batch, static_cast<Fp*>(d_out), out_stride,
+                                 static_cast<Fp*>(d_tail), tail_n, reinterpret_cast<Fp*>(blinds_out));
+}
+
+int uzk_split_t_device(const void* d_t, uint64_t t_len, uint64_t chunk, uint32_t n_chunks, const uint64_t* rands_mont, void* d_chunks,
+                       uint64_t chunk_stride, uint64_t* lens_out) {
+    API_LOCK;
+    if (!d_t || !rands_mont || !d_chunks) { set_error("uzk_split_t_device: null pointer"); return UZK_ERR_PARAMETER; }
+    if (d_t == d_chunks) { set_error("uzk_split_t_device: output aliases the input"); return UZK_ERR_PARAMETER; }
+    UZK_TRY(require_ready());
+    return split_t_run(ctx(), static_cast<const Fp*>(d_t), t_len, chunk, n_chunks, as_fp(rands_mont), static_cast<Fp*>(d_chunks), chunk_stride, lens_out);
+}
+
+int uzk_poly_eval_ptrs_device(const void* const* d_polys, const uint64_t* lens, const uint32_t* point_idx, uint32_t count,
+                              const uint64_t* points_mont, uint32_t n_points, uint64_t* out) {
+    API_LOCK;
+    if (count > 0 && (!d_polys || !lens || !point_idx || !points_mont || !out)) { set_error("uzk_poly_eval_ptrs_device: null pointer"); return UZK_ERR_PARAMETER; }
+    UZK_TRY(require_ready());
+    return poly_eval_ptrs(ctx(), d_polys, lens, point_idx, count, as_fp(points_mont), n_points, reinterpret_cast<Fp*>(out));
+}
+
+int uzk_open_quotient_ptrs_device(const void* const* d_polys, const uint64_t* lens, uint32_t count, const uint64_t* z_mont,
+                                  const uint64_t* alpha_mont, void* d_q, uint64_t q_cap, uint64_t* evals_out) {
+    API_LOCK;
+    if (!d_polys || !lens || !z_mont || !alpha_mont || !d_q) { set_error("uzk_open_quotient_ptrs_device: null pointer"); return UZK_ERR_PARAMETER; }
+    UZK_TRY(require_ready());
+    return open_quotient_ptrs(ctx(), d_polys, lens, count, *as_fp(z_mont), *as_fp(alpha_mont), static_cast<Fp*>(d_q), q_cap,
+                              reinterpret_cast<Fp*>(evals_out));
 }
 
 int uzk_t_quotient_device(const uzk_quotient_args* args, void* d_out, int sync) {

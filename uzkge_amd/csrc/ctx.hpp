@@ -23,6 +23,7 @@ void set_error(const char* fmt, ...);
     do {                                                                                   \
         hipError_t _e = (expr);                                                            \
         if (_e != hipSuccess) {                                                            \
+            (void)hipGetLastError(); /* the runtime keeps it as its sticky last error: clear it */ \
             ::uzk::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
             return UZK_ERR_DEVICE;                                                         \
         }                                                                                  \
@@ -74,6 +75,8 @@ struct Ctx {
     // MSM
     MsmWork* msm = nullptr;
     DevBuf msm_scalars;       // staging for host scalars
+    Fp* msm_tail_host = nullptr;   // pinned: the tail scalars of the current call (uzk_msm_g1_batch_tail_device)
+    size_t msm_tail_cap = 0;
     int msm_window_bits = 0;  // 0 = auto
     int tune_acc_variant = 0; // experiments (uzk_tune)
     int tune_task_len = 0;
@@ -122,6 +125,22 @@ struct Ctx {
     int prof_collect();   // sync + fold pending events into totals
 };
 
+// The scalars of an MSM call: vector b, element i is main[b * stride + i] for i < n_main and
+// tail[b * tail_n + (i - n_main)] beyond (n = n_main + tail_n).  The tail carries the blind factors of a commit
+// (apply_blind_factors, kzg_poly_commitment.rs:299-313) so that they ride in the commit's own MSM; it may live in
+// pinned host memory (a few dozen elements, read once by the digit kernel).
+struct ScalarView {
+    const Fp* main = nullptr;
+    uint64_t stride = 0;
+    uint32_t n_main = 0;
+    const Fp* tail = nullptr;
+    uint32_t tail_n = 0;
+    static ScalarView dense(const Fp* p, size_t n) { ScalarView v; v.main = p; v.stride = n; v.n_main = (uint32_t)n; return v; }
+    __host__ __device__ const Fp& at(uint32_t b, uint32_t i) const {
+        return i < n_main ? main[(uint64_t)b * stride + i] : tail[(uint64_t)b * tail_n + (i - n_main)];
+    }
+};
+
 Ctx& ctx();
 std::mutex& ctx_mutex();
 int require_ready();
@@ -148,10 +167,11 @@ struct KernelScope {
 };
 
 // entry points implemented in the .hip files
-int ntt_run(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse, const Fp* coset_shift_host, uint32_t batch);
+int ntt_run(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse, const Fp* coset_shift_host, uint32_t batch,
+            uint64_t in_stride = 0, uint64_t out_stride = 0);
 void ntt_free_plans(Ctx& c);
 void msm_plan_info(Ctx& c, size_t n, int* window_bits, int* windows);
-int msm_run(Ctx& c, const Affine* points, const Fp* d_scalars, size_t n, uint32_t batch, Jac* out_host, int pre_c,
+int msm_run(Ctx& c, const Affine* points, const ScalarView& scalars, size_t n, uint32_t batch, Jac* out_host, int pre_c,
             uint32_t pre_stride, uint32_t pre_off);
 int msm_build_table(Ctx& c, const Affine* d_points, size_t n, int cb, Affine** table_out, uint32_t* W_out);
 int msm_precompute_window_bits(size_t n, int forced);
@@ -164,6 +184,16 @@ int poly_eval_batch(Ctx& c, const Fp* d_coefs, uint64_t n, uint32_t batch, const
 int poly_eval_batch_host(Ctx& c, const Fp* coefs_host, uint64_t n, uint32_t batch, const Fp& x, Fp* out_host);
 int open_quotient_run(Ctx& c, const Fp* d_polys, uint64_t n, uint32_t batch, const Fp& z, const Fp& alpha, Fp* d_q,
                       Fp* evals_host);
+int poly_eval_ptrs(Ctx& c, const void* const* d_polys, const uint64_t* lens, const uint32_t* point_idx, uint32_t count,
+                   const Fp* points_host, uint32_t n_points, Fp* out_host);
+int open_quotient_ptrs(Ctx& c, const void* const* d_polys, const uint64_t* lens, uint32_t count, const Fp& z, const Fp& alpha, Fp* d_q,
+                       uint64_t q_cap, Fp* evals_host);
+int poly_hide_batch_run(Ctx& c, Fp* d_coefs, uint64_t stride, uint64_t len_in, uint32_t count, const Fp* blinds_host, uint32_t hd,
+                        uint64_t zeroing_degree);
+int fold_blinds_batch_run(Ctx& c, const Fp* d_polys, uint64_t in_stride, const uint64_t* lens_host, uint64_t N, uint32_t batch, Fp* d_out,
+                          uint64_t out_stride, Fp* d_tail, uint32_t tail_n, Fp* blinds_host);
+int split_t_run(Ctx& c, const Fp* d_t, uint64_t t_len, uint64_t chunk, uint32_t n_chunks, const Fp* rands_host, Fp* d_chunks,
+                uint64_t chunk_stride, uint64_t* lens_out);
 int fold_blinds_run(Ctx& c, const Fp* d_coefs, uint64_t len, uint64_t N, Fp* d_out, Fp* blinds_host);
 int poly_lincomb_run(Ctx& c, const void* const* d_polys, const uint64_t* lens, const Fp* scalars_host, uint32_t count, Fp* d_out,
                      uint64_t out_len);

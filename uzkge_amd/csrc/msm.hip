@@ -85,12 +85,12 @@ __device__ __forceinline__ uint32_t msm_fold_scalar_sign(Fp& k) {
 
 
 // scalars: [batch][n]; digits: [batch][wcnt][n] for the windows w0 .. w0 + wcnt of the W-window recoding
-__global__ __launch_bounds__(256) void msm_digits_kernel(const Fp* __restrict__ scalars, uint32_t* __restrict__ digits,
+__global__ __launch_bounds__(256) void msm_digits_kernel(ScalarView scalars, uint32_t* __restrict__ digits,
                                                          uint32_t n, uint32_t batch, int c, int W, int w0, int wcnt) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (uint64_t)n * batch) return;
     const uint32_t b = (uint32_t)(t / n), i = (uint32_t)(t % n);
-    Fp k = Fr::from_mont(scalars[t]);
+    Fp k = Fr::from_mont(scalars.at(b, i));
     const uint32_t flip = msm_fold_scalar_sign(k);
     const uint32_t mask = (1u << c) - 1, half = 1u << (c - 1);
     uint32_t carry = 0;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void msm_digits_kernel(const Fp* __restrict__ 
 // vector): besides the digits it leaves the chunk's pass-0 histograms counts[seg][ch][bins] for all
 // windows, so the sort's first histogram kernel (a 4-byte read of every entry) is not needed.
 // General mode, large n only (a chunk must be big enough to keep 1024 lanes busy).
-__global__ __launch_bounds__(1024) void msm_digits_hist_kernel(const Fp* __restrict__ scalars, uint32_t* __restrict__ digits,
+__global__ __launch_bounds__(1024) void msm_digits_hist_kernel(ScalarView scalars, uint32_t* __restrict__ digits,
                                                                uint32_t n, int c, int W, uint32_t shift, uint32_t bins,
                                                                uint32_t* __restrict__ counts) {
     extern __shared__ uint32_t hist[];       // [W][bins]
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(1024) void msm_digits_hist_kernel(const Fp* __restr
     __syncthreads();
     const uint32_t mask = (1u << c) - 1, half = 1u << (c - 1), bmask = bins - 1;
     for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        Fp k = Fr::from_mont(scalars[(size_t)b * n + i]);
+        Fp k = Fr::from_mont(scalars.at(b, i));
         const uint32_t flip = msm_fold_scalar_sign(k);
         uint32_t carry = 0;
         uint32_t* dst = digits + (size_t)b * W * n + i;
@@ -1591,7 +1591,7 @@ static int msm_group_plan(Ctx& c, MsmGroup& g, size_t n, uint32_t batch, int cb,
 
 // Phase 1 (asynchronous on g.st): digits, sort, task schedule, bucket accumulation, copy of the
 // largest bucket population to the host.
-static int msm_group_phase1(Ctx& c, MsmGroup& g, const Affine* points, const Fp* d_scalars, uint32_t pre_stride,
+static int msm_group_phase1(Ctx& c, MsmGroup& g, const Affine* points, const ScalarView& d_scalars, uint32_t pre_stride,
                             uint32_t pre_off) {
     MsmWork& m = *g.m;
     hipStream_t st = g.st;
@@ -1937,7 +1937,7 @@ bool msm_small_applies(Ctx& c, size_t n, uint32_t batch, int pre_c = 0) {
 // General mode: `points` are the bases, the host combines the W window sums by Horner.  Window-table mode (pre_c > 0):
 // `points` is T[w][i] = 2^(pre_c w) P_i (row stride pre_stride, first column pre_off), every window keeps its own bucket
 // set but reads its own row, and the window sums just add up -- no doublings on the host.
-static int msm_run_small(Ctx& c, const Affine* points, const Fp* d_scalars, size_t n, uint32_t batch, Jac* out_host, int pre_c,
+static int msm_run_small(Ctx& c, const Affine* points, const ScalarView& d_scalars, size_t n, uint32_t batch, Jac* out_host, int pre_c,
                          uint32_t pre_stride, uint32_t pre_off) {
     MsmWork& m = c.msm[0];
     hipStream_t st = c.stream;
@@ -2092,9 +2092,10 @@ void msm_plan_info(Ctx& c, size_t n, int* window_bits, int* windows) {
 // `points`: base array the sorted indices refer to (the SRS slice, or the window table).
 // Precomputed mode (pre_c > 0): `points` = table, entries of window j index pre_stride * j + pre_off + i.
 // `batch` scalar vectors of n elements each share the same bases; out_host[batch].
-int msm_run(Ctx& c, const Affine* points, const Fp* d_scalars, size_t n, uint32_t batch, Jac* out_host, int pre_c,
+int msm_run(Ctx& c, const Affine* points, const ScalarView& d_scalars, size_t n, uint32_t batch, Jac* out_host, int pre_c,
             uint32_t pre_stride, uint32_t pre_off) {
     if (batch == 0) return UZK_OK;
+    if ((size_t)d_scalars.n_main + d_scalars.tail_n != n) { set_error("msm: scalar view covers %u + %u elements, n = %zu", d_scalars.n_main, d_scalars.tail_n, n); return UZK_ERR_PARAMETER; }
     if (n == 0) { for (uint32_t b = 0; b < batch; ++b) out_host[b] = jac_inf(); return UZK_OK; }
     if (n >= (1ull << 31)) { set_error("msm: n = %zu exceeds 2^31 - 1 points per call", n); return UZK_ERR_PARAMETER; }
     if (!c.msm) c.msm = new MsmWork[2];

@@ -84,12 +84,12 @@ __device__ __forceinline__ uint32_t bitrev(uint32_t x, int bits) {
 
 __global__ __launch_bounds__(256) void ntt_small_kernel(const Fp* __restrict__ in, Fp* __restrict__ out,
                                                         int log_n, const Fp* __restrict__ tw,
-                                                        Fp scale, int use_scale) {
+                                                        Fp scale, int use_scale, uint64_t in_stride, uint64_t out_stride) {
     extern __shared__ uint4 lds_small[];
     Fp* s = reinterpret_cast<Fp*>(lds_small);
     const uint32_t n = 1u << log_n;
-    const Fp* src = in + (uint64_t)blockIdx.x * n;
-    Fp* dst = out + (uint64_t)blockIdx.x * n;
+    const Fp* src = in + (uint64_t)blockIdx.x * in_stride;
+    Fp* dst = out + (uint64_t)blockIdx.x * out_stride;
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) s[bitrev(i, log_n)] = src[i];
     __syncthreads();
     for (int lh = 0; lh < log_n; ++lh) {
@@ -147,7 +147,11 @@ __device__ __forceinline__ void radix4_rx(Fp& x0, Fp& x1, Fp& x2, Fp& x3, const 
 }
 
 struct PassArgs {
-    uint64_t batch_stride; // elements between consecutive vectors of a batch (= N)
+    uint64_t batch_stride; // elements between consecutive (sub-)transforms in the scratch buffers, and the size of the fused tables (= N)
+    // Elements between consecutive FULL vectors where the caller's memory is touched: the first pass's input and the last
+    // pass's output (uzk_ntt_fr_batch_strided_device: a batch that reads / writes slots of a wider array, e.g. the 6n-slots
+    // the prover keeps its coefficient polynomials in).  Contiguous vectors: the full vector length.
+    uint64_t in_vec_stride, out_vec_stride;
     uint64_t stride;       // N / R
     int log_S;             // log2 of the product of earlier radices
     const Fp* tw256;       // omega_256^e, direction-specific
@@ -200,8 +204,9 @@ __global__ __launch_bounds__(512) void ntt_pass_kernel(const Fp* __restrict__ in
     const int col = tid % T, q = tid / T;
     const uint64_t i0 = (uint64_t)blockIdx.x * T;
     const uint64_t i = i0 + col;
-    in += (uint64_t)blockIdx.y * a.batch_stride;     // batch of independent transforms
-    out += (uint64_t)blockIdx.y * a.batch_stride;
+    // batch of independent transforms: the first pass reads / the last pass writes the caller's (possibly strided) vectors
+    in += (uint64_t)blockIdx.y * (FIRST ? a.in_vec_stride : a.batch_stride);
+    out += (uint64_t)blockIdx.y * (a.twp == nullptr ? a.out_vec_stride : a.batch_stride);
 
     const Fp w4 = a.tw256[64];
     Fp x[4];
@@ -388,8 +393,10 @@ __global__ __launch_bounds__(TILE / 4) void ntt_pass29_kernel(const Fp* __restri
     const uint64_t i = i0 + col;
     const Fp* in_base = in;
     Fp* out_base = out;
-    in += (uint64_t)blockIdx.y * a.batch_stride;
-    out += (uint64_t)blockIdx.y * a.batch_stride;
+    // plain / coset transforms: the first pass reads and the last pass writes the caller's vectors (stride in_vec_stride /
+    // out_vec_stride); the radix-3 forms address whole vectors through in_base / out_base below
+    in += (uint64_t)blockIdx.y * ((FIRST && a.m3 == 0) ? a.in_vec_stride : a.batch_stride);
+    out += (uint64_t)blockIdx.y * ((a.twp == nullptr && a.out_mul <= 1) ? a.out_vec_stride : a.batch_stride);
 
     const L29 w4 = tw29_load(a.tw256, 256, 64);
     L29 x[4];
@@ -400,7 +407,7 @@ __global__ __launch_bounds__(TILE / 4) void ntt_pass29_kernel(const Fp* __restri
         if (a.m3 != 0) {
             // decimation in frequency by 3 in front of sub-transform r of vector blockIdx.y / 3 (see PassArgs)
             const uint32_t r = blockIdx.y % 3;
-            const Fp* vec = in_base + (uint64_t)(blockIdx.y / 3) * (3 * a.m3);
+            const Fp* vec = in_base + (uint64_t)(blockIdx.y / 3) * a.in_vec_stride;
             const bool tabled = a.in_tw[r] != nullptr;
             L29 al, be;
             if (r != 0) { al = F9::from_fp(a.alpha[r]); be = F9::from_fp(a.beta[r]); }
@@ -497,7 +504,7 @@ __global__ __launch_bounds__(TILE / 4) void ntt_pass29_kernel(const Fp* __restri
             // last pass of a fused transform: interleaved store (radix-3 outputs 3 i' + r) and / or coset post-scaling
             const uint32_t mul = a.out_mul > 1 ? a.out_mul : 1u;
             const uint32_t r = mul > 1 ? blockIdx.y % mul : 0u;
-            Fp* dst = mul > 1 ? out_base + (uint64_t)(blockIdx.y / mul) * (mul * a.batch_stride) : out;
+            Fp* dst = mul > 1 ? out_base + (uint64_t)(blockIdx.y / mul) * a.out_vec_stride : out;
             const Fp* otw = a.out_tw[r];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -704,15 +711,19 @@ static void launch_pass(Ctx& c, bool l29, bool first, const Fp* in, Fp* out, con
 // `batch` contiguous vectors of n elements each, d_in -> d_out (may alias)
 // `fx` (optional): the fused stages of PassArgs -- first-pass input tables / radix-3 load, last-pass interleaved store
 // and output tables; batch then counts sub-transforms (3 per vector when fx->m3 != 0).
+// in_vs / out_vs: elements between consecutive FULL vectors of the caller's input / output (0 = contiguous).
 static int ntt_pow2(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse, bool scaled, uint32_t batch,
-                    const PassArgs* fx = nullptr) {
+                    const PassArgs* fx = nullptr, uint64_t in_vs = 0, uint64_t out_vs = 0) {
     NttPlan* p = nullptr;
     UZK_TRY(get_plan(c, n, inverse, scaled, &p));
+    const uint64_t n_full = (fx && fx->m3) ? 3 * n : n;              // radix-3 forms: batch counts sub-transforms of n = m3
+    if (in_vs == 0) in_vs = n_full;
+    if (out_vs == 0) out_vs = n_full;
     if (p->log_n <= 11) {
         KernelScope ks(c, "ntt_small");
         const size_t shmem = (size_t)n * sizeof(Fp);
         hipLaunchKernelGGL(ntt_small_kernel, dim3(batch), dim3(256), shmem, c.stream, d_in, d_out, p->log_n,
-                           p->d_small_tw, p->scale, scaled ? 1 : 0);
+                           p->d_small_tw, p->scale, scaled ? 1 : 0, in_vs, out_vs);
         UZK_HIP(hipGetLastError());
         return UZK_OK;
     }
@@ -721,7 +732,9 @@ static int ntt_pow2(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse,
     Fp* s0 = c.ntt_scratch[0].as<Fp>();
     Fp* s1 = nullptr;
     const bool in_place = (d_in == d_out);
-    if (in_place && (p->npass & 1)) {
+    // A strided output holds other data between its vectors: intermediate passes then stay in the two scratch buffers.
+    const bool out_dense = out_vs == n_full;
+    if ((in_place && (p->npass & 1)) || (!out_dense && p->npass > 2)) {
         UZK_TRY(c.ntt_scratch[1].reserve(bytes));
         s1 = c.ntt_scratch[1].as<Fp>();
     }
@@ -732,6 +745,7 @@ static int ntt_pow2(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse,
     for (int j = 0; j < p->npass; ++j) {
         const int remaining = p->npass - 1 - j;
         Fp* dst = (remaining % 2 == 0) ? d_out : s0;
+        if (!out_dense && remaining > 0) dst = (j % 2 == 0) ? s0 : s1;      // scratch only until the last pass
         if (dst == src) dst = s1;   // only when in_place and npass is odd, at j == 0
         PassArgs a{};
         if (fx != nullptr) {
@@ -739,6 +753,8 @@ static int ntt_pow2(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse,
             if (j == p->npass - 1) { a.out_mul = fx->out_mul; for (int k = 0; k < 3; ++k) a.out_tw[k] = fx->out_tw[k]; }
         }
         a.batch_stride = n;
+        a.in_vec_stride = in_vs;
+        a.out_vec_stride = out_vs;
         a.stride = n >> p->bits[j];
         a.log_S = log_S;
         a.tw256 = p->d_tw256;
@@ -888,22 +904,37 @@ static int get_fused(Ctx& c, uint64_t n, bool inverse, const Fp* shift, NttFused
     return UZK_OK;
 }
 
-// `batch` independent transforms over contiguous vectors of n elements (d_in -> d_out, may alias).
-int ntt_run(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse, const Fp* coset_shift_host, uint32_t batch) {
+// `batch` independent transforms of n elements each (d_in -> d_out, may alias when the strides are equal); consecutive
+// vectors are in_stride / out_stride elements apart (0 = contiguous).
+int ntt_run(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse, const Fp* coset_shift_host, uint32_t batch,
+            uint64_t in_stride, uint64_t out_stride) {
     if (!domain_supported(n)) {
         set_error("no evaluation domain of size %llu (need 2^k, k<=28, or 3*2^k)", (unsigned long long)n);
         return UZK_ERR_FFT;
     }
     if (batch == 0) return UZK_OK;
     if (batch > 65535) { set_error("ntt: batch %u exceeds 65535", batch); return UZK_ERR_PARAMETER; }
+    if (in_stride == n) in_stride = 0;
+    if (out_stride == n) out_stride = 0;
+    if ((in_stride && in_stride < n) || (out_stride && out_stride < n)) { set_error("ntt: a vector stride is smaller than n"); return UZK_ERR_PARAMETER; }
+    if (d_in == d_out && in_stride != out_stride) { set_error("ntt: in-place transforms need equal strides"); return UZK_ERR_PARAMETER; }
+    const bool strided = in_stride != 0 || out_stride != 0;
     // 29-bit-limb pass kernels: coset scaling and the radix-3 stage of 3 * 2^k domains run inside the first / last pass
     // (no separate scaling, decimation or combination kernels; 2 launches for the prover's 98304-point coset FFTs)
     const uint64_t sub_n = n % 3 == 0 ? n / 3 : n;
     if (c.tune_ntt_l29 && c.tune_ntt_fused && sub_n >= 4096 && (n % 3 == 0 || coset_shift_host != nullptr)) {
         NttFused* f = nullptr;
         UZK_TRY(get_fused(c, n, inverse, coset_shift_host, &f));
-        if (n % 3 == 0) return ntt_pow2(c, d_in, d_out, sub_n, inverse, false, 3 * batch, &f->fx);
-        return ntt_pow2(c, d_in, d_out, n, inverse, inverse, batch, &f->fx);
+        if (n % 3 == 0) return ntt_pow2(c, d_in, d_out, sub_n, inverse, false, 3 * batch, &f->fx, in_stride, out_stride);
+        return ntt_pow2(c, d_in, d_out, n, inverse, inverse, batch, &f->fx, in_stride, out_stride);
+    }
+    if (n % 3 != 0 && coset_shift_host == nullptr) return ntt_pow2(c, d_in, d_out, n, inverse, inverse, batch, nullptr, in_stride, out_stride);
+    if (strided) {
+        // the separate scaling / decimation kernels (small or unfused transforms) work on contiguous batches: one vector at a time
+        for (uint32_t b = 0; b < batch; ++b)
+            UZK_TRY(ntt_run(c, d_in + (uint64_t)b * (in_stride ? in_stride : n), d_out + (uint64_t)b * (out_stride ? out_stride : n), n, inverse,
+                            coset_shift_host, 1, 0, 0));
+        return UZK_OK;
     }
     const dim3 egrid((unsigned)((n + 255) / 256), batch);
     const Fp* src = d_in;

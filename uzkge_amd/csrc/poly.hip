@@ -140,13 +140,26 @@ __global__ __launch_bounds__(64) void poly_eval_finish_kernel(const Fp* __restri
 // polynomial to arrive (a counter per polynomial, reset by that workgroup) adds the block sums and stores the value
 // straight into pinned host memory: no table kernel, no finish kernel, no copy kernel.
 constexpr int kEvalSmallPer = 4, kEvalSmallBlock = 256 * kEvalSmallPer, kEvalSmallMaxBlocks = 256;
-__global__ __launch_bounds__(256) void poly_eval_small_kernel(const Fp* __restrict__ coefs, uint64_t n, Fp x, Fp* __restrict__ partial,
+constexpr uint32_t kEvalMaxPolys = 64, kEvalMaxPoints = 4;
+// The polynomials of one launch: poly b has len[b] coefficients at p[b] and is evaluated at x[pt[b]] -- the prover's round 4
+// (prover.rs:246-273: 15 polynomials at zeta, 4 at zeta * omega) is ONE launch.  By value: 1.2 KB of kernel arguments.
+struct EvalArgs {
+    const Fp* p[kEvalMaxPolys];
+    uint32_t len[kEvalMaxPolys];
+    uint8_t pt[kEvalMaxPolys];
+    Fp x[kEvalMaxPoints];
+};
+__global__ __launch_bounds__(256) void poly_eval_small_kernel(EvalArgs a, Fp* __restrict__ partial,
                                                               uint32_t* __restrict__ counters, Fp* __restrict__ out_host) {
     __shared__ Fp pw[256];
     __shared__ Fp sh[256];
     __shared__ uint32_t last;
-    const uint32_t tid = threadIdx.x, blk = blockIdx.x, nblocks = gridDim.x, b = blockIdx.y;
-    const Fp* c = coefs + (uint64_t)b * n;
+    const uint32_t tid = threadIdx.x, blk = blockIdx.x, stride = gridDim.x, b = blockIdx.y;
+    const uint64_t n = a.len[b];
+    const uint32_t nblocks = (uint32_t)((n + kEvalSmallBlock - 1) / kEvalSmallBlock);
+    if (blk >= nblocks) return;                       // shorter polynomials of a mixed launch need fewer workgroups
+    const Fp* c = a.p[b];
+    const Fp x = a.x[a.pt[b]];
     const uint64_t base = (uint64_t)blk * kEvalSmallBlock + (uint64_t)tid * kEvalSmallPer;
     Fp h = Fr::zero();
 #pragma unroll
@@ -179,7 +192,7 @@ __global__ __launch_bounds__(256) void poly_eval_small_kernel(const Fp* __restri
         __syncthreads();
     }
     if (tid == 0) {
-        partial[(uint64_t)b * nblocks + blk] = Fr::mul(sh[0], wblk);
+        partial[(uint64_t)b * stride + blk] = Fr::mul(sh[0], wblk);
         __threadfence();
         last = (atomicAdd(&counters[b], 1u) == nblocks - 1) ? 1u : 0u;
     }
@@ -187,7 +200,7 @@ __global__ __launch_bounds__(256) void poly_eval_small_kernel(const Fp* __restri
     if (last && tid == 0) {
         __threadfence();
         Fp acc = Fr::zero();
-        for (uint32_t k = 0; k < nblocks; ++k) acc = Fr::add(acc, partial[(uint64_t)b * nblocks + k]);
+        for (uint32_t k = 0; k < nblocks; ++k) acc = Fr::add(acc, partial[(uint64_t)b * stride + k]);
         out_host[b] = acc;
         counters[b] = 0;                       // ready for the next call on this stream
     }
@@ -202,27 +215,38 @@ static int poly_host_reserve(Ctx& c, size_t bytes) {
     return UZK_OK;
 }
 
+// One launch over `count` <= 64 polynomials (each <= 2^18 coefficients), results copied to out_host after the stream is idle.
+static int poly_eval_small_launch(Ctx& c, const EvalArgs& a, uint32_t count, uint32_t max_blocks, Fp* out_host) {
+    UZK_TRY(c.poly_tmp.reserve((size_t)count * max_blocks * sizeof(Fp)));
+    if (c.poly_cnt.cap < (size_t)kEvalMaxPolys * 4) {
+        UZK_TRY(c.poly_cnt.reserve(4096));
+        UZK_HIP(hipMemsetAsync(c.poly_cnt.p, 0, c.poly_cnt.cap, c.stream));
+    }
+    UZK_TRY(poly_host_reserve(c, (size_t)kEvalMaxPolys * sizeof(Fp)));
+    {
+        KernelScope ks(c, "poly_eval");
+        hipLaunchKernelGGL(poly_eval_small_kernel, dim3(max_blocks, count), dim3(256), 0, c.stream, a, c.poly_tmp.as<Fp>(),
+                           c.poly_cnt.as<uint32_t>(), static_cast<Fp*>(c.poly_host));
+    }
+    UZK_HIP(hipGetLastError());
+    UZK_HIP(hipStreamSynchronize(c.stream));
+    std::memcpy(out_host, c.poly_host, (size_t)count * sizeof(Fp));
+    return UZK_OK;
+}
+
 int poly_eval_batch(Ctx& c, const Fp* d_coefs, uint64_t n, uint32_t batch, const Fp& x, Fp* out_host) {
     if (batch == 0) return UZK_OK;
     if (n == 0) { for (uint32_t b = 0; b < batch; ++b) out_host[b] = Fr::zero(); return UZK_OK; }
     if (batch > 65535) { set_error("poly_eval: batch %u exceeds 65535", batch); return UZK_ERR_PARAMETER; }
     const uint64_t nb_small = (n + kEvalSmallBlock - 1) / kEvalSmallBlock;
     if (nb_small <= (uint64_t)kEvalSmallMaxBlocks && c.tune_poly_small) {
-        const uint32_t nblocks = (uint32_t)nb_small;
-        UZK_TRY(c.poly_tmp.reserve((size_t)batch * nblocks * sizeof(Fp)));
-        if (c.poly_cnt.cap < (size_t)batch * 4) {
-            UZK_TRY(c.poly_cnt.reserve(std::max<size_t>((size_t)batch * 4, 4096)));
-            UZK_HIP(hipMemsetAsync(c.poly_cnt.p, 0, c.poly_cnt.cap, c.stream));
+        for (uint32_t b0 = 0; b0 < batch; b0 += kEvalMaxPolys) {
+            const uint32_t cnt = std::min<uint32_t>(kEvalMaxPolys, batch - b0);
+            EvalArgs a{};
+            a.x[0] = x;
+            for (uint32_t k = 0; k < cnt; ++k) { a.p[k] = d_coefs + (uint64_t)(b0 + k) * n; a.len[k] = (uint32_t)n; a.pt[k] = 0; }
+            UZK_TRY(poly_eval_small_launch(c, a, cnt, (uint32_t)nb_small, out_host + b0));
         }
-        UZK_TRY(poly_host_reserve(c, (size_t)batch * sizeof(Fp)));
-        {
-            KernelScope ks(c, "poly_eval");
-            hipLaunchKernelGGL(poly_eval_small_kernel, dim3(nblocks, batch), dim3(256), 0, c.stream, d_coefs, n, x, c.poly_tmp.as<Fp>(),
-                               c.poly_cnt.as<uint32_t>(), static_cast<Fp*>(c.poly_host));
-        }
-        UZK_HIP(hipGetLastError());
-        UZK_HIP(hipStreamSynchronize(c.stream));
-        std::memcpy(out_host, c.poly_host, (size_t)batch * sizeof(Fp));
         return UZK_OK;
     }
     const uint32_t nblocks = (uint32_t)((n + kEvalBlock - 1) / kEvalBlock);
@@ -239,6 +263,34 @@ int poly_eval_batch(Ctx& c, const Fp* d_coefs, uint64_t n, uint32_t batch, const
     UZK_HIP(hipGetLastError());
     UZK_HIP(hipMemcpyAsync(out_host, d_out, (size_t)batch * sizeof(Fp), hipMemcpyDeviceToHost, c.stream));
     UZK_HIP(hipStreamSynchronize(c.stream));
+    return UZK_OK;
+}
+
+// `count` device-resident polynomials, polynomial k evaluated at points[point_idx[k]]: one launch for count <= 64 and
+// lengths <= 2^18 (the prover's round 4), otherwise one call per polynomial.
+int poly_eval_ptrs(Ctx& c, const void* const* d_polys, const uint64_t* lens, const uint32_t* point_idx, uint32_t count,
+                   const Fp* points_host, uint32_t n_points, Fp* out_host) {
+    if (count == 0) return UZK_OK;
+    if (n_points == 0) { set_error("poly_eval: no evaluation point"); return UZK_ERR_PARAMETER; }
+    uint64_t max_len = 0;
+    for (uint32_t k = 0; k < count; ++k) {
+        if (point_idx[k] >= n_points) { set_error("poly_eval: polynomial %u names point %u of %u", k, point_idx[k], n_points); return UZK_ERR_PARAMETER; }
+        if (lens[k] && !d_polys[k]) { set_error("poly_eval: polynomial %u is null", k); return UZK_ERR_PARAMETER; }
+        max_len = std::max(max_len, lens[k]);
+    }
+    const uint64_t max_blocks = (max_len + kEvalSmallBlock - 1) / kEvalSmallBlock;
+    if (count <= kEvalMaxPolys && n_points <= kEvalMaxPoints && max_blocks <= (uint64_t)kEvalSmallMaxBlocks && max_len > 0 && c.tune_poly_small) {
+        EvalArgs a{};
+        for (uint32_t j = 0; j < n_points; ++j) a.x[j] = points_host[j];
+        bool any_empty = false;
+        for (uint32_t k = 0; k < count; ++k) {
+            a.p[k] = static_cast<const Fp*>(d_polys[k]); a.len[k] = (uint32_t)lens[k]; a.pt[k] = (uint8_t)point_idx[k];
+            any_empty = any_empty || lens[k] == 0;
+        }
+        if (!any_empty) return poly_eval_small_launch(c, a, count, (uint32_t)max_blocks, out_host);
+    }
+    for (uint32_t k = 0; k < count; ++k)
+        UZK_TRY(poly_eval_batch(c, static_cast<const Fp*>(d_polys[k]), lens[k], 1, points_host[point_idx[k]], out_host + k));
     return UZK_OK;
 }
 
@@ -529,15 +581,21 @@ int t_quotient_run(Ctx& c, const void* args_c_abi, Fp* d_out) {
 // the same for every lane (x_t += z^(16 * 2^k) x_(t + 2^k)).  n <= 2^20 coefficients per polynomial.
 // ---------------------------------------------------------------------------------------------
 
-// h[j] = sum_k apow[k] * polys[k*n + j]  - (j == 0 ? E : 0)
-__global__ __launch_bounds__(256) void open_lincomb_kernel(const Fp* __restrict__ polys, uint64_t n, uint32_t batch,
-                                                           const Fp* __restrict__ apow, Fp E, Fp* __restrict__ h) {
+constexpr uint32_t kLincombMax = 64;
+struct LincombArgs {                      // by value: 2.8 KB of kernel arguments, no staging copy and no synchronisation
+    const Fp* p[kLincombMax];
+    uint32_t len[kLincombMax];
+    Fp scalars[kLincombMax];
+    uint32_t count;
+};
+__global__ __launch_bounds__(256) void poly_lincomb_kernel(LincombArgs a, Fp* __restrict__ out, uint64_t out_len, int accumulate) {
+    const Fp* scalars = a.scalars;
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    Fp acc = polys[j];                                  // alpha^0 = 1
-    for (uint32_t k = 1; k < batch; ++k) acc = Fr::add(acc, Fr::mul(apow[k], polys[(uint64_t)k * n + j]));
-    if (j == 0) acc = Fr::sub(acc, E);
-    h[j] = acc;
+    if (j >= out_len) return;
+    Fp acc = accumulate ? out[j] : Fr::zero();
+    for (uint32_t k = 0; k < a.count; ++k)
+        if (j < a.len[k]) acc = Fr::add(acc, Fr::mul(scalars[k], a.p[k][j]));
+    out[j] = acc;
 }
 // s_i = h_i + z s_(i+1) within each block of 256 PER coefficients, carry-in 0; block_first[b] = s at the block's lowest index.
 // zp[k] = z^(PER * 2^k), k < 8.
@@ -583,10 +641,23 @@ __global__ __launch_bounds__(256) void open_div_block_kernel(const Fp* __restric
     if (tid == 0) block_first[blockIdx.x] = sh[0];
 }
 // carries between blocks (nblocks <= 256): c_b = sum_{b' > b} first[b'] z^(4096 (b' - b - 1)); zb[k] = z^(4096 * 2^k)
-__global__ __launch_bounds__(256) void open_div_carry_kernel(const Fp* __restrict__ block_first, uint32_t nblocks, DivPows pb,
-                                                             Fp* __restrict__ carry) {
+// Also leaves ztab[t] = (z^PER)^t, t <= 256, for the apply kernel: built in LDS by doubling with the multipliers
+// pw.zp[k] = z^(PER 2^k) the block kernel already uses (no host table, no upload, no synchronisation).
+__global__ __launch_bounds__(256) void open_div_carry_kernel(const Fp* __restrict__ block_first, uint32_t nblocks, DivPows pw, DivPows pb,
+                                                             Fp* __restrict__ carry, Fp* __restrict__ ztab) {
     __shared__ Fp sh[256];
     const uint32_t tid = threadIdx.x;
+    if (tid == 0) sh[0] = Fr::one();
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t half = 1u << k;
+        if (tid < half) sh[half + tid] = Fr::mul(sh[tid], pw.zp[k]);
+        __syncthreads();
+    }
+    ztab[tid] = sh[tid];
+    if (tid == 0) ztab[256] = pb.zp[0];                 // z^(256 PER)
+    __syncthreads();
     sh[tid] = tid < nblocks ? block_first[tid] : Fr::zero();
     __syncthreads();
 #pragma unroll
@@ -599,14 +670,15 @@ __global__ __launch_bounds__(256) void open_div_carry_kernel(const Fp* __restric
     }
     if (tid < nblocks) carry[tid] = (tid + 1 < 256) ? sh[tid + 1] : Fr::zero();
 }
-// q[i-1] = s_i + z^(block_hi - i) carry[block]  for 1 <= i < n ;  q[n-1] = 0 ; ztab[t] = z^t, t <= 4096
+// q[i-1] = s_i + z^(block_hi - i) carry[block]  for 1 <= i < n ;  q[n-1 .. q_cap) = 0 ; ztab16[t] = z^(PER t), t <= 256
 template <int kDivPer>
 __global__ __launch_bounds__(256) void open_div_apply_kernel(const Fp* __restrict__ s, const Fp* __restrict__ carry,
-                                                             const Fp* __restrict__ ztab16, Fp z, uint64_t n,
+                                                             const Fp* __restrict__ ztab16, Fp z, uint64_t n, uint64_t q_cap,
                                                              Fp* __restrict__ q) {
     constexpr int kDivBlock = 256 * kDivPer;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= q_cap) return;
+    if (i >= n) { q[i] = Fr::zero(); return; }
     if (i == 0) { q[n - 1] = Fr::zero(); return; }
     const uint64_t blk = i / kDivBlock;
     const uint32_t dist = (uint32_t)((blk + 1) * kDivBlock - i);      // 1 .. 4096
@@ -622,51 +694,83 @@ __global__ __launch_bounds__(256) void open_div_apply_kernel(const Fp* __restric
 }
 
 
-int open_quotient_run(Ctx& c, const Fp* d_polys, uint64_t n, uint32_t batch, const Fp& z, const Fp& alpha, Fp* d_q,
-                      Fp* evals_host) {
-    if (batch == 0 || n == 0) { set_error("open_quotient: need batch > 0 and n > 0"); return UZK_ERR_PARAMETER; }
+// h = sum_k alpha^k p_k over `count` device-resident polynomials of lens[k] coefficients; q = h div (X - z) written to d_q:
+// hlen - 1 coefficients (hlen = the longest polynomial) followed by zeros up to q_cap.  The constant sum_k alpha^k p_k(z)
+// that batch_prove subtracts first (pcs.rs:124-130) only changes h_0, i.e. the remainder -- never q -- so no evaluation is
+// needed for the quotient; evals_host (optional) receives p_k(z) all the same (one more launch and a synchronisation).
+// Without it the call is asynchronous: the power tables are built on the device.
+int open_quotient_ptrs(Ctx& c, const void* const* d_polys, const uint64_t* lens, uint32_t count, const Fp& z, const Fp& alpha, Fp* d_q,
+                       uint64_t q_cap, Fp* evals_host) {
+    if (count == 0) { set_error("open_quotient: need at least one polynomial"); return UZK_ERR_PARAMETER; }
+    uint64_t n = 0;
+    for (uint32_t k = 0; k < count; ++k) {
+        if (lens[k] && !d_polys[k]) { set_error("open_quotient: polynomial %u is null", k); return UZK_ERR_PARAMETER; }
+        if (d_polys[k] == d_q) { set_error("open_quotient: output aliases polynomial %u", k); return UZK_ERR_PARAMETER; }
+        n = std::max(n, lens[k]);
+    }
+    if (n == 0) { set_error("open_quotient: every polynomial is empty"); return UZK_ERR_PARAMETER; }
     if (n > (1ull << 20)) { set_error("open_quotient: n = %llu exceeds 2^20 coefficients", (unsigned long long)n); return UZK_ERR_PARAMETER; }
-    if (batch > 4096) { set_error("open_quotient: batch %u exceeds 4096", batch); return UZK_ERR_PARAMETER; }
-    UZK_TRY(poly_eval_batch(c, d_polys, n, batch, z, evals_host));          // p_k(z), also returned to the caller
-    std::vector<Fp> apow(batch);
-    Fp E = Fr::zero(), a = Fr::one();
-    for (uint32_t k = 0; k < batch; ++k) { apow[k] = a; E = Fr::add(E, Fr::mul(a, evals_host[k])); a = Fr::mul(a, alpha); }
+    if (q_cap < n) { set_error("open_quotient: d_q holds %llu elements, the quotient needs %llu", (unsigned long long)q_cap, (unsigned long long)n); return UZK_ERR_PARAMETER; }
+    if (evals_host) {
+        std::vector<uint32_t> pt(count, 0u);
+        UZK_TRY(poly_eval_ptrs(c, d_polys, lens, pt.data(), count, &z, 1, evals_host));     // p_k(z), returned to the caller
+    }
     const int per = (n <= (1ull << 16) && c.tune_poly_small) ? 4 : 16;       // coefficients per lane of the division kernels
     const int log_per = per == 4 ? 2 : 4;
     const uint64_t div_block = 256ull * per;
     const uint32_t nblocks = (uint32_t)((n + div_block - 1) / div_block);
-    // layout: apow[batch] | h[n] | s[n] | block_first[256] | carry[256] | ztab[257]
-    UZK_TRY(c.open_tmp.reserve(((size_t)batch + 2 * n + 256 + 256 + 257) * sizeof(Fp)));
-    Fp* d_apow = c.open_tmp.as<Fp>();
-    Fp* d_h = d_apow + batch;
+    // layout: h[n] | s[n] | block_first[256] | carry[256] | ztab[257]
+    UZK_TRY(c.open_tmp.reserve((2 * n + 256 + 256 + 257) * sizeof(Fp)));
+    Fp* d_h = c.open_tmp.as<Fp>();
     Fp* d_s = d_h + n;
     Fp* d_first = d_s + n;
     Fp* d_carry = d_first + 256;
     Fp* d_ztab = d_carry + 256;
-    std::vector<Fp> ztab(257);
     DivPows pw, pb;
     pw.z = z; pb.z = z;
     {
-        Fp z16 = z;
-        for (int i = 0; i < log_per; ++i) z16 = Fr::sqr(z16);               // z^per
-        Fp cur = Fr::one();
-        for (int t = 0; t <= 256; ++t) { ztab[t] = cur; cur = Fr::mul(cur, z16); }   // z^(per t)
-        Fp p = z16;
-        for (int k = 0; k < 8; ++k) { pw.zp[k] = p; p = Fr::sqr(p); }       // z^(per * 2^k)
-        p = ztab[256];                                                      // z^(256 per): one block
+        Fp p = z;
+        for (int i = 0; i < log_per; ++i) p = Fr::sqr(p);                   // z^per
+        for (int k = 0; k < 8; ++k) { pw.zp[k] = p; p = Fr::sqr(p); }       // z^(per * 2^k); p ends as z^(256 per): one block
         for (int k = 0; k < 8; ++k) { pb.zp[k] = p; p = Fr::sqr(p); }
     }
-    UZK_HIP(hipMemcpyAsync(d_apow, apow.data(), batch * sizeof(Fp), hipMemcpyHostToDevice, c.stream));
-    UZK_HIP(hipMemcpyAsync(d_ztab, ztab.data(), ztab.size() * sizeof(Fp), hipMemcpyHostToDevice, c.stream));
     KernelScope ks(c, "open_quotient");
-    hipLaunchKernelGGL(open_lincomb_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, d_polys, n, batch, d_apow, E, d_h);
+    Fp a = Fr::one();
+    for (uint32_t k0 = 0; k0 < count; k0 += kLincombMax) {                   // h = sum alpha^k p_k, 64 polynomials per launch
+        LincombArgs la;
+        la.count = std::min<uint32_t>(kLincombMax, count - k0);
+        for (uint32_t k = 0; k < la.count; ++k) {
+            la.p[k] = static_cast<const Fp*>(d_polys[k0 + k]);
+            la.len[k] = (uint32_t)lens[k0 + k];
+            la.scalars[k] = a;
+            a = Fr::mul(a, alpha);
+        }
+        hipLaunchKernelGGL(poly_lincomb_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, la, d_h, n, k0 ? 1 : 0);
+    }
     if (per == 4) hipLaunchKernelGGL(open_div_block_kernel<4>, dim3(nblocks), dim3(256), 0, c.stream, d_h, n, pw, d_s, d_first);
     else hipLaunchKernelGGL(open_div_block_kernel<16>, dim3(nblocks), dim3(256), 0, c.stream, d_h, n, pw, d_s, d_first);
-    hipLaunchKernelGGL(open_div_carry_kernel, dim3(1), dim3(256), 0, c.stream, d_first, nblocks, pb, d_carry);
-    if (per == 4) hipLaunchKernelGGL(open_div_apply_kernel<4>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, d_s, d_carry, d_ztab, z, n, d_q);
-    else hipLaunchKernelGGL(open_div_apply_kernel<16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, d_s, d_carry, d_ztab, z, n, d_q);
+    hipLaunchKernelGGL(open_div_carry_kernel, dim3(1), dim3(256), 0, c.stream, d_first, nblocks, pw, pb, d_carry, d_ztab);
+    if (per == 4) hipLaunchKernelGGL(open_div_apply_kernel<4>, dim3((unsigned)((q_cap + 255) / 256)), dim3(256), 0, c.stream, d_s, d_carry, d_ztab, z, n, q_cap, d_q);
+    else hipLaunchKernelGGL(open_div_apply_kernel<16>, dim3((unsigned)((q_cap + 255) / 256)), dim3(256), 0, c.stream, d_s, d_carry, d_ztab, z, n, q_cap, d_q);
     UZK_HIP(hipGetLastError());
-    UZK_HIP(hipStreamSynchronize(c.stream));     // apow / ztab are host vectors of this call
+    return UZK_OK;
+}
+
+// The contiguous form (batch polynomials of n coefficients each): the same through a pointer list.
+int open_quotient_run(Ctx& c, const Fp* d_polys, uint64_t n, uint32_t batch, const Fp& z, const Fp& alpha, Fp* d_q,
+                      Fp* evals_host) {
+    if (batch == 0 || n == 0) { set_error("open_quotient: need batch > 0 and n > 0"); return UZK_ERR_PARAMETER; }
+    if (batch > 4096) { set_error("open_quotient: batch %u exceeds 4096", batch); return UZK_ERR_PARAMETER; }
+    std::vector<const void*> ptrs(batch);
+    std::vector<uint64_t> lens(batch, n);
+    for (uint32_t k = 0; k < batch; ++k) ptrs[k] = d_polys + (uint64_t)k * n;
+    if (evals_host && batch > kEvalMaxPolys) {           // more evaluations than one launch holds: the batched evaluator
+        UZK_TRY(poly_eval_batch(c, d_polys, n, batch, z, evals_host));
+        UZK_TRY(open_quotient_ptrs(c, ptrs.data(), lens.data(), batch, z, alpha, d_q, n, nullptr));
+    } else {
+        UZK_TRY(open_quotient_ptrs(c, ptrs.data(), lens.data(), batch, z, alpha, d_q, n, evals_host));
+    }
+    UZK_HIP(hipStreamSynchronize(c.stream));             // this entry point's contract: q is in d_q when it returns
     return UZK_OK;
 }
 
@@ -711,22 +815,6 @@ int fold_blinds_run(Ctx& c, const Fp* d_coefs, uint64_t len, uint64_t N, Fp* d_o
 // (uzkge/src/plonk/helpers.rs:681-999: ~43 polynomials times scalars built from the evaluations and challenges --
 // those O(1) scalar formulas stay with the caller, exactly where the reference computes them).
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t kLincombMax = 64;
-struct LincombArgs {                      // by value: 2.8 KB of kernel arguments, no staging copy and no synchronisation
-    const Fp* p[kLincombMax];
-    uint32_t len[kLincombMax];
-    Fp scalars[kLincombMax];
-    uint32_t count;
-};
-__global__ __launch_bounds__(256) void poly_lincomb_kernel(LincombArgs a, Fp* __restrict__ out, uint64_t out_len) {
-    const Fp* scalars = a.scalars;
-    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= out_len) return;
-    Fp acc = Fr::zero();
-    for (uint32_t k = 0; k < a.count; ++k)
-        if (j < a.len[k]) acc = Fr::add(acc, Fr::mul(scalars[k], a.p[k][j]));
-    out[j] = acc;
-}
 int poly_lincomb_run(Ctx& c, const void* const* d_polys, const uint64_t* lens, const Fp* scalars_host, uint32_t count, Fp* d_out,
                      uint64_t out_len) {
     if (count == 0 || count > kLincombMax) { set_error("poly_lincomb: 1 <= count <= %u", kLincombMax); return UZK_ERR_PARAMETER; }
@@ -743,7 +831,7 @@ int poly_lincomb_run(Ctx& c, const void* const* d_polys, const uint64_t* lens, c
     for (uint32_t k = 0; k < count; ++k) a.scalars[k] = scalars_host[k];
     {
         KernelScope ks(c, "poly_lincomb");
-        hipLaunchKernelGGL(poly_lincomb_kernel, dim3((unsigned)((out_len + 255) / 256)), dim3(256), 0, c.stream, a, d_out, out_len);
+        hipLaunchKernelGGL(poly_lincomb_kernel, dim3((unsigned)((out_len + 255) / 256)), dim3(256), 0, c.stream, a, d_out, out_len, 0);
     }
     UZK_HIP(hipGetLastError());
     return UZK_OK;                                 // asynchronous on the library stream
@@ -768,6 +856,144 @@ int poly_hide_run(Ctx& c, Fp* d_coefs, uint64_t len, const Fp* blinds_host, uint
     for (uint32_t i = 0; i < 16; ++i) h.blinds[i] = i < hiding_degree ? blinds_host[i] : Fr::zero();
     hipLaunchKernelGGL(poly_hide_kernel, dim3(1), dim3(64), 0, c.stream, d_coefs, zeroing_degree, h, hiding_degree);
     UZK_HIP(hipGetLastError());
+    return UZK_OK;
+}
+
+// ---- batched forms for the prover's rounds: one launch where the single-polynomial entry points take one per polynomial ----
+
+// hide_polynomial for `count` polynomials stored `stride` elements apart, each holding len_in meaningful coefficients:
+// the reference resizes the coefficient vector with zeros up to zeroing_degree + hiding_degree before it adds the blinds
+// (helpers.rs:146-156), so slots [len_in, zeroing_degree + hiding_degree) are WRITTEN (zero, minus the blind), not read --
+// whatever an earlier proof left there does not matter.  One workgroup per polynomial.
+constexpr uint32_t kHideBatchMax = 64;       // count * hiding_degree
+struct HideBatchArgs { Fp blinds[kHideBatchMax]; };
+__global__ __launch_bounds__(256) void poly_hide_batch_kernel(Fp* __restrict__ coefs, uint64_t stride, uint64_t len_in,
+                                                              uint64_t zeroing_degree, uint32_t hd, HideBatchArgs h) {
+    Fp* c = coefs + (uint64_t)blockIdx.x * stride;
+    const Fp* bl = h.blinds + (size_t)blockIdx.x * hd;
+    const uint64_t top = zeroing_degree + hd;
+    for (uint64_t j = len_in + threadIdx.x; j < zeroing_degree; j += blockDim.x) c[j] = Fr::zero();   // the resize's zeros below the top slots
+    const uint32_t i = threadIdx.x;
+    if (i < hd) {
+        // low and top slots are distinct (hd <= zeroing_degree), so the two updates of a lane never touch the same element
+        const Fp lo = i < len_in ? c[i] : Fr::zero();
+        const uint64_t t = zeroing_degree + i;
+        const Fp hi = t < len_in ? c[t] : Fr::zero();
+        c[i] = Fr::add(lo, bl[i]);
+        c[t] = Fr::sub(hi, bl[i]);
+    }
+    (void)top;
+}
+int poly_hide_batch_run(Ctx& c, Fp* d_coefs, uint64_t stride, uint64_t len_in, uint32_t count, const Fp* blinds_host, uint32_t hd,
+                        uint64_t zeroing_degree) {
+    if (count == 0 || hd == 0) return UZK_OK;
+    if (hd > zeroing_degree || (uint64_t)count * hd > kHideBatchMax || zeroing_degree + hd > stride || len_in > stride) {
+        set_error("hide_polynomial_batch: need hiding_degree <= zeroing_degree, count * hiding_degree <= %u, zeroing_degree + hiding_degree <= stride", kHideBatchMax);
+        return UZK_ERR_PARAMETER;
+    }
+    if (len_in < hd) { set_error("hide_polynomial_batch: a polynomial shorter than its hiding degree"); return UZK_ERR_PARAMETER; }
+    HideBatchArgs h;
+    for (uint32_t i = 0; i < kHideBatchMax; ++i) h.blinds[i] = i < count * hd ? blinds_host[i] : Fr::zero();
+    KernelScope ks(c, "poly_hide");
+    hipLaunchKernelGGL(poly_hide_batch_kernel, dim3(count), dim3(256), 0, c.stream, d_coefs, stride, len_in, zeroing_degree, hd, h);
+    UZK_HIP(hipGetLastError());
+    return UZK_OK;
+}
+
+// The fold modulo X^N - 1 (pcs.rs:137-156, helpers.rs:1366-1383) for `batch` polynomials at once, and the scalars of
+// apply_blind_factors (kzg_poly_commitment.rs:299-313) left ON THE DEVICE in the layout the commit consumes:
+//   out[b][i]  = c_b[i] + c_b[N + i]  (i < len_b - N),  c_b[i]  (len_b - N <= i < min(len_b, N)),  0 beyond
+//   tail[b][i] = -c_b[N + i] = blind_i,  tail[b][K + i] = c_b[N + i] = -blind_i   (i < len_b - N; zero up to K = tail_n / 2)
+// so that fold -> FFT(N) -> MSM(evals || tail) runs without the blinds ever visiting the host.
+constexpr uint32_t kFoldBatchMax = 16;
+struct FoldBatchArgs { uint32_t len[kFoldBatchMax]; };
+__global__ __launch_bounds__(256) void fold_blinds_batch_kernel(const Fp* __restrict__ polys, uint64_t in_stride, FoldBatchArgs lens,
+                                                                uint64_t N, Fp* __restrict__ out, uint64_t out_stride,
+                                                                Fp* __restrict__ tail, uint32_t tail_n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t b = blockIdx.y;
+    if (i >= N) return;
+    const uint64_t len = lens.len[b];
+    const Fp* c = polys + (uint64_t)b * in_stride;
+    Fp v = i < len ? c[i] : Fr::zero();
+    const uint32_t K = tail_n / 2;
+    if (N + i < len) {
+        const Fp hi = c[N + i];
+        v = Fr::add(v, hi);
+        tail[(uint64_t)b * tail_n + i] = Fr::neg(hi);
+        tail[(uint64_t)b * tail_n + K + i] = hi;
+    } else if (i < K) {
+        tail[(uint64_t)b * tail_n + i] = Fr::zero();
+        tail[(uint64_t)b * tail_n + K + i] = Fr::zero();
+    }
+    out[(uint64_t)b * out_stride + i] = v;
+}
+int fold_blinds_batch_run(Ctx& c, const Fp* d_polys, uint64_t in_stride, const uint64_t* lens_host, uint64_t N, uint32_t batch, Fp* d_out,
+                          uint64_t out_stride, Fp* d_tail, uint32_t tail_n, Fp* blinds_host) {
+    if (batch == 0) return UZK_OK;
+    if (batch > kFoldBatchMax) { set_error("fold_blinds_batch: batch %u exceeds %u", batch, kFoldBatchMax); return UZK_ERR_PARAMETER; }
+    if (N == 0 || (tail_n & 1) || out_stride < N) { set_error("fold_blinds_batch: need N > 0, an even tail_n and out_stride >= N"); return UZK_ERR_PARAMETER; }
+    FoldBatchArgs la{};
+    for (uint32_t b = 0; b < batch; ++b) {
+        const uint64_t len = lens_host[b];
+        if (len > 2 * N || len > in_stride || (len > N && len - N > tail_n / 2)) {
+            set_error("fold_blinds_batch: polynomial %u: need len <= min(2N, in_stride) and len - N <= tail_n / 2 (len %llu, N %llu, tail_n %u)", b,
+                      (unsigned long long)len, (unsigned long long)N, tail_n);
+            return UZK_ERR_PARAMETER;
+        }
+        la.len[b] = (uint32_t)len;
+    }
+    {
+        KernelScope ks(c, "fold_blinds");
+        hipLaunchKernelGGL(fold_blinds_batch_kernel, dim3((unsigned)((N + 255) / 256), batch), dim3(256), 0, c.stream, d_polys, in_stride, la, N,
+                           d_out, out_stride, d_tail, tail_n);
+    }
+    UZK_HIP(hipGetLastError());
+    if (blinds_host && tail_n) {        // optional: the blinds as the reference's Vec (tail_n / 2 per polynomial, zero padded); synchronises
+        const uint32_t K = tail_n / 2;
+        UZK_HIP(hipMemcpy2DAsync(blinds_host, K * sizeof(Fp), d_tail, tail_n * sizeof(Fp), K * sizeof(Fp), batch, hipMemcpyDeviceToHost, c.stream));
+        UZK_HIP(hipStreamSynchronize(c.stream));
+    }
+    return UZK_OK;
+}
+
+// The split of t in split_t_and_commit (helpers.rs:1335-1363), `chunk` = the reference's `n` argument (n_constraints + 2):
+//   i < last: coefs = t[i chunk .. (i+1) chunk) (zero beyond t_len), resized to chunk + 1; coefs[chunk] += rand_i; coefs[0] -= rand_(i-1)
+//   last    : coefs = t[last chunk .. t_len)  (or [-rand_(last-1)] when that range is empty);   coefs[0] -= rand_(last-1)
+// written to d_chunks + i * chunk_stride, zero padded to chunk_stride.  rand_(n_chunks-1) is drawn but unused, as in the reference.
+constexpr uint32_t kSplitMax = 8;
+struct SplitArgs { Fp rands[kSplitMax]; };
+__global__ __launch_bounds__(256) void split_t_kernel(const Fp* __restrict__ t, uint64_t t_len, uint64_t chunk, uint32_t n_chunks,
+                                                      SplitArgs r, Fp* __restrict__ out, uint64_t chunk_stride) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = blockIdx.y;
+    if (j >= chunk_stride) return;
+    const bool last = i + 1 == n_chunks;
+    const uint64_t start = (uint64_t)i * chunk;
+    const uint64_t end = last ? t_len : min(t_len, start + chunk);
+    Fp v = (start + j < end) ? t[start + j] : Fr::zero();
+    if (!last && j == chunk) v = Fr::add(v, r.rands[i]);
+    if (j == 0 && i > 0) v = Fr::sub(v, r.rands[i - 1]);
+    out[(uint64_t)i * chunk_stride + j] = v;
+}
+int split_t_run(Ctx& c, const Fp* d_t, uint64_t t_len, uint64_t chunk, uint32_t n_chunks, const Fp* rands_host, Fp* d_chunks,
+                uint64_t chunk_stride, uint64_t* lens_out) {
+    if (n_chunks == 0 || n_chunks > kSplitMax || chunk == 0) { set_error("split_t: 1 <= n_chunks <= %u and chunk > 0", kSplitMax); return UZK_ERR_PARAMETER; }
+    const uint64_t last_start = (uint64_t)(n_chunks - 1) * chunk;
+    const uint64_t last_len = t_len > last_start ? t_len - last_start : 1;         // an empty last range becomes [-prev]
+    if (chunk_stride < chunk + 1 || chunk_stride < last_len) { set_error("split_t: chunk_stride too small"); return UZK_ERR_PARAMETER; }
+    SplitArgs r;
+    for (uint32_t i = 0; i < kSplitMax; ++i) r.rands[i] = i < n_chunks ? rands_host[i] : Fr::zero();
+    {
+        KernelScope ks(c, "split_t");
+        hipLaunchKernelGGL(split_t_kernel, dim3((unsigned)((chunk_stride + 255) / 256), n_chunks), dim3(256), 0, c.stream, d_t, t_len, chunk,
+                           n_chunks, r, d_chunks, chunk_stride);
+    }
+    UZK_HIP(hipGetLastError());
+    if (lens_out) {
+        for (uint32_t i = 0; i + 1 < n_chunks; ++i) lens_out[i] = chunk + 1;
+        lens_out[n_chunks - 1] = last_len;
+    }
     return UZK_OK;
 }
 
