@@ -570,9 +570,10 @@ def run_rank(args) -> None:
             b.profile_reset(); b.profile_enable(True); ch.run(); b.sync(); b.profile_enable(False)
             ktab = b.profile_table()
             ch.release()
-            extra["prover_chain"] = {"what": "every device-resident step of one 52-card proof chained (tools/prover_chain.py: 9+1 iFFT, 8+1+5+2 "
-                                             "commits with blinds, z_poly, 10 coset FFT(6n), quotient kernel, coset iFFT, split, evaluations, "
-                                             "r_poly-shaped combination, 2 openings), synthetic circuit tables, Python/torch glue included",
+            extra["prover_chain"] = {"what": "every device-resident step of one 52-card proof chained with the reference's call mix "
+                                             "(tools/prover_chain.py: 9+1 iFFT, 8+1+5+2 commits with blinds, z_poly, 10 coset FFT(6n), quotient "
+                                             "kernel, coset iFFT, split_t with chunk n+2, 19 evaluations, r_poly over 43 polynomials, openings "
+                                             "of 16 and 4 polynomials), synthetic circuit, Python (ctypes) glue included",
                                      "ms_per_chain": round(chain_ms, 3),
                                      "device_kernel_ms": round(sum(ms for k, (cnt, ms) in ktab.items() if not k.startswith("host_")), 3)}
         except Exception as e:
@@ -588,9 +589,10 @@ def run_rank(args) -> None:
                     _write_inputs(prover_chain.ChainInputs(1 << 14, 11), td, precompute=True)
                     r = subprocess.run([exe, td, "20", "4"], capture_output=True, text=True, timeout=300)
                 line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-                extra["prover_rounds_cpp"] = dict(json.loads(line[0]), what="the chain above issued from C++ through the C ABI only "
-                                                  "(no interpreter between the calls), window table, ms per chain; four_threads = four host "
-                                                  "threads with one context each running chains at the same time") if line else {"error": r.stderr[-300:]}
+                extra["prover_rounds_cpp"] = dict(json.loads(line[0]), what="the chain above issued from C++ (plain g++) through the C ABI "
+                                                  "only, no interpreter between the calls, window table; ms_per_chain = witness resident, "
+                                                  "ms_per_chain_with_witness_upload = the 9n witness elements uploaded from pinned memory every "
+                                                  "chain; four_threads = four host threads with one context each running chains at the same time") if line else {"error": r.stderr[-300:]}
                 if len(line) > 1:
                     extra["prover_rounds_cpp"]["four_threads"] = json.loads(line[1])
         except Exception as e:

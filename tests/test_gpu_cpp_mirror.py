@@ -77,44 +77,59 @@ def _write_inputs(inp, d, shuffle=True, precompute=True):
     put("bases", inp.bases)
     put("evals9", np.concatenate([inp.w_evals.reshape(-1, 4), inp.wsel_evals.reshape(-1, 4), inp.pi_evals]))
     put("perm", inp.perm, np.uint32)
-    put("tables", inp.tables)
+    put("table_polys", inp.table_polys)
     put("k", inp.k)
-    put("scalars", np.stack([inp.beta, inp.gamma, inp.alpha, inp.zeta, inp.alpha_open, inp.anemoi_g, inp.anemoi_g_inv, inp.edwards_a,
-                             inp.k1_inv, inp.zeta_omega]))
+    put("scalars", np.stack([inp.beta, inp.gamma, inp.alpha, inp.zeta, inp.alpha_open, inp.alpha_open2, inp.anemoi_g, inp.anemoi_g_inv,
+                             inp.edwards_a, inp.k1_inv, inp.zeta_omega]))
     put("z_h_inv", inp.z_h_inv)
-    put("blinds_w", inp.blinds_w); put("blinds_wsel", inp.blinds_wsel); put("blinds_z", inp.blinds_z)
+    put("blinds8", np.concatenate([inp.blinds_w, inp.blinds_wsel])); put("blinds_z", inp.blinds_z)
     put("t_rands", inp.t_rands); put("r_scalars", inp.r_scalars)
 
 
-@pytest.mark.gpu
-def test_cpp_prover_rounds_match_frozen_outputs(gpu, tmp_path):
-    """The C++ driver runs ChainInputs(4096, 7) and must reproduce tests/golden/vectors_v2.npz (commitments over the
-    reference's SRS files, evaluations, blinds, digests of the intermediates) -- the same fixture the Python chain is held to."""
-    import hashlib
+def _run_rounds_and_check(tmp_path, shuffle):
     import sys
     import numpy as np
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import oracle_c as oc
-    from prover_chain import ChainInputs
-    V2 = np.load(os.path.join(ROOT, "tests", "golden", "vectors_v2.npz"))
-    n = int(V2["n"][0])
-    inp = ChainInputs(n, int(V2["seed"][0]))
-    _write_inputs(inp, str(tmp_path))
+    for p in (os.path.join(ROOT, "tools"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    from prover_chain import N_TABLES, ChainInputs
+    V3 = np.load(os.path.join(ROOT, "tests", "golden", "vectors_v3.npz"))
+    n = int(V3["n"][0])
+    inp = ChainInputs(n, int(V3["seed"][0]))
+    _write_inputs(inp, str(tmp_path), shuffle=shuffle)
     exe = _build_rounds()
     # 3 timed chains, then 3 host threads (one context each, one shared SRS) running 3 chains each at the same time: every
     # thread must end with the single-threaded chain's commitments and evaluations
     r = subprocess.run([exe, str(tmp_path), "3", "3"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout and '"threads_agree_with_single": true' in r.stdout, r.stdout + r.stderr
     rd = lambda name, shape: np.fromfile(os.path.join(str(tmp_path), "out_" + name + ".bin"), dtype=np.uint64).reshape(shape)
-    for key, cnt in (("cm_w_wsel", 8), ("cm_z", 1), ("cm_t", 5), ("cm_q", 2)):
-        jac = rd(key, (cnt, 12))
-        assert np.array_equal(oc.points_from_affine([oc.jac_to_affine_ints(j) for j in jac]), V2[key]), key
-    for key in ("evals_zeta", "z_eval_zeta_omega", "open_evals_zeta", "open_evals_zeta_omega", "t_blinds", "q_blinds"):
-        assert np.array_equal(rd(key, (-1, 4)), V2[key]), key
-    m = 6 * n
+    m, cs = 6 * n, n + 8
+    small = {key: rd(key, (cnt, 12)) for key, cnt in (("cm_w_wsel", 8), ("cm_z", 1), ("cm_t", 5), ("cm_q", 2))}
+    small.update(evals=rd("evals", (-1, 4)), t_blinds=rd("t_blinds", (5, 3, 4)), q_blinds=rd("q_blinds", (2, 3, 4)))
     big = {"coefs": rd("coefs", (10, m, 4))[:, : n + 3], "coset_evals": rd("coset_evals", (10, m, 4)), "t_quotient": rd("t_quotient", (m, 4)),
-           "t": rd("t", (m, 4)), "z_evals": rd("z_evals", (n, 4)), "r": rd("r", (n + 3, 4))}
-    for key, arr in big.items():
-        dig = np.frombuffer(hashlib.sha256(np.ascontiguousarray(arr).tobytes()).digest(), dtype=np.uint8)
-        assert np.array_equal(dig, V2["sha256_" + key]), key
+           "t": rd("t", (m, 4)), "z_evals": rd("z_evals", (n, 4)), "r": rd("r", (n + 3, 4)), "chunks": rd("chunks", (5, cs, 4)),
+           "quotients": rd("quotients", (2, cs, 4)), "tables": rd("tables", (N_TABLES, m, 4))}
+    return V3, small, big, int(rd("tq_null_slots", (1,))[0])
+
+
+@pytest.mark.gpu
+def test_cpp_prover_rounds_match_frozen_outputs(gpu, tmp_path):
+    """The C++ driver (plain g++, the C ABI only) runs ChainInputs(4096, 7) and must reproduce tests/golden/vectors_v3.npz
+    (commitments over the reference's SRS files, evaluations, blinds, digests of the intermediates) -- the same fixture the
+    Python chain is held to."""
+    from test_gpu_golden import check_against_frozen
+    V3, small, big, nulls = _run_rounds_and_check(tmp_path, shuffle=True)
+    assert nulls == 0
+    check_against_frozen(V3, small, big)
+
+
+@pytest.mark.gpu
+def test_cpp_prover_rounds_without_shuffle_terms(gpu, tmp_path):
+    """The same driver for a circuit without the "shuffle" feature (zmatchmaking): 28 NULL slots in the quotient arguments, 15
+    evaluations, 19 polynomials in r, 12 in the opening at zeta; rounds 1-2 and the circuit tables are unchanged."""
+    import numpy as np
+    V3, small, big, nulls = _run_rounds_and_check(tmp_path, shuffle=False)
+    assert nulls == 28 and small["evals"].shape[0] == 15
+    assert np.array_equal(small["evals"][:15], V3["evals"][:15])             # the first 15 evaluations do not depend on the feature
+    from test_gpu_golden import affine_of, oc
+    for key in ("cm_w_wsel", "cm_z"):
+        assert np.array_equal(oc.points_from_affine([affine_of(j) for j in small[key]]), V3[key]), key

@@ -50,30 +50,31 @@ def test_ntt(gpu, n):
     assert np.array_equal(gpu.ntt(x, coset_shift=oc.fr_from_ints([7])[0]), V[f"ntt_{n}_coset7"])
 
 
-def test_prover_chain_against_frozen_outputs(gpu):
-    """The prover-round chain at n = 2^12 against tests/golden/vectors_v2.npz (made by make_vectors_v2.py from the oracle
-    chain): commitments over the reference's SRS files, evaluations, blinds, and digests of the large intermediates."""
+def check_against_frozen(V3, small, big):
+    """small: name -> array (commitments as Jacobian [k, 12]), big: name -> array; V3: the loaded fixture."""
     import hashlib
+    for key in ("cm_w_wsel", "cm_z", "cm_t", "cm_q"):
+        assert np.array_equal(oc.points_from_affine([affine_of(j) for j in small[key]]), V3[key]), key
+    for key in ("evals", "t_blinds", "q_blinds"):
+        assert np.array_equal(np.asarray(small[key]).reshape(V3[key].shape), V3[key]), key
+    for key in [f[len("sha256_"):] for f in V3.files if f.startswith("sha256_")]:
+        dig = np.frombuffer(hashlib.sha256(np.ascontiguousarray(big[key], dtype=np.uint64).tobytes()).digest(), dtype=np.uint8)
+        assert np.array_equal(dig, V3["sha256_" + key]), key
+
+
+def test_prover_chain_against_frozen_outputs(gpu):
+    """The prover-round chain at n = 2^12 against tests/golden/vectors_v3.npz (made by make_vectors_v3.py from the oracle
+    chain): commitments over the reference's SRS files, evaluations, blinds, and digests of the large intermediates."""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), "..", "tools"))
     from prover_chain import ChainInputs, ProverChain
-    V2 = np.load(os.path.join(GOLDEN, "vectors_v2.npz"))
-    n = int(V2["n"][0])
-    c = ProverChain(inputs=ChainInputs(n, int(V2["seed"][0])))
+    V3 = np.load(os.path.join(GOLDEN, "vectors_v3.npz"))
+    n = int(V3["n"][0])
+    c = ProverChain(inputs=ChainInputs(n, int(V3["seed"][0])), keep_blinds=True)
     try:
         o = c.run()
-        m = c.m
-        for key in ("cm_w_wsel", "cm_z", "cm_t", "cm_q"):
-            assert np.array_equal(oc.points_from_affine([affine_of(j) for j in o[key]]), V2[key]), key
-        for key in ("evals_zeta", "z_eval_zeta_omega", "open_evals_zeta", "open_evals_zeta_omega"):
-            assert np.array_equal(o[key], V2[key]), key
-        assert np.array_equal(np.concatenate([x.reshape(-1, 4) for x in o["t_blinds"]]), V2["t_blinds"])
-        assert np.array_equal(np.concatenate([x.reshape(-1, 4) for x in o["q_blinds"]]), V2["q_blinds"])
-        host = lambda t: t.cpu().numpy().view(np.uint64)
-        big = {"coefs": host(c.d_coefs).reshape(10, m, 4)[:, : n + 3], "coset_evals": host(c.d_coset).reshape(10, m, 4),
-               "t_quotient": host(c.d_tq), "t": host(c.d_t), "z_evals": host(c.d_z), "r": host(c.d_r)[: n + 3]}
-        for key, arr in big.items():
-            dig = np.frombuffer(hashlib.sha256(np.ascontiguousarray(arr, dtype=np.uint64).tobytes()).digest(), dtype=np.uint8)
-            assert np.array_equal(dig, V2["sha256_" + key]), key
+        snap = c.snapshot()
+        assert not snap["coefs_beyond"].any()
+        check_against_frozen(V3, o, snap)
     finally:
         c.release()

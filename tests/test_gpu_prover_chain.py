@@ -1,8 +1,10 @@
 """A checked prover-round chain: every device-resident step one 52-card proof issues (tools/prover_chain.py, the
 stand-in for BASELINE config #4 -- uzkge/src/plonk/prover.rs:88-394 cannot run here: no Rust toolchain), with each
 commitment, evaluation vector and intermediate polynomial compared against the same chain on the CPU oracle.
-Circuit tables and witness are synthetic (random elements of the real shapes: n = 2^14, 6n = 98304); the SRS files are
-the reference's (`lagrange-srs-16384.bin`, `srs-padding.bin`), so every commitment is an MSM over reference bases."""
+The call mix is the reference's (which polynomials are transformed / committed / evaluated / combined / opened, in which
+batches, at which lengths; split_t with chunk n + 2); circuit polynomials and witness are synthetic (random elements of the
+real shapes: n = 2^14, 6n = 98304); the SRS files are the reference's (`lagrange-srs-{8192,16384}.bin`, `srs-padding.bin`),
+so every commitment is an MSM over reference bases."""
 import os
 import sys
 
@@ -17,41 +19,30 @@ pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
 
 
-def _host(t):
-    return t.cpu().numpy().view(np.uint64)
-
-
 def _add_blinds(coefs, blinds, n):
     from chain_oracle import add_blinds
     return add_blinds(coefs, blinds, n)
 
 
 def _check_chain_against(c, o, want):
-    """c: ProverChain after run(), o: its outputs, want: chain_oracle.oracle_chain(inputs)."""
-    n, m = c.n, c.m
-    dev_coefs = _host(c.d_coefs).reshape(10, m, 4)
-    assert np.array_equal(dev_coefs[:, : n + 3], want["coefs"]) and not dev_coefs[:, n + 3:].any()     # hidden coefficient polynomials
+    """c: ProverChain(keep_blinds=True) after run(), o: its outputs, want: chain_oracle.oracle_chain(inputs)."""
+    snap = c.snapshot()
+    assert np.array_equal(snap["tables"], want["tables"])                    # setup: the circuit's coset tables (the indexer's batched coset FFT)
+    assert np.array_equal(snap["coefs"], want["coefs"]) and not snap["coefs_beyond"].any()       # hidden coefficient polynomials
     for key in ("cm_w_wsel", "cm_z", "cm_t", "cm_q"):
         got = oc.points_from_affine([affine_of(j) for j in o[key]])
         assert np.array_equal(got, want[key]), key
-    assert np.array_equal(_host(c.d_z), want["z_evals"])
-    assert np.array_equal(_host(c.d_coset).reshape(10, m, 4), want["coset_evals"])
-    assert np.array_equal(_host(c.d_tq), want["t_quotient"])
-    assert np.array_equal(_host(c.d_t), want["t"])
-    for i in range(5):
-        assert np.array_equal(o["t_blinds"][i], want["t_blinds"][i]), i
-    for i in range(2):
-        assert np.array_equal(o["q_blinds"][i], want["q_blinds"][i]), i
-    for key in ("evals_zeta", "z_eval_zeta_omega", "open_evals_zeta", "open_evals_zeta_omega"):
+    for key in ("z_evals", "coset_evals", "t_quotient", "t", "chunks", "r", "quotients"):
+        assert np.array_equal(snap[key], want[key]), key
+    for key in ("t_blinds", "q_blinds", "evals"):
         assert np.array_equal(o[key], want[key]), key
-    assert np.array_equal(_host(c.d_r)[: n + 3], want["r"])
 
 
 def test_prover_round_chain_matches_oracle_chain(gpu):
     from chain_oracle import oracle_chain
     from prover_chain import ChainInputs, ProverChain
     inp = ChainInputs(1 << 14, 11)
-    c = ProverChain(inputs=inp)
+    c = ProverChain(inputs=inp, keep_blinds=True)
     try:
         _check_chain_against(c, c.run(), oracle_chain(inp))
         # the general pipeline (no window table) commits to the same points
@@ -76,21 +67,20 @@ def test_quotient_without_shuffle_vectors(gpu, n):
     c = ProverChain(inputs=inp, shuffle=False, precompute=False)
     try:
         c.run()
-        m = c.m
+        snap = c.snapshot()
         assert sum(1 for p in c.tq_ptrs if not p) == 28
-        cos = _host(c.d_coset).reshape(10, m, 4).copy()
-        vecs = np.concatenate([cos, c.tables])
+        vecs = np.concatenate([snap["coset_evals"], snap["tables"]])
         for slot in list(range(5, 8)) + list(range(31, 56)):
             vecs[slot] = 0
         want = oc.t_quotient(n, 6, vecs, c.alpha, c.beta, c.gamma, c.k, c.anemoi_g, c.anemoi_g_inv, c.edwards_a, c.z_h_inv)
-        assert np.array_equal(_host(c.d_tq), want)
+        assert np.array_equal(snap["t_quotient"], want)
         # a partial set of shuffle vectors is an argument error, not a silent zero
         from uzkge_amd import UzkgeError
         bad = list(c.tq_ptrs)
-        bad[5] = c.d_coset.data_ptr()
+        bad[5] = c.d_coset.ptr
         with pytest.raises(UzkgeError):
             gpu.t_quotient_device(n, 6, bad, c.alpha, c.beta, c.gamma, c.k, c.anemoi_g, c.anemoi_g_inv, c.edwards_a, c.z_h_inv,
-                                  c.d_tq.data_ptr())
+                                  c.d_tq.ptr)
     finally:
         c.release()
 
@@ -101,7 +91,7 @@ def test_zmatchmaking_sized_chain_without_shuffle_terms(gpu):
     from chain_oracle import oracle_chain
     from prover_chain import ChainInputs, ProverChain
     inp = ChainInputs(8192, 23)
-    c = ProverChain(inputs=inp, shuffle=False)
+    c = ProverChain(inputs=inp, shuffle=False, keep_blinds=True)
     try:
         _check_chain_against(c, c.run(), oracle_chain(inp, shuffle=False))
     finally:
@@ -110,6 +100,7 @@ def test_zmatchmaking_sized_chain_without_shuffle_terms(gpu):
 
 def test_lincomb_and_hide_primitives(gpu):
     import torch
+    _host = lambda t: t.cpu().numpy().view(np.uint64)
     n = 1000
     from util import rand_fr_wire
     polys = [rand_fr_wire(ln, 40 + i) for i, ln in enumerate((n, n - 7, 3, n + 5))]
