@@ -1,16 +1,20 @@
 //! uzkge/src/gpu.rs -- the arkworks side of the MI355X backend (cargo feature `gpu`).
 //!
-//! Everything the two call sites need and nothing else:
+//! The two call sites of the hot path and the conversions the device-resident prover (`plonk/gpu_prover.rs`) shares:
 //!   * `commit`  replaces `normalize_batch` + `G1Projective::msm`   (poly_commit/kzg_poly_commitment.rs:287-290)
 //!   * `fft`     replaces `domain.fft(..)` / `domain.ifft(..)`      (poly_commit/field_polynomial.rs:585, 595)
 //!     and fuses the serial `mul_var` of the coset pair                 (field_polynomial.rs:589-591, 601-607)
+//!
+//! Both return `None` when the device cannot serve the call (no GPU, a HIP failure, out of device memory, a field that is
+//! not BN254's Fr): the caller then takes the arkworks path it always had.  Nothing here panics on a device error -- the
+//! reference builds with `panic = "abort"` (Cargo.toml:69), so a lost GPU must not take the prover down.
 //!
 //! Layout: arkworks' `Fp<MontBackend<_, 4>, 4>` wraps `BigInt<4>([u64; 4])` holding the Montgomery representation
 //! (R = 2^256) -- the wire format of include/uzkge_gpu.h -- but the structs are `repr(Rust)`, so limbs are copied
 //! field by field, never transmuted.
 use std::any::TypeId;
-use std::collections::{HashMap, HashSet};
-use std::sync::Mutex;
+use std::collections::HashMap;
+use std::sync::{Arc, Mutex};
 
 use ark_bn254::{Fq, Fr, G1Affine, G1Projective};
 use ark_ec::CurveGroup;
@@ -21,7 +25,7 @@ use uzkge_gpu_sys as sys;
 
 use crate::errors::UzkgeError;
 
-fn map_err(e: sys::Error) -> UzkgeError {
+pub(crate) fn map_err(e: sys::Error) -> UzkgeError {
     match e {
         sys::Error::Degree => UzkgeError::DegreeError,
         sys::Error::Fft => UzkgeError::FFTError,
@@ -31,80 +35,146 @@ fn map_err(e: sys::Error) -> UzkgeError {
 }
 
 #[inline]
-fn fr_limbs(s: &Fr) -> [u64; 4] {
+pub(crate) fn fr_limbs(s: &Fr) -> [u64; 4] {
     (s.0).0
 }
 #[inline]
-fn fr_from_limbs(l: [u64; 4]) -> Fr {
+pub(crate) fn fr_from_limbs(l: [u64; 4]) -> Fr {
     Fr::new_unchecked(BigInt(l))
 }
 #[inline]
 fn fq_limbs(s: &Fq) -> [u64; 4] {
     (s.0).0
 }
-fn affine_to_wire(p: &G1Affine) -> sys::uzk_g1_affine {
+pub(crate) fn affine_to_wire(p: &G1Affine) -> sys::uzk_g1_affine {
     if p.infinity {
         sys::uzk_g1_affine::default() // infinity = (0, 0), never on y^2 = x^3 + 3
     } else {
         sys::uzk_g1_affine { x: fq_limbs(&p.x), y: fq_limbs(&p.y) }
     }
 }
-fn jac_from_wire(j: &sys::uzk_g1_jac) -> G1Projective {
+pub(crate) fn jac_from_wire(j: &sys::uzk_g1_jac) -> G1Projective {
     // z == 0 is the identity in arkworks' Jacobian representation too
     G1Projective::new_unchecked(Fq::new_unchecked(BigInt(j.x)), Fq::new_unchecked(BigInt(j.y)), Fq::new_unchecked(BigInt(j.z)))
 }
 
-lazy_static! {
-    /// Device-resident SRS per parameter vector: keyed by address, length and a fingerprint of three points, so a
-    /// reallocated vector at the same address does not alias a released one.
-    static ref SRS: Mutex<HashMap<(usize, usize, [u64; 12]), sys::Srs>> = Mutex::new(HashMap::new());
-    /// Domain sizes whose generator has been compared with the library's.
-    static ref GENERATOR_CHECKED: Mutex<HashSet<u64>> = Mutex::new(HashSet::new());
-}
-
-fn fingerprint(wire: &[sys::uzk_g1_affine]) -> [u64; 12] {
-    let mut f = [0u64; 12];
-    for (slot, idx) in [0usize, wire.len() / 2, wire.len() - 1].iter().enumerate() {
-        f[4 * slot..4 * slot + 4].copy_from_slice(&wire[*idx].x);
+/// `&[F]` as `&[Fr]` when F is BN254's scalar field (an identity cast: same type), else None.
+pub(crate) fn as_fr_slice<F: PrimeField>(v: &[F]) -> Option<&[Fr]> {
+    if TypeId::of::<F>() != TypeId::of::<Fr>() {
+        return None;
     }
-    f
+    Some(unsafe { &*(v as *const [F] as *const [Fr]) })
+}
+/// `Vec<Fr>` as `Vec<F>` under the same condition.
+pub(crate) fn from_fr_vec<F: PrimeField>(v: Vec<Fr>) -> Vec<F> {
+    assert_eq!(TypeId::of::<F>(), TypeId::of::<Fr>());
+    let mut v = std::mem::ManuallyDrop::new(v);
+    unsafe { Vec::from_raw_parts(v.as_mut_ptr() as *mut F, v.len(), v.capacity()) }
 }
 
-/// Runs `f` on the device-resident copy of `public_parameter_group_1`, uploading it first if this is the first use:
-/// the bases are normalised and copied once per parameter vector, later commits only move scalars.  A static SRS also
-/// gets the window table (`uzk_srs_precompute`): same commitments, shorter calls.
-fn with_srs<T>(public_parameter_group_1: &[G1Projective], f: impl FnOnce(&sys::Srs) -> Result<T, sys::Error>) -> Result<T, UzkgeError> {
+/// The most device-resident SRS copies kept at once (least recently used goes first).  A process normally holds two or
+/// three: the monomial SRS, one Lagrange SRS per circuit size, the prover's combined commit bases.
+const SRS_CACHE_CAP: usize = 8;
+/// Below this many bases the window table (`uzk_srs_precompute`) shortens every commit (measured: 216 vs 248 us at 2^14);
+/// above it the general pipeline without a table is as fast or faster and the table would cost W * n * 64 bytes of HBM
+/// (21.43 vs 20.64 ms and 13 GiB at 2^24).
+const PRECOMPUTE_MAX_LEN: usize = 1 << 15;
+
+struct SrsEntry {
+    srs: Arc<sys::Srs>,
+    stamp: u64,
+}
+lazy_static! {
+    /// Device-resident SRS per parameter vector, keyed by length and a fingerprint of three points -- not by address: a
+    /// freshly loaded copy of the same parameters (`load_srs_params` allocates a new Vec every time) finds the resident one.
+    static ref SRS: Mutex<(HashMap<(usize, [u64; 12]), SrsEntry>, u64)> = Mutex::new((HashMap::new(), 0));
+    /// Domain sizes whose generator has been compared with the library's: true = equal.
+    static ref GENERATOR_CHECKED: Mutex<HashMap<u64, bool>> = Mutex::new(HashMap::new());
+}
+
+fn fingerprint_of(public_parameter_group_1: &[G1Projective]) -> [u64; 12] {
     let len = public_parameter_group_1.len();
     let probe = G1Projective::normalize_batch(&[public_parameter_group_1[0], public_parameter_group_1[len / 2], public_parameter_group_1[len - 1]]);
     let mut fp = [0u64; 12];
     for (slot, p) in probe.iter().enumerate() {
         fp[4 * slot..4 * slot + 4].copy_from_slice(&affine_to_wire(p).x);
     }
-    let key = (public_parameter_group_1.as_ptr() as usize, len, fp);
-    let mut cache = SRS.lock().unwrap();
-    if !cache.contains_key(&key) {
-        let wire: Vec<sys::uzk_g1_affine> = G1Projective::normalize_batch(public_parameter_group_1).iter().map(affine_to_wire).collect();
-        debug_assert_eq!(fingerprint(&wire), fp);
-        let srs = sys::Srs::register(&wire).map_err(map_err)?;
-        srs.precompute(0).map_err(map_err)?;
-        cache.insert(key, srs);
+    fp
+}
+
+/// The device-resident copy of `public_parameter_group_1`, uploaded on first use: the bases are normalised and copied once
+/// per parameter set, later commits only move scalars.  The registry lock is held for the lookup only -- never across a
+/// device call -- so commits from several prover threads (one context each) overlap on the GPU.
+pub(crate) fn resident_srs(public_parameter_group_1: &[G1Projective]) -> Result<Arc<sys::Srs>, sys::Error> {
+    let key = (public_parameter_group_1.len(), fingerprint_of(public_parameter_group_1));
+    {
+        let mut guard = SRS.lock().unwrap();
+        let (map, clock) = &mut *guard;
+        *clock += 1;
+        if let Some(e) = map.get_mut(&key) {
+            e.stamp = *clock;
+            return Ok(e.srs.clone());
+        }
     }
-    f(&cache[&key]).map_err(map_err)
+    // not resident: normalise and upload outside the lock (two threads may race here; the loser's copy is dropped)
+    let wire: Vec<sys::uzk_g1_affine> = G1Projective::normalize_batch(public_parameter_group_1).iter().map(affine_to_wire).collect();
+    let srs = sys::Srs::register(&wire)?;
+    if wire.len() <= PRECOMPUTE_MAX_LEN {
+        srs.precompute(0)?;
+    }
+    let srs = Arc::new(srs);
+    let mut guard = SRS.lock().unwrap();
+    let (map, clock) = &mut *guard;
+    *clock += 1;
+    if let Some(e) = map.get(&key) {
+        return Ok(e.srs.clone());
+    }
+    if map.len() >= SRS_CACHE_CAP {
+        // evict the least recently used entry; commits still running on it keep their Arc until they return
+        if let Some(oldest) = map.iter().min_by_key(|(_, e)| e.stamp).map(|(k, _)| *k) {
+            map.remove(&oldest);
+        }
+    }
+    map.insert(key, SrsEntry { srs: srs.clone(), stamp: *clock });
+    Ok(srs)
+}
+
+/// Drops the device copy of this parameter set (HBM is released when the last commit using it returns).
+pub fn release_srs(public_parameter_group_1: &[G1Projective]) {
+    if public_parameter_group_1.is_empty() {
+        return;
+    }
+    let key = (public_parameter_group_1.len(), fingerprint_of(public_parameter_group_1));
+    SRS.lock().unwrap().0.remove(&key);
+}
+
+/// Drops every device-resident SRS copy.
+pub fn release_all_srs() {
+    SRS.lock().unwrap().0.clear();
 }
 
 /// `commit` of kzg_poly_commitment.rs:278-293 for `coefs = polynomial.coefs[..=degree]` (the caller has done the
-/// DegreeError check).
-pub fn commit(public_parameter_group_1: &[G1Projective], coefs: &[Fr]) -> Result<G1Projective, UzkgeError> {
+/// DegreeError check).  `Ok(None)`: the device could not serve the call, take the arkworks path.
+pub fn commit(public_parameter_group_1: &[G1Projective], coefs: &[Fr]) -> Result<Option<G1Projective>, UzkgeError> {
+    let srs = match resident_srs(public_parameter_group_1) {
+        Ok(s) => s,
+        Err(sys::Error::Device) => return Ok(None),
+        Err(e) => return Err(map_err(e)),
+    };
     let scalars: Vec<[u64; 4]> = coefs.iter().map(fr_limbs).collect();
-    with_srs(public_parameter_group_1, |srs| srs.msm(0, &scalars)).map(|j| jac_from_wire(&j))
+    match srs.msm(0, &scalars) {
+        Ok(j) => Ok(Some(jac_from_wire(&j))),
+        Err(sys::Error::Device) => Ok(None),
+        Err(e) => Err(map_err(e)),
+    }
 }
 
 /// The prover's independent commits in one call (five wires + three selectors, prover.rs:160-192; the five chunks of
 /// t, helpers.rs:1390): every polynomial zero-padded to the longest.
-pub fn commit_batch(public_parameter_group_1: &[G1Projective], polys: &[&[Fr]]) -> Result<Vec<G1Projective>, UzkgeError> {
+pub fn commit_batch(public_parameter_group_1: &[G1Projective], polys: &[&[Fr]]) -> Result<Option<Vec<G1Projective>>, UzkgeError> {
     let n = polys.iter().map(|p| p.len()).max().unwrap_or(0);
     if n == 0 {
-        return Ok(vec![G1Projective::default(); polys.len()]);
+        return Ok(Some(vec![G1Projective::default(); polys.len()]));
     }
     let mut flat = vec![[0u64; 4]; n * polys.len()];
     for (b, p) in polys.iter().enumerate() {
@@ -112,50 +182,54 @@ pub fn commit_batch(public_parameter_group_1: &[G1Projective], polys: &[&[Fr]]) 
             *d = fr_limbs(c);
         }
     }
-    with_srs(public_parameter_group_1, |srs| srs.msm_batch(0, &flat, n)).map(|v| v.iter().map(jac_from_wire).collect())
+    let srs = match resident_srs(public_parameter_group_1) {
+        Ok(s) => s,
+        Err(sys::Error::Device) => return Ok(None),
+        Err(e) => return Err(map_err(e)),
+    };
+    match srs.msm_batch(0, &flat, n) {
+        Ok(v) => Ok(Some(v.iter().map(jac_from_wire).collect())),
+        Err(sys::Error::Device) => Ok(None),
+        Err(e) => Err(map_err(e)),
+    }
 }
 
-/// Once per domain size: arkworks' `group_gen` must be the generator the library transforms over (5^((r-1)/n)).
-/// A fork with another `LARGE_SUBGROUP_ROOT_OF_UNITY` would otherwise order the 3 * 2^k coset evaluations
-/// differently from the CPU-built `q_coset_evals` / `z_h_inv` tables and yield invalid proofs silently.
-fn assert_same_generator(n: u64, group_gen: &Fr) {
+/// Once per domain size: is arkworks' `group_gen` the generator the library transforms over (5^((r-1)/n))?  A fork with
+/// another `LARGE_SUBGROUP_ROOT_OF_UNITY` would order the 3 * 2^k coset evaluations differently from the CPU-built
+/// `q_coset_evals` / `z_h_inv` tables; such a domain size simply stays on the arkworks path (`false`), no wrong proofs and
+/// no panic.
+pub(crate) fn same_generator(n: u64, group_gen: &Fr) -> bool {
     let mut seen = GENERATOR_CHECKED.lock().unwrap();
-    if seen.contains(&n) {
-        return;
+    if let Some(ok) = seen.get(&n) {
+        return *ok;
     }
-    let ours = sys::domain_group_gen(n).expect("uzk_domain_group_gen");
-    assert_eq!(
-        fr_limbs(group_gen),
-        ours,
-        "uzkge-gpu: the size-{} evaluation domain of this arkworks fork uses another generator than libuzkge_gpu.so",
-        n
-    );
-    seen.insert(n);
+    let ok = match sys::domain_group_gen(n) {
+        Ok(ours) => ours == fr_limbs(group_gen),
+        Err(_) => false,
+    };
+    seen.insert(n, ok);
+    ok
 }
 
-/// `domain.fft(coefs)` / `domain.ifft(values)` on the GPU, `None` when F is not BN254's scalar field (the caller then
-/// takes the arkworks path).  `coset_shift`: forward = p(kX) (pass k), inverse = post-scale by k^-j (pass k^-1) --
-/// the serial `mul_var` of field_polynomial.rs:470-477 runs inside the transform.
+/// `domain.fft(coefs)` / `domain.ifft(values)` on the GPU; `None` when F is not BN254's scalar field, when this arkworks
+/// fork's generator of the domain is not the library's, or when the device cannot serve the call -- the caller then takes
+/// the arkworks path.  `coset_shift`: forward = p(kX) (pass k), inverse = post-scale by k^-j (pass k^-1) -- the serial
+/// `mul_var` of field_polynomial.rs:470-477 runs inside the transform.
 pub fn fft<F: PrimeField, E: EvaluationDomain<F>>(domain: &E, input: &[F], inverse: bool, coset_shift: Option<&F>) -> Option<Vec<F>> {
-    if TypeId::of::<F>() != TypeId::of::<Fr>() {
-        return None;
-    }
+    let input: &[Fr] = as_fr_slice(input)?;
     // F is Fr: same type, so these are identity casts, not reinterpretations
-    let input: &[Fr] = unsafe { &*(input as *const [F] as *const [Fr]) };
     let group_gen: Fr = unsafe { *(&domain.group_gen() as *const F as *const Fr) };
     let shift: Option<[u64; 4]> = coset_shift.map(|k| fr_limbs(unsafe { &*(k as *const F as *const Fr) }));
     let n = domain.size();
-    assert!(input.len() <= n);
-    assert_same_generator(n as u64, &group_gen);
+    if input.len() > n || !same_generator(n as u64, &group_gen) {
+        return None;
+    }
     let mut buf = vec![[0u64; 4]; n]; // the caller owns the Vec: short inputs are zero-padded here
     for (d, c) in buf.iter_mut().zip(input.iter()) {
         *d = fr_limbs(c);
     }
-    if let Err(e) = sys::ntt(&mut buf, inverse, shift.as_ref()) {
-        panic!("uzk_ntt_fr: {:?}: {}", e, sys::last_error());
+    if sys::ntt(&mut buf, inverse, shift.as_ref()).is_err() {
+        return None; // UZK_ERR_DEVICE (or an unsupported size): arkworks computes the same vector
     }
-    let out: Vec<Fr> = buf.into_iter().map(fr_from_limbs).collect();
-    // identity cast back to Vec<F>
-    let mut out = std::mem::ManuallyDrop::new(out);
-    Some(unsafe { Vec::from_raw_parts(out.as_mut_ptr() as *mut F, out.len(), out.capacity()) })
+    Some(from_fr_vec(buf.into_iter().map(fr_from_limbs).collect()))
 }

@@ -78,7 +78,8 @@ def oracle_chain(c, shuffle=True):
     tpolys = [ints(c.table_polys[i]) for i in range(c.table_polys.shape[0])]
     # ---- round 1
     evals9 = [c.w_evals[i] for i in range(5)] + [c.wsel_evals[i] for i in range(3)] + [c.pi_evals]
-    blinds9 = [ints(c.blinds_w[i]) for i in range(5)] + [ints(c.blinds_wsel[i]) for i in range(3)] + [[]]
+    from prover_chain import HIDE_W, HIDE_WSEL
+    blinds9 = [ints(c.blinds_w[i])[: HIDE_W[i]] for i in range(5)] + [ints(c.blinds_wsel[i])[:HIDE_WSEL] for i in range(3)] + [[]]
     polys = [add_blinds(ints(oc.ntt(evals9[i], inverse=True)), blinds9[i], n) for i in range(9)]
     out["cm_w_wsel"] = aff_wire([commit_with_blinds(c.lagrange_wire, mono_pts, evals9[i], blinds9[i], n) for i in range(8)])
     # ---- round 2

@@ -7,7 +7,7 @@
 //   setup     46 per-circuit polynomials -> coset evaluations over the 6n domain (the indexer's loop)        indexer.rs:316-470
 //   round 1   iFFT(n) x9 (5 wires, 3 wire selectors, pi) into 6n-slots, hide, 8 commits with blinds       prover.rs:151-192
 //   round 2   z_poly, iFFT(n), hide, commit                                                               prover.rs:199-209
-//   round 3   coset FFT(6n) x10, quotient kernel, coset iFFT(6n); split_t_and_commit (chunk n + 2):
+//   round 3   coset FFT(6n) x10, quotient kernel, coset iFFT(6n); split_t_and_commit (t of 5n + 11 coefficients, chunk n + 2):
 //             split, fold, FFT(n), 5 commits with blinds                                    helpers.rs:223-678, 1323-1408
 //   round 4   15 evaluations at zeta, 4 at zeta * omega: one launch                                       prover.rs:246-273
 //   round 5   r(X) = sum of 43 scalar_k p_k; batch_prove of 16 polynomials at zeta and of 4 at zeta * omega:
@@ -85,7 +85,8 @@ static void worker(uint64_t srs, int reps, bool write_outputs, bool own_context,
 
     // ---- inputs
     const auto meta = rd<uint64_t>("meta");                       // n, shuffle, precompute
-    const size_t n = meta[0], m = 6 * n, cs = n + 8, t_len = 5 * n + 8;
+    const size_t n = meta[0], m = 6 * n, cs = n + 8;
+    const uint64_t t_len = 5 * n + 11;     // deg t = 5n + 10 (ChainInputs.t_len)
     const bool shuffle = meta[1] != 0;
     const auto evals9 = rd<Fr>("evals9");                         // w0..w4, wsel0..2, pi  (9 n)
     const auto perm = rd<uint32_t>("perm");
@@ -95,7 +96,9 @@ static void worker(uint64_t srs, int reps, bool write_outputs, bool own_context,
     const Fr beta = sc[0], gamma = sc[1], alpha = sc[2], zeta = sc[3], alpha_open = sc[4], alpha_open2 = sc[5], anemoi_g = sc[6],
              anemoi_g_inv = sc[7], edwards_a = sc[8], k1_inv = sc[9], zeta_omega = sc[10];
     const auto z_h_inv = rd<Fr>("z_h_inv");                       // 6
-    const auto blinds8 = rd<Fr>("blinds8"), blinds_z = rd<Fr>("blinds_z");           // 8 x 2 (w0..4, wsel0..2), 3
+    // 8 x 3 (w0..4, wsel0..2; the hiding degrees are 3,3,3,2,2 and 2,2,2 -- constraint_system/turbo/mod.rs:366-373, prover.rs:186 --
+    // an unused third slot holds a zero blind, which changes nothing), 3 for z
+    const auto blinds8 = rd<Fr>("blinds8"), blinds_z = rd<Fr>("blinds_z");
     const auto t_rands = rd<Fr>("t_rands"), r_scalars = rd<Fr>("r_scalars");         // 5, 43
 
     // ---- device residency (the SRS is registered once, by main)
@@ -127,7 +130,7 @@ static void worker(uint64_t srs, int reps, bool write_outputs, bool own_context,
             for (uint32_t j = 0; j < hd; ++j) { t[i * 6 + j] = blinds[i * hd + j]; t[i * 6 + 3 + j] = fr_neg(blinds[i * hd + j]); }
         return t;
     };
-    const auto tail8 = tails(blinds8.data(), 8, 2), tail_z = tails(blinds_z.data(), 1, 3);
+    const auto tail8 = tails(blinds8.data(), 8, 3), tail_z = tails(blinds_z.data(), 1, 3);
 
     // the polynomials of rounds 4 and 5 by address and length (they never move)
     auto coef = [&](int slot) { return std::make_pair((const void*)(d_coefs + slot * m), (uint64_t)(n + 3)); };
@@ -174,7 +177,7 @@ static void worker(uint64_t srs, int reps, bool write_outputs, bool own_context,
         if (upload_witness) CK(uzk_dev_copy(d_evals, h_evals, 9 * n * sizeof(Fr), UZK_COPY_H2D));      // pinned: asynchronous
         // ---- round 1: iFFT straight into the 6n-slots, hide, commit
         CK(uzk_ntt_fr_batch_strided_device(d_evals, n, d_coefs, m, n, 9, 1, nullptr, 0));
-        CK(uzk_hide_polynomial_batch_device(d_coefs, m, n, 8, blinds8[0].l, 2, n));
+        CK(uzk_hide_polynomial_batch_device(d_coefs, m, n, 8, blinds8[0].l, 3, n));
         CK(uzk_msm_g1_batch_tail_device(srs, 0, d_evals, n, n, 8, tail8.data(), 6, 0, cm_w_wsel));
         // ---- round 2
         CK(uzk_z_poly_device(d_evals, d_perm, d_group, k[0].l, beta.l, gamma.l, (uint32_t)n, 5, d_z));
@@ -200,7 +203,10 @@ static void worker(uint64_t srs, int reps, bool write_outputs, bool own_context,
         CK(uzk_ntt_fr_device(d_tq, d_t, m, 1, k1_inv.l, 0));
         // split_t_and_commit (helpers.rs:1323-1408) with the reference's argument n + 2: every chunk's degree (= coefs.len())
         // has max_power_of_2 = n, so all five fold onto n coefficients
-        CK(uzk_split_t_device(d_t, t_len, n + 2, 5, t_rands[0].l, d_chunks, cs, chunk_lens));
+        // from_coefs trims t (field_polynomial.rs:86-90) and its coefs.len() drives the split: ask the device for the trimmed length
+        uint64_t t_trim = 0;
+        CK(uzk_poly_trimmed_len_device(d_t, m, &t_len, 1, &t_trim));
+        CK(uzk_split_t_device(d_t, t_trim, n + 2, 5, t_rands[0].l, d_chunks, cs, chunk_lens));
         CK(uzk_fold_blinds_batch_device(d_chunks, cs, chunk_lens, n, 5, d_fold, n, d_tail, 6, want_blinds ? t_blinds[0].l : nullptr));
         CK(uzk_ntt_fr_batch_device(d_fold, d_fold, n, 5, 0, nullptr, 0));
         CK(uzk_msm_g1_batch_tail_device(srs, 0, d_fold, n, n, 5, d_tail, 6, 1, cm_t));
@@ -211,7 +217,10 @@ static void worker(uint64_t srs, int reps, bool write_outputs, bool own_context,
         CK(uzk_poly_lincomb_device(r_p.data(), r_l.data(), r_scalars[0].l, (uint32_t)r_p.size(), d_r, n + 3));
         CK(uzk_open_quotient_ptrs_device(oz_p.data(), oz_l.data(), (uint32_t)oz_p.size(), zeta.l, alpha_open.l, d_q, cs, nullptr));
         CK(uzk_open_quotient_ptrs_device(ozo_p.data(), ozo_l.data(), (uint32_t)ozo_p.size(), zeta_omega.l, alpha_open2.l, d_q + cs, cs, nullptr));
-        const uint64_t q_lens[2] = {n + 2, n + 2};          // degree n + 1: max_power_of_2 = n, two blinds (pcs.rs:137-156)
+        // degree = q.degree() (pcs.rs:138) = trimmed length - 1 = n + 1: max_power_of_2 = n, two blinds (pcs.rs:137-156)
+        const uint64_t q_caps[2] = {n + 3, n + 3};
+        uint64_t q_lens[2];
+        CK(uzk_poly_trimmed_len_device(d_q, cs, q_caps, 2, q_lens));
         CK(uzk_fold_blinds_batch_device(d_q, cs, q_lens, n, 2, d_fold, n, d_tail, 6, want_blinds ? q_blinds[0].l : nullptr));
         CK(uzk_ntt_fr_batch_device(d_fold, d_fold, n, 2, 0, nullptr, 0));
         CK(uzk_msm_g1_batch_tail_device(srs, 0, d_fold, n, n, 2, d_tail, 6, 1, cm_q));

@@ -273,3 +273,19 @@ def test_open_quotient_pointer_list(gpu, want_evals):
         for d in devs:
             d.free()
         d_q.free()
+
+
+def test_trimmed_length_is_from_coefs_length(gpu):
+    stride = 5000
+    polys = np.zeros((4, stride, 4), dtype=np.uint64)
+    polys[0, :4099] = rand_fr_wire(4099, 1)                   # full
+    polys[1, :4000] = rand_fr_wire(4000, 2); polys[1, 3990:4000] = 0         # trailing zeros inside the given length
+    polys[3, 0] = rand_fr_wire(1, 3)[0]                       # a constant; polys[2] is the zero polynomial
+    polys[0, 4500] = rand_fr_wire(1, 4)[0]                    # junk beyond the given length is not looked at
+    d = Dev(gpu, 4 * stride, polys)
+    try:
+        got = gpu.poly_trimmed_len_device(d.ptr, stride, [4099, 4000, 4099, 4099])
+        assert [int(v) for v in got] == [4099, 3990, 0, 1]
+        assert int(gpu.poly_trimmed_len_device(d.ptr, stride, [4600])[0]) == 4501
+    finally:
+        d.free()

@@ -46,38 +46,156 @@ def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(QuotientArgs) == 8 + 56 * 8 + (3 + 5 + 3 + 16) * 32       # the same block in the ctypes mirror
 
 
+def _calls(src, name_re):
+    """[(name, n_args)] for every call `name(...)` in src whose name matches name_re; arguments counted at nesting depth 0."""
+    out = []
+    for m in re.finditer(r"\b(" + name_re + r")\s*\(", src):
+        i, depth, args, cur = m.end(), 1, 0, ""
+        while i < len(src) and depth:
+            ch = src[i]
+            if ch in "([{":
+                depth += 1
+            elif ch in ")]}":
+                depth -= 1
+            elif ch == "," and depth == 1:
+                args += 1 if cur.strip() else 0
+                cur = ""
+                i += 1
+                continue
+            if depth:
+                cur += ch
+            i += 1
+        out.append((m.group(1), args + (1 if cur.strip() else 0)))
+    return out
+
+
+def _strip_rust_comments(src):
+    return re.sub(r"//.*", "", src)
+
+
 def test_glue_and_wrappers_only_call_bound_functions():
-    ffi_fns = set(re.findall(r"pub fn (uzk_[a-z0-9_]+)\(", _ffi()))
-    lib = open(os.path.join(RUST, "uzkge-gpu-sys", "src", "lib.rs")).read()
-    used = set(re.findall(r"\b(uzk_[a-z0-9_]+)\(", lib))
-    assert used and used <= ffi_fns, used - ffi_fns
+    ffi = _ffi()
+    decl = {m.group(1): (0 if not m.group(2).strip() else m.group(2).count(",") + 1) for m in re.finditer(r"pub fn (uzk_[a-z0-9_]+)\((.*?)\)", ffi)}
+    consts = set(re.findall(r"pub const (UZK_[A-Z0-9_]+)", ffi))
+    lib = _strip_rust_comments(open(os.path.join(RUST, "uzkge-gpu-sys", "src", "lib.rs")).read())
+    used = _calls(lib, r"uzk_[a-z0-9_]+")
+    assert len(used) >= 25
+    for name, n_args in used:                                   # every FFI call of the wrappers: bound, and with that arity
+        assert name in decl, name
+        assert decl[name] == n_args, (name, decl[name], n_args)
+    for c in re.findall(r"\b(UZK_[A-Z0-9_]+)\b", lib):
+        assert c in consts, c
+    wrappers = {}
+    for m in re.finditer(r"pub fn ([a-z_0-9]+)\(", lib):          # parameter lists hold tuple types: count at depth 0
+        name, n_params = _calls(lib[m.start():], r"fn " + m.group(1))[0]
+        has_self = re.match(r"\s*&?(mut )?self\b", lib[m.end():]) is not None
+        wrappers[m.group(1)] = n_params - (1 if has_self else 0)
+    types = set(re.findall(r"pub (?:struct|enum|type) ([A-Za-z]+)", lib)) | set(re.findall(r"pub struct ([a-z_0-9]+)", ffi))
+    for fname in ("gpu.rs", "gpu_prover.rs"):
+        glue = _strip_rust_comments(open(os.path.join(RUST, "uzkge-glue", fname)).read())
+        for name, n_args in _calls(glue, r"sys::[a-z_0-9]+"):   # free functions of the -sys crate: exist, same arity
+            short = name.split("::")[1]
+            if short.startswith("uzk_"):
+                assert decl.get(short) == n_args, (fname, name, n_args)
+            else:
+                assert wrappers.get(short) == n_args, (fname, name, n_args, wrappers.get(short))
+        for t, meth in re.findall(r"sys::([A-Z][A-Za-z]+)::([a-z_0-9]+)", glue):
+            assert t in types and (re.search(rf"pub fn {meth}\(", lib) or meth[0].isupper() or t == "Error"), (fname, t, meth)
+        for c in re.findall(r"sys::(UZK_[A-Z0-9_]+)", glue):
+            assert c in consts, (fname, c)
+        for meth in re.findall(r"\b(?:srs|bases)\.([a-z_]+)\(", glue):
+            assert meth == "clone" or re.search(rf"pub fn {meth}\(", lib), (fname, meth)
+    # the generator check: group_gen is compared with the library's, once per domain size, and a mismatch falls back
     glue = open(os.path.join(RUST, "uzkge-glue", "gpu.rs")).read()
-    wrappers = set(re.findall(r"pub fn ([a-z_]+)", lib))
-    for call in re.findall(r"\bsys::([a-z_]+)\(", glue):
-        assert call in wrappers, call
-    for meth in re.findall(r"\bsrs\.([a-z_]+)\(", glue):
-        assert re.search(rf"pub fn {meth}\(", lib), meth
-    # the generator check: group_gen is compared with the library's, once per domain size
-    assert "assert_same_generator" in glue and "domain_group_gen" in glue
+    assert "same_generator" in glue and "domain_group_gen" in glue
+    # ADVICE r2 / VERDICT r2: no panic on a device error, no registry lock across a device call, eviction, size-aware table
+    assert "panic!" not in _strip_rust_comments(glue) and "Arc<sys::Srs>" in glue and "SRS_CACHE_CAP" in glue and "PRECOMPUTE_MAX_LEN" in glue
+    assert "release_srs" in glue
+
+
+def _entry_sequence_cpp():
+    src = open(os.path.join(ROOT, "tests", "cpp", "prover_rounds.cpp")).read()
+    body = src[src.index("auto chain = [&]() {"):src.index("want_blinds = write_outputs;")]
+    return [n for n, _ in _calls(re.sub(r"//.*", "", body), r"uzk_[a-z0-9_]+")]
+
+
+def _entry_sequence_rust():
+    lib = open(os.path.join(RUST, "uzkge-gpu-sys", "src", "lib.rs")).read()
+    wrapper_to_entry = {}
+    for m in re.finditer(r"pub fn ([a-z_0-9]+)\(", lib):
+        i = lib.index("{", m.end())
+        depth, j = 1, i + 1
+        while depth:                                             # the function's body, by brace matching
+            depth += {"{": 1, "}": -1}.get(lib[j], 0)
+            j += 1
+        names = re.findall(r"\b(uzk_[a-z0-9_]+)\(", lib[i:j])
+        if names:
+            wrapper_to_entry[m.group(1)] = names[0]
+    src = _strip_rust_comments(open(os.path.join(RUST, "uzkge-glue", "gpu_prover.rs")).read())
+    body = src[src.index("fn prove_on_device"):]
+    seq = []
+    for m in re.finditer(r"\bsys::([a-z_0-9]+)\(|\.(commit_with_tail|commit_with_device_tail|upload)\(", body):
+        w = m.group(1) or m.group(2)
+        if w in ("check",):
+            continue
+        seq.append(wrapper_to_entry.get(w, w))
+    return seq
+
+
+def test_rust_prover_issues_the_cpp_drivers_calls_in_order():
+    """rust/uzkge-glue/gpu_prover.rs mirrors tests/cpp/prover_rounds.cpp (the driver the GPU tests hold to frozen outputs)
+    call for call: the same entry points in the same order.  Uploads (the Rust side moves the witness and pi per proof) and
+    the entry-point family of a transform (plain / batched / strided) are not part of the comparison; the Rust side's
+    generic branch for odd polynomial lengths sits in its own function and is not part of the main sequence."""
+    norm = lambda n: "ntt" if n.startswith("uzk_ntt_fr") else n
+    skip = {"uzk_dev_copy", "upload"}
+    cpp = [norm(n) for n in _entry_sequence_cpp() if n not in skip]
+    rust = [norm(n) for n in _entry_sequence_rust() if n not in skip]
+    # the Rust main path holds, after each batched fold/commit, the fallback call to commit_folded_generic (no sys:: call inside
+    # prove_on_device), so the sequences must match exactly
+    assert rust == cpp, "\n".join(f"{a:45s} {b}" for a, b in zip(rust + [""] * 50, cpp + [""] * 50) if a or b)
+    assert len(cpp) >= 23
 
 
 def test_patch_targets_the_cited_call_sites():
     patch = open(os.path.join(RUST, "uzkge-gpu.patch")).read()
-    for f in ("uzkge/Cargo.toml", "uzkge/src/lib.rs", "uzkge/src/poly_commit/kzg_poly_commitment.rs",
-              "uzkge/src/poly_commit/field_polynomial.rs"):
-        assert f"+++ b/{f}" in patch
+    for f in PATCHED:
+        assert f"+++ b/{f}" in patch, f
     assert patch.count("crate::gpu::fft(") == 4 and "crate::gpu::commit(" in patch and 'gpu = ["uzkge-gpu-sys"]' in patch
+    assert "super::gpu_prover::prove(" in patch and "fn as_kzg_bn254" in patch and "fn commitment_from_g1" in patch
+    assert "pub(super) fn r_poly_or_comm" in patch and "mod gpu_prover;" in patch
+    added = "\n".join(l for l in patch.splitlines() if l.startswith("+") and not l.startswith("+++"))
+    assert "panic!" not in added and ".unwrap()" not in added
+
+
+PATCHED = ("Cargo.toml", "uzkge/Cargo.toml", "uzkge/src/lib.rs", "uzkge/src/plonk/mod.rs", "uzkge/src/plonk/helpers.rs", "uzkge/src/plonk/prover.rs",
+           "uzkge/src/poly_commit/pcs.rs", "uzkge/src/poly_commit/kzg_poly_commitment.rs", "uzkge/src/poly_commit/field_polynomial.rs")
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/uzkge"), reason="reference tree not present (GPU box)")
 def test_patch_applies_to_the_reference(tmp_path):
     if not shutil.which("patch"):
         pytest.skip("no patch(1)")
-    for f in ("Cargo.toml", "uzkge/Cargo.toml", "uzkge/src/lib.rs", "uzkge/src/poly_commit/kzg_poly_commitment.rs",
-              "uzkge/src/poly_commit/field_polynomial.rs"):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_rust_patch.py"), "--check"])
+    assert r.returncode == 0, "rust/uzkge-gpu.patch is stale: run tools/make_rust_patch.py"
+    for f in PATCHED:
         dst = tmp_path / f
         dst.parent.mkdir(parents=True, exist_ok=True)
         shutil.copy(os.path.join("/root/reference", f), dst)
-    r = subprocess.run(["patch", "-p1", "--dry-run", "-i", os.path.join(RUST, "uzkge-gpu.patch")], cwd=tmp_path,
-                       capture_output=True, text=True)
+    r = subprocess.run(["patch", "-p1", "-i", os.path.join(RUST, "uzkge-gpu.patch")], cwd=tmp_path, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+    # the glue names items of the reference: they exist where it looks for them, with the visibility it needs
+    helpers = open(tmp_path / "uzkge/src/plonk/helpers.rs").read()
+    for item in ("pub(super) fn r_poly_or_comm", "pub(super) fn pi_poly", "pub(super) fn first_lagrange_poly", "pub(super) struct PlonkChallenges"):
+        assert item in helpers, item
+    prover = open(tmp_path / "uzkge/src/plonk/prover.rs").read()
+    hook = prover.index("super::gpu_prover::prove(")
+    assert prover.index("transcript_init_plonk(") < hook < prover.index("// 1. Build the PI polynomial")
+    glue = open(os.path.join(RUST, "uzkge-glue", "gpu_prover.rs")).read()
+    indexer = open("/root/reference/uzkge/src/plonk/indexer.rs").read()
+    for field in set(re.findall(r"\bp\.([a-z_0-9]+)", glue)) | set(re.findall(r"prover_params\.([a-z_0-9]+)", glue)):
+        assert re.search(rf"pub {field}:", indexer), f"PlonkProverParams has no field {field}"
+    proof_fields = re.findall(r"^        ([a-z_0-9]+),$", glue[glue.index("Ok(PlonkProof {"):], flags=re.M)
+    for field in proof_fields:
+        assert re.search(rf"pub {field}:", indexer), f"PlonkProof has no field {field}"
+    assert len(proof_fields) == 14

@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""Regenerates rust/uzkge-gpu.patch: applies the `gpu`-feature edits to copies of the reference's files (read from
+/root/reference, which exists only in the build container) and writes the unified diff.  The edits are small anchors
+(cfg-gated hooks); everything of substance lives in rust/uzkge-glue/{gpu.rs, gpu_prover.rs} and rust/uzkge-gpu-sys.
+usage: python tools/make_rust_patch.py [--check]"""
+import difflib
+import os
+import sys
+
+REF = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "rust", "uzkge-gpu.patch")
+
+
+def sub(text, old, new, path):
+    assert text.count(old) == 1, f"{path}: anchor not found exactly once: {old[:60]!r}"
+    return text.replace(old, new)
+
+
+EDITS = {
+    "Cargo.toml": [('  "matchmaking",\n', '  "matchmaking",\n  "uzkge-gpu-sys",\n')],
+    "uzkge/Cargo.toml": [
+        ('tera = { workspace = true, optional = true }\n',
+         'tera = { workspace = true, optional = true }\nuzkge-gpu-sys = { path = "../uzkge-gpu-sys", optional = true }\n'),
+        ('debug = []\n',
+         'debug = []\n# MI355X backend: commit / fft / ifft (src/gpu.rs) and the device-resident prover (src/plonk/gpu_prover.rs);\n'
+         '# needs libuzkge_gpu.so, see uzkge-gpu-sys/build.rs\ngpu = ["uzkge-gpu-sys"]\n'),
+    ],
+    "uzkge/src/lib.rs": [
+        ('/// Module for anemoi hash.\n',
+         '/// MI355X backend glue (arkworks <-> libuzkge_gpu.so).\n#[cfg(feature = "gpu")]\npub mod gpu;\n\n/// Module for anemoi hash.\n'),
+    ],
+    "uzkge/src/plonk/mod.rs": [
+        ('/// Module for help functions.\npub(crate) mod helpers;\n',
+         '/// Module for help functions.\npub(crate) mod helpers;\n\n'
+         '/// `prover_with_lagrange` with the proof\'s polynomials resident on the MI355X.\n#[cfg(feature = "gpu")]\nmod gpu_prover;\n'
+         '#[cfg(feature = "gpu")]\npub use gpu_prover::release_circuits;\n'),
+    ],
+    "uzkge/src/plonk/helpers.rs": [
+        ('fn r_poly_or_comm<F: PrimeField, PCSType: HomomorphicPolyComElem<Scalar = F>>(',
+         'pub(super) fn r_poly_or_comm<F: PrimeField, PCSType: HomomorphicPolyComElem<Scalar = F>>('),
+    ],
+    "uzkge/src/plonk/prover.rs": [
+        ('            None\n        };\n\n    let commit = |evals: Vec<PCS::Field>,',
+         '            None\n        };\n\n'
+         '    // MI355X: BN254 KZG with a Lagrange SRS of the circuit\'s size proves with every polynomial resident on the device\n'
+         '    // (same transcript, same prng draws, same proof bytes); `None` = not applicable or no device: continue below.\n'
+         '    #[cfg(feature = "gpu")]\n'
+         '    if let Some(proof) = super::gpu_prover::prove(\n'
+         '        prng,\n        transcript,\n        pcs,\n        lagrange_pcs,\n        cs,\n        prover_params,\n        w,\n        &domain,\n        &online_values,\n'
+         '    )? {\n        return Ok(proof);\n    }\n\n'
+         '    let commit = |evals: Vec<PCS::Field>,'),
+    ],
+    "uzkge/src/poly_commit/pcs.rs": [
+        ('    /// Batch proof for polynomial evaluation.\n    /// `param` stores the instance parameters to be appended to the transcript.\n',
+         '    /// MI355X backend: the BN254 KZG scheme behind this PCS, if that is what it is (the device-resident prover asks).\n'
+         '    #[cfg(feature = "gpu")]\n'
+         '    fn as_kzg_bn254(&self) -> Option<&crate::poly_commit::kzg_poly_commitment::KZGCommitmentSchemeBN254> {\n        None\n    }\n\n'
+         '    /// MI355X backend: a G1 point computed on the device as this scheme\'s commitment type.\n'
+         '    #[cfg(feature = "gpu")]\n'
+         '    fn commitment_from_g1(_point: ark_bn254::G1Projective) -> Option<Self::Commitment> {\n        None\n    }\n\n'
+         '    /// Batch proof for polynomial evaluation.\n    /// `param` stores the instance parameters to be appended to the transcript.\n'),
+    ],
+    "uzkge/src/poly_commit/kzg_poly_commitment.rs": [
+        ('        let points_raw =\n            G1Projective::normalize_batch(&self.public_parameter_group_1[0..degree + 1]);\n',
+         '        // MI355X: resident SRS + device MSM (trailing zero coefficients are already trimmed: degree + 1 scalars);\n'
+         '        // `None` = no usable device, continue on the arkworks path\n'
+         '        #[cfg(feature = "gpu")]\n'
+         '        if let Some(cm) = crate::gpu::commit(&self.public_parameter_group_1, &coefs[0..degree + 1])? {\n'
+         '            return Ok(KZGCommitment(cm));\n        }\n\n'
+         '        let points_raw =\n            G1Projective::normalize_batch(&self.public_parameter_group_1[0..degree + 1]);\n'),
+        ('    fn eval(&self, poly: &FpPolynomial<Self::Field>, point: &Self::Field) -> Self::Field {\n        poly.eval(point)\n    }\n',
+         '    #[cfg(feature = "gpu")]\n    fn as_kzg_bn254(&self) -> Option<&KZGCommitmentSchemeBN254> {\n        Some(self)\n    }\n\n'
+         '    #[cfg(feature = "gpu")]\n    fn commitment_from_g1(point: G1Projective) -> Option<Self::Commitment> {\n        Some(KZGCommitment(point))\n    }\n\n'
+         '    fn eval(&self, poly: &FpPolynomial<Self::Field>, point: &Self::Field) -> Self::Field {\n        poly.eval(point)\n    }\n'),
+    ],
+    "uzkge/src/poly_commit/field_polynomial.rs": [
+        ('        assert!(domain.size() > self.degree());\n        domain.fft(&self.coefs)\n',
+         '        assert!(domain.size() > self.degree());\n        #[cfg(feature = "gpu")]\n'
+         '        if let Some(evals) = crate::gpu::fft(domain, &self.coefs, false, None) {\n            return evals;\n        }\n'
+         '        domain.fft(&self.coefs)\n'),
+        ('        self.mul_var(k).fft_with_domain(domain)\n',
+         '        #[cfg(feature = "gpu")]\n        {\n            assert!(domain.size() > self.degree());\n'
+         '            // the k^j scaling of mul_var runs inside the device transform\n'
+         '            if let Some(evals) = crate::gpu::fft(domain, &self.coefs, false, Some(k)) {\n                return evals;\n            }\n        }\n'
+         '        self.mul_var(k).fft_with_domain(domain)\n'),
+        ('        let coefs = domain.ifft(&values);\n',
+         '        #[cfg(feature = "gpu")]\n        if let Some(coefs) = crate::gpu::fft(domain, values, true, None) {\n            return Self::from_coefs(coefs);\n        }\n'
+         '        let coefs = domain.ifft(&values);\n'),
+        ('        Self::ifft_with_domain(domain, values).mul_var(k_inv)\n',
+         '        #[cfg(feature = "gpu")]\n        if let Some(coefs) = crate::gpu::fft(domain, values, true, Some(k_inv)) {\n            return Self::from_coefs(coefs);\n        }\n'
+         '        Self::ifft_with_domain(domain, values).mul_var(k_inv)\n'),
+    ],
+}
+
+
+def render() -> str:
+    out = []
+    for rel in sorted(EDITS):
+        old = open(os.path.join(REF, rel)).read()
+        new = old
+        for a, b in EDITS[rel]:
+            new = sub(new, a, b, rel)
+        diff = difflib.unified_diff(old.splitlines(keepends=True), new.splitlines(keepends=True), f"a/{rel}", f"b/{rel}", n=3)
+        out.append("".join(diff))
+    return "".join(out)
+
+
+if __name__ == "__main__":
+    if not os.path.isdir(REF):
+        sys.exit("the reference tree is not present: the committed patch is the artefact")
+    text = render()
+    if "--check" in sys.argv:
+        sys.exit(0 if os.path.exists(OUT) and open(OUT).read() == text else 1)
+    open(OUT, "w").write(text)
+    print(f"wrote {OUT} ({text.count(chr(10))} lines)")

@@ -35,7 +35,10 @@ from uzkge_amd import poly_commit as pc
 
 GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 N_WIRES, N_WSEL, N_TABLES = 5, 3, 46
-HIDE = {"w": 2, "wsel": 2, "z": 3}            # hiding degrees (prover.rs:166,186,204)
+# hiding degrees: TurboCS::get_hiding_degree (constraint_system/turbo/mod.rs:366-373) gives wires 0..2 three blinds and wires
+# 3, 4 two; wire selectors 2 (prover.rs:186), z 3 (prover.rs:204).  The batched hide takes one degree per call, so every
+# polynomial carries three blind slots and the unused third one is zero -- adding a zero blind is the identity.
+HIDE_W, HIDE_WSEL, HIDE_Z = (3, 3, 3, 2, 2), 2, 3
 # slots of the 46 per-circuit polynomials (= UZK_TQ_Q .. UZK_TQ_QECC minus UZK_TQ_Q): q (9), s (5), l1, qb, q_prk (4),
 # coset_quotient, q_shuffle_public_key (12), q_shuffle_generator (12), q_ecc
 T_Q, T_S, T_L1, T_QB, T_QPRK, T_CQ, T_QPK, T_QG, T_QECC = 0, 9, 14, 15, 16, 20, 21, 33, 45
@@ -98,7 +101,10 @@ class ChainInputs:
         sc = fr(16)
         self.beta, self.gamma, self.alpha, self.zeta, self.alpha_open = sc[0], sc[1], sc[2], sc[3], sc[4]
         self.anemoi_g, self.edwards_a, self.alpha_open2 = sc[5], sc[6], sc[7]
-        self.blinds_w = fr(N_WIRES, HIDE["w"]); self.blinds_wsel = fr(N_WSEL, HIDE["wsel"]); self.blinds_z = fr(HIDE["z"])
+        self.blinds_w = fr(N_WIRES, 3); self.blinds_wsel = fr(N_WSEL, 3); self.blinds_z = fr(HIDE_Z)
+        for i, hd in enumerate(HIDE_W):
+            self.blinds_w[i, hd:] = 0
+        self.blinds_wsel[:, HIDE_WSEL:] = 0
         self.t_rands = fr(5)
         self.r_scalars = fr(43)
         # 1 / Z_H on the coset: 1 / (k1^n * g_m^(n i) - 1), i < 6 (helpers.rs:242-252) -- O(1) host arithmetic
@@ -107,7 +113,8 @@ class ChainInputs:
         self.k1_inv = pc.fr_from_int(pow(k1, -1, R))
         self.anemoi_g_inv = pc.fr_from_int(pow(pc.fr_to_int(self.anemoi_g), -1, R))
         self.zeta_omega = pc.fr_from_int(pc.fr_to_int(self.zeta) * pc.fr_to_int(self.group_gen) % R)
-        self.t_len = 5 * n + 8                 # deg t = 5n + 7 for hidden wires of degree n + 1 and z of degree n + 2
+        # deg t = deg z + sum deg w_j - n = (n + 2) + 3 (n + 2) + 2 (n + 1) - n = 5n + 10 (the permutation term dominates)
+        self.t_len = 5 * n + 11
 
 
 class _Buf:
@@ -217,7 +224,9 @@ class ProverChain:
                             self.z_h_inv, self.d_tq.ptr, sync=False)
         b.ntt_device(self.d_tq.ptr, self.d_t.ptr, m, inverse=True, coset_shift=self.k1_inv)
         # split_t_and_commit (helpers.rs:1323-1408, chunk = n + 2): split with the random blinds, fold mod X^n - 1, FFT(n), commit
-        self.chunk_lens = b.split_t_device(self.d_t.ptr, self.t_len, n + 2, self.t_rands, self.d_chunks.ptr, cs)
+        # from_coefs trims t (field_polynomial.rs:86-90) and its coefs.len() drives the split: the trimmed length, from the device
+        t_len = int(b.poly_trimmed_len_device(self.d_t.ptr, m, [self.t_len])[0])
+        self.chunk_lens = b.split_t_device(self.d_t.ptr, t_len, n + 2, self.t_rands, self.d_chunks.ptr, cs)
         assert [pc.max_power_of_2(int(v)) for v in self.chunk_lens] == [n] * 5          # degree = coefs.len() (helpers.rs:1367)
         o["t_blinds"] = b.fold_blinds_batch_device(self.d_chunks.ptr, cs, self.chunk_lens, n, self.d_fold.ptr, n, self.d_tail.ptr, 6,
                                                    want_blinds=self.keep_blinds)
@@ -234,8 +243,10 @@ class ProverChain:
         for j, (plan_j, point, alpha) in enumerate(((at_zeta, self.zeta, self.alpha_open), (at_zeta_omega, self.zeta_omega, self.alpha_open2))):
             op = [self._poly(kind, idx) for kind, idx in plan_j]
             b.open_quotient_ptrs_device([p for p, _ in op], [ln for _, ln in op], point, alpha, self.d_q.at(j * cs), cs)
-        # q has degree n + 1 (n + 3 coefficients divided by X - z): max_power_of_2 = n, two blinds (pcs.rs:137-156)
-        o["q_blinds"] = b.fold_blinds_batch_device(self.d_q.ptr, cs, [n + 2, n + 2], n, self.d_fold.ptr, n, self.d_tail.ptr, 6,
+        # degree = q.degree() (pcs.rs:138): n + 1 for n + 3 coefficients divided by X - z, so max_power_of_2 = n and two blinds
+        q_lens = b.poly_trimmed_len_device(self.d_q.ptr, cs, [n + 3, n + 3])
+        assert [pc.max_power_of_2(int(v) - 1) for v in q_lens] == [n, n]
+        o["q_blinds"] = b.fold_blinds_batch_device(self.d_q.ptr, cs, q_lens, n, self.d_fold.ptr, n, self.d_tail.ptr, 6,
                                                    want_blinds=self.keep_blinds)
         b.ntt_batch_device(self.d_fold.ptr, self.d_fold.ptr, n, 2)
         o["cm_q"] = b.msm_batch_tail_device(self.srs, self.d_fold.ptr, n, n, 2, self.d_tail.ptr, 6)

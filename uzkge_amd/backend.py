@@ -477,6 +477,14 @@ def fold_blinds_batch_device(d_polys: int, in_stride: int, lens, n_fold: int, d_
     return bl[:, : tail_n // 2] if want_blinds else None
 
 
+def poly_trimmed_len_device(d_polys: int, stride: int, lens) -> np.ndarray:
+    """FpPolynomial::from_coefs' trimmed length of device-resident polynomials (1 + the highest non-zero index; 0 if zero)."""
+    ln = np.ascontiguousarray(lens, dtype=np.uint64)
+    out = np.zeros(ln.shape[0], dtype=np.uint64)
+    check(lib.uzk_poly_trimmed_len_device(ctypes.c_void_p(d_polys), stride, _ptr(ln), ln.shape[0], _ptr(out)))
+    return out
+
+
 def split_t_device(d_t: int, t_len: int, chunk: int, rands: np.ndarray, d_chunks: int, chunk_stride: int) -> np.ndarray:
     """Returns the chunk lengths (the reference's coefs.len())."""
     r = np.ascontiguousarray(rands, dtype=np.uint64).reshape(-1, 4)

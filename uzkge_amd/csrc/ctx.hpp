@@ -194,6 +194,7 @@ int fold_blinds_batch_run(Ctx& c, const Fp* d_polys, uint64_t in_stride, const u
                           uint64_t out_stride, Fp* d_tail, uint32_t tail_n, Fp* blinds_host);
 int split_t_run(Ctx& c, const Fp* d_t, uint64_t t_len, uint64_t chunk, uint32_t n_chunks, const Fp* rands_host, Fp* d_chunks,
                 uint64_t chunk_stride, uint64_t* lens_out);
+int poly_trimmed_len_run(Ctx& c, const Fp* d_polys, uint64_t stride, const uint64_t* lens_host, uint32_t batch, uint64_t* out_host);
 int fold_blinds_run(Ctx& c, const Fp* d_coefs, uint64_t len, uint64_t N, Fp* d_out, Fp* blinds_host);
 int poly_lincomb_run(Ctx& c, const void* const* d_polys, const uint64_t* lens, const Fp* scalars_host, uint32_t count, Fp* d_out,
                      uint64_t out_len);

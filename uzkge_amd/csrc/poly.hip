@@ -997,6 +997,55 @@ int split_t_run(Ctx& c, const Fp* d_t, uint64_t t_len, uint64_t chunk, uint32_t 
     return UZK_OK;
 }
 
+// FpPolynomial::from_coefs trims trailing zero coefficients (field_polynomial.rs:86-90) and the prover's control flow reads
+// the result: t's coefs.len() decides the split (helpers.rs:1333), q.degree() the fold of batch_prove (pcs.rs:138).  On the
+// device the polynomials keep their allocated length, so this gives the trimmed one: out[b] = 1 + the highest index below
+// lens[b] holding a non-zero coefficient, 0 for the zero polynomial.  One launch for the batch; synchronises (the answer is
+// control flow).
+constexpr uint32_t kTrimMax = 16;
+struct TrimArgs { uint32_t len[kTrimMax]; };
+__global__ __launch_bounds__(256) void poly_trimmed_len_kernel(const Fp* __restrict__ polys, uint64_t stride, TrimArgs lens,
+                                                               unsigned long long* __restrict__ out) {
+    const uint32_t b = blockIdx.y;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool nz = i < lens.len[b] && !Fr::is_zero(polys[(uint64_t)b * stride + i]);
+    // highest non-zero index of the wave, one atomic per wave that has any
+    const unsigned long long mask = __ballot(nz);
+    if (mask != 0 && (threadIdx.x & 63) == 0) {
+        const uint64_t top = (i & ~63ull) + (63 - __clzll(mask));
+        atomicMax(&out[b], (unsigned long long)(top + 1));
+    }
+}
+int poly_trimmed_len_run(Ctx& c, const Fp* d_polys, uint64_t stride, const uint64_t* lens_host, uint32_t batch, uint64_t* out_host) {
+    if (batch == 0) return UZK_OK;
+    if (batch > kTrimMax) { set_error("poly_trimmed_len: batch %u exceeds %u", batch, kTrimMax); return UZK_ERR_PARAMETER; }
+    TrimArgs la{};
+    uint64_t max_len = 0;
+    for (uint32_t b = 0; b < batch; ++b) {
+        if (lens_host[b] >= (1ull << 32) || (batch > 1 && lens_host[b] > stride)) { set_error("poly_trimmed_len: polynomial %u: bad length", b); return UZK_ERR_PARAMETER; }
+        la.len[b] = (uint32_t)lens_host[b];
+        max_len = std::max(max_len, lens_host[b]);
+    }
+    for (uint32_t b = 0; b < batch; ++b) out_host[b] = 0;
+    if (max_len == 0) return UZK_OK;
+    if (c.poly_cnt.cap < 4096) {
+        UZK_TRY(c.poly_cnt.reserve(4096));
+        UZK_HIP(hipMemsetAsync(c.poly_cnt.p, 0, c.poly_cnt.cap, c.stream));
+    }
+    unsigned long long* d_res = reinterpret_cast<unsigned long long*>(static_cast<char*>(c.poly_cnt.p) + 2048);   // beyond the evaluation counters
+    UZK_HIP(hipMemsetAsync(d_res, 0, kTrimMax * sizeof(unsigned long long), c.stream));
+    {
+        KernelScope ks(c, "poly_trimmed_len");
+        hipLaunchKernelGGL(poly_trimmed_len_kernel, dim3((unsigned)((max_len + 255) / 256), batch), dim3(256), 0, c.stream, d_polys, stride, la, d_res);
+    }
+    UZK_HIP(hipGetLastError());
+    unsigned long long res[kTrimMax];
+    UZK_HIP(hipMemcpyAsync(res, d_res, batch * sizeof(unsigned long long), hipMemcpyDeviceToHost, c.stream));
+    UZK_HIP(hipStreamSynchronize(c.stream));
+    for (uint32_t b = 0; b < batch; ++b) out_host[b] = res[b];
+    return UZK_OK;
+}
+
 int poly_eval_batch_host(Ctx& c, const Fp* coefs_host, uint64_t n, uint32_t batch, const Fp& x, Fp* out_host) {
     if (batch == 0) return UZK_OK;
     const size_t bytes = (size_t)n * batch * sizeof(Fp);
