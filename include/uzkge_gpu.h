@@ -245,8 +245,12 @@ int uzk_fold_blinds_batch_device(const void* d_polys, uint64_t in_stride, const 
                                  void* d_out, uint64_t out_stride, void* d_tail, uint32_t tail_n, uint64_t* blinds_out);
 /* FpPolynomial::from_coefs trims trailing zeros (field_polynomial.rs:86-90) and the prover branches on the result: t's
  * coefs.len() (helpers.rs:1333), q.degree() (pcs.rs:138).  out_lens[b] = 1 + the highest index < lens[b] with a non-zero
- * coefficient of polynomial b (d_polys + b * stride), 0 for the zero polynomial.  batch <= 16; synchronises. */
-int uzk_poly_trimmed_len_device(const void* d_polys, uint64_t stride, const uint64_t* lens, uint32_t batch, uint64_t* out_lens);
+ * coefficient of polynomial b (d_polys + b * stride), 0 for the zero polynomial.  batch <= 16.
+ * sync != 0: the values are in out_lens on return.  sync == 0: out_lens must be uzk_host_alloc memory; the stream fills it in
+ * order and the caller reads it after its next synchronising call -- a prover that KNOWS the lengths a well-formed proof has
+ * (t: 5n + 11 coefficients, q: n + 2) goes on with them and checks at the round's commit that the device agrees, instead of
+ * paying a synchronisation for an answer it already has. */
+int uzk_poly_trimmed_len_device(const void* d_polys, uint64_t stride, const uint64_t* lens, uint32_t batch, uint64_t* out_lens, int sync);
 /* The split of t in split_t_and_commit (helpers.rs:1335-1363); `chunk` is the reference's `n` argument (n_constraints + 2):
  * chunk i < last = t[i chunk .. (i+1) chunk) resized to chunk + 1 with coefs[chunk] += rands[i], coefs[0] -= rands[i-1];
  * the last chunk = t[last chunk .. t_len) (or [-rands[last-1]] if empty) with coefs[0] -= rands[last-1].  Written to

@@ -9,7 +9,7 @@
 //!             uzk_msm_g1_batch_tail_device (8 commits + blind factors)                                   prover.rs:151-192
 //!   round 2   uzk_z_poly_device, iFFT, hide, commit                                                      prover.rs:199-209
 //!   round 3   uzk_ntt_fr_batch_device (coset FFT x10), uzk_t_quotient_device, coset iFFT                 helpers.rs:223-678
-//!             uzk_poly_trimmed_len_device, uzk_split_t_device, uzk_fold_blinds_batch_device, FFT(n) x5,
+//!             uzk_poly_trimmed_len_device (asynchronous), uzk_split_t_device, uzk_fold_blinds_batch_device, FFT(n) x5,
 //!             uzk_msm_g1_batch_tail_device (device tail)                                                 helpers.rs:1323-1408
 //!   round 4   uzk_poly_eval_ptrs_device (15 + 4 evaluations, one launch)                                 prover.rs:246-273
 //!   round 5   uzk_poly_lincomb_device (r_poly: the scalars come from the reference's own r_poly_or_comm,
@@ -110,6 +110,7 @@ struct Workspace {
     d_tail: sys::DevBuf,   // 5 x 6
     d_q: sys::DevBuf,      // 2 x (n + 8)
     d_r: sys::DevBuf,
+    h_lens: sys::PinnedWords, // measured trimmed lengths: [0] t, [1], [2] the opening quotients
 }
 
 lazy_static! {
@@ -135,6 +136,7 @@ impl Workspace {
             d_tail: sys::DevBuf::new(5 * 6)?,
             d_q: sys::DevBuf::new(2 * cs)?,
             d_r: sys::DevBuf::new(cs)?,
+            h_lens: sys::PinnedWords::new(4)?,
         })
     }
 }
@@ -542,25 +544,39 @@ fn prove_on_device<R: CryptoRng + RngCore, PCS: PolyComScheme, CS: ConstraintSys
     dev(sys::t_quotient(&qa, ws.d_tq.as_ptr()))?;
     let k_inv = k[1].inverse().ok_or(UzkgeError::DivisionByZero)?;
     dev(sys::ntt_strided(ws.d_tq.as_ptr(), m, ws.d_t.as_ptr(), m, m, 1, true, Some(&limb_of(&k_inv))))?;
-    // FpPolynomial::from_coefs trimmed t (helpers.rs:673-677): its coefs.len() drives the split
-    let t_len = dev(sys::trimmed_len(ws.d_t.as_ptr(), m, &[m as u64]))?[0] as usize;
+    // FpPolynomial::from_coefs trimmed t (helpers.rs:673-677) and its coefs.len() drives the split.  A well-formed proof has
+    // deg t = deg z + sum_j deg w_j - n, i.e. 5n - 2 + sum_j hiding_j coefficients: go on with that while the device measures
+    // the trimmed length into pinned memory, compare after the commit (which synchronises), redo with the measured length if
+    // they ever differ -- same proof bytes as the reference either way, and no synchronisation spent on an answer known in advance.
+    let t_len_expected = 5 * n - 2 + hiding[..N_WIRES].iter().sum::<usize>();
+    dev(sys::trimmed_len_async(ws.d_t.as_ptr(), m, &[m as u64], ws.h_lens.at(0)))?;
 
     // split_t_and_commit (helpers.rs:1323-1408) with n = n_constraints + 2: one rand per chunk, drawn in chunk order
     let t_rands: Vec<Fr> = (0..N_WIRES).map(|_| Fr::rand(prng)).collect();
     let t_rands_l: Vec<Limbs> = t_rands.iter().map(fr_limbs).collect();
-    let chunk_lens = dev(sys::split_t(ws.d_t.as_ptr(), t_len, n + 2, &t_rands_l, ws.d_chunks.as_ptr(), csz))?;
-    let mut cm_t_vec: Vec<PCS::Commitment> = Vec::with_capacity(N_WIRES);
-    if chunk_lens.iter().all(|l| max_power_of_2(*l as usize) == n && *l as usize <= n + 3) {
-        // degree = coefs.len() (helpers.rs:1367): every chunk folds onto n coefficients -- one fold, one FFT, one commit
-        dev(sys::fold_blinds_batch(ws.d_chunks.as_ptr(), csz, &chunk_lens, n, ws.d_fold.as_ptr(), n, ws.d_tail.as_ptr(), 6))?;
-        dev(sys::ntt_strided(ws.d_fold.as_ptr(), n, ws.d_fold.as_ptr(), n, n, N_WIRES as u32, false, None))?;
-        for j in dev(circuit.bases.commit_with_device_tail(ws.d_fold.as_ptr(), n, n, N_WIRES as u32, ws.d_tail.as_ptr(), 6))?.iter() {
-            cm_t_vec.push(wrap(j)?);
+    let split_and_commit = |t_len: usize| -> Result<(Vec<u64>, Vec<PCS::Commitment>), UzkgeError> {
+        let chunk_lens = dev(sys::split_t(ws.d_t.as_ptr(), t_len, n + 2, &t_rands_l, ws.d_chunks.as_ptr(), csz))?;
+        let mut cms: Vec<PCS::Commitment> = Vec::with_capacity(N_WIRES);
+        if chunk_lens.iter().all(|l| max_power_of_2(*l as usize) == n && *l as usize <= n + 3) {
+            // degree = coefs.len() (helpers.rs:1367): every chunk folds onto n coefficients -- one fold, one FFT, one commit
+            dev(sys::fold_blinds_batch(ws.d_chunks.as_ptr(), csz, &chunk_lens, n, ws.d_fold.as_ptr(), n, ws.d_tail.as_ptr(), 6))?;
+            dev(sys::ntt_strided(ws.d_fold.as_ptr(), n, ws.d_fold.as_ptr(), n, n, N_WIRES as u32, false, None))?;
+            for j in dev(circuit.bases.commit_with_device_tail(ws.d_fold.as_ptr(), n, n, N_WIRES as u32, ws.d_tail.as_ptr(), 6))?.iter() {
+                cms.push(wrap(j)?);
+            }
+        } else {
+            for (i, l) in chunk_lens.iter().enumerate() {
+                cms.push(commit_folded_generic(pcs, circuit, ws, ws.d_chunks.at(i * csz), *l as usize, *l as usize)?);
+            }
         }
-    } else {
-        for (i, l) in chunk_lens.iter().enumerate() {
-            cm_t_vec.push(commit_folded_generic(pcs, circuit, ws, ws.d_chunks.at(i * csz), *l as usize, *l as usize)?);
-        }
+        Ok((chunk_lens, cms))
+    };
+    let (mut chunk_lens, mut cm_t_vec) = split_and_commit(t_len_expected)?;
+    let t_len = ws.h_lens.get(0) as usize;
+    if t_len != t_len_expected {
+        let redo = split_and_commit(t_len)?;
+        chunk_lens = redo.0;
+        cm_t_vec = redo.1;
     }
     for cm_t in cm_t_vec.iter() {
         transcript.append_commitment::<PCS::Commitment>(cm_t);
@@ -719,20 +735,31 @@ fn prove_on_device<R: CryptoRng + RngCore, PCS: PolyComScheme, CS: ConstraintSys
     let alpha_2: PCS::Field = transcript.get_challenge_field_elem(b"alpha");
     dev(sys::open_quotient(&open_zeta, &limb_of(&zeta), &limb_of(&alpha_1), ws.d_q.as_ptr(), csz))?;
     dev(sys::open_quotient(&open_zeta_omega, &limb_of(&zeta_omega), &limb_of(&alpha_2), ws.d_q.at(csz), csz))?;
-    // degree = q.degree() (pcs.rs:138): the trimmed length minus one
-    let q_lens = dev(sys::trimmed_len(ws.d_q.as_ptr(), csz, &[(n + 3) as u64, (n + 3) as u64]))?;
-    let degrees: Vec<usize> = q_lens.iter().map(|l| (*l as usize).saturating_sub(1)).collect();
-    let mut openings: Vec<PCS::Commitment> = Vec::with_capacity(2);
-    if degrees.iter().zip(q_lens.iter()).all(|(d, l)| max_power_of_2(*d) == n && *l as usize <= n + 3) {
-        dev(sys::fold_blinds_batch(ws.d_q.as_ptr(), csz, &q_lens, n, ws.d_fold.as_ptr(), n, ws.d_tail.as_ptr(), 6))?;
-        dev(sys::ntt_strided(ws.d_fold.as_ptr(), n, ws.d_fold.as_ptr(), n, n, 2, false, None))?;
-        for j in dev(circuit.bases.commit_with_device_tail(ws.d_fold.as_ptr(), n, n, 2, ws.d_tail.as_ptr(), 6))?.iter() {
-            openings.push(wrap(j)?);
+    // degree = q.degree() (pcs.rs:138) = the trimmed length minus one; expected: hlen - 1 coefficients, hlen = the longest
+    // polynomial of the opening.  Measured asynchronously, compared after the commit, as for t.
+    let hlen = |polys: &[(*const c_void, u64)]| polys.iter().map(|p| p.1).max().unwrap_or(1);
+    let q_expected = vec![hlen(&open_zeta).saturating_sub(1), hlen(&open_zeta_omega).saturating_sub(1)];
+    dev(sys::trimmed_len_async(ws.d_q.as_ptr(), csz, &[(n + 3) as u64, (n + 3) as u64], ws.h_lens.at(1)))?;
+    let fold_and_commit = |q_lens: &[u64]| -> Result<Vec<PCS::Commitment>, UzkgeError> {
+        let degrees: Vec<usize> = q_lens.iter().map(|l| (*l as usize).saturating_sub(1)).collect();
+        let mut out: Vec<PCS::Commitment> = Vec::with_capacity(2);
+        if degrees.iter().zip(q_lens.iter()).all(|(d, l)| max_power_of_2(*d) == n && *l as usize <= n + 3) {
+            dev(sys::fold_blinds_batch(ws.d_q.as_ptr(), csz, q_lens, n, ws.d_fold.as_ptr(), n, ws.d_tail.as_ptr(), 6))?;
+            dev(sys::ntt_strided(ws.d_fold.as_ptr(), n, ws.d_fold.as_ptr(), n, n, 2, false, None))?;
+            for j in dev(circuit.bases.commit_with_device_tail(ws.d_fold.as_ptr(), n, n, 2, ws.d_tail.as_ptr(), 6))?.iter() {
+                out.push(wrap(j)?);
+            }
+        } else {
+            for j in 0..2 {
+                out.push(commit_folded_generic(pcs, circuit, ws, ws.d_q.at(j * csz), q_lens[j] as usize, degrees[j])?);
+            }
         }
-    } else {
-        for j in 0..2 {
-            openings.push(commit_folded_generic(pcs, circuit, ws, ws.d_q.at(j * csz), q_lens[j] as usize, degrees[j])?);
-        }
+        Ok(out)
+    };
+    let mut openings = fold_and_commit(&q_expected)?;
+    let q_measured = vec![ws.h_lens.get(1), ws.h_lens.get(2)];
+    if q_measured != q_expected {
+        openings = fold_and_commit(&q_measured)?;
     }
     let opening_witness_zeta_omega = openings.pop().unwrap();
     let opening_witness_zeta = openings.pop().unwrap();

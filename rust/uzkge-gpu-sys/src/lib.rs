@@ -247,11 +247,39 @@ pub fn z_poly(d_w: *const c_void, d_perm: *const c_void, d_group: *const c_void,
     check(unsafe { uzk_z_poly_device(d_w, d_perm as *const u32, d_group, k.as_ptr() as *const u64, beta.as_ptr(), gamma.as_ptr(), n as u32, k.len() as u32, d_z) })
 }
 
-/// Trimmed lengths (FpPolynomial::from_coefs) of `lens.len()` device polynomials `stride` apart (uzk_poly_trimmed_len_device).
-pub fn trimmed_len(d_polys: *const c_void, stride: usize, lens: &[u64]) -> Result<Vec<u64>, Error> {
-    let mut out = vec![0u64; lens.len()];
-    check(unsafe { uzk_poly_trimmed_len_device(d_polys, stride as u64, lens.as_ptr(), lens.len() as u32, out.as_mut_ptr()) })?;
-    Ok(out)
+/// A few u64 words of pinned host memory (uzk_host_alloc) that the device stream writes in order: results a prover reads
+/// after its next synchronising call instead of waiting for them.
+pub struct PinnedWords {
+    ptr: *mut u64,
+    count: usize,
+}
+unsafe impl Send for PinnedWords {}
+impl PinnedWords {
+    pub fn new(count: usize) -> Result<Self, Error> {
+        let mut p: *mut c_void = std::ptr::null_mut();
+        check(unsafe { uzk_host_alloc(count * 8, &mut p) })?;
+        Ok(PinnedWords { ptr: p as *mut u64, count })
+    }
+    /// Word `i`; meaningful once the stream has passed the call that writes it (after a synchronising call).
+    pub fn get(&self, i: usize) -> u64 {
+        assert!(i < self.count);
+        unsafe { std::ptr::read_volatile(self.ptr.add(i)) }
+    }
+    pub fn at(&self, i: usize) -> *mut u64 {
+        assert!(i <= self.count);
+        unsafe { self.ptr.add(i) }
+    }
+}
+impl Drop for PinnedWords {
+    fn drop(&mut self) {
+        unsafe { uzk_host_free(self.ptr as *mut c_void) };
+    }
+}
+
+/// Trimmed lengths (FpPolynomial::from_coefs) of `lens.len()` device polynomials `stride` apart (uzk_poly_trimmed_len_device),
+/// measured asynchronously into `out` (pinned): read them after the next synchronising call.
+pub fn trimmed_len_async(d_polys: *const c_void, stride: usize, lens: &[u64], out: *mut u64) -> Result<(), Error> {
+    check(unsafe { uzk_poly_trimmed_len_device(d_polys, stride as u64, lens.as_ptr(), lens.len() as u32, out, 0) })
 }
 
 /// The split of t (uzk_split_t_device); returns the chunks' coefs.len().

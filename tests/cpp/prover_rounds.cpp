@@ -120,6 +120,9 @@ static void worker(uint64_t srs, int reps, bool write_outputs, bool own_context,
         upload(d_group, x);
         CK(uzk_ntt_fr_device(d_group, d_group, n, 0, nullptr, 1));
     }
+    // Pinned result words of the asynchronous trimmed-length checks: [0] t, [1..2] the two opening quotients.
+    uint64_t* h_lens = nullptr;
+    { void* p = nullptr; CK(uzk_host_alloc(4 * sizeof(uint64_t), &p)); h_lens = static_cast<uint64_t*>(p); }
     Fr* h_evals = nullptr;                                        // pinned copy of the witness for the upload-inclusive timing
     { void* p = nullptr; CK(uzk_host_alloc(9 * n * sizeof(Fr), &p)); h_evals = static_cast<Fr*>(p); std::memcpy(h_evals, evals9.data(), 9 * n * sizeof(Fr)); }
 
@@ -172,6 +175,7 @@ static void worker(uint64_t srs, int reps, bool write_outputs, bool own_context,
     uint64_t chunk_lens[5];
     void* tq_ptrs[UZK_TQ_NVEC];
     bool want_blinds = false, upload_witness = false;
+    int redone = 0;                                               // rounds redone because a measured length differed from the expected one
 
     auto chain = [&]() {
         if (upload_witness) CK(uzk_dev_copy(d_evals, h_evals, 9 * n * sizeof(Fr), UZK_COPY_H2D));      // pinned: asynchronous
@@ -203,13 +207,21 @@ static void worker(uint64_t srs, int reps, bool write_outputs, bool own_context,
         CK(uzk_ntt_fr_device(d_tq, d_t, m, 1, k1_inv.l, 0));
         // split_t_and_commit (helpers.rs:1323-1408) with the reference's argument n + 2: every chunk's degree (= coefs.len())
         // has max_power_of_2 = n, so all five fold onto n coefficients
-        // from_coefs trims t (field_polynomial.rs:86-90) and its coefs.len() drives the split: ask the device for the trimmed length
-        uint64_t t_trim = 0;
-        CK(uzk_poly_trimmed_len_device(d_t, m, &t_len, 1, &t_trim));
-        CK(uzk_split_t_device(d_t, t_trim, n + 2, 5, t_rands[0].l, d_chunks, cs, chunk_lens));
-        CK(uzk_fold_blinds_batch_device(d_chunks, cs, chunk_lens, n, 5, d_fold, n, d_tail, 6, want_blinds ? t_blinds[0].l : nullptr));
-        CK(uzk_ntt_fr_batch_device(d_fold, d_fold, n, 5, 0, nullptr, 0));
-        CK(uzk_msm_g1_batch_tail_device(srs, 0, d_fold, n, n, 5, d_tail, 6, 1, cm_t));
+        // from_coefs trims t (field_polynomial.rs:86-90) and its coefs.len() drives the split (helpers.rs:1333).  A well-formed proof
+        // has deg t = 5n + 10, so the chain goes on with t_len = 5n + 11 while the device measures the real trimmed length into
+        // pinned memory; the commit below synchronises, then the two are compared -- and the split is redone with the measured
+        // length in the (never observed) case that they differ.
+        CK(uzk_poly_trimmed_len_device(d_t, m, &t_len, 1, h_lens, 0));
+        auto split_and_commit = [&](uint64_t len) {
+            // split_t_and_commit (helpers.rs:1323-1408) with the reference's argument n + 2: every chunk's degree (= coefs.len())
+            // has max_power_of_2 = n, so all five fold onto n coefficients
+            CK(uzk_split_t_device(d_t, len, n + 2, 5, t_rands[0].l, d_chunks, cs, chunk_lens));
+            CK(uzk_fold_blinds_batch_device(d_chunks, cs, chunk_lens, n, 5, d_fold, n, d_tail, 6, want_blinds ? t_blinds[0].l : nullptr));
+            CK(uzk_ntt_fr_batch_device(d_fold, d_fold, n, 5, 0, nullptr, 0));
+            CK(uzk_msm_g1_batch_tail_device(srs, 0, d_fold, n, n, 5, d_tail, 6, 1, cm_t));
+        };
+        split_and_commit(t_len);
+        if (h_lens[0] != t_len) { ++redone; split_and_commit(h_lens[0]); }
         // ---- round 4: the evaluations of prover.rs:246-273 in one launch
         CK(uzk_poly_eval_ptrs_device(ev_p.data(), ev_l.data(), ev_point.data(), (uint32_t)ev_p.size(), points[0].l, 2, evals[0].l));
         // ---- round 5
@@ -217,13 +229,19 @@ static void worker(uint64_t srs, int reps, bool write_outputs, bool own_context,
         CK(uzk_poly_lincomb_device(r_p.data(), r_l.data(), r_scalars[0].l, (uint32_t)r_p.size(), d_r, n + 3));
         CK(uzk_open_quotient_ptrs_device(oz_p.data(), oz_l.data(), (uint32_t)oz_p.size(), zeta.l, alpha_open.l, d_q, cs, nullptr));
         CK(uzk_open_quotient_ptrs_device(ozo_p.data(), ozo_l.data(), (uint32_t)ozo_p.size(), zeta_omega.l, alpha_open2.l, d_q + cs, cs, nullptr));
-        // degree = q.degree() (pcs.rs:138) = trimmed length - 1 = n + 1: max_power_of_2 = n, two blinds (pcs.rs:137-156)
+        // degree = q.degree() (pcs.rs:138) = trimmed length - 1 = n + 1 for polynomials of n + 3 coefficients: max_power_of_2 = n,
+        // two blinds (pcs.rs:137-156).  Same pattern as for t: go on with the expected lengths, let the device measure, compare
+        // after the commit's synchronisation.
         const uint64_t q_caps[2] = {n + 3, n + 3};
-        uint64_t q_lens[2];
-        CK(uzk_poly_trimmed_len_device(d_q, cs, q_caps, 2, q_lens));
-        CK(uzk_fold_blinds_batch_device(d_q, cs, q_lens, n, 2, d_fold, n, d_tail, 6, want_blinds ? q_blinds[0].l : nullptr));
-        CK(uzk_ntt_fr_batch_device(d_fold, d_fold, n, 2, 0, nullptr, 0));
-        CK(uzk_msm_g1_batch_tail_device(srs, 0, d_fold, n, n, 2, d_tail, 6, 1, cm_q));
+        CK(uzk_poly_trimmed_len_device(d_q, cs, q_caps, 2, h_lens + 1, 0));
+        auto fold_and_commit = [&](const uint64_t* q_lens) {
+            CK(uzk_fold_blinds_batch_device(d_q, cs, q_lens, n, 2, d_fold, n, d_tail, 6, want_blinds ? q_blinds[0].l : nullptr));
+            CK(uzk_ntt_fr_batch_device(d_fold, d_fold, n, 2, 0, nullptr, 0));
+            CK(uzk_msm_g1_batch_tail_device(srs, 0, d_fold, n, n, 2, d_tail, 6, 1, cm_q));
+        };
+        const uint64_t q_expected[2] = {n + 2, n + 2};
+        fold_and_commit(q_expected);
+        if (h_lens[1] != q_expected[0] || h_lens[2] != q_expected[1]) { ++redone; fold_and_commit(h_lens + 1); }
     };
 
     want_blinds = write_outputs;
@@ -268,7 +286,8 @@ static void worker(uint64_t srs, int reps, bool write_outputs, bool own_context,
     }
     for (void* p : {(void*)d_evals, (void*)d_perm, (void*)d_coefs, (void*)d_coset, (void*)d_tq, (void*)d_t, (void*)d_z, (void*)d_chunks, (void*)d_fold,
                     (void*)d_tail, (void*)d_q, (void*)d_r, (void*)d_group, (void*)d_tpolys, (void*)d_tables}) CK(uzk_dev_free(p));
-    CK(uzk_host_free(h_evals));
+    CK(uzk_host_free(h_evals)); CK(uzk_host_free(h_lens));
+    if (redone) std::fprintf(stderr, "note: %d round tail(s) redone with measured polynomial lengths\n", redone);
     if (own_context) { CK(uzk_ctx_set_current(0)); CK(uzk_ctx_destroy(ctx)); }
 }
 

@@ -287,5 +287,20 @@ def test_trimmed_length_is_from_coefs_length(gpu):
         got = gpu.poly_trimmed_len_device(d.ptr, stride, [4099, 4000, 4099, 4099])
         assert [int(v) for v in got] == [4099, 3990, 0, 1]
         assert int(gpu.poly_trimmed_len_device(d.ptr, stride, [4600])[0]) == 4501
+        # asynchronous form: pinned result words, valid after the next synchronising call; ordinary memory is refused
+        import ctypes
+        from uzkge_amd import UzkgeError
+        h = gpu.host_alloc(4 * 8)
+        try:
+            view = np.ctypeslib.as_array(ctypes.cast(h, ctypes.POINTER(ctypes.c_uint64)), shape=(4,))
+            for rep in range(3):                 # alternating result sets inside the library: repeated calls do not disturb each other
+                view[:] = 12345
+                gpu.poly_trimmed_len_async_device(d.ptr, stride, [4099, 4000, 4099, 4099], h)
+                gpu.sync()
+                assert [int(v) for v in view] == [4099, 3990, 0, 1]
+            with pytest.raises(UzkgeError):
+                gpu.poly_trimmed_len_async_device(d.ptr, stride, [4099], np.zeros(1, dtype=np.uint64).ctypes.data)
+        finally:
+            gpu.host_free(h)
     finally:
         d.free()

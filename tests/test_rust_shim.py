@@ -193,7 +193,7 @@ def test_patch_applies_to_the_reference(tmp_path):
     assert prover.index("transcript_init_plonk(") < hook < prover.index("// 1. Build the PI polynomial")
     glue = open(os.path.join(RUST, "uzkge-glue", "gpu_prover.rs")).read()
     indexer = open("/root/reference/uzkge/src/plonk/indexer.rs").read()
-    for field in set(re.findall(r"\bp\.([a-z_0-9]+)", glue)) | set(re.findall(r"prover_params\.([a-z_0-9]+)", glue)):
+    for field in set(re.findall(r"\bp\.([a-z_][a-z_0-9]*)", glue)) | set(re.findall(r"prover_params\.([a-z_][a-z_0-9]*)", glue)):
         assert re.search(rf"pub {field}:", indexer), f"PlonkProverParams has no field {field}"
     proof_fields = re.findall(r"^        ([a-z_0-9]+),$", glue[glue.index("Ok(PlonkProof {"):], flags=re.M)
     for field in proof_fields:

@@ -23,6 +23,7 @@ Everything goes through the C ABI alone (uzk_dev_alloc / uzk_dev_copy for the bu
 tests/cpp/prover_rounds.cpp and rust/uzkge-glue/gpu_prover.rs issue the same calls in the same order.
 tests/test_gpu_prover_chain.py checks every commitment, evaluation and intermediate polynomial against the CPU oracle chain.
 As a script: timing of the whole chain (python tools/prover_chain.py [--reps 5])."""
+import ctypes
 import os
 import sys
 import time
@@ -165,6 +166,7 @@ class ProverChain:
         self.d_tail = _Buf(5 * 6)
         self.d_q = _Buf(2 * self.cs)
         self.d_r = _Buf(self.cs)
+        self.h_lens = b.host_alloc(4 * 8)     # pinned result words of the asynchronous trimmed-length checks: t, q at zeta, q at zeta omega
         # the circuit's polynomials and their coset evaluations (the indexer's work, once per circuit): zero-padded copy into
         # 6n-slots, one batched coset FFT in place
         self.d_tpolys = _Buf(N_TABLES * n)
@@ -224,14 +226,22 @@ class ProverChain:
                             self.z_h_inv, self.d_tq.ptr, sync=False)
         b.ntt_device(self.d_tq.ptr, self.d_t.ptr, m, inverse=True, coset_shift=self.k1_inv)
         # split_t_and_commit (helpers.rs:1323-1408, chunk = n + 2): split with the random blinds, fold mod X^n - 1, FFT(n), commit
-        # from_coefs trims t (field_polynomial.rs:86-90) and its coefs.len() drives the split: the trimmed length, from the device
-        t_len = int(b.poly_trimmed_len_device(self.d_t.ptr, m, [self.t_len])[0])
-        self.chunk_lens = b.split_t_device(self.d_t.ptr, t_len, n + 2, self.t_rands, self.d_chunks.ptr, cs)
-        assert [pc.max_power_of_2(int(v)) for v in self.chunk_lens] == [n] * 5          # degree = coefs.len() (helpers.rs:1367)
-        o["t_blinds"] = b.fold_blinds_batch_device(self.d_chunks.ptr, cs, self.chunk_lens, n, self.d_fold.ptr, n, self.d_tail.ptr, 6,
-                                                   want_blinds=self.keep_blinds)
-        b.ntt_batch_device(self.d_fold.ptr, self.d_fold.ptr, n, 5)
-        o["cm_t"] = b.msm_batch_tail_device(self.srs, self.d_fold.ptr, n, n, 5, self.d_tail.ptr, 6)
+        # from_coefs trims t (field_polynomial.rs:86-90) and its coefs.len() drives the split (helpers.rs:1333): go on with the length a
+        # well-formed proof has (deg t = 5n + 10) while the device measures the trimmed one into pinned memory; compare after the
+        # commit has synchronised, redo the split with the measured length if they ever differ
+        lens_view = np.ctypeslib.as_array(ctypes.cast(self.h_lens, ctypes.POINTER(ctypes.c_uint64)), shape=(4,))
+        b.poly_trimmed_len_async_device(self.d_t.ptr, m, [self.t_len], self.h_lens)
+
+        def split_and_commit(t_len):
+            self.chunk_lens = b.split_t_device(self.d_t.ptr, t_len, n + 2, self.t_rands, self.d_chunks.ptr, cs)
+            assert [pc.max_power_of_2(int(v)) for v in self.chunk_lens] == [n] * 5      # degree = coefs.len() (helpers.rs:1367)
+            o["t_blinds"] = b.fold_blinds_batch_device(self.d_chunks.ptr, cs, self.chunk_lens, n, self.d_fold.ptr, n, self.d_tail.ptr, 6,
+                                                       want_blinds=self.keep_blinds)
+            b.ntt_batch_device(self.d_fold.ptr, self.d_fold.ptr, n, 5)
+            o["cm_t"] = b.msm_batch_tail_device(self.srs, self.d_fold.ptr, n, n, 5, self.d_tail.ptr, 6)
+        split_and_commit(self.t_len)
+        if int(lens_view[0]) != self.t_len:
+            split_and_commit(int(lens_view[0]))
         # ---- round 4: the evaluations of prover.rs:246-273 in one launch
         plan = eval_plan(self.shuffle)
         pl = [self._poly(kind, idx) for kind, idx, _ in plan]
@@ -243,13 +253,19 @@ class ProverChain:
         for j, (plan_j, point, alpha) in enumerate(((at_zeta, self.zeta, self.alpha_open), (at_zeta_omega, self.zeta_omega, self.alpha_open2))):
             op = [self._poly(kind, idx) for kind, idx in plan_j]
             b.open_quotient_ptrs_device([p for p, _ in op], [ln for _, ln in op], point, alpha, self.d_q.at(j * cs), cs)
-        # degree = q.degree() (pcs.rs:138): n + 1 for n + 3 coefficients divided by X - z, so max_power_of_2 = n and two blinds
-        q_lens = b.poly_trimmed_len_device(self.d_q.ptr, cs, [n + 3, n + 3])
-        assert [pc.max_power_of_2(int(v) - 1) for v in q_lens] == [n, n]
-        o["q_blinds"] = b.fold_blinds_batch_device(self.d_q.ptr, cs, q_lens, n, self.d_fold.ptr, n, self.d_tail.ptr, 6,
-                                                   want_blinds=self.keep_blinds)
-        b.ntt_batch_device(self.d_fold.ptr, self.d_fold.ptr, n, 2)
-        o["cm_q"] = b.msm_batch_tail_device(self.srs, self.d_fold.ptr, n, n, 2, self.d_tail.ptr, 6)
+        # degree = q.degree() (pcs.rs:138): n + 1 for n + 3 coefficients divided by X - z, so max_power_of_2 = n and two blinds;
+        # expected lengths first, the device's measurement checked after the commit
+        b.poly_trimmed_len_async_device(self.d_q.ptr, cs, [n + 3, n + 3], self.h_lens + 8)
+
+        def fold_and_commit(q_lens):
+            assert [pc.max_power_of_2(int(v) - 1) for v in q_lens] == [n, n]
+            o["q_blinds"] = b.fold_blinds_batch_device(self.d_q.ptr, cs, q_lens, n, self.d_fold.ptr, n, self.d_tail.ptr, 6,
+                                                       want_blinds=self.keep_blinds)
+            b.ntt_batch_device(self.d_fold.ptr, self.d_fold.ptr, n, 2)
+            o["cm_q"] = b.msm_batch_tail_device(self.srs, self.d_fold.ptr, n, n, 2, self.d_tail.ptr, 6)
+        fold_and_commit([n + 2, n + 2])
+        if [int(lens_view[1]), int(lens_view[2])] != [n + 2, n + 2]:
+            fold_and_commit([int(lens_view[1]), int(lens_view[2])])
         return o
 
     def snapshot(self):
@@ -270,6 +286,9 @@ class ProverChain:
         if self.d_perm:
             b.dev_free(self.d_perm)
             self.d_perm = 0
+        if self.h_lens:
+            b.host_free(self.h_lens)
+            self.h_lens = 0
 
 
 if __name__ == "__main__":

@@ -58,7 +58,7 @@ PROTOTYPES = {
     "uzk_ntt_fr_batch_strided_device": (_I, [_P, _U64, _P, _U64, _U64, ctypes.c_uint32, _I, _P, _I]),
     "uzk_hide_polynomial_batch_device": (_I, [_P, _U64, _U64, ctypes.c_uint32, _P, ctypes.c_uint32, _U64]),
     "uzk_fold_blinds_batch_device": (_I, [_P, _U64, _P, _U64, ctypes.c_uint32, _P, _U64, _P, ctypes.c_uint32, _P]),
-    "uzk_poly_trimmed_len_device": (_I, [_P, _U64, _P, ctypes.c_uint32, _P]),
+    "uzk_poly_trimmed_len_device": (_I, [_P, _U64, _P, ctypes.c_uint32, _P, _I]),
     "uzk_split_t_device": (_I, [_P, _U64, _U64, ctypes.c_uint32, _P, _P, _U64, _P]),
     "uzk_poly_eval_ptrs_device": (_I, [_P, _P, _P, ctypes.c_uint32, _P, ctypes.c_uint32, _P]),
     "uzk_open_quotient_ptrs_device": (_I, [_P, _P, ctypes.c_uint32, _P, _P, _P, _U64, _P]),

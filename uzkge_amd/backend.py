@@ -481,8 +481,14 @@ def poly_trimmed_len_device(d_polys: int, stride: int, lens) -> np.ndarray:
     """FpPolynomial::from_coefs' trimmed length of device-resident polynomials (1 + the highest non-zero index; 0 if zero)."""
     ln = np.ascontiguousarray(lens, dtype=np.uint64)
     out = np.zeros(ln.shape[0], dtype=np.uint64)
-    check(lib.uzk_poly_trimmed_len_device(ctypes.c_void_p(d_polys), stride, _ptr(ln), ln.shape[0], _ptr(out)))
+    check(lib.uzk_poly_trimmed_len_device(ctypes.c_void_p(d_polys), stride, _ptr(ln), ln.shape[0], _ptr(out), 1))
     return out
+
+
+def poly_trimmed_len_async_device(d_polys: int, stride: int, lens, h_out: int) -> None:
+    """The same without waiting: h_out = address of uzk_host_alloc memory (len(lens) u64), valid after the next synchronising call."""
+    ln = np.ascontiguousarray(lens, dtype=np.uint64)
+    check(lib.uzk_poly_trimmed_len_device(ctypes.c_void_p(d_polys), stride, _ptr(ln), ln.shape[0], ctypes.c_void_p(h_out), 0))
 
 
 def split_t_device(d_t: int, t_len: int, chunk: int, rands: np.ndarray, d_chunks: int, chunk_stride: int) -> np.ndarray:

@@ -872,11 +872,15 @@ int uzk_fold_blinds_batch_device(const void* d_polys, uint64_t in_stride, const 
                                  static_cast<Fp*>(d_tail), tail_n, reinterpret_cast<Fp*>(blinds_out));
 }
 
-int uzk_poly_trimmed_len_device(const void* d_polys, uint64_t stride, const uint64_t* lens, uint32_t batch, uint64_t* out_lens) {
+int uzk_poly_trimmed_len_device(const void* d_polys, uint64_t stride, const uint64_t* lens, uint32_t batch, uint64_t* out_lens, int sync) {
     API_LOCK;
     if (batch > 0 && (!d_polys || !lens || !out_lens)) { set_error("uzk_poly_trimmed_len_device: null pointer"); return UZK_ERR_PARAMETER; }
+    if (!sync && batch > 0 && !is_pinned_block(out_lens, batch * sizeof(uint64_t))) {
+        set_error("uzk_poly_trimmed_len_device: an asynchronous call needs out_lens in uzk_host_alloc memory");
+        return UZK_ERR_PARAMETER;
+    }
     UZK_TRY(require_ready());
-    return poly_trimmed_len_run(ctx(), static_cast<const Fp*>(d_polys), stride, lens, batch, out_lens);
+    return poly_trimmed_len_run(ctx(), static_cast<const Fp*>(d_polys), stride, lens, batch, out_lens, sync != 0);
 }
 
 int uzk_split_t_device(const void* d_t, uint64_t t_len, uint64_t chunk, uint32_t n_chunks, const uint64_t* rands_mont, void* d_chunks,

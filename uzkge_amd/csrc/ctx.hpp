@@ -98,7 +98,8 @@ struct Ctx {
     int tune_overlap = 0;     // 1: run large MSMs as two overlapping pipeline instances (experiment)  // 1: force one lane per bucket in the fold kernels
     // poly.hip workspaces (grow-only)
     DevBuf poly_tmp, poly_tmp2, poly_io, zpoly_tmp, open_tmp;
-    DevBuf poly_cnt;                 // per-polynomial arrival counters of poly_eval_small (zero between calls)
+    DevBuf poly_cnt;                 // per-polynomial arrival counters of poly_eval_small (zero between calls); trimmed-length results
+    uint32_t trim_flip = 0;          // which of the two trimmed-length result sets the next call uses
     void* poly_host = nullptr;       // pinned, device-visible: small results written by the kernels themselves
     size_t poly_host_cap = 0;
     // ntt.hip: decimated sub-vectors of the small 3 * 2^k path; three-level power tables of arbitrary
@@ -194,7 +195,7 @@ int fold_blinds_batch_run(Ctx& c, const Fp* d_polys, uint64_t in_stride, const u
                           uint64_t out_stride, Fp* d_tail, uint32_t tail_n, Fp* blinds_host);
 int split_t_run(Ctx& c, const Fp* d_t, uint64_t t_len, uint64_t chunk, uint32_t n_chunks, const Fp* rands_host, Fp* d_chunks,
                 uint64_t chunk_stride, uint64_t* lens_out);
-int poly_trimmed_len_run(Ctx& c, const Fp* d_polys, uint64_t stride, const uint64_t* lens_host, uint32_t batch, uint64_t* out_host);
+int poly_trimmed_len_run(Ctx& c, const Fp* d_polys, uint64_t stride, const uint64_t* lens_host, uint32_t batch, uint64_t* out_host, bool sync);
 int fold_blinds_run(Ctx& c, const Fp* d_coefs, uint64_t len, uint64_t N, Fp* d_out, Fp* blinds_host);
 int poly_lincomb_run(Ctx& c, const void* const* d_polys, const uint64_t* lens, const Fp* scalars_host, uint32_t count, Fp* d_out,
                      uint64_t out_len);

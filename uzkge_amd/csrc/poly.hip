@@ -1006,17 +1006,22 @@ constexpr uint32_t kTrimMax = 16;
 struct TrimArgs { uint32_t len[kTrimMax]; };
 __global__ __launch_bounds__(256) void poly_trimmed_len_kernel(const Fp* __restrict__ polys, uint64_t stride, TrimArgs lens,
                                                                unsigned long long* __restrict__ out) {
+    __shared__ unsigned long long top_of_block;
     const uint32_t b = blockIdx.y;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (threadIdx.x == 0) top_of_block = 0;
+    __syncthreads();
     const bool nz = i < lens.len[b] && !Fr::is_zero(polys[(uint64_t)b * stride + i]);
-    // highest non-zero index of the wave, one atomic per wave that has any
+    // highest non-zero index of the wave -> of the workgroup (LDS) -> one global atomic per workgroup that has any, and
+    // only if it can raise the current value (most workgroups of a dense polynomial lie below it)
     const unsigned long long mask = __ballot(nz);
-    if (mask != 0 && (threadIdx.x & 63) == 0) {
-        const uint64_t top = (i & ~63ull) + (63 - __clzll(mask));
-        atomicMax(&out[b], (unsigned long long)(top + 1));
-    }
+    if (mask != 0 && (threadIdx.x & 63) == 0) atomicMax(&top_of_block, (unsigned long long)((i & ~63ull) + (63 - __clzll(mask)) + 1));
+    __syncthreads();
+    if (threadIdx.x == 0 && top_of_block > out[b]) atomicMax(&out[b], top_of_block);
 }
-int poly_trimmed_len_run(Ctx& c, const Fp* d_polys, uint64_t stride, const uint64_t* lens_host, uint32_t batch, uint64_t* out_host) {
+// out_host: ordinary memory (sync: the values are there on return) or, with sync == false, pinned memory of uzk_host_alloc
+// that the stream fills in order -- the caller reads it after its next synchronising call.
+int poly_trimmed_len_run(Ctx& c, const Fp* d_polys, uint64_t stride, const uint64_t* lens_host, uint32_t batch, uint64_t* out_host, bool sync) {
     if (batch == 0) return UZK_OK;
     if (batch > kTrimMax) { set_error("poly_trimmed_len: batch %u exceeds %u", batch, kTrimMax); return UZK_ERR_PARAMETER; }
     TrimArgs la{};
@@ -1026,23 +1031,24 @@ int poly_trimmed_len_run(Ctx& c, const Fp* d_polys, uint64_t stride, const uint6
         la.len[b] = (uint32_t)lens_host[b];
         max_len = std::max(max_len, lens_host[b]);
     }
-    for (uint32_t b = 0; b < batch; ++b) out_host[b] = 0;
-    if (max_len == 0) return UZK_OK;
+    if (max_len == 0) { for (uint32_t b = 0; b < batch; ++b) out_host[b] = 0; return UZK_OK; }
     if (c.poly_cnt.cap < 4096) {
         UZK_TRY(c.poly_cnt.reserve(4096));
         UZK_HIP(hipMemsetAsync(c.poly_cnt.p, 0, c.poly_cnt.cap, c.stream));
     }
-    unsigned long long* d_res = reinterpret_cast<unsigned long long*>(static_cast<char*>(c.poly_cnt.p) + 2048);   // beyond the evaluation counters
+    // result slots beyond the evaluation counters; two sets, used alternately, so that an asynchronous call's copy-out and the
+    // next call's reset never touch the same words
+    c.trim_flip ^= 1u;
+    unsigned long long* d_res = reinterpret_cast<unsigned long long*>(static_cast<char*>(c.poly_cnt.p) + 2048) + c.trim_flip * kTrimMax;
     UZK_HIP(hipMemsetAsync(d_res, 0, kTrimMax * sizeof(unsigned long long), c.stream));
     {
         KernelScope ks(c, "poly_trimmed_len");
         hipLaunchKernelGGL(poly_trimmed_len_kernel, dim3((unsigned)((max_len + 255) / 256), batch), dim3(256), 0, c.stream, d_polys, stride, la, d_res);
     }
     UZK_HIP(hipGetLastError());
-    unsigned long long res[kTrimMax];
-    UZK_HIP(hipMemcpyAsync(res, d_res, batch * sizeof(unsigned long long), hipMemcpyDeviceToHost, c.stream));
-    UZK_HIP(hipStreamSynchronize(c.stream));
-    for (uint32_t b = 0; b < batch; ++b) out_host[b] = res[b];
+    static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "result words are copied as they are");
+    UZK_HIP(hipMemcpyAsync(out_host, d_res, batch * sizeof(uint64_t), hipMemcpyDeviceToHost, c.stream));
+    if (sync) UZK_HIP(hipStreamSynchronize(c.stream));
     return UZK_OK;
 }
 
