@@ -278,6 +278,7 @@ static void copy_tuning(const Ctx& from, Ctx& to) {
     to.tune_fused_hist = from.tune_fused_hist; to.tune_sort_packed = from.tune_sort_packed; to.tune_ntt_fused = from.tune_ntt_fused;
     to.tune_ntt_tile = from.tune_ntt_tile; to.tune_ntt_l29 = from.tune_ntt_l29; to.tune_small = from.tune_small;
     to.tune_fold_mode = from.tune_fold_mode; to.tune_chunk_log = from.tune_chunk_log; to.tune_overlap = from.tune_overlap;
+    to.tune_stream_log = from.tune_stream_log; to.tune_stream_min_log = from.tune_stream_min_log;
 }
 int uzk_ctx_create(uint64_t* ctx_out) {
     if (!ctx_out) { set_error("uzk_ctx_create: null pointer"); return UZK_ERR_PARAMETER; }
@@ -595,7 +596,11 @@ int uzk_msm_g1(uint64_t srs_handle, size_t offset, const uint64_t* scalars_mont,
     Ctx::Srs srs;
     UZK_TRY(msm_checked(srs_handle, offset, n, &srs));
     Jac r = jac_inf();
-    if (n > 0) {
+    const bool table = srs.d_table && !c.tune_no_precompute;
+    if (n >= ((size_t)1 << c.tune_stream_min_log) && n <= ((size_t)1 << c.tune_chunk_log) && !table && c.tune_stream_log >= 0) {
+        // large general-mode MSM: the scalars arrive in point chunks under the previous chunk's accumulation (msm.hip)
+        UZK_TRY(msm_run_streamed(c, srs.d_points + offset, as_fp(scalars_mont), n, &r));
+    } else if (n > 0) {
         UZK_TRY(c.msm_scalars.reserve(n * sizeof(Fp)));
         UZK_HIP(hipMemcpyAsync(c.msm_scalars.p, scalars_mont, n * sizeof(Fp), hipMemcpyHostToDevice, c.stream));
         UZK_TRY(msm_dispatch(srs, offset, c.msm_scalars.as<Fp>(), n, 1, &r));
@@ -1066,6 +1071,8 @@ int uzk_tune(const char* key, int value) {
     else if (!std::strcmp(key, "msm_quad_reduce")) c.tune_quad_reduce = value;
     else if (!std::strcmp(key, "msm_x29")) c.tune_x29 = value;
     else if (!std::strcmp(key, "poly_small")) c.tune_poly_small = value;
+    else if (!std::strcmp(key, "msm_stream_log")) c.tune_stream_log = value;
+    else if (!std::strcmp(key, "msm_stream_min_log")) c.tune_stream_min_log = (value >= 4 && value <= 26) ? value : 22;
     else if (!std::strcmp(key, "msm_chunk_log")) c.tune_chunk_log = (value >= 8 && value <= 26) ? value : 26;
     else { set_error("uzk_tune: unknown key %s", key); return UZK_ERR_PARAMETER; }
     return UZK_OK;

@@ -95,6 +95,8 @@ struct Ctx {
     int tune_small = 1;       // 1: n <= 2^15 takes the one-workgroup-per-slot pipeline (msm_small_*)
     int tune_fold_mode = 0;   // experiment: level-1 fold of the small pipeline = 1 + 16 * quad + lanes per chunk
     int tune_chunk_log = 26;  // point-chunk size of one sort pass (tests lower it to reach the chunk loop at small n)
+    int tune_stream_log = 0;  // log2 of the point chunk of a streamed host-scalar MSM (0 = 21); -1: never stream (upload, then one MSM)
+    int tune_stream_min_log = 22;  // host-scalar MSMs of at least 2^this points are streamed (tests lower it)
     int tune_overlap = 0;     // 1: run large MSMs as two overlapping pipeline instances (experiment)  // 1: force one lane per bucket in the fold kernels
     // poly.hip workspaces (grow-only)
     DevBuf poly_tmp, poly_tmp2, poly_io, zpoly_tmp, open_tmp;
@@ -174,6 +176,7 @@ void ntt_free_plans(Ctx& c);
 void msm_plan_info(Ctx& c, size_t n, int* window_bits, int* windows);
 int msm_run(Ctx& c, const Affine* points, const ScalarView& scalars, size_t n, uint32_t batch, Jac* out_host, int pre_c,
             uint32_t pre_stride, uint32_t pre_off);
+int msm_run_streamed(Ctx& c, const Affine* points, const Fp* scalars_host, size_t n, Jac* out_host);
 int msm_build_table(Ctx& c, const Affine* d_points, size_t n, int cb, Affine** table_out, uint32_t* W_out);
 int msm_precompute_window_bits(size_t n, int forced);
 void msm_free(Ctx& c);

@@ -715,7 +715,7 @@ template <int GS>
 __global__ __launch_bounds__(256) void msm_finalize_kernel(const XYZZ* __restrict__ in, const uint32_t* __restrict__ in_cnt,
                                                            const uint32_t* __restrict__ in_off,
                                                            const uint32_t* __restrict__ in_base,
-                                                           XYZZ* __restrict__ buckets, uint32_t NB, uint32_t W) {
+                                                           XYZZ* __restrict__ buckets, uint32_t NB, uint32_t W, int accumulate) {
     const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t t = gt / GS;
     const uint32_t sub = (uint32_t)(gt % GS);
@@ -723,7 +723,11 @@ __global__ __launch_bounds__(256) void msm_finalize_kernel(const XYZZ* __restric
     const uint32_t w = (uint32_t)(t / NB);
     const uint32_t cnt = in_cnt[t];
     XYZZ acc = fold_partials<GS>(in + in_base[w] + in_off[t], cnt, sub);
-    if (sub == 0) buckets[t] = acc;
+    if (sub == 0) {
+        // streamed MSMs (msm_run_streamed) add every later point chunk's bucket sums onto the first one's
+        if (accumulate && cnt != 0) { XYZZ prev = buckets[t]; xyzz_add(prev, acc); buckets[t] = prev; }
+        else if (!accumulate) buckets[t] = acc;
+    }
 }
 
 // ---- 6. bucket reduction ------------------------------------------------------------------------
@@ -1736,8 +1740,9 @@ static int msm_group_phase1(Ctx& c, MsmGroup& g, const Affine* points, const Sca
     return UZK_OK;
 }
 
-// Phase 2: wait for the read-back, fold the partial sums, reduce the buckets, copy the window sums.
-static int msm_group_phase2(Ctx& c, MsmGroup& g) {
+// Phase 2: wait for the read-back, fold the partial sums into the bucket array (`accumulate`: onto what an earlier point
+// chunk left there), and -- unless more chunks follow -- reduce the buckets and copy the window sums.
+static int msm_group_phase2(Ctx& c, MsmGroup& g, bool accumulate = false, bool reduce = true) {
     MsmWork& m = *g.m;
     hipStream_t st = g.st;
     c.cur_stream = st;
@@ -1793,14 +1798,15 @@ static int msm_group_phase2(Ctx& c, MsmGroup& g) {
         const dim3 grid((unsigned)((g.TBK * gs + 255) / 256));
         if (gs == 16)
             hipLaunchKernelGGL(msm_finalize_kernel<16>, grid, dim3(256), 0, st, g.part_cur, g.cnt_cur, g.off_cur, g.base_cur,
-                               buckets, g.NB, g.Wd);
+                               buckets, g.NB, g.Wd, accumulate ? 1 : 0);
         else if (gs == 4)
             hipLaunchKernelGGL(msm_finalize_kernel<4>, grid, dim3(256), 0, st, g.part_cur, g.cnt_cur, g.off_cur, g.base_cur,
-                               buckets, g.NB, g.Wd);
+                               buckets, g.NB, g.Wd, accumulate ? 1 : 0);
         else
             hipLaunchKernelGGL(msm_finalize_kernel<1>, grid, dim3(256), 0, st, g.part_cur, g.cnt_cur, g.off_cur, g.base_cur,
-                               buckets, g.NB, g.Wd);
+                               buckets, g.NB, g.Wd, accumulate ? 1 : 0);
     }
+    if (!reduce) { UZK_HIP(hipGetLastError()); return UZK_OK; }
     {
         KernelScope ks(c, "msm_reduce");
         if (g.scan_reduce) {
@@ -2080,6 +2086,80 @@ static int msm_run_small(Ctx& c, const Affine* points, const ScalarView& d_scala
     }
     auto window_sum = [&](uint32_t b, uint32_t w) -> const XYZZ& { return m.h_sums[(size_t)b * W + w]; };
     msm_horner_host(c, batch, W, pre_c > 0 ? 0 : cb, window_sum, out_host);
+    return UZK_OK;
+}
+
+// ---- streamed: host scalars of a large MSM arrive in point chunks while the previous chunk is being accumulated --------
+// Only msm_digits reads the scalars, but the sort needs every digit of its input, so a monolithic MSM cannot start before
+// the whole upload is in (2^24 scalars = 512 MiB = 10 ms of PCIe in front of 20 ms of compute).  Here the points are cut into
+// chunks that run the whole pipeline up to the bucket array one after the other -- same window width as the full problem,
+// ONE bucket set: every chunk's bucket sums are added onto the previous ones (msm_finalize, accumulate), the reduction runs
+// once at the end -- so the total number of mixed additions is that of the monolithic MSM, and chunk k + 1 uploads under
+// chunk k's accumulation.  uzk_msm_g1 (host scalars, general mode) takes this path from 2^22 points on.
+int msm_run_streamed(Ctx& c, const Affine* points, const Fp* scalars_host, size_t n, Jac* out_host) {
+    if (!c.msm) c.msm = new MsmWork[2];
+    const int cb = choose_window_bits(n, c.msm_window_bits);
+    const uint32_t W = (uint32_t)msm_num_windows(cb);
+    // Chunk schedule: the first upload is the only one nothing hides, so it is small (2^20 points = 32 MiB = 0.6 ms); the
+    // chunks then double up to 2^22, where the per-chunk costs (task tables, the pass over the bucket array) are a few
+    // per cent of the accumulation.  Measured at 2^24 (tools/stream_msm.py): uniform 2^20 / 2^21 / 2^22 chunks 24.8 / 23.5 /
+    // 25.1 ms, upload-then-compute 31.1 ms, device-resident scalars 20.6 ms.  uzk_tune("msm_stream_log", k): uniform 2^k.
+    std::vector<size_t> bounds{0};
+    {
+        const size_t cap = (size_t)1 << (c.tune_stream_log > 0 ? std::max(16, std::min(26, c.tune_stream_log)) : 22);
+        size_t sz = c.tune_stream_log > 0 ? cap : std::min<size_t>(cap, (size_t)1 << 20);
+        int at_this_size = 0;
+        while (bounds.back() < n) {
+            bounds.push_back(std::min(n, bounds.back() + sz));
+            if (++at_this_size >= (sz == ((size_t)1 << 20) ? 2 : 1) && sz < cap) { sz <<= 1; at_this_size = 0; }
+        }
+    }
+    const size_t nchunks = bounds.size() - 1;
+    size_t chunk = 0;
+    for (size_t k = 0; k < nchunks; ++k) chunk = std::max(chunk, bounds[k + 1] - bounds[k]);
+    if (!c.stream2) UZK_HIP(hipStreamCreateWithFlags(&c.stream2, hipStreamNonBlocking));
+    hipStream_t copy_st = c.stream2;
+    UZK_TRY(c.msm_scalars.reserve(2 * chunk * sizeof(Fp)));            // double buffer
+    Fp* stage[2] = {c.msm_scalars.as<Fp>(), c.msm_scalars.as<Fp>() + chunk};
+    hipEvent_t up_done[2] = {c.get_event(), c.get_event()}, consumed[2] = {c.get_event(), c.get_event()};
+    auto give_back = [&] { for (int i = 0; i < 2; ++i) { c.event_pool.push_back(up_done[i]); c.event_pool.push_back(consumed[i]); } };
+    MsmGroup g;
+    g.m = &c.msm[0];
+    g.st = c.stream;
+    int rc = UZK_OK;
+    auto upload = [&](size_t k) -> int {
+        const size_t lo = bounds[k], len = bounds[k + 1] - lo;
+        const int s = (int)(k & 1);
+        if (k >= 2) UZK_HIP(hipStreamWaitEvent(copy_st, consumed[s], 0));        // the digits kernel of chunk k - 2 has read this half
+        HostScope hs(c, "host_msm_upload");
+        UZK_HIP(hipMemcpyAsync(stage[s], scalars_host + lo, len * sizeof(Fp), hipMemcpyHostToDevice, copy_st));
+        UZK_HIP(hipEventRecord(up_done[s], copy_st));
+        return UZK_OK;
+    };
+    rc = msm_group_plan(c, g, chunk, 1, cb, false, W, 0, W);        // size every workspace for the largest chunk before anything is queued
+    if (rc == UZK_OK) rc = upload(0);
+    for (size_t k = 0; k < nchunks && rc == UZK_OK; ++k) {
+        const size_t lo = bounds[k], len = bounds[k + 1] - lo;
+        const int s = (int)(k & 1);
+        rc = msm_group_plan(c, g, len, 1, cb, false, W, 0, W);
+        if (rc != UZK_OK) break;
+        if (hipStreamWaitEvent(c.stream, up_done[s], 0) != hipSuccess) { rc = UZK_ERR_DEVICE; set_error("msm: stream wait failed"); break; }
+        { HostScope hs(c, "host_msm_enqueue1"); rc = msm_group_phase1(c, g, points + lo, ScalarView::dense(stage[s], len), 0, 0); }
+        if (rc != UZK_OK) break;
+        // phase 1 is queued: its first kernel (digits) is the only reader of the staging half.  Marking the half free after the
+        // whole phase is simpler than an event in the middle of it and costs nothing: the next upload into this half is two
+        // chunks away.
+        (void)hipEventRecord(consumed[s], c.stream);
+        if (k + 1 < nchunks) rc = upload(k + 1);           // pageable source: the call returns when the chunk is on its way; the GPU works meanwhile
+        if (rc != UZK_OK) break;
+        { HostScope hs(c, "host_msm_wait1_enqueue2"); rc = msm_group_phase2(c, g, /*accumulate*/ k > 0, /*reduce*/ k + 1 == nchunks); }
+    }
+    { HostScope hs(c, "host_msm_wait2"); (void)hipStreamSynchronize(c.stream); (void)hipStreamSynchronize(copy_st); }
+    c.cur_stream = c.stream;
+    give_back();
+    UZK_TRY(rc);
+    auto window_sum = [&](uint32_t, uint32_t w) -> const XYZZ& { return g.m->h_sums[w]; };
+    msm_horner_host(c, 1, W, cb, window_sum, out_host);
     return UZK_OK;
 }
 
