@@ -279,16 +279,23 @@ def run_rank(args) -> None:
     gather_in = torch.zeros(96, dtype=torch.uint8, device=coll_dev)
     gather_out = torch.zeros(96 * world, dtype=torch.uint8, device=coll_dev)
 
+    split = {"msm_s": 0.0, "exchange_s": 0.0}     # where a step's time goes on THIS rank (wall clock, accumulated over the steps)
+
     def step():
         # the rank's partial sum arrives in host memory (the window sums are combined there); the exchange is
         # the 96-byte all-gather over RCCL / xGMI and every rank folds the N partials
+        t_a = time.perf_counter()
         part = b.msm_device(srs, sc.data_ptr(), n)
+        t_b = time.perf_counter()
+        split["msm_s"] += t_b - t_a
         if not use_dist:
             return part
         gather_in.copy_(torch.from_numpy(part.view(np.uint8)))
         dist.all_gather_into_tensor(gather_out, gather_in)
         allp = gather_out.cpu().numpy().view(np.uint64).reshape(world, 12)
-        return b.g1_fold(allp)
+        res = b.g1_fold(allp)
+        split["exchange_s"] += time.perf_counter() - t_b      # includes waiting for the slowest rank's partial
+        return res
 
     def fence():
         b.sync()
@@ -316,9 +323,21 @@ def run_rank(args) -> None:
         step()
     b.profile_reset()
     b.profile_enable(True)
+    split["msm_s"] = split["exchange_s"] = 0.0
+    t_local = time.perf_counter()
     elapsed, result = timed_steps(step, args.steps)
+    local_elapsed = time.perf_counter() - t_local             # this rank's own clock around the same region (incl. the fences)
     b.profile_enable(False)
     prof = b.profile_table()
+    # per-rank view of the timed region, so that a multi-GPU run explains itself: every rank's ms per step, its MSM share and
+    # its exchange share (all-gather of the 96-byte partials + fold; expected << 0.1 ms, i.e. flat weak scaling)
+    mine = {"rank": rank, "ms_per_step": round(local_elapsed / args.steps * 1e3, 4), "msm_ms_per_step": round(split["msm_s"] / args.steps * 1e3, 4),
+            "exchange_ms_per_step": round(split["exchange_s"] / args.steps * 1e3, 4)}
+    per_rank = [mine]
+    if use_dist:
+        objs = [None] * world
+        dist.all_gather_object(objs, mine)
+        per_rank = sorted(objs, key=lambda o: o["rank"])
 
     ms_per_step = elapsed / args.steps * 1e3
     value = world * n * args.steps / elapsed
@@ -502,6 +521,15 @@ def run_rank(args) -> None:
             if n >= (1 << 20):
                 s20, _ = time_msm(srs, sc.data_ptr(), 1 << 20, reps=10)
                 extra["msm_2p20"] = {"ms_per_msm": round(s20 * 1e3, 4), "points_per_sec": (1 << 20) / s20}
+                # the window table at this size (uzk_srs_precompute): where does it stop paying?  (gpu.rs registers it up to 2^15 bases)
+                srs20 = b.Srs.from_device(pts.data_ptr(), 1 << 20)
+                try:
+                    for cbits in (20, 22):
+                        srs20.precompute(cbits)
+                        s20t, r20t = time_msm(srs20, sc.data_ptr(), 1 << 20, reps=10)
+                        extra["msm_2p20"][f"window_table_c{cbits}_ms"] = round(s20t * 1e3, 4)
+                finally:
+                    srs20.release()
         except Exception as e:
             extra["msm_2p20"] = {"error": str(e)}
         try:     # PCIe-inclusive: the host-pointer entry points (scalars / vector cross PCIe inside the call)
@@ -657,6 +685,10 @@ def run_rank(args) -> None:
             "dist_world_size": dist.get_world_size() if use_dist else 1,
             "collective_backend": (dist.get_backend() if use_dist else None),
             "device_ids": dev_ids, "device_uuids": dev_uuids,
+            # every rank's own view of the timed region: ms per step, of which its MSM and of which the exchange (the 96-byte
+            # all-gather + the fold, including the wait for the slowest rank).  `ms_per_step` above is the maximum over ranks.
+            "per_rank": per_rank,
+            "exchange_ms_per_step_max": max(r["exchange_ms_per_step"] for r in per_rank),
             "roofline": roofline, "cpu_baseline": cpu_baseline, "extra": extra,
             "result_is_infinity": bool(not result[8:12].any()),
             "result_affine_sha256": hashlib.sha256(np.ascontiguousarray(b.g1_to_affine(result)).tobytes()).hexdigest()[:16],

@@ -1,32 +1,30 @@
 #!/usr/bin/env python3
-"""Interleaved A/B of the NTT pass tile size (uzk_tune "ntt_tile": 2048 elements / 512 threads vs 1024 / 256): identical
-outputs, alternating timing, single transforms and the prover's batched shapes."""
+"""A/B of the NTT pass tile (elements per workgroup): 2048 (512 threads), 1024 (256 threads), 512 (128 threads: experiment).
+Outputs are compared with the default's; times are per call, device resident, best of three rounds."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
+import numpy as np
 from uzkge_amd import backend as b
 b.init(0)
-nmax = 1 << 24
-src = torch.empty((nmax, 4), dtype=torch.int64, device="cuda")
-o0 = torch.empty((nmax, 4), dtype=torch.int64, device="cuda")
-o1 = torch.empty((nmax, 4), dtype=torch.int64, device="cuda")
-b.synth_scalars(src.data_ptr(), nmax, 7)
-shift = src[:1].cpu().numpy().view("uint64")[0]
-cases = [(1 << lg, 1, None) for lg in (12, 14, 16, 18, 20, 22, 24)] + [(1 << 14, 10, None), (98304, 10, shift), (98304, 1, shift), (3 << 20, 1, None)]
-for n, batch, cs in cases:
-    same = True
-    for inv in (False, True):
-        b.tune("ntt_tile", 2048); b.ntt_batch_device(src.data_ptr(), o0.data_ptr(), n, batch, inverse=inv, coset_shift=cs, sync=True)
-        b.tune("ntt_tile", 1024); b.ntt_batch_device(src.data_ptr(), o1.data_ptr(), n, batch, inverse=inv, coset_shift=cs, sync=True)
-        same = same and bool(torch.equal(o0[:n * batch], o1[:n * batch]))
-    t = {2048: 1e9, 1024: 1e9}
-    reps = 30 if n * batch <= (1 << 22) else 8
-    for rnd in range(4):
-        for v in (2048, 1024):
-            b.tune("ntt_tile", v)
-            b.ntt_batch_device(src.data_ptr(), o0.data_ptr(), n, batch, coset_shift=cs, sync=True)
+nmax = 1 << 22
+d_x, d_y, d_r = b.dev_alloc(nmax * 32 * 10), b.dev_alloc(nmax * 32 * 10), b.dev_alloc(nmax * 32 * 10)
+b.synth_scalars(d_x, nmax * 10, 7)
+for lg, batch in ((12, 1), (14, 1), (14, 10), (16, 1), (18, 1), (20, 1), (22, 1), (22, 4)):
+    n = 1 << lg
+    b.tune("ntt_tile", 0)
+    b.ntt_batch_device(d_x, d_r, n, batch, sync=True)
+    ref = b.dev_download(d_r, (batch * n, 4))
+    row = []
+    for tile in (2048, 1024, 512):
+        b.tune("ntt_tile", tile)
+        b.ntt_batch_device(d_x, d_y, n, batch, sync=True)
+        same = bool(np.array_equal(b.dev_download(d_y, (batch * n, 4)), ref))
+        best = 1e9
+        for rnd in range(3):
             t0 = time.perf_counter()
-            for _ in range(reps): b.ntt_batch_device(src.data_ptr(), o0.data_ptr(), n, batch, coset_shift=cs)
-            b.sync(); t[v] = min(t[v], (time.perf_counter() - t0) / reps)
-    print(f"n={n:9d} batch={batch:3d} coset={cs is not None!s:5s} equal={same}  tile2048 {t[2048]*1e6:9.1f} us  tile1024 {t[1024]*1e6:9.1f} us  ({(t[1024]/t[2048]-1)*100:+.1f} %)", flush=True)
+            for _ in range(20): b.ntt_batch_device(d_x, d_y, n, batch)
+            b.sync()
+            best = min(best, (time.perf_counter() - t0) / 20)
+        row.append(f"tile {tile}: {best * 1e6:8.1f} us {'ok' if same else 'MISMATCH'}")
+    print(f"2^{lg} x{batch}: " + "  ".join(row), flush=True)
 b.tune("ntt_tile", 0)

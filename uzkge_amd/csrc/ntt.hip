@@ -383,7 +383,7 @@ __device__ __forceinline__ L29 lds_get29(const uint4* lds, int idx) {
 template <int B, bool FIRST, int TILE>
 __global__ __launch_bounds__(TILE / 4) void ntt_pass29_kernel(const Fp* __restrict__ in, Fp* __restrict__ out,
                                                              PassArgs a) {
-    constexpr int R = 1 << B, T = TILE / R, Q = R / 4, SH = 8 - B, NT = TILE / 4, PL = TILE + 64;
+    constexpr int R = 1 << B, T = TILE / R, Q = R / 4, SH = 8 - B, NT = TILE / 4, PL = TILE + (TILE >= 1024 ? 64 : 16);
     constexpr int N4 = B / 2;
     constexpr bool TAIL2 = (B & 1) != 0;
     __shared__ uint4 lds[(9 * PL + 3) / 4];
@@ -689,7 +689,12 @@ static void launch_pass(Ctx& c, bool l29, bool first, const Fp* in, Fp* out, con
     // on a chip the launch does not fill, shorter load / compute / store phases -- 25..32 % faster from 2^12 to 2^18 and
     // for the prover's shapes (10 x 2^14: 36 -> 26 us, 98304 on a coset: 48 -> 34 us); equal within 2 % above.
     const bool small_tile = c.tune_ntt_tile == 1024 || (c.tune_ntt_tile == 0 && n * (uint64_t)batch < (1ull << 20));
-    if (l29 && small_tile) {
+    if (l29 && c.tune_ntt_tile == 512) {          // experiment: two waves per workgroup (uzk_tune("ntt_tile", 512))
+        KernelScope ks(c, first ? "ntt_pass_first" : "ntt_pass");
+        const unsigned g5 = (unsigned)((n / R) / (512 / R));
+        if (first) hipLaunchKernelGGL((ntt_pass29_kernel<B, true, 512>), dim3(g5, batch), dim3(128), 0, c.stream, in, out, a);
+        else hipLaunchKernelGGL((ntt_pass29_kernel<B, false, 512>), dim3(g5, batch), dim3(128), 0, c.stream, in, out, a);
+    } else if (l29 && small_tile) {
         KernelScope ks(c, first ? "ntt_pass_first" : "ntt_pass");
         const unsigned g2 = (unsigned)((n / R) / (1024 / R));
         if (first) hipLaunchKernelGGL((ntt_pass29_kernel<B, true, 1024>), dim3(g2, batch), dim3(256), 0, c.stream, in, out, a);
