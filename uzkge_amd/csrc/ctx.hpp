@@ -97,6 +97,7 @@ struct Ctx {
     int tune_chunk_log = 26;  // point-chunk size of one sort pass (tests lower it to reach the chunk loop at small n)
     int tune_stream_log = 0;  // log2 of the point chunk of a streamed host-scalar MSM (0 = 21); -1: never stream (upload, then one MSM)
     int tune_stream_min_log = 22;  // host-scalar MSMs of at least 2^this points are streamed (tests lower it)
+    int tune_scatter4 = 0;    // experiment: large packed sorts scatter 8192-entry tiles of 4-byte words (msm_radix_scatter4_kernel): measured slower
     int tune_overlap = 0;     // 1: run large MSMs as two overlapping pipeline instances (experiment)  // 1: force one lane per bucket in the fold kernels
     // poly.hip workspaces (grow-only)
     DevBuf poly_tmp, poly_tmp2, poly_io, zpoly_tmp, open_tmp;

@@ -389,6 +389,79 @@ __global__ __launch_bounds__(TB) void msm_radix_scatter_kernel(RadixArgs a) {
     }
 }
 
+// EXPERIMENT (uzk_tune("msm_scatter4", 1); off by default -- a negative result, profiles/r03_ab_scatter4.txt): the same scatter for
+// passes whose OUTPUT is a 4-byte word (the packed intermediate entry, or the final index | sign), i.e. every pass of the large
+// sorts, with a tile of TB * E = 8192 entries: with 512 bins a tile leaves 16 entries = 64 bytes per bin, a whole memory line
+// (the 4096-entry tile's 32-byte runs cost 1.85x write traffic at 2^24, rocprofv3 WRITE_SIZE); the tile is kept in LDS as the
+// output word plus a 16-bit bin (6 bytes per entry instead of 8), and the destination of entry k is one table lookup
+// (pos = delta[bin] + k).  Measured per pass at 2^24: 1.11 ms against 1.01 ms for the 4096-entry tile, 2^23: 0.55 vs 0.50, 2^26:
+// equal -- the scatter is bound by its LDS round trips and their barriers, not by the partial-line writes.
+template <int TB, int E, bool FROM_DIGITS, bool OUT_VAL, bool PK_IN>
+__global__ __launch_bounds__(TB) void msm_radix_scatter4_kernel(RadixArgs a) {
+    constexpr int TILE = TB * E;
+    __shared__ uint32_t ebuf[TILE];
+    __shared__ uint16_t bbuf[TILE];
+    __shared__ uint32_t tcnt[512], toff[512], gcur[512], wsum[16];
+    const uint32_t tid = threadIdx.x;
+    uint32_t seg, base, lo, hi;
+    size_t cidx;
+    if (!radix_work<FROM_DIGITS>(a, seg, cidx, base, lo, hi)) return;
+    const uint32_t* coff = a.counts + cidx;
+    for (uint32_t b = tid; b < a.bins; b += TB) gcur[b] = a.bin_base[(size_t)seg * a.bins + b] + coff[b];
+    uint32_t* out = OUT_VAL ? a.out_vals : reinterpret_cast<uint32_t*>(a.out_entries);
+    const uint32_t low_mask = (1u << a.shift) - 1;
+    for (uint32_t t0 = lo; t0 < hi; t0 += TILE) {
+        for (uint32_t b = tid; b < a.bins; b += TB) tcnt[b] = 0;
+        __syncthreads();
+        uint32_t word[E], rank[E];
+        uint16_t bin[E];
+        bool ok[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const uint32_t k = t0 + tid + e * TB;
+            uint32_t key = 0, val = 0;
+            ok[e] = (k < hi) && radix_load<FROM_DIGITS, PK_IN>(a, seg, base, k, key, val);
+            bin[e] = (uint16_t)((key >> a.shift) & a.mask);
+            word[e] = OUT_VAL ? val : pk_make(key & low_mask, val, a.pk_out_bits);
+            if (ok[e]) rank[e] = atomicAdd(&tcnt[bin[e]], 1u);
+        }
+        __syncthreads();
+        {   // exclusive scan of tcnt[0..bins) -> toff: each wave scans whole 64-bin groups
+            const uint32_t ngroups = (a.bins + 63) / 64, lane = tid & 63;
+            for (uint32_t g = tid >> 6; g < ngroups; g += TB / 64) {
+                const uint32_t b = g * 64 + lane;
+                const uint32_t v = (b < a.bins) ? tcnt[b] : 0;
+                uint32_t incl = v;
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t t = __shfl_up((int)incl, o);
+                    if ((int)lane >= o) incl += t;
+                }
+                if (b < a.bins) toff[b] = incl - v;
+                if (lane == 63) wsum[g] = incl;
+            }
+            __syncthreads();
+            for (uint32_t b = tid; b < a.bins; b += TB) {
+                uint32_t pre = 0;
+                for (uint32_t g = 0; g < (b >> 6); ++g) pre += wsum[g];
+                toff[b] += pre;
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if (ok[e]) { const uint32_t at = toff[bin[e]] + rank[e]; ebuf[at] = word[e]; bbuf[at] = bin[e]; }
+        }
+        const uint32_t last = a.bins - 1;
+        const uint32_t total = toff[last] + tcnt[last];
+        __syncthreads();
+        // toff becomes delta = global cursor - tile offset (wraps harmlessly), the cursor moves on
+        for (uint32_t b = tid; b < a.bins; b += TB) { const uint32_t g0 = gcur[b]; gcur[b] = g0 + tcnt[b]; toff[b] = g0 - toff[b]; }
+        __syncthreads();
+        for (uint32_t k = tid; k < total; k += TB) out[toff[bbuf[k]] + k] = ebuf[k];
+        __syncthreads();
+    }
+}
+
 // ---- 3. task scans -----------------------------------------------------------------------------
 // One workgroup per bucket window: v[b] = div ? ceil(cnt[b] / div) : cnt[b]; writes v (optional), the
 // exclusive prefix of v within the window, the window total, and folds max(cnt) into *max_out.
@@ -1682,7 +1755,11 @@ static int msm_group_phase1(Ctx& c, MsmGroup& g, const Affine* points, const Sca
         }
         {
             KernelScope ks(c, "msm_sort_scatter");
+            // large two-pass sorts with packed entries: both passes write 4-byte words -- the line-sized-run scatter (tune: msm_scatter4)
+            const bool four = c.tune_scatter4 && g.pk_bits != 0 && g.entries >= (1ull << 26);
             if (first && last) hipLaunchKernelGGL((msm_radix_scatter_kernel<1024, 8, true, true, false>), grid, dim3(1024), 0, st, a);
+            else if (first && four) hipLaunchKernelGGL((msm_radix_scatter4_kernel<512, 16, true, false, false>), grid, dim3(512), 0, st, a);
+            else if (last && four) hipLaunchKernelGGL((msm_radix_scatter4_kernel<512, 16, false, true, true>), grid, dim3(512), 0, st, a);
             else if (first && g.entries >= (1ull << 26))   // large sorts: 512 lanes, 4096-entry tiles (measured)
                 hipLaunchKernelGGL((msm_radix_scatter_kernel<512, 8, true, false, false>), grid, dim3(512), 0, st, a);
             else if (first) hipLaunchKernelGGL((msm_radix_scatter_kernel<1024, 8, true, false, false>), grid, dim3(1024), 0, st, a);
