@@ -273,7 +273,7 @@ int uzk_shutdown(void) {
 static void copy_tuning(const Ctx& from, Ctx& to) {
     to.msm_window_bits = from.msm_window_bits;
     to.tune_acc_variant = from.tune_acc_variant; to.tune_task_len = from.tune_task_len; to.tune_no_precompute = from.tune_no_precompute;
-    to.tune_fold_group = from.tune_fold_group; to.tune_scan_reduce = from.tune_scan_reduce; to.tune_poly_small = from.tune_poly_small;
+    to.tune_fold_group = from.tune_fold_group; to.tune_scan_reduce = from.tune_scan_reduce; to.tune_poly_small = from.tune_poly_small; to.tune_tq_split = from.tune_tq_split;
     to.tune_x29 = from.tune_x29; to.tune_quad_reduce = from.tune_quad_reduce; to.tune_reduce_seg = from.tune_reduce_seg;
     to.tune_fused_hist = from.tune_fused_hist; to.tune_sort_packed = from.tune_sort_packed; to.tune_ntt_fused = from.tune_ntt_fused;
     to.tune_ntt_tile = from.tune_ntt_tile; to.tune_ntt_l29 = from.tune_ntt_l29; to.tune_small = from.tune_small;
@@ -1071,6 +1071,7 @@ int uzk_tune(const char* key, int value) {
     else if (!std::strcmp(key, "msm_quad_reduce")) c.tune_quad_reduce = value;
     else if (!std::strcmp(key, "msm_x29")) c.tune_x29 = value;
     else if (!std::strcmp(key, "poly_small")) c.tune_poly_small = value;
+    else if (!std::strcmp(key, "tq_split")) c.tune_tq_split = value;
     else if (!std::strcmp(key, "msm_scatter4")) c.tune_scatter4 = value;
     else if (!std::strcmp(key, "msm_stream_log")) c.tune_stream_log = value;
     else if (!std::strcmp(key, "msm_stream_min_log")) c.tune_stream_min_log = (value >= 4 && value <= 26) ? value : 22;

@@ -85,9 +85,13 @@ __device__ __forceinline__ uint32_t msm_fold_scalar_sign(Fp& k) {
 
 
 // scalars: [batch][n]; digits: [batch][wcnt][n] for the windows w0 .. w0 + wcnt of the W-window recoding
+// `zero8` (optional): eight counters this launch clears for the kernels behind it on the stream (the small pipeline's task /
+// chunk / exception counters: one fill launch less per commit).
 __global__ __launch_bounds__(256) void msm_digits_kernel(ScalarView scalars, uint32_t* __restrict__ digits,
-                                                         uint32_t n, uint32_t batch, int c, int W, int w0, int wcnt) {
+                                                         uint32_t n, uint32_t batch, int c, int W, int w0, int wcnt,
+                                                         uint32_t* __restrict__ zero8 = nullptr) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (zero8 != nullptr && t < 8) zero8[t] = 0;
     if (t >= (uint64_t)n * batch) return;
     const uint32_t b = (uint32_t)(t / n), i = (uint32_t)(t % n);
     Fp k = Fr::from_mont(scalars.at(b, i));
@@ -1694,7 +1698,7 @@ static int msm_group_phase1(Ctx& c, MsmGroup& g, const Affine* points, const Sca
         KernelScope ks(c, "msm_digits");
         const uint64_t tot = (uint64_t)g.n32 * g.batch;
         hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_scalars, digits, g.n32,
-                           g.batch, g.cb, (int)g.W_total, (int)g.w0, (int)g.W);
+                           g.batch, g.cb, (int)g.W_total, (int)g.w0, (int)g.W, (uint32_t*)nullptr);
     }
     // ---- counting sort, high bits first
     for (int p = 0; p < g.P; ++p) {
@@ -2096,12 +2100,11 @@ static int msm_run_small(Ctx& c, const Affine* points, const ScalarView& d_scala
     }
     {
         HostScope hs(c, "host_msm_enqueue1");
-        UZK_HIP(hipMemsetAsync(counters, 0, 32, st));
         {
             KernelScope ks(c, "msm_digits");
-            const uint64_t tot = (uint64_t)n32 * batch;
+            const uint64_t tot = (uint64_t)n32 * batch;                  // n >= 1: the grid has the lanes that clear the eight counters
             hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_scalars, digits, n32, batch,
-                               cb, (int)W, 0, (int)W);
+                               cb, (int)W, 0, (int)W, counters);
         }
         {
             KernelScope ks(c, "msm_small_sort");

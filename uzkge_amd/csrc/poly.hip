@@ -64,6 +64,68 @@ __global__ __launch_bounds__(256) void fr_scan_apply_kernel(Fp* __restrict__ out
     out[pos] = Fr::mul(out[pos], tot_scan[blk - 1]);
 }
 
+// The two scans of z_poly (prefix products of the numerators, suffix products of the denominators, same length) as ONE launch
+// sequence: blockIdx.y picks the array.  in / out: [2][n] contiguous; array 0 forward, array 1 reverse.
+__global__ __launch_bounds__(256) void fr_scan_block2_kernel(const Fp* __restrict__ in, Fp* __restrict__ out, Fp* __restrict__ block_tot,
+                                                             uint64_t n, uint64_t nb) {
+    __shared__ Fp sh[256];
+    const uint32_t tid = threadIdx.x, which = blockIdx.y;
+    const int reverse = which;
+    in += (uint64_t)which * n; out += (uint64_t)which * n;
+    const uint64_t base = (uint64_t)blockIdx.x * kScanBlock + (uint64_t)tid * kScanPer;
+    Fp v[kScanPer];
+    Fp run = Fr::one();
+#pragma unroll
+    for (int e = 0; e < kScanPer; ++e) {
+        const uint64_t i = base + e;
+        Fp x = Fr::one();
+        if (i < n) x = in[reverse ? n - 1 - i : i];
+        run = Fr::mul(run, x);
+        v[e] = run;
+    }
+    sh[tid] = run;
+    __syncthreads();
+    for (uint32_t off = 1; off < 256; off <<= 1) {
+        Fp t = (tid >= off) ? sh[tid - off] : Fr::one();
+        __syncthreads();
+        if (tid >= off) sh[tid] = Fr::mul(sh[tid], t);
+        __syncthreads();
+    }
+    const Fp pre = tid ? sh[tid - 1] : Fr::one();
+#pragma unroll
+    for (int e = 0; e < kScanPer; ++e) {
+        const uint64_t i = base + e;
+        if (i < n) out[reverse ? n - 1 - i : i] = tid ? Fr::mul(v[e], pre) : v[e];
+    }
+    if (tid == 255) block_tot[(uint64_t)which * nb + blockIdx.x] = sh[255];
+}
+// second level for both arrays (nb <= 256 blocks each: n <= 2^19) and the fix-up of every element, in one kernel: each
+// workgroup rebuilds the exclusive prefix of the block totals it needs (nb - 1 dependent products at most, nb = 8 at n = 2^14)
+__global__ __launch_bounds__(256) void fr_scan_apply2_kernel(Fp* __restrict__ out, const Fp* __restrict__ block_tot, uint64_t n, uint64_t nb) {
+    const uint32_t which = blockIdx.y;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t blk = i / kScanBlock;
+    if (blk == 0) return;
+    const Fp* tot = block_tot + (uint64_t)which * nb;
+    Fp pre = tot[0];
+    for (uint64_t b = 1; b < blk; ++b) pre = Fr::mul(pre, tot[b]);
+    Fp* o = out + (uint64_t)which * n;
+    const uint64_t pos = which ? n - 1 - i : i;
+    o[pos] = Fr::mul(o[pos], pre);
+}
+// d_in / d_out: [2][n]; n <= 32 * kScanBlock (the fix-up walks the block totals serially)
+static int fr_scan_mul2(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, DevBuf& tmp) {
+    const uint64_t nb = (n + kScanBlock - 1) / kScanBlock;
+    UZK_TRY(tmp.reserve(2 * nb * sizeof(Fp)));
+    KernelScope ks(c, "fr_scan");
+    hipLaunchKernelGGL(fr_scan_block2_kernel, dim3((unsigned)nb, 2), dim3(256), 0, c.stream, d_in, d_out, tmp.as<Fp>(), n, nb);
+    if (nb > 1)
+        hipLaunchKernelGGL(fr_scan_apply2_kernel, dim3((unsigned)((n + 255) / 256), 2), dim3(256), 0, c.stream, d_out, tmp.as<Fp>(), n, nb);
+    UZK_HIP(hipGetLastError());
+    return UZK_OK;
+}
+
 // d_out[i] = prod_{t <= i} d_in[t]  (reverse: prod_{t >= i}); n <= 2048^2
 static int fr_scan_mul(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool reverse, DevBuf& tmp) {
     if (n == 0) return UZK_OK;
@@ -306,7 +368,8 @@ struct ZPolyArgs {
 // i < n-1: num[i] = prod_j (f_j(i) + gamma + beta k_j w^i), den[i] = prod_j (f_j(i) + gamma + beta perm_j(i))
 __global__ __launch_bounds__(256) void z_poly_terms_kernel(ZPolyArgs a, Fp* __restrict__ num, Fp* __restrict__ den) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i + 1 >= a.n) return;
+    if (i >= a.n) return;
+    if (i + 1 == a.n) { num[i] = Fr::one(); den[i] = Fr::one(); return; }     // pads the two scans to n elements (fr_scan_mul2)
     const Fp gi = a.group[i];
     Fp nm = Fr::one(), dn = Fr::one();
     for (uint32_t j = 0; j < a.n_wires; ++j) {
@@ -356,10 +419,18 @@ int z_poly_device(Ctx& c, const Fp* d_w, const uint32_t* d_perm, const Fp* d_gro
     const uint32_t m = n - 1;
     {
         KernelScope ks(c, "z_poly_terms");
-        hipLaunchKernelGGL(z_poly_terms_kernel, dim3((m + 255) / 256), dim3(256), 0, c.stream, a, d_num, d_den);
+        hipLaunchKernelGGL(z_poly_terms_kernel, dim3((n + 255) / 256), dim3(256), 0, c.stream, a, d_num, d_den);
     }
-    UZK_TRY(fr_scan_mul(c, d_num, d_P, m, false, c.poly_tmp));
-    UZK_TRY(fr_scan_mul(c, d_den, d_S, m, true, c.poly_tmp2));
+    if (m <= 32ull * kScanBlock) {
+        // num | den and P | S are adjacent pairs of the workspace: both scans in two launches instead of six.  The pairs are n
+        // apart while the scans run over m = n - 1 elements: the kernels take the array distance from their `n`, so scan
+        // n elements each -- the extra last element (index n - 1 of num / den) is never read by the combine step, it only has to be
+        // defined: z_poly_terms leaves it untouched, so give it a one.
+        UZK_TRY(fr_scan_mul2(c, d_num, d_P, n, c.poly_tmp));
+    } else {
+        UZK_TRY(fr_scan_mul(c, d_num, d_P, m, false, c.poly_tmp));
+        UZK_TRY(fr_scan_mul(c, d_den, d_S, m, true, c.poly_tmp2));
+    }
     Fp total;
     UZK_HIP(hipMemcpyAsync(&total, d_S, sizeof(Fp), hipMemcpyDeviceToHost, c.stream));
     UZK_HIP(hipStreamSynchronize(c.stream));
@@ -414,14 +485,8 @@ struct QuotientDev {
     Fp zhi[16];
 };
 
-// SHUFFLE = false: the circuit has no shuffle / ECC selectors (uzkge built without the "shuffle" feature, e.g.
-// zmatchmaking): terms 12..18 of helpers.rs:437-655 do not exist and their 28 vectors are not read.
-template <bool SHUFFLE>
-__global__ __launch_bounds__(256) void t_quotient_kernel(QuotientDev a, Fp* __restrict__ out) {
-    const uint32_t point = blockIdx.x * blockDim.x + threadIdx.x;
-    if (point >= a.m) return;
-    uint32_t nxt = point + a.factor;
-    if (nxt >= a.m) nxt -= a.m;
+// Terms 1..11 of the reference's loop body (helpers.rs:284-436): gate, permutation, L1, booleanity, Anemoi round.
+__device__ __forceinline__ Fp tq_terms_1_to_11(const QuotientDev& a, uint32_t point, uint32_t nxt) {
     const Fp one = Fr::one();
     auto L = [&](int slot) -> Fp { return a.vec[slot][point]; };
     const Fp w0 = L(0), w1 = L(1), w2 = L(2), w3 = L(3), w4 = L(4);
@@ -481,47 +546,83 @@ __global__ __launch_bounds__(256) void t_quotient_kernel(QuotientDev a, Fp* __re
         s = Fr::add(s, Fr::mul(a.ap[9], e11));
         acc = Fr::sub(acc, Fr::mul(prk3, s));
     }
-    // terms 12..18: shuffle / ECC
-    if constexpr (SHUFFLE) {
-        const Fp ws0 = L(5), ws1 = L(6), ws2 = L(7), qecc = L(55);
-        const Fp om0 = Fr::sub(one, ws0), om1 = Fr::sub(one, ws1);
-        Fp sel[4];
-        sel[0] = Fr::sub(Fr::add(Fr::mul(om0, om1), qecc), one);
-        sel[1] = Fr::mul(ws0, om1);
-        sel[2] = Fr::mul(om0, ws1);
-        sel[3] = Fr::mul(ws0, ws1);
-        const Fp S = Fr::add(Fr::add(sel[0], sel[1]), Fr::add(sel[2], sel[3]));
-        Fp sums[6];     // sum sel_ab * {pk_x, pk_y, pk_dxy, g_x, g_y, g_dxy}_ab
+    return acc;
+}
+// Terms 12..18 (helpers.rs:437-655, #[cfg(feature = "shuffle")]): the selector-weighted curve additions and the ECC / wire-selector
+// booleanity terms.
+__device__ __forceinline__ Fp tq_terms_12_to_18(const QuotientDev& a, uint32_t point, uint32_t nxt) {
+    const Fp one = Fr::one();
+    auto L = [&](int slot) -> Fp { return a.vec[slot][point]; };
+    const Fp w0 = L(0), w1 = L(1), w2 = L(2), w3 = L(3), w4 = L(4);
+    const Fp w0n = a.vec[0][nxt], w1n = a.vec[1][nxt], w2n = a.vec[2][nxt];
+    const Fp w0w1 = Fr::mul(w0, w1), w2w3 = Fr::mul(w2, w3);
+    const Fp ws0 = L(5), ws1 = L(6), ws2 = L(7), qecc = L(55);
+    const Fp om0 = Fr::sub(one, ws0), om1 = Fr::sub(one, ws1);
+    Fp sel[4];
+    sel[0] = Fr::sub(Fr::add(Fr::mul(om0, om1), qecc), one);
+    sel[1] = Fr::mul(ws0, om1);
+    sel[2] = Fr::mul(om0, ws1);
+    sel[3] = Fr::mul(ws0, ws1);
+    const Fp S = Fr::add(Fr::add(sel[0], sel[1]), Fr::add(sel[2], sel[3]));
+    Fp sums[6];     // sum sel_ab * {pk_x, pk_y, pk_dxy, g_x, g_y, g_dxy}_ab
 #pragma unroll
-        for (int v = 0; v < 6; ++v) {
-            Fp s = Fr::mul(sel[0], L(31 + 4 * v));
+    for (int v = 0; v < 6; ++v) {
+        Fp s = Fr::mul(sel[0], L(31 + 4 * v));
 #pragma unroll
-            for (int ab = 1; ab < 4; ++ab) s = Fr::add(s, Fr::mul(sel[ab], L(31 + 4 * v + ab)));
-            sums[v] = s;
-        }
-        const Fp ws2S = Fr::mul(ws2, S);
-        const Fp ws2SY = Fr::mul(ws2, sums[1]), ws2GY = Fr::mul(ws2, sums[4]);
-        const Fp w01SD = Fr::mul(w0w1, sums[2]), w23GD = Fr::mul(w2w3, sums[5]);
-        // 12: ws2 w0n S - ws2 w0 SY - w1 SX + w0 w1 w0n SD
-        Fp t12 = Fr::sub(Fr::add(Fr::mul(ws2S, w0n), Fr::mul(w01SD, w0n)), Fr::add(Fr::mul(ws2SY, w0), Fr::mul(w1, sums[0])));
-        // 13: ws2 w1n S + a w0 SX - ws2 w1 SY - w0 w1 w1n SD
-        Fp t13 = Fr::sub(Fr::add(Fr::mul(ws2S, w1n), Fr::mul(Fr::mul(a.ea, w0), sums[0])), Fr::add(Fr::mul(ws2SY, w1), Fr::mul(w01SD, w1n)));
-        // 14: ws2 w2n S - ws2 w2 GY - w3 GX + w2 w3 w2n GD
-        Fp t14 = Fr::sub(Fr::add(Fr::mul(ws2S, w2n), Fr::mul(w23GD, w2n)), Fr::add(Fr::mul(ws2GY, w2), Fr::mul(w3, sums[3])));
-        // 15: ws2 w4 S + a w2 GX - ws2 w3 GY - w2 w3 w4 GD
-        Fp t15 = Fr::sub(Fr::add(Fr::mul(ws2S, w4), Fr::mul(Fr::mul(a.ea, w2), sums[3])), Fr::add(Fr::mul(ws2GY, w3), Fr::mul(w23GD, w4)));
-        Fp s = Fr::mul(a.ap[10], t12);
-        s = Fr::add(s, Fr::mul(a.ap[11], t13));
-        s = Fr::add(s, Fr::mul(a.ap[12], t14));
-        s = Fr::add(s, Fr::mul(a.ap[13], t15));
-        const Fp omq = Fr::sub(one, qecc);
-        // 16, 17: q_ecc ws (1 - ws) + (1 - q_ecc) ws ; 18: q_ecc (1 + ws2)(1 - ws2)
-        s = Fr::add(s, Fr::mul(a.ap[14], Fr::mul(ws0, Fr::add(Fr::mul(qecc, om0), omq))));
-        s = Fr::add(s, Fr::mul(a.ap[15], Fr::mul(ws1, Fr::add(Fr::mul(qecc, om1), omq))));
-        s = Fr::add(s, Fr::mul(a.ap[16], Fr::mul(qecc, Fr::mul(Fr::add(one, ws2), Fr::sub(one, ws2)))));
-        acc = Fr::add(acc, s);
+        for (int ab = 1; ab < 4; ++ab) s = Fr::add(s, Fr::mul(sel[ab], L(31 + 4 * v + ab)));
+        sums[v] = s;
     }
+    const Fp ws2S = Fr::mul(ws2, S);
+    const Fp ws2SY = Fr::mul(ws2, sums[1]), ws2GY = Fr::mul(ws2, sums[4]);
+    const Fp w01SD = Fr::mul(w0w1, sums[2]), w23GD = Fr::mul(w2w3, sums[5]);
+    // 12: ws2 w0n S - ws2 w0 SY - w1 SX + w0 w1 w0n SD
+    Fp t12 = Fr::sub(Fr::add(Fr::mul(ws2S, w0n), Fr::mul(w01SD, w0n)), Fr::add(Fr::mul(ws2SY, w0), Fr::mul(w1, sums[0])));
+    // 13: ws2 w1n S + a w0 SX - ws2 w1 SY - w0 w1 w1n SD
+    Fp t13 = Fr::sub(Fr::add(Fr::mul(ws2S, w1n), Fr::mul(Fr::mul(a.ea, w0), sums[0])), Fr::add(Fr::mul(ws2SY, w1), Fr::mul(w01SD, w1n)));
+    // 14: ws2 w2n S - ws2 w2 GY - w3 GX + w2 w3 w2n GD
+    Fp t14 = Fr::sub(Fr::add(Fr::mul(ws2S, w2n), Fr::mul(w23GD, w2n)), Fr::add(Fr::mul(ws2GY, w2), Fr::mul(w3, sums[3])));
+    // 15: ws2 w4 S + a w2 GX - ws2 w3 GY - w2 w3 w4 GD
+    Fp t15 = Fr::sub(Fr::add(Fr::mul(ws2S, w4), Fr::mul(Fr::mul(a.ea, w2), sums[3])), Fr::add(Fr::mul(ws2GY, w3), Fr::mul(w23GD, w4)));
+    Fp s = Fr::mul(a.ap[10], t12);
+    s = Fr::add(s, Fr::mul(a.ap[11], t13));
+    s = Fr::add(s, Fr::mul(a.ap[12], t14));
+    s = Fr::add(s, Fr::mul(a.ap[13], t15));
+    const Fp omq = Fr::sub(one, qecc);
+    // 16, 17: q_ecc ws (1 - ws) + (1 - q_ecc) ws ; 18: q_ecc (1 + ws2)(1 - ws2)
+    s = Fr::add(s, Fr::mul(a.ap[14], Fr::mul(ws0, Fr::add(Fr::mul(qecc, om0), omq))));
+    s = Fr::add(s, Fr::mul(a.ap[15], Fr::mul(ws1, Fr::add(Fr::mul(qecc, om1), omq))));
+    s = Fr::add(s, Fr::mul(a.ap[16], Fr::mul(qecc, Fr::mul(Fr::add(one, ws2), Fr::sub(one, ws2)))));
+    return s;
+}
+
+// SHUFFLE = false: the circuit has no shuffle / ECC selectors (uzkge built without the "shuffle" feature, e.g.
+// zmatchmaking): terms 12..18 of helpers.rs:437-655 do not exist and their 28 vectors are not read.
+template <bool SHUFFLE>
+__global__ __launch_bounds__(256) void t_quotient_kernel(QuotientDev a, Fp* __restrict__ out) {
+    const uint32_t point = blockIdx.x * blockDim.x + threadIdx.x;
+    if (point >= a.m) return;
+    uint32_t nxt = point + a.factor;
+    if (nxt >= a.m) nxt -= a.m;
+    Fp acc = tq_terms_1_to_11(a, point, nxt);
+    if constexpr (SHUFFLE) acc = Fr::add(acc, tq_terms_12_to_18(a, point, nxt));
     out[point] = Fr::mul(acc, a.zhi[point % a.factor]);
+}
+// The same for shuffle circuits with the two groups of terms on two WAVES of a 128-lane workgroup (64 points each): at the
+// prover's size the loop has only 6n = 98 304 points -- 1.5 waves per SIMD, every lane a chain of ~140 dependent-latency products
+// -- so the kernel is bound by the length of one lane's chain, not by issue slots or HBM; splitting the chain in two roughly
+// equal parts (77 / 60 products) doubles the waves and halves the chain.  Field arithmetic is exact: the sum is the same element.
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void t_quotient_split_kernel(QuotientDev a, Fp* __restrict__ out) {
+    __shared__ Fp part[64];
+    const uint32_t lane = threadIdx.x & 63, half = threadIdx.x >> 6;
+    const uint32_t point = blockIdx.x * 64 + lane;
+    const bool live = point < a.m;
+    uint32_t nxt = point + a.factor;
+    if (nxt >= a.m) nxt -= a.m;
+    Fp acc = Fr::zero();
+    if (live) acc = half ? tq_terms_12_to_18(a, point, nxt) : tq_terms_1_to_11(a, point, nxt);
+    if (half) part[lane] = acc;
+    __syncthreads();
+    if (!half && live) out[point] = Fr::mul(Fr::add(acc, part[lane]), a.zhi[point % a.factor]);
 }
 
 struct QuotientArgsAbi {      // byte-for-byte uzk_quotient_args (include/uzkge_gpu.h): 8-byte aligned limbs
@@ -565,7 +666,10 @@ int t_quotient_run(Ctx& c, const void* args_c_abi, Fp* d_out) {
     d.g2p1 = Fr::add(Fr::sqr(g), Fr::one());
     for (int i = 0; i < 16; ++i) d.zhi[i] = fp_from_words(A.z_h_inv[i]);
     KernelScope ks(c, "t_quotient");
-    if (shuffle_present) hipLaunchKernelGGL(t_quotient_kernel<true>, dim3((d.m + 255) / 256), dim3(256), 0, c.stream, d, d_out);
+    // small domains (the prover's 6n = 98 304 points): the two term groups on two waves per 64 points; large ones fill the chip
+    // with one lane per point
+    if (shuffle_present && c.tune_tq_split && d.m <= (1u << 19)) hipLaunchKernelGGL(t_quotient_split_kernel, dim3((d.m + 63) / 64), dim3(128), 0, c.stream, d, d_out);
+    else if (shuffle_present) hipLaunchKernelGGL(t_quotient_kernel<true>, dim3((d.m + 255) / 256), dim3(256), 0, c.stream, d, d_out);
     else hipLaunchKernelGGL(t_quotient_kernel<false>, dim3((d.m + 255) / 256), dim3(256), 0, c.stream, d, d_out);
     UZK_HIP(hipGetLastError());
     return UZK_OK;
@@ -588,15 +692,38 @@ struct LincombArgs {                      // by value: 2.8 KB of kernel argument
     Fp scalars[kLincombMax];
     uint32_t count;
 };
+// GS lanes per coefficient: lane `sub` takes the polynomials k = sub, sub + GS, ... and a shuffle tree adds the GS partial sums.
+// At the prover's size (n + 3 = 16 387 coefficients: a quarter of a wave per SIMD) one lane per coefficient is a chain of
+// `count` dependent products on an idle chip; four lanes make it a quarter as long (r_poly's 43 polynomials: 35 -> 12 us).
+template <int GS>
 __global__ __launch_bounds__(256) void poly_lincomb_kernel(LincombArgs a, Fp* __restrict__ out, uint64_t out_len, int accumulate) {
     const Fp* scalars = a.scalars;
-    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= out_len) return;
-    Fp acc = accumulate ? out[j] : Fr::zero();
-    for (uint32_t k = 0; k < a.count; ++k)
-        if (j < a.len[k]) acc = Fr::add(acc, Fr::mul(scalars[k], a.p[k][j]));
-    out[j] = acc;
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t j = gid / GS;
+    const uint32_t sub = (uint32_t)(gid % GS);
+    const bool live = j < out_len;                    // whole groups leave the range together; dead lanes still take part in the shuffles
+    Fp acc = (accumulate && live && sub == 0) ? out[j] : Fr::zero();
+    if (live)
+        for (uint32_t k = sub; k < a.count; k += GS)
+            if (j < a.len[k]) acc = Fr::add(acc, Fr::mul(scalars[k], a.p[k][j]));
+    if constexpr (GS > 1) {
+#pragma unroll
+        for (int o = GS / 2; o > 0; o >>= 1) {
+            Fp q;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) q.v[w] = (uint32_t)__shfl_down((int)acc.v[w], o);
+            if (sub + (uint32_t)o < (uint32_t)GS) acc = Fr::add(acc, q);
+        }
+    }
+    if (live && sub == 0) out[j] = acc;
 }
+static void launch_lincomb(Ctx& c, const LincombArgs& a, Fp* d_out, uint64_t out_len, int accumulate) {
+    if (out_len <= (1ull << 17) && a.count >= 8 && c.tune_poly_small)
+        hipLaunchKernelGGL(poly_lincomb_kernel<4>, dim3((unsigned)((out_len * 4 + 255) / 256)), dim3(256), 0, c.stream, a, d_out, out_len, accumulate);
+    else
+        hipLaunchKernelGGL(poly_lincomb_kernel<1>, dim3((unsigned)((out_len + 255) / 256)), dim3(256), 0, c.stream, a, d_out, out_len, accumulate);
+}
+
 // s_i = h_i + z s_(i+1) within each block of 256 PER coefficients, carry-in 0; block_first[b] = s at the block's lowest index.
 // zp[k] = z^(PER * 2^k), k < 8.
 struct DivPows { Fp z; Fp zp[8]; };
@@ -745,7 +872,7 @@ int open_quotient_ptrs(Ctx& c, const void* const* d_polys, const uint64_t* lens,
             la.scalars[k] = a;
             a = Fr::mul(a, alpha);
         }
-        hipLaunchKernelGGL(poly_lincomb_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, la, d_h, n, k0 ? 1 : 0);
+        launch_lincomb(c, la, d_h, n, k0 ? 1 : 0);
     }
     if (per == 4) hipLaunchKernelGGL(open_div_block_kernel<4>, dim3(nblocks), dim3(256), 0, c.stream, d_h, n, pw, d_s, d_first);
     else hipLaunchKernelGGL(open_div_block_kernel<16>, dim3(nblocks), dim3(256), 0, c.stream, d_h, n, pw, d_s, d_first);
@@ -831,7 +958,7 @@ int poly_lincomb_run(Ctx& c, const void* const* d_polys, const uint64_t* lens, c
     for (uint32_t k = 0; k < count; ++k) a.scalars[k] = scalars_host[k];
     {
         KernelScope ks(c, "poly_lincomb");
-        hipLaunchKernelGGL(poly_lincomb_kernel, dim3((unsigned)((out_len + 255) / 256)), dim3(256), 0, c.stream, a, d_out, out_len, 0);
+        launch_lincomb(c, a, d_out, out_len, 0);
     }
     UZK_HIP(hipGetLastError());
     return UZK_OK;                                 // asynchronous on the library stream
@@ -1005,10 +1132,12 @@ int split_t_run(Ctx& c, const Fp* d_t, uint64_t t_len, uint64_t chunk, uint32_t 
 constexpr uint32_t kTrimMax = 16;
 struct TrimArgs { uint32_t len[kTrimMax]; };
 __global__ __launch_bounds__(256) void poly_trimmed_len_kernel(const Fp* __restrict__ polys, uint64_t stride, TrimArgs lens,
-                                                               unsigned long long* __restrict__ out) {
+                                                               unsigned long long* __restrict__ out,
+                                                               unsigned long long* __restrict__ clear_for_next) {
     __shared__ unsigned long long top_of_block;
     const uint32_t b = blockIdx.y;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x == 0 && b == 0 && threadIdx.x < kTrimMax) clear_for_next[threadIdx.x] = 0;     // the set the NEXT call accumulates into
     if (threadIdx.x == 0) top_of_block = 0;
     __syncthreads();
     const bool nz = i < lens.len[b] && !Fr::is_zero(polys[(uint64_t)b * stride + i]);
@@ -1036,14 +1165,16 @@ int poly_trimmed_len_run(Ctx& c, const Fp* d_polys, uint64_t stride, const uint6
         UZK_TRY(c.poly_cnt.reserve(4096));
         UZK_HIP(hipMemsetAsync(c.poly_cnt.p, 0, c.poly_cnt.cap, c.stream));
     }
-    // result slots beyond the evaluation counters; two sets, used alternately, so that an asynchronous call's copy-out and the
-    // next call's reset never touch the same words
+    // Result slots beyond the evaluation counters: two sets used alternately.  Both start zero (the buffer is cleared when it is
+    // allocated); every launch accumulates into one set and clears the other for the call after it -- whose copy-out of that
+    // set, issued by the call before this one, is behind it on the stream.  No fill launch.
     c.trim_flip ^= 1u;
-    unsigned long long* d_res = reinterpret_cast<unsigned long long*>(static_cast<char*>(c.poly_cnt.p) + 2048) + c.trim_flip * kTrimMax;
-    UZK_HIP(hipMemsetAsync(d_res, 0, kTrimMax * sizeof(unsigned long long), c.stream));
+    unsigned long long* sets = reinterpret_cast<unsigned long long*>(static_cast<char*>(c.poly_cnt.p) + 2048);
+    unsigned long long* d_res = sets + c.trim_flip * kTrimMax;
     {
         KernelScope ks(c, "poly_trimmed_len");
-        hipLaunchKernelGGL(poly_trimmed_len_kernel, dim3((unsigned)((max_len + 255) / 256), batch), dim3(256), 0, c.stream, d_polys, stride, la, d_res);
+        hipLaunchKernelGGL(poly_trimmed_len_kernel, dim3((unsigned)((max_len + 255) / 256), batch), dim3(256), 0, c.stream, d_polys, stride, la, d_res,
+                           sets + (c.trim_flip ^ 1u) * kTrimMax);
     }
     UZK_HIP(hipGetLastError());
     static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "result words are copied as they are");
