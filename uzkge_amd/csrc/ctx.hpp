@@ -83,7 +83,7 @@ struct Ctx {
     int tune_no_precompute = 0;
     int tune_fold_group = 0;
     int tune_scan_reduce = 1; // bucket reduction by suffix scans: 1 = for windows of <= 2^14 buckets, 2 = always, 3 = always with quads, 0 = never
-    int tune_tq_split = 1;    // 1: the quotient kernel of shuffle circuits splits its terms over two waves per 64 points (small domains)
+    int tune_tq_split = 3;    // small domains: the quotient kernel's term groups on separate waves per 64 points; 3 / 1: at three / two waves per SIMD, 0: one lane per point
     int tune_poly_small = 1;  // 1: one-launch kernels for small polynomials (evaluation)
     int tune_x29 = 1;         // 1: quad reductions on the 29-bit-limb form (ecquad29.hpp), 0: on the 8 x 32-bit arithmetic
     int tune_quad_reduce = 1; // 1: up to 2^19 buckets the scan reduction runs on quads (ecquad.hpp); 0: lanes only

@@ -485,27 +485,29 @@ struct QuotientDev {
     Fp zhi[16];
 };
 
-// Terms 1..11 of the reference's loop body (helpers.rs:284-436): gate, permutation, L1, booleanity, Anemoi round.
-__device__ __forceinline__ Fp tq_terms_1_to_11(const QuotientDev& a, uint32_t point, uint32_t nxt) {
+// The reference's loop body (helpers.rs:284-656) in four groups of terms of about equal length (34 / 43 / 36 / 38 products), so
+// that small domains can put them on four waves (t_quotient_split_kernel); PART: 0 = terms 1-3 (gate, permutation),
+// 1 = terms 4-11 (L1, booleanity, Anemoi round), 2 = terms 12, 13 (public-key curve addition), 3 = terms 14-18 (generator
+// curve addition, ECC / wire-selector booleanity).  Parts 2 and 3 exist only with the "shuffle" feature.
+template <int PART>
+__device__ __forceinline__ Fp tq_part(const QuotientDev& a, uint32_t point, uint32_t nxt) {
     const Fp one = Fr::one();
     auto L = [&](int slot) -> Fp { return a.vec[slot][point]; };
-    const Fp w0 = L(0), w1 = L(1), w2 = L(2), w3 = L(3), w4 = L(4);
-    const Fp w0n = a.vec[0][nxt], w1n = a.vec[1][nxt], w2n = a.vec[2][nxt];
-    const Fp z = L(9), zn = a.vec[9][nxt];
-    const Fp w0w1 = Fr::mul(w0, w1), w2w3 = Fr::mul(w2, w3);
-
-    // term1: gate
-    Fp acc = Fr::mul(L(10), w0);
-    acc = Fr::add(acc, Fr::mul(L(11), w1));
-    acc = Fr::add(acc, Fr::mul(L(12), w2));
-    acc = Fr::add(acc, Fr::mul(L(13), w3));
-    acc = Fr::add(acc, Fr::mul(L(14), w0w1));
-    acc = Fr::add(acc, Fr::mul(L(15), w2w3));
-    acc = Fr::add(acc, Fr::add(L(16), L(8)));
-    acc = Fr::add(acc, Fr::mul(L(17), Fr::mul(Fr::mul(w0w1, w2w3), w4)));
-    acc = Fr::sub(acc, Fr::mul(L(18), w4));
-    // term2 - term3: permutation
-    {
+    if constexpr (PART == 0) {
+        const Fp w0 = L(0), w1 = L(1), w2 = L(2), w3 = L(3), w4 = L(4);
+        const Fp z = L(9), zn = a.vec[9][nxt];
+        const Fp w0w1 = Fr::mul(w0, w1), w2w3 = Fr::mul(w2, w3);
+        // term1: gate
+        Fp acc = Fr::mul(L(10), w0);
+        acc = Fr::add(acc, Fr::mul(L(11), w1));
+        acc = Fr::add(acc, Fr::mul(L(12), w2));
+        acc = Fr::add(acc, Fr::mul(L(13), w3));
+        acc = Fr::add(acc, Fr::mul(L(14), w0w1));
+        acc = Fr::add(acc, Fr::mul(L(15), w2w3));
+        acc = Fr::add(acc, Fr::add(L(16), L(8)));
+        acc = Fr::add(acc, Fr::mul(L(17), Fr::mul(Fr::mul(w0w1, w2w3), w4)));
+        acc = Fr::sub(acc, Fr::mul(L(18), w4));
+        // term2 - term3: permutation
         const Fp cq = L(30);
         const Fp wg[5] = {Fr::add(w0, a.gamma), Fr::add(w1, a.gamma), Fr::add(w2, a.gamma), Fr::add(w3, a.gamma), Fr::add(w4, a.gamma)};
         Fp t2 = Fr::mul(a.ap[1], z), t3 = Fr::mul(a.ap[1], zn);
@@ -514,19 +516,21 @@ __device__ __forceinline__ Fp tq_terms_1_to_11(const QuotientDev& a, uint32_t po
             t2 = Fr::mul(t2, Fr::add(wg[j], Fr::mul(a.bk[j], cq)));
             t3 = Fr::mul(t3, Fr::add(wg[j], Fr::mul(a.beta, L(19 + j))));
         }
-        acc = Fr::add(acc, Fr::sub(t2, t3));
-    }
-    // term4: alpha^2 L1 (z - 1)
-    acc = Fr::add(acc, Fr::mul(Fr::mul(a.ap[2], L(24)), Fr::sub(z, one)));
-    // terms 5..7: qb * sum alpha^(2+i) w_i (w_i - 1)
-    {
-        Fp s = Fr::mul(a.ap[3], Fr::mul(w1, Fr::sub(w1, one)));
-        s = Fr::add(s, Fr::mul(a.ap[4], Fr::mul(w2, Fr::sub(w2, one))));
-        s = Fr::add(s, Fr::mul(a.ap[5], Fr::mul(w3, Fr::sub(w3, one))));
-        acc = Fr::add(acc, Fr::mul(L(25), s));
-    }
-    // terms 8..11: Anemoi round, all weighted by q_prk3 and subtracted
-    {
+        return Fr::add(acc, Fr::sub(t2, t3));
+    } else if constexpr (PART == 1) {
+        const Fp w0 = L(0), w1 = L(1), w2 = L(2), w3 = L(3), w4 = L(4);
+        const Fp w0n = a.vec[0][nxt], w1n = a.vec[1][nxt], w2n = a.vec[2][nxt];
+        const Fp z = L(9);
+        // term4: alpha^2 L1 (z - 1)
+        Fp acc = Fr::mul(Fr::mul(a.ap[2], L(24)), Fr::sub(z, one));
+        // terms 5..7: qb * sum alpha^(2+i) w_i (w_i - 1)
+        {
+            Fp s = Fr::mul(a.ap[3], Fr::mul(w1, Fr::sub(w1, one)));
+            s = Fr::add(s, Fr::mul(a.ap[4], Fr::mul(w2, Fr::sub(w2, one))));
+            s = Fr::add(s, Fr::mul(a.ap[5], Fr::mul(w3, Fr::sub(w3, one))));
+            acc = Fr::add(acc, Fr::mul(L(25), s));
+        }
+        // terms 8..11: Anemoi round, all weighted by q_prk3 and subtracted
         const Fp prk1 = L(26), prk2 = L(27), prk3 = L(28), prk4 = L(29);
         const Fp w3w0 = Fr::add(w0, w3), w2w1 = Fr::add(w1, w2);
         const Fp w3_2w0 = Fr::add(w0, w3w0), w2_2w1 = Fr::add(w1, w2w1);
@@ -544,55 +548,51 @@ __device__ __forceinline__ Fp tq_terms_1_to_11(const QuotientDev& a, uint32_t po
         s = Fr::add(s, Fr::mul(a.ap[7], e9));
         s = Fr::add(s, Fr::mul(a.ap[8], e10));
         s = Fr::add(s, Fr::mul(a.ap[9], e11));
-        acc = Fr::sub(acc, Fr::mul(prk3, s));
-    }
-    return acc;
-}
-// Terms 12..18 (helpers.rs:437-655, #[cfg(feature = "shuffle")]): the selector-weighted curve additions and the ECC / wire-selector
-// booleanity terms.
-__device__ __forceinline__ Fp tq_terms_12_to_18(const QuotientDev& a, uint32_t point, uint32_t nxt) {
-    const Fp one = Fr::one();
-    auto L = [&](int slot) -> Fp { return a.vec[slot][point]; };
-    const Fp w0 = L(0), w1 = L(1), w2 = L(2), w3 = L(3), w4 = L(4);
-    const Fp w0n = a.vec[0][nxt], w1n = a.vec[1][nxt], w2n = a.vec[2][nxt];
-    const Fp w0w1 = Fr::mul(w0, w1), w2w3 = Fr::mul(w2, w3);
-    const Fp ws0 = L(5), ws1 = L(6), ws2 = L(7), qecc = L(55);
-    const Fp om0 = Fr::sub(one, ws0), om1 = Fr::sub(one, ws1);
-    Fp sel[4];
-    sel[0] = Fr::sub(Fr::add(Fr::mul(om0, om1), qecc), one);
-    sel[1] = Fr::mul(ws0, om1);
-    sel[2] = Fr::mul(om0, ws1);
-    sel[3] = Fr::mul(ws0, ws1);
-    const Fp S = Fr::add(Fr::add(sel[0], sel[1]), Fr::add(sel[2], sel[3]));
-    Fp sums[6];     // sum sel_ab * {pk_x, pk_y, pk_dxy, g_x, g_y, g_dxy}_ab
+        return Fr::sub(acc, Fr::mul(prk3, s));
+    } else {
+        // the four selector weights of the curve-addition constraints, shared by terms 12..15
+        const Fp ws0 = L(5), ws1 = L(6), ws2 = L(7), qecc = L(55);
+        const Fp om0 = Fr::sub(one, ws0), om1 = Fr::sub(one, ws1);
+        Fp sel[4];
+        sel[0] = Fr::sub(Fr::add(Fr::mul(om0, om1), qecc), one);
+        sel[1] = Fr::mul(ws0, om1);
+        sel[2] = Fr::mul(om0, ws1);
+        sel[3] = Fr::mul(ws0, ws1);
+        const Fp S = Fr::add(Fr::add(sel[0], sel[1]), Fr::add(sel[2], sel[3]));
+        const Fp ws2S = Fr::mul(ws2, S);
+        constexpr int V0 = PART == 2 ? 0 : 3;           // sums of sel_ab * {x, y, dxy}_ab: the public key's (slots 31..42) or the generator's (43..54)
+        Fp sums[3];
 #pragma unroll
-    for (int v = 0; v < 6; ++v) {
-        Fp s = Fr::mul(sel[0], L(31 + 4 * v));
+        for (int v = 0; v < 3; ++v) {
+            Fp s = Fr::mul(sel[0], L(31 + 4 * (V0 + v)));
 #pragma unroll
-        for (int ab = 1; ab < 4; ++ab) s = Fr::add(s, Fr::mul(sel[ab], L(31 + 4 * v + ab)));
-        sums[v] = s;
+            for (int ab = 1; ab < 4; ++ab) s = Fr::add(s, Fr::mul(sel[ab], L(31 + 4 * (V0 + v) + ab)));
+            sums[v] = s;
+        }
+        const Fp ws2Y = Fr::mul(ws2, sums[1]);
+        if constexpr (PART == 2) {
+            const Fp w0 = L(0), w1 = L(1), w0n = a.vec[0][nxt], w1n = a.vec[1][nxt];
+            const Fp w01SD = Fr::mul(Fr::mul(w0, w1), sums[2]);
+            // 12: ws2 w0n S - ws2 w0 SY - w1 SX + w0 w1 w0n SD
+            Fp t12 = Fr::sub(Fr::add(Fr::mul(ws2S, w0n), Fr::mul(w01SD, w0n)), Fr::add(Fr::mul(ws2Y, w0), Fr::mul(w1, sums[0])));
+            // 13: ws2 w1n S + a w0 SX - ws2 w1 SY - w0 w1 w1n SD
+            Fp t13 = Fr::sub(Fr::add(Fr::mul(ws2S, w1n), Fr::mul(Fr::mul(a.ea, w0), sums[0])), Fr::add(Fr::mul(ws2Y, w1), Fr::mul(w01SD, w1n)));
+            return Fr::add(Fr::mul(a.ap[10], t12), Fr::mul(a.ap[11], t13));
+        } else {
+            const Fp w2 = L(2), w3 = L(3), w4 = L(4), w2n = a.vec[2][nxt];
+            const Fp w23GD = Fr::mul(Fr::mul(w2, w3), sums[2]);
+            // 14: ws2 w2n S - ws2 w2 GY - w3 GX + w2 w3 w2n GD
+            Fp t14 = Fr::sub(Fr::add(Fr::mul(ws2S, w2n), Fr::mul(w23GD, w2n)), Fr::add(Fr::mul(ws2Y, w2), Fr::mul(w3, sums[0])));
+            // 15: ws2 w4 S + a w2 GX - ws2 w3 GY - w2 w3 w4 GD
+            Fp t15 = Fr::sub(Fr::add(Fr::mul(ws2S, w4), Fr::mul(Fr::mul(a.ea, w2), sums[0])), Fr::add(Fr::mul(ws2Y, w3), Fr::mul(w23GD, w4)));
+            Fp s = Fr::add(Fr::mul(a.ap[12], t14), Fr::mul(a.ap[13], t15));
+            const Fp omq = Fr::sub(one, qecc);
+            // 16, 17: q_ecc ws (1 - ws) + (1 - q_ecc) ws ; 18: q_ecc (1 + ws2)(1 - ws2)
+            s = Fr::add(s, Fr::mul(a.ap[14], Fr::mul(ws0, Fr::add(Fr::mul(qecc, om0), omq))));
+            s = Fr::add(s, Fr::mul(a.ap[15], Fr::mul(ws1, Fr::add(Fr::mul(qecc, om1), omq))));
+            return Fr::add(s, Fr::mul(a.ap[16], Fr::mul(qecc, Fr::mul(Fr::add(one, ws2), Fr::sub(one, ws2)))));
+        }
     }
-    const Fp ws2S = Fr::mul(ws2, S);
-    const Fp ws2SY = Fr::mul(ws2, sums[1]), ws2GY = Fr::mul(ws2, sums[4]);
-    const Fp w01SD = Fr::mul(w0w1, sums[2]), w23GD = Fr::mul(w2w3, sums[5]);
-    // 12: ws2 w0n S - ws2 w0 SY - w1 SX + w0 w1 w0n SD
-    Fp t12 = Fr::sub(Fr::add(Fr::mul(ws2S, w0n), Fr::mul(w01SD, w0n)), Fr::add(Fr::mul(ws2SY, w0), Fr::mul(w1, sums[0])));
-    // 13: ws2 w1n S + a w0 SX - ws2 w1 SY - w0 w1 w1n SD
-    Fp t13 = Fr::sub(Fr::add(Fr::mul(ws2S, w1n), Fr::mul(Fr::mul(a.ea, w0), sums[0])), Fr::add(Fr::mul(ws2SY, w1), Fr::mul(w01SD, w1n)));
-    // 14: ws2 w2n S - ws2 w2 GY - w3 GX + w2 w3 w2n GD
-    Fp t14 = Fr::sub(Fr::add(Fr::mul(ws2S, w2n), Fr::mul(w23GD, w2n)), Fr::add(Fr::mul(ws2GY, w2), Fr::mul(w3, sums[3])));
-    // 15: ws2 w4 S + a w2 GX - ws2 w3 GY - w2 w3 w4 GD
-    Fp t15 = Fr::sub(Fr::add(Fr::mul(ws2S, w4), Fr::mul(Fr::mul(a.ea, w2), sums[3])), Fr::add(Fr::mul(ws2GY, w3), Fr::mul(w23GD, w4)));
-    Fp s = Fr::mul(a.ap[10], t12);
-    s = Fr::add(s, Fr::mul(a.ap[11], t13));
-    s = Fr::add(s, Fr::mul(a.ap[12], t14));
-    s = Fr::add(s, Fr::mul(a.ap[13], t15));
-    const Fp omq = Fr::sub(one, qecc);
-    // 16, 17: q_ecc ws (1 - ws) + (1 - q_ecc) ws ; 18: q_ecc (1 + ws2)(1 - ws2)
-    s = Fr::add(s, Fr::mul(a.ap[14], Fr::mul(ws0, Fr::add(Fr::mul(qecc, om0), omq))));
-    s = Fr::add(s, Fr::mul(a.ap[15], Fr::mul(ws1, Fr::add(Fr::mul(qecc, om1), omq))));
-    s = Fr::add(s, Fr::mul(a.ap[16], Fr::mul(qecc, Fr::mul(Fr::add(one, ws2), Fr::sub(one, ws2)))));
-    return s;
 }
 
 // SHUFFLE = false: the circuit has no shuffle / ECC selectors (uzkge built without the "shuffle" feature, e.g.
@@ -603,26 +603,45 @@ __global__ __launch_bounds__(256) void t_quotient_kernel(QuotientDev a, Fp* __re
     if (point >= a.m) return;
     uint32_t nxt = point + a.factor;
     if (nxt >= a.m) nxt -= a.m;
-    Fp acc = tq_terms_1_to_11(a, point, nxt);
-    if constexpr (SHUFFLE) acc = Fr::add(acc, tq_terms_12_to_18(a, point, nxt));
+    Fp acc = Fr::add(tq_part<0>(a, point, nxt), tq_part<1>(a, point, nxt));
+    if constexpr (SHUFFLE) acc = Fr::add(acc, Fr::add(tq_part<2>(a, point, nxt), tq_part<3>(a, point, nxt)));
     out[point] = Fr::mul(acc, a.zhi[point % a.factor]);
 }
-// The same for shuffle circuits with the two groups of terms on two WAVES of a 128-lane workgroup (64 points each): at the
-// prover's size the loop has only 6n = 98 304 points -- 1.5 waves per SIMD, every lane a chain of ~140 dependent-latency products
-// -- so the kernel is bound by the length of one lane's chain, not by issue slots or HBM; splitting the chain in two roughly
-// equal parts (77 / 60 products) doubles the waves and halves the chain.  Field arithmetic is exact: the sum is the same element.
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void t_quotient_split_kernel(QuotientDev a, Fp* __restrict__ out) {
-    __shared__ Fp part[64];
-    const uint32_t lane = threadIdx.x & 63, half = threadIdx.x >> 6;
+// The same with the groups of terms on the WAVES of a workgroup (64 points per workgroup, NPARTS waves): at the prover's size
+// the loop has only 6n = 98 304 points -- 1.5 waves per SIMD, every lane a chain of ~150 dependent-latency products -- so the
+// kernel is bound by the length of one lane's chain, not by issue slots or HBM; cutting the chain in four parts of 34..43
+// products quadruples the waves (measured at n = 2^14, tools/ab_tq_split.py: 200 us in one piece, 143 us in two, 126 us in four --
+// about 90 % of what 98 304 x 150 products cost in issue slots on the whole chip).  Field arithmetic is exact: the
+// sum is the same element.  NPARTS = 4 with the shuffle-feature terms, 2 without.
+template <int NPARTS, int WPE>
+__global__ __launch_bounds__(64 * NPARTS) __attribute__((amdgpu_waves_per_eu(WPE))) void t_quotient_split_kernel(QuotientDev a, Fp* __restrict__ out) {
+    __shared__ Fp part[NPARTS - 1][64];
+    const uint32_t lane = threadIdx.x & 63, which = threadIdx.x >> 6;
     const uint32_t point = blockIdx.x * 64 + lane;
     const bool live = point < a.m;
     uint32_t nxt = point + a.factor;
     if (nxt >= a.m) nxt -= a.m;
     Fp acc = Fr::zero();
-    if (live) acc = half ? tq_terms_12_to_18(a, point, nxt) : tq_terms_1_to_11(a, point, nxt);
-    if (half) part[lane] = acc;
+    if (live) {
+        if (which == 0) acc = tq_part<0>(a, point, nxt);
+        else if (which == 1) acc = tq_part<1>(a, point, nxt);
+        else if (NPARTS > 2 && which == 2) acc = tq_part<2>(a, point, nxt);
+        else if (NPARTS > 2) acc = tq_part<3>(a, point, nxt);
+    }
+    if (which) part[which - 1][lane] = acc;
     __syncthreads();
-    if (!half && live) out[point] = Fr::mul(Fr::add(acc, part[lane]), a.zhi[point % a.factor]);
+    if (which == 0 && live) {
+#pragma unroll
+        for (int p = 0; p < NPARTS - 1; ++p) acc = Fr::add(acc, part[p][lane]);
+        // 1 / Z_H of this point's coset class, by selects: a dynamic index into the by-value argument block would make the compiler
+        // copy all 1.9 KB of it to scratch in every lane
+        const uint32_t cls = point % a.factor;
+        Fp zhi = a.zhi[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i)
+            if (cls == (uint32_t)i) zhi = a.zhi[i];
+        out[point] = Fr::mul(acc, zhi);
+    }
 }
 
 struct QuotientArgsAbi {      // byte-for-byte uzk_quotient_args (include/uzkge_gpu.h): 8-byte aligned limbs
@@ -668,7 +687,12 @@ int t_quotient_run(Ctx& c, const void* args_c_abi, Fp* d_out) {
     KernelScope ks(c, "t_quotient");
     // small domains (the prover's 6n = 98 304 points): the two term groups on two waves per 64 points; large ones fill the chip
     // with one lane per point
-    if (shuffle_present && c.tune_tq_split && d.m <= (1u << 19)) hipLaunchKernelGGL(t_quotient_split_kernel, dim3((d.m + 63) / 64), dim3(128), 0, c.stream, d, d_out);
+    const bool split = c.tune_tq_split && d.m <= (1u << 19);
+    if (shuffle_present && split) {
+        if (c.tune_tq_split == 3) hipLaunchKernelGGL((t_quotient_split_kernel<4, 3>), dim3((d.m + 63) / 64), dim3(256), 0, c.stream, d, d_out);
+        else hipLaunchKernelGGL((t_quotient_split_kernel<4, 2>), dim3((d.m + 63) / 64), dim3(256), 0, c.stream, d, d_out);
+    }
+    else if (split) hipLaunchKernelGGL((t_quotient_split_kernel<2, 3>), dim3((d.m + 63) / 64), dim3(128), 0, c.stream, d, d_out);
     else if (shuffle_present) hipLaunchKernelGGL(t_quotient_kernel<true>, dim3((d.m + 255) / 256), dim3(256), 0, c.stream, d, d_out);
     else hipLaunchKernelGGL(t_quotient_kernel<false>, dim3((d.m + 255) / 256), dim3(256), 0, c.stream, d, d_out);
     UZK_HIP(hipGetLastError());
