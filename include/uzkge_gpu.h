@@ -74,6 +74,14 @@ int uzk_ctx_set_current(uint64_t ctx);
 /* Frees the context's stream, plans and workspaces; no thread may be inside a call on it.  A thread whose current
  * context has been destroyed (here or by uzk_shutdown) works on the default context from its next call on. */
 int uzk_ctx_destroy(uint64_t ctx);
+/* The calling thread's current context waits -- on the device, the host does not block -- for everything queued so far on
+ * context `other` (0 = the default context).  A prover thread that owns TWO contexts has two lanes, each with its own stream
+ * and workspaces: steps of a proof that do not depend on each other run side by side (the coset FFTs of the wire polynomials
+ * under the commit of the same round, uzkge/src/plonk/prover.rs:160-192 / helpers.rs:256-266; the two batch_prove openings,
+ * prover.rs:349-372), and this call is the dependency edge between the lanes. */
+int uzk_ctx_wait(uint64_t other);
+/* The calling thread's current context (0 = the default one). */
+int uzk_ctx_current(uint64_t* ctx_out);
 
 /* ---- device memory ------------------------------------------------------------------------ */
 /* Everything a host language needs to keep data resident between the *_device entry points: with these it links

@@ -188,7 +188,11 @@ static void worker(uint64_t srs, int reps, bool write_outputs, bool own_context,
         CK(uzk_ntt_fr_batch_strided_device(d_z, n, d_coefs + 9 * m, m, n, 1, 1, nullptr, 0));
         CK(uzk_hide_polynomial_batch_device(d_coefs + 9 * m, m, n, 1, blinds_z[0].l, 3, n));
         CK(uzk_msm_g1_batch_tail_device(srs, 0, d_z, n, n, 1, tail_z.data(), 6, 0, cm_z));
-        // ---- round 3
+        // ---- round 3.  (Measured and not done: a second context as a side lane -- uzk_ctx_wait is the edge -- for the nine coset
+        // FFTs that need only round 1's coefficients, under round 1's commit: that commit is eight vectors wide and fills the
+        // issue slots itself, the chain gains nothing (2.08 ms either way) and four provers sharing the GPU lose 18 %
+        // (857 -> 702 proofs/s); for the opening at zeta * omega beside r(X) and the opening at zeta: 2.097 -> 2.082 ms, not worth
+        // a second stream per prover.)
         CK(uzk_ntt_fr_batch_device(d_coefs, d_coset, m, 10, 0, k[1].l, 0));
         uzk_quotient_args qa;
         std::memset(&qa, 0, sizeof qa);
@@ -298,6 +302,17 @@ int main(int argc, char** argv) {
     const int threads = argc > 3 ? std::atoi(argv[3]) : 1;
     setenv("GPU_MAX_HW_QUEUES", "16", /*overwrite*/ 0);   // one stream per prover thread; before the process's first HIP call
     CK(uzk_init(0));
+    if (const char* t = std::getenv("UZK_TUNE")) {        // "key=value[,key=value]": experiment switches for A/B runs (contexts inherit them)
+        std::string all(t);
+        size_t pos = 0;
+        while (pos < all.size()) {
+            const size_t end = all.find(',', pos) == std::string::npos ? all.size() : all.find(',', pos);
+            const std::string kv = all.substr(pos, end - pos);
+            const size_t eq = kv.find('=');
+            if (eq != std::string::npos) CK(uzk_tune(kv.substr(0, eq).c_str(), std::atoi(kv.c_str() + eq + 1)));
+            pos = end + 1;
+        }
+    }
     const auto meta = rd<uint64_t>("meta");
     const auto bases = rd<uzk_g1_affine>("bases");                // n + 6 points
     uint64_t srs = 0;

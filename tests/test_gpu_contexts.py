@@ -122,3 +122,35 @@ def test_new_contexts_inherit_the_creators_tuning(gpu):
         gpu.ctx_set_current(0)
         gpu.set_msm_window_bits(0)
         gpu.ctx_destroy(h)
+
+
+def test_ctx_wait_orders_two_contexts_of_one_thread(gpu):
+    """uzk_ctx_wait: a thread that owns two contexts (two streams, two workspace sets) makes one wait, on the device, for what
+    the other has queued.  Context B transforms a vector context A is still producing: without the edge B would read it too
+    early; with it the result is the oracle's.  uzk_ctx_current names the thread's context."""
+    from uzkge_amd import UzkgeError
+    n, batch = 1 << 14, 24
+    x = np.stack([rand_fr_wire(n, 700 + i) for i in range(batch)])
+    d_x, d_y, d_z = gpu.dev_alloc(batch * n * 32), gpu.dev_alloc(batch * n * 32), gpu.dev_alloc(batch * n * 32)
+    a = gpu.ctx_current()
+    assert a == 0
+    h = gpu.ctx_create()
+    try:
+        gpu.dev_upload(d_x, x)
+        for rep in range(3):
+            gpu.ntt_batch_device(d_x, d_y, n, batch)               # context A: asynchronous
+            gpu.ctx_set_current(h)
+            assert gpu.ctx_current() == h
+            gpu.ctx_wait(a)                                        # B: after everything A has queued
+            gpu.ntt_batch_device(d_y, d_z, n, batch, inverse=True, sync=True)
+            assert np.array_equal(gpu.dev_download(d_z, (batch, n, 4)), x), rep
+            gpu.ctx_set_current(a)
+            gpu.ctx_wait(h)                                        # and back: A may overwrite d_y only after B has read it
+        gpu.ctx_wait(a)                                            # waiting for oneself is a no-op
+        with pytest.raises(UzkgeError):
+            gpu.ctx_wait(987654)
+    finally:
+        gpu.ctx_set_current(0)
+        gpu.ctx_destroy(h)
+        for p in (d_x, d_y, d_z):
+            gpu.dev_free(p)

@@ -28,6 +28,8 @@ PROTOTYPES = {
     "uzk_ctx_create": (_I, [ctypes.POINTER(_U64)]),
     "uzk_ctx_set_current": (_I, [_U64]),
     "uzk_ctx_destroy": (_I, [_U64]),
+    "uzk_ctx_wait": (_I, [_U64]),
+    "uzk_ctx_current": (_I, [ctypes.POINTER(_U64)]),
     "uzk_dev_alloc": (_I, [_SZ, ctypes.POINTER(_P)]),
     "uzk_dev_free": (_I, [_P]),
     "uzk_host_alloc": (_I, [_SZ, ctypes.POINTER(_P)]),

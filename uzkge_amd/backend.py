@@ -51,6 +51,17 @@ def ctx_destroy(ctx: int) -> None:
     check(lib.uzk_ctx_destroy(ctx))
 
 
+def ctx_current() -> int:
+    h = ctypes.c_uint64(0)
+    check(lib.uzk_ctx_current(ctypes.byref(h)))
+    return h.value
+
+
+def ctx_wait(other: int) -> None:
+    """The calling thread's current context waits on the device for everything queued so far on context `other`."""
+    check(lib.uzk_ctx_wait(other))
+
+
 class Srs:
     """Device-resident SRS (static bases of KZG commit)."""
 

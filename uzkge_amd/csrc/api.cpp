@@ -325,6 +325,39 @@ int uzk_ctx_destroy(uint64_t handle) {
     return UZK_OK;
 }
 
+int uzk_ctx_current(uint64_t* ctx_out) {
+    if (!ctx_out) { set_error("uzk_ctx_current: null pointer"); return UZK_ERR_PARAMETER; }
+    (void)ctx();                                         // a handle whose context is gone resolves to the default context here
+    *ctx_out = t_handle;
+    return UZK_OK;
+}
+// The calling thread's current context waits (on the device: no host synchronisation) for everything queued so far on
+// `other`.  Two contexts in one prover thread are two lanes with their own stream and workspaces: independent steps of a
+// proof -- the coset FFTs of the wire polynomials and the commit of the same round, the two openings -- run side by side,
+// and this is the edge between them.
+int uzk_ctx_wait(uint64_t other) {
+    Ctx* cur = &ctx();
+    Ctx* oth = nullptr;
+    if (other == 0) oth = &default_ctx();
+    else {
+        Shared& s = shared();
+        std::lock_guard<std::mutex> lk(s.mu);
+        auto it = s.contexts.find(other);
+        if (it == s.contexts.end()) { set_error("uzk_ctx_wait: unknown context %llu", (unsigned long long)other); return UZK_ERR_PARAMETER; }
+        oth = it->second;
+    }
+    if (oth == cur) return UZK_OK;
+    std::unique_lock<std::mutex> l1(cur->mu, std::defer_lock), l2(oth->mu, std::defer_lock);
+    std::lock(l1, l2);                                   // both locks, in whatever order avoids a deadlock with a thread waiting the other way
+    UZK_TRY(require_ready());
+    if (!oth->ready) return UZK_OK;                      // nothing was ever queued there
+    hipEvent_t ev = oth->get_event();
+    UZK_HIP(hipEventRecord(ev, oth->stream));
+    UZK_HIP(hipStreamWaitEvent(cur->stream, ev, 0));
+    oth->event_pool.push_back(ev);                       // the wait has captured this recording; a later re-record does not move it
+    return UZK_OK;
+}
+
 /* ---- device memory ----------------------------------------------------------------------------
  * What a host language needs to keep data resident between the *_device entry points without linking the HIP runtime
  * itself.  Copies and fills are ordered on the calling context's stream, i.e. with that context's kernels. */
