@@ -792,34 +792,32 @@ __global__ __launch_bounds__(256) void open_div_block_kernel(const Fp* __restric
     if (tid == 0) block_first[blockIdx.x] = sh[0];
 }
 // carries between blocks (nblocks <= 256): c_b = sum_{b' > b} first[b'] z^(4096 (b' - b - 1)); zb[k] = z^(4096 * 2^k)
-// Also leaves ztab[t] = (z^PER)^t, t <= 256, for the apply kernel: built in LDS by doubling with the multipliers
-// pw.zp[k] = z^(PER 2^k) the block kernel already uses (no host table, no upload, no synchronisation).
-__global__ __launch_bounds__(256) void open_div_carry_kernel(const Fp* __restrict__ block_first, uint32_t nblocks, DivPows pw, DivPows pb,
+// Also leaves ztab[t] = (z^PER)^t, t <= 256, for the apply kernel (no host table, no upload, no synchronisation): the lower 256
+// lanes run the carry scan, the upper 256 build the table in LDS by doubling with the multipliers pw.zp[k] = z^(PER 2^k) --
+// two independent chains of eight dependent products side by side.
+__global__ __launch_bounds__(512) void open_div_carry_kernel(const Fp* __restrict__ block_first, uint32_t nblocks, DivPows pw, DivPows pb,
                                                              Fp* __restrict__ carry, Fp* __restrict__ ztab) {
-    __shared__ Fp sh[256];
-    const uint32_t tid = threadIdx.x;
-    if (tid == 0) sh[0] = Fr::one();
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const uint32_t half = 1u << k;
-        if (tid < half) sh[half + tid] = Fr::mul(sh[tid], pw.zp[k]);
-        __syncthreads();
-    }
-    ztab[tid] = sh[tid];
-    if (tid == 0) ztab[256] = pb.zp[0];                 // z^(256 PER)
-    __syncthreads();
-    sh[tid] = tid < nblocks ? block_first[tid] : Fr::zero();
+    __shared__ Fp sh[256], zt[256];
+    const uint32_t t = threadIdx.x & 255;
+    const bool table = threadIdx.x >= 256;
+    if (!table) sh[t] = t < nblocks ? block_first[t] : Fr::zero();
+    else if (t == 0) zt[0] = Fr::one();
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const uint32_t off = 1u << k;
-        Fp t = (tid + off < 256) ? sh[tid + off] : Fr::zero();
+        Fp x = Fr::zero();
+        if (!table && t + off < 256) x = sh[t + off];
         __syncthreads();
-        if (tid + off < 256) sh[tid] = Fr::add(sh[tid], Fr::mul(pb.zp[k], t));
+        if (!table) { if (t + off < 256) sh[t] = Fr::add(sh[t], Fr::mul(pb.zp[k], x)); }
+        else if (t < off) zt[off + t] = Fr::mul(zt[t], pw.zp[k]);
         __syncthreads();
     }
-    if (tid < nblocks) carry[tid] = (tid + 1 < 256) ? sh[tid + 1] : Fr::zero();
+    if (!table) { if (t < nblocks) carry[t] = (t + 1 < 256) ? sh[t + 1] : Fr::zero(); }
+    else {
+        ztab[t] = zt[t];
+        if (t == 0) ztab[256] = pb.zp[0];               // z^(256 PER)
+    }
 }
 // q[i-1] = s_i + z^(block_hi - i) carry[block]  for 1 <= i < n ;  q[n-1 .. q_cap) = 0 ; ztab16[t] = z^(PER t), t <= 256
 template <int kDivPer>
@@ -900,7 +898,7 @@ int open_quotient_ptrs(Ctx& c, const void* const* d_polys, const uint64_t* lens,
     }
     if (per == 4) hipLaunchKernelGGL(open_div_block_kernel<4>, dim3(nblocks), dim3(256), 0, c.stream, d_h, n, pw, d_s, d_first);
     else hipLaunchKernelGGL(open_div_block_kernel<16>, dim3(nblocks), dim3(256), 0, c.stream, d_h, n, pw, d_s, d_first);
-    hipLaunchKernelGGL(open_div_carry_kernel, dim3(1), dim3(256), 0, c.stream, d_first, nblocks, pw, pb, d_carry, d_ztab);
+    hipLaunchKernelGGL(open_div_carry_kernel, dim3(1), dim3(512), 0, c.stream, d_first, nblocks, pw, pb, d_carry, d_ztab);
     if (per == 4) hipLaunchKernelGGL(open_div_apply_kernel<4>, dim3((unsigned)((q_cap + 255) / 256)), dim3(256), 0, c.stream, d_s, d_carry, d_ztab, z, n, q_cap, d_q);
     else hipLaunchKernelGGL(open_div_apply_kernel<16>, dim3((unsigned)((q_cap + 255) / 256)), dim3(256), 0, c.stream, d_s, d_carry, d_ztab, z, n, q_cap, d_q);
     UZK_HIP(hipGetLastError());
