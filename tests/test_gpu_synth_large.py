@@ -198,3 +198,41 @@ def test_point_chunk_loop_small(gpu):
     finally:
         srs.release()
     assert chunked == one == affine_of(oc.msm_pippenger(wire[:3000], s, 0, 2))
+
+
+@pytest.mark.parametrize("cfg,chunk", [(1, 1), (10, 1), (13, 1), (15, 1), (0, 1), (1, 0), (0, 0)])
+def test_segment_sort_skewed_segments(gpu, cfg, chunk):
+    """The one-workgroup-per-segment last sort pass (msm_radix_segment_kernel) next to the generic kernels it leaves the
+    long segments to: 2^20 points whose scalars are uniform except for runs that put (a) 40000 entries into one bucket
+    (longer than any instantiation holds: the generic path), (b) 30000 into one bucket (fits the registers of the largest
+    instantiation but not its LDS buffer: written directly), (c) 2 x 12500 into two buckets of one segment (two LDS
+    rounds), (d) 3000 into one bucket (beyond the small instantiations).  Every instantiation forced in turn (10 + k),
+    the automatic choice (1) and the generic path alone (0) give the closed-form result.  The same runs reach the first
+    pass's one-workgroup-per-chunk kernel (msm_radix_chunk_kernel; `chunk` = 0: the generic tile scatter): run (a) fills
+    one bin of chunk 0 beyond the LDS buffer (direct writes), the uniform rest goes out in rounds of whole bins."""
+    n = 1 << 20
+    pts = torch.empty((n, 8), dtype=torch.int64, device="cuda")
+    sc = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    seed_int = 0x5E65047
+    gpu.synth_points_arith(pts.data_ptr(), n, oc.fr_from_ints([seed_int])[0])
+    gpu.synth_scalars(sc.data_ptr(), n, 777)
+    host = sc.cpu().numpy().view(np.uint64).reshape(-1, 4).copy()
+    vals = oc.fr_from_ints([0x1234, 0x7ABC, 0x7ABD + 0x100, 0x7ABD + 0x101, opy.R - 0x2222])
+    at = 1000
+    for v, cnt in ((0, 40000), (1, 30000), (2, 12500), (3, 12500), (4, 3000)):
+        host[at:at + cnt] = vals[v]
+        at += cnt + 17
+    sc.copy_(torch.from_numpy(host.view(np.int64)).reshape(n, 4))
+    torch.cuda.synchronize()
+    srs = gpu.Srs.from_device(pts.data_ptr(), n)
+    gpu.tune("msm_seg_sort", cfg)
+    gpu.tune("msm_chunk_sort", chunk)
+    try:
+        got = affine_of(gpu.msm_device(srs, sc.data_ptr(), n))
+    finally:
+        gpu.tune("msm_seg_sort", 1)
+        gpu.tune("msm_chunk_sort", 1)
+        srs.release()
+    k = weighted_index_sum(host)
+    assert got == opy.g1_mul(opy.g1_mul(opy.G1_GEN, seed_int), k)

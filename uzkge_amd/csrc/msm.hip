@@ -27,6 +27,7 @@
 //                larger c, ~25 % fewer additions, no per-window reduction and no host Horner.
 // No MFMA anywhere: the work is 254-bit modular integer arithmetic on v_mad_u64_u32.
 #include <algorithm>
+#include <cmath>
 #include <mutex>
 #include <functional>
 #include <memory>
@@ -168,8 +169,9 @@ struct RadixArgs {
     const uint32_t* item_off;    // else: work items (fixed-size chunks) of segment s are item_off[s] .. item_off[s+1]
     uint32_t nseg, chunk;        // else: number of segments, entries per work item
     uint32_t shift, mask, bins;  // bin = (key >> shift) & mask
-    uint32_t* counts;            // pass 0: [seg][chunk][bins], later passes: [item][bins]
-                                 // (hist: counts, after scan: exclusive chunk prefixes)
+    uint32_t* counts;            // pass 0: [seg][chunk][bins], later passes: [item][bins]  (written by the histogram)
+    uint32_t* prefix;            // same shape: the scan's exclusive chunk prefixes, read by the scatter (= counts when one
+                                 // workgroup scans a segment; a second array when several do, which re-read the counts)
     uint32_t* bin_base;          // [seg][bins] absolute output start of each bin
     uint32_t* bin_count;         // [seg][bins]
     uint2* out_entries;          // !OUT_VAL
@@ -178,6 +180,8 @@ struct RadixArgs {
     // key bits above the point index and its sign,  e = key_low << (idx_bits + 1) | sign << idx_bits | idx.
     // 0 = 8-byte {key, val} entries.
     uint32_t pk_in_bits, pk_out_bits;   // idx_bits of the input / output entry format (0 = unpacked)
+    uint32_t seg_min_len;               // later passes: only segments LONGER than this are this path's (0 = all): the rest went to
+                                        // msm_radix_segment_kernel
 };
 __device__ __forceinline__ uint32_t pk_key(uint32_t e, uint32_t idx_bits) { return e >> (idx_bits + 1); }
 __device__ __forceinline__ uint32_t pk_val(uint32_t e, uint32_t idx_bits) {
@@ -192,7 +196,7 @@ __device__ __forceinline__ uint32_t pk_make(uint32_t key_low, uint32_t val, uint
 // dependent (a skewed scalar set can put every entry into one segment), so the work is a 1-D list
 // of fixed-size items built from the actual lengths; workgroups past the end of the list leave.
 template <bool FROM_DIGITS>
-__device__ __forceinline__ bool radix_work(const RadixArgs& a, uint32_t& seg, size_t& cidx, uint32_t& base,
+__device__ __forceinline__ bool radix_work(const RadixArgs& a, uint32_t item, uint32_t& seg, size_t& cidx, uint32_t& base,
                                            uint32_t& lo, uint32_t& hi) {
     if constexpr (FROM_DIGITS) {
         const uint32_t ch = blockIdx.x, nch = gridDim.x;
@@ -204,7 +208,6 @@ __device__ __forceinline__ bool radix_work(const RadixArgs& a, uint32_t& seg, si
         hi = min(a.n, lo + cs);
         return true;
     } else {
-        const uint32_t item = blockIdx.x;
         if (item >= a.item_off[a.nseg]) return false;
         uint32_t l = 0, h = a.nseg;            // largest s with item_off[s] <= item (skips empty segments)
         while (h - l > 1) {
@@ -247,45 +250,69 @@ __device__ __forceinline__ bool radix_load(const RadixArgs& a, uint32_t seg, uin
 template <bool FROM_DIGITS, bool PK_IN>
 __global__ __launch_bounds__(1024) void msm_radix_hist_kernel(RadixArgs a) {
     __shared__ uint32_t cnt[512];
-    uint32_t seg, base, lo, hi;
-    size_t cidx;
-    if (!radix_work<FROM_DIGITS>(a, seg, cidx, base, lo, hi)) return;
-    for (uint32_t b = threadIdx.x; b < a.bins; b += blockDim.x) cnt[b] = 0;
-    __syncthreads();
-    for (uint32_t k = lo + threadIdx.x; k < hi; k += blockDim.x) {
-        if constexpr (FROM_DIGITS) {
-            const uint32_t mag = a.digits[(size_t)seg * a.n + k] & ~kSignBit;
-            if (mag) atomicAdd(&cnt[((mag - 1) >> a.shift) & a.mask], 1u);
-        } else if constexpr (PK_IN) {
-            const uint32_t e = reinterpret_cast<const uint32_t*>(a.in_entries)[(size_t)base + k];
-            atomicAdd(&cnt[(pk_key(e, a.pk_in_bits) >> a.shift) & a.mask], 1u);
-        } else {
-            atomicAdd(&cnt[(a.in_entries[(size_t)base + k].x >> a.shift) & a.mask], 1u);
+    // later passes: the grid strides over the work items (their number is data dependent; the launch is sized for the chip)
+    for (uint32_t item = blockIdx.x;; item += gridDim.x) {
+        uint32_t seg, base, lo, hi;
+        size_t cidx;
+        if (!radix_work<FROM_DIGITS>(a, item, seg, cidx, base, lo, hi)) return;
+        for (uint32_t b = threadIdx.x; b < a.bins; b += blockDim.x) cnt[b] = 0;
+        __syncthreads();
+        for (uint32_t k = lo + threadIdx.x; k < hi; k += blockDim.x) {
+            if constexpr (FROM_DIGITS) {
+                const uint32_t mag = a.digits[(size_t)seg * a.n + k] & ~kSignBit;
+                if (mag) atomicAdd(&cnt[((mag - 1) >> a.shift) & a.mask], 1u);
+            } else if constexpr (PK_IN) {
+                const uint32_t e = reinterpret_cast<const uint32_t*>(a.in_entries)[(size_t)base + k];
+                atomicAdd(&cnt[(pk_key(e, a.pk_in_bits) >> a.shift) & a.mask], 1u);
+            } else {
+                atomicAdd(&cnt[(a.in_entries[(size_t)base + k].x >> a.shift) & a.mask], 1u);
+            }
         }
+        __syncthreads();
+        uint32_t* dst = a.counts + cidx;
+        for (uint32_t b = threadIdx.x; b < a.bins; b += blockDim.x) dst[b] = cnt[b];
+        if constexpr (FROM_DIGITS) return;
+        __syncthreads();
     }
-    __syncthreads();
-    uint32_t* dst = a.counts + cidx;
-    for (uint32_t b = threadIdx.x; b < a.bins; b += blockDim.x) dst[b] = cnt[b];
 }
 
-// grid (nseg), block 512: chunk prefixes per bin, bin totals, exclusive scan over bins.
+// grid (nseg, G), block 512: chunk prefixes per bin, bin totals, exclusive scan over bins.
 // Absolute output start of the segment = out_start_of[seg] (or seg * out_stride when null).
+// The chunk walk is a chain of dependent read-modify-writes per bin (512 chunks at n = 2^24: 170 us for the first pass's
+// 15 workgroups); with G > 1 workgroup g of a segment walks only the chunks [g, g + 1) * nch / G, after summing the counts of
+// the chunks before them (independent loads, read again rather than waited for), and the last one, which then holds the bin
+// totals, writes the bin tables.
 __global__ __launch_bounds__(512) void msm_radix_scan_kernel(RadixArgs a, uint32_t nch, const uint32_t* __restrict__ out_start_of,
                                                              uint32_t out_stride) {
     __shared__ uint32_t wsum[8];
-    const uint32_t seg = blockIdx.x, b = threadIdx.x;
+    const uint32_t seg = blockIdx.x, b = threadIdx.x, G = gridDim.y, g = blockIdx.y;
+    if (a.seg_min_len && a.seg_len[seg] <= a.seg_min_len) return;   // msm_radix_segment_kernel wrote this segment's tables
     uint32_t run = 0;
     if (b < a.bins) {
         size_t first = (size_t)seg * nch;
         uint32_t cnt = nch;
         if (a.item_off) { first = a.item_off[seg]; cnt = a.item_off[seg + 1] - a.item_off[seg]; }
-        for (uint32_t ch = 0; ch < cnt; ++ch) {
-            uint32_t* p = a.counts + (first + ch) * a.bins + b;
-            const uint32_t v = *p;
-            *p = run;
+        const uint32_t per = (cnt + G - 1) / G;
+        const uint32_t c0 = min(cnt, g * per), c1 = min(cnt, c0 + per);
+        const uint32_t* p0 = a.counts + first * a.bins + b;
+        uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+        uint32_t ch = 0;
+        for (; ch + 4 <= c0; ch += 4) {
+            r0 += p0[(size_t)ch * a.bins];
+            r1 += p0[(size_t)(ch + 1) * a.bins];
+            r2 += p0[(size_t)(ch + 2) * a.bins];
+            r3 += p0[(size_t)(ch + 3) * a.bins];
+        }
+        for (; ch < c0; ++ch) r0 += p0[(size_t)ch * a.bins];
+        run = r0 + r1 + r2 + r3;
+        for (ch = c0; ch < c1; ++ch) {
+            const size_t at = (first + ch) * a.bins + b;
+            const uint32_t v = a.counts[at];
+            a.prefix[at] = run;
             run += v;
         }
     }
+    if (g + 1 != G) return;                       // the last workgroup's `run` is the bin total
     uint32_t incl = run;
     for (int o = 1; o < 64; o <<= 1) {
         const uint32_t t = __shfl_up((int)incl, o);
@@ -305,13 +332,15 @@ __global__ __launch_bounds__(512) void msm_radix_scan_kernel(RadixArgs a, uint32
 
 // item_off[s] = sum_{t < s} ceil(seg_len[t] / chunk), item_off[nseg] = total  (one workgroup)
 __global__ __launch_bounds__(1024) void msm_radix_items_kernel(const uint32_t* __restrict__ seg_len, uint32_t nseg,
-                                                               uint32_t chunk, uint32_t* __restrict__ item_off) {
+                                                               uint32_t chunk, uint32_t* __restrict__ item_off, uint32_t min_len) {
     __shared__ uint32_t part[1024];
     const uint32_t tid = threadIdx.x;
     const uint32_t per = (nseg + 1023) / 1024;
     const uint32_t lo = min(nseg, tid * per), hi = min(nseg, lo + per);
     uint32_t s = 0;
-    for (uint32_t k = lo; k < hi; ++k) s += (seg_len[k] + chunk - 1) / chunk;
+    // segments of <= min_len entries belong to msm_radix_segment_kernel: no items
+    auto items_of = [&](uint32_t k) { const uint32_t l = seg_len[k]; return l > min_len ? (l + chunk - 1) / chunk : 0u; };
+    for (uint32_t k = lo; k < hi; ++k) s += items_of(k);
     part[tid] = s;
     __syncthreads();
     for (uint32_t off = 1; off < 1024; off <<= 1) {
@@ -321,7 +350,7 @@ __global__ __launch_bounds__(1024) void msm_radix_items_kernel(const uint32_t* _
         __syncthreads();
     }
     uint32_t run = part[tid] - s;
-    for (uint32_t k = lo; k < hi; ++k) { item_off[k] = run; run += (seg_len[k] + chunk - 1) / chunk; }
+    for (uint32_t k = lo; k < hi; ++k) { item_off[k] = run; run += items_of(k); }
     if (tid == 1023) item_off[nseg] = part[1023];
 }
 
@@ -332,10 +361,11 @@ __global__ __launch_bounds__(TB) void msm_radix_scatter_kernel(RadixArgs a) {
     __shared__ uint2 buf[TILE];
     __shared__ uint32_t tcnt[512], toff[512], gcur[512], wsum[16];
     const uint32_t tid = threadIdx.x;
+    for (uint32_t item = blockIdx.x;; item += gridDim.x) {   // later passes: grid-stride over the work items
     uint32_t seg, base, lo, hi;
     size_t cidx;
-    if (!radix_work<FROM_DIGITS>(a, seg, cidx, base, lo, hi)) return;
-    const uint32_t* coff = a.counts + cidx;
+    if (!radix_work<FROM_DIGITS>(a, item, seg, cidx, base, lo, hi)) return;
+    const uint32_t* coff = a.prefix + cidx;
     for (uint32_t b = tid; b < a.bins; b += TB) gcur[b] = a.bin_base[(size_t)seg * a.bins + b] + coff[b];
     for (uint32_t t0 = lo; t0 < hi; t0 += TILE) {
         for (uint32_t b = tid; b < a.bins; b += TB) tcnt[b] = 0;
@@ -391,6 +421,8 @@ __global__ __launch_bounds__(TB) void msm_radix_scatter_kernel(RadixArgs a) {
         for (uint32_t b = tid; b < a.bins; b += TB) gcur[b] += tcnt[b];
         __syncthreads();
     }
+    if constexpr (FROM_DIGITS) return;
+    }
 }
 
 // EXPERIMENT (uzk_tune("msm_scatter4", 1); off by default -- a negative result, profiles/r03_ab_scatter4.txt): the same scatter for
@@ -407,10 +439,11 @@ __global__ __launch_bounds__(TB) void msm_radix_scatter4_kernel(RadixArgs a) {
     __shared__ uint16_t bbuf[TILE];
     __shared__ uint32_t tcnt[512], toff[512], gcur[512], wsum[16];
     const uint32_t tid = threadIdx.x;
+    for (uint32_t item = blockIdx.x;; item += gridDim.x) {   // later passes: grid-stride over the work items
     uint32_t seg, base, lo, hi;
     size_t cidx;
-    if (!radix_work<FROM_DIGITS>(a, seg, cidx, base, lo, hi)) return;
-    const uint32_t* coff = a.counts + cidx;
+    if (!radix_work<FROM_DIGITS>(a, item, seg, cidx, base, lo, hi)) return;
+    const uint32_t* coff = a.prefix + cidx;
     for (uint32_t b = tid; b < a.bins; b += TB) gcur[b] = a.bin_base[(size_t)seg * a.bins + b] + coff[b];
     uint32_t* out = OUT_VAL ? a.out_vals : reinterpret_cast<uint32_t*>(a.out_entries);
     const uint32_t low_mask = (1u << a.shift) - 1;
@@ -463,6 +496,191 @@ __global__ __launch_bounds__(TB) void msm_radix_scatter4_kernel(RadixArgs a) {
         __syncthreads();
         for (uint32_t k = tid; k < total; k += TB) out[toff[bbuf[k]] + k] = ebuf[k];
         __syncthreads();
+    }
+    if constexpr (FROM_DIGITS) return;
+    }
+}
+
+// Last pass of a packed two-pass sort, ONE workgroup per segment (round 3).  After the first pass a segment -- the entries of
+// one window that share the key's high bits -- is n / 512 entries long (32768 at n = 2^24): short enough to sit in one
+// workgroup's registers (E entries per lane).  The workgroup then does the whole pass by itself: histogram of the low key bits
+// (LDS atomics), exclusive scan, the bucket tables (start / population of every bucket of the segment), and the scatter
+// through an LDS buffer that leaves as ONE contiguous run of full lines.  Compared with the generic pass this drops the separate
+// histogram kernel (a second read of every entry), the per-chunk counter arrays and their scan, the work-item list, and the
+// 32-byte partial-line writes of the 4096-entry tiles.  The LDS buffer may be smaller than the segment: the buckets are then
+// written in rounds of whole bins (two workgroups per CU at n = 2^24, so one's loads run under the other's LDS phase); a single
+// bin larger than the buffer (heavily skewed scalars) is written directly, its order being irrelevant.
+// Segments longer than TB * E entries are left alone: the generic kernels behind this launch take exactly those
+// (RadixArgs::seg_min_len), so skewed inputs keep their load-balanced path.
+template <int TB, int E, int BUFN>
+__global__ __launch_bounds__(TB, TB >= 512 ? 4 : 2) void msm_radix_segment_kernel(RadixArgs a) {   // 512 lanes: two workgroups per CU
+    constexpr uint32_t CAP = (uint32_t)TB * E;
+    constexpr int MAXBINS = 512;
+    __shared__ uint32_t buf[BUFN];
+    __shared__ uint32_t cnt[MAXBINS], off[MAXBINS + 1], cur[MAXBINS], wsum[8];
+    const uint32_t seg = blockIdx.x, tid = threadIdx.x;
+    const uint32_t len = a.seg_len[seg];
+    if (len > CAP) return;                               // the generic path owns this segment
+    const uint32_t start = a.seg_start[seg];
+    const uint32_t bins = a.bins;
+    for (uint32_t b = tid; b < bins; b += TB) cnt[b] = 0;
+    __syncthreads();
+    const uint32_t* __restrict__ in = reinterpret_cast<const uint32_t*>(a.in_entries) + start;
+    uint32_t e[E];
+    // entry i of this lane is k = tid + i * TB; it exists for i < mine (one compare per use instead of E kept predicates)
+    const int mine = tid < len ? (int)((len - tid + TB - 1) / TB) : 0;
+#pragma unroll
+    for (int i = 0; i < E; ++i) e[i] = i < mine ? in[tid + (uint32_t)i * TB] : 0u;
+#pragma unroll
+    for (int i = 0; i < E; ++i)
+        if (i < mine) atomicAdd(&cnt[(pk_key(e[i], a.pk_in_bits) >> a.shift) & a.mask], 1u);
+    __syncthreads();
+    {   // exclusive scan of cnt[0..bins) -> off, off[bins] = len
+        const uint32_t ngroups = (bins + 63) / 64, lane = tid & 63;
+        for (uint32_t g = tid >> 6; g < ngroups; g += TB / 64) {
+            const uint32_t b = g * 64 + lane;
+            const uint32_t v = (b < bins) ? cnt[b] : 0;
+            uint32_t incl = v;
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = __shfl_up((int)incl, o);
+                if ((int)lane >= o) incl += t;
+            }
+            if (b < bins) off[b] = incl - v;
+            if (lane == 63) wsum[g] = incl;
+        }
+        __syncthreads();
+        for (uint32_t b = tid; b < bins; b += TB) {
+            uint32_t pre = 0;
+            for (uint32_t g = 0; g < (b >> 6); ++g) pre += wsum[g];
+            const uint32_t o = off[b] + pre;
+            off[b] = o;
+            cur[b] = o;
+            a.bin_base[(size_t)seg * bins + b] = start + o;
+            a.bin_count[(size_t)seg * bins + b] = cnt[b];
+        }
+        if (tid == 0) off[bins] = len;
+        __syncthreads();
+    }
+    uint32_t* __restrict__ out = a.out_vals + start;
+    uint32_t b_lo = 0;
+    while (b_lo < bins) {
+        // this round: bins [b_lo, b_hi), as many as the buffer holds; a single bin beyond the buffer goes out directly
+        const uint32_t base = off[b_lo];
+        uint32_t l = b_lo, h = bins + 1;                 // largest b_hi with off[b_hi] - base <= BUFN
+        while (h - l > 1) {
+            const uint32_t mid = (l + h) >> 1;
+            if (off[mid] - base <= (uint32_t)BUFN) l = mid; else h = mid;
+        }
+        const bool direct = (l == b_lo);
+        const uint32_t b_hi = direct ? b_lo + 1 : l;
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            // (opaque to the optimiser: the bin is recomputed from the entry here, two shifts, rather than kept in a
+            // register per entry from the histogram loop -- E = 72 entries are all the registers two workgroups per CU leave)
+            asm volatile("" : "+v"(e[i]));
+            const uint32_t bin = (pk_key(e[i], a.pk_in_bits) >> a.shift) & a.mask;
+            if (i < mine && bin >= b_lo && bin < b_hi) {
+                const uint32_t pos = atomicAdd(&cur[bin], 1u);
+                const uint32_t val = pk_val(e[i], a.pk_in_bits);
+                if (direct) out[pos] = val; else buf[pos - base] = val;
+            }
+        }
+        __syncthreads();
+        if (!direct) {
+            const uint32_t total = off[b_hi] - base;
+            for (uint32_t k = tid; k < total; k += TB) out[base + k] = buf[k];
+            __syncthreads();
+        }
+        b_lo = b_hi;
+    }
+}
+
+// First pass of a packed two-pass sort with the same shape: ONE workgroup takes its whole chunk of a window's digits (<= TB * E,
+// 32768 for the large sorts) into registers.  The chunk's bin populations are already known (the histogram pass, fused into the
+// digit kernel at large n) and so are the bins' destinations (the scan), so the only LDS atomic is the one that hands out the
+// position inside the bin; the packed entries leave through the LDS buffer in rounds of whole bins, every bin as ONE run of
+// 64 entries on average (two full lines) instead of the 8-entry runs of a 4096-entry tile (1.85x write traffic at 2^24,
+// rocprofv3 WRITE_SIZE), copied out by half-waves.  grid (chunks, segments) as for the generic scatter.
+template <int TB, int E, int BUFN>
+__global__ __launch_bounds__(TB, 4) void msm_radix_chunk_kernel(RadixArgs a) {
+    constexpr int MAXBINS = 512;
+    __shared__ uint32_t buf[BUFN];
+    __shared__ uint32_t cnt[MAXBINS], off[MAXBINS + 1], cur[MAXBINS], gdst[MAXBINS], wsum[8];
+    const uint32_t ch = blockIdx.x, nch = gridDim.x, seg = blockIdx.y, tid = threadIdx.x;
+    const uint32_t bins = a.bins;
+    const size_t cidx = ((size_t)seg * nch + ch) * bins;
+    const uint32_t cs = (a.n + nch - 1) / nch;
+    const uint32_t lo = min(a.n, ch * cs), hi = min(a.n, lo + cs), len = hi - lo;       // len <= TB * E (host)
+    for (uint32_t b = tid; b < bins; b += TB) {
+        cnt[b] = a.counts[cidx + b];
+        gdst[b] = a.bin_base[(size_t)seg * bins + b] + a.prefix[cidx + b];
+    }
+    const uint32_t* __restrict__ in = a.digits + (size_t)seg * a.n + lo;
+    uint32_t d[E];
+    const int mine = tid < len ? (int)((len - tid + TB - 1) / TB) : 0;
+#pragma unroll
+    for (int i = 0; i < E; ++i) d[i] = i < mine ? in[tid + (uint32_t)i * TB] : 0u;       // a zero digit is dropped
+    __syncthreads();
+    {   // exclusive scan of cnt[0..bins) -> off, off[bins] = entries of the chunk
+        const uint32_t ngroups = (bins + 63) / 64, lane = tid & 63;
+        for (uint32_t g = tid >> 6; g < ngroups; g += TB / 64) {
+            const uint32_t b = g * 64 + lane;
+            const uint32_t v = (b < bins) ? cnt[b] : 0;
+            uint32_t incl = v;
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = __shfl_up((int)incl, o);
+                if ((int)lane >= o) incl += t;
+            }
+            if (b < bins) off[b] = incl - v;
+            if (lane == 63) wsum[g] = incl;
+        }
+        __syncthreads();
+        uint32_t tot = 0;
+        for (uint32_t b = tid; b < bins; b += TB) {
+            uint32_t pre = 0;
+            for (uint32_t g = 0; g < (b >> 6); ++g) pre += wsum[g];
+            const uint32_t o = off[b] + pre;
+            off[b] = o;
+            cur[b] = o;
+            if (b == bins - 1) tot = o + cnt[b];
+        }
+        if (tid == ((bins - 1) % TB)) off[bins] = tot;
+        __syncthreads();
+    }
+    uint32_t* __restrict__ out = reinterpret_cast<uint32_t*>(a.out_entries);
+    const uint32_t low_mask = (1u << a.shift) - 1;
+    uint32_t b_lo = 0;
+    while (b_lo < bins) {
+        const uint32_t base = off[b_lo];
+        uint32_t l = b_lo, h = bins + 1;                 // largest b_hi with off[b_hi] - base <= BUFN
+        while (h - l > 1) {
+            const uint32_t mid = (l + h) >> 1;
+            if (off[mid] - base <= (uint32_t)BUFN) l = mid; else h = mid;
+        }
+        const bool direct = (l == b_lo);                 // one bin beyond the buffer (skewed scalars): written directly
+        const uint32_t b_hi = direct ? b_lo + 1 : l;
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            asm volatile("" : "+v"(d[i]));               // key and bin recomputed per round, not kept per entry
+            const uint32_t mag = d[i] & ~kSignBit;
+            const uint32_t key = mag - 1;
+            const uint32_t bin = (key >> a.shift) & a.mask;
+            if (mag != 0 && bin >= b_lo && bin < b_hi) {
+                const uint32_t pos = atomicAdd(&cur[bin], 1u);
+                const uint32_t word = pk_make(key & low_mask, (lo + tid + (uint32_t)i * TB) | (d[i] & kSignBit), a.pk_out_bits);
+                if (direct) out[gdst[bin] + (pos - base)] = word; else buf[pos - base] = word;
+            }
+        }
+        __syncthreads();
+        if (!direct) {
+            const uint32_t hl = tid & 31;
+            for (uint32_t b = b_lo + (tid >> 5); b < b_hi; b += TB / 32) {
+                const uint32_t c = cnt[b], src = off[b] - base, dst = gdst[b];
+                for (uint32_t j = hl; j < c; j += 32) out[dst + j] = buf[src + j];
+            }
+            __syncthreads();
+        }
+        b_lo = b_hi;
     }
 }
 
@@ -1538,6 +1756,9 @@ int msm_build_table(Ctx& c, const Affine* d_points, size_t n, int cb, Affine** t
 }
 
 struct SortPass { uint32_t shift, bins, nseg, nch, chunk, items_bound; };
+// register capacities (TB * E) of the msm_radix_segment_kernel instantiations, smallest first
+constexpr int kSegCfgs = 6;
+constexpr uint32_t kSegCap[kSegCfgs] = {128 * 12, 256 * 12, 256 * 24, 256 * 40, 512 * 40, 512 * 72};
 
 // One pipeline instance: the windows [w0, w0 + W) of every scalar vector, on its own stream with its
 // own workspace.  One instance per call by default; an experimental two-instance mode lets the second
@@ -1632,6 +1853,8 @@ static int msm_group_plan(Ctx& c, MsmGroup& g, size_t n, uint32_t batch, int cb,
         g.sp[p].nseg = nseg;
         const uint64_t avg = std::max<uint64_t>(1, (g.S0 * (uint64_t)g.seg_n) / nseg);
         g.sp[p].nch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(1024, avg / 32768));
+        // packed two-pass sorts: chunks of <= 32768 digits, what one workgroup of msm_radix_chunk_kernel takes into registers
+        if (p == 0 && g.pk_bits && avg <= (1ull << 25)) g.sp[p].nch = (uint32_t)((avg + 32767) / 32768);
         g.sp[p].chunk = (p == g.P - 1) ? 16384u : 32768u;   // later passes: fixed-size work items
         g.sp[p].items_bound = (uint32_t)(g.entries / g.sp[p].chunk) + nseg;
         nseg *= g.sp[p].bins;
@@ -1645,7 +1868,7 @@ static int msm_group_plan(Ctx& c, MsmGroup& g, size_t n, uint32_t batch, int cb,
     UZK_TRY(m.partials.reserve((size_t)2 * g.RW * g.groups * sizeof(XYZZ)));
     UZK_TRY(m.win_sums.reserve((size_t)g.RW * sizeof(XYZZ)));
     for (int p = 0; p < g.P; ++p) {
-        UZK_TRY(m.counts[p].reserve((size_t)(p == 0 ? g.sp[p].nseg * g.sp[p].nch : g.sp[p].items_bound) * g.sp[p].bins * 4));
+        UZK_TRY(m.counts[p].reserve((size_t)(p == 0 ? 2 * g.sp[p].nseg * g.sp[p].nch : g.sp[p].items_bound) * g.sp[p].bins * 4));
         if (p > 0) UZK_TRY(m.items[p].reserve(((size_t)g.sp[p].nseg + 1) * 4));
         if (p + 1 < g.P) {
             UZK_TRY(m.segs_start[p].reserve((size_t)g.sp[p].nseg * g.sp[p].bins * 4));
@@ -1707,6 +1930,7 @@ static int msm_group_phase1(Ctx& c, MsmGroup& g, const Affine* points, const Sca
         RadixArgs a{};
         a.shift = sp.shift; a.bins = sp.bins; a.mask = sp.bins - 1;
         a.counts = m.counts[p].as<uint32_t>();
+        a.prefix = first ? a.counts + (size_t)sp.nseg * sp.nch * sp.bins : a.counts;   // first pass: several scan workgroups per segment
         if (first) {
             a.digits = digits;
             a.n = g.seg_n;
@@ -1722,21 +1946,35 @@ static int msm_group_phase1(Ctx& c, MsmGroup& g, const Affine* points, const Sca
             a.bin_base = m.segs_start[p].as<uint32_t>(); a.bin_count = m.segs_len[p].as<uint32_t>();
             a.out_entries = m.ent[p & 1].as<uint2>();
         }
+        // Last pass of a packed two-pass sort: segments of the expected length (mean + 8 sigma of a uniform split fits the
+        // kernel's registers) are sorted by one workgroup each (msm_radix_segment_kernel); the generic kernels below then
+        // only see the longer ones (skewed scalar sets), normally none.
+        int seg_cfg = -1;
+        if (last && !first && g.P == 2 && a.pk_in_bits && c.tune_seg_sort && sp.bins <= 512) {
+            const double mean = (double)g.seg_n / (double)g.sp[0].bins;
+            const double need = mean + 8.0 * std::sqrt(mean) + 64.0;
+            for (int k = 0; k < kSegCfgs; ++k)
+                if ((double)kSegCap[k] >= need) { seg_cfg = k; break; }
+            if (c.tune_seg_sort >= 10) seg_cfg = std::min(kSegCfgs - 1, c.tune_seg_sort - 10);   // tests: a given instantiation
+            if (seg_cfg >= 0) a.seg_min_len = kSegCap[seg_cfg];
+        }
         if (!first) {
             a.item_off = m.items[p].as<uint32_t>();
             a.nseg = sp.nseg;
             a.chunk = sp.chunk;
             KernelScope ks(c, "msm_sort_items");
             hipLaunchKernelGGL(msm_radix_items_kernel, dim3(1), dim3(1024), 0, st, a.seg_len, a.nseg, a.chunk,
-                               m.items[p].as<uint32_t>());
+                               m.items[p].as<uint32_t>(), a.seg_min_len);
         }
-        const dim3 grid = first ? dim3(sp.nch, sp.nseg) : dim3(sp.items_bound);
+        // later passes: the work-item list is data dependent; the launch covers its bound up to a few workgroups per CU and
+        // strides over the rest (behind the segment kernel the list is normally empty: 2048 workgroups that leave at once)
+        const dim3 grid = first ? dim3(sp.nch, sp.nseg) : dim3(seg_cfg >= 0 ? std::min<uint32_t>(sp.items_bound, 2048u) : sp.items_bound);
         // Workspace guard (the round-1 fault -- a write past a sort counter array while the two-pass sort was being
         // written, DESIGN.md 3.1 -- must fail here, on the host, not on the device): every workgroup of this pass
         // owns `bins` counters, every segment `bins` entries of bin_base / bin_count, and both output arrays hold
         // all entries.
         {
-            const size_t wgs = (size_t)grid.x * grid.y;
+            const size_t wgs = first ? 2 * (size_t)grid.x * grid.y : (size_t)sp.items_bound;   // counters: one set per work item (+ prefixes)
             const size_t ent_bytes = g.pk_bits ? 4 : sizeof(uint2);
             const bool ok = m.counts[p].cap >= wgs * sp.bins * 4 &&
                             (last ? (m.bucket_start.cap >= (size_t)sp.nseg * sp.bins * 4 && m.bucket_count.cap >= (size_t)sp.nseg * sp.bins * 4 &&
@@ -1746,6 +1984,18 @@ static int msm_group_phase1(Ctx& c, MsmGroup& g, const Affine* points, const Sca
                             (first || m.items[p].cap >= ((size_t)sp.nseg + 1) * 4);
             if (!ok) { set_error("msm: sort pass %d: a workspace is smaller than its launch needs (internal error)", p); return UZK_ERR_DEVICE; }
         }
+        if (seg_cfg >= 0) {
+            KernelScope ks(c, "msm_sort_segment");
+            const dim3 sgrid(sp.nseg);
+            switch (seg_cfg) {
+                case 0: hipLaunchKernelGGL((msm_radix_segment_kernel<128, 12, 1536>), sgrid, dim3(128), 0, st, a); break;
+                case 1: hipLaunchKernelGGL((msm_radix_segment_kernel<256, 12, 3072>), sgrid, dim3(256), 0, st, a); break;
+                case 2: hipLaunchKernelGGL((msm_radix_segment_kernel<256, 24, 6144>), sgrid, dim3(256), 0, st, a); break;
+                case 3: hipLaunchKernelGGL((msm_radix_segment_kernel<256, 40, 10240>), sgrid, dim3(256), 0, st, a); break;
+                case 4: hipLaunchKernelGGL((msm_radix_segment_kernel<512, 40, 18432>), sgrid, dim3(512), 0, st, a); break;
+                default: hipLaunchKernelGGL((msm_radix_segment_kernel<512, 72, 18432>), sgrid, dim3(512), 0, st, a); break;
+            }
+        }
         if (!(first && fused_hist)) {
             KernelScope ks(c, "msm_sort_hist");
             if (first) hipLaunchKernelGGL((msm_radix_hist_kernel<true, false>), grid, dim3(1024), 0, st, a);
@@ -1754,14 +2004,19 @@ static int msm_group_phase1(Ctx& c, MsmGroup& g, const Affine* points, const Sca
         }
         {
             KernelScope ks(c, "msm_sort_scan");
-            hipLaunchKernelGGL(msm_radix_scan_kernel, dim3(sp.nseg), dim3(512), 0, st, a, sp.nch,
+            // first pass: few segments with many chunks each -- several workgroups per segment
+            const uint32_t scan_g = first ? std::max<uint32_t>(1, std::min<uint32_t>(sp.nch / 16, 1024 / std::max<uint32_t>(1, sp.nseg))) : 1u;
+            hipLaunchKernelGGL(msm_radix_scan_kernel, dim3(sp.nseg, scan_g), dim3(512), 0, st, a, sp.nch,
                                first ? (const uint32_t*)nullptr : a.seg_start, first ? g.seg_n : 0u);
         }
         {
             KernelScope ks(c, "msm_sort_scatter");
             // large two-pass sorts with packed entries: both passes write 4-byte words -- the line-sized-run scatter (tune: msm_scatter4)
             const bool four = c.tune_scatter4 && g.pk_bits != 0 && g.entries >= (1ull << 26);
-            if (first && last) hipLaunchKernelGGL((msm_radix_scatter_kernel<1024, 8, true, true, false>), grid, dim3(1024), 0, st, a);
+            const uint32_t cs0 = first ? (g.seg_n + sp.nch - 1) / sp.nch : 0u;
+            if (first && !last && a.pk_out_bits && c.tune_chunk_sort && sp.bins <= 512 && cs0 <= 32768 && !g.pre)
+                hipLaunchKernelGGL((msm_radix_chunk_kernel<512, 64, 18176>), grid, dim3(512), 0, st, a);
+            else if (first && last) hipLaunchKernelGGL((msm_radix_scatter_kernel<1024, 8, true, true, false>), grid, dim3(1024), 0, st, a);
             else if (first && four) hipLaunchKernelGGL((msm_radix_scatter4_kernel<512, 16, true, false, false>), grid, dim3(512), 0, st, a);
             else if (last && four) hipLaunchKernelGGL((msm_radix_scatter4_kernel<512, 16, false, true, true>), grid, dim3(512), 0, st, a);
             else if (first && g.entries >= (1ull << 26))   // large sorts: 512 lanes, 4096-entry tiles (measured)
