@@ -173,5 +173,19 @@ inline Jac horner(uint32_t windows, int c, const Get& get) {
     return j_to(total);
 }
 
+// The same sum when every window arrives as two class sums (msm_class_sums_kernel): window w = 2^s * hi(w) + lo(w).
+// sum_w 2^(c w) (2^s hi_w + lo_w) by one Horner chain with the doublings split c - s | s: no more doublings than above.
+template <class GetHi, class GetLo>
+inline Jac horner_split(uint32_t windows, int c, int s, const GetHi& hi, const GetLo& lo) {
+    J total = j_inf();
+    for (int w = (int)windows - 1; w >= 0; --w) {
+        if (w != (int)windows - 1) for (int d = 0; d < c - s; ++d) total = j_dbl(total);
+        total = j_add(total, j_from_xyzz(x4_from(hi((uint32_t)w))));
+        for (int d = 0; d < s; ++d) total = j_dbl(total);
+        total = j_add(total, j_from_xyzz(x4_from(lo((uint32_t)w))));
+    }
+    return j_to(total);
+}
+
 }  // namespace h64
 }  // namespace uzk

@@ -52,7 +52,7 @@ constexpr uint32_t kCombineFan = 32;   // partial sums folded per lane and level
 constexpr int kMaxPasses = 3;
 
 struct MsmWork {
-    DevBuf digits, bucket_count, bucket_start, sorted, buckets, partials, win_sums;
+    DevBuf digits, bucket_count, bucket_start, sorted, buckets, partials, win_sums, class_sums;
     DevBuf ent[2];                           // radix ping-pong ({key, val} entries)
     DevBuf counts[kMaxPasses], segs_start[kMaxPasses], segs_len[kMaxPasses], items[kMaxPasses];
     DevBuf lvl_cnt[2], lvl_off[2], lvl_part[2], small, task_desc, exc;
@@ -1181,6 +1181,73 @@ __global__ __launch_bounds__(256) void msm_fold_scan_kernel(const XYZZ* __restri
     if (tid == 0) out[w] = sh[0];
 }
 
+// Class sums (round 3): the first level of a bucket reduction without weights.  With the bucket index i = h * 2^s + l,
+//   sum_i (i + 1) B_i  =  2^s * sum_h h R_h  +  sum_l (l + 1) C_l,     R_h = sum_l B_(h,l)  (rows),  C_l = sum_h B_(h,l)  (columns):
+// 2 additions per bucket like the running sums above, but PLAIN sums -- no per-lane chain of 2 * seg dependent additions, no
+// double-and-add, no scan: every lane adds 8 buckets, the 256 partial sums of a workgroup are folded in LDS by fewer and fewer
+// lanes (4, 4, 2 to one: 15 dependent additions in all), and what is left -- 2 * 256 class sums per window instead of 2^15 or
+// 2^16 buckets -- goes through the scan kernels above as a problem of the size they are quick at.  The host's Horner takes
+// the two sums of a window with its doublings split c - s | s (host_ec64.hpp horner_split).
+// grid (tiles, logical windows, 2): z = 0 rows, z = 1 columns; a tile = 2048 buckets: 8 rows, or 2048 / H columns of all H
+// rows.  out: [window][2][nb2] with rows at index h - 1 (weight h; R_0 has weight 0 and is dropped) and columns at l.
+__global__ __launch_bounds__(256) void msm_class_sums_kernel(const XYZZ* __restrict__ buckets, XYZZ* __restrict__ out, uint32_t nbk,
+                                                              uint32_t log_s, uint32_t nb2) {
+    __shared__ XYZZ sh[256];
+    const uint32_t tile = blockIdx.x, w = blockIdx.y, cols = blockIdx.z, t = threadIdx.x;
+    const uint32_t Lc = 1u << log_s, H = nbk >> log_s;
+    const XYZZ* bw = buckets + (size_t)w * nbk;
+    XYZZ* ow = out + ((size_t)w * 2 + cols) * nb2;
+    // G = partial sums per class inside the workgroup: a row is 2^s / 8 lanes, a column H / 8
+    const uint32_t G = cols ? H / 8 : Lc / 8;
+    XYZZ acc = xyzz_inf();
+    if (!cols) {
+        const XYZZ* src = bw + (size_t)tile * 2048 + (size_t)t * 8;
+#pragma unroll 1
+        for (uint32_t k = 0; k < 8; ++k) { XYZZ q = src[k]; xyzz_add(acc, q); }
+    } else {
+        const uint32_t col = tile * (256 / G) + t / G, hg = t % G;
+#pragma unroll 1
+        for (uint32_t k = 0; k < 8; ++k) { XYZZ q = bw[(size_t)(hg * 8 + k) * Lc + col]; xyzz_add(acc, q); }
+    }
+    sh[t] = acc;
+    __syncthreads();
+    // fold groups of G consecutive partial sums, 4 (or 2) to one per step; lane j takes partial sums j*f .. j*f + f - 1
+    // From 64 outputs per step on, a QUAD takes each output (ecquad.hpp): these steps are chains of dependent additions on a
+    // few lanes, where four lanes per addition are four times faster (3.2 us against 13 us for a lone wave's 8 x 32-bit addition).
+    uint32_t live = 256;
+    const uint32_t qi = t >> 2, ql = t & 3;
+    for (uint32_t g = G; g > 1;) {
+        const uint32_t f = (g % 4 == 0) ? 4 : 2;
+        live /= f;
+        XYZZ a;
+        if (live <= 64) {
+            if (qi < live) {
+                a = sh[qi * f];
+                for (uint32_t k = 1; k < f; ++k) { const XYZZ q = sh[qi * f + k]; xyzz_add_quad(a, q, ql); }
+            }
+            __syncthreads();
+            if (qi < live && ql == 0) sh[qi] = a;
+        } else {
+            if (t < live) {
+                a = sh[t * f];
+                for (uint32_t k = 1; k < f; ++k) { XYZZ q = sh[t * f + k]; xyzz_add(a, q); }
+            }
+            __syncthreads();
+            if (t < live) sh[t] = a;
+        }
+        __syncthreads();
+        g /= f;
+    }
+    if (t < 256 / G) {
+        const uint32_t cls = tile * (256 / G) + t;          // row h or column l
+        if (!cols) { if (cls != 0) ow[cls - 1] = sh[t]; }
+        else ow[cls] = sh[t];
+    }
+    // padding of the row array: weights H .. nb2 do not exist (and R_0's slot moved down by one)
+    // (the column array likewise beyond its 2^s columns when there are more rows than columns)
+    if (tile == 0) for (uint32_t k = (cols ? Lc : H - 1) + t; k < nb2; k += 256) ow[k] = xyzz_inf();
+}
+
 // The two kernels above with one quad per lane-role (block 256 = 64 quads, ecquad.hpp): the same identity, every
 // dependent addition / doubling at a quarter of its latency.  t = quad index in the workgroup.
 // 256 threads = one wave per SIMD: two waves share the SIMD's issue port and every dependent step takes twice as long
@@ -1693,7 +1760,7 @@ void msm_free(Ctx& c) {
     for (int q = 0; q < 2; ++q) {
         MsmWork* m = &c.msm[q];
         m->digits.release(); m->bucket_count.release(); m->bucket_start.release(); m->sorted.release();
-        m->buckets.release(); m->partials.release(); m->win_sums.release(); m->small.release(); m->task_desc.release(); m->exc.release();
+        m->buckets.release(); m->partials.release(); m->win_sums.release(); m->class_sums.release(); m->small.release(); m->task_desc.release(); m->exc.release();
         for (int k = 0; k < 2; ++k) {
             m->ent[k].release(); m->lvl_cnt[k].release(); m->lvl_off[k].release(); m->lvl_part[k].release();
         }
@@ -1774,6 +1841,7 @@ struct MsmGroup {
     uint32_t kb = 0, NBL = 0, S0 = 0, seg_n = 0, NB = 0, Wd = 0, RW = 0, seg = 0, groups = 0, L = 0;
     int P = 0;
     bool scan_reduce = false, quad_reduce = false;
+    uint32_t class_s = 0, nb2 = 0;                          // > 0: class-sum reduction (msm_class_sums_kernel), 2 * nb2 class sums per window
     uint32_t rl = 256;                                      // reduction lanes (quads) per workgroup
     uint32_t pk_bits = 0;   // > 0: 4-byte packed entries between the two sort passes (index bits)
     SortPass sp[kMaxPasses];
@@ -1824,6 +1892,12 @@ static int msm_group_plan(Ctx& c, MsmGroup& g, size_t n, uint32_t batch, int cb,
         g.seg = std::max<uint32_t>(1, std::min<uint32_t>(c.tune_reduce_seg > 0 ? (uint32_t)c.tune_reduce_seg : kSeg, g.NBL / 256));
     }
     g.groups = (g.NBL + g.seg * g.rl - 1) / (g.seg * g.rl);
+    // windows of >= 2^12 buckets: class sums first (2 x 256 sums per window), the scans above on those
+    g.class_s = 0; g.nb2 = 0;
+    if (c.tune_class_reduce && g.NBL >= 4096 && g.NBL <= (1u << 18) && (uint64_t)g.RW * 2 <= 65535) {
+        g.class_s = 8;
+        g.nb2 = std::max<uint32_t>(256, g.NBL >> 8);
+    }
     const uint64_t all_entries = (uint64_t)W_total * n * batch;
     // Task length: long enough that a typical bucket (4x the mean population) is ONE task -- its partial
     // sum then needs no folding -- but short enough that there are >= ~200k tasks to fill the chip
@@ -1865,8 +1939,9 @@ static int msm_group_plan(Ctx& c, MsmGroup& g, size_t n, uint32_t batch, int cb,
     UZK_TRY(m.bucket_count.reserve((size_t)g.TBK * 4));
     UZK_TRY(m.bucket_start.reserve((size_t)g.TBK * 4));
     UZK_TRY(m.buckets.reserve((size_t)g.TBK * sizeof(XYZZ)));
-    UZK_TRY(m.partials.reserve((size_t)2 * g.RW * g.groups * sizeof(XYZZ)));
-    UZK_TRY(m.win_sums.reserve((size_t)g.RW * sizeof(XYZZ)));
+    UZK_TRY(m.partials.reserve((size_t)2 * g.RW * std::max<uint32_t>(g.groups, g.class_s ? 2 * (g.nb2 / 256 + 1) : 0) * sizeof(XYZZ)));
+    UZK_TRY(m.win_sums.reserve((size_t)g.RW * 2 * sizeof(XYZZ)));
+    if (g.class_s) UZK_TRY(m.class_sums.reserve((size_t)g.RW * 2 * g.nb2 * sizeof(XYZZ)));
     for (int p = 0; p < g.P; ++p) {
         UZK_TRY(m.counts[p].reserve((size_t)(p == 0 ? 2 * g.sp[p].nseg * g.sp[p].nch : g.sp[p].items_bound) * g.sp[p].bins * 4));
         if (p > 0) UZK_TRY(m.items[p].reserve(((size_t)g.sp[p].nseg + 1) * 4));
@@ -1884,10 +1959,10 @@ static int msm_group_plan(Ctx& c, MsmGroup& g, size_t n, uint32_t batch, int cb,
     UZK_TRY(m.small.reserve(16384));
     UZK_TRY(m.task_desc.reserve((size_t)g.bound0 * sizeof(TaskDesc)));
     UZK_TRY(m.exc.reserve((size_t)g.bound0 * 4));
-    if (m.h_sums_cap < g.RW) {
+    if (m.h_sums_cap < (size_t)g.RW * 2) {
         if (m.h_sums) (void)hipHostFree(m.h_sums);
-        UZK_HIP(hipHostMalloc(reinterpret_cast<void**>(&m.h_sums), (size_t)g.RW * sizeof(XYZZ), hipHostMallocDefault));
-        m.h_sums_cap = g.RW;
+        UZK_HIP(hipHostMalloc(reinterpret_cast<void**>(&m.h_sums), (size_t)g.RW * 2 * sizeof(XYZZ), hipHostMallocDefault));
+        m.h_sums_cap = (size_t)g.RW * 2;
     }
     if (!m.h_max) UZK_HIP(hipHostMalloc(reinterpret_cast<void**>(&m.h_max), 64, hipHostMallocDefault));
     return UZK_OK;
@@ -2143,6 +2218,30 @@ static int msm_group_phase2(Ctx& c, MsmGroup& g, bool accumulate = false, bool r
                                buckets, g.NB, g.Wd, accumulate ? 1 : 0);
     }
     if (!reduce) { UZK_HIP(hipGetLastError()); return UZK_OK; }
+    if (g.class_s) {
+        // level 1: class sums; level 2: the quad scans over 2 * RW logical windows of nb2 "buckets" each -- window sums
+        // [w][0] = sum_h h R_h and [w][1] = sum_l (l + 1) C_l, combined by the host's Horner (2^s * [0] + [1])
+        XYZZ* cls = m.class_sums.as<XYZZ>();
+        const uint32_t RW2 = g.RW * 2;
+        {
+            KernelScope ks(c, "msm_reduce_class");
+            hipLaunchKernelGGL(msm_class_sums_kernel, dim3(g.NBL / 2048, g.RW, 2), dim3(256), 0, st, buckets, cls, g.NBL, g.class_s, g.nb2);
+        }
+        {
+            KernelScope ks(c, "msm_reduce");
+            const uint32_t seg2 = 4, log_seg2 = 2, groups2 = (g.nb2 + seg2 * kQuadLanes - 1) / (seg2 * kQuadLanes);
+            XYZZ* part_r = partials + (size_t)RW2 * groups2;
+            // one workgroup per logical window (nb2 = 256): its P1 partial IS the window sum
+            hipLaunchKernelGGL(msm_reduce_scan_quad_kernel, dim3(groups2, RW2), dim3(kQuadLanes * 4), 0, st, cls, groups2 == 1 ? win_sums : partials,
+                               part_r, g.nb2, groups2, seg2, log_seg2);
+            if (groups2 > 1)
+                hipLaunchKernelGGL(msm_fold_scan_quad_kernel, dim3(RW2), dim3(kQuadLanes * 4), 0, st, partials, part_r, win_sums, groups2,
+                                   kLogQuadLanes + log_seg2);
+        }
+        UZK_HIP(hipGetLastError());
+        UZK_HIP(hipMemcpyAsync(m.h_sums, win_sums, (size_t)RW2 * sizeof(XYZZ), hipMemcpyDeviceToHost, st));
+        return UZK_OK;
+    }
     {
         KernelScope ks(c, "msm_reduce");
         if (g.scan_reduce) {
@@ -2244,11 +2343,16 @@ HornerPool& horner_pool() {
 }  // namespace
 
 // Host: per scalar vector, Horner over its W window sums (c doublings per step).
+// `class_s` > 0: window_sum(b, w) is the first of TWO consecutive sums of the window (class sums: 2^class_s * [0] + [1])
 template <class WindowSum>
-static void msm_horner_host(Ctx& c, uint32_t batch, uint32_t wpp, int cb, const WindowSum& window_sum, Jac* out_host) {
+static void msm_horner_host(Ctx& c, uint32_t batch, uint32_t wpp, int cb, const WindowSum& window_sum, Jac* out_host, int class_s = 0) {
     // 4 x 64-bit host arithmetic, Jacobian doublings (host_ec64.hpp): 57 -> 32 us for the 32 windows of a 2^14-point commit
     auto horner = [&](uint32_t b) {
-        out_host[b] = h64::horner(wpp, cb, [&](uint32_t w) -> const XYZZ& { return window_sum(b, w); });
+        if (class_s > 0)
+            out_host[b] = h64::horner_split(wpp, std::max(cb, class_s), class_s, [&](uint32_t w) -> const XYZZ& { return (&window_sum(b, w))[0]; },
+                                            [&](uint32_t w) -> const XYZZ& { return (&window_sum(b, w))[1]; });
+        else
+            out_host[b] = h64::horner(wpp, cb, [&](uint32_t w) -> const XYZZ& { return window_sum(b, w); });
     };
     HostScope hs_horner(c, "host_msm_horner");
     if (batch > 1 && wpp > 1) {
@@ -2493,8 +2597,9 @@ int msm_run_streamed(Ctx& c, const Affine* points, const Fp* scalars_host, size_
     c.cur_stream = c.stream;
     give_back();
     UZK_TRY(rc);
-    auto window_sum = [&](uint32_t, uint32_t w) -> const XYZZ& { return g.m->h_sums[w]; };
-    msm_horner_host(c, 1, W, cb, window_sum, out_host);
+    const uint32_t per = g.class_s ? 2u : 1u;
+    auto window_sum = [&](uint32_t, uint32_t w) -> const XYZZ& { return g.m->h_sums[(size_t)w * per]; };
+    msm_horner_host(c, 1, W, cb, window_sum, out_host, (int)g.class_s);
     return UZK_OK;
 }
 
@@ -2550,12 +2655,13 @@ int msm_run(Ctx& c, const Affine* points, const ScalarView& d_scalars, size_t n,
     // 7. host: per scalar vector, Horner over its logical windows (c doublings per step); one window
     //    each when precomputed.  Window w of vector b lives in the group that owns w.
     const uint32_t wpp = pre ? 1u : W;
+    const uint32_t per = g[0].class_s ? 2u : 1u;            // both groups of a split share the window width, hence the mode
     auto window_sum = [&](uint32_t b, uint32_t w) -> const XYZZ& {
-        if (pre) return g[0].m->h_sums[b];
+        if (pre) return g[0].m->h_sums[(size_t)b * per];
         const int k = (split && w >= wa) ? 1 : 0;
-        return g[k].m->h_sums[(size_t)b * g[k].W + (w - g[k].w0)];
+        return g[k].m->h_sums[((size_t)b * g[k].W + (w - g[k].w0)) * per];
     };
-    msm_horner_host(c, batch, wpp, cb, window_sum, out_host);
+    msm_horner_host(c, batch, wpp, cb, window_sum, out_host, (int)g[0].class_s);
     return UZK_OK;
 }
 
