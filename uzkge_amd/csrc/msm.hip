@@ -1742,9 +1742,11 @@ static int choose_window_bits(size_t n, int forced) {
     if (forced >= 4 && forced <= 22) return forced;
     int lg = 0;
     while ((1ull << (lg + 1)) <= n) ++lg;
-    if (lg <= 17) return 8;
-    if (lg == 18) return 15;
-    if (lg <= 21) return 16;                 // 2^19 buckets: the reduction still runs on quads (msm_group_plan)
+    // measured with the class-sum reduction (tools/sweep_c_large.py, profiles/r03c_sweep_c.txt): 2^17: c = 15 0.68 ms against
+    // 0.72 at c = 8; 2^21: c = 17 3.01 against 3.04 at c = 16
+    if (lg <= 16) return 8;
+    if (lg <= 18) return 15;
+    if (lg <= 20) return 16;
     return 17;
 }
 int msm_precompute_window_bits(size_t n, int forced) {
