@@ -170,7 +170,21 @@ struct PassArgs {
     uint32_t use_ab;       // alpha / beta present (else plain sums for every r is NOT implied: r != 0 always needs them)
     const Fp* out_tw[3];
     uint32_t out_mul;      // 0 / 1: contiguous
+    uint32_t prio;         // experiment (uzk_tune("ntt_prio")): wave priorities that de-synchronise the workgroups sharing a CU
 };
+
+// ntt_prio: 1 = every other generation of workgroups runs at a higher priority; 2 = every other workgroup; 3 = a workgroup's
+// priority rises with the sub-pass it is in (oldest first)
+__device__ __forceinline__ void ntt_prio_start(uint32_t mode) {
+    if (mode == 1) { if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(2); }
+    else if (mode == 2) { if (blockIdx.x & 1) __builtin_amdgcn_s_setprio(2); }
+}
+__device__ __forceinline__ void ntt_prio_step(uint32_t mode, int k) {
+    if (mode != 3) return;
+    if (k == 1) __builtin_amdgcn_s_setprio(1);
+    else if (k == 2) __builtin_amdgcn_s_setprio(2);
+    else if (k >= 3) __builtin_amdgcn_s_setprio(3);
+}
 
 constexpr int kPlane = 2048 + 64;   // uint4 slots per LDS plane (transposed layout needs T*(R+1))
 
@@ -398,6 +412,7 @@ __global__ __launch_bounds__(TILE / 4) void ntt_pass29_kernel(const Fp* __restri
     in += (uint64_t)blockIdx.y * ((FIRST && a.m3 == 0) ? a.in_vec_stride : a.batch_stride);
     out += (uint64_t)blockIdx.y * ((a.twp == nullptr && a.out_mul <= 1) ? a.out_vec_stride : a.batch_stride);
 
+    ntt_prio_start(a.prio);
     const L29 w4 = tw29_load(a.tw256, 256, 64);
     L29 x[4];
     int rows[4];
@@ -448,6 +463,7 @@ __global__ __launch_bounds__(TILE / 4) void ntt_pass29_kernel(const Fp* __restri
 #pragma unroll
     for (int k = 1; k < N4; ++k) {
         const int S = 1 << (2 * k);
+        ntt_prio_step(a.prio, k);
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < 4; ++s) lds_put29<PL>(lds, rows[s] * T + col, x[s]);
@@ -765,6 +781,7 @@ static int ntt_pow2(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse,
         a.tw256 = p->d_tw256;
         a.twp = p->d_tw_pass[j];
         a.twp_count = p->tw_count[j];
+        a.prio = (uint32_t)c.tune_ntt_prio;
         const bool first = (j == 0);
         switch (p->bits[j]) {
             case 5: launch_pass<5>(c, p->l29, first, src, dst, a, n, batch); break;
