@@ -1862,7 +1862,9 @@ static int msm_group_plan(Ctx& c, MsmGroup& g, size_t n, uint32_t batch, int cb,
     g.NBL = 1u << g.kb;
     g.S0 = pre ? batch : batch * W;                         // sort segments
     g.seg_n = pre ? (uint32_t)g.per_poly : g.n32;
-    g.NB = std::min<uint32_t>(g.NBL, 1u << 15);             // bucket windows of <= 2^15 buckets for the scans
+    // bucket windows of <= 2^scan_nb_log (<= 2^15) buckets for the task scans, as many of them as the 1024-entry window table holds
+    g.NB = std::min<uint32_t>(g.NBL, 1u << std::max(10, std::min(15, c.tune_scan_nb_log)));
+    while (((uint64_t)g.S0 * g.NBL) / g.NB > 1024 && g.NB < (1u << 15)) g.NB <<= 1;
     g.Wd = (uint32_t)(((uint64_t)g.S0 * g.NBL) / g.NB);
     g.TBK = (uint64_t)g.Wd * g.NB;
     if (g.Wd > 1024) { set_error("msm: too many bucket windows (%u): lower the batch", g.Wd); return UZK_ERR_PARAMETER; }
