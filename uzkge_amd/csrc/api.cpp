@@ -589,6 +589,10 @@ static int msm_dispatch_view(const Ctx::Srs& s, size_t offset, const ScalarView&
     return msm_run(c, s.d_points + offset, sv, n, batch, out, 0, 0, 0);
 }
 static int msm_dispatch_one(const Ctx::Srs& s, size_t offset, const Fp* d_scalars, size_t n, uint32_t batch, Jac* out) {
+    Ctx& c = ctx();
+    // one vector of more than 2^24 points over plain bases: chunks of 2^24 into one bucket set (msm_run_chunked)
+    if (batch == 1 && n > ((size_t)1 << 24) && !(s.d_table && !c.tune_no_precompute) && c.tune_chunk_log >= 25)
+        return msm_run_chunked(c, s.d_points + offset, d_scalars, n, out);
     return msm_dispatch_view(s, offset, ScalarView::dense(d_scalars, n), n, batch, out);
 }
 // The sort indexes (point, window) pairs with 31 bits, so one pass handles at most 2^26 points per

@@ -184,6 +184,7 @@ void msm_plan_info(Ctx& c, size_t n, int* window_bits, int* windows);
 int msm_run(Ctx& c, const Affine* points, const ScalarView& scalars, size_t n, uint32_t batch, Jac* out_host, int pre_c,
             uint32_t pre_stride, uint32_t pre_off);
 int msm_run_streamed(Ctx& c, const Affine* points, const Fp* scalars_host, size_t n, Jac* out_host);
+int msm_run_chunked(Ctx& c, const Affine* points, const Fp* d_scalars, size_t n, Jac* out_host);
 int msm_build_table(Ctx& c, const Affine* d_points, size_t n, int cb, Affine** table_out, uint32_t* W_out);
 int msm_precompute_window_bits(size_t n, int forced);
 void msm_free(Ctx& c);
