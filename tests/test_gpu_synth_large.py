@@ -200,8 +200,8 @@ def test_point_chunk_loop_small(gpu):
     assert chunked == one == affine_of(oc.msm_pippenger(wire[:3000], s, 0, 2))
 
 
-@pytest.mark.parametrize("cfg,chunk", [(1, 1), (10, 1), (13, 1), (15, 1), (0, 1), (1, 0), (0, 0)])
-def test_segment_sort_skewed_segments(gpu, cfg, chunk):
+@pytest.mark.parametrize("cfg,chunk,fold_big", [(1, 1, 1), (10, 1, 1), (13, 1, 1), (15, 1, 1), (0, 1, 1), (1, 0, 1), (0, 0, 1), (1, 1, 0)])
+def test_segment_sort_skewed_segments(gpu, cfg, chunk, fold_big):
     """The one-workgroup-per-segment last sort pass (msm_radix_segment_kernel) next to the generic kernels it leaves the
     long segments to: 2^20 points whose scalars are uniform except for runs that put (a) 40000 entries into one bucket
     (longer than any instantiation holds: the generic path), (b) 30000 into one bucket (fits the registers of the largest
@@ -209,7 +209,9 @@ def test_segment_sort_skewed_segments(gpu, cfg, chunk):
     rounds), (d) 3000 into one bucket (beyond the small instantiations).  Every instantiation forced in turn (10 + k),
     the automatic choice (1) and the generic path alone (0) give the closed-form result.  The same runs reach the first
     pass's one-workgroup-per-chunk kernel (msm_radix_chunk_kernel; `chunk` = 0: the generic tile scatter): run (a) fills
-    one bin of chunk 0 beyond the LDS buffer (direct writes), the uniform rest goes out in rounds of whole bins."""
+    one bin of chunk 0 beyond the LDS buffer (direct writes), the uniform rest goes out in rounds of whole bins.
+    The planted buckets hold hundreds of partial sums, so the extra fold levels run: with one wave per long fold
+    (msm_fold_big_kernel, `fold_big` = 1) and with the one-lane-per-output kernels alone (0)."""
     n = 1 << 20
     pts = torch.empty((n, 8), dtype=torch.int64, device="cuda")
     sc = torch.empty((n, 4), dtype=torch.int64, device="cuda")
@@ -228,11 +230,13 @@ def test_segment_sort_skewed_segments(gpu, cfg, chunk):
     srs = gpu.Srs.from_device(pts.data_ptr(), n)
     gpu.tune("msm_seg_sort", cfg)
     gpu.tune("msm_chunk_sort", chunk)
+    gpu.tune("msm_fold_big", fold_big)
     try:
         got = affine_of(gpu.msm_device(srs, sc.data_ptr(), n))
     finally:
         gpu.tune("msm_seg_sort", 1)
         gpu.tune("msm_chunk_sort", 1)
+        gpu.tune("msm_fold_big", 1)
         srs.release()
     k = weighted_index_sum(host)
     assert got == opy.g1_mul(opy.g1_mul(opy.G1_GEN, seed_int), k)

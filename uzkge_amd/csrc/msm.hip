@@ -52,7 +52,7 @@ constexpr uint32_t kCombineFan = 32;   // partial sums folded per lane and level
 constexpr int kMaxPasses = 3;
 
 struct MsmWork {
-    DevBuf digits, bucket_count, bucket_start, sorted, buckets, partials, win_sums, class_sums;
+    DevBuf digits, bucket_count, bucket_start, sorted, buckets, partials, win_sums, class_sums, big;
     DevBuf ent[2];                           // radix ping-pong ({key, val} entries)
     DevBuf counts[kMaxPasses], segs_start[kMaxPasses], segs_len[kMaxPasses], items[kMaxPasses];
     DevBuf lvl_cnt[2], lvl_off[2], lvl_part[2], small, task_desc, exc;
@@ -985,13 +985,17 @@ __device__ __forceinline__ XYZZ fold_partials(const XYZZ* __restrict__ src, uint
 }
 
 // Intermediate level (only for buckets holding > G*L points): out task = sum of <= G partials.
+// `big` (GS = 1 only, optional): outputs that fold more than big_thresh partial sums are not folded here but appended to a list
+// {src offset, count, destination} for msm_fold_big_kernel -- see there.
+struct BigFold { uint32_t src, cnt, dst, pad; };
 template <int GS>
 __global__ __launch_bounds__(256) void msm_combine_kernel(const XYZZ* __restrict__ in, const uint32_t* __restrict__ in_cnt,
                                                           const uint32_t* __restrict__ in_off,
                                                           const uint32_t* __restrict__ in_base,
                                                           const uint32_t* __restrict__ task_off,
                                                           const uint32_t* __restrict__ win_base, XYZZ* __restrict__ out,
-                                                          uint32_t NB, uint32_t W, uint32_t G) {
+                                                          uint32_t NB, uint32_t W, uint32_t G, uint32_t* __restrict__ big_count,
+                                                          BigFold* __restrict__ big, uint32_t big_thresh) {
     const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t tid = gt / GS, sub = gt % GS;
     if (tid >= win_base[W]) return;          // whole groups leave together
@@ -1000,9 +1004,36 @@ __global__ __launch_bounds__(256) void msm_combine_kernel(const XYZZ* __restrict
     const uint32_t total = in_cnt[(size_t)w * NB + b];
     const uint32_t first = j * G;
     const uint32_t cnt = min(G, total - first);
-    const XYZZ* src = in + in_base[w] + in_off[(size_t)w * NB + b] + first;
-    XYZZ acc = fold_partials<GS>(src, cnt, sub);
+    const uint32_t at = in_base[w] + in_off[(size_t)w * NB + b] + first;
+    if (GS == 1 && big != nullptr && cnt > big_thresh) {
+        BigFold e; e.src = at; e.cnt = cnt; e.dst = tid; e.pad = 0;
+        big[atomicAdd(big_count, 1u)] = e;
+        return;
+    }
+    XYZZ acc = fold_partials<GS>(in + at, cnt, sub);
     if (sub == 0) out[tid] = acc;
+}
+// Skewed scalar sets (a real witness is full of 0 / 1 / -1) put thousands of partial sums into a few buckets while everything
+// else has one or two.  With one lane per output those few fold up to 32 partial sums in a row at a lone wave's latency
+// (~10 us per addition): two levels were 0.61 of the 1.78 ms of a 2^20-point prover-mix MSM.  Here one WAVE takes a listed
+// output: lane k loads partial sum k, five shuffle-tree steps add them -- 5 dependent additions instead of 31.
+// grid-stride over the list (its length is data dependent), one wave per workgroup.  mode: 0 = write, 1 = add onto dst.
+__global__ __launch_bounds__(64) void msm_fold_big_kernel(const XYZZ* __restrict__ in, const uint32_t* __restrict__ big_count,
+                                                          const BigFold* __restrict__ big, XYZZ* __restrict__ out, int accumulate) {
+    const uint32_t total = *big_count, lane = threadIdx.x;
+    for (uint32_t i = blockIdx.x; i < total; i += gridDim.x) {
+        const BigFold e = big[i];
+        XYZZ acc = xyzz_inf();
+        for (uint32_t k = lane; k < e.cnt; k += 64) { XYZZ q = in[e.src + k]; xyzz_add(acc, q); }
+        for (int o = 32; o > 0; o >>= 1) {
+            XYZZ q = xyzz_shfl_down(acc, o);
+            if (lane + (uint32_t)o < 64) xyzz_add(acc, q);
+        }
+        if (lane == 0) {
+            if (accumulate) { XYZZ prev = out[e.dst]; xyzz_add(prev, acc); out[e.dst] = prev; }
+            else out[e.dst] = acc;
+        }
+    }
 }
 
 // Last level: one group per bucket folds its <= G partials into the dense bucket array.
@@ -1010,13 +1041,19 @@ template <int GS>
 __global__ __launch_bounds__(256) void msm_finalize_kernel(const XYZZ* __restrict__ in, const uint32_t* __restrict__ in_cnt,
                                                            const uint32_t* __restrict__ in_off,
                                                            const uint32_t* __restrict__ in_base,
-                                                           XYZZ* __restrict__ buckets, uint32_t NB, uint32_t W, int accumulate) {
+                                                           XYZZ* __restrict__ buckets, uint32_t NB, uint32_t W, int accumulate,
+                                                           uint32_t* __restrict__ big_count, BigFold* __restrict__ big, uint32_t big_thresh) {
     const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t t = gt / GS;
     const uint32_t sub = (uint32_t)(gt % GS);
     if (t >= (size_t)W * NB) return;
     const uint32_t w = (uint32_t)(t / NB);
     const uint32_t cnt = in_cnt[t];
+    if (GS == 1 && big != nullptr && cnt > big_thresh) {          // msm_fold_big_kernel writes (or adds onto) this bucket
+        BigFold e; e.src = in_base[w] + in_off[t]; e.cnt = cnt; e.dst = (uint32_t)t; e.pad = 0;
+        big[atomicAdd(big_count, 1u)] = e;
+        return;
+    }
     XYZZ acc = fold_partials<GS>(in + in_base[w] + in_off[t], cnt, sub);
     if (sub == 0) {
         // streamed MSMs (msm_run_streamed) add every later point chunk's bucket sums onto the first one's
@@ -1762,7 +1799,7 @@ void msm_free(Ctx& c) {
     for (int q = 0; q < 2; ++q) {
         MsmWork* m = &c.msm[q];
         m->digits.release(); m->bucket_count.release(); m->bucket_start.release(); m->sorted.release();
-        m->buckets.release(); m->partials.release(); m->win_sums.release(); m->class_sums.release(); m->small.release(); m->task_desc.release(); m->exc.release();
+        m->buckets.release(); m->partials.release(); m->win_sums.release(); m->class_sums.release(); m->big.release(); m->small.release(); m->task_desc.release(); m->exc.release();
         for (int k = 0; k < 2; ++k) {
             m->ent[k].release(); m->lvl_cnt[k].release(); m->lvl_off[k].release(); m->lvl_part[k].release();
         }
@@ -2174,6 +2211,16 @@ static int msm_group_phase2(Ctx& c, MsmGroup& g, bool accumulate = false, bool r
     // (measured at n = 2^14, batch 1..8: four lanes per bucket beat sixteen by 2..20 %)
     const uint32_t gs = (c.tune_fold_group == 4 || c.tune_fold_group == 16) ? (uint32_t)c.tune_fold_group
                       : (g.TBK >= (1u << 18) || c.tune_fold_group == 1) ? 1u : (tmax > 2 ? 4u : 1u);
+    // skewed inputs (the extra levels exist only for them; a last level that still folds more than kBigThresh partial sums
+    // somewhere): the one-lane-per-output kernels hand their long folds to msm_fold_big_kernel, one wave each
+    constexpr uint32_t kBigThresh = 4;
+    const bool big_mode = gs == 1 && c.tune_fold_big && tmax > kBigThresh;
+    uint32_t* big_count = sm + 3904;
+    BigFold* big_list = nullptr;
+    if (big_mode) {
+        UZK_TRY(m.big.reserve((size_t)(g.bound0 / G + g.TBK + 1) * sizeof(BigFold)));       // every output of a level could be listed
+        big_list = m.big.as<BigFold>();
+    }
     int lvl = 0;
     uint64_t bound_prev = g.bound0;
     while (tmax > G) {
@@ -2195,13 +2242,17 @@ static int msm_group_phase2(Ctx& c, MsmGroup& g, bool accumulate = false, bool r
             const dim3 grid((unsigned)((bound_nx * gs + 255) / 256));
             if (gs == 16)
                 hipLaunchKernelGGL(msm_combine_kernel<16>, grid, dim3(256), 0, st, g.part_cur, g.cnt_cur, g.off_cur, g.base_cur,
-                                   off_nx, base_nx, part_nx, g.NB, g.Wd, G);
+                                   off_nx, base_nx, part_nx, g.NB, g.Wd, G, (uint32_t*)nullptr, (BigFold*)nullptr, 0u);
             else if (gs == 4)
                 hipLaunchKernelGGL(msm_combine_kernel<4>, grid, dim3(256), 0, st, g.part_cur, g.cnt_cur, g.off_cur, g.base_cur,
-                                   off_nx, base_nx, part_nx, g.NB, g.Wd, G);
-            else
+                                   off_nx, base_nx, part_nx, g.NB, g.Wd, G, (uint32_t*)nullptr, (BigFold*)nullptr, 0u);
+            else {
+                if (big_mode) UZK_HIP(hipMemsetAsync(big_count, 0, 4, st));
                 hipLaunchKernelGGL(msm_combine_kernel<1>, grid, dim3(256), 0, st, g.part_cur, g.cnt_cur, g.off_cur, g.base_cur,
-                                   off_nx, base_nx, part_nx, g.NB, g.Wd, G);
+                                   off_nx, base_nx, part_nx, g.NB, g.Wd, G, big_count, big_list, kBigThresh);
+                if (big_mode)
+                    hipLaunchKernelGGL(msm_fold_big_kernel, dim3(2048), dim3(64), 0, st, g.part_cur, big_count, big_list, part_nx, 0);
+            }
         }
         g.cnt_cur = cnt_nx; g.off_cur = off_nx; g.base_cur = base_nx; g.part_cur = part_nx;
         bound_prev = bound_nx;
@@ -2213,13 +2264,18 @@ static int msm_group_phase2(Ctx& c, MsmGroup& g, bool accumulate = false, bool r
         const dim3 grid((unsigned)((g.TBK * gs + 255) / 256));
         if (gs == 16)
             hipLaunchKernelGGL(msm_finalize_kernel<16>, grid, dim3(256), 0, st, g.part_cur, g.cnt_cur, g.off_cur, g.base_cur,
-                               buckets, g.NB, g.Wd, accumulate ? 1 : 0);
+                               buckets, g.NB, g.Wd, accumulate ? 1 : 0, (uint32_t*)nullptr, (BigFold*)nullptr, 0u);
         else if (gs == 4)
             hipLaunchKernelGGL(msm_finalize_kernel<4>, grid, dim3(256), 0, st, g.part_cur, g.cnt_cur, g.off_cur, g.base_cur,
-                               buckets, g.NB, g.Wd, accumulate ? 1 : 0);
-        else
+                               buckets, g.NB, g.Wd, accumulate ? 1 : 0, (uint32_t*)nullptr, (BigFold*)nullptr, 0u);
+        else {
+            const bool big_last = big_mode && tmax > kBigThresh;
+            if (big_last) UZK_HIP(hipMemsetAsync(big_count, 0, 4, st));
             hipLaunchKernelGGL(msm_finalize_kernel<1>, grid, dim3(256), 0, st, g.part_cur, g.cnt_cur, g.off_cur, g.base_cur,
-                               buckets, g.NB, g.Wd, accumulate ? 1 : 0);
+                               buckets, g.NB, g.Wd, accumulate ? 1 : 0, big_count, big_last ? big_list : (BigFold*)nullptr, kBigThresh);
+            if (big_last)
+                hipLaunchKernelGGL(msm_fold_big_kernel, dim3(2048), dim3(64), 0, st, g.part_cur, big_count, big_list, buckets, accumulate ? 1 : 0);
+        }
     }
     if (!reduce) { UZK_HIP(hipGetLastError()); return UZK_OK; }
     if (g.class_s) {
