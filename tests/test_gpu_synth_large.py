@@ -240,3 +240,31 @@ def test_segment_sort_skewed_segments(gpu, cfg, chunk, fold_big):
         srs.release()
     k = weighted_index_sum(host)
     assert got == opy.g1_mul(opy.g1_mul(opy.G1_GEN, seed_int), k)
+
+
+@pytest.mark.parametrize("log_n,batch", [(17, 3), (19, 2)])
+def test_batched_general_pipeline_closed_form(gpu, log_n, batch):
+    """uzk_msm_g1_batch_device above the small pipeline's sizes: `batch` vectors through one launch sequence of the general
+    pipeline (batch * W sort segments per pass, 2 * batch * W logical windows in the class-sum reduction); every vector against
+    the closed form and against its own single call."""
+    n = 1 << log_n
+    pts = torch.empty((n, 8), dtype=torch.int64, device="cuda")
+    sc = torch.empty((batch * n, 4), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    seed_int = 0xBA7C4ED
+    gpu.synth_points_arith(pts.data_ptr(), n, oc.fr_from_ints([seed_int])[0])
+    for k in range(batch):
+        if k == 1:
+            gpu.synth_scalars_mix(sc.data_ptr() + k * n * 32, n, 50 + k)
+        else:
+            gpu.synth_scalars(sc.data_ptr() + k * n * 32, n, 50 + k)
+    srs = gpu.Srs.from_device(pts.data_ptr(), n)
+    try:
+        outs = [affine_of(j) for j in gpu.msm_batch_device(srs, sc.data_ptr(), n, batch)]
+        singles = [affine_of(gpu.msm_device(srs, sc.data_ptr() + k * n * 32, n)) for k in range(batch)]
+    finally:
+        srs.release()
+    q = opy.g1_mul(opy.G1_GEN, seed_int)
+    host = _wire(sc).reshape(batch, n, 4)
+    for k in range(batch):
+        assert outs[k] == singles[k] == opy.g1_mul(q, weighted_index_sum(host[k])), k
