@@ -694,9 +694,12 @@ __global__ __launch_bounds__(1024) void msm_scan_win_kernel(const uint32_t* __re
                                                             uint32_t* __restrict__ v_out,
                                                             uint32_t* __restrict__ off_out,
                                                             uint32_t* __restrict__ win_total,
-                                                            uint32_t* __restrict__ max_out, uint32_t NB) {
+                                                            uint32_t* __restrict__ max_out, uint32_t NB,
+                                                            uint32_t* __restrict__ len_hist = nullptr) {
     __shared__ uint32_t part[1024];
+    __shared__ uint32_t lh[256];
     extern __shared__ uint32_t stage[];
+    if (len_hist != nullptr) { if (threadIdx.x < 256) lh[threadIdx.x] = 0; __syncthreads(); }
     const uint32_t w = blockIdx.x, tid = threadIdx.x;
     const uint32_t per = (NB + 1023) / 1024;
     const uint32_t lo = min(NB, tid * per), hi = min(NB, lo + per);
@@ -715,9 +718,18 @@ __global__ __launch_bounds__(1024) void msm_scan_win_kernel(const uint32_t* __re
     for (uint32_t i = tid; i < NB; i += 1024) {
         const uint32_t c = cnt[i];
         mx = max(mx, c);
-        stage[pad(i)] = val(c);
+        const uint32_t T = val(c);
+        stage[pad(i)] = T;
+        // level 0 (div = task length): the bucket's T tasks are r of q + 1 points and T - r of q (balanced split, task_extent):
+        // their lengths go into the schedule's histogram here, in O(1) per bucket whatever T is
+        if (len_hist != nullptr && c != 0) {
+            const uint32_t q = c / T, r = c - q * T;
+            if (r) atomicAdd(&lh[min(q + 1, 255u)], r);
+            atomicAdd(&lh[min(q, 255u)], T - r);
+        }
     }
     __syncthreads();
+    if (len_hist != nullptr && tid < 256 && lh[tid]) atomicAdd(&len_hist[tid], lh[tid]);
     uint32_t s = 0;
     for (uint32_t b = lo; b < hi; ++b) s += stage[pad(b)];
     part[tid] = s;
@@ -874,6 +886,83 @@ __global__ __launch_bounds__(256) void msm_task_fill_kernel(const uint32_t* __re
         TaskDesc d;
         d.start = start; d.cnt = cnt; d.task = tid; d.pad = 0;
         desc[base[key] + rank] = d;
+    }
+}
+
+// The same schedule without a search per task (round 3): one lane per BUCKET.  A bucket's tasks are two runs of equal lengths
+// (r of q + 1 points, T - r of q), so the lane reserves two ranges of the schedule (LDS-aggregated counters, as above) and
+// writes its descriptors; task ids are win_base[w] + task_off[bucket] + j as everywhere.  Buckets with more than kFillInline
+// tasks (skewed scalars) are appended to a list and written by one wave each (msm_task_fill_big_kernel).  The histogram of
+// the lengths comes from msm_scan_win_kernel.  Replaces msm_task_hist_kernel + msm_task_fill_kernel (one binary search over
+// the window's 2^15 prefixes per task, twice: 0.18 ms at 2^24).
+constexpr uint32_t kFillInline = 4;
+struct BigBucket { uint32_t start, total, T, tid0; };
+__global__ __launch_bounds__(256) void msm_bucket_fill_kernel(const uint32_t* __restrict__ win_base, const uint32_t* __restrict__ task_cnt,
+                                                              const uint32_t* __restrict__ task_off,
+                                                              const uint32_t* __restrict__ bucket_start,
+                                                              const uint32_t* __restrict__ bucket_count, uint32_t NB, uint64_t TBK,
+                                                              uint32_t* __restrict__ cursor, TaskDesc* __restrict__ desc,
+                                                              uint32_t* __restrict__ big_count, BigBucket* __restrict__ big) {
+    __shared__ uint32_t h[kLenBins], base[kLenBins];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t T = 0, total = 0, q = 0, r = 0, start = 0, tid0 = 0, rank_hi = 0, rank_lo = 0;
+    bool inline_fill = false;
+    if (t < TBK) {
+        T = task_cnt[t];
+        if (T != 0) {
+            total = bucket_count[t];
+            start = bucket_start[t];
+            tid0 = win_base[t / NB] + task_off[t];
+            q = total / T; r = total - q * T;
+            if (T <= kFillInline) {
+                inline_fill = true;
+                if (r) rank_hi = atomicAdd(&h[min(q + 1, kLenBins - 1)], r);
+                rank_lo = atomicAdd(&h[min(q, kLenBins - 1)], T - r);
+            } else {
+                BigBucket e; e.start = start; e.total = total; e.T = T; e.tid0 = tid0;
+                big[atomicAdd(big_count, 1u)] = e;
+            }
+        }
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], h[threadIdx.x]);
+    __syncthreads();
+    if (inline_fill) {
+        const uint32_t p_hi = base[min(q + 1, kLenBins - 1)] + rank_hi, p_lo = base[min(q, kLenBins - 1)] + rank_lo;
+        for (uint32_t j = 0; j < T; ++j) {
+            TaskDesc d;
+            d.start = start + j * q + min(j, r);
+            d.cnt = q + (j < r ? 1u : 0u);
+            d.task = tid0 + j;
+            d.pad = 0;
+            desc[j < r ? p_hi + j : p_lo + (j - r)] = d;
+        }
+    }
+}
+// one wave per listed bucket (grid-stride; the list is normally empty)
+__global__ __launch_bounds__(64) void msm_task_fill_big_kernel(const uint32_t* __restrict__ big_count, const BigBucket* __restrict__ big,
+                                                               uint32_t* __restrict__ cursor, TaskDesc* __restrict__ desc) {
+    const uint32_t n_big = *big_count, lane = threadIdx.x;
+    for (uint32_t i = blockIdx.x; i < n_big; i += gridDim.x) {
+        const BigBucket e = big[i];
+        const uint32_t q = e.total / e.T, r = e.total - q * e.T;
+        uint32_t p_hi = 0, p_lo = 0;
+        if (lane == 0) {
+            if (r) p_hi = atomicAdd(&cursor[min(q + 1, kLenBins - 1)], r);
+            p_lo = atomicAdd(&cursor[min(q, kLenBins - 1)], e.T - r);
+        }
+        p_hi = (uint32_t)__shfl((int)p_hi, 0);
+        p_lo = (uint32_t)__shfl((int)p_lo, 0);
+        for (uint32_t j = lane; j < e.T; j += 64) {
+            TaskDesc d;
+            d.start = e.start + j * q + min(j, r);
+            d.cnt = q + (j < r ? 1u : 0u);
+            d.task = e.tid0 + j;
+            d.pad = 0;
+            desc[j < r ? p_hi + j : p_lo + (j - r)] = d;
+        }
     }
 }
 
@@ -2148,17 +2237,29 @@ static int msm_group_phase1(Ctx& c, MsmGroup& g, const Affine* points, const Sca
     g.off_cur = m.lvl_off[0].as<uint32_t>();
     g.base_cur = sm + 1024;
     g.part_cur = m.lvl_part[0].as<XYZZ>();
+    uint32_t* len_hist = sm + 3328;
+    uint32_t* len_cur = sm + 3328 + kLenBins;
+    const bool bucket_fill = c.tune_bucket_fill != 0;
     {
         KernelScope ks(c, "msm_scan_win");
+        if (bucket_fill) UZK_HIP(hipMemsetAsync(len_hist, 0, kLenBins * 4, st));
         hipLaunchKernelGGL(msm_scan_win_kernel, dim3(g.Wd), dim3(1024), scan_win_lds(g.NB), st, bcount, g.L, g.cnt_cur, g.off_cur, win_tot,
-                           d_max, g.NB);
+                           d_max, g.NB, bucket_fill ? len_hist : (uint32_t*)nullptr);
         hipLaunchKernelGGL(msm_win_base_kernel, dim3(1), dim3(1024), 0, st, win_tot, g.base_cur, g.Wd);
     }
     TaskDesc* desc = m.task_desc.as<TaskDesc>();
-    {
+    if (bucket_fill) {
+        // one lane per bucket; the lengths' histogram came out of msm_scan_win_kernel
         KernelScope ks(c, "msm_task_order");
-        uint32_t* len_hist = sm + 3328;
-        uint32_t* len_cur = sm + 3328 + kLenBins;
+        uint32_t* big_count = sm + 3908;
+        UZK_TRY(m.big.reserve((size_t)(g.TBK + 1) * sizeof(BigBucket)));        // (shared with the fold lists of phase 2)
+        UZK_HIP(hipMemsetAsync(big_count, 0, 4, st));
+        hipLaunchKernelGGL(msm_task_scan_kernel, dim3(1), dim3(256), 0, st, len_hist, len_cur);
+        hipLaunchKernelGGL(msm_bucket_fill_kernel, dim3((unsigned)((g.TBK + 255) / 256)), dim3(256), 0, st, g.base_cur, g.cnt_cur, g.off_cur,
+                           bstart, bcount, g.NB, g.TBK, len_cur, desc, big_count, m.big.as<BigBucket>());
+        hipLaunchKernelGGL(msm_task_fill_big_kernel, dim3(1024), dim3(64), 0, st, big_count, m.big.as<BigBucket>(), len_cur, desc);
+    } else {
+        KernelScope ks(c, "msm_task_order");
         UZK_HIP(hipMemsetAsync(len_hist, 0, kLenBins * 4, st));
         const dim3 tgrid((unsigned)((g.bound0 + 255) / 256));
         hipLaunchKernelGGL(msm_task_hist_kernel, tgrid, dim3(256), 0, st, g.base_cur, g.Wd, g.off_cur, bstart, bcount, g.NB,
@@ -2214,6 +2315,7 @@ static int msm_group_phase2(Ctx& c, MsmGroup& g, bool accumulate = false, bool r
     // skewed inputs (the extra levels exist only for them; a last level that still folds more than kBigThresh partial sums
     // somewhere): the one-lane-per-output kernels hand their long folds to msm_fold_big_kernel, one wave each
     constexpr uint32_t kBigThresh = 4;
+    static_assert(sizeof(BigFold) == sizeof(BigBucket), "the two lists share one buffer");
     const bool big_mode = gs == 1 && c.tune_fold_big && tmax > kBigThresh;
     uint32_t* big_count = sm + 3904;
     BigFold* big_list = nullptr;
