@@ -19,10 +19,10 @@ KNOBS = [
     # round 3: segment / chunk sort kernels and the class-sum reduction, off one at a time and at window widths on either side
     {"msm_seg_sort": 0}, {"msm_chunk_sort": 0}, {"msm_class_reduce": 0}, {"msm_class_reduce": 0, "window_bits": 13}, {"window_bits": 13},
     {"window_bits": 14}, {"window_bits": 18}, {"window_bits": 19}, {"msm_class_reduce": 0, "window_bits": 19}, {"msm_seg_sort": 15, "window_bits": 15},
-    {"msm_bucket_fill": 0}, {"msm_bucket_fill": 0, "msm_task_len": 5}, {"msm_task_len": 3}, {"msm_fold_big": 0, "msm_task_len": 2},
+    {"msm_bucket_fill": 0}, {"msm_bucket_fill": 0, "msm_task_len": 5}, {"msm_task_len": 3}, {"msm_fold_big": 0, "msm_task_len": 2}, {"msm_direct": 0}, {"msm_direct": 0, "msm_task_len": 2}, {"msm_acc_variant": 1, "msm_task_len": 40},
 ]
 DEFAULTS = {"msm_small": 1, "msm_fold_mode": 0, "msm_acc_variant": 0, "msm_sort_packed": 1, "msm_fused_hist": 1, "msm_scan_reduce": 1, "msm_quad_reduce": 1, "msm_x29": 1, "msm_reduce_seg": 0,
-            "msm_task_len": 0, "msm_fold_group": 0, "window_bits": 0, "msm_seg_sort": 1, "msm_chunk_sort": 1, "msm_class_reduce": 1, "msm_bucket_fill": 1, "msm_fold_big": 1}
+            "msm_task_len": 0, "msm_fold_group": 0, "window_bits": 0, "msm_seg_sort": 1, "msm_chunk_sort": 1, "msm_class_reduce": 1, "msm_bucket_fill": 1, "msm_fold_big": 1, "msm_direct": 1}
 
 
 def _apply(gpu, cfg):

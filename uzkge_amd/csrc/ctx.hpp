@@ -105,6 +105,7 @@ struct Ctx {
     int tune_scan_nb_log = 15; // log2 of the bucket windows of the task scans (msm_scan_win: one workgroup per window)
     int tune_fold_big = 1;    // 1: outputs that fold many partial sums (skewed scalars) take one wave each (msm_fold_big_kernel)
     int tune_bucket_fill = 1; // 1: the task schedule is written by one lane per bucket (msm_bucket_fill_kernel), 0: one search per task
+    int tune_direct = 1;      // 1: a bucket that is one task is written by the accumulator itself (msm.hip task_dst)
     int tune_scatter4 = 0;    // experiment: large packed sorts scatter 8192-entry tiles of 4-byte words (msm_radix_scatter4_kernel): measured slower
     int tune_overlap = 0;     // 1: run large MSMs as two overlapping pipeline instances (experiment)  // 1: force one lane per bucket in the fold kernels
     // poly.hip workspaces (grow-only)

@@ -902,7 +902,7 @@ __global__ __launch_bounds__(256) void msm_bucket_fill_kernel(const uint32_t* __
                                                               const uint32_t* __restrict__ bucket_start,
                                                               const uint32_t* __restrict__ bucket_count, uint32_t NB, uint64_t TBK,
                                                               uint32_t* __restrict__ cursor, TaskDesc* __restrict__ desc,
-                                                              uint32_t* __restrict__ big_count, BigBucket* __restrict__ big) {
+                                                              uint32_t* __restrict__ big_count, BigBucket* __restrict__ big, uint32_t direct) {
     __shared__ uint32_t h[kLenBins], base[kLenBins];
     h[threadIdx.x] = 0;
     __syncthreads();
@@ -935,7 +935,7 @@ __global__ __launch_bounds__(256) void msm_bucket_fill_kernel(const uint32_t* __
             TaskDesc d;
             d.start = start + j * q + min(j, r);
             d.cnt = q + (j < r ? 1u : 0u);
-            d.task = tid0 + j;
+            d.task = (direct && T == 1) ? (kSignBit | (uint32_t)t) : tid0 + j;     // a one-task bucket's sum IS the bucket
             d.pad = 0;
             desc[j < r ? p_hi + j : p_lo + (j - r)] = d;
         }
@@ -966,12 +966,17 @@ __global__ __launch_bounds__(64) void msm_task_fill_big_kernel(const uint32_t* _
     }
 }
 
+// Where a task's sum goes: its slot among the partial sums, or -- a bucket that is ONE task (msm_bucket_fill_kernel marks it with
+// the top bit when the launch sequence allows) -- straight into the bucket array, so that msm_finalize has nothing to copy for it.
+__device__ __forceinline__ XYZZ& task_dst(XYZZ* __restrict__ partials, XYZZ* __restrict__ direct, uint32_t task) {
+    return (task & kSignBit) ? direct[task & ~kSignBit] : partials[task];
+}
 template <int MINW, bool RELAXED>
 __global__ __launch_bounds__(256, MINW) void msm_accumulate_kernel(const Affine* __restrict__ points,
                                                              const uint32_t* __restrict__ sorted,
                                                              const TaskDesc* __restrict__ desc,
                                                              const uint32_t* __restrict__ win_base,
-                                                             XYZZ* __restrict__ partials, uint32_t W) {
+                                                             XYZZ* __restrict__ partials, uint32_t W, XYZZ* __restrict__ direct = nullptr) {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= win_base[W]) return;
     const TaskDesc d = desc[slot];
@@ -991,7 +996,7 @@ __global__ __launch_bounds__(256, MINW) void msm_accumulate_kernel(const Affine*
         else xyzz_madd(acc, cur, neg);
     }
     if constexpr (RELAXED) xyzz_canon(acc);
-    partials[d.task] = acc;
+    task_dst(partials, direct, d.task) = acc;
 }
 
 // The same loop on the 29-bit-limb accumulator (ec29.hpp).  A task whose additions degenerate
@@ -1003,7 +1008,7 @@ __global__ __launch_bounds__(256, 4) void msm_accumulate29_kernel(const Affine* 
                                                                   const uint32_t* __restrict__ win_base,
                                                                   XYZZ* __restrict__ partials, uint32_t W,
                                                                   uint32_t* __restrict__ exc_count,
-                                                                  uint32_t* __restrict__ exc_list) {
+                                                                  uint32_t* __restrict__ exc_list, XYZZ* __restrict__ direct = nullptr) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= win_base[W]) return;
@@ -1025,7 +1030,7 @@ __global__ __launch_bounds__(256, 4) void msm_accumulate29_kernel(const Affine* 
             return;
         }
     }
-    partials[d.task] = acc29_to_xyzz(acc);
+    task_dst(partials, direct, d.task) = acc29_to_xyzz(acc);
 #endif
 }
 // Tasks the fast kernel gave up on, redone from scratch with the complete canonical group law.
@@ -1034,7 +1039,7 @@ __global__ __launch_bounds__(256) void msm_accumulate_exc_kernel(const Affine* _
                                                                  const TaskDesc* __restrict__ desc,
                                                                  XYZZ* __restrict__ partials,
                                                                  const uint32_t* __restrict__ exc_count,
-                                                                 const uint32_t* __restrict__ exc_list) {
+                                                                 const uint32_t* __restrict__ exc_list, XYZZ* __restrict__ direct = nullptr) {
     const uint32_t total = *exc_count;                      // grid-stride: any grid size covers the whole list
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const TaskDesc d = desc[exc_list[i]];
@@ -1044,7 +1049,7 @@ __global__ __launch_bounds__(256) void msm_accumulate_exc_kernel(const Affine* _
             const uint32_t e = run[k];
             xyzz_madd(acc, load_point(points, e & ~kSignBit), (e & kSignBit) != 0);
         }
-        partials[d.task] = acc;
+        task_dst(partials, direct, d.task) = acc;
     }
 }
 
@@ -1131,13 +1136,15 @@ __global__ __launch_bounds__(256) void msm_finalize_kernel(const XYZZ* __restric
                                                            const uint32_t* __restrict__ in_off,
                                                            const uint32_t* __restrict__ in_base,
                                                            XYZZ* __restrict__ buckets, uint32_t NB, uint32_t W, int accumulate,
-                                                           uint32_t* __restrict__ big_count, BigFold* __restrict__ big, uint32_t big_thresh) {
+                                                           uint32_t* __restrict__ big_count, BigFold* __restrict__ big, uint32_t big_thresh,
+                                                           int skip_single) {
     const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t t = gt / GS;
     const uint32_t sub = (uint32_t)(gt % GS);
     if (t >= (size_t)W * NB) return;
     const uint32_t w = (uint32_t)(t / NB);
     const uint32_t cnt = in_cnt[t];
+    if (skip_single && cnt == 1) return;                          // the accumulator wrote this bucket itself (task_dst)
     if (GS == 1 && big != nullptr && cnt > big_thresh) {          // msm_fold_big_kernel writes (or adds onto) this bucket
         BigFold e; e.src = in_base[w] + in_off[t]; e.cnt = cnt; e.dst = (uint32_t)t; e.pad = 0;
         big[atomicAdd(big_count, 1u)] = e;
@@ -1149,6 +1156,16 @@ __global__ __launch_bounds__(256) void msm_finalize_kernel(const XYZZ* __restric
         if (accumulate && cnt != 0) { XYZZ prev = buckets[t]; xyzz_add(prev, acc); buckets[t] = prev; }
         else if (!accumulate) buckets[t] = acc;
     }
+}
+
+// Skewed inputs need extra fold levels, which re-materialise EVERY bucket's partial sums level by level: the sums the accumulator
+// wrote straight into the bucket array go back to their slots first (one copy per one-task bucket; only ever runs for such inputs).
+__global__ __launch_bounds__(256) void msm_undirect_kernel(const XYZZ* __restrict__ buckets, const uint32_t* __restrict__ cnt,
+                                                           const uint32_t* __restrict__ off, const uint32_t* __restrict__ base,
+                                                           XYZZ* __restrict__ partials, uint32_t NB, uint64_t TBK) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= TBK || cnt[t] != 1) return;
+    partials[base[t / NB] + off[t]] = buckets[t];
 }
 
 // ---- 6. bucket reduction ------------------------------------------------------------------------
@@ -1969,6 +1986,7 @@ struct MsmGroup {
     uint32_t kb = 0, NBL = 0, S0 = 0, seg_n = 0, NB = 0, Wd = 0, RW = 0, seg = 0, groups = 0, L = 0;
     int P = 0;
     bool scan_reduce = false, quad_reduce = false;
+    bool direct = false;                                    // one-task buckets were written by the accumulator itself (task_dst)
     uint32_t class_s = 0, nb2 = 0;                          // > 0: class-sum reduction (msm_class_sums_kernel), 2 * nb2 class sums per window
     uint32_t rl = 256;                                      // reduction lanes (quads) per workgroup
     uint32_t pk_bits = 0;   // > 0: 4-byte packed entries between the two sort passes (index bits)
@@ -2100,8 +2118,9 @@ static int msm_group_plan(Ctx& c, MsmGroup& g, size_t n, uint32_t batch, int cb,
 
 // Phase 1 (asynchronous on g.st): digits, sort, task schedule, bucket accumulation, copy of the
 // largest bucket population to the host.
+// `direct_ok`: phase 2 will WRITE the bucket array (not add onto an earlier chunk's), so one-task buckets may be written here
 static int msm_group_phase1(Ctx& c, MsmGroup& g, const Affine* points, const ScalarView& d_scalars, uint32_t pre_stride,
-                            uint32_t pre_off) {
+                            uint32_t pre_off, bool direct_ok = true) {
     MsmWork& m = *g.m;
     hipStream_t st = g.st;
     c.cur_stream = st;
@@ -2240,6 +2259,8 @@ static int msm_group_phase1(Ctx& c, MsmGroup& g, const Affine* points, const Sca
     uint32_t* len_hist = sm + 3328;
     uint32_t* len_cur = sm + 3328 + kLenBins;
     const bool bucket_fill = c.tune_bucket_fill != 0;
+    g.direct = bucket_fill && direct_ok && c.tune_direct;
+    XYZZ* direct_buckets = g.direct ? m.buckets.as<XYZZ>() : nullptr;
     {
         KernelScope ks(c, "msm_scan_win");
         if (bucket_fill) UZK_HIP(hipMemsetAsync(len_hist, 0, kLenBins * 4, st));
@@ -2256,7 +2277,7 @@ static int msm_group_phase1(Ctx& c, MsmGroup& g, const Affine* points, const Sca
         UZK_HIP(hipMemsetAsync(big_count, 0, 4, st));
         hipLaunchKernelGGL(msm_task_scan_kernel, dim3(1), dim3(256), 0, st, len_hist, len_cur);
         hipLaunchKernelGGL(msm_bucket_fill_kernel, dim3((unsigned)((g.TBK + 255) / 256)), dim3(256), 0, st, g.base_cur, g.cnt_cur, g.off_cur,
-                           bstart, bcount, g.NB, g.TBK, len_cur, desc, big_count, m.big.as<BigBucket>());
+                           bstart, bcount, g.NB, g.TBK, len_cur, desc, big_count, m.big.as<BigBucket>(), g.direct ? 1u : 0u);
         hipLaunchKernelGGL(msm_task_fill_big_kernel, dim3(1024), dim3(64), 0, st, big_count, m.big.as<BigBucket>(), len_cur, desc);
     } else {
         KernelScope ks(c, "msm_task_order");
@@ -2273,19 +2294,19 @@ static int msm_group_phase1(Ctx& c, MsmGroup& g, const Affine* points, const Sca
         const dim3 grid((unsigned)((g.bound0 + 255) / 256));
         if (c.tune_acc_variant == 1)        // canonical arithmetic throughout (cross-check of the other loops)
             hipLaunchKernelGGL((msm_accumulate_kernel<1, false>), grid, dim3(256), 0, st, points, sorted, desc, g.base_cur,
-                               g.part_cur, g.Wd);
+                               g.part_cur, g.Wd, direct_buckets);
         else if (c.tune_acc_variant == 0) { // default: 29-bit-limb accumulator + (normally empty) exception pass
             uint32_t* exc_count = sm + 3900;
             uint32_t* exc_list = m.exc.as<uint32_t>();
             UZK_HIP(hipMemsetAsync(exc_count, 0, 4, st));
             hipLaunchKernelGGL(msm_accumulate29_kernel, grid, dim3(256), 0, st, points, sorted, desc, g.base_cur, g.part_cur,
-                               g.Wd, exc_count, exc_list);
+                               g.Wd, exc_count, exc_list, direct_buckets);
             hipLaunchKernelGGL(msm_accumulate_exc_kernel, grid, dim3(256), 0, st, points, sorted, desc, g.part_cur,
-                               exc_count, exc_list);
+                               exc_count, exc_list, direct_buckets);
         }
         else                                // 2: 8 x 32-bit relaxed Montgomery
             hipLaunchKernelGGL((msm_accumulate_kernel<1, true>), grid, dim3(256), 0, st, points, sorted, desc, g.base_cur,
-                               g.part_cur, g.Wd);
+                               g.part_cur, g.Wd, direct_buckets);
     }
     UZK_HIP(hipGetLastError());
     // the largest bucket decides how many fold levels are needed (one tiny read-back)
@@ -2323,6 +2344,14 @@ static int msm_group_phase2(Ctx& c, MsmGroup& g, bool accumulate = false, bool r
         UZK_TRY(m.big.reserve((size_t)(g.bound0 / G + g.TBK + 1) * sizeof(BigFold)));       // every output of a level could be listed
         big_list = m.big.as<BigFold>();
     }
+    if (g.direct && tmax > G) {          // extra levels ahead: the directly written one-task sums go back among the partial sums
+        KernelScope ks(c, "msm_combine");
+        hipLaunchKernelGGL(msm_undirect_kernel, dim3((unsigned)((g.TBK + 255) / 256)), dim3(256), 0, st, buckets, g.cnt_cur, g.off_cur,
+                           g.base_cur, g.part_cur, g.NB, g.TBK);
+        g.direct = false;
+    }
+    if (accumulate && g.direct) { set_error("msm: direct bucket writes in an accumulating chunk (internal error)"); return UZK_ERR_DEVICE; }
+    const int skip_single = g.direct ? 1 : 0;
     int lvl = 0;
     uint64_t bound_prev = g.bound0;
     while (tmax > G) {
@@ -2366,15 +2395,15 @@ static int msm_group_phase2(Ctx& c, MsmGroup& g, bool accumulate = false, bool r
         const dim3 grid((unsigned)((g.TBK * gs + 255) / 256));
         if (gs == 16)
             hipLaunchKernelGGL(msm_finalize_kernel<16>, grid, dim3(256), 0, st, g.part_cur, g.cnt_cur, g.off_cur, g.base_cur,
-                               buckets, g.NB, g.Wd, accumulate ? 1 : 0, (uint32_t*)nullptr, (BigFold*)nullptr, 0u);
+                               buckets, g.NB, g.Wd, accumulate ? 1 : 0, (uint32_t*)nullptr, (BigFold*)nullptr, 0u, skip_single);
         else if (gs == 4)
             hipLaunchKernelGGL(msm_finalize_kernel<4>, grid, dim3(256), 0, st, g.part_cur, g.cnt_cur, g.off_cur, g.base_cur,
-                               buckets, g.NB, g.Wd, accumulate ? 1 : 0, (uint32_t*)nullptr, (BigFold*)nullptr, 0u);
+                               buckets, g.NB, g.Wd, accumulate ? 1 : 0, (uint32_t*)nullptr, (BigFold*)nullptr, 0u, skip_single);
         else {
             const bool big_last = big_mode && tmax > kBigThresh;
             if (big_last) UZK_HIP(hipMemsetAsync(big_count, 0, 4, st));
             hipLaunchKernelGGL(msm_finalize_kernel<1>, grid, dim3(256), 0, st, g.part_cur, g.cnt_cur, g.off_cur, g.base_cur,
-                               buckets, g.NB, g.Wd, accumulate ? 1 : 0, big_count, big_last ? big_list : (BigFold*)nullptr, kBigThresh);
+                               buckets, g.NB, g.Wd, accumulate ? 1 : 0, big_count, big_last ? big_list : (BigFold*)nullptr, kBigThresh, skip_single);
             if (big_last)
                 hipLaunchKernelGGL(msm_fold_big_kernel, dim3(2048), dim3(64), 0, st, g.part_cur, big_count, big_list, buckets, accumulate ? 1 : 0);
         }
@@ -2745,7 +2774,7 @@ int msm_run_streamed(Ctx& c, const Affine* points, const Fp* scalars_host, size_
         rc = msm_group_plan(c, g, len, 1, cb, false, W, 0, W);
         if (rc != UZK_OK) break;
         if (hipStreamWaitEvent(c.stream, up_done[s], 0) != hipSuccess) { rc = UZK_ERR_DEVICE; set_error("msm: stream wait failed"); break; }
-        { HostScope hs(c, "host_msm_enqueue1"); rc = msm_group_phase1(c, g, points + lo, ScalarView::dense(stage[s], len), 0, 0); }
+        { HostScope hs(c, "host_msm_enqueue1"); rc = msm_group_phase1(c, g, points + lo, ScalarView::dense(stage[s], len), 0, 0, /*direct_ok*/ k == 0); }
         if (rc != UZK_OK) break;
         // phase 1 is queued: its first kernel (digits) is the only reader of the staging half.  Marking the half free after the
         // whole phase is simpler than an event in the middle of it and costs nothing: the next upload into this half is two
@@ -2783,7 +2812,7 @@ int msm_run_chunked(Ctx& c, const Affine* points, const Fp* d_scalars, size_t n,
         const size_t len = std::min(chunk, n - lo);
         rc = msm_group_plan(c, g, len, 1, cb, false, W, 0, W);
         if (rc != UZK_OK) break;
-        { HostScope hs(c, "host_msm_enqueue1"); rc = msm_group_phase1(c, g, points + lo, ScalarView::dense(d_scalars + lo, len), 0, 0); }
+        { HostScope hs(c, "host_msm_enqueue1"); rc = msm_group_phase1(c, g, points + lo, ScalarView::dense(d_scalars + lo, len), 0, 0, /*direct_ok*/ k == 0); }
         if (rc != UZK_OK) break;
         { HostScope hs(c, "host_msm_wait1_enqueue2"); rc = msm_group_phase2(c, g, /*accumulate*/ k > 0, /*reduce*/ lo + len >= n); }
     }
