@@ -1333,7 +1333,7 @@ __global__ __launch_bounds__(256) void msm_fold_scan_kernel(const XYZZ* __restri
 // the two sums of a window with its doublings split c - s | s (host_ec64.hpp horner_split).
 // grid (tiles, logical windows, 2): z = 0 rows, z = 1 columns; a tile = 2048 buckets: 8 rows, or 2048 / H columns of all H
 // rows.  out: [window][2][nb2] with rows at index h - 1 (weight h; R_0 has weight 0 and is dropped) and columns at l.
-__global__ __launch_bounds__(256) void msm_class_sums_kernel(const XYZZ* __restrict__ buckets, XYZZ* __restrict__ out, uint32_t nbk,
+__global__ __launch_bounds__(256, 3) void msm_class_sums_kernel(const XYZZ* __restrict__ buckets, XYZZ* __restrict__ out, uint32_t nbk,
                                                               uint32_t log_s, uint32_t nb2) {
     __shared__ XYZZ sh[256];
     const uint32_t tile = blockIdx.x, w = blockIdx.y, cols = blockIdx.z, t = threadIdx.x;
