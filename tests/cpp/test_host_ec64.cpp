@@ -102,6 +102,27 @@ int main() {
         for (auto& x : s) x = xyzz_inf();
         EXPECT(Fq::is_zero(h64::horner((uint32_t)W, c, [&](uint32_t w) -> const XYZZ& { return s[w]; }).z));
     }
+    // horner_split (class-sum reduction): window w arrives as hi(w), lo(w) with value 2^s hi + lo; the split chain must equal
+    // the plain Horner over the combined window sums, for every width the general pipeline picks and a pre-mode single window
+    for (int c : {15, 16, 17, 18, 19}) {
+        const int s8 = 8;
+        const int W = (254 + c - 1) / c + 1;
+        std::vector<XYZZ> hi(W), lo(W), comb(W);
+        for (int w = 0; w < W; ++w) {
+            hi[w] = (g() % 6 == 0) ? xyzz_inf() : scalar_mul(g1, g());
+            lo[w] = (g() % 6 == 0) ? xyzz_inf() : scalar_mul(g1, g());
+            XYZZ t = hi[w];
+            for (int d = 0; d < s8; ++d) t = xyzz_dbl(t);
+            xyzz_add(t, lo[w]);
+            comb[w] = t;
+        }
+        if (W > 3) { hi[2] = lo[2]; XYZZ t = hi[2]; for (int d = 0; d < s8; ++d) t = xyzz_dbl(t); xyzz_add(t, lo[2]); comb[2] = t; }
+        EXPECT(same_point(h64::horner_split((uint32_t)W, c, s8, [&](uint32_t w) -> const XYZZ& { return hi[w]; },
+                                            [&](uint32_t w) -> const XYZZ& { return lo[w]; }), horner_ref(comb, c)));
+        // one logical window (window-table mode): 2^s hi + lo
+        EXPECT(same_point(h64::horner_split(1u, c, s8, [&](uint32_t) -> const XYZZ& { return hi[0]; },
+                                            [&](uint32_t) -> const XYZZ& { return lo[0]; }), xyzz_to_jac(comb[0])));
+    }
     std::printf(failures ? "FAILED (%d)\n" : "OK\n", failures);
     return failures ? 1 : 0;
 }
