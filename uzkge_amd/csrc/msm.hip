@@ -5,19 +5,24 @@
 //
 // Pipeline (all on the library stream; see DESIGN.md "MSM"):
 //   1 msm_digits      scalar -> canonical (one Montgomery mul by 1) -> signed c-bit digits
-//                     d_w in [-2^(c-1), 2^(c-1)], stored [window][i] (coalesced both ways)
-//   2 msm_sort_*      counting sort of the (window, bucket) keys in 1-3 radix passes of <= 9 bits;
-//                     every pass = LDS histogram per (segment, chunk), per-segment scan, scatter
-//                     that sorts an 8192/4096-entry tile in LDS first so global stores are runs
-//   3 msm_scan_win    bucket populations -> task counts (runs of <= L points) + prefixes
+//                     d_w in [-2^(c-1), 2^(c-1)], stored [window][i] (coalesced both ways); at large n the same kernel
+//                     leaves the first sort pass's histograms
+//   2 sort            counting sort of the (window, bucket) keys, high bits first.  Two-pass sorts with 4-byte packed
+//                     entries (the large sizes) keep their unit of work in registers: msm_radix_chunk (first pass: one
+//                     workgroup per 32768-digit chunk, bins leave as runs of two lines), msm_radix_segment (last pass: one
+//                     workgroup per segment, contiguous output, bucket tables); the generic msm_radix_{hist,scan,scatter}
+//                     (LDS-tiled, work-item list) take every other shape and the over-long segments of skewed inputs
+//   3 task tables     msm_scan_win (tasks per bucket, prefixes, length histogram) -> msm_bucket_fill: runs of <= L points,
+//                     scheduled longest first, one lane per bucket
 //   4 msm_accumulate  one lane per TASK: gathers the 64-byte affine point from HBM (next point
 //                     prefetched under the current mixed add), XYZZ accumulator in VGPRs -- the
 //                     dominant kernel; buckets are split so skewed scalar sets and small n still
-//                     fill the chip and the grid has no long tail
+//                     fill the chip and the grid has no long tail; a bucket that is one task is written in place
 //   5 msm_combine /   partial sums of one bucket are folded <= 32 at a time (extra levels only
-//     msm_finalize    when one bucket holds more than 32*L points), last level writes buckets
-//   6 msm_reduce      sum_b b*B_b: short running sums per lane, double-and-add for the segment
-//                     weight, LDS tree per workgroup; msm_fold_partials adds the group results
+//     msm_finalize    when one bucket holds more than 32*L points; long folds by one wave each: msm_fold_big)
+//   6 reduction       sum_b b*B_b: class sums (rows / columns of the bucket index, plain additions: msm_class_sums), then
+//                     suffix scans + trees on quads over 2 x 256 class sums per window (msm_reduce_scan_quad); small
+//                     windows: the scans alone
 //   7 host            general mode: Horner over the W window sums (c doublings each)
 //
 // Two modes share every kernel:
