@@ -701,10 +701,12 @@ template <int B>
 static void launch_pass(Ctx& c, bool l29, bool first, const Fp* in, Fp* out, const PassArgs& a, uint64_t n, uint32_t batch) {
     constexpr int R = 1 << B, T = 2048 / R;
     const unsigned grid = (unsigned)((n / R) / T);
-    // Tiles of 1024 elements (256 threads, four workgroups per CU) below 2^20 elements in all: twice as many workgroups
+    // Tiles of 1024 elements (256 threads, four workgroups per CU) up to 2^24 elements in all: twice as many workgroups
     // on a chip the launch does not fill, shorter load / compute / store phases -- 25..32 % faster from 2^12 to 2^18 and
-    // for the prover's shapes (10 x 2^14: 36 -> 26 us, 98304 on a coset: 48 -> 34 us); equal within 2 % above.
-    const bool small_tile = c.tune_ntt_tile == 1024 || (c.tune_ntt_tile == 0 && n * (uint64_t)batch < (1ull << 20));
+    // for the prover's shapes (10 x 2^14: 36 -> 26 us, 98304 on a coset: 48 -> 34 us); re-measured at the end of round 3
+    // (tools/ab_ntt_knob.py ntt_tile 0 1024, two boxes): 2^22 413 -> 391 / 392 -> 380 us, 2^23 851 -> 813 / 828 -> 809,
+    // 2^24 1711 -> 1682 / 1682 -> 1673, 2^20 and below equal -- the finer turnover of four workgroups per CU wins there too.
+    const bool small_tile = c.tune_ntt_tile == 1024 || (c.tune_ntt_tile == 0 && n * (uint64_t)batch <= (1ull << 24));
     if (l29 && c.tune_ntt_tile == 512) {          // experiment: two waves per workgroup (uzk_tune("ntt_tile", 512))
         KernelScope ks(c, first ? "ntt_pass_first" : "ntt_pass");
         const unsigned g5 = (unsigned)((n / R) / (512 / R));
