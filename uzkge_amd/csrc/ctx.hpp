@@ -92,6 +92,7 @@ struct Ctx {
     int tune_sort_packed = 1; // 1: 4-byte entries between the two sort passes when the fields fit
     int tune_ntt_fused = 1;   // 1: coset scaling and the radix-3 stage inside the first / last pass (0: separate kernels)
     int tune_ntt_tile = 0;    // elements per workgroup of an NTT pass: 2048 (512 threads), 1024 (256 threads), 0 = by size
+    int tune_ntt_order = 0;   // experiment: the passes' radix bits as decimal digits (868 = 2^8, 2^6, 2^8); 0 = the plan's choice
     int tune_ntt_prio = 0;    // experiment: wave priorities in the NTT passes (ntt.hip ntt_prio_start / ntt_prio_step)
     int tune_ntt_l29 = 1;     // 1: NTT passes on the 29-bit-limb representation (0: 8x32-bit relaxed Montgomery)
     int tune_small = 1;       // 1: n <= 2^15 takes the one-workgroup-per-slot pipeline (msm_small_*)

@@ -593,7 +593,7 @@ static int upload(Fp** dst, const std::vector<Fp>& src, hipStream_t st) {
 
 static int get_plan(Ctx& c, uint64_t n, bool inverse, bool scaled, NttPlan** out) {
     const bool l29 = c.tune_ntt_l29 != 0;
-    const uint64_t key = (n << 3) | (inverse ? 1u : 0u) | (scaled ? 2u : 0u) | (l29 ? 4u : 0u);
+    const uint64_t key = (n << 3) | (inverse ? 1u : 0u) | (scaled ? 2u : 0u) | (l29 ? 4u : 0u) | ((uint64_t)(c.tune_ntt_order & 0xFFFF) << 44);
     auto it = c.ntt_plans.find(key);
     if (it != c.ntt_plans.end()) { *out = it->second; return UZK_OK; }
     NttPlan* p = new NttPlan();
@@ -636,6 +636,16 @@ static int get_plan(Ctx& c, uint64_t n, bool inverse, bool scaled, NttPlan** out
                             if (cst < best_cost) { best_cost = cst; for (int j = 0; j < 4; ++j) p->bits[j] = cur[j]; }
                         }
             if (best_cost == (1 << 30)) { delete p; set_error("ntt: no radix split for 2^%d", k); return UZK_ERR_FFT; }
+            // experiment (uzk_tune("ntt_order", 868) = passes of 2^8, 2^6, 2^8): the decimal digits give the passes' radix
+            // bits in order, taken only when they are 5..8 each and add up to k
+            if (c.tune_ntt_order > 0) {
+                int d[4] = {0, 0, 0, 0}, nd = 0, sum = 0, v = c.tune_ntt_order;
+                int rev[4], nr = 0;
+                while (v > 0 && nr < 4) { rev[nr++] = v % 10; v /= 10; }
+                bool ok = v == 0 && nr >= 1;
+                for (int j = nr - 1; j >= 0 && ok; --j) { d[nd++] = rev[j]; sum += rev[j]; ok = rev[j] >= 5 && rev[j] <= 8; }
+                if (ok && sum == k) { p->npass = nd; for (int j = 0; j < 4; ++j) p->bits[j] = d[j]; }
+            }
         }
         std::vector<Fp> pw;
         host_pow_tables(w, pw);
