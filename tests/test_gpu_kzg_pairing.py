@@ -42,7 +42,7 @@ def _combine(cms, vals, alpha):
     return c, v
 
 
-@pytest.mark.parametrize("n", [4096, 16384])
+@pytest.mark.parametrize("n", [4096, 8192, 16384])     # 8192: zmatchmaking's circuit size (matchmaking/src/build_cs.rs:68-99)
 def test_batch_prove_opening_verifies_under_the_reference_g2(gpu, g2, n):
     from uzkge_amd.poly_commit import FpPolynomial, KZGCommitmentSchemeBN254, batch_prove, fr_from_int, fr_to_int, load_srs_params
     pcs = load_srs_params(_blob("srs-padding.bin"), n)
