@@ -1,0 +1,271 @@
+"""TEST INFRASTRUCTURE ONLY -- the verifier's side of uzkge's TurboPlonk restated on Python integers, and a satisfiable synthetic
+circuit for the device-resident prover chain (tools/prover_chain.py).
+
+Why: the reference holds no fixture for the quotient polynomial t(X) (`t_poly`, uzkge/src/plonk/helpers.rs:223-678), the
+permutation product z(X) (`z_poly`, :160-220) or `split_t_and_commit` (:1323-1408) -- SURVEY.md section 8 rows f2 / f4 / a8.  What the
+reference does hold is its VERIFIER (uzkge/src/plonk/verifier.rs:17-164): with the linearisation commitment
+C_r = sum scalar_k C_k (`r_commitment` -> `r_poly_or_comm`, helpers.rs:681-1002) and the value r(zeta) the verifier derives from the
+proof's evaluations alone (`r_eval_zeta`, :1182-1321), the opening check at zeta (pcs.batch + batch_verify_diff_points,
+verifier.rs:118-163; here: the pairing equation of kzg_poly_commitment.rs:344-371 over the reference's G2 parameters,
+oracle/bn254_pairing.py) holds only if
+        t(zeta) Z_H(zeta) = [gate + permutation + boolean + anemoi + shuffle terms](zeta),
+i.e. only if the quotient kernel, the grand product, the split and the linear combination are all right, for a circuit whose
+constraints the witness really satisfies.  This file supplies the three ingredients:
+
+  make_satisfiable(inp)     rewrites a ChainInputs in place: witness constant on the cycles of the permutation (copy constraints),
+                            selectors random with q_c solved from  q1 w1 + q2 w2 + q3 w3 + q4 w4 + qm1 w1 w2 + qm2 w3 w4 + qc + PI
+                            + q5 w1 w2 w3 w4 wo - qo wo = 0  (turbo/mod.rs:193-222), s polynomials encoding the permutation
+                            (indexer.rs:195-203,301-328), L1 = (X^n - 1)/(X - 1) (indexer.rs:345-350: evaluations (n, 0, ..)),
+                            coset_quotient = X (indexer.rs:278-282); the boolean gate on the rows whose wires 1..3 hold bits
+                            (a third of the cycles carry bits); the four anemoi round constraints on EVERY row, their
+                            processed round keys solved from the witness (helpers.rs:348-398; x -> x^5 is a bijection of Fr);
+                            the shuffle gadget (helpers.rs:437-656) on one row in sixteen: q_ecc = 1, wire selectors picking one
+                            of the four table columns, the gadget's four relations fixing the next row's wires 0..2 and the
+                            row's output wire (positions kept out of the copy constraints) -- so all 18 terms of t(X) are live
+  r_scalars(...)            the 43 (shuffle feature) or 19 scalars of r(X) in the order of prover_chain.r_plan
+  r_eval_zeta(...)          the verifier's value of r at zeta
+
+Only tests import this file."""
+import os
+import sys
+
+import numpy as np
+
+import oracle_c as oc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import bn254_py as opy  # noqa: E402
+
+R = opy.R
+
+
+def _ints(a):
+    return oc.fr_to_ints(np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4))
+
+
+def _wire(xs):
+    return oc.fr_from_ints(list(xs))
+
+
+def _intt(evals_ints):
+    """coefficient form of the polynomial with these evaluations over the size-len domain (ifft_with_domain)"""
+    return oc.ntt(_wire(evals_ints), inverse=True)
+
+
+def make_satisfiable(inp, seed=1):
+    """Rewrites `inp` (prover_chain.ChainInputs) so that its witness satisfies its circuit; see the module docstring."""
+    import prover_chain as pch
+    n = inp.n
+    rng = np.random.default_rng(seed)
+
+    def rnd(count):
+        return [int(x) for x in rng.integers(1, 1 << 62, count)]
+    omega = _ints(inp.group_gen)[0]
+    group = [1] * n
+    for i in range(1, n):
+        group[i] = group[i - 1] * omega % R
+    k = _ints(inp.k)
+    # ---- copy constraints: a permutation of many short cycles (a uniformly random one has a dozen huge cycles, i.e. a dozen
+    # distinct witness values): shuffled positions cut into groups of 1..4, each group one cycle
+    total = pch.N_WIRES * n
+    # rows that carry the shuffle gadget (one in sixteen): their output wire and the next row's wires 0..2 are DETERMINED by the
+    # gadget's equations, so those positions stay out of every copy constraint (fixed points of the permutation)
+    shuffle_rows = list(range(5, n - 1, 16))
+    free = set()
+    for i in shuffle_rows:
+        free.update((4 * n + i, 0 * n + i + 1, 1 * n + i + 1, 2 * n + i + 1))
+    order = np.array([p for p in rng.permutation(total) if int(p) not in free], dtype=np.int64)
+    perm = np.arange(total, dtype=np.int64)
+    at = 0
+    while at < len(order):
+        ln = min(int(rng.integers(1, 5)), len(order) - at)
+        grp = order[at:at + ln]
+        perm[grp] = np.roll(grp, -1)
+        at += ln
+    inp.perm = perm.astype(np.uint32).reshape(pch.N_WIRES, n)
+    # ---- witness: one value per cycle of the permutation (w[pos] == w[perm[pos]] for every flat position)
+    label = np.full(total, -1, dtype=np.int64)
+    vals = [0] * total
+    for start in range(total):
+        if label[start] >= 0:
+            continue
+        # a third of the cycles carry a bit: rows whose wires 1..3 are all bits get the boolean gate switched on below
+        v = int(rng.integers(0, 2)) if rng.integers(0, 3) == 0 else int(rng.integers(1, 1 << 62)) ** 3 % R
+        pos = start
+        while label[pos] < 0:
+            label[pos] = start
+            vals[pos] = v
+            pos = int(perm[pos])
+    w = [vals[j * n:(j + 1) * n] for j in range(pch.N_WIRES)]
+    tp = inp.table_polys
+    # ---- shuffle gadget (helpers.rs:437-656, terms 12-18) on `shuffle_rows`: q_ecc = 1, wire selectors 0 / 1 pick one of the
+    # four table columns (sel_ij), the third wire selector is +-1, and the twisted-Edwards style relations
+    #   s w0' - s w0 y - w1 x + w0 w1 w0' dxy = 0      s w1' + a w0 x - s w1 y - w0 w1 w1' dxy = 0       (public-key tables)
+    #   s w2' - s w2 y - w3 x + w2 w3 w2' dxy = 0      s wo  + a w2 x - s w3 y - w2 w3 wo  dxy = 0       (generator tables)
+    # fix the next row's wires 0..2 and this row's output wire.  The 24 table polynomials keep their random coefficients.
+    ea = _ints(inp.edwards_a)[0]
+    pk = [_ints(oc.ntt(np.ascontiguousarray(tp[pch.T_QPK + t]))) for t in range(12)]       # x_ij (4), y_ij (4), dxy_ij (4): evaluations
+    gt = [_ints(oc.ntt(np.ascontiguousarray(tp[pch.T_QG + t]))) for t in range(12)]
+    q_ecc = [0] * n
+    wsel = [[0] * n for _ in range(3)]
+    inv = lambda v: pow(v % R, -1, R)
+    for i in shuffle_rows:
+        a0, b0 = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+        ij = {(0, 0): 0, (1, 0): 1, (0, 1): 2, (1, 1): 3}[(a0, b0)]      # sel_00, sel_01 = wsel0 (1 - wsel1), sel_10, sel_11
+        s2 = 1 if int(rng.integers(0, 2)) else R - 1
+        q_ecc[i], wsel[0][i], wsel[1][i], wsel[2][i] = 1, a0, b0, s2
+        x, y, d = pk[ij][i], pk[4 + ij][i], pk[8 + ij][i]
+        gx, gy, gd = gt[ij][i], gt[4 + ij][i], gt[8 + ij][i]
+        w0, w1, w2, w3 = w[0][i], w[1][i], w[2][i], w[3][i]
+        w[0][i + 1] = (s2 * w0 % R * y + w1 * x) % R * inv(s2 + w0 * w1 % R * d) % R
+        w[1][i + 1] = (s2 * w1 % R * y - ea * w0 % R * x) % R * inv(s2 - w0 * w1 % R * d) % R
+        w[2][i + 1] = (s2 * w2 % R * gy + w3 * gx) % R * inv(s2 + w2 * w3 % R * gd) % R
+        w[4][i] = (s2 * w3 % R * gy - ea * w2 % R * gx) % R * inv(s2 - w2 * w3 % R * gd) % R
+    inp.w_evals = np.stack([_wire(col) for col in w])
+    inp.wsel_evals = np.stack([_wire(col) for col in wsel])
+    tp[pch.T_QECC] = _intt(q_ecc)
+    pi = _ints(inp.pi_evals)
+    # ---- selectors (evaluations), q_c solved row by row from the gate equation
+    q = [rnd(n) for _ in range(9)]
+    for i in range(n):
+        w0, w1, w2, w3, w4 = (w[j][i] for j in range(5))
+        acc = (q[0][i] * w0 + q[1][i] * w1 + q[2][i] * w2 + q[3][i] * w3 + q[4][i] * w0 * w1 + q[5][i] * w2 * w3
+               + q[7][i] * (w0 * w1 % R) * (w2 * w3 % R) % R * w4 - q[8][i] * w4 + pi[i]) % R
+        q[6][i] = (-acc) % R
+    for s in range(9):
+        tp[pch.T_Q + s] = _intt(q[s])
+    # ---- permutation polynomials: s_j(omega^i) = k[p // n] * omega^(p % n), p = perm[j n + i]
+    for j in range(pch.N_WIRES):
+        col = [k[int(p) // n] * group[int(p) % n] % R for p in perm[j * n:(j + 1) * n]]
+        tp[pch.T_S + j] = _intt(col)
+    # ---- helpers
+    tp[pch.T_L1] = _wire([1] * n)                                   # sum_j X^j = (X^n - 1) / (X - 1)
+    # boolean gate (helpers.rs:326-346: qb * w_j (w_j - 1), j = 1, 2, 3) on every row whose wires 1..3 hold bits
+    qb = [1 if all(w[j][i] in (0, 1) for j in (1, 2, 3)) else 0 for i in range(n)]
+    assert sum(qb) > 50
+    tp[pch.T_QB] = _intt(qb)
+    # anemoi round constraints (helpers.rs:348-398) on EVERY row: for the given witness (this row and the next, cyclically) the
+    # four processed round keys are solved from the four equations -- x -> x^5 is a bijection of Fr (5 does not divide r - 1)
+    g = _ints(inp.anemoi_g)[0]
+    ginv = pow(g, -1, R)
+    fifth = pow(5, -1, R - 1)
+    g2p1 = (g * g + 1) % R
+    prk = [[0] * n for _ in range(4)]
+    for i in range(n):
+        nx = (i + 1) % n
+        w0, w1, w2, w3, wo = (w[j][i] for j in range(5))
+        w3_w0, w2_w1 = (w3 + w0) % R, (w2 + w1) % R
+        w3_2w0, w2_2w1 = (w3_w0 + w0) % R, (w2_w1 + w1) % R
+        a5 = (w[0][nx] - ginv - g * w[2][nx] % R * w[2][nx]) % R                 # term10: (tmp - w2')^5 = w0' - 1/g - g w2'^2
+        tmp = (w[2][nx] + pow(a5, fifth, R)) % R
+        prk[2][i] = (tmp - w3_w0 - g * w2_w1) % R                                 # tmp = w3_w0 + g w2_w1 + q_prk3
+        prk[0][i] = (a5 + g * tmp % R * tmp - (w3_2w0 + g * w2_2w1)) % R          # term8
+        b5 = (w[1][nx] - ginv - g * wo % R * wo) % R                              # term11: (tmp' - wo)^5 = w1' - 1/g - g wo^2
+        tmp2 = (wo + pow(b5, fifth, R)) % R
+        prk[3][i] = (tmp2 - g * w3_w0 - g2p1 * w2_w1) % R                         # tmp' = g w3_w0 + (g^2 + 1) w2_w1 + q_prk4
+        prk[1][i] = (b5 + g * tmp2 % R * tmp2 - (g * w3_2w0 + g2p1 * w2_2w1)) % R  # term9
+    for s4 in range(4):
+        tp[pch.T_QPRK + s4] = _intt(prk[s4])
+    cq = np.zeros((n, 4), dtype=np.uint64)
+    cq[1] = _wire([1])[0]
+    tp[pch.T_CQ] = cq                                               # coset_quotient(x) = x on the coset k1 * <g_m>
+    return inp
+
+
+def _challenge_ints(inp):
+    g = lambda name: _ints(getattr(inp, name))[0]
+    return dict(alpha=g("alpha"), beta=g("beta"), gamma=g("gamma"), zeta=g("zeta"), anemoi_g=g("anemoi_g"), edwards_a=g("edwards_a"))
+
+
+def first_lagrange_poly(zeta, n):
+    """helpers.rs:1412-1425: (Z_H(zeta), (zeta^n - 1) / (zeta - 1))"""
+    zh = (pow(zeta, n, R) - 1) % R
+    return zh, zh * pow((zeta - 1) % R, -1, R) % R
+
+
+def eval_pi_poly(pi_rows, zeta, zh, omega, n):
+    """helpers.rs:1135-1165: sum_j pi_j L_j(zeta) with L_j(X) = c_j (X^n - 1) / (X - omega^j), c_j = omega^j / n; pi_rows = {row: value}"""
+    ninv = pow(n, -1, R)
+    acc = 0
+    for j, v in pi_rows.items():
+        wj = pow(omega, j, R)
+        acc += v * wj % R * ninv % R * pow((zeta - wj) % R, -1, R)
+    return acc % R * zh % R
+
+
+def r_scalars(ch, k, n, ev, shuffle=True):
+    """helpers.rs:681-1002 as scalars, in the order of prover_chain.r_plan: q (9), z, the last s, qb, q_prk1, q_prk2,
+    [q_pk (12), q_g (12)], the five t chunks.  `ev`: w (5 at zeta), s (4), prk3, z_omega, w_omega (3), [q_ecc, wsel (3)]."""
+    a, beta, gamma, zeta = ch["alpha"], ch["beta"], ch["gamma"], ch["zeta"]
+    ap = [pow(a, e, R) for e in range(17)]
+    w, s, prk3, z_om, w_om = ev["w"], ev["s"], ev["prk3"], ev["z_omega"], ev["w_omega"]
+    zh, l1 = first_lagrange_poly(zeta, n)
+    # eval_selector_multipliers (turbo/mod.rs:224-245): (w1, w2, w3, w4, w1 w2, w3 w4, 1, w1 w2 w3 w4 wo, -wo)
+    out = [w[0], w[1], w[2], w[3], w[0] * w[1] % R, w[2] * w[3] % R, 1, w[0] * w[1] % R * w[2] % R * w[3] % R * w[4] % R, (-w[4]) % R]
+    z_scalar = a                                                    # compute_z_scalar_in_r (:1004-1028)
+    for i in range(5):
+        z_scalar = z_scalar * ((w[i] + k[i] * beta % R * zeta + gamma) % R) % R
+    z_scalar = (z_scalar + l1 * ap[2]) % R
+    out.append(z_scalar)
+    s_last = a * z_om % R * beta % R
+    for i in range(4):
+        s_last = s_last * ((w[i] + beta * s[i] + gamma) % R) % R
+    out.append((-s_last) % R)
+    out.append((w[1] * (w[1] - 1) % R * ap[3] + w[2] * (w[2] - 1) % R * ap[4] + w[3] * (w[3] - 1) % R * ap[5]) % R)
+    out.append(prk3 * ap[6] % R)
+    out.append(prk3 * ap[7] % R)
+    if shuffle:
+        qe, ws, ea = ev["q_ecc"], ev["wsel"], ch["edwards_a"]
+        sel = [((1 - ws[0]) * (1 - ws[1]) + qe - 1) % R, ws[0] * (1 - ws[1]) % R, (1 - ws[0]) * ws[1] % R, ws[0] * ws[1] % R]
+        # q_shuffle_public_key_polys: x_ij (4), y_ij (4), dxy_ij (4); alpha^10 and alpha^11 terms (:752-860)
+        pk_x = (-ap[10] * w[1] + ap[11] * w[0] % R * ea) % R
+        pk_y = (-ap[10] * ws[2] % R * w[0] - ap[11] * ws[2] % R * w[1]) % R
+        pk_d = (ap[10] * w[0] % R * w[1] % R * w_om[0] - ap[11] * w[0] % R * w[1] % R * w_om[1]) % R
+        # q_shuffle_generator_polys: alpha^12 and alpha^13 terms (:862-968)
+        g_x = (-ap[12] * w[3] + ap[13] * w[2] % R * ea) % R
+        g_y = (-ap[12] * ws[2] % R * w[2] - ap[13] * ws[2] % R * w[3]) % R
+        g_d = (ap[12] * w[2] % R * w[3] % R * w_om[2] - ap[13] * w[2] % R * w[3] % R * w[4]) % R
+        for base in (pk_x, pk_y, pk_d):
+            out += [base * sij % R for sij in sel]
+        for base in (g_x, g_y, g_d):
+            out += [base * sij % R for sij in sel]
+    factor = pow(zeta, n + 2, R)                                    # n_t_polys = cs_size + 2 (verifier.rs:79)
+    e = zh
+    for _ in range(5):
+        out.append((-e) % R)
+        e = e * factor % R
+    return out
+
+
+def r_eval_zeta(ch, n, ev, pi_eval, shuffle=True):
+    """helpers.rs:1182-1321"""
+    a, beta, gamma, zeta, g = ch["alpha"], ch["beta"], ch["gamma"], ch["zeta"], ch["anemoi_g"]
+    ginv = pow(g, -1, R)
+    ap = [pow(a, e, R) for e in range(17)]
+    w, s, prk3, prk4, z_om, w_om = ev["w"], ev["s"], ev["prk3"], ev["prk4"], ev["z_omega"], ev["w_omega"]
+    _, l1 = first_lagrange_poly(zeta, n)
+    term1 = a * z_om % R
+    for i in range(4):
+        term1 = term1 * ((w[i] + beta * s[i] + gamma) % R) % R
+    term1 = term1 * ((w[4] + gamma) % R) % R
+    term2 = l1 * ap[2] % R
+    w3_w0, w2_w1 = (w[3] + w[0]) % R, (w[2] + w[1]) % R
+    w3_2w0, w2_2w1 = (w3_w0 + w[0]) % R, (w2_w1 + w[1]) % R
+    tmp = (w3_w0 + g * w2_w1 + prk3) % R
+    term3 = ap[6] * prk3 % R * ((pow((tmp - w_om[2]) % R, 5, R) + g * tmp % R * tmp - (w3_2w0 + g * w2_2w1)) % R) % R
+    term5 = ap[8] * prk3 % R * ((pow((tmp - w_om[2]) % R, 5, R) + g * w_om[2] % R * w_om[2] + ginv - w_om[0]) % R) % R
+    g2p1 = (g * g + 1) % R
+    tmp = (g * w3_w0 + g2p1 * w2_w1 + prk4) % R
+    term4 = ap[7] * prk3 % R * ((pow((tmp - w[4]) % R, 5, R) + g * tmp % R * tmp - (g * w3_2w0 + g2p1 * w2_2w1)) % R) % R
+    term6 = ap[9] * prk3 % R * ((pow((tmp - w[4]) % R, 5, R) + g * w[4] % R * w[4] + ginv - w_om[1]) % R) % R
+    res = (term1 + term2 - pi_eval + term3 + term4 + term5 + term6) % R
+    if shuffle:
+        qe, ws = ev["q_ecc"], ev["wsel"]
+        sel = [((1 - ws[0]) * (1 - ws[1]) + qe - 1) % R, ws[0] * (1 - ws[1]) % R, (1 - ws[0]) * ws[1] % R, ws[0] * ws[1] % R]
+        term7 = ws[2] * ((ap[10] * w_om[0] + ap[11] * w_om[1] + ap[12] * w_om[2] + ap[13] * w[4]) % R) % R * (sum(sel) % R) % R
+        term8 = ap[14] * ((qe * ws[0] % R * (1 - ws[0]) + (1 - qe) * ws[0]) % R) % R
+        term9 = ap[15] * ((qe * ws[1] % R * (1 - ws[1]) + (1 - qe) * ws[1]) % R) % R
+        term10 = ap[16] * qe % R * (1 - ws[2]) % R * (1 + ws[2]) % R
+        res = (res - term7 - term8 - term9 - term10) % R
+    return res

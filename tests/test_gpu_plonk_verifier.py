@@ -1,0 +1,109 @@
+"""The device-resident prover chain held to the reference's VERIFIER equations, for a circuit its witness really satisfies.
+
+tests/test_gpu_kzg_pairing.py pins the opening flow: there r(X) uses seeded stand-in scalars and r's evaluation is read off the
+device.  Here the circuit is satisfiable (tests/plonk_verifier_oracle.py make_satisfiable), r(X)'s 43 scalars are the reference's
+formulas of the proof's evaluations (helpers.rs:681-1002), and the value the opening at zeta must hit is the one the VERIFIER
+derives from those evaluations alone (`r_eval_zeta`, helpers.rs:1182-1321; PI(zeta): `eval_pi_poly`, :1135-1165).  The pairing
+equation (kzg_poly_commitment.rs:344-371, the reference's G2 parameters) then holds only if
+     t(zeta) Z_H(zeta) = [gate + permutation + L1 + boolean + anemoi + shuffle terms](zeta)
+i.e. only if the quotient kernel (`t_poly`, helpers.rs:223-678), the grand product (`z_poly`, :160-220), `split_t_and_commit`
+(:1323-1408), the evaluations and the linear combination are all right -- SURVEY.md section 8 rows f2, f4, a8, which no stored
+fixture of the reference covers.  A witness with ONE wrong value must fail the same check."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import bn254_py as opy
+import bn254_pairing as pr
+import oracle_c as oc
+import plonk_verifier_oracle as pv
+from util import GOLDEN, affine_of
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+
+def _run_and_verify(inp, shuffle=True):
+    import prover_chain as pch
+    from uzkge_amd import backend as b
+    g2 = pr.parse_srs_g2(open(os.path.join(GOLDEN, "srs-padding.bin"), "rb").read())
+    n = inp.n
+    ch = pv._challenge_ints(inp)
+    k = pv._ints(inp.k)
+    plan = pch.eval_plan(shuffle)
+    at = {(kind, idx, pt): i for i, (kind, idx, pt) in enumerate(plan)}
+
+    def evals_of(rows):
+        v = pv._ints(rows)
+        ev = {"w": [v[at[("c", i, 0)]] for i in range(5)], "s": [v[at[("t", pch.T_S + i, 0)]] for i in range(4)],
+              "prk3": v[at[("t", pch.T_QPRK + 2, 0)]], "prk4": v[at[("t", pch.T_QPRK + 3, 0)]], "z_omega": v[at[("c", 9, 1)]],
+              "w_omega": [v[at[("c", i, 1)]] for i in range(3)]}
+        if shuffle:
+            ev["q_ecc"] = v[at[("t", pch.T_QECC, 0)]]
+            ev["wsel"] = [v[at[("c", 5 + i, 0)]] for i in range(3)]
+        return ev
+    c = pch.ProverChain(inputs=inp, precompute=False, shuffle=shuffle)
+    c.r_scalar_hook = lambda rows: oc.fr_from_ints(pv.r_scalars(ch, k, n, evals_of(rows), shuffle))
+    try:
+        o = c.run()
+        ev = evals_of(o["evals"])
+        scalars = pv.r_scalars(ch, k, n, ev, shuffle)
+        # the verifier's commitments: the circuit's (one batched Lagrange commit of its polynomials' evaluations) and the proof's
+        table_cms = [affine_of(j) for j in b.msm_batch(c.srs, b.ntt_batch(inp.table_polys))]
+        own = [affine_of(j) for j in o["cm_w_wsel"]] + [None, affine_of(o["cm_z"][0])]
+        chunks = [affine_of(j) for j in o["cm_t"]]
+        cm_of = lambda kind, idx: table_cms[idx] if kind == "t" else own[idx] if kind == "c" else chunks[idx]
+        rp = pch.r_plan(shuffle)
+        assert len(rp) == len(scalars)
+        cm_r = None                                                             # r_commitment (helpers.rs:1082-1133)
+        for (kind, idx), s in zip(rp, scalars):
+            cm_r = opy.g1_add(cm_r, opy.g1_mul(cm_of(kind, idx), s))
+        zh, _ = pv.first_lagrange_poly(ch["zeta"], n)
+        pi = pv._ints(inp.pi_evals[:8])
+        pi_eval = pv.eval_pi_poly({i: v for i, v in enumerate(pi)}, ch["zeta"], zh, pv._ints(inp.group_gen)[0], n)
+        v_r = pv.r_eval_zeta(ch, n, ev, pi_eval, shuffle)                       # the VERIFIER's value, from the evaluations alone
+        at_zeta, _ = pch.open_plan(shuffle)
+        vals_by = dict(zip([p for p in at_zeta if p[0] != "r"], ev["w"] + ev["s"] + [ev["prk3"], ev["prk4"]] +
+                           ([ev["q_ecc"]] + ev["wsel"] if shuffle else [])))
+        cms, vals = [], []
+        for kind, idx in at_zeta:
+            cms.append(cm_r if kind == "r" else cm_of(kind, idx))
+            vals.append(v_r if kind == "r" else vals_by[(kind, idx)])
+        alpha_open = pv._ints(inp.alpha_open)[0]
+        comb_c, comb_v, mult = None, 0, 1
+        for cm, val in zip(cms, vals):                                          # pcs.batch (pcs.rs:170-200): powers of the batching challenge
+            comb_c = opy.g1_add(comb_c, opy.g1_mul(cm, mult))
+            comb_v = (comb_v + mult * val) % opy.R
+            mult = mult * alpha_open % opy.R
+        g1_0 = opy.wire_to_affine(inp.mono_wire[0].tobytes())
+        ok = pr.kzg_verify(g1_0, g2[0], g2[1], comb_c, ch["zeta"], comb_v, affine_of(o["cm_q"][0]), opy.g1_mul, opy.g1_add)
+        t_tail = c.snapshot()["t"][5 * n + 11:]
+        return ok, bool(np.any(t_tail))
+    finally:
+        c.release()
+
+
+@pytest.mark.parametrize("shuffle", [True, False])
+def test_chain_satisfies_the_verifier_equations(gpu, shuffle):
+    import prover_chain as pch
+    inp = pv.make_satisfiable(pch.ChainInputs(1 << 14, 21), seed=4)
+    ok, tail = _run_and_verify(inp, shuffle)
+    assert not tail          # the numerator is divisible by Z_H: t has 5n + 11 coefficients and nothing beyond
+    assert ok
+
+
+@pytest.mark.parametrize("what", ["wire", "wire_selector"])
+def test_one_wrong_witness_value_fails_the_verifier_equations(gpu, what):
+    import prover_chain as pch
+    inp = pv.make_satisfiable(pch.ChainInputs(1 << 14, 21), seed=4)
+    if what == "wire":               # breaks row 777's gate, an anemoi relation and a copy constraint
+        inp.w_evals[2, 777] = oc.fr_from_ints([(pv._ints(inp.w_evals[2, 777:778])[0] + 1) % opy.R])[0]
+    else:                            # row 21 carries the shuffle gadget: the other table column no longer matches the wires
+        bit = pv._ints(inp.wsel_evals[0, 21:22])[0]
+        assert bit in (0, 1) and pv._ints(inp.wsel_evals[2, 21:22])[0] in (1, opy.R - 1)
+        inp.wsel_evals[0, 21] = oc.fr_from_ints([1 - bit])[0]
+    ok, tail = _run_and_verify(inp, True)
+    assert tail              # the division by Z_H leaves a remainder: the 6n-point interpolation fills the top coefficients
+    assert not ok

@@ -248,7 +248,10 @@ class ProverChain:
         o["evals"] = b.poly_eval_ptrs_device([p for p, _ in pl], [ln for _, ln in pl], [pt for _, _, pt in plan], np.stack([self.zeta, self.zeta_omega]))
         # ---- round 5: r(X) = sum of scalars * polynomials (r_poly's shape), then the two openings
         rp = [self._poly(kind, idx) for kind, idx in r_plan(self.shuffle)]
-        b.poly_lincomb_device([p for p, _ in rp], [ln for _, ln in rp], self.r_scalars[: len(rp)], self.d_r.ptr, n + 3)
+        # r_poly's scalars are O(1) formulas of the evaluations and the challenges (helpers.rs:681-1002) and stay with the caller, as in
+        # the reference: the timing runs pass seeded stand-ins, tests/test_gpu_plonk_verifier.py derives them from round 4's evaluations
+        r_scalars = self.r_scalar_hook(o["evals"]) if getattr(self, "r_scalar_hook", None) is not None else self.r_scalars
+        b.poly_lincomb_device([p for p, _ in rp], [ln for _, ln in rp], r_scalars[: len(rp)], self.d_r.ptr, n + 3)
         at_zeta, at_zeta_omega = open_plan(self.shuffle)
         for j, (plan_j, point, alpha) in enumerate(((at_zeta, self.zeta, self.alpha_open), (at_zeta_omega, self.zeta_omega, self.alpha_open2))):
             op = [self._poly(kind, idx) for kind, idx in plan_j]
