@@ -238,10 +238,10 @@ def r_scalars(ch, k, n, ev, shuffle=True):
     return out
 
 
-def r_eval_zeta(ch, n, ev, pi_eval, shuffle=True):
-    """helpers.rs:1182-1321"""
+def r_eval_zeta(ch, n, ev, pi_eval, shuffle=True, anemoi_g_inv=None):
+    """helpers.rs:1182-1321.  `anemoi_g_inv`: the key's stored inverse (a circuit without anemoi rounds stores 0 for both)."""
     a, beta, gamma, zeta, g = ch["alpha"], ch["beta"], ch["gamma"], ch["zeta"], ch["anemoi_g"]
-    ginv = pow(g, -1, R)
+    ginv = pow(g, -1, R) if anemoi_g_inv is None else anemoi_g_inv
     ap = [pow(a, e, R) for e in range(17)]
     w, s, prk3, prk4, z_om, w_om = ev["w"], ev["s"], ev["prk3"], ev["prk4"], ev["z_omega"], ev["w_omega"]
     _, l1 = first_lagrange_poly(zeta, n)
