@@ -107,15 +107,32 @@ def _pt(xy):
     return (x, y)
 
 
+def proof_from_bytes(raw: bytes):
+    """PlonkProof::from_bytes_be (indexer.rs:592-700; layout of to_bytes_be :539-590): 14 uncompressed points, 19 scalars, 2 points,
+    32-byte big-endian words."""
+    assert len(raw) == 1632
+    words = [int.from_bytes(raw[32 * i: 32 * i + 32], "big") for i in range(51)]
+    pts = lambda lo, cnt: [_pt(words[lo + 2 * i: lo + 2 * i + 2]) for i in range(cnt)]
+    return {"cm_w": pts(0, 5), "cm_wsel": pts(10, 3), "cm_t": pts(16, 5), "cm_z": pts(26, 1)[0],
+            "prk3": words[28], "prk4": words[29], "w": words[30:35], "w_omega": words[35:38], "z_omega": words[38],
+            "s": words[39:43], "q_ecc": words[43], "wsel": words[44:47], "open_zeta": pts(47, 1)[0], "open_zeta_omega": pts(49, 1)[0]}
+
+
+def proof_to_bytes(proof) -> bytes:
+    """PlonkProof::to_bytes_be (indexer.rs:539-590)"""
+    def pt(p):
+        x, y = (0, 0) if p is None else p
+        return x.to_bytes(32, "big") + y.to_bytes(32, "big")
+    sc = lambda v: (v % R).to_bytes(32, "big")
+    out = b"".join(pt(p) for p in proof["cm_w"] + proof["cm_wsel"] + proof["cm_t"] + [proof["cm_z"]])
+    out += sc(proof["prk3"]) + sc(proof["prk4"]) + b"".join(sc(v) for v in proof["w"] + proof["w_omega"]) + sc(proof["z_omega"])
+    out += b"".join(sc(v) for v in proof["s"]) + sc(proof["q_ecc"]) + b"".join(sc(v) for v in proof["wsel"])
+    return out + pt(proof["open_zeta"]) + pt(proof["open_zeta_omega"])
+
+
 def load_golden():
     d = json.load(open(os.path.join(GOLDEN, "plonk_52_golden.json")))
-    raw = bytes.fromhex(d["proof_hex"])
-    words = [int.from_bytes(raw[32 * i: 32 * i + 32], "big") for i in range(len(raw) // 32)]
-    pts = lambda lo, cnt: [_pt(words[lo + 2 * i: lo + 2 * i + 2]) for i in range(cnt)]
-    proof = {"cm_w": pts(0, 5), "cm_wsel": pts(10, 3), "cm_t": pts(16, 5), "cm_z": pts(26, 1)[0],
-             "prk3": words[28], "prk4": words[29], "w": words[30:35], "w_omega": words[35:38], "z_omega": words[38],
-             "s": words[39:43], "q_ecc": words[43], "wsel": words[44:47], "open_zeta": pts(47, 1)[0], "open_zeta_omega": pts(49, 1)[0]}
-    assert len(words) == 51
+    proof = proof_from_bytes(bytes.fromhex(d["proof_hex"]))
     vk = {"cm_q": [_pt(p) for p in d["cm_q"]], "cm_s": [_pt(p) for p in d["cm_s"]], "cm_qb": _pt(d["cm_qb"]),
           "cm_prk": [_pt(p) for p in d["cm_prk"]], "cm_q_ecc": _pt(d["cm_q_ecc"]),
           "cm_shuffle_generator": [_pt(p) for p in d["cm_shuffle_generator"]],

@@ -107,3 +107,118 @@ def test_one_wrong_witness_value_fails_the_verifier_equations(gpu, what):
     ok, tail = _run_and_verify(inp, True)
     assert tail              # the division by Z_H leaves a remainder: the 6n-point interpolation fills the top coefficients
     assert not ok
+
+
+class _FiatShamir:
+    """The prover's side of the reference's transcript (prover.rs:151-372 appends what verifier.rs:166-222 re-derives), driving the
+    chain's challenges; tests/plonk_golden_verifier.py holds the transcript itself, pinned on the reference's golden proof."""
+
+    def __init__(self, vk, pi, n_cards, plan, shuffle=True):
+        import plonk_golden_verifier as gv
+        from uzkge_amd.poly_commit import fr_from_int
+        self.wire, self.plan, self.vk, self.ch = fr_from_int, plan, vk, {}
+        t = gv.Transcript(b"Plonk shuffle Proof")
+        t.append_u64(n_cards)
+        t.append_message(b"PLONK")
+        t.append_u64(vk["cs_size"])
+        t.append_message(opy.R.to_bytes(32, "big"))
+        for c in vk["cm_q"] + vk["cm_s"]:
+            t.append_commitment(c)
+        t.append_challenge(vk["root"])
+        for k in vk["k"]:
+            t.append_challenge(k)
+        for v in pi:
+            t.append_challenge(v)
+        self.t = t
+
+    def beta_gamma(self, cms):
+        for j in cms:
+            self.t.append_commitment(affine_of(j))
+        self.ch["beta"] = self.t.challenge()
+        self.t.append_single_byte(0x01)
+        self.ch["gamma"] = self.t.challenge()
+        return self.wire(self.ch["beta"]), self.wire(self.ch["gamma"])
+
+    def alpha(self, cm_z):
+        self.t.append_commitment(affine_of(cm_z[0]))
+        self.ch["alpha"] = self.t.challenge()
+        return self.wire(self.ch["alpha"])
+
+    def zeta(self, cm_t):
+        for j in cm_t:
+            self.t.append_commitment(affine_of(j))
+        self.ch["zeta"] = self.t.challenge()
+        return self.wire(self.ch["zeta"])
+
+    def after_evaluations(self, rows, zeta_w, zeta_omega_w):
+        import prover_chain as pch
+        v = pv._ints(rows)
+        at = {(kind, idx, pt): i for i, (kind, idx, pt) in enumerate(self.plan)}
+        order = [("c", i, 0) for i in range(5)] + [("t", pch.T_S + i, 0) for i in range(4)] + [("c", 5 + i, 0) for i in range(3)] + \
+            [("t", pch.T_QPRK + 2, 0), ("t", pch.T_QPRK + 3, 0), ("c", 9, 1), ("t", pch.T_QECC, 0)] + [("c", i, 1) for i in range(3)]
+        for key in order:                                       # prover.rs:275-298
+            self.t.append_challenge(v[at[key]])
+        self.ch["u"] = self.t.challenge()
+        out = []
+        for point in (zeta_w, zeta_omega_w):                    # batch_prove -> init_pcs_batch_eval_transcript + alpha (pcs.rs:107-118)
+            self.t.append_message(b"New PCS-Batch-Eval Protocol")
+            self.t.append_message(opy.R.to_bytes(32, "big"))
+            self.t.append_u64(self.vk["cs_size"] + 2)
+            self.t.append_challenge(pv._ints(point)[0])
+            out.append(self.wire(self.t.challenge()))
+        return out
+
+
+def test_a_whole_proof_from_the_chain_is_accepted_by_the_golden_proof_verifier(gpu):
+    """Prove -> verify, non-interactively: the chain's challenges come from the reference's transcript, its commitments,
+    evaluations and opening proofs are packed as a PlonkProof, the circuit's commitments as a verifier key, and
+    tests/plonk_golden_verifier.py -- the verifier restatement that accepts the REFERENCE's golden proof -- must accept it
+    (and reject it with one evaluation changed).  The circuit has anemoi rounds and the quintic selector live, which the golden
+    circuit has not."""
+    import plonk_golden_verifier as gv
+    import prover_chain as pch
+    from uzkge_amd import backend as b
+    n = 1 << 14
+    inp = pv.make_satisfiable(pch.ChainInputs(n, 21), seed=4)
+    c = pch.ProverChain(inputs=inp, precompute=False)
+    try:
+        table_cms = [affine_of(j) for j in b.msm_batch(c.srs, b.ntt_batch(inp.table_polys))]
+        omega = pv._ints(inp.group_gen)[0]
+        ninv = pow(n, -1, opy.R)
+        g = pv._ints(inp.anemoi_g)[0]
+        vk = {"cm_q": table_cms[pch.T_Q:pch.T_Q + 9], "cm_s": table_cms[pch.T_S:pch.T_S + 5], "cm_qb": table_cms[pch.T_QB],
+              "cm_prk": table_cms[pch.T_QPRK:pch.T_QPRK + 4], "cm_q_ecc": table_cms[pch.T_QECC],
+              "cm_shuffle_generator": table_cms[pch.T_QG:pch.T_QG + 12], "cm_shuffle_public_key": table_cms[pch.T_QPK:pch.T_QPK + 12],
+              "anemoi_g": g, "anemoi_g_inv": pow(g, -1, opy.R), "k": pv._ints(inp.k), "edwards_a": pv._ints(inp.edwards_a)[0],
+              "root": omega, "cs_size": n, "pi_root_powers": [pow(omega, j, opy.R) for j in range(8)],
+              "pi_lagrange": [pow(omega, j, opy.R) * ninv % opy.R for j in range(8)]}
+        pi = pv._ints(inp.pi_evals[:8])
+        plan = pch.eval_plan(True)
+        fs = _FiatShamir(vk, pi, 52, plan)
+        c.fs = fs
+        k = vk["k"]
+        at = {(kind, idx, pt): i for i, (kind, idx, pt) in enumerate(plan)}
+
+        def evals_of(rows):
+            v = pv._ints(rows)
+            return {"w": [v[at[("c", i, 0)]] for i in range(5)], "s": [v[at[("t", pch.T_S + i, 0)]] for i in range(4)],
+                    "prk3": v[at[("t", pch.T_QPRK + 2, 0)]], "prk4": v[at[("t", pch.T_QPRK + 3, 0)]], "z_omega": v[at[("c", 9, 1)]],
+                    "w_omega": [v[at[("c", i, 1)]] for i in range(3)], "q_ecc": v[at[("t", pch.T_QECC, 0)]],
+                    "wsel": [v[at[("c", 5 + i, 0)]] for i in range(3)]}
+        chd = lambda: {"alpha": fs.ch["alpha"], "beta": fs.ch["beta"], "gamma": fs.ch["gamma"], "zeta": fs.ch["zeta"], "anemoi_g": g,
+                       "edwards_a": vk["edwards_a"]}
+        c.r_scalar_hook = lambda rows: oc.fr_from_ints(pv.r_scalars(chd(), k, n, evals_of(rows), True))
+        o = c.run()
+        ev = evals_of(o["evals"])
+        proof = {"cm_w": [affine_of(j) for j in o["cm_w_wsel"][:5]], "cm_wsel": [affine_of(j) for j in o["cm_w_wsel"][5:8]],
+                 "cm_t": [affine_of(j) for j in o["cm_t"]], "cm_z": affine_of(o["cm_z"][0]), "prk3": ev["prk3"], "prk4": ev["prk4"],
+                 "w": ev["w"], "w_omega": ev["w_omega"], "z_omega": ev["z_omega"], "s": ev["s"], "q_ecc": ev["q_ecc"], "wsel": ev["wsel"],
+                 "open_zeta": affine_of(o["cm_q"][0]), "open_zeta_omega": affine_of(o["cm_q"][1])}
+        assert ev["prk3"] != 0 and vk["cm_q"][7] is not None            # anemoi rounds and the quintic selector are live here
+        assert gv.verify(vk, proof, pi, n_cards=52)
+        raw = gv.proof_to_bytes(proof)                                  # the reference's proof format (indexer.rs:539-590): 1632 bytes
+        assert len(raw) == 1632 and gv.verify(vk, gv.proof_from_bytes(raw), pi, n_cards=52)
+        bad = dict(proof); bad["s"] = list(proof["s"]); bad["s"][1] = (bad["s"][1] + 1) % opy.R
+        assert not gv.verify(vk, bad, pi, n_cards=52)
+    finally:
+        c.release()

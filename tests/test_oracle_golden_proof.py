@@ -30,8 +30,13 @@ def test_fixture_matches_the_pinned_constants():
 
 
 def test_reference_golden_proof_is_accepted():
+    import json, os
+    from util import GOLDEN
     vk, proof, pi = gv.load_golden()
     assert gv.verify(vk, proof, pi)
+    # the byte codec (PlonkProof::to_bytes_be / from_bytes_be, indexer.rs:539-700) round-trips the reference's 1632 bytes
+    raw = bytes.fromhex(json.load(open(os.path.join(GOLDEN, "plonk_52_golden.json")))["proof_hex"])
+    assert gv.proof_to_bytes(proof) == raw
 
 
 def test_tampered_inputs_are_rejected():

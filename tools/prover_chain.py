@@ -209,11 +209,19 @@ class ProverChain:
         b.ntt_batch_strided_device(self.d_evals.ptr, n, coefs.ptr, m, n, 9, inverse=True)
         b.hide_polynomial_batch_device(coefs.ptr, m, n, np.concatenate([self.blinds_w, self.blinds_wsel]), n)
         o["cm_w_wsel"] = b.msm_batch_tail_device(self.srs, self.d_evals.ptr, n, n, 8, self._tails(list(self.blinds_w) + list(self.blinds_wsel)), 6)
+        # Fiat-Shamir: the challenges are the caller's (the Rust prover draws them from its transcript after each round,
+        # prover.rs:194-244,300-302).  Seeded stand-ins for the timing runs; `self.fs` (tests/test_gpu_plonk_verifier.py) derives them
+        # from the commitments and evaluations the way the reference's transcript does.
+        fs = getattr(self, "fs", None)
+        if fs is not None:
+            self.beta, self.gamma = fs.beta_gamma(o["cm_w_wsel"])
         # ---- round 2: permutation grand product
         b.z_poly_device(self.d_evals.ptr, self.d_perm, self.d_group.ptr, self.k, self.beta, self.gamma, n, N_WIRES, self.d_z.ptr)
         b.ntt_batch_strided_device(self.d_z.ptr, n, coefs.at(9 * m), m, n, 1, inverse=True)
         b.hide_polynomial_batch_device(coefs.at(9 * m), m, n, self.blinds_z.reshape(1, 3, 4), n)
         o["cm_z"] = b.msm_batch_tail_device(self.srs, self.d_z.ptr, n, n, 1, self._tails([self.blinds_z]), 6)
+        if fs is not None:
+            self.alpha = fs.alpha(o["cm_z"])
         # ---- round 3: quotient polynomial
         b.ntt_batch_device(coefs.ptr, self.d_coset.ptr, m, 10, coset_shift=self.k[1])
         cos = [self.d_coset.at(i * m) for i in range(10)]
@@ -242,6 +250,9 @@ class ProverChain:
         split_and_commit(self.t_len)
         if int(lens_view[0]) != self.t_len:
             split_and_commit(int(lens_view[0]))
+        if fs is not None:
+            self.zeta = fs.zeta(o["cm_t"])
+            self.zeta_omega = pc.fr_from_int(pc.fr_to_int(self.zeta) * pc.fr_to_int(self.group_gen) % pc.FR_MODULUS)
         # ---- round 4: the evaluations of prover.rs:246-273 in one launch
         plan = eval_plan(self.shuffle)
         pl = [self._poly(kind, idx) for kind, idx, _ in plan]
@@ -250,6 +261,8 @@ class ProverChain:
         rp = [self._poly(kind, idx) for kind, idx in r_plan(self.shuffle)]
         # r_poly's scalars are O(1) formulas of the evaluations and the challenges (helpers.rs:681-1002) and stay with the caller, as in
         # the reference: the timing runs pass seeded stand-ins, tests/test_gpu_plonk_verifier.py derives them from round 4's evaluations
+        if fs is not None:
+            self.alpha_open, self.alpha_open2 = fs.after_evaluations(o["evals"], self.zeta, self.zeta_omega)
         r_scalars = self.r_scalar_hook(o["evals"]) if getattr(self, "r_scalar_hook", None) is not None else self.r_scalars
         b.poly_lincomb_device([p for p, _ in rp], [ln for _, ln in rp], r_scalars[: len(rp)], self.d_r.ptr, n + 3)
         at_zeta, at_zeta_omega = open_plan(self.shuffle)
