@@ -532,6 +532,25 @@ def run_rank(args) -> None:
                     srs20.release()
         except Exception as e:
             extra["msm_2p20"] = {"error": str(e)}
+        try:     # 2^26 points on this one GPU (BASELINE config #5's total size; the N > 1 runs shard it): chunks of 2^24 into one bucket set
+            if n == (1 << 24) and world == 1:
+                n26 = 1 << 26
+                pts26 = torch.empty((n26, 8), dtype=torch.int64, device=dev)
+                sc26 = torch.empty((n26, 4), dtype=torch.int64, device=dev)
+                torch.cuda.synchronize()
+                b.synth_points_random(pts26.data_ptr(), n26, seed ^ 0x26)
+                b.synth_scalars(sc26.data_ptr(), n26, seed ^ 0x2626)
+                srs26 = b.Srs.from_device(pts26.data_ptr(), n26)
+                try:
+                    s26, _ = time_msm(srs26, sc26.data_ptr(), n26, reps=2)
+                    extra["msm_2p26"] = {"ms_per_msm": round(s26 * 1e3, 3), "points_per_sec": n26 / s26,
+                                         "what": "2^26 random points + uniform scalars resident on ONE GPU: four chunks of 2^24 into one bucket set (msm_run_chunked)"}
+                finally:
+                    srs26.release()
+                    del pts26, sc26
+                    torch.cuda.empty_cache()
+        except Exception as e:
+            extra["msm_2p26"] = {"error": str(e)}
         try:     # PCIe-inclusive: the host-pointer entry points (scalars / vector cross PCIe inside the call)
             hs = sc.cpu().numpy().view(np.uint64).reshape(-1, 4)
             def host_msm_ms(reps=3):
