@@ -315,6 +315,117 @@ typedef struct {
  * #[cfg(feature = "shuffle")]) are then not evaluated. */
 int uzk_t_quotient_device(const uzk_quotient_args* args, void* d_out, int sync);
 
+/* ---- circuits and the five prover rounds ------------------------------------------------------------------------------------
+ * prover_with_lagrange (uzkge/src/plonk/prover.rs:88-394) behind the C ABI: the per-circuit data of PlonkProverParams
+ * (uzkge/src/plonk/indexer.rs:76-138) lives in HBM as a CIRCUIT, one proof's polynomials in a PROVER (a workspace), and one call
+ * per Fiat-Shamir round does everything the reference does between two transcript draws.  The host keeps what is O(1) or
+ * protocol: the transcript, the prng (blinds), r_poly's scalars.  Every host language -- the C++ driver tests/cpp/prover_rounds.cpp,
+ * the Python driver tools/prover_chain.py, rust/uzkge-glue/gpu_prover.rs -- runs the same tested implementation.
+ *
+ * Slots of a circuit's polynomials = the quotient kernel's order (UZK_TQ_Q .. UZK_TQ_QECC) minus UZK_TQ_Q.
+ * Coset evaluations over the quotient domain (indexer.rs:316-470: q_coset_evals, s_coset_evals, ...) are never uploaded: the
+ * library derives them from the coefficient forms with one batched coset FFT (k[1], the 6n domain) -- exact arithmetic, so the
+ * bytes are the indexer's, and the ordering of the 6n domain becomes internal to the library (every vector over that domain is
+ * produced and consumed here: the proof does not depend on which primitive 6n-th root enumerates it). */
+#define UZK_CIRCUIT_SLOTS 46
+enum {
+    UZK_CS_Q = 0,               /* 9: q_polys */
+    UZK_CS_S = 9,               /* 5: s_polys */
+    UZK_CS_L1 = 14,             /* l1_coefs */
+    UZK_CS_QB = 15,             /* qb_poly */
+    UZK_CS_QPRK = 16,           /* 4: q_prk_polys */
+    UZK_CS_COSET_QUOTIENT = 20, /* prover_params.coset_quotient = k[1] * g_m^i: pass NULL, the library builds it (= the polynomial X) */
+    UZK_CS_QPK = 21,            /* 12: q_shuffle_public_key_polys */
+    UZK_CS_QG = 33,             /* 12: q_shuffle_generator_polys */
+    UZK_CS_QECC = 45            /* q_ecc_poly */
+};
+typedef struct {
+    uint32_t n;                 /* cs.size(): a power of two, 8 <= n <= 2^20 */
+    uint32_t shuffle;           /* != 0: built with the "shuffle" feature -- all 46 slots; 0: slots 0..20 only (zmatchmaking) */
+    uint32_t precompute;        /* != 0: window table over the commit bases (uzk_srs_precompute): shorter commits, 32 MiB at n = 2^14 */
+    uint32_t reserved;
+    const uzk_g1_affine* lagrange_bases;  /* n points: lagrange_pcs.public_parameter_group_1 (prover.rs:125-130) */
+    const uzk_g1_affine* blind_bases;     /* 6 points: pcs.public_parameter_group_1[0..3) || [n..n+3) (apply_blind_factors) */
+    const uint32_t* permutation;          /* 5 n entries < 5 n: prover_params.permutation */
+    uint64_t k[5][4];                     /* verifier_params.k */
+    uint64_t anemoi_g[4], anemoi_g_inv[4], edwards_a[4];
+    uint64_t group_gen[4];                /* domain.group_gen of the size-n domain: must equal uzk_domain_group_gen(n), else UZK_ERR_FFT */
+    const uint64_t* polys[UZK_CIRCUIT_SLOTS];   /* coefficient forms (host); slots >= 21 are ignored without shuffle; slot 20: NULL
+                                                   (a polynomial given there replaces X: the frozen test vectors use a random one) */
+    uint64_t poly_lens[UZK_CIRCUIT_SLOTS];      /* coefs.len() <= n (FpPolynomial::from_coefs has trimmed them); 0 = the zero polynomial */
+} uzk_circuit_desc;
+/* Uploads the circuit, derives the 46 (21) coset tables, registers the commit bases.  The handle is process-wide: provers of
+ * every context may use it at the same time. */
+int uzk_circuit_create(const uzk_circuit_desc* desc, uint64_t* circuit_out);
+/* Replaces `count` polynomials from `first_slot` on (coefficient forms, host; lens[i] <= n) and re-derives their coset tables:
+ * what refresh_prover_params_public_key (shuffle/src/gen_params/params.rs:57-129) does to q_shuffle_public_key_polys /
+ * _coset_evals once per game -- first_slot = UZK_CS_QPK, count = 12.  Copy on write: a proof in flight (between its round 1 and
+ * its round 5) keeps the tables it started with, the next round 1 sees the new ones; nothing is freed under a running kernel. */
+int uzk_circuit_update_tables(uint64_t circuit, uint32_t first_slot, uint32_t count, const uint64_t* const* polys, const uint64_t* lens);
+/* The per-table loop of refresh_prover_params_public_key (params.rs:88-121) and indexer_with_lagrange (indexer.rs:316-470) as
+ * one device call: `count` evaluation vectors over the size-n domain (host, n elements each, evals + i * n)
+ *   -> batched iFFT(n) -> batched coset FFT(6n, k[1]) -> batched Lagrange commit of the evaluations,
+ * the results installed in slots first_slot .. first_slot + count (as uzk_circuit_update_tables would).  Outputs, each optional
+ * (NULL): polys_out = count x n coefficients (zero padded; lens_out[i] = coefs.len() after from_coefs' trimming), coset_out =
+ * count x 6n coset evaluations in the library's enumeration of the 6n domain (uzk_domain_group_gen(6 n)), commitments_out =
+ * count commitments (lagrange_pcs.commit(evals), no blinds). */
+int uzk_circuit_refresh_tables(uint64_t circuit, uint32_t first_slot, uint32_t count, const uint64_t* evals, uint64_t* polys_out,
+                               uint64_t* lens_out, uint64_t* coset_out, uzk_g1_jac* commitments_out);
+/* Device address and coefficient count of a slot's polynomial (which = 0; n elements allocated) or coset table (which = 1; 6n
+ * elements) as of now -- tests and diagnostics. */
+int uzk_circuit_table(uint64_t circuit, uint32_t slot, int which, const void** d_out, uint64_t* len_out);
+/* Waits for the calling context's stream; tables still held by a proof in flight are freed when that proof ends. */
+int uzk_circuit_release(uint64_t circuit);
+
+/* A prover = the device buffers of `batch` proofs over circuits of size n that advance in lockstep (batch = 1: one proof; a
+ * server with several witnesses of one circuit waiting runs them as ONE sequence of wider launches -- commits of 8 x batch
+ * vectors, transforms of 10 x batch).  Use a prover from one thread at a time; give concurrent prover threads their own
+ * context (uzk_ctx_create) and their own prover. */
+int uzk_prover_create(uint32_t n, uint32_t batch, uint64_t* prover_out);
+int uzk_prover_destroy(uint64_t prover);
+/* Per-proof arrays below are [batch][...]: element b of every input / output belongs to proof b.
+ *
+ * Round 1 (prover.rs:151-192): PI polynomial, wire and wire-selector polynomials: iFFT(n), hide_polynomial, commit with blinds.
+ *   witness   batch x 5 n: cs.extend_witness(w) (wire-major).          wsel  batch x 3 n: cs.compute_witness_selectors(), or NULL
+ *   inputs_on_device != 0: witness / wsel are device addresses (a witness produced on the device); host memory of
+ *     uzk_host_alloc is uploaded asynchronously, other host memory synchronously
+ *   pi_index  pi_count constraint indices (verifier_params.public_vars_constraint_indices), shared by the batch;
+ *   pi_value  batch x pi_count online values (helpers.rs:111-131; a repeated index takes its first value, as find_position does)
+ *   hiding    5 (+3 with wsel) hiding degrees <= 3: cs.get_hiding_degree(i), then 2 per wire selector (prover.rs:186)
+ *   blinds    batch x (5 or 8) x 3 elements: the draws of hide_polynomial in the reference's order, unused third slots zero
+ *   cm_out    batch x (5 or 8) commitments: cm_w_vec, then cm_w_sel_vec
+ * Takes the circuit's CURRENT tables for the whole proof. */
+int uzk_prove_round1(uint64_t prover, uint64_t circuit, const void* witness, const void* wsel, int inputs_on_device,
+                     const uint32_t* pi_index, const uint64_t* pi_value, uint32_t pi_count, const uint32_t* hiding,
+                     const uint64_t* blinds, uzk_g1_jac* cm_out);
+/* Round 2 (prover.rs:194-209): z_poly, iFFT, hide with 3 blinds, commit.  beta, gamma: batch x 4 limbs; blinds_z: batch x 3. */
+int uzk_prove_round2(uint64_t prover, const uint64_t* beta, const uint64_t* gamma, const uint64_t* blinds_z, uzk_g1_jac* cm_z_out);
+/* Round 3 (prover.rs:211-239): t_poly (helpers.rs:223-678) and split_t_and_commit with n_constraints + 2 (helpers.rs:1323-1408).
+ * alpha: batch x 4 limbs; t_rands: batch x 5 (one draw per chunk, chunk order); cm_t_out: batch x 5.
+ * from_coefs trims t and the trimmed length drives the split: the library goes on with the length a satisfied circuit gives
+ * (5 n - 2 + the wires' hiding degrees), measures the real one on the device meanwhile and redoes the split if they differ.
+ * UZK_ERR_COMMITMENT: t is longer than 5 (n + 2) + 1 coefficients (the witness does not satisfy the circuit; the reference
+ * indexes past its n + 3 SRS powers in apply_blind_factors and aborts there) or a chunk is shorter than n. */
+int uzk_prove_round3(uint64_t prover, const uint64_t* alpha, const uint64_t* t_rands, uzk_g1_jac* cm_t_out);
+/* Round 4 (prover.rs:241-273): the opening evaluations, in the reference's order of computation:
+ *   w_polys_eval_zeta (5), s_polys_eval_zeta (4), prk_3, prk_4, z_eval_zeta_omega, w_polys_eval_zeta_omega (3)
+ *   and, for a shuffle circuit, q_ecc_poly_eval_zeta, w_sel_polys_eval_zeta (3):  15 or 19 elements per proof.
+ * zeta: batch x 4 limbs; zeta * omega is formed here. */
+int uzk_prove_round4(uint64_t prover, const uint64_t* zeta, uint64_t* evals_out);
+/* Round 5 (prover.rs:296-372): r(X) = sum_k r_scalars[k] * p_k over (in this order) q_polys (9), z, s_polys[4], qb, q_prk1,
+ * q_prk2, [q_shuffle_public_key (12), q_shuffle_generator (12)], t chunks (5): 19 or 43 scalars per proof, which the caller gets
+ * from the reference's r_poly_or_comm (helpers.rs:681-1002); then both batch_prove calls (pcs.rs:107-168) with their transcript
+ * challenges alpha_zeta / alpha_zeta_omega: quotient, fold, FFT(n), Lagrange commit, blind factors.
+ * openings_out: batch x 2 (opening_witness_zeta, opening_witness_zeta_omega).  Ends the proof: the circuit tables are released. */
+int uzk_prove_round5(uint64_t prover, const uint64_t* r_scalars, const uint64_t* alpha_zeta, const uint64_t* alpha_zeta_omega,
+                     uzk_g1_jac* openings_out);
+/* Device address and element count (per proof: proof b's part starts b * elems_out elements in) of a prover buffer -- tests:
+ *   0 evals (10 n: w0..4, w_sel0..2, pi, z)  1 coefs (10 x 6n slots, same order)  2 coset evaluations (10 x 6n)
+ *   3 quotient evaluations (6n)  4 t (6n)  5 t chunks (5 x (n + 8))  6 folded (5 n)  7 tails (5 x 6)
+ *   8 opening quotients (2 x (n + 8))  9 r (n + 8).
+ * Without wire selectors the slot order of 0..2 is w0..4, pi, z (7 slots used). */
+int uzk_prover_buffer(uint64_t prover, int which, void** d_out, uint64_t* elems_out);
+
 /* ---- synthetic workloads (bench / tests; generated on device, nothing uploaded) -------- */
 /* d_points[i] = (i + 1) * Q with Q = seed_scalar * G: n distinct valid G1 points whose discrete
  * logs relative to Q are known, so MSM(points, s) == (sum_i s_i (i+1)) * Q for any size. */
@@ -363,7 +474,9 @@ int uzk_msm_plan_info(size_t n, int* window_bits, int* windows);
 /* Experiment switches for A/B measurements in one process (keys: "msm_acc_variant",
  * "msm_task_len", "msm_no_precompute", "msm_fold_group", "msm_overlap", "msm_sort_packed", "msm_fused_hist", "msm_reduce_seg", "msm_scan_reduce", "msm_quad_reduce", "ntt_tile",
  * "msm_chunk_log", "msm_stream_log", "msm_stream_min_log", "msm_small", "msm_fold_mode", "ntt_l29", "ntt_fused",
- * "msm_seg_sort", "msm_chunk_sort", "msm_class_reduce", "msm_fold_big", "msm_bucket_fill", "msm_direct", "msm_scan_nb_log", "ntt_prio", "ntt_order"); never needed for correctness. */
+ * "msm_seg_sort", "msm_chunk_sort", "msm_class_reduce", "msm_fold_big", "msm_bucket_fill", "msm_direct", "msm_scan_nb_log", "ntt_prio", "ntt_order",
+ * "prover_t_cap": round 3 reads t as its first 5n - 2 + sum(hiding) coefficients -- for the timing / parity chains on synthetic circuits
+ * whose witness satisfies nothing); never needed for correctness. */
 int uzk_tune(const char* key, int value);
 
 #ifdef __cplusplus

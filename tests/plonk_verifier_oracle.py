@@ -170,6 +170,7 @@ def make_satisfiable(inp, seed=1):
     cq = np.zeros((n, 4), dtype=np.uint64)
     cq[1] = _wire([1])[0]
     tp[pch.T_CQ] = cq                                               # coset_quotient(x) = x on the coset k1 * <g_m>
+    inp.satisfiable = True              # the chain then leaves slot 20 to the library and round 3 checks t's real length
     return inp
 
 

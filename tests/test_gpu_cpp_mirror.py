@@ -107,8 +107,9 @@ def _run_rounds_and_check(tmp_path, shuffle):
     small.update(evals=rd("evals", (-1, 4)), t_blinds=rd("t_blinds", (5, 3, 4)), q_blinds=rd("q_blinds", (2, 3, 4)))
     big = {"coefs": rd("coefs", (10, m, 4))[:, : n + 3], "coset_evals": rd("coset_evals", (10, m, 4)), "t_quotient": rd("t_quotient", (m, 4)),
            "t": rd("t", (m, 4)), "z_evals": rd("z_evals", (n, 4)), "r": rd("r", (n + 3, 4)), "chunks": rd("chunks", (5, cs, 4)),
-           "quotients": rd("quotients", (2, cs, 4)), "tables": rd("tables", (N_TABLES, m, 4))}
-    return V3, small, big, int(rd("tq_null_slots", (1,))[0])
+           "quotients": rd("quotients", (2, cs, 4)), "tables": rd("tables", (-1, m, 4))}
+    assert N_TABLES == 46
+    return V3, small, big
 
 
 @pytest.mark.gpu
@@ -117,18 +118,19 @@ def test_cpp_prover_rounds_match_frozen_outputs(gpu, tmp_path):
     (commitments over the reference's SRS files, evaluations, blinds, digests of the intermediates) -- the same fixture the
     Python chain is held to."""
     from test_gpu_golden import check_against_frozen
-    V3, small, big, nulls = _run_rounds_and_check(tmp_path, shuffle=True)
-    assert nulls == 0
+    V3, small, big = _run_rounds_and_check(tmp_path, shuffle=True)
+    assert big["tables"].shape[0] == 46
     check_against_frozen(V3, small, big)
 
 
 @pytest.mark.gpu
 def test_cpp_prover_rounds_without_shuffle_terms(gpu, tmp_path):
-    """The same driver for a circuit without the "shuffle" feature (zmatchmaking): 28 NULL slots in the quotient arguments, 15
-    evaluations, 19 polynomials in r, 12 in the opening at zeta; rounds 1-2 and the circuit tables are unchanged."""
+    """The same driver for a circuit without the "shuffle" feature (zmatchmaking): a circuit of 21 slots (the 25 shuffle / ECC
+    tables do not exist, the quotient kernel gets 28 NULL slots), 15 evaluations, 19 polynomials in r, 12 in the opening at
+    zeta; rounds 1-2 are unchanged."""
     import numpy as np
-    V3, small, big, nulls = _run_rounds_and_check(tmp_path, shuffle=False)
-    assert nulls == 28 and small["evals"].shape[0] == 15
+    V3, small, big = _run_rounds_and_check(tmp_path, shuffle=False)
+    assert big["tables"].shape[0] == 21 and small["evals"].shape[0] == 15
     assert np.array_equal(small["evals"][:15], V3["evals"][:15])             # the first 15 evaluations do not depend on the feature
     from test_gpu_golden import affine_of, oc
     for key in ("cm_w_wsel", "cm_z"):

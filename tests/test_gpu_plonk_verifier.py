@@ -104,6 +104,15 @@ def test_one_wrong_witness_value_fails_the_verifier_equations(gpu, what):
         bit = pv._ints(inp.wsel_evals[0, 21:22])[0]
         assert bit in (0, 1) and pv._ints(inp.wsel_evals[2, 21:22])[0] in (1, opy.R - 1)
         inp.wsel_evals[0, 21] = oc.fr_from_ints([1 - bit])[0]
+    # the prover itself notices: t no longer has the 5n + 11 coefficients of a satisfied circuit, and round 3 refuses to go on
+    # (the reference aborts at this point: apply_blind_factors indexes past its n + 3 SRS powers, kzg_poly_commitment.rs:299-313)
+    from uzkge_amd import UzkgeError
+    from uzkge_amd import _native as N
+    with pytest.raises(UzkgeError) as e:
+        _run_and_verify(inp, True)
+    assert e.value.code == N.UZK_ERR_COMMITMENT and "does not satisfy" in str(e.value)
+    # forced past that check (t read as its first 5n + 11 coefficients), the proof comes out and the verifier's equations reject it
+    inp.satisfiable = False
     ok, tail = _run_and_verify(inp, True)
     assert tail              # the division by Z_H leaves a remainder: the 6n-point interpolation fills the top coefficients
     assert not ok

@@ -19,8 +19,9 @@ are the reference's own.  Fiat-Shamir challenges, the prover's random blinds and
 Every commit is `lagrange_pcs.commit(evals)` + `apply_blind_factors` (prover.rs:132-142) as ONE batched MSM: the registered
 bases are lagrange[0..n) || srs[0..3) || srs[n..n+3), the scalars evals || b || -b (uzk_msm_g1_batch_tail_device).
 
-Everything goes through the C ABI alone (uzk_dev_alloc / uzk_dev_copy for the buffers): no torch, no HIP binding --
-tests/cpp/prover_rounds.cpp and rust/uzkge-glue/gpu_prover.rs issue the same calls in the same order.
+Everything goes through the C ABI alone: uzk_circuit_create makes the circuit resident, uzk_prover_create the proof's buffers,
+and uzk_prove_round1..5 run the five rounds -- the implementation tests/cpp/prover_rounds.cpp and rust/uzkge-glue/gpu_prover.rs
+drive as well (no torch, no HIP binding).
 tests/test_gpu_prover_chain.py checks every commitment, evaluation and intermediate polynomial against the CPU oracle chain.
 As a script: timing of the whole chain (python tools/prover_chain.py [--reps 5])."""
 import ctypes
@@ -118,14 +119,11 @@ class ChainInputs:
         self.t_len = 5 * n + 11
 
 
-class _Buf:
-    """`count` field elements of device memory from uzk_dev_alloc."""
+class _View:
+    """A prover buffer seen from Python: device address, element count, download."""
 
-    def __init__(self, count: int, zero: bool = False):
-        self.count = count
-        self.ptr = b.dev_alloc(count * 32)
-        if zero:
-            b.dev_memset(self.ptr, 0, count * 32)
+    def __init__(self, ptr: int, count: int):
+        self.ptr, self.count = ptr, count
 
     def at(self, elem: int) -> int:
         return self.ptr + 32 * elem
@@ -133,178 +131,110 @@ class _Buf:
     def host(self, count: int = None, offset: int = 0) -> np.ndarray:
         return b.dev_download(self.at(offset), (self.count - offset if count is None else count, 4))
 
-    def free(self):
-        if self.ptr:
-            b.dev_free(self.ptr)
-            self.ptr = 0
-
 
 class ProverChain:
+    """One proof through uzk_prove_round1..5 (include/uzkge_gpu.h): the circuit is a uzk_circuit handle, the proof's buffers a
+    uzk_prover; this class only supplies what the Rust prover supplies -- witness, blinds, challenges, r_poly's scalars."""
+
     def __init__(self, n: int = 1 << 14, seed: int = 2024, shuffle: bool = True, precompute: bool = True, inputs: ChainInputs = None,
                  keep_blinds: bool = False):
         b.init(0)
-        self.keep_blinds = keep_blinds       # tests: also fetch the fold blinds (a synchronisation per fold; timing runs leave it off)
+        self.keep_blinds = keep_blinds       # tests: also fetch the fold blinds (read back from the tail buffer after rounds 3 and 5)
         inp = inputs if inputs is not None else ChainInputs(n, seed)
         self.__dict__.update(inp.__dict__)               # the inputs' fields are read as attributes of the chain
         self.inputs, self.shuffle = inp, shuffle
-        n, m = self.n, self.m
-        self.srs = b.Srs.from_host(self.bases)
+        n = self.n
         b.tune("msm_no_precompute", 0)
-        if precompute:
-            self.srs.precompute(0)            # static SRS: window table (same commitments, shorter calls)
-        self.cs = n + 8                       # stride of the chunk / quotient arrays
-        # ---- device residency
-        self.d_evals = _Buf(9 * n)            # w0..w4, wsel0..2, pi
-        b.dev_upload(self.d_evals.ptr, np.concatenate([self.w_evals.reshape(-1, 4), self.wsel_evals.reshape(-1, 4), self.pi_evals]))
-        self.d_perm = b.dev_alloc(N_WIRES * n * 4)
-        b.dev_upload(self.d_perm, self.perm)
-        self.d_coefs = _Buf(10 * m, zero=True)           # 10 polynomials of this proof, 6n slots each (zero beyond n + 3)
-        self.d_coset = _Buf(10 * m)
-        self.d_tq, self.d_t, self.d_z = _Buf(m), _Buf(m), _Buf(n)
-        self.d_chunks = _Buf(5 * self.cs)
-        self.d_fold = _Buf(5 * n)
-        self.d_tail = _Buf(5 * 6)
-        self.d_q = _Buf(2 * self.cs)
-        self.d_r = _Buf(self.cs)
-        self.h_lens = b.host_alloc(4 * 8)     # pinned result words of the asynchronous trimmed-length checks: t, q at zeta, q at zeta omega
-        # the circuit's polynomials and their coset evaluations (the indexer's work, once per circuit): zero-padded copy into
-        # 6n-slots, one batched coset FFT in place
-        self.d_tpolys = _Buf(N_TABLES * n)
-        b.dev_upload(self.d_tpolys.ptr, self.table_polys.reshape(-1, 4))
-        self.d_tables = _Buf(N_TABLES * m, zero=True)
-        b.dev_copy2d(self.d_tables.ptr, m * 32, self.d_tpolys.ptr, n * 32, n * 32, N_TABLES)
-        b.ntt_batch_device(self.d_tables.ptr, self.d_tables.ptr, m, N_TABLES, coset_shift=self.k[1], sync=True)
-        # the powers group[i] = omega^i on the device: forward NTT of X (coefficient 1 at index 1)
-        x = np.zeros((n, 4), dtype=np.uint64)
-        x[1] = pc.fr_from_int(1)
-        self.d_group = _Buf(n)
-        b.dev_upload(self.d_group.ptr, x)
-        b.ntt_device(self.d_group.ptr, self.d_group.ptr, n, sync=True)
+        # a random circuit is satisfied by nothing: its t fills all 6n coefficients, and round 3 would refuse it (as the reference
+        # aborts on it).  The timing / parity chains take t as its first t_len coefficients (tests/chain_oracle.py does the same);
+        # circuits made satisfiable (tests/plonk_verifier_oracle.py) run the real check.
+        b.tune("prover_t_cap", 0 if getattr(inp, "satisfiable", False) else 1)
+        polys = [self.table_polys[i] for i in range(N_TABLES)]
+        if getattr(inp, "satisfiable", False):
+            polys[T_CQ] = None               # coset_quotient: the library builds it (the random circuits keep their arbitrary slot 20)
+        self.circuit = b.Circuit(n, self.lagrange_wire, self.bases[n:], self.perm, self.k, self.anemoi_g, self.anemoi_g_inv, self.edwards_a,
+                                 polys, shuffle=shuffle, precompute=precompute)
+        self.prover = b.Prover(n, 1)
+        self.cs = n + 8
+        self._srs = None
+        self.witness = np.ascontiguousarray(self.w_evals.reshape(1, N_WIRES * n, 4))
+        self.wsel = np.ascontiguousarray(self.wsel_evals.reshape(1, N_WSEL * n, 4))
+        self.pi_index = np.arange(8, dtype=np.uint32)    # ChainInputs puts its eight public inputs on the first eight constraints
+        self.hiding = list(HIDE_W) + [HIDE_WSEL] * N_WSEL
+        self.d_coset = _View(*self.prover.buffer(b.PB_COSET))
+        self.d_tq = _View(*self.prover.buffer(b.PB_TQ))
         self.out = {}
 
-    # the device address and length of a polynomial named by a plan entry
-    def _poly(self, kind, idx):
-        n, m = self.n, self.m
-        if kind == "c":
-            return self.d_coefs.at(idx * m), n + 3
-        if kind == "t":
-            return self.d_tpolys.at(idx * n), n
-        if kind == "k":
-            return self.d_chunks.at(idx * self.cs), int(self.chunk_lens[idx])
-        return self.d_r.ptr, n + 3
+    @property
+    def srs(self):
+        """The Lagrange bases || blind bases as a plain SRS handle (tests commit the circuit's own polynomials with it)."""
+        if self._srs is None:
+            self._srs = b.Srs.from_host(self.bases)
+        return self._srs
 
-    @staticmethod
-    def _tails(blinds_list):
-        tail = np.zeros((len(blinds_list), 6, 4), dtype=np.uint64)
-        for i, bl in enumerate(blinds_list):
-            bl = np.asarray(bl, dtype=np.uint64).reshape(-1, 4)
-            tail[i, : bl.shape[0]] = bl
-            tail[i, 3:3 + bl.shape[0]] = pc.fr_neg(bl)
-        return tail
+    @property
+    def tq_ptrs(self):
+        """The 56 vector addresses round 3 hands the quotient kernel (UZK_TQ_* order), rebuilt from the public accessors."""
+        m = self.m
+        cos = [self.d_coset.at(i * m) for i in range(10)]
+        tab = [self.circuit.table(i, coset=True)[0] if i < self.circuit.n_slots else 0 for i in range(N_TABLES)]
+        return cos[:5] + [cos[5 + i] if self.shuffle else 0 for i in range(3)] + [cos[8], cos[9]] + tab
+
+    def _blinds_from_tail(self, count):
+        tail = self.prover.download(b.PB_TAIL)[: count * 6].reshape(count, 6, 4)
+        return np.ascontiguousarray(tail[:, :3])
 
     def run(self):
-        n, m, o, cs = self.n, self.m, self.out, self.cs
-        coefs = self.d_coefs
-        # ---- round 1: iFFT of the nine evaluation vectors straight into their 6n-slots, hide, commit wires and wire selectors
-        b.ntt_batch_strided_device(self.d_evals.ptr, n, coefs.ptr, m, n, 9, inverse=True)
-        b.hide_polynomial_batch_device(coefs.ptr, m, n, np.concatenate([self.blinds_w, self.blinds_wsel]), n)
-        o["cm_w_wsel"] = b.msm_batch_tail_device(self.srs, self.d_evals.ptr, n, n, 8, self._tails(list(self.blinds_w) + list(self.blinds_wsel)), 6)
-        # Fiat-Shamir: the challenges are the caller's (the Rust prover draws them from its transcript after each round,
-        # prover.rs:194-244,300-302).  Seeded stand-ins for the timing runs; `self.fs` (tests/test_gpu_plonk_verifier.py) derives them
-        # from the commitments and evaluations the way the reference's transcript does.
+        o, pr = self.out, self.prover
+        # ---- round 1.  Fiat-Shamir: the challenges are the caller's (the Rust prover draws them from its transcript after each
+        # round, prover.rs:194-244,300-302).  Seeded stand-ins for the timing runs; `self.fs` (tests/test_gpu_plonk_verifier.py)
+        # derives them from the commitments and evaluations the way the reference's transcript does.
+        o["cm_w_wsel"] = pr.round1(self.circuit, self.witness, self.wsel, self.pi_index, self.pi_evals[:8].reshape(1, 8, 4), self.hiding,
+                                   np.concatenate([self.blinds_w, self.blinds_wsel]))
         fs = getattr(self, "fs", None)
         if fs is not None:
             self.beta, self.gamma = fs.beta_gamma(o["cm_w_wsel"])
-        # ---- round 2: permutation grand product
-        b.z_poly_device(self.d_evals.ptr, self.d_perm, self.d_group.ptr, self.k, self.beta, self.gamma, n, N_WIRES, self.d_z.ptr)
-        b.ntt_batch_strided_device(self.d_z.ptr, n, coefs.at(9 * m), m, n, 1, inverse=True)
-        b.hide_polynomial_batch_device(coefs.at(9 * m), m, n, self.blinds_z.reshape(1, 3, 4), n)
-        o["cm_z"] = b.msm_batch_tail_device(self.srs, self.d_z.ptr, n, n, 1, self._tails([self.blinds_z]), 6)
+        # ---- round 2
+        o["cm_z"] = pr.round2(self.beta, self.gamma, self.blinds_z)
         if fs is not None:
             self.alpha = fs.alpha(o["cm_z"])
-        # ---- round 3: quotient polynomial
-        b.ntt_batch_device(coefs.ptr, self.d_coset.ptr, m, 10, coset_shift=self.k[1])
-        cos = [self.d_coset.at(i * m) for i in range(10)]
-        tab = [self.d_tables.at(i * m) for i in range(N_TABLES)]
-        ptrs = cos[:5] + [cos[5 + i] if self.shuffle else 0 for i in range(3)] + [cos[8], cos[9]]
-        ptrs += tab[:21]                                                     # q (9), s (5), l1, qb, q_prk (4), coset_quotient
-        ptrs += [tab[21 + i] if self.shuffle else 0 for i in range(25)]      # q_pk (12), q_g (12), q_ecc
-        self.tq_ptrs = ptrs
-        b.t_quotient_device(n, 6, ptrs, self.alpha, self.beta, self.gamma, self.k, self.anemoi_g, self.anemoi_g_inv, self.edwards_a,
-                            self.z_h_inv, self.d_tq.ptr, sync=False)
-        b.ntt_device(self.d_tq.ptr, self.d_t.ptr, m, inverse=True, coset_shift=self.k1_inv)
-        # split_t_and_commit (helpers.rs:1323-1408, chunk = n + 2): split with the random blinds, fold mod X^n - 1, FFT(n), commit
-        # from_coefs trims t (field_polynomial.rs:86-90) and its coefs.len() drives the split (helpers.rs:1333): go on with the length a
-        # well-formed proof has (deg t = 5n + 10) while the device measures the trimmed one into pinned memory; compare after the
-        # commit has synchronised, redo the split with the measured length if they ever differ
-        lens_view = np.ctypeslib.as_array(ctypes.cast(self.h_lens, ctypes.POINTER(ctypes.c_uint64)), shape=(4,))
-        b.poly_trimmed_len_async_device(self.d_t.ptr, m, [self.t_len], self.h_lens)
-
-        def split_and_commit(t_len):
-            self.chunk_lens = b.split_t_device(self.d_t.ptr, t_len, n + 2, self.t_rands, self.d_chunks.ptr, cs)
-            assert [pc.max_power_of_2(int(v)) for v in self.chunk_lens] == [n] * 5      # degree = coefs.len() (helpers.rs:1367)
-            o["t_blinds"] = b.fold_blinds_batch_device(self.d_chunks.ptr, cs, self.chunk_lens, n, self.d_fold.ptr, n, self.d_tail.ptr, 6,
-                                                       want_blinds=self.keep_blinds)
-            b.ntt_batch_device(self.d_fold.ptr, self.d_fold.ptr, n, 5)
-            o["cm_t"] = b.msm_batch_tail_device(self.srs, self.d_fold.ptr, n, n, 5, self.d_tail.ptr, 6)
-        split_and_commit(self.t_len)
-        if int(lens_view[0]) != self.t_len:
-            split_and_commit(int(lens_view[0]))
+        # ---- round 3
+        o["cm_t"] = pr.round3(self.alpha, self.t_rands)
+        if self.keep_blinds:
+            o["t_blinds"] = self._blinds_from_tail(5)
         if fs is not None:
             self.zeta = fs.zeta(o["cm_t"])
             self.zeta_omega = pc.fr_from_int(pc.fr_to_int(self.zeta) * pc.fr_to_int(self.group_gen) % pc.FR_MODULUS)
-        # ---- round 4: the evaluations of prover.rs:246-273 in one launch
-        plan = eval_plan(self.shuffle)
-        pl = [self._poly(kind, idx) for kind, idx, _ in plan]
-        o["evals"] = b.poly_eval_ptrs_device([p for p, _ in pl], [ln for _, ln in pl], [pt for _, _, pt in plan], np.stack([self.zeta, self.zeta_omega]))
-        # ---- round 5: r(X) = sum of scalars * polynomials (r_poly's shape), then the two openings
-        rp = [self._poly(kind, idx) for kind, idx in r_plan(self.shuffle)]
-        # r_poly's scalars are O(1) formulas of the evaluations and the challenges (helpers.rs:681-1002) and stay with the caller, as in
-        # the reference: the timing runs pass seeded stand-ins, tests/test_gpu_plonk_verifier.py derives them from round 4's evaluations
+        # ---- round 4
+        o["evals"] = pr.round4(self.zeta, self.shuffle)
+        # ---- round 5.  r_poly's scalars are O(1) formulas of the evaluations and the challenges (helpers.rs:681-1002) and stay
+        # with the caller, as in the reference: the timing runs pass seeded stand-ins, tests/test_gpu_plonk_verifier.py derives
+        # them from round 4's evaluations
         if fs is not None:
             self.alpha_open, self.alpha_open2 = fs.after_evaluations(o["evals"], self.zeta, self.zeta_omega)
         r_scalars = self.r_scalar_hook(o["evals"]) if getattr(self, "r_scalar_hook", None) is not None else self.r_scalars
-        b.poly_lincomb_device([p for p, _ in rp], [ln for _, ln in rp], r_scalars[: len(rp)], self.d_r.ptr, n + 3)
-        at_zeta, at_zeta_omega = open_plan(self.shuffle)
-        for j, (plan_j, point, alpha) in enumerate(((at_zeta, self.zeta, self.alpha_open), (at_zeta_omega, self.zeta_omega, self.alpha_open2))):
-            op = [self._poly(kind, idx) for kind, idx in plan_j]
-            b.open_quotient_ptrs_device([p for p, _ in op], [ln for _, ln in op], point, alpha, self.d_q.at(j * cs), cs)
-        # degree = q.degree() (pcs.rs:138): n + 1 for n + 3 coefficients divided by X - z, so max_power_of_2 = n and two blinds;
-        # expected lengths first, the device's measurement checked after the commit
-        b.poly_trimmed_len_async_device(self.d_q.ptr, cs, [n + 3, n + 3], self.h_lens + 8)
-
-        def fold_and_commit(q_lens):
-            assert [pc.max_power_of_2(int(v) - 1) for v in q_lens] == [n, n]
-            o["q_blinds"] = b.fold_blinds_batch_device(self.d_q.ptr, cs, q_lens, n, self.d_fold.ptr, n, self.d_tail.ptr, 6,
-                                                       want_blinds=self.keep_blinds)
-            b.ntt_batch_device(self.d_fold.ptr, self.d_fold.ptr, n, 2)
-            o["cm_q"] = b.msm_batch_tail_device(self.srs, self.d_fold.ptr, n, n, 2, self.d_tail.ptr, 6)
-        fold_and_commit([n + 2, n + 2])
-        if [int(lens_view[1]), int(lens_view[2])] != [n + 2, n + 2]:
-            fold_and_commit([int(lens_view[1]), int(lens_view[2])])
+        o["cm_q"] = pr.round5(r_scalars[: len(r_plan(self.shuffle))], self.alpha_open, self.alpha_open2)
+        if self.keep_blinds:
+            o["q_blinds"] = self._blinds_from_tail(2)
         return o
 
     def snapshot(self):
         """The device-resident intermediates of the last run as host arrays, named as tests/chain_oracle.py names them."""
-        n, m, cs = self.n, self.m, self.cs
+        n, m, cs, pr = self.n, self.m, self.cs, self.prover
         b.sync()
-        coefs = self.d_coefs.host().reshape(10, m, 4)
-        return {"coefs": coefs[:, : n + 3], "coefs_beyond": coefs[:, n + 3:], "coset_evals": self.d_coset.host().reshape(10, m, 4),
-                "t_quotient": self.d_tq.host(), "t": self.d_t.host(), "z_evals": self.d_z.host(), "r": self.d_r.host(n + 3),
-                "chunks": self.d_chunks.host().reshape(5, cs, 4), "quotients": self.d_q.host().reshape(2, cs, 4),
-                "tables": self.d_tables.host().reshape(N_TABLES, m, 4)}
+        coefs = pr.download(b.PB_COEFS).reshape(10, m, 4)
+        tables = np.stack([b.dev_download(self.circuit.table(i, coset=True)[0], (m, 4)) for i in range(self.circuit.n_slots)])
+        return {"coefs": coefs[:, : n + 3], "coefs_beyond": coefs[:, n + 3:], "coset_evals": pr.download(b.PB_COSET).reshape(10, m, 4),
+                "t_quotient": pr.download(b.PB_TQ), "t": pr.download(b.PB_T), "z_evals": pr.download(b.PB_EVALS).reshape(10, n, 4)[9],
+                "r": pr.download(b.PB_R)[: n + 3], "chunks": pr.download(b.PB_CHUNKS).reshape(5, cs, 4),
+                "quotients": pr.download(b.PB_Q).reshape(2, cs, 4), "tables": tables}
 
     def release(self):
-        self.srs.release()
-        for v in list(self.__dict__.values()):
-            if isinstance(v, _Buf):
-                v.free()
-        if self.d_perm:
-            b.dev_free(self.d_perm)
-            self.d_perm = 0
-        if self.h_lens:
-            b.host_free(self.h_lens)
-            self.h_lens = 0
+        if self._srs is not None:
+            self._srs.release()
+            self._srs = None
+        self.prover.destroy()
+        self.circuit.release()
 
 
 if __name__ == "__main__":

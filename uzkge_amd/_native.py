@@ -74,6 +74,19 @@ PROTOTYPES = {
     "uzk_fold_blinds_device": (_I, [_P, ctypes.c_uint64, ctypes.c_uint64, _P, _P]),
     "uzk_poly_lincomb_device": (_I, [_P, _P, _P, ctypes.c_uint32, _P, ctypes.c_uint64]),
     "uzk_hide_polynomial_device": (_I, [_P, ctypes.c_uint64, _P, ctypes.c_uint32, ctypes.c_uint64]),
+    "uzk_circuit_create": (_I, [_P, ctypes.POINTER(_U64)]),
+    "uzk_circuit_update_tables": (_I, [_U64, ctypes.c_uint32, ctypes.c_uint32, _P, _P]),
+    "uzk_circuit_refresh_tables": (_I, [_U64, ctypes.c_uint32, ctypes.c_uint32, _P, _P, _P, _P, _P]),
+    "uzk_circuit_table": (_I, [_U64, ctypes.c_uint32, _I, ctypes.POINTER(_P), ctypes.POINTER(_U64)]),
+    "uzk_circuit_release": (_I, [_U64]),
+    "uzk_prover_create": (_I, [ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_U64)]),
+    "uzk_prover_destroy": (_I, [_U64]),
+    "uzk_prove_round1": (_I, [_U64, _U64, _P, _P, _I, _P, _P, ctypes.c_uint32, _P, _P, _P]),
+    "uzk_prove_round2": (_I, [_U64, _P, _P, _P, _P]),
+    "uzk_prove_round3": (_I, [_U64, _P, _P, _P]),
+    "uzk_prove_round4": (_I, [_U64, _P, _P]),
+    "uzk_prove_round5": (_I, [_U64, _P, _P, _P, _P]),
+    "uzk_prover_buffer": (_I, [_U64, _I, ctypes.POINTER(_P), ctypes.POINTER(_U64)]),
     "uzk_synth_points_arith": (_I, [_P, _SZ, _P]),
     "uzk_synth_points_random": (_I, [_P, _SZ, _U64]),
     "uzk_synth_scalars": (_I, [_P, _SZ, _U64]),
@@ -142,4 +155,20 @@ class QuotientArgs(ctypes.Structure):
         ("k", (ctypes.c_uint64 * 4) * 5),
         ("anemoi_g", ctypes.c_uint64 * 4), ("anemoi_g_inv", ctypes.c_uint64 * 4), ("edwards_a", ctypes.c_uint64 * 4),
         ("z_h_inv", (ctypes.c_uint64 * 4) * 16),
+    ]
+
+
+CIRCUIT_SLOTS = 46
+
+
+class CircuitDesc(ctypes.Structure):
+    """uzk_circuit_desc (include/uzkge_gpu.h)."""
+    _fields_ = [
+        ("n", ctypes.c_uint32), ("shuffle", ctypes.c_uint32), ("precompute", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
+        ("lagrange_bases", ctypes.c_void_p), ("blind_bases", ctypes.c_void_p), ("permutation", ctypes.c_void_p),
+        ("k", (ctypes.c_uint64 * 4) * 5),
+        ("anemoi_g", ctypes.c_uint64 * 4), ("anemoi_g_inv", ctypes.c_uint64 * 4), ("edwards_a", ctypes.c_uint64 * 4),
+        ("group_gen", ctypes.c_uint64 * 4),
+        ("polys", ctypes.c_void_p * CIRCUIT_SLOTS),
+        ("poly_lens", ctypes.c_uint64 * CIRCUIT_SLOTS),
     ]

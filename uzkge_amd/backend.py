@@ -531,3 +531,152 @@ def open_quotient_ptrs_device(d_polys, lens, z: np.ndarray, alpha: np.ndarray, d
     check(lib.uzk_open_quotient_ptrs_device(_ptr_list(d_polys), _ptr(ln), cnt, _ptr(_fr4(z)), _ptr(_fr4(alpha)), ctypes.c_void_p(d_q), q_cap,
                                             _ptr(ev) if want_evals else None))
     return ev
+
+
+# ---- circuits and the five prover rounds (uzk_circuit_*, uzk_prover_*, uzk_prove_round1..5) ---------------------------
+CS_Q, CS_S, CS_L1, CS_QB, CS_QPRK, CS_COSET_QUOTIENT, CS_QPK, CS_QG, CS_QECC = 0, 9, 14, 15, 16, 20, 21, 33, 45
+PB_EVALS, PB_COEFS, PB_COSET, PB_TQ, PB_T, PB_CHUNKS, PB_FOLD, PB_TAIL, PB_Q, PB_R = range(10)
+
+
+def trimmed_len(coefs: np.ndarray) -> int:
+    """coefs.len() after FpPolynomial::from_coefs (field_polynomial.rs:86-90): trailing zero coefficients dropped."""
+    nz = np.nonzero(np.any(np.asarray(coefs).reshape(-1, 4) != 0, axis=1))[0]
+    return int(nz[-1]) + 1 if nz.size else 0
+
+
+class Circuit:
+    """A circuit resident in HBM (uzk_circuit_create): commit bases, permutation, the 46 (21) polynomials and their coset tables."""
+
+    def __init__(self, n: int, lagrange_bases: np.ndarray, blind_bases: np.ndarray, permutation: np.ndarray, k: np.ndarray, anemoi_g, anemoi_g_inv,
+                 edwards_a, polys, shuffle: bool = True, precompute: bool = False, group_gen=None, lens=None):
+        d = N.CircuitDesc()
+        d.n, d.shuffle, d.precompute = n, int(shuffle), int(precompute)
+        keep = []
+        lag = np.ascontiguousarray(lagrange_bases, dtype=np.uint64).reshape(-1, 8)
+        bb = np.ascontiguousarray(blind_bases, dtype=np.uint64).reshape(-1, 8)
+        perm = np.ascontiguousarray(permutation, dtype=np.uint32).reshape(-1)
+        assert lag.shape[0] == n and bb.shape[0] == 6 and perm.shape[0] == 5 * n
+        keep += [lag, bb, perm]
+        d.lagrange_bases, d.blind_bases, d.permutation = lag.ctypes.data, bb.ctypes.data, perm.ctypes.data
+
+        kk = np.ascontiguousarray(k, dtype=np.uint64).reshape(5, 4)
+        for j in range(5):
+            for w in range(4):
+                d.k[j][w] = int(kk[j, w])
+        for name, val in (("anemoi_g", anemoi_g), ("anemoi_g_inv", anemoi_g_inv), ("edwards_a", edwards_a),
+                          ("group_gen", domain_group_gen(n) if group_gen is None else group_gen)):
+            v = np.ascontiguousarray(val, dtype=np.uint64).reshape(4)
+            for w in range(4):
+                getattr(d, name)[w] = int(v[w])
+        n_slots = N.CIRCUIT_SLOTS if shuffle else CS_QPK
+        for s in range(n_slots):
+            if polys[s] is None:            # slot 20 (coset_quotient) is normally None: the library builds it
+                continue
+            a = np.ascontiguousarray(polys[s], dtype=np.uint64).reshape(-1, 4)
+            keep.append(a)
+            d.polys[s] = a.ctypes.data
+            d.poly_lens[s] = trimmed_len(a) if lens is None else int(lens[s])
+        h = ctypes.c_uint64(0)
+        check(lib.uzk_circuit_create(ctypes.byref(d), ctypes.byref(h)))
+        self.handle, self.n, self.shuffle, self.n_slots = h.value, n, shuffle, n_slots
+
+    def update_tables(self, first_slot: int, polys, lens=None) -> None:
+        arrs = [np.ascontiguousarray(p, dtype=np.uint64).reshape(-1, 4) for p in polys]
+        ptrs = (ctypes.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        ln = (ctypes.c_uint64 * len(arrs))(*[trimmed_len(a) if lens is None else int(lens[i]) for i, a in enumerate(arrs)])
+        check(lib.uzk_circuit_update_tables(self.handle, first_slot, len(arrs), ptrs, ln))
+
+    def refresh_tables(self, first_slot: int, evals: np.ndarray, want_polys: bool = True, want_coset: bool = False):
+        """The refresh / indexer loop on the device: evaluation vectors -> iFFT -> coset FFT -> Lagrange commit, installed in the
+        slots.  Returns (commitments [count,12], polys [count,n,4] | None, lens, coset [count,6n,4] | None)."""
+        e = np.ascontiguousarray(evals, dtype=np.uint64).reshape(-1, self.n, 4)
+        cnt = e.shape[0]
+        polys = np.zeros((cnt, self.n, 4), dtype=np.uint64) if want_polys else None
+        coset = np.zeros((cnt, 6 * self.n, 4), dtype=np.uint64) if want_coset else None
+        lens = np.zeros(cnt, dtype=np.uint64)
+        cms = np.zeros((cnt, 12), dtype=np.uint64)
+        check(lib.uzk_circuit_refresh_tables(self.handle, first_slot, cnt, _ptr(e), _ptr(polys) if want_polys else None, _ptr(lens),
+                                             _ptr(coset) if want_coset else None, _ptr(cms)))
+        return cms, polys, lens, coset
+
+    def table(self, slot: int, coset: bool = False):
+        """(device address, element count) of a slot's polynomial or coset table."""
+        p, ln = ctypes.c_void_p(0), ctypes.c_uint64(0)
+        check(lib.uzk_circuit_table(self.handle, slot, int(coset), ctypes.byref(p), ctypes.byref(ln)))
+        return p.value or 0, ln.value
+
+    def release(self) -> None:
+        if self.handle:
+            check(lib.uzk_circuit_release(self.handle))
+            self.handle = 0
+
+
+class Prover:
+    """The device buffers of `batch` proofs in lockstep (uzk_prover_create) and the five rounds."""
+
+    def __init__(self, n: int, batch: int = 1):
+        h = ctypes.c_uint64(0)
+        check(lib.uzk_prover_create(n, batch, ctypes.byref(h)))
+        self.handle, self.n, self.batch = h.value, n, batch
+
+    def round1(self, circuit: Circuit, witness, wsel, pi_index, pi_value, hiding, blinds, on_device: bool = False) -> np.ndarray:
+        """witness / wsel: arrays [batch, 5n, 4] / [batch, 3n, 4] (or None), or device addresses with on_device."""
+        B, n_first = self.batch, 8 if wsel is not None else 5
+        if on_device:
+            w_ptr, s_ptr = ctypes.c_void_p(witness), (ctypes.c_void_p(wsel) if wsel is not None else None)
+        else:
+            w = np.ascontiguousarray(witness, dtype=np.uint64).reshape(B, 5 * self.n, 4)
+            s = None if wsel is None else np.ascontiguousarray(wsel, dtype=np.uint64).reshape(B, 3 * self.n, 4)
+            w_ptr, s_ptr = _ptr(w), (None if s is None else _ptr(s))
+        idx = np.ascontiguousarray(pi_index, dtype=np.uint32).reshape(-1)
+        val = np.ascontiguousarray(pi_value, dtype=np.uint64).reshape(B, idx.size, 4) if idx.size else np.zeros((B, 0, 4), dtype=np.uint64)
+        hd = np.ascontiguousarray(hiding, dtype=np.uint32).reshape(n_first)
+        bl = np.ascontiguousarray(blinds, dtype=np.uint64).reshape(B, n_first, 3, 4)
+        out = np.zeros((B * n_first, 12), dtype=np.uint64)
+        check(lib.uzk_prove_round1(self.handle, circuit.handle, w_ptr, s_ptr, int(on_device), idx.ctypes.data_as(ctypes.c_void_p) if idx.size else None,
+                                   _ptr(val) if idx.size else None, idx.size, hd.ctypes.data_as(ctypes.c_void_p), _ptr(bl), _ptr(out)))
+        return out
+
+    def round2(self, beta, gamma, blinds_z) -> np.ndarray:
+        B = self.batch
+        out = np.zeros((B, 12), dtype=np.uint64)
+        check(lib.uzk_prove_round2(self.handle, _ptr(_frs(beta, B)), _ptr(_frs(gamma, B)), _ptr(_frs(blinds_z, 3 * B)), _ptr(out)))
+        return out
+
+    def round3(self, alpha, t_rands) -> np.ndarray:
+        B = self.batch
+        out = np.zeros((5 * B, 12), dtype=np.uint64)
+        check(lib.uzk_prove_round3(self.handle, _ptr(_frs(alpha, B)), _ptr(_frs(t_rands, 5 * B)), _ptr(out)))
+        return out
+
+    def round4(self, zeta, shuffle: bool = True) -> np.ndarray:
+        B, per = self.batch, 19 if shuffle else 15
+        out = np.zeros((B * per, 4), dtype=np.uint64)
+        check(lib.uzk_prove_round4(self.handle, _ptr(_frs(zeta, B)), _ptr(out)))
+        return out
+
+    def round5(self, r_scalars, alpha_zeta, alpha_zeta_omega) -> np.ndarray:
+        B = self.batch
+        rs = np.ascontiguousarray(r_scalars, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros((2 * B, 12), dtype=np.uint64)
+        check(lib.uzk_prove_round5(self.handle, _ptr(rs), _ptr(_frs(alpha_zeta, B)), _ptr(_frs(alpha_zeta_omega, B)), _ptr(out)))
+        return out
+
+    def buffer(self, which: int):
+        """(device address, elements per proof) of a prover buffer (PB_*)."""
+        p, ln = ctypes.c_void_p(0), ctypes.c_uint64(0)
+        check(lib.uzk_prover_buffer(self.handle, which, ctypes.byref(p), ctypes.byref(ln)))
+        return p.value or 0, ln.value
+
+    def download(self, which: int, proof: int = 0) -> np.ndarray:
+        p, ln = self.buffer(which)
+        return dev_download(p + 32 * ln * proof, (ln, 4))
+
+    def destroy(self) -> None:
+        if self.handle:
+            check(lib.uzk_prover_destroy(self.handle))
+            self.handle = 0
+
+
+def _frs(a, count: int) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.uint64).reshape(count, 4)

@@ -248,6 +248,7 @@ int uzk_init(int device) {
 // belongs to the caller and is not touched.
 int uzk_shutdown(void) {
     Shared& s = shared();
+    prover_release_all();                  // circuits and provers own device memory and SRS entries (takes Shared::mu itself)
     std::lock_guard<std::mutex> lk(s.mu);
     if (!s.bound) return UZK_OK;
     (void)hipSetDevice(s.device);
@@ -278,7 +279,7 @@ static void copy_tuning(const Ctx& from, Ctx& to) {
     to.tune_fused_hist = from.tune_fused_hist; to.tune_sort_packed = from.tune_sort_packed; to.tune_ntt_fused = from.tune_ntt_fused;
     to.tune_ntt_tile = from.tune_ntt_tile; to.tune_ntt_l29 = from.tune_ntt_l29; to.tune_small = from.tune_small;
     to.tune_fold_mode = from.tune_fold_mode; to.tune_chunk_log = from.tune_chunk_log; to.tune_overlap = from.tune_overlap;
-    to.tune_seg_sort = from.tune_seg_sort; to.tune_direct = from.tune_direct; to.tune_bucket_fill = from.tune_bucket_fill; to.tune_fold_big = from.tune_fold_big; to.tune_scan_nb_log = from.tune_scan_nb_log; to.tune_ntt_prio = from.tune_ntt_prio; to.tune_ntt_order = from.tune_ntt_order; to.tune_class_reduce = from.tune_class_reduce; to.tune_chunk_sort = from.tune_chunk_sort; to.tune_scatter4 = from.tune_scatter4; to.tune_stream_log = from.tune_stream_log; to.tune_stream_min_log = from.tune_stream_min_log;
+    to.tune_seg_sort = from.tune_seg_sort; to.tune_direct = from.tune_direct; to.tune_bucket_fill = from.tune_bucket_fill; to.tune_fold_big = from.tune_fold_big; to.tune_scan_nb_log = from.tune_scan_nb_log; to.tune_ntt_prio = from.tune_ntt_prio; to.tune_ntt_order = from.tune_ntt_order; to.tune_class_reduce = from.tune_class_reduce; to.tune_chunk_sort = from.tune_chunk_sort; to.tune_scatter4 = from.tune_scatter4; to.tune_stream_log = from.tune_stream_log; to.tune_stream_min_log = from.tune_stream_min_log; to.tune_prover_t_cap = from.tune_prover_t_cap;
 }
 int uzk_ctx_create(uint64_t* ctx_out) {
     if (!ctx_out) { set_error("uzk_ctx_create: null pointer"); return UZK_ERR_PARAMETER; }
@@ -413,8 +414,10 @@ int uzk_host_free(void* h_ptr) {
     UZK_HIP(hipHostFree(h_ptr));
     return UZK_OK;
 }
+}  // extern "C"
+namespace uzk {
 // true when [p, p + bytes) lies inside a block of uzk_host_alloc
-static bool is_pinned_block(const void* p, size_t bytes) {
+bool is_pinned_block(const void* p, size_t bytes) {
     Shared& s = shared();
     std::lock_guard<std::mutex> lk(s.mu);
     auto it = s.pinned.upper_bound(p);
@@ -424,6 +427,8 @@ static bool is_pinned_block(const void* p, size_t bytes) {
     const char* q = static_cast<const char*>(p);
     return q >= base && q + bytes <= base + it->second;
 }
+}  // namespace uzk
+extern "C" {
 static int dev_copy_common(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows, int kind, const char* who) {
     if (kind != UZK_COPY_H2D && kind != UZK_COPY_D2H && kind != UZK_COPY_D2D) { set_error("%s: kind must be UZK_COPY_H2D / D2H / D2D", who); return UZK_ERR_PARAMETER; }
     if (width == 0 || rows == 0) return UZK_OK;
@@ -467,7 +472,9 @@ int uzk_dev_memset2d(void* d_dst, size_t pitch, int byte, size_t width, size_t r
 }
 
 /* ---- SRS (process-wide registry: the bases are read-only and shared by every context) ------------ */
-static uint64_t srs_insert(const Ctx::Srs& e) {
+}  // extern "C"
+namespace uzk {
+uint64_t srs_insert(const Ctx::Srs& e) {
     Shared& s = shared();
     std::lock_guard<std::mutex> lk(s.mu);
     const uint64_t h = s.next_handle++;
@@ -475,7 +482,7 @@ static uint64_t srs_insert(const Ctx::Srs& e) {
     return h;
 }
 // copy of the registry entry (the pointers stay valid until uzk_srs_release / uzk_srs_precompute on that handle)
-static bool srs_lookup(uint64_t handle, Ctx::Srs* out) {
+bool srs_lookup(uint64_t handle, Ctx::Srs* out) {
     Shared& s = shared();
     std::lock_guard<std::mutex> lk(s.mu);
     auto it = s.srs.find(handle);
@@ -483,6 +490,23 @@ static bool srs_lookup(uint64_t handle, Ctx::Srs* out) {
     *out = it->second;
     return true;
 }
+// removes the entry and hands it to the caller, who frees what it owns
+bool srs_erase(uint64_t handle, Ctx::Srs* out) {
+    Shared& s = shared();
+    std::lock_guard<std::mutex> lk(s.mu);
+    auto it = s.srs.find(handle);
+    if (it == s.srs.end()) return false;
+    *out = it->second;
+    s.srs.erase(it);
+    return true;
+}
+int bound_device() {
+    Shared& s = shared();
+    std::lock_guard<std::mutex> lk(s.mu);
+    return s.bound ? s.device : -1;
+}
+}  // namespace uzk
+extern "C" {
 
 int uzk_srs_register(const uzk_g1_affine* points, size_t n, uint64_t* handle_out) {
     API_LOCK;
@@ -581,13 +605,17 @@ static int msm_checked(uint64_t srs_handle, size_t offset, size_t n, Ctx::Srs* s
     }
     return UZK_OK;
 }
+}  // extern "C"
+namespace uzk {
 // general mode unless the handle carries a window table
-static int msm_dispatch_view(const Ctx::Srs& s, size_t offset, const ScalarView& sv, size_t n, uint32_t batch, Jac* out) {
+int msm_dispatch_view(const Ctx::Srs& s, size_t offset, const ScalarView& sv, size_t n, uint32_t batch, Jac* out) {
     Ctx& c = ctx();
     if (s.d_table && !c.tune_no_precompute)
         return msm_run(c, s.d_table, sv, n, batch, out, s.pre_c, (uint32_t)s.n, (uint32_t)offset);
     return msm_run(c, s.d_points + offset, sv, n, batch, out, 0, 0, 0);
 }
+}  // namespace uzk
+extern "C" {
 static int msm_dispatch_one(const Ctx::Srs& s, size_t offset, const Fp* d_scalars, size_t n, uint32_t batch, Jac* out) {
     Ctx& c = ctx();
     // one vector of more than 2^24 points over plain bases: chunks of 2^24 into one bucket set (msm_run_chunked)
@@ -1119,7 +1147,8 @@ int uzk_tune(const char* key, int value) {
     else if (!std::strcmp(key, "msm_scan_nb_log")) c.tune_scan_nb_log = value;
     else if (!std::strcmp(key, "msm_class_reduce")) c.tune_class_reduce = value;
     else if (!std::strcmp(key, "msm_chunk_sort")) c.tune_chunk_sort = value;
-    else if (!std::strcmp(key, "msm_stream_log")) c.tune_stream_log = value;
+    else if (!std::strcmp(key, "msm_stream_log")) c.tune_stream_log = (value >= -1 && value <= 26) ? value : 0;
+    else if (!std::strcmp(key, "prover_t_cap")) c.tune_prover_t_cap = value;
     else if (!std::strcmp(key, "msm_stream_min_log")) c.tune_stream_min_log = (value >= 4 && value <= 26) ? value : 22;
     else if (!std::strcmp(key, "msm_chunk_log")) c.tune_chunk_log = (value >= 8 && value <= 26) ? value : 26;
     else { set_error("uzk_tune: unknown key %s", key); return UZK_ERR_PARAMETER; }

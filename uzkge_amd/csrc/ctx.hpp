@@ -108,6 +108,7 @@ struct Ctx {
     int tune_bucket_fill = 1; // 1: the task schedule is written by one lane per bucket (msm_bucket_fill_kernel), 0: one search per task
     int tune_direct = 1;      // 1: a bucket that is one task is written by the accumulator itself (msm.hip task_dst)
     int tune_scatter4 = 0;    // experiment: large packed sorts scatter 8192-entry tiles of 4-byte words (msm_radix_scatter4_kernel): measured slower
+    int tune_prover_t_cap = 0; // tests / timing chains on synthetic (unsatisfied) circuits: round 3 takes t as its first 5n - 2 + sum(hiding) coefficients and ignores what lies beyond
     int tune_overlap = 0;     // 1: run large MSMs as two overlapping pipeline instances (experiment)  // 1: force one lane per bucket in the fold kernels
     // poly.hip workspaces (grow-only)
     DevBuf poly_tmp, poly_tmp2, poly_io, zpoly_tmp, open_tmp;
@@ -149,15 +150,29 @@ struct ScalarView {
     uint32_t n_main = 0;
     const Fp* tail = nullptr;
     uint32_t tail_n = 0;
+    // Vectors in groups: vector b lives at main[(b / group) * group_stride + (b % group) * stride].  The prover's batched round 1
+    // commits 8 of the 10 evaluation vectors of every proof of a lockstep batch (prover.cpp); one group = everything else.
+    uint32_t group = 0xffffffffu;
+    uint64_t group_stride = 0;
     static ScalarView dense(const Fp* p, size_t n) { ScalarView v; v.main = p; v.stride = n; v.n_main = (uint32_t)n; return v; }
     __host__ __device__ const Fp& at(uint32_t b, uint32_t i) const {
-        return i < n_main ? main[(uint64_t)b * stride + i] : tail[(uint64_t)b * tail_n + (i - n_main)];
+        return i < n_main ? main[(uint64_t)(b / group) * group_stride + (uint64_t)(b % group) * stride + i]
+                          : tail[(uint64_t)b * tail_n + (i - n_main)];
     }
 };
 
 Ctx& ctx();
 std::mutex& ctx_mutex();
 int require_ready();
+// api.cpp: the process-wide SRS registry and the pinned-block table, for prover.cpp
+uint64_t srs_insert(const Ctx::Srs& e);
+bool srs_lookup(uint64_t handle, Ctx::Srs* out);
+bool srs_erase(uint64_t handle, Ctx::Srs* out);
+bool is_pinned_block(const void* p, size_t bytes);
+int msm_dispatch_view(const Ctx::Srs& s, size_t offset, const ScalarView& sv, size_t n, uint32_t batch, Jac* out);
+int bound_device();            // the device the process is bound to, -1 when unbound
+// prover.cpp: frees every circuit and prover (uzk_shutdown)
+void prover_release_all();
 
 // RAII kernel-launch bracket:  { KernelScope ks(c, "name"); kernel<<<...>>>(...); }
 // host-side section timer feeding the same profile table (entries named host_*)
@@ -215,6 +230,7 @@ int fold_blinds_run(Ctx& c, const Fp* d_coefs, uint64_t len, uint64_t N, Fp* d_o
 int poly_lincomb_run(Ctx& c, const void* const* d_polys, const uint64_t* lens, const Fp* scalars_host, uint32_t count, Fp* d_out,
                      uint64_t out_len);
 int poly_hide_run(Ctx& c, Fp* d_coefs, uint64_t len, const Fp* blinds_host, uint32_t hiding_degree, uint64_t zeroing_degree);
+int poly_scatter_run(Ctx& c, Fp* d_dst, uint64_t dst_stride, const uint32_t* idx_pinned, const Fp* val_pinned, uint32_t count, uint32_t batch);
 struct QuotientDev;
 int t_quotient_run(Ctx& c, const void* args_c_abi, Fp* d_out);
 int z_poly_device(Ctx& c, const Fp* d_w, const uint32_t* d_perm, const Fp* d_group, const Fp* k_host, const Fp& beta,

@@ -219,6 +219,7 @@ __global__ __launch_bounds__(256) void poly_eval_small_kernel(EvalArgs a, Fp* __
     const uint32_t tid = threadIdx.x, blk = blockIdx.x, stride = gridDim.x, b = blockIdx.y;
     const uint64_t n = a.len[b];
     const uint32_t nblocks = (uint32_t)((n + kEvalSmallBlock - 1) / kEvalSmallBlock);
+    if (n == 0 && blk == 0 && tid == 0) out_host[b] = Fr::zero();    // the zero polynomial (a real circuit's unused selectors trim to it)
     if (blk >= nblocks) return;                       // shorter polynomials of a mixed launch need fewer workgroups
     const Fp* c = a.p[b];
     const Fp x = a.x[a.pt[b]];
@@ -344,12 +345,8 @@ int poly_eval_ptrs(Ctx& c, const void* const* d_polys, const uint64_t* lens, con
     if (count <= kEvalMaxPolys && n_points <= kEvalMaxPoints && max_blocks <= (uint64_t)kEvalSmallMaxBlocks && max_len > 0 && c.tune_poly_small) {
         EvalArgs a{};
         for (uint32_t j = 0; j < n_points; ++j) a.x[j] = points_host[j];
-        bool any_empty = false;
-        for (uint32_t k = 0; k < count; ++k) {
-            a.p[k] = static_cast<const Fp*>(d_polys[k]); a.len[k] = (uint32_t)lens[k]; a.pt[k] = (uint8_t)point_idx[k];
-            any_empty = any_empty || lens[k] == 0;
-        }
-        if (!any_empty) return poly_eval_small_launch(c, a, count, (uint32_t)max_blocks, out_host);
+        for (uint32_t k = 0; k < count; ++k) { a.p[k] = static_cast<const Fp*>(d_polys[k]); a.len[k] = (uint32_t)lens[k]; a.pt[k] = (uint8_t)point_idx[k]; }
+        return poly_eval_small_launch(c, a, count, (uint32_t)max_blocks, out_host);
     }
     for (uint32_t k = 0; k < count; ++k)
         UZK_TRY(poly_eval_batch(c, static_cast<const Fp*>(d_polys[k]), lens[k], 1, points_host[point_idx[k]], out_host + k));
@@ -1004,6 +1001,23 @@ int poly_hide_run(Ctx& c, Fp* d_coefs, uint64_t len, const Fp* blinds_host, uint
     HideArgs h;                                    // the blinds travel as kernel arguments: no staging copy, no synchronisation
     for (uint32_t i = 0; i < 16; ++i) h.blinds[i] = i < hiding_degree ? blinds_host[i] : Fr::zero();
     hipLaunchKernelGGL(poly_hide_kernel, dim3(1), dim3(64), 0, c.stream, d_coefs, zeroing_degree, h, hiding_degree);
+    UZK_HIP(hipGetLastError());
+    return UZK_OK;
+}
+
+// The evaluations of the PI polynomial (pi_poly, helpers.rs:111-131): dst_b[idx[j]] = val[b][j] for `batch` vectors dst_stride
+// apart that the caller has zeroed.  idx / val sit in pinned host memory the kernel reads directly (a few hundred entries).
+// The caller lists a repeated index once (the reference's find_position takes the first occurrence), so writes never collide.
+__global__ __launch_bounds__(256) void poly_scatter_kernel(Fp* __restrict__ dst, uint64_t dst_stride, const uint32_t* __restrict__ idx,
+                                                           const Fp* __restrict__ val, uint32_t count) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    dst[(uint64_t)blockIdx.y * dst_stride + idx[j]] = val[(uint64_t)blockIdx.y * count + j];
+}
+int poly_scatter_run(Ctx& c, Fp* d_dst, uint64_t dst_stride, const uint32_t* idx_pinned, const Fp* val_pinned, uint32_t count, uint32_t batch) {
+    if (count == 0 || batch == 0) return UZK_OK;
+    KernelScope ks(c, "poly_scatter");
+    hipLaunchKernelGGL(poly_scatter_kernel, dim3((count + 255) / 256, batch), dim3(256), 0, c.stream, d_dst, dst_stride, idx_pinned, val_pinned, count);
     UZK_HIP(hipGetLastError());
     return UZK_OK;
 }
