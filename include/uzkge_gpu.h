@@ -371,6 +371,12 @@ int uzk_circuit_update_tables(uint64_t circuit, uint32_t first_slot, uint32_t co
  * count commitments (lagrange_pcs.commit(evals), no blinds). */
 int uzk_circuit_refresh_tables(uint64_t circuit, uint32_t first_slot, uint32_t count, const uint64_t* evals, uint64_t* polys_out,
                                uint64_t* lens_out, uint64_t* coset_out, uzk_g1_jac* commitments_out);
+/* The same loop without a circuit -- what indexer_with_lagrange (indexer.rs:316-470) runs once per deck size for its 34 (9)
+ * selector / permutation vectors: `count` evaluation vectors (host, n each) -> batched iFFT(n) -> polys_out (count x n, zero padded;
+ * lens_out = coefs.len()), [coset_out: batched coset FFT over the 6n domain with shift k1: count x 6n], [commitments_out: one batched
+ * MSM of the evaluations over the first n bases of `lagrange_srs` (uzk_srs_register)].  Every output is optional. */
+int uzk_preprocess_tables(uint64_t lagrange_srs, uint32_t n, uint32_t count, const uint64_t* evals, const uint64_t* k1_mont, uint64_t* polys_out,
+                          uint64_t* lens_out, uint64_t* coset_out, uzk_g1_jac* commitments_out);
 /* Device address and coefficient count of a slot's polynomial (which = 0; n elements allocated) or coset table (which = 1; 6n
  * elements) as of now -- tests and diagnostics. */
 int uzk_circuit_table(uint64_t circuit, uint32_t slot, int which, const void** d_out, uint64_t* len_out);

@@ -104,89 +104,13 @@ pub fn domain_group_gen(n: u64) -> Result<[u64; 4], Error> {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Device residency: what the device-resident prover flow (uzkge/src/plonk/gpu_prover.rs) builds on.  Nothing here links the
-// HIP runtime: buffers come from uzk_dev_alloc, copies from uzk_dev_copy*.
+// The device-resident prover (uzkge/src/plonk/gpu_prover.rs): circuits, provers and the five rounds.  Nothing here links the
+// HIP runtime, and nothing here decides anything: lengths, folds, table snapshots and error conditions live in the library.
 // ---------------------------------------------------------------------------------------------------------------------
 use std::os::raw::c_void;
 
 /// One field element on the wire: 4 little-endian u64 limbs, Montgomery form.
 pub type Limbs = [u64; 4];
-const FR_BYTES: usize = 32;
-
-/// `count` field elements of device memory (uzk_dev_alloc); freed on drop.
-pub struct DevBuf {
-    ptr: *mut c_void,
-    count: usize,
-}
-// the pointer names device memory; the library serialises access per context
-unsafe impl Send for DevBuf {}
-unsafe impl Sync for DevBuf {}
-
-impl DevBuf {
-    pub fn new(count: usize) -> Result<Self, Error> {
-        let mut ptr: *mut c_void = std::ptr::null_mut();
-        check(unsafe { uzk_dev_alloc(count * FR_BYTES, &mut ptr) })?;
-        Ok(DevBuf { ptr, count })
-    }
-    pub fn zeroed(count: usize) -> Result<Self, Error> {
-        let b = Self::new(count)?;
-        check(unsafe { uzk_dev_memset(b.ptr, 0, count * FR_BYTES) })?;
-        Ok(b)
-    }
-    pub fn from_host(data: &[Limbs]) -> Result<Self, Error> {
-        let b = Self::new(data.len())?;
-        b.upload(0, data)?;
-        Ok(b)
-    }
-    pub fn len(&self) -> usize { self.count }
-    pub fn is_empty(&self) -> bool { self.count == 0 }
-    /// Device address of element `elem`.
-    pub fn at(&self, elem: usize) -> *mut c_void {
-        assert!(elem <= self.count);
-        unsafe { (self.ptr as *mut u8).add(elem * FR_BYTES) as *mut c_void }
-    }
-    pub fn as_ptr(&self) -> *mut c_void { self.ptr }
-    /// Host -> device at element offset `elem`; `data` may be reused when this returns.
-    pub fn upload(&self, elem: usize, data: &[Limbs]) -> Result<(), Error> {
-        assert!(elem + data.len() <= self.count);
-        check(unsafe { uzk_dev_copy(self.at(elem), data.as_ptr() as *const c_void, data.len() * FR_BYTES, UZK_COPY_H2D) })
-    }
-    /// Device -> host; synchronises the calling context's stream.
-    pub fn download(&self, elem: usize, count: usize) -> Result<Vec<Limbs>, Error> {
-        assert!(elem + count <= self.count);
-        let mut out = vec![[0u64; 4]; count];
-        check(unsafe { uzk_dev_copy(out.as_mut_ptr() as *mut c_void, self.at(elem), count * FR_BYTES, UZK_COPY_D2H) })?;
-        Ok(out)
-    }
-}
-
-impl Drop for DevBuf {
-    fn drop(&mut self) {
-        unsafe { uzk_dev_free(self.ptr) };
-    }
-}
-
-/// Raw device bytes (the permutation: u32 indices).
-pub struct DevBytes {
-    ptr: *mut c_void,
-}
-unsafe impl Send for DevBytes {}
-unsafe impl Sync for DevBytes {}
-impl DevBytes {
-    pub fn from_u32(data: &[u32]) -> Result<Self, Error> {
-        let mut ptr: *mut c_void = std::ptr::null_mut();
-        check(unsafe { uzk_dev_alloc(data.len() * 4, &mut ptr) })?;
-        let b = DevBytes { ptr };
-        check(unsafe { uzk_dev_copy(b.ptr, data.as_ptr() as *const c_void, data.len() * 4, UZK_COPY_H2D) })?;
-        Ok(b)
-    }
-    pub fn as_ptr(&self) -> *mut c_void { self.ptr }
-}
-impl Drop for DevBytes {
-    fn drop(&mut self) {
-        unsafe { uzk_dev_free(self.ptr) };
-    }
-}
 
 /// A context (one stream, one set of workspaces, one lock) for a prover thread; see `uzk_ctx_create`.
 pub struct Context(u64);
@@ -210,121 +134,121 @@ impl Drop for Context {
     }
 }
 
-fn opt_ptr(s: Option<&Limbs>) -> *const u64 {
-    s.map_or(std::ptr::null(), |v| v.as_ptr())
+/// A circuit resident in HBM (`uzk_circuit_create`): commit bases, permutation, the 46 (21) polynomials and their coset tables.
+/// Process-wide: provers of every thread may use it at the same time.  Released on drop.
+pub struct Circuit {
+    handle: u64,
 }
-
-/// `batch` transforms of n elements, consecutive vectors in_stride / out_stride elements apart (uzk_ntt_fr_batch_strided_device).
-pub fn ntt_strided(d_in: *const c_void, in_stride: usize, d_out: *mut c_void, out_stride: usize, n: usize, batch: u32, inverse: bool,
-                   coset_shift: Option<&Limbs>) -> Result<(), Error> {
-    check(unsafe { uzk_ntt_fr_batch_strided_device(d_in, in_stride as u64, d_out, out_stride as u64, n as u64, batch, inverse as c_int, opt_ptr(coset_shift), 0) })
-}
-
-impl Srs {
-    /// commit(evals) + apply_blind_factors in one batched MSM (uzk_msm_g1_batch_tail_device): host tail.
-    pub fn commit_with_tail(&self, d_scalars: *const c_void, stride: usize, n: usize, batch: u32, tail: &[Limbs], tail_n: u32) -> Result<Vec<uzk_g1_jac>, Error> {
-        assert_eq!(tail.len(), batch as usize * tail_n as usize);
-        let mut out = vec![uzk_g1_jac::default(); batch as usize];
-        check(unsafe { uzk_msm_g1_batch_tail_device(self.handle, 0, d_scalars, stride, n, batch, tail.as_ptr() as *const c_void, tail_n, 0, out.as_mut_ptr()) })?;
-        Ok(out)
+impl Circuit {
+    /// `desc` and everything it points to are read before this returns.
+    pub fn create(desc: &uzk_circuit_desc) -> Result<Self, Error> {
+        let mut handle = 0u64;
+        check(unsafe { uzk_circuit_create(desc, &mut handle) })?;
+        Ok(Circuit { handle })
     }
-    /// The same with the tail left on the device by `fold_blinds_batch`.
-    pub fn commit_with_device_tail(&self, d_scalars: *const c_void, stride: usize, n: usize, batch: u32, d_tail: *const c_void, tail_n: u32) -> Result<Vec<uzk_g1_jac>, Error> {
-        let mut out = vec![uzk_g1_jac::default(); batch as usize];
-        check(unsafe { uzk_msm_g1_batch_tail_device(self.handle, 0, d_scalars, stride, n, batch, d_tail, tail_n, 1, out.as_mut_ptr()) })?;
-        Ok(out)
+    /// Replaces the polynomials of slots first_slot.. (coefficient forms, trimmed as `FpPolynomial::from_coefs` leaves them) and
+    /// re-derives their coset tables; copy on write: a proof in flight keeps the tables it started with.
+    pub fn update_tables(&self, first_slot: u32, polys: &[Vec<Limbs>]) -> Result<(), Error> {
+        let ptrs: Vec<*const u64> = polys.iter().map(|p| p.as_ptr() as *const u64).collect();
+        let lens: Vec<u64> = polys.iter().map(|p| p.len() as u64).collect();
+        check(unsafe { uzk_circuit_update_tables(self.handle, first_slot, polys.len() as u32, ptrs.as_ptr(), lens.as_ptr()) })
     }
-}
-
-/// hide_polynomial for `count` polynomials `stride` apart (uzk_hide_polynomial_batch_device); blinds: count * hiding_degree.
-pub fn hide_batch(d_coefs: *mut c_void, stride: usize, len_in: usize, count: u32, blinds: &[Limbs], hiding_degree: u32, zeroing_degree: usize) -> Result<(), Error> {
-    assert_eq!(blinds.len(), (count * hiding_degree) as usize);
-    check(unsafe { uzk_hide_polynomial_batch_device(d_coefs, stride as u64, len_in as u64, count, blinds.as_ptr() as *const u64, hiding_degree, zeroing_degree as u64) })
-}
-
-/// z_poly on device-resident wires / permutation / domain (uzk_z_poly_device).
-pub fn z_poly(d_w: *const c_void, d_perm: *const c_void, d_group: *const c_void, k: &[Limbs], beta: &Limbs, gamma: &Limbs, n: usize, d_z: *mut c_void) -> Result<(), Error> {
-    check(unsafe { uzk_z_poly_device(d_w, d_perm as *const u32, d_group, k.as_ptr() as *const u64, beta.as_ptr(), gamma.as_ptr(), n as u32, k.len() as u32, d_z) })
-}
-
-/// A few u64 words of pinned host memory (uzk_host_alloc) that the device stream writes in order: results a prover reads
-/// after its next synchronising call instead of waiting for them.
-pub struct PinnedWords {
-    ptr: *mut u64,
-    count: usize,
-}
-unsafe impl Send for PinnedWords {}
-impl PinnedWords {
-    pub fn new(count: usize) -> Result<Self, Error> {
-        let mut p: *mut c_void = std::ptr::null_mut();
-        check(unsafe { uzk_host_alloc(count * 8, &mut p) })?;
-        Ok(PinnedWords { ptr: p as *mut u64, count })
+    /// The refresh / indexer loop as one device call (`uzk_circuit_refresh_tables`): `evals.len() / n` evaluation vectors of n
+    /// elements -> (coefficient forms: n each, zero padded; their trimmed lengths; coset evaluations: 6n each, empty unless
+    /// `want_coset`; the Lagrange commitments of the evaluations), installed in the slots.
+    #[allow(clippy::type_complexity)]
+    pub fn refresh_tables(&self, first_slot: u32, evals: &[Limbs], n: usize, want_coset: bool) -> Result<(Vec<Limbs>, Vec<u64>, Vec<Limbs>, Vec<uzk_g1_jac>), Error> {
+        if n == 0 || evals.len() % n != 0 {
+            return Err(Error::Parameter);
+        }
+        let count = evals.len() / n;
+        let mut polys = vec![[0u64; 4]; evals.len()];
+        let mut lens = vec![0u64; count];
+        let mut coset = vec![[0u64; 4]; if want_coset { 6 * evals.len() } else { 0 }];
+        let mut cms = vec![uzk_g1_jac::default(); count];
+        let coset_ptr = if want_coset { coset.as_mut_ptr() as *mut u64 } else { std::ptr::null_mut() };
+        check(unsafe {
+            uzk_circuit_refresh_tables(self.handle, first_slot, count as u32, evals.as_ptr() as *const u64, polys.as_mut_ptr() as *mut u64, lens.as_mut_ptr(), coset_ptr,
+                                       cms.as_mut_ptr())
+        })?;
+        Ok((polys, lens, coset, cms))
     }
-    /// Word `i`; meaningful once the stream has passed the call that writes it (after a synchronising call).
-    pub fn get(&self, i: usize) -> u64 {
-        assert!(i < self.count);
-        unsafe { std::ptr::read_volatile(self.ptr.add(i)) }
-    }
-    pub fn at(&self, i: usize) -> *mut u64 {
-        assert!(i <= self.count);
-        unsafe { self.ptr.add(i) }
-    }
+    pub fn handle(&self) -> u64 { self.handle }
 }
-impl Drop for PinnedWords {
+impl Drop for Circuit {
     fn drop(&mut self) {
-        unsafe { uzk_host_free(self.ptr as *mut c_void) };
+        unsafe { uzk_circuit_release(self.handle) };
     }
 }
 
-/// Trimmed lengths (FpPolynomial::from_coefs) of `lens.len()` device polynomials `stride` apart (uzk_poly_trimmed_len_device),
-/// measured asynchronously into `out` (pinned): read them after the next synchronising call.
-pub fn trimmed_len_async(d_polys: *const c_void, stride: usize, lens: &[u64], out: *mut u64) -> Result<(), Error> {
-    check(unsafe { uzk_poly_trimmed_len_device(d_polys, stride as u64, lens.as_ptr(), lens.len() as u32, out, 0) })
+/// The device buffers of `batch` proofs in lockstep over circuits of size n (`uzk_prover_create`) and the five rounds.  Per-proof
+/// arrays are [batch][..]; lengths are checked by the library (a short slice is a `Parameter` error here, never a read past it).
+pub struct Prover {
+    handle: u64,
+    n: usize,
+    batch: usize,
 }
-
-/// The split of t (uzk_split_t_device); returns the chunks' coefs.len().
-pub fn split_t(d_t: *const c_void, t_len: usize, chunk: usize, rands: &[Limbs], d_chunks: *mut c_void, chunk_stride: usize) -> Result<Vec<u64>, Error> {
-    let mut lens = vec![0u64; rands.len()];
-    check(unsafe { uzk_split_t_device(d_t, t_len as u64, chunk as u64, rands.len() as u32, rands.as_ptr() as *const u64, d_chunks, chunk_stride as u64, lens.as_mut_ptr()) })?;
-    Ok(lens)
+impl Prover {
+    pub fn new(n: u32, batch: u32) -> Result<Self, Error> {
+        let mut handle = 0u64;
+        check(unsafe { uzk_prover_create(n, batch, &mut handle) })?;
+        Ok(Prover { handle, n: n as usize, batch: batch as usize })
+    }
+    /// prover.rs:151-192.  witness: batch x 5n; wsel: batch x 3n or empty; hiding: 5 (+3); blinds: batch x (5 | 8) x 3.
+    #[allow(clippy::too_many_arguments)]
+    pub fn round1(&self, circuit: &Circuit, witness: &[Limbs], wsel: &[Limbs], pi_index: &[u32], pi_value: &[Limbs], hiding: &[u32], blinds: &[Limbs]) -> Result<Vec<uzk_g1_jac>, Error> {
+        let n_first = if wsel.is_empty() { 5 } else { 8 };
+        if witness.len() != self.batch * 5 * self.n || (!wsel.is_empty() && wsel.len() != self.batch * 3 * self.n) || hiding.len() != n_first
+            || blinds.len() != self.batch * n_first * 3 || pi_value.len() != self.batch * pi_index.len() {
+            return Err(Error::Parameter);
+        }
+        let mut out = vec![uzk_g1_jac::default(); self.batch * n_first];
+        let wsel_ptr = if wsel.is_empty() { std::ptr::null() } else { wsel.as_ptr() as *const c_void };
+        check(unsafe {
+            uzk_prove_round1(self.handle, circuit.handle, witness.as_ptr() as *const c_void, wsel_ptr, 0, pi_index.as_ptr(), pi_value.as_ptr() as *const u64,
+                             pi_index.len() as u32, hiding.as_ptr(), blinds.as_ptr() as *const u64, out.as_mut_ptr())
+        })?;
+        Ok(out)
+    }
+    /// prover.rs:194-209 for one proof (batch 1).
+    pub fn round2(&self, beta: &Limbs, gamma: &Limbs, blinds_z: &[Limbs]) -> Result<uzk_g1_jac, Error> {
+        if self.batch != 1 || blinds_z.len() != 3 {
+            return Err(Error::Parameter);
+        }
+        let mut out = uzk_g1_jac::default();
+        check(unsafe { uzk_prove_round2(self.handle, beta.as_ptr(), gamma.as_ptr(), blinds_z.as_ptr() as *const u64, &mut out) })?;
+        Ok(out)
+    }
+    /// prover.rs:211-239 for one proof: the five commitments of t's chunks.
+    pub fn round3(&self, alpha: &Limbs, t_rands: &[Limbs]) -> Result<Vec<uzk_g1_jac>, Error> {
+        if self.batch != 1 || t_rands.len() != 5 {
+            return Err(Error::Parameter);
+        }
+        let mut out = vec![uzk_g1_jac::default(); 5];
+        check(unsafe { uzk_prove_round3(self.handle, alpha.as_ptr(), t_rands.as_ptr() as *const u64, out.as_mut_ptr()) })?;
+        Ok(out)
+    }
+    /// prover.rs:241-273 for one proof: 19 evaluations (the first 15 are meaningful for a circuit without the shuffle feature).
+    pub fn round4(&self, zeta: &Limbs) -> Result<Vec<Limbs>, Error> {
+        if self.batch != 1 {
+            return Err(Error::Parameter);
+        }
+        let mut out = vec![[0u64; 4]; 19];
+        check(unsafe { uzk_prove_round4(self.handle, zeta.as_ptr(), out.as_mut_ptr() as *mut u64) })?;
+        Ok(out)
+    }
+    /// prover.rs:296-372 for one proof: r_scalars (19 | 43, the order of uzk_prove_round5), the two opening commitments.
+    pub fn round5(&self, r_scalars: &[Limbs], alpha_zeta: &Limbs, alpha_zeta_omega: &Limbs) -> Result<Vec<uzk_g1_jac>, Error> {
+        if self.batch != 1 || (r_scalars.len() != 19 && r_scalars.len() != 43) {
+            return Err(Error::Parameter);
+        }
+        let mut out = vec![uzk_g1_jac::default(); 2];
+        check(unsafe { uzk_prove_round5(self.handle, r_scalars.as_ptr() as *const u64, alpha_zeta.as_ptr(), alpha_zeta_omega.as_ptr(), out.as_mut_ptr()) })?;
+        Ok(out)
+    }
 }
-
-/// Fold modulo X^N - 1 for a batch, blinds left on the device as the next commit's tail (uzk_fold_blinds_batch_device).
-pub fn fold_blinds_batch(d_polys: *const c_void, in_stride: usize, lens: &[u64], n_fold: usize, d_out: *mut c_void, out_stride: usize, d_tail: *mut c_void, tail_n: u32) -> Result<(), Error> {
-    check(unsafe { uzk_fold_blinds_batch_device(d_polys, in_stride as u64, lens.as_ptr(), n_fold as u64, lens.len() as u32, d_out, out_stride as u64, d_tail, tail_n, std::ptr::null_mut()) })
-}
-
-/// out[k] = p_k(points[point_idx[k]]) (uzk_poly_eval_ptrs_device).
-pub fn eval_ptrs(polys: &[(*const c_void, u64)], point_idx: &[u32], points: &[Limbs]) -> Result<Vec<Limbs>, Error> {
-    assert_eq!(polys.len(), point_idx.len());
-    let ptrs: Vec<*const c_void> = polys.iter().map(|p| p.0).collect();
-    let lens: Vec<u64> = polys.iter().map(|p| p.1).collect();
-    let mut out = vec![[0u64; 4]; polys.len()];
-    check(unsafe { uzk_poly_eval_ptrs_device(ptrs.as_ptr(), lens.as_ptr(), point_idx.as_ptr(), polys.len() as u32, points.as_ptr() as *const u64, points.len() as u32, out.as_mut_ptr() as *mut u64) })?;
-    Ok(out)
-}
-
-/// d_out[j] = sum_k scalars[k] * p_k[j] (uzk_poly_lincomb_device).
-pub fn lincomb(polys: &[(*const c_void, u64)], scalars: &[Limbs], d_out: *mut c_void, out_len: usize) -> Result<(), Error> {
-    assert_eq!(polys.len(), scalars.len());
-    let ptrs: Vec<*const c_void> = polys.iter().map(|p| p.0).collect();
-    let lens: Vec<u64> = polys.iter().map(|p| p.1).collect();
-    check(unsafe { uzk_poly_lincomb_device(ptrs.as_ptr(), lens.as_ptr(), scalars.as_ptr() as *const u64, polys.len() as u32, d_out, out_len as u64) })
-}
-
-/// q = (sum_k alpha^k p_k) div (X - z) -> d_q (uzk_open_quotient_ptrs_device, no evaluations: asynchronous).
-pub fn open_quotient(polys: &[(*const c_void, u64)], z: &Limbs, alpha: &Limbs, d_q: *mut c_void, q_cap: usize) -> Result<(), Error> {
-    let ptrs: Vec<*const c_void> = polys.iter().map(|p| p.0).collect();
-    let lens: Vec<u64> = polys.iter().map(|p| p.1).collect();
-    check(unsafe { uzk_open_quotient_ptrs_device(ptrs.as_ptr(), lens.as_ptr(), polys.len() as u32, z.as_ptr(), alpha.as_ptr(), d_q, q_cap as u64, std::ptr::null_mut()) })
-}
-
-/// The quotient evaluations of t_poly (uzk_t_quotient_device), asynchronous.
-pub fn t_quotient(args: &uzk_quotient_args, d_out: *mut c_void) -> Result<(), Error> {
-    check(unsafe { uzk_t_quotient_device(args, d_out, 0) })
-}
-
-/// Device-to-device pitched copy (uzk_dev_copy2d).
-pub fn copy2d_d2d(dst: *mut c_void, dst_pitch: usize, src: *const c_void, src_pitch: usize, width: usize, rows: usize) -> Result<(), Error> {
-    check(unsafe { uzk_dev_copy2d(dst, dst_pitch, src, src_pitch, width, rows, UZK_COPY_D2D) })
+impl Drop for Prover {
+    fn drop(&mut self) {
+        unsafe { uzk_prover_destroy(self.handle) };
+    }
 }

@@ -79,7 +79,7 @@ def test_glue_and_wrappers_only_call_bound_functions():
     consts = set(re.findall(r"pub const (UZK_[A-Z0-9_]+)", ffi))
     lib = _strip_rust_comments(open(os.path.join(RUST, "uzkge-gpu-sys", "src", "lib.rs")).read())
     used = _calls(lib, r"uzk_[a-z0-9_]+")
-    assert len(used) >= 25
+    assert len(used) >= 20
     for name, n_args in used:                                   # every FFI call of the wrappers: bound, and with that arity
         assert name in decl, name
         assert decl[name] == n_args, (name, decl[name], n_args)
@@ -113,48 +113,54 @@ def test_glue_and_wrappers_only_call_bound_functions():
     assert "release_srs" in glue
 
 
-def _entry_sequence_cpp():
-    src = open(os.path.join(ROOT, "tests", "cpp", "prover_rounds.cpp")).read()
-    body = src[src.index("auto chain = [&]() {"):src.index("want_blinds = write_outputs;")]
-    return [n for n, _ in _calls(re.sub(r"//.*", "", body), r"uzk_[a-z0-9_]+")]
+def _round_sequence(src, pattern):
+    return [m.group(1) for m in re.finditer(pattern, src)]
 
 
-def _entry_sequence_rust():
+def test_rust_prover_drives_the_library_rounds_like_the_cpp_driver():
+    """One implementation of the five rounds -- the library's.  rust/uzkge-glue/gpu_prover.rs and tests/cpp/prover_rounds.cpp (the
+    driver the GPU tests hold to frozen outputs and to the reference's verifier) both issue uzk_prove_round1..5, in order, once
+    per proof, and nothing else between them that touches the device; the Rust wrappers they go through call exactly those
+    entry points."""
+    cpp = re.sub(r"//.*", "", open(os.path.join(ROOT, "tests", "cpp", "prover_rounds.cpp")).read())
+    body = cpp[cpp.index("auto chain = [&]() {"):cpp.index("want_blinds = write_outputs;")]
+    assert _round_sequence(body, r"\buzk_prove_round(\d)\(") == list("12345")
     lib = open(os.path.join(RUST, "uzkge-gpu-sys", "src", "lib.rs")).read()
-    wrapper_to_entry = {}
-    for m in re.finditer(r"pub fn ([a-z_0-9]+)\(", lib):
-        i = lib.index("{", m.end())
-        depth, j = 1, i + 1
-        while depth:                                             # the function's body, by brace matching
-            depth += {"{": 1, "}": -1}.get(lib[j], 0)
-            j += 1
-        names = re.findall(r"\b(uzk_[a-z0-9_]+)\(", lib[i:j])
-        if names:
-            wrapper_to_entry[m.group(1)] = names[0]
-    src = _strip_rust_comments(open(os.path.join(RUST, "uzkge-glue", "gpu_prover.rs")).read())
-    body = src[src.index("fn prove_on_device"):]
-    seq = []
-    for m in re.finditer(r"\bsys::([a-z_0-9]+)\(|\.(commit_with_tail|commit_with_device_tail|upload)\(", body):
-        w = m.group(1) or m.group(2)
-        if w in ("check",):
-            continue
-        seq.append(wrapper_to_entry.get(w, w))
-    return seq
+    for k in "12345":                                           # wrapper roundK -> uzk_prove_roundK and nothing else
+        m = re.search(rf"pub fn round{k}\(.*?\n    }}\n", lib, flags=re.S)
+        assert m and re.findall(r"\b(uzk_[a-z0-9_]+)\(", m.group(0)) == [f"uzk_prove_round{k}"], k
+    glue = _strip_rust_comments(open(os.path.join(RUST, "uzkge-glue", "gpu_prover.rs")).read())
+    rounds = glue[glue.index("fn rounds<"):]
+    assert _round_sequence(rounds, r"prover\.round(\d)\(") == list("12345")
+    # no device call of the old call-by-call flow is left in the glue: the only sys:: items it names are the three handles' types,
+    # their constructors and the slot constants
+    assert set(re.findall(r"sys::([A-Za-z_0-9]+)", glue)) <= {"Circuit", "Prover", "Error", "uzk_g1_affine", "uzk_g1_jac", "uzk_circuit_desc",
+                                                               "UZK_CIRCUIT_SLOTS", "UZK_CS_Q", "UZK_CS_S", "UZK_CS_L1", "UZK_CS_QB", "UZK_CS_QPRK",
+                                                               "UZK_CS_QPK", "UZK_CS_QG", "UZK_CS_QECC", "domain_group_gen"}
+    assert len(glue.splitlines()) < 400                        # marshalling, not orchestration (was 786 lines of it)
 
 
-def test_rust_prover_issues_the_cpp_drivers_calls_in_order():
-    """rust/uzkge-glue/gpu_prover.rs mirrors tests/cpp/prover_rounds.cpp (the driver the GPU tests hold to frozen outputs)
-    call for call: the same entry points in the same order.  Uploads (the Rust side moves the witness and pi per proof) and
-    the entry-point family of a transform (plain / batched / strided) are not part of the comparison; the Rust side's
-    generic branch for odd polynomial lengths sits in its own function and is not part of the main sequence."""
-    norm = lambda n: "ntt" if n.startswith("uzk_ntt_fr") else n
-    skip = {"uzk_dev_copy", "upload"}
-    cpp = [norm(n) for n in _entry_sequence_cpp() if n not in skip]
-    rust = [norm(n) for n in _entry_sequence_rust() if n not in skip]
-    # the Rust main path holds, after each batched fold/commit, the fallback call to commit_folded_generic (no sys:: call inside
-    # prove_on_device), so the sequences must match exactly
-    assert rust == cpp, "\n".join(f"{a:45s} {b}" for a, b in zip(rust + [""] * 50, cpp + [""] * 50) if a or b)
-    assert len(cpp) >= 23
+def test_circuit_identity_is_the_verifier_key_not_an_address():
+    """VERDICT r3 / ADVICE r3: the resident circuit is found by its verifier-key commitments; the public-key commitments name the
+    tables it currently holds, and a mismatch replaces the twelve tables (under the lock that also covers round 1) before the
+    proof starts -- `refresh_prover_params_public_key` swaps them in place once per game (shuffle/src/gen_params/params.rs:57-129)."""
+    glue = _strip_rust_comments(open(os.path.join(RUST, "uzkge-glue", "gpu_prover.rs")).read())
+    key_fn = glue[glue.index("fn circuit_key"):glue.index("fn public_key_of")]
+    for field in ("cm_q_vec", "cm_s_vec", "cm_qb", "cm_prk_vec", "cm_q_ecc", "cm_shuffle_generator_vec", "cs_size"):
+        assert field in key_fn, field
+    assert "cm_shuffle_public_key_vec" not in key_fn and "cm_shuffle_public_key_vec" in glue[glue.index("fn public_key_of"):glue.index("fn coefs_of")]
+    assert "as *const PlonkProverParams" not in glue and "as usize, n" not in glue          # no address in any key
+    rounds = glue[glue.index("fn rounds<"):]
+    lock, check, update, r1 = (rounds.index(t) for t in ("entry.lock()", "r.public_key != public_key", "update_tables(sys::UZK_CS_QPK", "prover.round1("))
+    assert lock < check < update < r1 and "r.public_key = public_key" in rounds[update:r1]
+    refresh = glue[glue.index("pub fn refresh_public_key"):glue.index("pub fn release_circuits")]
+    assert "refresh_tables(sys::UZK_CS_QPK" in refresh and "r.public_key = bytes_of(&cms)" in refresh
+    # no data-dependent panic where an error or the CPU path is available (ADVICE r3): no assert / expect / indexing-by-panic helpers
+    assert not re.search(r"\bassert(_eq)?!|\.expect\(|panic!", glue)
+    # the unwraps left are the reference's own "safe unwrap"s (prover.rs:197,213,243,301, helpers.rs:1045) and one Option known to be Some
+    allowed = ("insert_beta_gamma(beta, gamma).unwrap()", "insert_alpha(alpha).unwrap()", "insert_zeta(zeta).unwrap()", "insert_u(u).unwrap()",
+               "guard.as_ref().unwrap()", "eval_selector_multipliers(&w_refs).unwrap()")
+    assert glue.count(".unwrap()") == sum(glue.count(a) for a in allowed) == len(allowed)
 
 
 def test_patch_targets_the_cited_call_sites():
@@ -164,11 +170,12 @@ def test_patch_targets_the_cited_call_sites():
     assert patch.count("crate::gpu::fft(") == 4 and "crate::gpu::commit(" in patch and 'gpu = ["uzkge-gpu-sys"]' in patch
     assert "super::gpu_prover::prove(" in patch and "fn as_kzg_bn254" in patch and "fn commitment_from_g1" in patch
     assert "pub(super) fn r_poly_or_comm" in patch and "mod gpu_prover;" in patch
+    assert "uzkge::plonk::gpu_refresh_public_key(" in patch and 'gpu = ["uzkge/gpu"]' in patch          # the refresh loop's device hook
     added = "\n".join(l for l in patch.splitlines() if l.startswith("+") and not l.startswith("+++"))
     assert "panic!" not in added and ".unwrap()" not in added
 
 
-PATCHED = ("Cargo.toml", "uzkge/Cargo.toml", "uzkge/src/lib.rs", "uzkge/src/plonk/mod.rs", "uzkge/src/plonk/helpers.rs", "uzkge/src/plonk/prover.rs",
+PATCHED = ("Cargo.toml", "shuffle/Cargo.toml", "shuffle/src/gen_params/params.rs", "uzkge/Cargo.toml", "uzkge/src/lib.rs", "uzkge/src/plonk/mod.rs", "uzkge/src/plonk/helpers.rs", "uzkge/src/plonk/prover.rs",
            "uzkge/src/poly_commit/pcs.rs", "uzkge/src/poly_commit/kzg_poly_commitment.rs", "uzkge/src/poly_commit/field_polynomial.rs")
 
 
@@ -186,7 +193,7 @@ def test_patch_applies_to_the_reference(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     # the glue names items of the reference: they exist where it looks for them, with the visibility it needs
     helpers = open(tmp_path / "uzkge/src/plonk/helpers.rs").read()
-    for item in ("pub(super) fn r_poly_or_comm", "pub(super) fn pi_poly", "pub(super) fn first_lagrange_poly", "pub(super) struct PlonkChallenges"):
+    for item in ("pub(super) fn r_poly_or_comm", "pub(super) fn first_lagrange_poly", "pub(super) struct PlonkChallenges"):
         assert item in helpers, item
     prover = open(tmp_path / "uzkge/src/plonk/prover.rs").read()
     hook = prover.index("super::gpu_prover::prove(")
@@ -195,7 +202,12 @@ def test_patch_applies_to_the_reference(tmp_path):
     indexer = open("/root/reference/uzkge/src/plonk/indexer.rs").read()
     for field in set(re.findall(r"\bp\.([a-z_][a-z_0-9]*)", glue)) | set(re.findall(r"prover_params\.([a-z_][a-z_0-9]*)", glue)):
         assert re.search(rf"pub {field}:", indexer), f"PlonkProverParams has no field {field}"
-    proof_fields = re.findall(r"^        ([a-z_0-9]+),$", glue[glue.index("Ok(PlonkProof {"):], flags=re.M)
+    for field in set(re.findall(r"\bvp\.([a-z_][a-z_0-9]*)", glue)):
+        assert re.search(rf"pub {field}:", indexer), f"PlonkVerifierParams has no field {field}"
+    params_rs = open(tmp_path / "shuffle/src/gen_params/params.rs").read()
+    hook = params_rs.index("uzkge::plonk::gpu_refresh_public_key(")
+    assert params_rs.index("compute_shuffle_public_key_selectors()") < hook < params_rs.index("let q_shuffle_public_key_polys: Vec<FpPolynomial<Fr>>")
+    proof_fields = re.findall(r"^        ([a-z_0-9]+)[,:]", glue[glue.index("Ok(PlonkProof {"):], flags=re.M)
     for field in proof_fields:
         assert re.search(rf"pub {field}:", indexer), f"PlonkProof has no field {field}"
     assert len(proof_fields) == 14

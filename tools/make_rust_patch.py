@@ -34,7 +34,26 @@ EDITS = {
         ('/// Module for help functions.\npub(crate) mod helpers;\n',
          '/// Module for help functions.\npub(crate) mod helpers;\n\n'
          '/// `prover_with_lagrange` with the proof\'s polynomials resident on the MI355X.\n#[cfg(feature = "gpu")]\nmod gpu_prover;\n'
-         '#[cfg(feature = "gpu")]\npub use gpu_prover::release_circuits;\n'),
+         '#[cfg(feature = "gpu")]\npub use gpu_prover::release_circuits;\n'
+         '#[cfg(all(feature = "gpu", feature = "shuffle"))]\npub use gpu_prover::refresh_public_key as gpu_refresh_public_key;\n'),
+    ],
+    "shuffle/Cargo.toml": [
+        ('no_vk = []\n', 'no_vk = []\n# MI355X backend (uzkge/gpu): device-resident prover and the public-key refresh as one device call\ngpu = ["uzkge/gpu"]\n'),
+    ],
+    "shuffle/src/gen_params/params.rs": [
+        ('    let q_shuffle_public_key_evals = params.cs.compute_shuffle_public_key_selectors();\n',
+         '    let q_shuffle_public_key_evals = params.cs.compute_shuffle_public_key_selectors();\n\n'
+         '    // MI355X: the loop below (12 x iFFT, coset FFT over the 6n domain, Lagrange commit) as one device call that also replaces\n'
+         '    // the resident circuit\'s public-key tables; `None` = not applicable or no device: the CPU loop runs as before.\n'
+         '    #[cfg(feature = "gpu")]\n'
+         '    if let Some((polys, coset_evals, cms)) = uzkge::plonk::gpu_refresh_public_key(\n'
+         '        &pcs,\n        lagrange_pcs,\n        &params.prover_params,\n        &domain.group_gen,\n        &domain_m.group_gen,\n'
+         '        &q_shuffle_public_key_evals,\n    ) {\n'
+         '        let res: Vec<_> = cms.iter().map(|c| c.0).collect();\n'
+         '        params.prover_params.q_shuffle_public_key_polys = polys;\n'
+         '        params.prover_params.q_shuffle_public_key_coset_evals = coset_evals;\n'
+         '        params\n            .prover_params\n            .verifier_params\n            .cm_shuffle_public_key_vec = cms;\n'
+         '        return Ok(res);\n    }\n'),
     ],
     "uzkge/src/plonk/helpers.rs": [
         ('fn r_poly_or_comm<F: PrimeField, PCSType: HomomorphicPolyComElem<Scalar = F>>(',

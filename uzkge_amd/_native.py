@@ -77,6 +77,7 @@ PROTOTYPES = {
     "uzk_circuit_create": (_I, [_P, ctypes.POINTER(_U64)]),
     "uzk_circuit_update_tables": (_I, [_U64, ctypes.c_uint32, ctypes.c_uint32, _P, _P]),
     "uzk_circuit_refresh_tables": (_I, [_U64, ctypes.c_uint32, ctypes.c_uint32, _P, _P, _P, _P, _P]),
+    "uzk_preprocess_tables": (_I, [_U64, ctypes.c_uint32, ctypes.c_uint32, _P, _P, _P, _P, _P, _P]),
     "uzk_circuit_table": (_I, [_U64, ctypes.c_uint32, _I, ctypes.POINTER(_P), ctypes.POINTER(_U64)]),
     "uzk_circuit_release": (_I, [_U64]),
     "uzk_prover_create": (_I, [ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_U64)]),

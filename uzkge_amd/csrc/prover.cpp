@@ -131,15 +131,22 @@ static uint64_t max_power_of_2(uint64_t degree) {
     return p;
 }
 
+// coefficient forms [count][n] (zero padded) -> coset evaluations [count][6n]: zero-padded copy and ONE batched coset FFT
+// (indexer.rs:316-470: `coset_fft_with_domain(&domain_m, &k[1])` per table)
+static int derive_cosets(Ctx& c, uint32_t n, const Fp& k1, const Fp* polys, Fp* cosets, uint32_t count) {
+    const uint64_t m = 6ull * n;
+    UZK_HIP(hipMemsetAsync(cosets, 0, (size_t)count * m * sizeof(Fp), c.stream));
+    UZK_HIP(hipMemcpy2DAsync(cosets, (size_t)m * sizeof(Fp), polys, (size_t)n * sizeof(Fp), (size_t)n * sizeof(Fp), count, hipMemcpyDeviceToDevice, c.stream));
+    return ntt_run(c, cosets, cosets, m, false, &k1, count);
+}
+
 // Installs `count` polynomials whose coefficient forms already sit in blk (polys area: [count][n], zero padded) as slots
-// first .. first + count of a new table set: zero-padded copy into the coset area ([count][6n]) and ONE batched coset FFT.
+// first .. first + count of a new table set.
 static int derive_and_install(Ctx& c, Circuit& cir, std::shared_ptr<DevBlock> blk, uint32_t first, uint32_t count, const uint64_t* lens) {
     const uint32_t n = cir.n, m = cir.m;
     Fp* polys = static_cast<Fp*>(blk->p);
     Fp* cosets = polys + (uint64_t)count * n;
-    UZK_HIP(hipMemsetAsync(cosets, 0, (size_t)count * m * sizeof(Fp), c.stream));
-    UZK_HIP(hipMemcpy2DAsync(cosets, (size_t)m * sizeof(Fp), polys, (size_t)n * sizeof(Fp), (size_t)n * sizeof(Fp), count, hipMemcpyDeviceToDevice, c.stream));
-    UZK_TRY(ntt_run(c, cosets, cosets, m, false, &cir.k[1], count));
+    UZK_TRY(derive_cosets(c, n, cir.k[1], polys, cosets, count));
     UZK_HIP(hipStreamSynchronize(c.stream));                       // other contexts' streams read these tables
     auto next = std::make_shared<TableSet>();
     std::lock_guard<std::mutex> lk(cir.mu);
@@ -152,6 +159,22 @@ static int derive_and_install(Ctx& c, Circuit& cir, std::shared_ptr<DevBlock> bl
         s.len = lens[i];
     }
     cir.tables = next;
+    return UZK_OK;
+}
+
+// `count` evaluation vectors (host) -> coefficient forms in d_polys ([count][n]: batched iFFT), their trimmed lengths
+// (FpPolynomial::from_coefs after ifft_with_domain, field_polynomial.rs:594-597) and, optionally, the Lagrange commitments of the
+// evaluations (the commit closure's Lagrange branch, indexer.rs:284-299) over `srs`.
+static int polys_from_evals(Ctx& c, const Ctx::Srs* srs, uint32_t n, uint32_t count, const uint64_t* evals, Fp* d_polys, std::vector<uint64_t>& lens, Jac* cms) {
+    UZK_TRY(c.poly_io.reserve((size_t)count * n * sizeof(Fp)));
+    Fp* d_evals = c.poly_io.as<Fp>();
+    UZK_HIP(hipMemcpyAsync(d_evals, evals, (size_t)count * n * sizeof(Fp), hipMemcpyHostToDevice, c.stream));
+    UZK_TRY(ntt_run(c, d_evals, d_polys, n, true, nullptr, count));
+    lens.assign(count, 0);
+    std::vector<uint64_t> cap(16, n);
+    for (uint32_t i0 = 0; i0 < count; i0 += 16)
+        UZK_TRY(poly_trimmed_len_run(c, d_polys + (uint64_t)i0 * n, n, cap.data(), std::min<uint32_t>(16, count - i0), lens.data() + i0, true));
+    if (cms) UZK_TRY(msm_dispatch_view(*srs, 0, ScalarView::dense(d_evals, n), n, count, cms));
     return UZK_OK;
 }
 
@@ -369,29 +392,47 @@ int uzk_circuit_refresh_tables(uint64_t circuit, uint32_t first_slot, uint32_t c
     std::shared_ptr<DevBlock> blk;
     UZK_TRY(dev_block((size_t)count * ((size_t)n + m) * sizeof(Fp), &blk));
     Fp* d_polys = static_cast<Fp*>(blk->p);
-    // evaluations -> (staging) -> batched iFFT(n) into the block's coefficient area; the Lagrange commit reads the staging copy
-    UZK_TRY(c.poly_io.reserve((size_t)count * n * sizeof(Fp)));
-    Fp* d_evals = c.poly_io.as<Fp>();
-    UZK_HIP(hipMemcpyAsync(d_evals, evals, (size_t)count * n * sizeof(Fp), hipMemcpyHostToDevice, c.stream));
-    UZK_TRY(ntt_run(c, d_evals, d_polys, n, true, nullptr, count));
-    // coefs.len() after FpPolynomial::from_coefs (ifft_with_domain, field_polynomial.rs:594-597): measured on the device
-    std::vector<uint64_t> lens(count), cap(16, n);
-    for (uint32_t i0 = 0; i0 < count; i0 += 16) {
-        const uint32_t cnt = std::min<uint32_t>(16, count - i0);
-        UZK_TRY(poly_trimmed_len_run(c, d_polys + (uint64_t)i0 * n, n, cap.data(), cnt, lens.data() + i0, true));
-    }
-    if (commitments_out) {
-        std::vector<Jac> cm(count);
-        ScalarView sv = ScalarView::dense(d_evals, n);
-        Ctx::Srs srs;
-        if (!srs_lookup(cir->srs, &srs)) { set_error("uzk_circuit_refresh_tables: the circuit's commit bases are gone"); return UZK_ERR_PARAMETER; }
-        UZK_TRY(msm_dispatch_view(srs, 0, sv, n, count, cm.data()));
-        std::memcpy(commitments_out, cm.data(), (size_t)count * sizeof(Jac));
-    }
+    Ctx::Srs srs;
+    if (!srs_lookup(cir->srs, &srs)) { set_error("uzk_circuit_refresh_tables: the circuit's commit bases are gone"); return UZK_ERR_PARAMETER; }
+    std::vector<uint64_t> lens;
+    std::vector<Jac> cm(commitments_out ? count : 0);
+    UZK_TRY(polys_from_evals(c, &srs, n, count, evals, d_polys, lens, commitments_out ? cm.data() : nullptr));
+    if (commitments_out) std::memcpy(commitments_out, cm.data(), (size_t)count * sizeof(Jac));
     UZK_TRY(derive_and_install(c, *cir, blk, first_slot, count, lens.data()));
     if (polys_out) UZK_HIP(hipMemcpyAsync(polys_out, d_polys, (size_t)count * n * sizeof(Fp), hipMemcpyDeviceToHost, c.stream));
     if (coset_out) UZK_HIP(hipMemcpyAsync(coset_out, d_polys + (uint64_t)count * n, (size_t)count * m * sizeof(Fp), hipMemcpyDeviceToHost, c.stream));
     if (polys_out || coset_out) UZK_HIP(hipStreamSynchronize(c.stream));
+    if (lens_out) std::memcpy(lens_out, lens.data(), (size_t)count * sizeof(uint64_t));
+    return UZK_OK;
+}
+
+int uzk_preprocess_tables(uint64_t lagrange_srs, uint32_t n, uint32_t count, const uint64_t* evals, const uint64_t* k1_mont, uint64_t* polys_out,
+                          uint64_t* lens_out, uint64_t* coset_out, uzk_g1_jac* commitments_out) {
+    API_LOCK;
+    if (!evals || (coset_out && !k1_mont)) { set_error("uzk_preprocess_tables: null pointer"); return UZK_ERR_PARAMETER; }
+    if (n < 2 || n > (1u << 24) || (n & (n - 1)) || count == 0 || count > 4096) { set_error("uzk_preprocess_tables: n must be a power of two in 2 .. 2^24, 1 <= count <= 4096"); return UZK_ERR_PARAMETER; }
+    UZK_TRY(require_ready());
+    Ctx& c = ctx();
+    Ctx::Srs srs;
+    if (commitments_out) {
+        if (!srs_lookup(lagrange_srs, &srs)) { set_error("uzk_preprocess_tables: unknown SRS handle %llu", (unsigned long long)lagrange_srs); return UZK_ERR_PARAMETER; }
+        if (srs.n < n) { set_error("uzk_preprocess_tables: the SRS holds %zu bases, n = %u", srs.n, n); return UZK_ERR_DEGREE; }
+    }
+    const uint64_t m = 6ull * n;
+    std::shared_ptr<DevBlock> blk;
+    UZK_TRY(dev_block((size_t)count * ((size_t)n + (coset_out ? m : 0)) * sizeof(Fp), &blk));
+    Fp* d_polys = static_cast<Fp*>(blk->p);
+    std::vector<uint64_t> lens;
+    std::vector<Jac> cm(commitments_out ? count : 0);
+    UZK_TRY(polys_from_evals(c, &srs, n, count, evals, d_polys, lens, commitments_out ? cm.data() : nullptr));
+    if (commitments_out) std::memcpy(commitments_out, cm.data(), (size_t)count * sizeof(Jac));
+    if (coset_out) {
+        Fp* d_cosets = d_polys + (uint64_t)count * n;
+        UZK_TRY(derive_cosets(c, n, fp_of(k1_mont), d_polys, d_cosets, count));
+        UZK_HIP(hipMemcpyAsync(coset_out, d_cosets, (size_t)count * m * sizeof(Fp), hipMemcpyDeviceToHost, c.stream));
+    }
+    if (polys_out) UZK_HIP(hipMemcpyAsync(polys_out, d_polys, (size_t)count * n * sizeof(Fp), hipMemcpyDeviceToHost, c.stream));
+    UZK_HIP(hipStreamSynchronize(c.stream));
     if (lens_out) std::memcpy(lens_out, lens.data(), (size_t)count * sizeof(uint64_t));
     return UZK_OK;
 }
