@@ -342,7 +342,10 @@ enum {
 typedef struct {
     uint32_t n;                 /* cs.size(): a power of two, 8 <= n <= 2^20 */
     uint32_t shuffle;           /* != 0: built with the "shuffle" feature -- all 46 slots; 0: slots 0..20 only (zmatchmaking) */
-    uint32_t precompute;        /* != 0: window table over the commit bases (uzk_srs_precompute): shorter commits, 32 MiB at n = 2^14 */
+    uint32_t precompute;        /* window tables over the commit bases (uzk_srs_precompute): 0 none; 1 automatic -- two tables, 8-bit
+                                   windows for provers of one proof (shortest chain of dependent additions) and 15-bit windows for
+                                   lockstep batches (17 instead of 32 additions per scalar), 50 MiB at n = 2^14; 4 .. 24: one table
+                                   of that window width for every prover */
     uint32_t reserved;
     const uzk_g1_affine* lagrange_bases;  /* n points: lagrange_pcs.public_parameter_group_1 (prover.rs:125-130) */
     const uzk_g1_affine* blind_bases;     /* 6 points: pcs.public_parameter_group_1[0..3) || [n..n+3) (apply_blind_factors) */

@@ -66,7 +66,8 @@ template <class T> static std::vector<T> times(const std::vector<T>& v, uint32_t
 
 struct Inputs {
     uint64_t n = 0;
-    bool shuffle = true, precompute = true, satisfiable = false;
+    bool shuffle = true, satisfiable = false;
+    uint32_t precompute = 1;                            // uzk_circuit_desc.precompute: 0 none, 1 automatic, 4 .. 24 a window width
     std::vector<Fr> witness, wsel, pi_value, blinds8, blinds_z, t_rands, r_scalars, k, sc;
     std::vector<uint32_t> pi_index, perm;
     std::vector<Fr> table_polys;
@@ -74,7 +75,7 @@ struct Inputs {
     uint32_t hiding[8] = {3, 3, 3, 2, 2, 2, 2, 2};      // constraint_system/turbo/mod.rs:366-373, prover.rs:186
     void load() {
         const auto meta = rd<uint64_t>("meta");                   // n, shuffle, precompute
-        n = meta[0]; shuffle = meta[1] != 0; precompute = meta.size() > 2 && meta[2]; satisfiable = meta.size() > 3 && meta[3];
+        n = meta[0]; shuffle = meta[1] != 0; precompute = meta.size() > 2 ? (uint32_t)meta[2] : 0; satisfiable = meta.size() > 3 && meta[3];
         const auto evals9 = rd<Fr>("evals9");                     // w0..w4, wsel0..2, pi  (9 n)
         witness.assign(evals9.begin(), evals9.begin() + 5 * n);
         wsel.assign(evals9.begin() + 5 * n, evals9.begin() + 8 * n);

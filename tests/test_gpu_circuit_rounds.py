@@ -144,16 +144,19 @@ def _circuit_of(b, inp, shuffle=True, precompute=False):
                      [inp.table_polys[i] for i in range(pch.N_TABLES)], shuffle=shuffle, precompute=precompute)
 
 
-def test_lockstep_batch_equals_single_proofs(gpu):
+@pytest.mark.parametrize("precompute", [0, 1, 11])
+def test_lockstep_batch_equals_single_proofs(gpu, precompute):
     """uzk_prover_create(n, 3): three different witnesses / blinds / challenges over one circuit advance in lockstep (commits of
-    24 vectors, transforms of 30); every lane must equal the proof a batch-1 prover makes of it."""
+    24 vectors, transforms of 30); every lane must equal the proof a batch-1 prover makes of it.  precompute = 1: the batch commits
+    over the 15-bit window table (one shared bucket set per vector, general pipeline), the single proofs over the 8-bit one (one
+    workgroup per window): two MSM pipelines, two tables, the same points."""
     import prover_chain as pch
     b = gpu
     n = 1 << 12
     inp = pch.ChainInputs(n, 31)
     lanes = _round_inputs(inp, 3)
     b.tune("prover_t_cap", 1)                    # random circuits: see tools/prover_chain.py
-    cir = _circuit_of(b, inp)
+    cir = _circuit_of(b, inp, precompute=precompute)
     p3, p1 = b.Prover(n, 3), b.Prover(n, 1)
     try:
         o3 = _run_rounds(b, cir, p3, lanes)

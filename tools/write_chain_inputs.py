@@ -11,6 +11,6 @@ d = sys.argv[1]
 os.makedirs(d, exist_ok=True)
 log_n = int(sys.argv[2]) if len(sys.argv) > 2 else 14
 seed = int(sys.argv[3]) if len(sys.argv) > 3 else 11
-pre = bool(int(sys.argv[4])) if len(sys.argv) > 4 else True
+pre = int(sys.argv[4]) if len(sys.argv) > 4 else 1       # uzk_circuit_desc.precompute: 0, 1 (automatic) or a window width
 _write_inputs(ChainInputs(1 << log_n, seed), d, precompute=pre)
 print("wrote", d)

@@ -20,6 +20,7 @@ constexpr uint32_t kSlots = UZK_CIRCUIT_SLOTS;
 constexpr uint32_t kWires = 5, kWsel = 3, kProofSlots = 10;       // slots of a proof's own polynomials: w0..4, w_sel0..2, pi, z
 constexpr uint32_t kTail = 6;                                      // blinds || -blinds, three slots each (apply_blind_factors)
 constexpr uint32_t kMaxBatch = 64;
+constexpr int kBatchWindowBits = 15;                             // window width of the lockstep-batch commit table (tools/rounds_window_sweep.sh)
 
 struct DevBlock {                                                  // device memory that any thread may drop the last reference to
     void* p = nullptr;
@@ -59,6 +60,7 @@ struct TableSet { SlotRef s[kSlots]; };
 struct Circuit {
     uint32_t n = 0, m = 0, shuffle = 0, n_slots = 0;
     uint64_t srs = 0;                                              // registry handle: lagrange[0..n) || pcs[0..3) || pcs[n..n+3)
+    uint64_t srs_batch = 0;                                        // the same bases under a second handle with the wide-window table (0: none)
     Fp k[kWires], anemoi_g, anemoi_g_inv, edwards_a, group_gen, k1_inv, z_h_inv[6];
     std::shared_ptr<DevBlock> fixed;                               // permutation (5n u32) | group (n Fp)
     const uint32_t* d_perm = nullptr;
@@ -209,18 +211,24 @@ static int upload_and_install(Ctx& c, Circuit& cir, uint32_t first, uint32_t cou
 }
 
 static void release_circuit_srs(Circuit& cir) {
-    Ctx::Srs e;
-    if (cir.srs && srs_erase(cir.srs, &e)) {
-        if (e.owned && e.d_points) (void)hipFree(e.d_points);
-        if (e.d_table) (void)hipFree(e.d_table);
+    for (uint64_t* h : {&cir.srs_batch, &cir.srs}) {               // the second handle adopted the first one's points: it goes first
+        Ctx::Srs e;
+        if (*h && srs_erase(*h, &e)) {
+            if (e.owned && e.d_points) (void)hipFree(e.d_points);
+            if (e.d_table) (void)hipFree(e.d_table);
+        }
+        *h = 0;
     }
-    cir.srs = 0;
 }
 
-// commit = lagrange_pcs.commit(evals) + apply_blind_factors (prover.rs:132-142) as ONE batched MSM with tail scalars
-static int commit(Circuit& cir, const ScalarView& sv, uint32_t batch, Jac* out) {
+// commit = lagrange_pcs.commit(evals) + apply_blind_factors (prover.rs:132-142) as ONE batched MSM with tail scalars.
+// Two window tables serve two regimes (measured): a single proof's commits are chains of dependent additions on
+// a mostly idle chip -- narrow windows, one workgroup per (vector, window), shortest chain; the 8 x B / 5 x B / 2 x B vectors of
+// a lockstep batch fill the chip, and there the NUMBER of additions counts: 15-bit windows over one shared bucket set per
+// vector take 17 additions per scalar instead of 32.
+static int commit(Circuit& cir, const ScalarView& sv, uint32_t batch, uint32_t lockstep, Jac* out) {
     Ctx::Srs srs;
-    if (!srs_lookup(cir.srs, &srs)) { set_error("prover: the circuit's commit bases are gone"); return UZK_ERR_PARAMETER; }
+    if (!srs_lookup(lockstep >= 2 && cir.srs_batch ? cir.srs_batch : cir.srs, &srs)) { set_error("prover: the circuit's commit bases are gone"); return UZK_ERR_PARAMETER; }
     return msm_dispatch_view(srs, 0, sv, (size_t)sv.n_main + sv.tail_n, batch, out);
 }
 
@@ -335,8 +343,16 @@ int uzk_circuit_create(const uzk_circuit_desc* desc, uint64_t* circuit_out) {
         UZK_TRY(uzk_srs_register(bases.data(), bases.size(), &cir->srs));
     }
     if (desc->precompute) {
-        const int rc = uzk_srs_precompute(cir->srs, 0);
-        if (rc != UZK_OK) { (void)uzk_srs_release(cir->srs); return rc; }
+        if (desc->precompute != 1 && (desc->precompute < 4 || desc->precompute > 24)) { (void)uzk_srs_release(cir->srs); set_error("uzk_circuit_create: precompute must be 0, 1 (automatic) or a window width 4 .. 24"); return UZK_ERR_PARAMETER; }
+        int rc = uzk_srs_precompute(cir->srs, desc->precompute == 1 ? 0 : (int)desc->precompute);
+        if (rc == UZK_OK && desc->precompute == 1) {
+            // automatic: a second table for lockstep batches over the same resident bases (adopted, not copied)
+            Ctx::Srs first;
+            if (!srs_lookup(cir->srs, &first)) rc = UZK_ERR_PARAMETER;
+            if (rc == UZK_OK) rc = uzk_srs_register_device(first.d_points, first.n, &cir->srs_batch);
+            if (rc == UZK_OK) rc = uzk_srs_precompute(cir->srs_batch, kBatchWindowBits);
+        }
+        if (rc != UZK_OK) { release_circuit_srs(*cir); return rc; }
     }
     int rc;
     {
@@ -359,7 +375,7 @@ int uzk_circuit_create(const uzk_circuit_desc* desc, uint64_t* circuit_out) {
         };
         if (rc == UZK_OK) rc = body();
     }
-    if (rc != UZK_OK) { (void)uzk_srs_release(cir->srs); return rc; }
+    if (rc != UZK_OK) { release_circuit_srs(*cir); return rc; }
     Registry& r = reg();
     std::lock_guard<std::mutex> lk(r.mu);
     const uint64_t h = r.next++;
@@ -393,7 +409,7 @@ int uzk_circuit_refresh_tables(uint64_t circuit, uint32_t first_slot, uint32_t c
     UZK_TRY(dev_block((size_t)count * ((size_t)n + m) * sizeof(Fp), &blk));
     Fp* d_polys = static_cast<Fp*>(blk->p);
     Ctx::Srs srs;
-    if (!srs_lookup(cir->srs, &srs)) { set_error("uzk_circuit_refresh_tables: the circuit's commit bases are gone"); return UZK_ERR_PARAMETER; }
+    if (!srs_lookup(count >= 2 && cir->srs_batch ? cir->srs_batch : cir->srs, &srs)) { set_error("uzk_circuit_refresh_tables: the circuit's commit bases are gone"); return UZK_ERR_PARAMETER; }
     std::vector<uint64_t> lens;
     std::vector<Jac> cm(commitments_out ? count : 0);
     UZK_TRY(polys_from_evals(c, &srs, n, count, evals, d_polys, lens, commitments_out ? cm.data() : nullptr));
@@ -630,7 +646,7 @@ int uzk_prove_round1(uint64_t prover, uint64_t circuit, const void* witness, con
     sv.group = n_first; sv.group_stride = (uint64_t)kProofSlots * n;
     ROUND_TRY(stage_tail(c, tail, &sv.tail));
     std::vector<Jac> cm((size_t)B * n_first);
-    ROUND_TRY(commit(*cir, sv, B * n_first, cm.data()));
+    ROUND_TRY(commit(*cir, sv, B * n_first, B, cm.data()));
     std::memcpy(cm_out, cm.data(), cm.size() * sizeof(Jac));
     p.round = 1;
     return UZK_OK;
@@ -663,7 +679,7 @@ int uzk_prove_round2(uint64_t prover, const uint64_t* beta, const uint64_t* gamm
     sv.main = p.evals(0, z); sv.stride = (uint64_t)kProofSlots * n; sv.n_main = n; sv.tail_n = kTail;
     ROUND_TRY(stage_tail(c, tail, &sv.tail));
     std::vector<Jac> cm(B);
-    ROUND_TRY(commit(cir, sv, B, cm.data()));
+    ROUND_TRY(commit(cir, sv, B, B, cm.data()));
     std::memcpy(cm_z_out, cm.data(), cm.size() * sizeof(Jac));
     p.round = 2;
     return UZK_OK;
@@ -733,7 +749,7 @@ int uzk_prove_round3(uint64_t prover, const uint64_t* alpha, const uint64_t* t_r
         UZK_TRY(ntt_run(c, p.d_fold, p.d_fold, n, false, nullptr, B * 5));
         ScalarView sv;
         sv.main = p.d_fold; sv.stride = n; sv.n_main = n; sv.tail = p.d_tail; sv.tail_n = kTail;
-        return commit(cir, sv, B * 5, cm.data());
+        return commit(cir, sv, B * 5, B, cm.data());
     };
     std::vector<uint64_t> t_len(B, t_expected);
     ROUND_TRY(split_and_commit(t_len));
@@ -858,7 +874,7 @@ int uzk_prove_round5(uint64_t prover, const uint64_t* r_scalars, const uint64_t*
         UZK_TRY(ntt_run(c, p.d_fold, p.d_fold, n, false, nullptr, B * 2));
         ScalarView sv;
         sv.main = p.d_fold; sv.stride = n; sv.n_main = n; sv.tail = p.d_tail; sv.tail_n = kTail;
-        return commit(cir, sv, B * 2, cm.data());
+        return commit(cir, sv, B * 2, B, cm.data());
     };
     std::vector<uint64_t> q_len((size_t)B * 2, (uint64_t)n + 2);
     ROUND_TRY(fold_and_commit(q_len));
