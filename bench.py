@@ -83,6 +83,86 @@ def _sample_clocks(work, sync, seconds: float = 2.0):
     return {"sclk_mhz": sclk, "power_w": pws[len(pws) // 2] if pws else None, "samples": len(samples)}
 
 
+class _ClockSampler:
+    """Shader clock (MHz) and socket power (W) sampled in the background WHILE a region runs (the timed steps): a driver line then
+    carries the clock and power of its own box during its own measurement -- the pool's boxes differ by several per cent under
+    the power cap.  Reads through librocm_smi64 in-process (rsmi_dev_gpu_clk_freq_get / rsmi_dev_current_socket_power_get: what
+    `rocm-smi --showclocks --showpower` prints, without a process per sample); the rocm-smi tool itself is the fallback.  (The
+    amdgpu hwmon files were tried first and read 102 MHz under full load on this pool: not the shader clock.)"""
+
+    def __init__(self, device_index: int = 0, period_s: float = 0.01):
+        self.samples, self._stop, self._th, self.period = [], False, None, period_s
+        self.source, self._lib, self._dev = None, None, device_index
+        try:
+            import ctypes
+
+            class Freq(ctypes.Structure):
+                _fields_ = [("has_deep_sleep", ctypes.c_bool), ("num_supported", ctypes.c_uint32), ("current", ctypes.c_uint32),
+                            ("frequency", ctypes.c_uint64 * 33)]
+            lib = ctypes.CDLL("librocm_smi64.so")
+            if lib.rsmi_init(ctypes.c_uint64(0)) == 0:
+                self._lib, self._Freq, self._ct = lib, Freq, ctypes
+                if self._read() is not None:
+                    self.source = "librocm_smi64"
+        except Exception:
+            self._lib = None
+        if self.source is None:
+            import shutil
+            self._lib = None
+            if shutil.which("rocm-smi"):
+                self.source = "rocm-smi"
+
+    def _read(self):
+        if self._lib is not None:
+            ct = self._ct
+            f = self._Freq()
+            if self._lib.rsmi_dev_gpu_clk_freq_get(ct.c_uint32(self._dev), ct.c_int(0), ct.byref(f)) != 0 or f.current >= 33:      # RSMI_CLK_TYPE_SYS
+                return None
+            pw = ct.c_uint64(0)
+            watts = None
+            if self._lib.rsmi_dev_current_socket_power_get(ct.c_uint32(self._dev), ct.byref(pw)) == 0:
+                watts = pw.value / 1e6
+            return f.frequency[f.current] / 1e6, watts
+        import re
+        import subprocess
+        try:
+            out = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=10).stdout
+        except Exception:
+            return None
+        m = re.search(r"sclk clock level:\s*\d+:\s*\((\d+)Mhz\)", out)
+        pw = re.search(r"Power \(W\):\s*([0-9.]+)", out)
+        return (float(m.group(1)), float(pw.group(1)) if pw else None) if m else None
+
+    def _loop(self):
+        while not self._stop:
+            t = time.perf_counter()
+            r = self._read()
+            if r:
+                self.samples.append((t, r[0], r[1]))
+            if self._lib is not None:
+                time.sleep(self.period)
+
+    def start(self):
+        import threading
+        if self.source:
+            self._th = threading.Thread(target=self._loop, daemon=True)
+            self._th.start()
+        return self
+
+    def stop(self, t0: float, t1: float):
+        """Median over the samples taken inside [t0, t1] (perf_counter values); None when there were none."""
+        self._stop = True
+        if self._th:
+            self._th.join(timeout=15)
+        inside = [x for x in self.samples if t0 <= x[0] <= t1]
+        if not inside:
+            return None
+        sclk = sorted(x[1] for x in inside)[len(inside) // 2]
+        pws = sorted(x[2] for x in inside if x[2] is not None)
+        return {"sclk_mhz_timed": round(sclk), "power_w_timed": round(pws[len(pws) // 2], 1) if pws else None, "samples": len(inside),
+                "source": self.source, "what": "median shader clock and socket power sampled in the background during the timed steps"}
+
+
 def _free_port() -> int:
     import socket
     with socket.socket() as sk:
@@ -183,6 +263,46 @@ def _load_counters(name: str):
     return d, None
 
 
+def _gather_proofs(dist, world, mine):
+    """One proof per device is the realistic multi-GPU mode at the prover's size: every rank proves on its own GPU,
+    nothing is exchanged, the job's rate is the sum.  `mine`: this rank's {"proofs_per_s": ..} (or {"error": ..})."""
+    per = [mine]
+    if world > 1:
+        objs = [None] * world
+        dist.all_gather_object(objs, mine)
+        per = objs
+    rates = [p.get("proofs_per_s") for p in per]
+    return {"what": "every rank runs tests/cpp/prover_rounds on its own GPU (4 host threads x 4 proofs in lockstep, one circuit resident "
+                    "per process): whole proofs' device work through uzk_prove_round1..5, no collective",
+            "per_rank": per, "proofs_per_s_total": (sum(rates) if all(r is not None for r in rates) else None)}
+
+
+def _run_prover_rounds(extra_args, visible_device=None, n_log=14, timeout=300):
+    """tests/cpp/prover_rounds (built by __graft_entry__.build(): plain g++, the C ABI only) on ChainInputs(2^n_log, 11); returns its
+    JSON lines.  visible_device: the child sees only that GPU (an entry of the parent's own visible list)."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "tests", "cpp", "prover_rounds")
+    if not os.path.exists(exe):
+        raise RuntimeError("tests/cpp/prover_rounds is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    for p in (os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import prover_chain
+    from test_gpu_cpp_mirror import _write_inputs
+    env = dict(os.environ)
+    if visible_device is not None:
+        seen = [v for v in env.get("HIP_VISIBLE_DEVICES", "").split(",") if v != ""]
+        env["HIP_VISIBLE_DEVICES"] = seen[visible_device] if visible_device < len(seen) else str(visible_device)
+    with tempfile.TemporaryDirectory() as td:
+        _write_inputs(prover_chain.ChainInputs(1 << n_log, 11), td, precompute=True)
+        r = subprocess.run([exe, td] + [str(a) for a in extra_args], capture_output=True, text=True, timeout=timeout, env=env)
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        raise RuntimeError((r.stdout + r.stderr)[-400:])
+    return lines
+
+
 def dry_run_rank(args, rank, world, dist, np) -> None:
     """--dry-run: the launcher, the rendezvous, the all-gather of 96-byte partials and the fold, with no GPU:
     rank r contributes (r + 1) * G (built with the host-side fold of the C ABI)."""
@@ -200,11 +320,13 @@ def dry_run_rank(args, rank, world, dist, np) -> None:
         recv.copy_(send)
     total = b.g1_fold(recv.numpy().view(np.uint64).reshape(world, 12))
     aff = b.g1_to_affine(total)
+    # the proofs-per-device extra of a real N > 1 run: every rank reports its own rate, rank 0 prints the sum (here: 100 (r + 1))
+    proofs = _gather_proofs(dist, world, {"rank": rank, "proofs_per_s": 100.0 * (rank + 1)})
     if rank == 0:
         print(json.dumps({"metric": "bn254_g1_msm_points_per_sec", "value": 0.0, "unit": "points/s", "n_gpus": world,
                           "dry_run": True, "dist_world_size": dist.get_world_size() if world > 1 else 1,
                           "fold_of_rank_partials_affine": [int(x) for x in aff],
-                          "expect": f"{world * (world + 1) // 2} * G"}))
+                          "expect": f"{world * (world + 1) // 2} * G", "extra": {"proofs_per_device": proofs}}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -324,9 +446,11 @@ def run_rank(args) -> None:
     b.profile_reset()
     b.profile_enable(True)
     split["msm_s"] = split["exchange_s"] = 0.0
+    sampler = _ClockSampler(local_rank).start() if rank == 0 else None
     t_local = time.perf_counter()
     elapsed, result = timed_steps(step, args.steps)
     local_elapsed = time.perf_counter() - t_local             # this rank's own clock around the same region (incl. the fences)
+    clocks_timed = sampler.stop(t_local, t_local + local_elapsed) if sampler else None
     b.profile_enable(False)
     prof = b.profile_table()
     # per-rank view of the timed region, so that a multi-GPU run explains itself: every rank's ms per step, its MSM share and
@@ -403,6 +527,11 @@ def run_rank(args) -> None:
     }
     if traffic_note:
         roofline["traffic_note"] = traffic_note
+    if clocks_timed:
+        alu.update(clocks_timed)
+        alu["peak_at_timed_clock"] = round(_issue_peak_t(clocks_timed["sclk_mhz_timed"]), 2)
+        if alu_achieved:
+            alu["frac_at_timed_clock"] = round(alu_achieved / _issue_peak_t(clocks_timed["sclk_mhz_timed"]), 4)
     # device kernels (HIP events) and, prefixed host_, the host-side sections of the call (wall clock)
     kernels = {k: {"launches": v[0], "avg_ms": round(v[1] / max(v[0], 1), 4)} for k, v in sorted(prof.items())}
 
@@ -425,6 +554,19 @@ def run_rank(args) -> None:
                                 "points_per_gpu": m5, "total_points": m5 * world, "steps": max(3, args.steps // 2),
                                 "ms_per_step": round(el5 / max(3, args.steps // 2) * 1e3, 4),
                                 "value": m5 * world * max(3, args.steps // 2) / el5, "unit": "points/s", "scaling": "strong"}
+
+    # ---- proofs per second, one prover process per device (the realistic scaling mode at n = 2^14) --------
+    if world > 1 and not args.no_extras:
+        try:
+            lines = _run_prover_rounds([15, 4, 4], visible_device=dev_index)
+            mine_p = {"rank": rank, "device": dev_index, "proofs_per_s": lines[-1]["proofs_per_s"], "ms_per_proof_single": lines[0]["ms_per_chain"],
+                      "threads_agree_with_single": lines[-1]["threads_agree_with_single"]}
+        except Exception as e:
+            mine_p = {"rank": rank, "device": dev_index, "error": str(e)[-300:]}
+        proofs = _gather_proofs(dist, world, mine_p)
+        if rank == 0:
+            extra["proofs_per_device"] = proofs
+            extra["proofs_per_s_total"] = proofs["proofs_per_s_total"]
 
     # ---- NTT 2^22 (single GPU path; replicas only under N > 1) --------------------------------
     if not args.no_ntt and rank == 0:
@@ -635,24 +777,41 @@ def run_rank(args) -> None:
         except Exception as e:
             extra["prover_chain"] = {"error": str(e)}
         try:     # the same chain issued from compiled host code (tests/cpp/prover_rounds.cpp, built by __graft_entry__.build())
-            import subprocess
-            import tempfile
-            exe = os.path.join(ROOT, "tests", "cpp", "prover_rounds")
-            if os.path.exists(exe):
-                sys.path.insert(0, os.path.join(ROOT, "tests"))
-                from test_gpu_cpp_mirror import _write_inputs
-                with tempfile.TemporaryDirectory() as td:
-                    _write_inputs(prover_chain.ChainInputs(1 << 14, 11), td, precompute=True)
-                    r = subprocess.run([exe, td, "20", "4"], capture_output=True, text=True, timeout=300)
-                line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-                extra["prover_rounds_cpp"] = dict(json.loads(line[0]), what="the chain above issued from C++ (plain g++) through the C ABI "
-                                                  "only, no interpreter between the calls, window table; ms_per_chain = witness resident, "
-                                                  "ms_per_chain_with_witness_upload = the 9n witness elements uploaded from pinned memory every "
-                                                  "chain; four_threads = four host threads with one context each running chains at the same time") if line else {"error": r.stderr[-300:]}
-                if len(line) > 1:
-                    extra["prover_rounds_cpp"]["four_threads"] = json.loads(line[1])
+            lines = _run_prover_rounds([20, 4])
+            extra["prover_rounds_cpp"] = dict(lines[0], what="one proof's device work through uzk_circuit_create / uzk_prove_round1..5 from C++ (plain "
+                                              "g++, the C ABI only); median of five timed blocks after 0.5 s of warm-up; ms_per_chain = witness resident, "
+                                              "ms_per_chain_with_witness_upload = the 8n witness elements uploaded from pinned memory every proof; "
+                                              "four_threads = four host threads (one context and one prover each, one shared circuit); lockstep = four "
+                                              "threads x four proofs per uzk_prove_round call (uzk_prover_create(n, 4): commits over the 15-bit window table)")
+            if len(lines) > 1:
+                extra["prover_rounds_cpp"]["four_threads"] = lines[1]
+            lines = _run_prover_rounds([20, 4, 4])
+            extra["prover_rounds_cpp"]["lockstep"] = lines[-1]
+            extra["proofs_per_s_total"] = lines[-1]["proofs_per_s"]
         except Exception as e:
             extra["prover_rounds_cpp"] = {"error": str(e)}
+        try:     # the per-game refresh of the twelve public-key tables (params.rs:88-121) as one device call
+            import prover_chain
+            inp = prover_chain.ChainInputs(1 << 14, 11)
+            cir = b.Circuit(inp.n, inp.lagrange_wire, inp.bases[inp.n:], inp.perm, inp.k, inp.anemoi_g, inp.anemoi_g_inv, inp.edwards_a,
+                            [inp.table_polys[i] for i in range(prover_chain.N_TABLES)], precompute=True)
+            ev = np.ascontiguousarray(inp.table_polys[prover_chain.T_QPK:prover_chain.T_QPK + 12])
+            res = {}
+            for name, kw in (("device_only", dict(want_polys=False, want_coset=False)), ("with_polys_download", dict(want_polys=True, want_coset=False)),
+                             ("with_polys_and_coset_download", dict(want_polys=True, want_coset=True))):
+                cir.refresh_tables(b.CS_QPK, ev, **kw)
+                t4 = time.perf_counter()
+                for _ in range(5):
+                    cir.refresh_tables(b.CS_QPK, ev, **kw)
+                res[name + "_ms"] = round((time.perf_counter() - t4) / 5 * 1e3, 3)
+            b.profile_reset(); b.profile_enable(True); cir.refresh_tables(b.CS_QPK, ev, want_polys=False); b.sync(); b.profile_enable(False)
+            res["device_kernel_ms"] = round(sum(ms for k, (cnt, ms) in b.profile_table().items() if not k.startswith("host_")), 3)
+            cir.release()
+            extra["public_key_refresh"] = dict(res, what="uzk_circuit_refresh_tables at n = 2^14: 12 evaluation vectors uploaded (6 MiB) -> batched iFFT(n) -> "
+                                               "batched coset FFT(6n) -> batched Lagrange commit, the circuit's tables replaced (copy on write); wall ms per call "
+                                               "incl. the upload; refresh_prover_params_public_key runs this loop call by call on the CPU once per game")
+        except Exception as e:
+            extra["public_key_refresh"] = {"error": str(e)}
 
     # ---- CPU baseline + parity on a bounded sample (rank 0, N = 1 only) -----------------------
     cpu_baseline = None

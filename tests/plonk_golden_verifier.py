@@ -130,8 +130,9 @@ def proof_to_bytes(proof) -> bytes:
     return out + pt(proof["open_zeta"]) + pt(proof["open_zeta_omega"])
 
 
-def load_golden():
-    d = json.load(open(os.path.join(GOLDEN, "plonk_52_golden.json")))
+def load_golden(cards=52):
+    """The reference's golden verification case for a deck of `cards` (52: cs_size 16384; 20: cs_size 4096)."""
+    d = json.load(open(os.path.join(GOLDEN, "plonk_%d_golden.json" % cards)))
     proof = proof_from_bytes(bytes.fromhex(d["proof_hex"]))
     vk = {"cm_q": [_pt(p) for p in d["cm_q"]], "cm_s": [_pt(p) for p in d["cm_s"]], "cm_qb": _pt(d["cm_qb"]),
           "cm_prk": [_pt(p) for p in d["cm_prk"]], "cm_q_ecc": _pt(d["cm_q_ecc"]),

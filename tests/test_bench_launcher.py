@@ -34,6 +34,10 @@ def test_gpus_flag_spawns_that_many_ranks(world):
     aff = np.array(out["fold_of_rank_partials_affine"], dtype=np.uint64)
     want = opy.g1_mul(opy.G1_GEN, world * (world + 1) // 2)
     assert opy.wire_to_affine(aff.tobytes()) == want
+    # one prover process per device (the N > 1 run's proofs-per-second extra): every rank's own rate arrives at rank 0, which sums
+    pd = out["extra"]["proofs_per_device"]
+    assert [p["rank"] for p in pd["per_rank"]] == list(range(world))
+    assert pd["proofs_per_s_total"] == sum(100.0 * (r + 1) for r in range(world))
 
 
 def test_a_failing_rank_fails_the_launcher():
