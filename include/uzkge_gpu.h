@@ -454,7 +454,8 @@ int uzk_synth_scalars_mix(void* d_scalars, size_t n, uint64_t seed);
  * limb representation of the hot loops (fp29.hpp): 10 mul, 11 add, 12/13 sub with 4M / 12M offsets,
  * 14 a lazy-carry chain, 15 form round trip, 16/17 squaring vs product of a lazy operand, 18/19 the
  * multi-subtrahend offsets of ec29.hpp, 20 the dual product, 21..23 the C++ forms of the
- * assembly products 10 / 16 / 20.  a, b, out: n elements (host memory). */
+ * assembly products 10 / 16 / 20; 24 / 25 the constant-operand product (a * b as PLAIN integers mod M, b canonical; 25 with a lazy
+ * first operand 2 (a + 4M)), 26 its companion constant floor(b 2^261 / M) mod 2^256.  a, b, out: n elements (host memory). */
 int uzk_field_op_device(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 /* op: 0 a + b (mixed add), 1 a + b (full XYZZ add), 2 2a, 3 a - b, 4 2(a + b); 5..7 the four-lane addition of the
  * small-MSM folds (ecquad.hpp): 5 a + b, 6 2(a + b) (its doubling branch), 7 (a + b) + (a - b); 8..10 the same three on the
@@ -482,7 +483,7 @@ int uzk_msm_set_window_bits(int c);
 int uzk_msm_plan_info(size_t n, int* window_bits, int* windows);
 /* Experiment switches for A/B measurements in one process (keys: "msm_acc_variant",
  * "msm_task_len", "msm_no_precompute", "msm_fold_group", "msm_overlap", "msm_sort_packed", "msm_fused_hist", "msm_reduce_seg", "msm_scan_reduce", "msm_quad_reduce", "ntt_tile",
- * "msm_chunk_log", "msm_stream_log", "msm_stream_min_log", "msm_small", "msm_fold_mode", "ntt_l29", "ntt_fused",
+ * "msm_chunk_log", "msm_stream_log", "msm_stream_min_log", "msm_small", "msm_fold_mode", "ntt_l29", "ntt_fused", "ntt_mulc",
  * "msm_seg_sort", "msm_chunk_sort", "msm_class_reduce", "msm_fold_big", "msm_bucket_fill", "msm_direct", "msm_scan_nb_log", "ntt_prio", "ntt_order",
  * "prover_t_cap": round 3 reads t as its first 5n - 2 + sum(hiding) coefficients -- for the timing / parity chains on synthetic circuits
  * whose witness satisfies nothing); never needed for correctness. */

@@ -144,3 +144,20 @@ def test_l29_representation_matches_canonical_arithmetic(gpu, field, mod):
         d = (x - y) % mod
         want = (2 * d * (x + y) * i261 - d * (y * 32) * i261) * i5 % mod
         assert to_int(got[i]) == want, (field, i)
+
+
+@pytest.mark.parametrize("field", ["fr", "fq"])
+def test_constant_operand_product(gpu, field):
+    """fp29.hpp mulc (Shoup's form on 29-bit limbs, the NTT's twiddle product): x * w mod M as plain integers for canonical w and its
+    companion floor(w 2^261 / M); the first operand anywhere below 2^256 (op 24) or lazy, 2 (x + 4M) with limbs near 2^31.7 (op 25)."""
+    import random
+    mod = opy.R if field == "fr" else opy.P
+    rng = random.Random(5)
+    xs = [rng.randrange(1 << 256) for _ in range(300)] + [0, 1, mod - 1, mod, mod + 1, (1 << 256) - 1, 2 * mod, 5 * mod]
+    ws = [rng.randrange(mod) for _ in range(300)] + [mod - 1, 0, 1, 2, mod - 2, (1 << 253), mod // 2, 3]
+    to_wire = lambda vals: np.array([[(v >> (64 * k)) & ((1 << 64) - 1) for k in range(4)] for v in vals], dtype=np.uint64)
+    from_wire = lambda a: [sum(int(a[i, k]) << (64 * k) for k in range(4)) for i in range(a.shape[0])]
+    a, b = to_wire(xs), to_wire(ws)
+    assert from_wire(gpu.field_op(field, 24, a, b)) == [x * w % mod for x, w in zip(xs, ws)]
+    assert from_wire(gpu.field_op(field, 25, a, b)) == [2 * (x + 4 * mod) * w % mod for x, w in zip(xs, ws)]
+    assert from_wire(gpu.field_op(field, 26, a, b)) == [((w << 261) // mod) % (1 << 256) for w in ws]

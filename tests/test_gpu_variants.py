@@ -70,11 +70,13 @@ def test_ntt_variants_agree(gpu, n):
             gpu.tune("ntt_l29", 1); gpu.ntt_device(x.data_ptr(), b_.data_ptr(), n, inverse=inv, sync=True)
             assert torch.equal(a, b_)
             for tile in (1024, 2048):      # both workgroup tile sizes of the pass kernels (0 = chosen by size)
-                gpu.tune("ntt_tile", tile); gpu.ntt_device(x.data_ptr(), a.data_ptr(), n, inverse=inv, sync=True)
-                assert torch.equal(a, b_), tile
-            gpu.tune("ntt_tile", 0)
+                for mulc in (1, 0):        # tile twiddles by the constant-operand product (default) / Montgomery products throughout
+                    gpu.tune("ntt_tile", tile); gpu.tune("ntt_mulc", mulc)
+                    gpu.ntt_device(x.data_ptr(), a.data_ptr(), n, inverse=inv, sync=True)
+                    assert torch.equal(a, b_), (tile, mulc)
+            gpu.tune("ntt_tile", 0); gpu.tune("ntt_mulc", 1)
     finally:
-        gpu.tune("ntt_l29", 1); gpu.tune("ntt_tile", 0)
+        gpu.tune("ntt_l29", 1); gpu.tune("ntt_tile", 0); gpu.tune("ntt_mulc", 1)
 
 
 @pytest.mark.parametrize("n", [1, 2, 33, 1000, 4096, 16384, 32768])

@@ -70,8 +70,40 @@ def gen(kind):
     return "\n".join(L)
 
 
+def gen_mulc(scalar_w=False):
+    """x * w mod M for a PRECOMPUTED operand w (a twiddle) with its companion wq = floor(w 2^261 / M) -- Shoup's form on 29-bit
+    limbs: no quotient digits, no serial chain through them.
+      step 1  q~ = the top nine limbs of x * wq, from columns 7..16 only (the dropped low columns move q~ by at most one):
+              q~ in {Q - 2, Q - 1, Q} for the true quotient Q = floor(x w / M)                                  53 MADs
+      step 2  r = (x * w + q~ * (2^261 - M)) mod 2^261 = x w - q~ M, columns 0..8 only                          90 MADs
+    143 MADs + 35 shifts / masks against 162 + 43 for the Montgomery product.  x: value < 2^261, limbs < 2^31.5; w, wq:
+    normalized.  Result: normalized, value < 3M, the plain product (no Montgomery factor)."""
+    # scalar_w: w and wq are wave-uniform and sit in SGPRs (omega_4 of the NTT butterflies): eighteen VGPRs fewer
+    name = "l29_mulcs_asm" if scalar_w else "l29_mulc_asm"
+    L = [f"template <class C>\n__device__ __forceinline__ L29 {name}(const L29& x, const L29& w, const L29& wq) {{"]
+    L.append("    constexpr uint32_t MASK = (1u << 29) - 1;")
+    L.append("    uint64_t acc = 0;")
+    L.append("    uint32_t q0, q1, q2, q3, q4, q5, q6, q7, q8;")
+    L.append("    L29 r;")
+    for k in range(7, 17):
+        lo, hi = max(0, k - 8), min(k, 8)
+        emit([(f"x.l[{i}]", f"wq.l[{k - i}]", scalar_w) for i in range(lo, hi + 1)], L)
+        if k >= 9:
+            L.append(f"    q{k - 9} = (uint32_t)acc & MASK;")
+        L.append("    acc >>= 29;")
+    L.append("    q8 = (uint32_t)acc;")
+    L.append("    acc = 0;")
+    for k in range(9):
+        emit([(f"x.l[{i}]", f"w.l[{k - i}]", scalar_w) for i in range(k + 1)] + [(f"q{i}", f"C::MC[{k - i}]", True) for i in range(k + 1)], L)
+        L.append(f"    r.l[{k}] = (uint32_t)acc & MASK;")
+        if k < 8:
+            L.append("    acc >>= 29;")
+    L.append("    return r;\n}")
+    return "\n".join(L)
+
+
 def main():
-    out = "// GENERATED by tools/gen_mul29_asm.py -- do not edit.\n" + "\n".join(gen(k) for k in ("mul", "sqr", "mul2")) + "\n"
+    out = "// GENERATED by tools/gen_mul29_asm.py -- do not edit.\n" + "\n".join(gen(k) for k in ("mul", "sqr", "mul2")) + "\n" + gen_mulc() + "\n" + gen_mulc(True) + "\n"
     open("uzkge_amd/csrc/mul29_gfx950.inc", "w").write(out)
     print(len(out.splitlines()), "lines")
 

@@ -83,6 +83,12 @@ __global__ __launch_bounds__(256) void k(uint32_t* io, uint32_t inv) {
         for (int i = 0; i < 9; ++i) { x.l[i] = io[t * 9 + i] & 0x1fffffff; y.l[i] = (io[t * 9 + i] >> 3) & 0x1fffffff; }
         for (int i = 0; i < ITERS; ++i) x = Fq29::mul(x, y);
         for (int i = 0; i < 9; ++i) io[t * 9 + i] = x.l[i];
+    } else if constexpr (MODE == 3) {
+        // the constant-operand product (fp29.hpp mulc): 143 MADs, no quotient digits
+        L29 x, y, yq;
+        for (int i = 0; i < 9; ++i) { x.l[i] = io[t * 9 + i] & 0x1fffffff; y.l[i] = (io[t * 9 + i] >> 3) & 0x1fffffff; yq.l[i] = (io[t * 9 + i] >> 2) & 0x1fffffff; }
+        for (int i = 0; i < ITERS; ++i) x = Fq29::mulc(x, y, yq);
+        for (int i = 0; i < 9; ++i) io[t * 9 + i] = x.l[i];
     } else {
         Fp x, y;
         for (int i = 0; i < 8; ++i) { x.v[i] = io[t * 9 + i]; y.v[i] = io[t * 9 + i] >> 3; }
@@ -103,4 +109,4 @@ void run(const char* name, int wps) {
     printf("%-10s waves/SIMD=%d  %.3f ms  %.3e op/s  %.0f cycles(@2.4GHz)/wave-op/SIMD\n", name, wps, best, ops / (best * 1e-3), best * 1e-3 * 2.4e9 / ((double)wps * ITERS));
     hipFree(d);
 }
-int main() { for (int w : {2, 3, 4, 8}) { run<0>("l29_cpp", w); run<2>("l29_asm_columns", w); run<1>("fips32_rx", w); } }
+int main() { for (int w : {1, 2, 3, 4, 8}) { run<2>("l29_montgomery", w); run<3>("l29_mulc_shoup", w); run<1>("fips32_rx", w); } }

@@ -279,7 +279,7 @@ static void copy_tuning(const Ctx& from, Ctx& to) {
     to.tune_fused_hist = from.tune_fused_hist; to.tune_sort_packed = from.tune_sort_packed; to.tune_ntt_fused = from.tune_ntt_fused;
     to.tune_ntt_tile = from.tune_ntt_tile; to.tune_ntt_l29 = from.tune_ntt_l29; to.tune_small = from.tune_small;
     to.tune_fold_mode = from.tune_fold_mode; to.tune_chunk_log = from.tune_chunk_log; to.tune_overlap = from.tune_overlap;
-    to.tune_seg_sort = from.tune_seg_sort; to.tune_direct = from.tune_direct; to.tune_bucket_fill = from.tune_bucket_fill; to.tune_fold_big = from.tune_fold_big; to.tune_scan_nb_log = from.tune_scan_nb_log; to.tune_ntt_prio = from.tune_ntt_prio; to.tune_ntt_order = from.tune_ntt_order; to.tune_class_reduce = from.tune_class_reduce; to.tune_chunk_sort = from.tune_chunk_sort; to.tune_scatter4 = from.tune_scatter4; to.tune_stream_log = from.tune_stream_log; to.tune_stream_min_log = from.tune_stream_min_log; to.tune_prover_t_cap = from.tune_prover_t_cap;
+    to.tune_seg_sort = from.tune_seg_sort; to.tune_direct = from.tune_direct; to.tune_bucket_fill = from.tune_bucket_fill; to.tune_fold_big = from.tune_fold_big; to.tune_scan_nb_log = from.tune_scan_nb_log; to.tune_ntt_prio = from.tune_ntt_prio; to.tune_ntt_order = from.tune_ntt_order; to.tune_class_reduce = from.tune_class_reduce; to.tune_chunk_sort = from.tune_chunk_sort; to.tune_scatter4 = from.tune_scatter4; to.tune_stream_log = from.tune_stream_log; to.tune_stream_min_log = from.tune_stream_min_log; to.tune_prover_t_cap = from.tune_prover_t_cap; to.tune_ntt_mulc = from.tune_ntt_mulc;
 }
 int uzk_ctx_create(uint64_t* ctx_out) {
     if (!ctx_out) { set_error("uzk_ctx_create: null pointer"); return UZK_ERR_PARAMETER; }
@@ -1036,7 +1036,7 @@ int uzk_synth_scalars_mix(void* d_scalars, size_t n, uint64_t seed) {
 int uzk_field_op_device(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
     API_LOCK;
     if (n > 0 && (!a || !b || !out)) { set_error("uzk_field_op_device: null pointer"); return UZK_ERR_PARAMETER; }
-    if (field < 0 || field > 1 || op < 0 || op > 23) { set_error("uzk_field_op_device: bad field/op"); return UZK_ERR_PARAMETER; }
+    if (field < 0 || field > 1 || op < 0 || op > 26) { set_error("uzk_field_op_device: bad field/op"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
     return field_op_device(ctx(), field, op, as_fp(a), as_fp(b), reinterpret_cast<Fp*>(out), n);
 }
@@ -1126,6 +1126,7 @@ int uzk_tune(const char* key, int value) {
     else if (!std::strcmp(key, "msm_overlap")) c.tune_overlap = value;
     else if (!std::strcmp(key, "ntt_l29")) c.tune_ntt_l29 = value;
     else if (!std::strcmp(key, "ntt_fused")) c.tune_ntt_fused = value;
+    else if (!std::strcmp(key, "ntt_mulc")) c.tune_ntt_mulc = value;
     else if (!std::strcmp(key, "ntt_tile")) c.tune_ntt_tile = value;
     else if (!std::strcmp(key, "ntt_prio")) c.tune_ntt_prio = value;
     else if (!std::strcmp(key, "ntt_order")) c.tune_ntt_order = value;

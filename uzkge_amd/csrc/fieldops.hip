@@ -58,6 +58,17 @@ __global__ __launch_bounds__(256) void field_op_kernel(int op, const Fp* __restr
             L29 a = F29::from_fp(x), b = F29::from_fp(y);
             r = F29::to_fp(F29::canon(F29::mul2_cpp(a, F29::to_261(b), F29::add(a, b), F29::to_261(a))));
         } break;
+        // the constant-operand product (fp29.hpp mulc): y canonical, x any 256-bit value; out = x * y mod M as PLAIN integers
+        case 24: { const L29 w = F29::from_fp(y); r = F29::to_fp(F29::canon(F29::mulc(F29::from_fp(x), w, F29::wq_of(w)))); } break;
+        // ... with a lazy first operand near the limb bound: 2 (x + 4M) as limb-wise sums (limbs < 2^31.7, value < 19M)
+        case 25: {
+            const L29 w = F29::from_fp(y);
+            L29 t = F29::add(F29::from_fp(x), F29::constant(F29::Cfg::OFF4));
+            t = F29::add(t, t);
+            r = F29::to_fp(F29::canon(F29::mulc(t, w, F29::wq_of(w))));
+        } break;
+        // wq_of(y) itself, low 256 bits (floor(y 2^261 / M) mod 2^256)
+        case 26: r = F29::to_fp(F29::wq_of(F29::from_fp(y))); break;
         default: r = F::to_mont(x); break;
     }
     out[i] = r;

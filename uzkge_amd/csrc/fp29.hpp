@@ -82,13 +82,13 @@ struct Field29 {
         for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] + b.l[i];
         return r;
     }
-    // a - b + OFF (OFF = 4M or 12M with borrowed limbs)
+    // a - b + OFF (OFF = 4M, 8M or 12M with borrowed limbs)
     template <int K>
     __device__ __forceinline__ static L29 sub(const L29& a, const L29& b) {
-        static_assert(K == 4 || K == 12, "offsets 4M and 12M are provided");
+        static_assert(K == 4 || K == 8 || K == 12, "offsets 4M, 8M and 12M are provided");
         L29 r;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] - b.l[i] + (K == 4 ? C::OFF4[i] : C::OFF12[i]);
+        for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] - b.l[i] + (K == 4 ? C::OFF4[i] : K == 8 ? C::OFF8[i] : C::OFF12[i]);
         return r;
     }
     __device__ __forceinline__ static L29 norm(const L29& a) {
@@ -118,6 +118,34 @@ struct Field29 {
     __device__ __forceinline__ static L29 mul(const L29& a, const L29& b) { return l29_mul_asm<C>(a, b); }
     __device__ __forceinline__ static L29 sqr(const L29& a) { return l29_sqr_asm<C>(a); }
     __device__ __forceinline__ static L29 mul2(const L29& a, const L29& b, const L29& c, const L29& d) { return l29_mul2_asm<C>(a, b, c, d); }
+    // x * w mod M for a PRECOMPUTED w (a twiddle) and its companion wq = wq_of(w): the plain product, no Montgomery factor,
+    // no quotient digits (mul29_gfx950.inc: 143 MADs + 35 shifts / masks against 162 + 43).  x: value < 2^261, limbs < 2^31.5;
+    // w, wq normalized.  Result normalized, value < 3M.
+    __device__ __forceinline__ static L29 mulc(const L29& x, const L29& w, const L29& wq) { return l29_mulc_asm<C>(x, w, wq); }
+    // the same with a wave-uniform w / wq held in scalar registers (made uniform by uniform())
+    __device__ __forceinline__ static L29 mulcs(const L29& x, const L29& w, const L29& wq) { return l29_mulcs_asm<C>(x, w, wq); }
+    __device__ __forceinline__ static L29 uniform(const L29& a) {
+        L29 r;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) r.l[i] = __builtin_amdgcn_readfirstlane(a.l[i]);
+        return r;
+    }
+    // a * b mod 2^261 (the low nine columns), normalized operands
+    __device__ __forceinline__ static L29 mullo(const L29& a, const L29& b) {
+        uint64_t acc = 0;
+        L29 r;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+#pragma unroll
+            for (int i = 0; i <= k; ++i) acc += (uint64_t)a.l[i] * b.l[k - i];
+            r.l[k] = (uint32_t)acc & MASK;
+            acc >>= 29;
+        }
+        return r;
+    }
+    // floor(w 2^261 / M) for a canonical plain value w: w 2^261 - rho is a multiple of M (rho = w 2^261 mod M), so the quotient
+    // is that difference times M^-1 modulo 2^261 -- one Montgomery product, one canon, one low-half product.
+    __device__ __forceinline__ static L29 wq_of(const L29& w) { return mullo(canon(mul(w, constant(C::R522))), constant(C::NEGINV261)); }
     // the same three in plain C++ (reference for the generated assembly; KAT ops compare them)
     __device__ __forceinline__ static L29 mul_cpp(const L29& a, const L29& b) {
         uint64_t acc = 0;

@@ -38,6 +38,8 @@ struct NttPlan {
     int npass = 0;
     int bits[4] = {0, 0, 0, 0};
     Fp* d_tw256 = nullptr;        // omega_256^e (direction-specific), e < 256   (n >= 4096)
+    Fp* d_tw256c = nullptr;       // the same 256 twiddles as pairs (w, floor(w 2^261 / M)) for the constant-operand product: two
+                                  // sets of limb planes, the second 256 * 36 bytes behind the first (uzk_tune("ntt_mulc"))
     Fp* d_tw_pass[4] = {nullptr, nullptr, nullptr, nullptr};
     uint64_t tw_count[4] = {0, 0, 0, 0};   // entries per pass table
     Fp* d_small_tw = nullptr;     // omega_n^e, e < n/2                          (n <= 2048)
@@ -155,6 +157,7 @@ struct PassArgs {
     uint64_t stride;       // N / R
     int log_S;             // log2 of the product of earlier radices
     const Fp* tw256;       // omega_256^e, direction-specific
+    const Fp* tw256c;      // the same as (w, wq) pairs for the constant-operand product (ntt_pass29_kernel<.., MULC = true>)
     const Fp* twp;         // pass table [m'][sigma] (nullptr on the last pass)
     uint64_t twp_count;    // entries of twp (29-bit-limb kernels: tables are limb planes, see tw29_load)
     // ---- fused coset scaling and radix-3 stage (29-bit-limb kernels only; all zero = plain transform) ----
@@ -344,6 +347,25 @@ __global__ __launch_bounds__(256) void ntt_repack_tw_kernel(const Fp* __restrict
     p2[i] = v.l[8];
 }
 
+// src[i] = w_i 2^261 mod M (canonical, 8 x 32 bits)  ->  two sets of limb planes: the plain values w_i and their companions
+// floor(w_i 2^261 / M) = (w_i 2^261 mod M) * (-M^-1) mod 2^261 -- the operands of F9::mulc.
+__global__ __launch_bounds__(256) void ntt_pair_tw_kernel(const Fp* __restrict__ src, Fp* __restrict__ dst_base, uint64_t count) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const L29 rho = F9::from_fp(src[i]);
+    const L29 w = F9::canon(F9::mul(rho, F9::constant(F9::Cfg::R1)));
+    const L29 wq = F9::mullo(rho, F9::constant(F9::Cfg::NEGINV261));
+    for (int half = 0; half < 2; ++half) {
+        const L29& v = half ? wq : w;
+        uint4* p0 = reinterpret_cast<uint4*>(reinterpret_cast<char*>(dst_base) + (size_t)half * count * 36);
+        uint4* p1 = p0 + count;
+        uint32_t* p2 = reinterpret_cast<uint32_t*>(p1 + count);
+        p0[i] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+        p1[i] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+        p2[i] = v.l[8];
+    }
+}
+
 // planes[j] = g^j * scale in 2^261-form (three-level power table of g), j < count: the coset / radix-3 input and
 // output tables of the fused transforms
 __global__ __launch_bounds__(256) void ntt_gen_pow_planes_kernel(Fp* __restrict__ dst_base, uint64_t count,
@@ -376,6 +398,22 @@ __device__ __forceinline__ void radix4_l(L29& x0, L29& x1, L29& x2, L29& x3, con
     L29 t = x1; x1 = x2; x2 = t;
 }
 
+// The same butterfly around the constant-operand product (F9::mulc: plain product, value < 3M out, value < 2^261 in).  Inputs
+// < 3M (a mulc result, or a loaded element): first layer sums < 6M, differences < 7M; the second layer subtracts a sum of two
+// (value < 6M, limbs < 2^30), hence the 8M offset; outputs < 12M / 14M / 10M / 11M, limbs < 2^31.4.
+__device__ __forceinline__ void radix4_c(L29& x0, L29& x1, L29& x2, L29& x3, const L29& w4, const L29& w4q) {
+    bf2_l(x0, x2);
+    bf2_l(x1, x3); x3 = F9::mulcs(x3, w4, w4q);                   // omega_4 and its companion are wave-uniform: scalar registers
+    { const L29 s = F9::add(x0, x1); x1 = F9::sub<8>(x0, x1); x0 = s; }
+    bf2_l(x2, x3);
+    L29 t = x1; x1 = x2; x2 = t;
+}
+// entry idx of a pair table of `count` twiddles: the plain value and its companion
+__device__ __forceinline__ void tw29_load_pair(const Fp* base, uint64_t count, uint64_t idx, L29& w, L29& wq) {
+    w = tw29_load(base, count, idx);
+    wq = tw29_load(reinterpret_cast<const Fp*>(reinterpret_cast<const char*>(base) + count * 36), count, idx);
+}
+
 // two uint4 planes + one u32 plane per element slot; PL = slots per plane (tile + 64: the transposed layout needs T*(R+1))
 template <int PL>
 __device__ __forceinline__ void lds_put29(uint4* lds, int idx, const L29& v) {
@@ -394,7 +432,11 @@ __device__ __forceinline__ L29 lds_get29(const uint4* lds, int idx) {
 }
 
 // TILE elements per workgroup (TILE / 4 threads): 2048 (two workgroups per CU) or 1024 (four, shorter turnover bubbles)
-template <int B, bool FIRST, int TILE>
+// MULC: the twiddles of the tile (omega_4 inside the butterflies, omega_256^e between the sub-passes -- 8.75 of the 10.75 products per
+// element of a 2^22 transform) are multiplied in by the constant-operand product over the pair table a.tw256c; the pass
+// twiddles and the fused coset / radix-3 tables stay Montgomery products over their 2^261-form tables (streamed tables: a pair
+// would double their traffic).  Both forms compute x * w mod M up to the lazy multiple of M, so they mix freely.
+template <int B, bool FIRST, int TILE, bool MULC>
 __global__ __launch_bounds__(TILE / 4) void ntt_pass29_kernel(const Fp* __restrict__ in, Fp* __restrict__ out,
                                                              PassArgs a) {
     constexpr int R = 1 << B, T = TILE / R, Q = R / 4, SH = 8 - B, NT = TILE / 4, PL = TILE + (TILE >= 1024 ? 64 : 16);
@@ -413,7 +455,18 @@ __global__ __launch_bounds__(TILE / 4) void ntt_pass29_kernel(const Fp* __restri
     out += (uint64_t)blockIdx.y * ((a.twp == nullptr && a.out_mul <= 1) ? a.out_vec_stride : a.batch_stride);
 
     ntt_prio_start(a.prio);
-    const L29 w4 = tw29_load(a.tw256, 256, 64);
+    L29 w4, w4q;
+    if constexpr (MULC) { tw29_load_pair(a.tw256c, 256, 64, w4, w4q); w4 = F9::uniform(w4); w4q = F9::uniform(w4q); }
+    else w4 = tw29_load(a.tw256, 256, 64);
+    // one twiddled output of a butterfly: x * omega_256^e
+    auto twiddle = [&](L29& v, int e) {
+        if constexpr (MULC) { L29 w, wq; tw29_load_pair(a.tw256c, 256, e, w, wq); v = F9::mulc(v, w, wq); }
+        else v = F9::mul(v, tw29_load(a.tw256, 256, e));
+    };
+    auto butterfly = [&](L29& y0, L29& y1, L29& y2, L29& y3) {
+        if constexpr (MULC) radix4_c(y0, y1, y2, y3, w4, w4q);
+        else radix4_l(y0, y1, y2, y3, w4);
+    };
     L29 x[4];
     int rows[4];
 
@@ -450,11 +503,11 @@ __global__ __launch_bounds__(TILE / 4) void ntt_pass29_kernel(const Fp* __restri
 #pragma unroll
         for (int t = 0; t < 4; ++t) x[t] = F9::from_fp(in[i + (uint64_t)(q + t * Q) * a.stride]);
     }
-    radix4_l(x[0], x[1], x[2], x[3], w4);
+    butterfly(x[0], x[1], x[2], x[3]);
     if constexpr (N4 > 1 || TAIL2) {
         x[0] = F9::reduce(x[0]);
 #pragma unroll
-        for (int s = 1; s < 4; ++s) x[s] = F9::mul(x[s], tw29_load(a.tw256, 256, (q * s) << SH));
+        for (int s = 1; s < 4; ++s) twiddle(x[s], (q * s) << SH);
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s) rows[s] = q * 4 + s;
@@ -470,13 +523,13 @@ __global__ __launch_bounds__(TILE / 4) void ntt_pass29_kernel(const Fp* __restri
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < 4; ++t) x[t] = lds_get29<PL>(lds, (q + t * Q) * T + col);
-        radix4_l(x[0], x[1], x[2], x[3], w4);
+        butterfly(x[0], x[1], x[2], x[3]);
         const int mp = q >> (2 * k), sl = q & (S - 1);
         const bool more = (R >> (2 * k + 2)) > 1;
         if (more) {
             x[0] = F9::reduce(x[0]);
 #pragma unroll
-            for (int s = 1; s < 4; ++s) x[s] = F9::mul(x[s], tw29_load(a.tw256, 256, (S * mp * s) << SH));
+            for (int s = 1; s < 4; ++s) twiddle(x[s], (S * mp * s) << SH);
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) rows[s] = (mp << (2 * k + 2)) + s * S + sl;
@@ -670,7 +723,12 @@ static int get_plan(Ctx& c, uint64_t n, bool inverse, bool scaled, NttPlan** out
             *tab = planes;
             return UZK_OK;
         };
-        if (l29) UZK_TRY(to_planes(&p->d_tw256, 256));
+        if (l29) {
+            // the 256 tile twiddles once more as (w, floor(w 2^261 / M)) pairs for the constant-operand product
+            UZK_HIP(hipMalloc(reinterpret_cast<void**>(&p->d_tw256c), 2 * 256 * 36 + 64));
+            hipLaunchKernelGGL(ntt_pair_tw_kernel, dim3(1), dim3(256), 0, c.stream, p->d_tw256, p->d_tw256c, (uint64_t)256);
+            UZK_TRY(to_planes(&p->d_tw256, 256));
+        }
         int log_S = 0;
         for (int j = 0; j + 1 < p->npass; ++j) {
             const uint64_t count = n >> log_S;   // (N / (S R)) * R
@@ -698,6 +756,7 @@ void ntt_free_plans(Ctx& c) {
     for (auto& kv : c.ntt_plans) {
         NttPlan* p = kv.second;
         if (p->d_tw256) (void)hipFree(p->d_tw256);
+        if (p->d_tw256c) (void)hipFree(p->d_tw256c);
         if (p->d_small_tw) (void)hipFree(p->d_small_tw);
         if (p->d_pow) (void)hipFree(p->d_pow);
         for (auto* t : p->d_tw_pass) if (t) (void)hipFree(t);
@@ -720,17 +779,23 @@ static void launch_pass(Ctx& c, bool l29, bool first, const Fp* in, Fp* out, con
     if (l29 && c.tune_ntt_tile == 512) {          // experiment: two waves per workgroup (uzk_tune("ntt_tile", 512))
         KernelScope ks(c, first ? "ntt_pass_first" : "ntt_pass");
         const unsigned g5 = (unsigned)((n / R) / (512 / R));
-        if (first) hipLaunchKernelGGL((ntt_pass29_kernel<B, true, 512>), dim3(g5, batch), dim3(128), 0, c.stream, in, out, a);
-        else hipLaunchKernelGGL((ntt_pass29_kernel<B, false, 512>), dim3(g5, batch), dim3(128), 0, c.stream, in, out, a);
+        if (first) hipLaunchKernelGGL((ntt_pass29_kernel<B, true, 512, false>), dim3(g5, batch), dim3(128), 0, c.stream, in, out, a);
+        else hipLaunchKernelGGL((ntt_pass29_kernel<B, false, 512, false>), dim3(g5, batch), dim3(128), 0, c.stream, in, out, a);
     } else if (l29 && small_tile) {
         KernelScope ks(c, first ? "ntt_pass_first" : "ntt_pass");
         const unsigned g2 = (unsigned)((n / R) / (1024 / R));
-        if (first) hipLaunchKernelGGL((ntt_pass29_kernel<B, true, 1024>), dim3(g2, batch), dim3(256), 0, c.stream, in, out, a);
-        else hipLaunchKernelGGL((ntt_pass29_kernel<B, false, 1024>), dim3(g2, batch), dim3(256), 0, c.stream, in, out, a);
+        const bool mulc = a.tw256c != nullptr;
+        if (first && mulc) hipLaunchKernelGGL((ntt_pass29_kernel<B, true, 1024, true>), dim3(g2, batch), dim3(256), 0, c.stream, in, out, a);
+        else if (mulc) hipLaunchKernelGGL((ntt_pass29_kernel<B, false, 1024, true>), dim3(g2, batch), dim3(256), 0, c.stream, in, out, a);
+        else if (first) hipLaunchKernelGGL((ntt_pass29_kernel<B, true, 1024, false>), dim3(g2, batch), dim3(256), 0, c.stream, in, out, a);
+        else hipLaunchKernelGGL((ntt_pass29_kernel<B, false, 1024, false>), dim3(g2, batch), dim3(256), 0, c.stream, in, out, a);
     } else if (l29) {
         KernelScope ks(c, first ? "ntt_pass_first" : "ntt_pass");
-        if (first) hipLaunchKernelGGL((ntt_pass29_kernel<B, true, 2048>), dim3(grid, batch), dim3(512), 0, c.stream, in, out, a);
-        else hipLaunchKernelGGL((ntt_pass29_kernel<B, false, 2048>), dim3(grid, batch), dim3(512), 0, c.stream, in, out, a);
+        const bool mulc = a.tw256c != nullptr;
+        if (first && mulc) hipLaunchKernelGGL((ntt_pass29_kernel<B, true, 2048, true>), dim3(grid, batch), dim3(512), 0, c.stream, in, out, a);
+        else if (mulc) hipLaunchKernelGGL((ntt_pass29_kernel<B, false, 2048, true>), dim3(grid, batch), dim3(512), 0, c.stream, in, out, a);
+        else if (first) hipLaunchKernelGGL((ntt_pass29_kernel<B, true, 2048, false>), dim3(grid, batch), dim3(512), 0, c.stream, in, out, a);
+        else hipLaunchKernelGGL((ntt_pass29_kernel<B, false, 2048, false>), dim3(grid, batch), dim3(512), 0, c.stream, in, out, a);
     } else if (first) {
         KernelScope ks(c, "ntt_pass_first");
         hipLaunchKernelGGL((ntt_pass_kernel<B, true>), dim3(grid, batch), dim3(512), 0, c.stream, in, out, a);
@@ -791,6 +856,7 @@ static int ntt_pow2(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse,
         a.stride = n >> p->bits[j];
         a.log_S = log_S;
         a.tw256 = p->d_tw256;
+        a.tw256c = c.tune_ntt_mulc ? p->d_tw256c : nullptr;
         a.twp = p->d_tw_pass[j];
         a.twp_count = p->tw_count[j];
         a.prio = (uint32_t)c.tune_ntt_prio;
