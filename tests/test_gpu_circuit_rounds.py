@@ -356,3 +356,59 @@ def test_preprocess_tables_without_a_circuit(gpu):
             assert affine_of(cms[t]) == oc.jac_to_affine_ints(oc.msm_pippenger(wire, np.ascontiguousarray(evals[t]), 0, 4)), t
     finally:
         srs.release()
+
+
+def test_provers_on_several_contexts_while_the_tables_are_being_swapped(gpu):
+    """Three prover threads (one context and one prover each, one shared circuit) prove in a loop while the main thread keeps
+    swapping the twelve public-key tables between two sets: every proof must be, as a whole, the proof of set A or the proof of
+    set B (the snapshot a proof takes at round 1 is never torn, nothing is freed under a running kernel)."""
+    import threading
+    import prover_chain as pch
+    b = gpu
+    n = 1 << 12
+    inp = pch.ChainInputs(n, 91)
+    b.tune("prover_t_cap", 1)
+    cir = _circuit_of(b, inp)
+    set_a = [np.ascontiguousarray(inp.table_polys[pch.T_QPK + t]) for t in range(12)]
+    set_b = [rand_fr_wire(n, 950 + t) for t in range(12)]
+    pr0 = b.Prover(n, 1)
+    want = {}
+    try:
+        for name, tables in (("b", set_b), ("a", set_a)):
+            cir.update_tables(b.CS_QPK, tables)
+            o = _run_rounds(b, cir, pr0, [inp])
+            want[name] = ([affine_of(j) for j in o["cm_t"]], [affine_of(j) for j in o["cm_q"]], o["evals"].tobytes())
+        assert want["a"] != want["b"]
+        stop, seen, errors = threading.Event(), [], []
+
+        def worker():
+            try:
+                ctx = b.ctx_create()
+                b.ctx_set_current(ctx)
+                b.tune("prover_t_cap", 1)                     # tuning is per context
+                pr = b.Prover(n, 1)
+                try:
+                    while not stop.is_set():
+                        o = _run_rounds(b, cir, pr, [inp])
+                        seen.append(([affine_of(j) for j in o["cm_t"]], [affine_of(j) for j in o["cm_q"]], o["evals"].tobytes()))
+                finally:
+                    pr.destroy()
+                    b.ctx_set_current(0)
+                    b.ctx_destroy(ctx)
+            except Exception as e:        # surfaced by the main thread
+                errors.append(e)
+        threads = [threading.Thread(target=worker) for _ in range(3)]
+        for t in threads:
+            t.start()
+        for i in range(40):
+            cir.update_tables(b.CS_QPK, set_b if i % 2 == 0 else set_a)
+        stop.set()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        assert len(seen) >= 6
+        kinds = {"a" if s == want["a"] else "b" if s == want["b"] else "torn" for s in seen}
+        assert kinds <= {"a", "b"}, kinds
+    finally:
+        pr0.destroy(); cir.release()
+        b.tune("prover_t_cap", 0)
