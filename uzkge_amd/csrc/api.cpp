@@ -353,9 +353,9 @@ int uzk_ctx_wait(uint64_t other) {
     UZK_TRY(require_ready());
     if (!oth->ready) return UZK_OK;                      // nothing was ever queued there
     hipEvent_t ev = oth->get_event();
+    struct Return { Ctx* c; hipEvent_t e; ~Return() { c->event_pool.push_back(e); } } back{oth, ev};   // on every path, errors included
     UZK_HIP(hipEventRecord(ev, oth->stream));
-    UZK_HIP(hipStreamWaitEvent(cur->stream, ev, 0));
-    oth->event_pool.push_back(ev);                       // the wait has captured this recording; a later re-record does not move it
+    UZK_HIP(hipStreamWaitEvent(cur->stream, ev, 0));     // the wait has captured this recording; a later re-record does not move it
     return UZK_OK;
 }
 
@@ -406,12 +406,15 @@ int uzk_host_free(void* h_ptr) {
     {
         Shared& s = shared();
         std::lock_guard<std::mutex> lk(s.mu);
-        auto it = s.pinned.find(h_ptr);
-        if (it == s.pinned.end()) { set_error("uzk_host_free: %p is not a block of uzk_host_alloc", h_ptr); return UZK_ERR_PARAMETER; }
-        s.pinned.erase(it);
+        if (s.pinned.find(h_ptr) == s.pinned.end()) { set_error("uzk_host_free: %p is not a block of uzk_host_alloc", h_ptr); return UZK_ERR_PARAMETER; }
     }
     UZK_HIP(hipStreamSynchronize(ctx().stream));
     UZK_HIP(hipHostFree(h_ptr));
+    {   // only now is the block gone: a failure above leaves it registered (still pinned, still freeable)
+        Shared& s = shared();
+        std::lock_guard<std::mutex> lk(s.mu);
+        s.pinned.erase(h_ptr);
+    }
     return UZK_OK;
 }
 }  // extern "C"
