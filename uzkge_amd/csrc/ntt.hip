@@ -437,7 +437,7 @@ __device__ __forceinline__ L29 lds_get29(const uint4* lds, int idx) {
 // twiddles and the fused coset / radix-3 tables stay Montgomery products over their 2^261-form tables (streamed tables: a pair
 // would double their traffic).  Both forms compute x * w mod M up to the lazy multiple of M, so they mix freely.
 template <int B, bool FIRST, int TILE, bool MULC>
-__global__ __launch_bounds__(TILE / 4) void ntt_pass29_kernel(const Fp* __restrict__ in, Fp* __restrict__ out,
+__global__ __launch_bounds__(TILE / 4) __attribute__((amdgpu_waves_per_eu(4))) void ntt_pass29_kernel(const Fp* __restrict__ in, Fp* __restrict__ out,
                                                              PassArgs a) {
     constexpr int R = 1 << B, T = TILE / R, Q = R / 4, SH = 8 - B, NT = TILE / 4, PL = TILE + (TILE >= 1024 ? 64 : 16);
     constexpr int N4 = B / 2;
@@ -445,6 +445,12 @@ __global__ __launch_bounds__(TILE / 4) void ntt_pass29_kernel(const Fp* __restri
     __shared__ uint4 lds[(9 * PL + 3) / 4];
     const int tid = threadIdx.x;
     const int col = tid % T, q = tid / T;
+    // The untwiddled output of a butterfly has to become small again (it may be the next butterfly's subtrahend).  Measured and
+    // not kept (round 4, profiles/r04_ab_ntt_reduce_lazy.txt): a table-driven form of this step -- q M from a 16-row LDS table, limb-wise
+    // subtraction over a pre-lent M, one parallel carry step: ~45 instructions against ~90 -- pushed the kernels past 128 VGPRs; held
+    // to 128 they spill, and the transform lost a third of what the constant-operand product had won (2^22: 0.947 -> 0.963 of the
+    // Montgomery path's time).
+    auto shrink = [&](L29& v) { v = F9::reduce(v); };
     const uint64_t i0 = (uint64_t)blockIdx.x * T;
     const uint64_t i = i0 + col;
     const Fp* in_base = in;
@@ -505,7 +511,7 @@ __global__ __launch_bounds__(TILE / 4) void ntt_pass29_kernel(const Fp* __restri
     }
     butterfly(x[0], x[1], x[2], x[3]);
     if constexpr (N4 > 1 || TAIL2) {
-        x[0] = F9::reduce(x[0]);
+        shrink(x[0]);
 #pragma unroll
         for (int s = 1; s < 4; ++s) twiddle(x[s], (q * s) << SH);
     }
@@ -527,7 +533,7 @@ __global__ __launch_bounds__(TILE / 4) void ntt_pass29_kernel(const Fp* __restri
         const int mp = q >> (2 * k), sl = q & (S - 1);
         const bool more = (R >> (2 * k + 2)) > 1;
         if (more) {
-            x[0] = F9::reduce(x[0]);
+            shrink(x[0]);
 #pragma unroll
             for (int s = 1; s < 4; ++s) twiddle(x[s], (S * mp * s) << SH);
         }
