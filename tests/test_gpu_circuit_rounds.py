@@ -412,3 +412,54 @@ def test_provers_on_several_contexts_while_the_tables_are_being_swapped(gpu):
     finally:
         pr0.destroy(); cir.release()
         b.tune("prover_t_cap", 0)
+
+
+@pytest.mark.parametrize("n", [64, 1024])
+def test_small_circuits_are_self_consistent(gpu, n):
+    """Sizes below the reference's parameter files (its smallest Lagrange SRS has 4096 bases): the one-workgroup NTT, the 3 * 2^k
+    path of the small quotient domain, the tiny-n MSM windows.  No oracle chain exists at these sizes (it reads the reference's
+    SRS files), so the rounds are held to themselves: a lockstep pair over the window tables equals two single proofs without
+    tables, the evaluations equal the oracle's Horner values of the coefficient polynomials read back from the device."""
+    import prover_chain as pch
+    b = gpu
+    big = pch.ChainInputs(4096, 17)
+    rng = np.random.default_rng(n)
+
+    def lane(seed):
+        x = pch.ChainInputs.__new__(pch.ChainInputs)
+        x.n, x.m, x.seed = n, 6 * n, seed
+        x.w_evals = rand_fr_wire(5 * n, seed).reshape(5, n, 4)
+        x.wsel_evals = rand_fr_wire(3 * n, seed + 1).reshape(3, n, 4)
+        x.pi_evals = np.zeros((n, 4), dtype=np.uint64); x.pi_evals[:8] = rand_fr_wire(8, seed + 2)
+        sc = rand_fr_wire(16, seed + 3)
+        x.beta, x.gamma, x.alpha, x.zeta, x.alpha_open, x.alpha_open2 = sc[0], sc[1], sc[2], sc[3], sc[4], sc[5]
+        x.blinds_w = rand_fr_wire(15, seed + 4).reshape(5, 3, 4); x.blinds_w[3:, 2] = 0
+        x.blinds_wsel = rand_fr_wire(9, seed + 5).reshape(3, 3, 4); x.blinds_wsel[:, 2] = 0
+        x.blinds_z, x.t_rands, x.r_scalars = rand_fr_wire(3, seed + 6), rand_fr_wire(5, seed + 7), rand_fr_wire(43, seed + 8)
+        return x
+    lanes = [lane(100), lane(200)]
+    bases = np.ascontiguousarray(big.lagrange_wire[: n + 6])                    # any n + 6 valid points serve as commit bases here
+    perm = rng.permutation(5 * n).astype(np.uint32)
+    k, polys = rand_fr_wire(5, 9), [rand_fr_wire(n, 300 + i) for i in range(pch.N_TABLES)]
+    g = rand_fr_wire(1, 10)[0]
+    ginv = oc.fr_inv(g)
+    b.tune("prover_t_cap", 1)
+    mk = lambda pre: b.Circuit(n, bases[:n], bases[n:], perm, k, g, ginv, rand_fr_wire(1, 11)[0], polys, precompute=pre)
+    c0, c1 = mk(0), mk(1)
+    p1, p2 = b.Prover(n, 1), b.Prover(n, 2)
+    try:
+        o2 = _run_rounds(b, c1, p2, lanes)
+        coefs2 = [p2.download(b.PB_COEFS, lane_i).reshape(10, 6 * n, 4) for lane_i in range(2)]
+        for i, x in enumerate(lanes):
+            o1 = _run_rounds(b, c0, p1, [x])
+            for key, per in (("cm1", 8), ("cm_z", 1), ("cm_t", 5), ("cm_q", 2)):
+                assert [affine_of(j) for j in o2[key][i * per:(i + 1) * per]] == [affine_of(j) for j in o1[key]], (n, i, key)
+            assert np.array_equal(o2["evals"][i * 19:(i + 1) * 19], o1["evals"])
+            # w0(zeta) and z(zeta omega) by the oracle's Horner over the coefficients the device holds
+            w0 = np.ascontiguousarray(coefs2[i][0, : n + 3])
+            assert np.array_equal(oc.poly_eval(w0, x.zeta).reshape(4), o2["evals"][i * 19])
+            zw = oc.fr_mul(x.zeta, b.domain_group_gen(n))
+            assert np.array_equal(oc.poly_eval(np.ascontiguousarray(coefs2[i][9, : n + 3]), zw).reshape(4), o2["evals"][i * 19 + 11])
+    finally:
+        p1.destroy(); p2.destroy(); c0.release(); c1.release()
+        b.tune("prover_t_cap", 0)

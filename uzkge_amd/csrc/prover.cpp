@@ -350,7 +350,11 @@ int uzk_circuit_create(const uzk_circuit_desc* desc, uint64_t* circuit_out) {
             Ctx::Srs first;
             if (!srs_lookup(cir->srs, &first)) rc = UZK_ERR_PARAMETER;
             if (rc == UZK_OK) rc = uzk_srs_register_device(first.d_points, first.n, &cir->srs_batch);
-            if (rc == UZK_OK) rc = uzk_srs_precompute(cir->srs_batch, kBatchWindowBits);
+            // window width of the lockstep table: 15 bits at n = 2^14 (swept), one bit per halving below, never under the 8 bits
+            // of the one-workgroup-per-window pipeline
+            int lg = 0;
+            while ((2u << lg) <= n) ++lg;
+            if (rc == UZK_OK) rc = uzk_srs_precompute(cir->srs_batch, std::max(8, std::min(kBatchWindowBits, lg + 1)));
         }
         if (rc != UZK_OK) { release_circuit_srs(*cir); return rc; }
     }
