@@ -100,3 +100,45 @@ def test_max_power_of_2_follows_the_reference_loop():
     with pytest.raises(UzkgeError) as e:
         commit_folded_lagrange(None, None, np.zeros((1, 4), dtype=np.uint64), 0)
     assert e.value.kind == "FFTError"
+
+
+def test_circuit_and_prover_entry_points_check_their_arguments_before_the_device():
+    """uzk_circuit_create / uzk_prover_create / uzk_prove_round*: argument errors are reported as such with or without a GPU (the
+    checks run before anything touches the device), unknown handles are ParameterError, and without a GPU a well-formed call fails
+    with DeviceError -- there is no CPU fallback behind the round API either."""
+    import ctypes
+    from uzkge_amd import UzkgeError, _native as N, backend as b
+    wire, _ = load_srs("lagrange-srs-4096.bin")
+    n = 4096
+    perm = np.arange(5 * n, dtype=np.uint32)
+    k = oc.fr_from_ints([1, 2, 3, 4, 5])
+    one = oc.fr_from_ints([1])[0]
+    polys = [oc.fr_from_ints([i + 1, 1]) for i in range(46)]
+    args = dict(lagrange_bases=wire, blind_bases=wire[:6], permutation=perm, k=k, anemoi_g=one, anemoi_g_inv=one, edwards_a=one, polys=polys)
+    for bad_n in (0, 8, 4097, 1 << 21):                              # not a power of two in 16 .. 2^20
+        d = N.CircuitDesc(); d.n = bad_n
+        h = ctypes.c_uint64(0)
+        assert N.lib.uzk_circuit_create(ctypes.byref(d), ctypes.byref(h)) == N.UZK_ERR_PARAMETER
+    with pytest.raises(UzkgeError) as e:                              # a foreign root of unity: FFTError, before any upload
+        b.Circuit(n, group_gen=oc.fr_from_ints([7])[0], **args)
+    assert e.value.kind == "FFTError"
+    bad_perm = perm.copy(); bad_perm[17] = 5 * n
+    with pytest.raises(UzkgeError) as e:
+        b.Circuit(n, **dict(args, permutation=bad_perm))
+    assert e.value.kind == "ParameterError" and "permutation[17]" in str(e.value)
+    h = ctypes.c_uint64(0)
+    assert N.lib.uzk_prover_create(100, 1, ctypes.byref(h)) == N.UZK_ERR_PARAMETER        # n not a power of two
+    assert N.lib.uzk_prover_create(4096, 0, ctypes.byref(h)) == N.UZK_ERR_PARAMETER       # empty batch
+    z = np.zeros(64, dtype=np.uint64)
+    p = z.ctypes.data_as(ctypes.c_void_p)
+    assert N.lib.uzk_prove_round2(12345, p, p, p, p) == N.UZK_ERR_PARAMETER               # unknown prover
+    assert N.lib.uzk_prove_round5(12345, p, p, p, p) == N.UZK_ERR_PARAMETER
+    assert N.lib.uzk_circuit_release(999) == N.UZK_ERR_PARAMETER
+    assert N.lib.uzk_circuit_update_tables(999, 21, 12, p, p) == N.UZK_ERR_PARAMETER
+    if b.device_count() == 0:
+        with pytest.raises(UzkgeError) as e:
+            b.Circuit(n, **args)
+        assert e.value.kind == "DeviceError"
+        with pytest.raises(UzkgeError) as e:
+            b.Prover(n, 1)
+        assert e.value.kind == "DeviceError"
