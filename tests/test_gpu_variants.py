@@ -70,13 +70,18 @@ def test_ntt_variants_agree(gpu, n):
             gpu.tune("ntt_l29", 1); gpu.ntt_device(x.data_ptr(), b_.data_ptr(), n, inverse=inv, sync=True)
             assert torch.equal(a, b_)
             for tile in (1024, 2048):      # both workgroup tile sizes of the pass kernels (0 = chosen by size)
-                for mulc in (1, 0):        # tile twiddles by the constant-operand product (default) / Montgomery products throughout
-                    gpu.tune("ntt_tile", tile); gpu.tune("ntt_mulc", mulc)
+                for mulc, planes in ((1, 2), (0, 2), (1, 0), (0, 0)):      # tile twiddles by the constant-operand product (default) /
+                    gpu.tune("ntt_tile", tile); gpu.tune("ntt_mulc", mulc)     # Montgomery products throughout; limb planes (default) / 8 x 32-bit
+                    gpu.tune("ntt_planes", planes)                             # words between the passes
                     gpu.ntt_device(x.data_ptr(), a.data_ptr(), n, inverse=inv, sync=True)
-                    assert torch.equal(a, b_), (tile, mulc)
-            gpu.tune("ntt_tile", 0); gpu.tune("ntt_mulc", 1)
+                    assert torch.equal(a, b_), (tile, mulc, planes)
+                    if planes:             # in place and batched through the plane buffers
+                        y = x.clone()
+                        gpu.ntt_device(y.data_ptr(), y.data_ptr(), n, inverse=inv, sync=True)
+                        assert torch.equal(y, b_), (tile, mulc, "in place")
+            gpu.tune("ntt_tile", 0); gpu.tune("ntt_mulc", 1); gpu.tune("ntt_planes", 1)
     finally:
-        gpu.tune("ntt_l29", 1); gpu.tune("ntt_tile", 0); gpu.tune("ntt_mulc", 1)
+        gpu.tune("ntt_l29", 1); gpu.tune("ntt_tile", 0); gpu.tune("ntt_mulc", 1); gpu.tune("ntt_planes", 1)
 
 
 @pytest.mark.parametrize("n", [1, 2, 33, 1000, 4096, 16384, 32768])

@@ -174,6 +174,12 @@ struct PassArgs {
     const Fp* out_tw[3];
     uint32_t out_mul;      // 0 / 1: contiguous
     uint32_t prio;         // experiment (uzk_tune("ntt_prio")): wave priorities that de-synchronise the workgroups sharing a CU
+    // Limb planes between the passes (uzk_tune("ntt_planes"), plain power-of-two transforms): the intermediate vectors live in the
+    // two scratch buffers as three planes over plane_count = batch * N entries (limbs 0-3, 4-7, 8: 36 bytes per element, the
+    // layout of the twiddle tables) instead of 8 x 32-bit words, so a pass boundary costs neither the 9 -> 8 word packing of the
+    // store nor the 8 -> 9 unpacking of the next load (~47 instructions per element and boundary) for 12 % more bytes there.
+    uint32_t in_planes, out_planes;
+    uint64_t plane_count;
 };
 
 // ntt_prio: 1 = every other generation of workgroups runs at a higher priority; 2 = every other workgroup; 3 = a workgroup's
@@ -334,6 +340,14 @@ __device__ __forceinline__ L29 tw29_load(const Fp* base, uint64_t count, uint64_
     v.l[8] = p2[idx];
     return v;
 }
+__device__ __forceinline__ void plane29_store(Fp* base, uint64_t count, uint64_t idx, const L29& v) {
+    uint4* p0 = reinterpret_cast<uint4*>(base);
+    uint4* p1 = p0 + count;
+    uint32_t* p2 = reinterpret_cast<uint32_t*>(p1 + count);
+    p0[idx] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    p1[idx] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+    p2[idx] = v.l[8];
+}
 __global__ __launch_bounds__(256) void ntt_repack_tw_kernel(const Fp* __restrict__ src, Fp* __restrict__ dst_base,
                                                             uint64_t count) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -457,8 +471,15 @@ __global__ __launch_bounds__(TILE / 4) __attribute__((amdgpu_waves_per_eu(4))) v
     Fp* out_base = out;
     // plain / coset transforms: the first pass reads and the last pass writes the caller's vectors (stride in_vec_stride /
     // out_vec_stride); the radix-3 forms address whole vectors through in_base / out_base below
-    in += (uint64_t)blockIdx.y * ((FIRST && a.m3 == 0) ? a.in_vec_stride : a.batch_stride);
-    out += (uint64_t)blockIdx.y * ((a.twp == nullptr && a.out_mul <= 1) ? a.out_vec_stride : a.batch_stride);
+    // limb-plane buffers are addressed by element index from the plane base: the vector's offset stays an index
+    const uint64_t in_off = a.in_planes ? (uint64_t)blockIdx.y * a.batch_stride : 0, out_off = a.out_planes ? (uint64_t)blockIdx.y * a.batch_stride : 0;
+    if (!a.in_planes) in += (uint64_t)blockIdx.y * ((FIRST && a.m3 == 0) ? a.in_vec_stride : a.batch_stride);
+    if (!a.out_planes) out += (uint64_t)blockIdx.y * ((a.twp == nullptr && a.out_mul <= 1) ? a.out_vec_stride : a.batch_stride);
+    auto load_in = [&](uint64_t idx) -> L29 { return a.in_planes ? tw29_load(in, a.plane_count, in_off + idx) : F9::from_fp(in[idx]); };
+    auto store_out = [&](uint64_t idx, const L29& v) {        // v normalized, value < 2^256
+        if (a.out_planes) plane29_store(out, a.plane_count, out_off + idx, v);
+        else out[idx] = F9::to_fp(v);
+    };
 
     ntt_prio_start(a.prio);
     L29 w4, w4q;
@@ -507,7 +528,7 @@ __global__ __launch_bounds__(TILE / 4) __attribute__((amdgpu_waves_per_eu(4))) v
         }
     } else {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) x[t] = F9::from_fp(in[i + (uint64_t)(q + t * Q) * a.stride]);
+        for (int t = 0; t < 4; ++t) x[t] = load_in(i + (uint64_t)(q + t * Q) * a.stride);
     }
     butterfly(x[0], x[1], x[2], x[3]);
     if constexpr (N4 > 1 || TAIL2) {
@@ -570,7 +591,7 @@ __global__ __launch_bounds__(TILE / 4) __attribute__((amdgpu_waves_per_eu(4))) v
             const int ce = e / R, re = e % R;
             L29 v = lds_get29<PL>(lds, ce * (R + 1) + re);
             v = F9::mul(v, tw29_load(a.twp, a.twp_count, base + e));      // normalized, < 2M: fits 8 words
-            out[base + e] = F9::to_fp(v);
+            store_out(base + e, v);
         }
     } else {
         const uint64_t mp = i >> a.log_S, sp = i & ((1ull << a.log_S) - 1);
@@ -595,7 +616,7 @@ __global__ __launch_bounds__(TILE / 4) __attribute__((amdgpu_waves_per_eu(4))) v
             L29 v = x[j];
             if (a.twp != nullptr) v = F9::mul(v, tw29_load(a.twp, a.twp_count, (mp << B) + rows[j]));
             else v = F9::canon(v);                 // last pass: back to [0, M)
-            out[base + ((uint64_t)rows[j] << a.log_S)] = F9::to_fp(v);
+            store_out(base + ((uint64_t)rows[j] << a.log_S), v);
         }
         }
     }
@@ -831,13 +852,18 @@ static int ntt_pow2(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse,
         UZK_HIP(hipGetLastError());
         return UZK_OK;
     }
-    const size_t bytes = (size_t)n * batch * sizeof(Fp);
+    // limb planes between the passes: plain transforms on the 29-bit-limb kernels with at least one intermediate vector
+    // (measured, profiles/r04_ab_ntt_planes.txt: 3..5 % faster up to 2^20 elements per launch, 5 % SLOWER from 2^21 on -- three
+    // plane streams and 12 % more bytes where the passes start to feel HBM; uzk_tune("ntt_planes", 2) forces them at every size)
+    const bool planes = p->l29 && fx == nullptr && p->npass >= 2 &&
+                        (c.tune_ntt_planes == 2 || (c.tune_ntt_planes == 1 && n * (uint64_t)batch <= (1ull << 20)));
+    const size_t bytes = (size_t)n * batch * (planes ? 36 : sizeof(Fp)) + 64;
     UZK_TRY(c.ntt_scratch[0].reserve(bytes));
     Fp* s0 = c.ntt_scratch[0].as<Fp>();
     Fp* s1 = nullptr;
     const bool in_place = (d_in == d_out);
     // A strided output holds other data between its vectors: intermediate passes then stay in the two scratch buffers.
-    const bool out_dense = out_vs == n_full;
+    const bool out_dense = out_vs == n_full && !planes;             // ... and so do limb-plane intermediates (36 bytes per element)
     if ((in_place && (p->npass & 1)) || (!out_dense && p->npass > 2)) {
         UZK_TRY(c.ntt_scratch[1].reserve(bytes));
         s1 = c.ntt_scratch[1].as<Fp>();
@@ -866,6 +892,9 @@ static int ntt_pow2(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse,
         a.twp = p->d_tw_pass[j];
         a.twp_count = p->tw_count[j];
         a.prio = (uint32_t)c.tune_ntt_prio;
+        a.in_planes = planes && j > 0;
+        a.out_planes = planes && remaining > 0;
+        a.plane_count = (uint64_t)n * batch;
         const bool first = (j == 0);
         switch (p->bits[j]) {
             case 5: launch_pass<5>(c, p->l29, first, src, dst, a, n, batch); break;
