@@ -455,7 +455,8 @@ int uzk_synth_scalars_mix(void* d_scalars, size_t n, uint64_t seed);
  * 14 a lazy-carry chain, 15 form round trip, 16/17 squaring vs product of a lazy operand, 18/19 the
  * multi-subtrahend offsets of ec29.hpp, 20 the dual product, 21..23 the C++ forms of the
  * assembly products 10 / 16 / 20; 24 / 25 the constant-operand product (a * b as PLAIN integers mod M, b canonical; 25 with a lazy
- * first operand 2 (a + 4M)), 26 its companion constant floor(b 2^261 / M) mod 2^256.  a, b, out: n elements (host memory). */
+ * first operand 2 (a + 4M)), 26 its companion constant floor(b 2^261 / M) mod 2^256, 27 the NTT's lazy reduction of a + b + 4M, raw
+ * (value < 3M, congruent to a + b).  a, b, out: n elements (host memory). */
 int uzk_field_op_device(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 /* op: 0 a + b (mixed add), 1 a + b (full XYZZ add), 2 2a, 3 a - b, 4 2(a + b); 5..7 the four-lane addition of the
  * small-MSM folds (ecquad.hpp): 5 a + b, 6 2(a + b) (its doubling branch), 7 (a + b) + (a - b); 8..10 the same three on the

@@ -161,3 +161,7 @@ def test_constant_operand_product(gpu, field):
     assert from_wire(gpu.field_op(field, 24, a, b)) == [x * w % mod for x, w in zip(xs, ws)]
     assert from_wire(gpu.field_op(field, 25, a, b)) == [2 * (x + 4 * mod) * w % mod for x, w in zip(xs, ws)]
     assert from_wire(gpu.field_op(field, 26, a, b)) == [((w << 261) // mod) % (1 << 256) for w in ws]
+    # the passes' lazy reduction (op 27: reduce3 of x + w + 4M, raw): same residue, below 3M, for any 256-bit operands
+    ys = [rng.randrange(1 << 256) for _ in range(300)] + [(1 << 256) - 1, 0, 5 * mod, mod, mod - 1, (1 << 256) - 1, 1, 2 * mod + 1]
+    got = from_wire(gpu.field_op(field, 27, a, to_wire(ys)))
+    assert all(g < 3 * mod and (g - x - y) % mod == 0 for g, x, y in zip(got, xs, ys))

@@ -70,7 +70,7 @@ def test_ntt_variants_agree(gpu, n):
             gpu.tune("ntt_l29", 1); gpu.ntt_device(x.data_ptr(), b_.data_ptr(), n, inverse=inv, sync=True)
             assert torch.equal(a, b_)
             for tile in (1024, 2048):      # both workgroup tile sizes of the pass kernels (0 = chosen by size)
-                for mulc, planes in ((1, 2), (0, 2), (1, 0), (0, 0)):      # tile twiddles by the constant-operand product (default) /
+                for mulc, planes in ((1, 2), (0, 2), (1, 0), (0, 0), (2, 0), (2, 2)):   # tile twiddles by the constant-operand product (default; 2: with the full reduce) /
                     gpu.tune("ntt_tile", tile); gpu.tune("ntt_mulc", mulc)     # Montgomery products throughout; limb planes (default) / 8 x 32-bit
                     gpu.tune("ntt_planes", planes)                             # words between the passes
                     gpu.ntt_device(x.data_ptr(), a.data_ptr(), n, inverse=inv, sync=True)

@@ -22,7 +22,7 @@ for t in range(cases):
     b.tune("ntt_l29", rng.choice([0, 1, 1]))
     b.tune("ntt_fused", rng.choice([0, 1, 1]))
     b.tune("ntt_tile", rng.choice([0, 0, 1024, 2048]))
-    b.tune("ntt_mulc", rng.choice([1, 1, 0]))
+    b.tune("ntt_mulc", rng.choice([1, 1, 0, 2]))
     b.tune("ntt_planes", rng.choice([1, 2, 0]))
     x = rand_fr_wire(n * batch, rng.randrange(1 << 30)).reshape(batch, n, 4)
     got = b.ntt_batch(x, inverse=inv, coset_shift=shift)

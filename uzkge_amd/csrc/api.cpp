@@ -1039,7 +1039,7 @@ int uzk_synth_scalars_mix(void* d_scalars, size_t n, uint64_t seed) {
 int uzk_field_op_device(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
     API_LOCK;
     if (n > 0 && (!a || !b || !out)) { set_error("uzk_field_op_device: null pointer"); return UZK_ERR_PARAMETER; }
-    if (field < 0 || field > 1 || op < 0 || op > 26) { set_error("uzk_field_op_device: bad field/op"); return UZK_ERR_PARAMETER; }
+    if (field < 0 || field > 1 || op < 0 || op > 27) { set_error("uzk_field_op_device: bad field/op"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
     return field_op_device(ctx(), field, op, as_fp(a), as_fp(b), reinterpret_cast<Fp*>(out), n);
 }
@@ -1129,7 +1129,7 @@ int uzk_tune(const char* key, int value) {
     else if (!std::strcmp(key, "msm_overlap")) c.tune_overlap = value;
     else if (!std::strcmp(key, "ntt_l29")) c.tune_ntt_l29 = value;
     else if (!std::strcmp(key, "ntt_fused")) c.tune_ntt_fused = value;
-    else if (!std::strcmp(key, "ntt_mulc")) c.tune_ntt_mulc = value;
+    else if (!std::strcmp(key, "ntt_mulc")) c.tune_ntt_mulc = (value >= 0 && value <= 2) ? value : 1;
     else if (!std::strcmp(key, "ntt_planes")) c.tune_ntt_planes = value;
     else if (!std::strcmp(key, "ntt_tile")) c.tune_ntt_tile = value;
     else if (!std::strcmp(key, "ntt_prio")) c.tune_ntt_prio = value;

@@ -95,7 +95,7 @@ struct Ctx {
     int tune_ntt_order = 0;   // experiment: the passes' radix bits as decimal digits (868 = 2^8, 2^6, 2^8); 0 = the plan's choice
     int tune_ntt_prio = 0;    // experiment: wave priorities in the NTT passes (ntt.hip ntt_prio_start / ntt_prio_step)
     int tune_ntt_planes = 1;  // 1: the intermediate vectors of a plain multi-pass transform of <= 2^20 elements are limb planes (36 B per element), 2: at every size, 0: 8 x 32-bit words
-    int tune_ntt_mulc = 1;    // 1: the tile twiddles of the NTT passes go through the constant-operand product (fp29.hpp mulc), 0: Montgomery products throughout
+    int tune_ntt_mulc = 1;    // 1: the tile twiddles of the NTT passes go through the constant-operand product (fp29.hpp mulc), 0: Montgomery products throughout, 2: as 1 with the full reduce() for the untwiddled butterfly outputs (A/B)
     int tune_ntt_l29 = 1;     // 1: NTT passes on the 29-bit-limb representation (0: 8x32-bit relaxed Montgomery)
     int tune_small = 1;       // 1: n <= 2^15 takes the one-workgroup-per-slot pipeline (msm_small_*)
     int tune_fold_mode = 0;   // experiment: level-1 fold of the small pipeline = 1 + 16 * quad + lanes per chunk

@@ -69,6 +69,9 @@ __global__ __launch_bounds__(256) void field_op_kernel(int op, const Fp* __restr
         } break;
         // wq_of(y) itself, low 256 bits (floor(y 2^261 / M) mod 2^256)
         case 26: r = F29::to_fp(F29::wq_of(F29::from_fp(y))); break;
+        // reduce3 of the lazy sum x + y + 4M (x, y any 256-bit values: limbs < 2^31.4, value < 14.6M for Fr and Fq), RAW: the caller
+        // checks the residue and the bound value < 3M
+        case 27: r = F29::to_fp(F29::reduce3(F29::add(F29::add(F29::from_fp(x), F29::from_fp(y)), F29::constant(F29::Cfg::OFF4)))); break;
         default: r = F::to_mont(x); break;
     }
     out[i] = r;

@@ -276,6 +276,22 @@ struct Field29 {
         r.l[8] = (uint32_t)((int64_t)a.l[8] - (int64_t)((uint64_t)q * C::M[8]) + c);
         return r;
     }
+    // a: limbs < 2^31.5, value < 16 M  ->  normalized, value < 3M, same residue: a + q (2^261 - M) with the multiple of 2^261
+    // dropped at the top limb.  q comes from the RAW top limb (the unpropagated carries of the low limbs add < 8 to it, nothing
+    // against M >> 232 = 2^21.8): q in {Q - 2, Q - 1, Q} for Q = floor(value / M).  One chain of 18 MADs with the carry pass
+    // folded in -- 37 instructions against reduce()'s ~65 (norm() first, then a signed chain).
+    __device__ __forceinline__ static L29 reduce3(const L29& a) {
+        const uint32_t q = __umulhi(a.l[8], C::MU);
+        uint64_t acc = 0;
+        L29 r;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            asm("v_mad_u64_u32 %0, vcc, %1, 1, %0\n\tv_mad_u64_u32 %0, vcc, %2, %3, %0" : "+v"(acc) : "v"(a.l[i]), "v"(q), "s"(C::MC[i]) : "vcc");
+            r.l[i] = (uint32_t)acc & MASK;
+            acc >>= 29;
+        }
+        return r;
+    }
     // a as for reduce()  ->  the unique representative in [0, M), normalized.
     __device__ __forceinline__ static L29 canon(const L29& a_in) {
         L29 r = reduce(a_in);

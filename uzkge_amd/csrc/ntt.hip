@@ -180,6 +180,7 @@ struct PassArgs {
     // store nor the 8 -> 9 unpacking of the next load (~47 instructions per element and boundary) for 12 % more bytes there.
     uint32_t in_planes, out_planes;
     uint64_t plane_count;
+    uint32_t shrink_full;  // MULC kernels: F9::reduce instead of F9::reduce3 for the untwiddled butterfly output (uzk_tune("ntt_mulc", 2))
 };
 
 // ntt_prio: 1 = every other generation of workgroups runs at a higher priority; 2 = every other workgroup; 3 = a workgroup's
@@ -464,7 +465,12 @@ __global__ __launch_bounds__(TILE / 4) __attribute__((amdgpu_waves_per_eu(4))) v
     // subtraction over a pre-lent M, one parallel carry step: ~45 instructions against ~90 -- pushed the kernels past 128 VGPRs; held
     // to 128 they spill, and the transform lost a third of what the constant-operand product had won (2^22: 0.947 -> 0.963 of the
     // Montgomery path's time).
-    auto shrink = [&](L29& v) { v = F9::reduce(v); };
+    // Round 4, kept: with the constant-operand product the butterflies take inputs < 3M, so the untwiddled output only needs
+    // F9::reduce3 (one MAD chain from the raw top limb, 37 instructions against ~65; a.shrink_full: the A/B switch back).
+    auto shrink = [&](L29& v) {
+        if constexpr (MULC) { if (a.shrink_full) v = F9::reduce(v); else v = F9::reduce3(v); }
+        else v = F9::reduce(v);
+    };
     const uint64_t i0 = (uint64_t)blockIdx.x * T;
     const uint64_t i = i0 + col;
     const Fp* in_base = in;
@@ -490,6 +496,11 @@ __global__ __launch_bounds__(TILE / 4) __attribute__((amdgpu_waves_per_eu(4))) v
         if constexpr (MULC) { L29 w, wq; tw29_load_pair(a.tw256c, 256, e, w, wq); v = F9::mulc(v, w, wq); }
         else v = F9::mul(v, tw29_load(a.tw256, 256, e));
     };
+    // The twiddle between two passes stays a Montgomery product over the 2^261-form table.  Measured and not kept (round 4,
+    // profiles/r04_ab_ntt_reduce3_pairs.txt): (w, wq) pair tables for pass tables of up to 2^18 entries, i.e. the constant-operand
+    // product here too -- no difference at any size (2^14 24.5 / 24.4 us, 2^22 370.0 / 375.0), the 36 instructions saved per product
+    // against twice the table bytes per load.
+    auto pass_twiddle = [&](const L29& v, uint64_t idx) -> L29 { return F9::mul(v, tw29_load(a.twp, a.twp_count, idx)); };
     auto butterfly = [&](L29& y0, L29& y1, L29& y2, L29& y3) {
         if constexpr (MULC) radix4_c(y0, y1, y2, y3, w4, w4q);
         else radix4_l(y0, y1, y2, y3, w4);
@@ -590,7 +601,7 @@ __global__ __launch_bounds__(TILE / 4) __attribute__((amdgpu_waves_per_eu(4))) v
             const int e = tid + j * NT;
             const int ce = e / R, re = e % R;
             L29 v = lds_get29<PL>(lds, ce * (R + 1) + re);
-            v = F9::mul(v, tw29_load(a.twp, a.twp_count, base + e));      // normalized, < 2M: fits 8 words
+            v = pass_twiddle(v, base + e);                                // normalized, < 2M: fits 8 words
             store_out(base + e, v);
         }
     } else {
@@ -614,7 +625,7 @@ __global__ __launch_bounds__(TILE / 4) __attribute__((amdgpu_waves_per_eu(4))) v
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             L29 v = x[j];
-            if (a.twp != nullptr) v = F9::mul(v, tw29_load(a.twp, a.twp_count, (mp << B) + rows[j]));
+            if (a.twp != nullptr) v = pass_twiddle(v, (mp << B) + rows[j]);
             else v = F9::canon(v);                 // last pass: back to [0, M)
             store_out(base + ((uint64_t)rows[j] << a.log_S), v);
         }
@@ -872,6 +883,7 @@ static int ntt_pow2(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse,
     // never write the buffer they read.
     const Fp* src = d_in;
     int log_S = 0;
+    const bool mulc_kernels = c.tune_ntt_mulc != 0 && p->l29 && c.tune_ntt_tile != 512;   // the 512-element tiles are Montgomery only
     for (int j = 0; j < p->npass; ++j) {
         const int remaining = p->npass - 1 - j;
         Fp* dst = (remaining % 2 == 0) ? d_out : s0;
@@ -888,7 +900,8 @@ static int ntt_pow2(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse,
         a.stride = n >> p->bits[j];
         a.log_S = log_S;
         a.tw256 = p->d_tw256;
-        a.tw256c = c.tune_ntt_mulc ? p->d_tw256c : nullptr;
+        a.tw256c = mulc_kernels ? p->d_tw256c : nullptr;
+        a.shrink_full = c.tune_ntt_mulc == 2;
         a.twp = p->d_tw_pass[j];
         a.twp_count = p->tw_count[j];
         a.prio = (uint32_t)c.tune_ntt_prio;
