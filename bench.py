@@ -210,8 +210,8 @@ def main() -> None:
                     help="scalar set of the headline loop: (A) uniform or (B) the prover-like mix of BASELINE.md section 4")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: every rank contributes (rank + 1) * G; exercises the launcher, the collective and the fold")
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-n", type=int, default=24, help="log2 MSM points per GPU")
     ap.add_argument("--ntt-log-n", type=int, default=22)
     ap.add_argument("--points", choices=["random", "arith"], default="random")
