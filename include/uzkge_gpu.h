@@ -25,7 +25,8 @@
  *   UZK_ERR_FFT        -> UzkgeError::FFTError         (no evaluation domain of that size)
  *   UZK_ERR_COMMITMENT -> UzkgeError::CommitmentError  (length mismatch: ark `msm` Err(min_len))
  *   UZK_ERR_PARAMETER  -> UzkgeError::ParameterError   (bad handle / null pointer)
- *   UZK_ERR_DEVICE     -> (new) no gfx950 device, HIP runtime failure, out of device memory
+ *   UZK_ERR_DEVICE     -> (new) no gfx950 device, HIP runtime failure, out of device memory; also out of HOST memory inside the
+ *                         library (no C++ exception leaves an entry point: each is a function-try-block)
  * There is NO CPU fallback: without a usable GPU every compute entry point returns UZK_ERR_DEVICE.
  */
 #ifndef UZKGE_GPU_H

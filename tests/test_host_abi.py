@@ -142,3 +142,20 @@ def test_circuit_and_prover_entry_points_check_their_arguments_before_the_device
         with pytest.raises(UzkgeError) as e:
             b.Prover(n, 1)
         assert e.value.kind == "DeviceError"
+
+
+def test_no_cpp_exception_can_leave_an_entry_point():
+    """The callers of the C ABI cannot unwind C++ (Rust builds with panic = "abort"; ctypes): every `int uzk_*` definition of the
+    library is a function-try-block that ends in uzk::on_exception (message + UZK_ERR_DEVICE)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    defined = set()
+    for name in ("api.cpp", "prover.cpp"):
+        src = open(os.path.join(root, "uzkge_amd", "csrc", name)).read()
+        for m in re.finditer(r"^int (uzk_[a-z0-9_]+)\([^;{]*\)\s*(try\s*)?\{", src, re.M):
+            assert m.group(2), f"{name}: {m.group(1)} is not a function-try-block"
+            assert f'return uzk::on_exception("{m.group(1)}");' in src, m.group(1)
+            defined.add(m.group(1))
+    header = open(os.path.join(root, "include", "uzkge_gpu.h")).read()
+    declared = set(re.findall(r"^int (uzk_[a-z0-9_]+)\(", header, re.M))
+    assert declared <= defined, sorted(declared - defined)

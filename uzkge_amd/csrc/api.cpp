@@ -7,6 +7,8 @@
 #include <cstdarg>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <new>
 
 #include "ctx.hpp"
 #include "host_ec64.hpp"
@@ -21,6 +23,18 @@ void set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof g_err, fmt, ap);
     va_end(ap);
+}
+
+// Every extern "C" entry point is a function-try-block that ends here: no C++ exception (std::bad_alloc from a host-side vector,
+// map or shared_ptr; std::system_error from a mutex) crosses the C ABI into a caller that cannot unwind it (Rust with
+// panic = "abort", ctypes).  Locks taken by the entry point are released by the unwinding; a prover that was mid-round must be
+// destroyed by the caller.
+int on_exception(const char* fn) noexcept {
+    try { throw; }
+    catch (const std::bad_alloc&) { set_error("%s: out of host memory", fn); }
+    catch (const std::exception& e) { set_error("%s: %s", fn, e.what()); }
+    catch (...) { set_error("%s: C++ exception of unknown type", fn); }
+    return UZK_ERR_DEVICE;
 }
 
 // Process-wide state: the device this process is bound to, the SRS registry (bases are read-only and shared by
@@ -211,13 +225,13 @@ extern "C" {
 const char* uzk_version(void) { return "uzkge-amd 0.3 (gfx950) src:" UZK_SRC_HASH; }
 const char* uzk_last_error(void) { return g_err; }
 
-int uzk_device_count(void) {
+int uzk_device_count(void) try {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
-}
+} catch (...) { return uzk::on_exception("uzk_device_count"); }
 
-int uzk_init(int device) {
+int uzk_init(int device) try {
     API_LOCK;
     Shared& s = shared();
     {
@@ -240,13 +254,13 @@ int uzk_init(int device) {
         }
     }
     return require_ready();
-}
+} catch (...) { return uzk::on_exception("uzk_init"); }
 
 // Frees every context (the default one and those of uzk_ctx_create), every SRS and table, and unbinds the device.
 // No other thread may be inside the library.  Threads that had made a destroyed context current fall back to the
 // default context on their next call (the handle no longer resolves).  Memory from uzk_dev_alloc / uzk_host_alloc
 // belongs to the caller and is not touched.
-int uzk_shutdown(void) {
+int uzk_shutdown(void) try {
     Shared& s = shared();
     prover_release_all();                  // circuits and provers own device memory and SRS entries (takes Shared::mu itself)
     std::lock_guard<std::mutex> lk(s.mu);
@@ -266,7 +280,7 @@ int uzk_shutdown(void) {
     s.bound = false;
     s.device = -1;
     return UZK_OK;
-}
+} catch (...) { return uzk::on_exception("uzk_shutdown"); }
 
 /* ---- contexts ------------------------------------------------------------------------------- */
 // the experiment switches and the forced window width travel with the creator: a tool that tunes the default context
@@ -281,7 +295,7 @@ static void copy_tuning(const Ctx& from, Ctx& to) {
     to.tune_fold_mode = from.tune_fold_mode; to.tune_chunk_log = from.tune_chunk_log; to.tune_overlap = from.tune_overlap;
     to.tune_seg_sort = from.tune_seg_sort; to.tune_direct = from.tune_direct; to.tune_bucket_fill = from.tune_bucket_fill; to.tune_fold_big = from.tune_fold_big; to.tune_scan_nb_log = from.tune_scan_nb_log; to.tune_ntt_prio = from.tune_ntt_prio; to.tune_ntt_order = from.tune_ntt_order; to.tune_class_reduce = from.tune_class_reduce; to.tune_chunk_sort = from.tune_chunk_sort; to.tune_scatter4 = from.tune_scatter4; to.tune_stream_log = from.tune_stream_log; to.tune_stream_min_log = from.tune_stream_min_log; to.tune_prover_t_cap = from.tune_prover_t_cap; to.tune_ntt_mulc = from.tune_ntt_mulc; to.tune_ntt_planes = from.tune_ntt_planes;
 }
-int uzk_ctx_create(uint64_t* ctx_out) {
+int uzk_ctx_create(uint64_t* ctx_out) try {
     if (!ctx_out) { set_error("uzk_ctx_create: null pointer"); return UZK_ERR_PARAMETER; }
     Ctx* c = new Ctx();
     {
@@ -296,8 +310,8 @@ int uzk_ctx_create(uint64_t* ctx_out) {
     s.contexts[h] = c;
     *ctx_out = h;
     return UZK_OK;
-}
-int uzk_ctx_set_current(uint64_t handle) {
+} catch (...) { return uzk::on_exception("uzk_ctx_create"); }
+int uzk_ctx_set_current(uint64_t handle) try {
     if (handle == 0) { t_handle = 0; t_cached = nullptr; return UZK_OK; }
     Shared& s = shared();
     std::lock_guard<std::mutex> lk(s.mu);
@@ -307,8 +321,8 @@ int uzk_ctx_set_current(uint64_t handle) {
     t_cached = it->second;
     t_epoch = s.epoch.load(std::memory_order_acquire);
     return UZK_OK;
-}
-int uzk_ctx_destroy(uint64_t handle) {
+} catch (...) { return uzk::on_exception("uzk_ctx_set_current"); }
+int uzk_ctx_destroy(uint64_t handle) try {
     Shared& s = shared();
     Ctx* c = nullptr;
     {
@@ -324,19 +338,19 @@ int uzk_ctx_destroy(uint64_t handle) {
     { std::lock_guard<std::mutex> lk(c->mu); ctx_release(*c); }
     delete c;
     return UZK_OK;
-}
+} catch (...) { return uzk::on_exception("uzk_ctx_destroy"); }
 
-int uzk_ctx_current(uint64_t* ctx_out) {
+int uzk_ctx_current(uint64_t* ctx_out) try {
     if (!ctx_out) { set_error("uzk_ctx_current: null pointer"); return UZK_ERR_PARAMETER; }
     (void)ctx();                                         // a handle whose context is gone resolves to the default context here
     *ctx_out = t_handle;
     return UZK_OK;
-}
+} catch (...) { return uzk::on_exception("uzk_ctx_current"); }
 // The calling thread's current context waits (on the device: no host synchronisation) for everything queued so far on
 // `other`.  Two contexts in one prover thread are two lanes with their own stream and workspaces: independent steps of a
 // proof -- the coset FFTs of the wire polynomials and the commit of the same round, the two openings -- run side by side,
 // and this is the edge between them.
-int uzk_ctx_wait(uint64_t other) {
+int uzk_ctx_wait(uint64_t other) try {
     Ctx* cur = &ctx();
     Ctx* oth = nullptr;
     if (other == 0) oth = &default_ctx();
@@ -357,12 +371,12 @@ int uzk_ctx_wait(uint64_t other) {
     UZK_HIP(hipEventRecord(ev, oth->stream));
     UZK_HIP(hipStreamWaitEvent(cur->stream, ev, 0));     // the wait has captured this recording; a later re-record does not move it
     return UZK_OK;
-}
+} catch (...) { return uzk::on_exception("uzk_ctx_wait"); }
 
 /* ---- device memory ----------------------------------------------------------------------------
  * What a host language needs to keep data resident between the *_device entry points without linking the HIP runtime
  * itself.  Copies and fills are ordered on the calling context's stream, i.e. with that context's kernels. */
-int uzk_dev_alloc(size_t bytes, void** d_out) {
+int uzk_dev_alloc(size_t bytes, void** d_out) try {
     API_LOCK;
     if (!d_out) { set_error("uzk_dev_alloc: null pointer"); return UZK_ERR_PARAMETER; }
     *d_out = nullptr;
@@ -376,17 +390,17 @@ int uzk_dev_alloc(size_t bytes, void** d_out) {
         return UZK_ERR_DEVICE;
     }
     return UZK_OK;
-}
+} catch (...) { return uzk::on_exception("uzk_dev_alloc"); }
 // Waits for the calling context's stream first: work queued on it may still use the block.
-int uzk_dev_free(void* d_ptr) {
+int uzk_dev_free(void* d_ptr) try {
     API_LOCK;
     if (!d_ptr) return UZK_OK;
     UZK_TRY(require_ready());
     UZK_HIP(hipStreamSynchronize(ctx().stream));
     UZK_HIP(hipFree(d_ptr));
     return UZK_OK;
-}
-int uzk_host_alloc(size_t bytes, void** h_out) {
+} catch (...) { return uzk::on_exception("uzk_dev_free"); }
+int uzk_host_alloc(size_t bytes, void** h_out) try {
     API_LOCK;
     if (!h_out) { set_error("uzk_host_alloc: null pointer"); return UZK_ERR_PARAMETER; }
     *h_out = nullptr;
@@ -398,8 +412,8 @@ int uzk_host_alloc(size_t bytes, void** h_out) {
     std::lock_guard<std::mutex> lk(s.mu);
     s.pinned[*h_out] = bytes;
     return UZK_OK;
-}
-int uzk_host_free(void* h_ptr) {
+} catch (...) { return uzk::on_exception("uzk_host_alloc"); }
+int uzk_host_free(void* h_ptr) try {
     API_LOCK;
     if (!h_ptr) return UZK_OK;
     UZK_TRY(require_ready());
@@ -416,7 +430,7 @@ int uzk_host_free(void* h_ptr) {
         s.pinned.erase(h_ptr);
     }
     return UZK_OK;
-}
+} catch (...) { return uzk::on_exception("uzk_host_free"); }
 }  // extern "C"
 namespace uzk {
 // true when [p, p + bytes) lies inside a block of uzk_host_alloc
@@ -448,23 +462,23 @@ static int dev_copy_common(void* dst, size_t dpitch, const void* src, size_t spi
     if (kind == UZK_COPY_D2H || (kind == UZK_COPY_H2D && !is_pinned_block(src, span))) UZK_HIP(hipStreamSynchronize(c.stream));
     return UZK_OK;
 }
-int uzk_dev_copy(void* dst, const void* src, size_t bytes, int kind) {
+int uzk_dev_copy(void* dst, const void* src, size_t bytes, int kind) try {
     API_LOCK;
     return dev_copy_common(dst, bytes, src, bytes, bytes, 1, kind, "uzk_dev_copy");
-}
-int uzk_dev_copy2d(void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t width, size_t rows, int kind) {
+} catch (...) { return uzk::on_exception("uzk_dev_copy"); }
+int uzk_dev_copy2d(void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t width, size_t rows, int kind) try {
     API_LOCK;
     return dev_copy_common(dst, dst_pitch, src, src_pitch, width, rows, kind, "uzk_dev_copy2d");
-}
-int uzk_dev_memset(void* d_dst, int byte, size_t bytes) {
+} catch (...) { return uzk::on_exception("uzk_dev_copy2d"); }
+int uzk_dev_memset(void* d_dst, int byte, size_t bytes) try {
     API_LOCK;
     if (bytes == 0) return UZK_OK;
     if (!d_dst) { set_error("uzk_dev_memset: null pointer"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
     UZK_HIP(hipMemsetAsync(d_dst, byte, bytes, ctx().stream));
     return UZK_OK;
-}
-int uzk_dev_memset2d(void* d_dst, size_t pitch, int byte, size_t width, size_t rows) {
+} catch (...) { return uzk::on_exception("uzk_dev_memset"); }
+int uzk_dev_memset2d(void* d_dst, size_t pitch, int byte, size_t width, size_t rows) try {
     API_LOCK;
     if (width == 0 || rows == 0) return UZK_OK;
     if (!d_dst) { set_error("uzk_dev_memset2d: null pointer"); return UZK_ERR_PARAMETER; }
@@ -472,7 +486,7 @@ int uzk_dev_memset2d(void* d_dst, size_t pitch, int byte, size_t width, size_t r
     UZK_TRY(require_ready());
     UZK_HIP(hipMemset2DAsync(d_dst, pitch, byte, width, rows, ctx().stream));
     return UZK_OK;
-}
+} catch (...) { return uzk::on_exception("uzk_dev_memset2d"); }
 
 /* ---- SRS (process-wide registry: the bases are read-only and shared by every context) ------------ */
 }  // extern "C"
@@ -511,7 +525,7 @@ int bound_device() {
 }  // namespace uzk
 extern "C" {
 
-int uzk_srs_register(const uzk_g1_affine* points, size_t n, uint64_t* handle_out) {
+int uzk_srs_register(const uzk_g1_affine* points, size_t n, uint64_t* handle_out) try {
     API_LOCK;
     if (!handle_out || (n > 0 && !points)) { set_error("uzk_srs_register: null pointer"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
@@ -526,9 +540,9 @@ int uzk_srs_register(const uzk_g1_affine* points, size_t n, uint64_t* handle_out
     }
     *handle_out = srs_insert(s);
     return UZK_OK;
-}
+} catch (...) { return uzk::on_exception("uzk_srs_register"); }
 
-int uzk_srs_register_device(const void* d_points, size_t n, uint64_t* handle_out) {
+int uzk_srs_register_device(const void* d_points, size_t n, uint64_t* handle_out) try {
     API_LOCK;
     if (!handle_out || (n > 0 && !d_points)) { set_error("uzk_srs_register_device: null pointer"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
@@ -538,10 +552,10 @@ int uzk_srs_register_device(const void* d_points, size_t n, uint64_t* handle_out
     s.d_points = const_cast<Affine*>(static_cast<const Affine*>(d_points));
     *handle_out = srs_insert(s);
     return UZK_OK;
-}
+} catch (...) { return uzk::on_exception("uzk_srs_register_device"); }
 
 // The caller makes sure no context still runs an MSM over this handle.
-int uzk_srs_release(uint64_t handle) {
+int uzk_srs_release(uint64_t handle) try {
     API_LOCK;
     Ctx& c = ctx();
     Shared& sh = shared();
@@ -558,10 +572,10 @@ int uzk_srs_release(uint64_t handle) {
     if (e.owned && e.d_points) (void)hipFree(e.d_points);
     if (e.d_table) (void)hipFree(e.d_table);
     return UZK_OK;
-}
+} catch (...) { return uzk::on_exception("uzk_srs_release"); }
 
 // Build the table before contexts start using the handle concurrently (the entry is replaced, not versioned).
-int uzk_srs_precompute(uint64_t handle, int window_bits) {
+int uzk_srs_precompute(uint64_t handle, int window_bits) try {
     API_LOCK;
     UZK_TRY(require_ready());
     Ctx& c = ctx();
@@ -589,14 +603,14 @@ int uzk_srs_precompute(uint64_t handle, int window_bits) {
     }
     if (old_table) { (void)hipStreamSynchronize(c.stream); (void)hipFree(old_table); }
     return UZK_OK;
-}
+} catch (...) { return uzk::on_exception("uzk_srs_precompute"); }
 
-int uzk_srs_len(uint64_t handle, size_t* n_out) {
+int uzk_srs_len(uint64_t handle, size_t* n_out) try {
     Ctx::Srs s;
     if (!n_out || !srs_lookup(handle, &s)) { set_error("uzk_srs_len: unknown handle"); return UZK_ERR_PARAMETER; }
     *n_out = s.n;
     return UZK_OK;
-}
+} catch (...) { return uzk::on_exception("uzk_srs_len"); }
 
 /* ---- MSM ---------------------------------------------------------------------------------- */
 static int msm_checked(uint64_t srs_handle, size_t offset, size_t n, Ctx::Srs* srs_out) {
@@ -644,7 +658,7 @@ static int msm_dispatch(const Ctx::Srs& s, size_t offset, const Fp* d_scalars, s
     return UZK_OK;
 }
 
-int uzk_msm_g1_device(uint64_t srs_handle, size_t offset, const void* d_scalars_mont, size_t n, uzk_g1_jac* out) {
+int uzk_msm_g1_device(uint64_t srs_handle, size_t offset, const void* d_scalars_mont, size_t n, uzk_g1_jac* out) try {
     API_LOCK;
     if (!out || (n > 0 && !d_scalars_mont)) { set_error("uzk_msm_g1_device: null pointer"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
@@ -654,9 +668,9 @@ int uzk_msm_g1_device(uint64_t srs_handle, size_t offset, const void* d_scalars_
     UZK_TRY(msm_dispatch(srs, offset, static_cast<const Fp*>(d_scalars_mont), n, 1, &r));
     std::memcpy(out, &r, sizeof r);
     return UZK_OK;
-}
+} catch (...) { return uzk::on_exception("uzk_msm_g1_device"); }
 
-int uzk_msm_g1(uint64_t srs_handle, size_t offset, const uint64_t* scalars_mont, size_t n, uzk_g1_jac* out) {
+int uzk_msm_g1(uint64_t srs_handle, size_t offset, const uint64_t* scalars_mont, size_t n, uzk_g1_jac* out) try {
     API_LOCK;
     if (!out || (n > 0 && !scalars_mont)) { set_error("uzk_msm_g1: null pointer"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
@@ -675,10 +689,10 @@ int uzk_msm_g1(uint64_t srs_handle, size_t offset, const uint64_t* scalars_mont,
     }
     std::memcpy(out, &r, sizeof r);
     return UZK_OK;
-}
+} catch (...) { return uzk::on_exception("uzk_msm_g1"); }
 
 int uzk_msm_g1_batch_device(uint64_t srs_handle, size_t offset, const void* d_scalars_mont, size_t n, uint32_t batch,
-                            uzk_g1_jac* out) {
+                            uzk_g1_jac* out) try {
     API_LOCK;
     if (batch > 0 && (!out || (n > 0 && !d_scalars_mont))) { set_error("uzk_msm_g1_batch_device: null pointer"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
@@ -688,10 +702,10 @@ int uzk_msm_g1_batch_device(uint64_t srs_handle, size_t offset, const void* d_sc
     UZK_TRY(msm_dispatch(srs, offset, static_cast<const Fp*>(d_scalars_mont), n, batch, r.data()));
     if (batch) std::memcpy(out, r.data(), (size_t)batch * sizeof(Jac));
     return UZK_OK;
-}
+} catch (...) { return uzk::on_exception("uzk_msm_g1_batch_device"); }
 
 int uzk_msm_g1_batch(uint64_t srs_handle, size_t offset, const uint64_t* scalars_mont, size_t n, uint32_t batch,
-                     uzk_g1_jac* out) {
+                     uzk_g1_jac* out) try {
     API_LOCK;
     if (batch > 0 && (!out || (n > 0 && !scalars_mont))) { set_error("uzk_msm_g1_batch: null pointer"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
@@ -707,11 +721,11 @@ int uzk_msm_g1_batch(uint64_t srs_handle, size_t offset, const uint64_t* scalars
     }
     if (batch) std::memcpy(out, r.data(), (size_t)batch * sizeof(Jac));
     return UZK_OK;
-}
+} catch (...) { return uzk::on_exception("uzk_msm_g1_batch"); }
 
 // out[b] = sum_{i<n} d_scalars[b*stride + i] * SRS[offset + i] + sum_{j<tail_n} tail[b*tail_n + j] * SRS[offset + n + j]
 int uzk_msm_g1_batch_tail_device(uint64_t srs_handle, size_t offset, const void* d_scalars_mont, size_t stride, size_t n, uint32_t batch,
-                                 const void* tail_scalars_mont, uint32_t tail_n, int tail_on_device, uzk_g1_jac* out) {
+                                 const void* tail_scalars_mont, uint32_t tail_n, int tail_on_device, uzk_g1_jac* out) try {
     API_LOCK;
     if (batch > 0 && (!out || (n > 0 && !d_scalars_mont) || (tail_n > 0 && !tail_scalars_mont))) { set_error("uzk_msm_g1_batch_tail_device: null pointer"); return UZK_ERR_PARAMETER; }
     if (batch > 1 && stride < n) { set_error("uzk_msm_g1_batch_tail_device: stride %zu smaller than n %zu", stride, n); return UZK_ERR_PARAMETER; }
@@ -746,18 +760,18 @@ int uzk_msm_g1_batch_tail_device(uint64_t srs_handle, size_t offset, const void*
     UZK_TRY(msm_dispatch_view(srs, offset, sv, total, batch, r.data()));
     std::memcpy(out, r.data(), (size_t)batch * sizeof(Jac));
     return UZK_OK;
-}
+} catch (...) { return uzk::on_exception("uzk_msm_g1_batch_tail_device"); }
 
-int uzk_msm_g1_raw(const uzk_g1_affine* points, const uint64_t* scalars_mont, size_t n, uzk_g1_jac* out) {
+int uzk_msm_g1_raw(const uzk_g1_affine* points, const uint64_t* scalars_mont, size_t n, uzk_g1_jac* out) try {
     if (!out || (n > 0 && (!points || !scalars_mont))) { set_error("uzk_msm_g1_raw: null pointer"); return UZK_ERR_PARAMETER; }
     uint64_t h = 0;
     UZK_TRY(uzk_srs_register(points, n, &h));
     int rc = uzk_msm_g1(h, 0, scalars_mont, n, out);
     (void)uzk_srs_release(h);
     return rc;
-}
+} catch (...) { return uzk::on_exception("uzk_msm_g1_raw"); }
 
-int uzk_g1_fold(const uzk_g1_jac* partials, size_t count, uzk_g1_jac* out) {
+int uzk_g1_fold(const uzk_g1_jac* partials, size_t count, uzk_g1_jac* out) try {
     if (!out || (count > 0 && !partials)) { set_error("uzk_g1_fold: null pointer"); return UZK_ERR_PARAMETER; }
     h64::J acc = h64::j_inf();
     for (size_t i = 0; i < count; ++i) {
@@ -768,27 +782,27 @@ int uzk_g1_fold(const uzk_g1_jac* partials, size_t count, uzk_g1_jac* out) {
     const Jac r = h64::j_to(acc);
     std::memcpy(out, &r, sizeof r);
     return UZK_OK;
-}
+} catch (...) { return uzk::on_exception("uzk_g1_fold"); }
 
-int uzk_g1_to_affine(const uzk_g1_jac* p, uzk_g1_affine* out) {
+int uzk_g1_to_affine(const uzk_g1_jac* p, uzk_g1_affine* out) try {
     if (!p || !out) { set_error("uzk_g1_to_affine: null pointer"); return UZK_ERR_PARAMETER; }
     Jac j;
     std::memcpy(&j, p, sizeof j);
     Affine a = jac_to_affine_host(j);
     std::memcpy(out, &a, sizeof a);
     return UZK_OK;
-}
+} catch (...) { return uzk::on_exception("uzk_g1_to_affine"); }
 
 /* ---- NTT ---------------------------------------------------------------------------------- */
-int uzk_domain_supported(uint64_t n) { return domain_supported(n) ? 1 : 0; }
+int uzk_domain_supported(uint64_t n) try { return domain_supported(n) ? 1 : 0; } catch (...) { return uzk::on_exception("uzk_domain_supported"); }
 
-int uzk_domain_group_gen(uint64_t n, uint64_t out_mont[4]) {
+int uzk_domain_group_gen(uint64_t n, uint64_t out_mont[4]) try {
     if (!out_mont) { set_error("uzk_domain_group_gen: null pointer"); return UZK_ERR_PARAMETER; }
     if (!domain_supported(n)) { set_error("no evaluation domain of size %llu", (unsigned long long)n); return UZK_ERR_FFT; }
     Fp w = fr_root_of_unity(n);
     std::memcpy(out_mont, &w, sizeof w);
     return UZK_OK;
-}
+} catch (...) { return uzk::on_exception("uzk_domain_group_gen"); }
 
 static int ntt_device_common(const void* d_in, void* d_out, uint64_t n, uint32_t batch, int inverse,
                              const uint64_t* coset_shift_mont, int sync) {
@@ -823,17 +837,17 @@ static int ntt_host_common(uint64_t* data, uint64_t n, uint32_t batch, int inver
     return UZK_OK;
 }
 
-int uzk_ntt_fr_device(const void* d_in, void* d_out, uint64_t n, int inverse, const uint64_t* coset_shift_mont, int sync) {
+int uzk_ntt_fr_device(const void* d_in, void* d_out, uint64_t n, int inverse, const uint64_t* coset_shift_mont, int sync) try {
     API_LOCK;
     return ntt_device_common(d_in, d_out, n, 1, inverse, coset_shift_mont, sync);
-}
+} catch (...) { return uzk::on_exception("uzk_ntt_fr_device"); }
 int uzk_ntt_fr_batch_device(const void* d_in, void* d_out, uint64_t n, uint32_t batch, int inverse,
-                            const uint64_t* coset_shift_mont, int sync) {
+                            const uint64_t* coset_shift_mont, int sync) try {
     API_LOCK;
     return ntt_device_common(d_in, d_out, n, batch, inverse, coset_shift_mont, sync);
-}
+} catch (...) { return uzk::on_exception("uzk_ntt_fr_batch_device"); }
 int uzk_ntt_fr_batch_strided_device(const void* d_in, uint64_t in_stride, void* d_out, uint64_t out_stride, uint64_t n, uint32_t batch,
-                                    int inverse, const uint64_t* coset_shift_mont, int sync) {
+                                    int inverse, const uint64_t* coset_shift_mont, int sync) try {
     API_LOCK;
     if (!domain_supported(n)) {
         set_error("no evaluation domain of size %llu (need 2^k, k<=28, or 3*2^k)", (unsigned long long)n);
@@ -846,50 +860,50 @@ int uzk_ntt_fr_batch_strided_device(const void* d_in, uint64_t in_stride, void* 
                     coset_shift_mont ? as_fp(coset_shift_mont) : nullptr, batch, in_stride, out_stride));
     if (sync) UZK_HIP(hipStreamSynchronize(c.stream));
     return UZK_OK;
-}
-int uzk_ntt_fr(uint64_t* data, uint64_t n, int inverse, const uint64_t* coset_shift_mont) {
+} catch (...) { return uzk::on_exception("uzk_ntt_fr_batch_strided_device"); }
+int uzk_ntt_fr(uint64_t* data, uint64_t n, int inverse, const uint64_t* coset_shift_mont) try {
     API_LOCK;
     return ntt_host_common(data, n, 1, inverse, coset_shift_mont);
-}
-int uzk_ntt_fr_batch(uint64_t* data, uint64_t n, uint32_t batch, int inverse, const uint64_t* coset_shift_mont) {
+} catch (...) { return uzk::on_exception("uzk_ntt_fr"); }
+int uzk_ntt_fr_batch(uint64_t* data, uint64_t n, uint32_t batch, int inverse, const uint64_t* coset_shift_mont) try {
     API_LOCK;
     return ntt_host_common(data, n, batch, inverse, coset_shift_mont);
-}
+} catch (...) { return uzk::on_exception("uzk_ntt_fr_batch"); }
 
 /* ---- polynomial helpers next to the hot path ------------------------------------------------ */
-int uzk_poly_eval_batch(const uint64_t* coefs, uint64_t n, uint32_t batch, const uint64_t* x_mont, uint64_t* out) {
+int uzk_poly_eval_batch(const uint64_t* coefs, uint64_t n, uint32_t batch, const uint64_t* x_mont, uint64_t* out) try {
     API_LOCK;
     if (!x_mont || (batch > 0 && (!out || (n > 0 && !coefs)))) { set_error("uzk_poly_eval_batch: null pointer"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
     return poly_eval_batch_host(ctx(), as_fp(coefs), n, batch, *as_fp(x_mont), reinterpret_cast<Fp*>(out));
-}
-int uzk_poly_eval_batch_device(const void* d_coefs, uint64_t n, uint32_t batch, const uint64_t* x_mont, uint64_t* out) {
+} catch (...) { return uzk::on_exception("uzk_poly_eval_batch"); }
+int uzk_poly_eval_batch_device(const void* d_coefs, uint64_t n, uint32_t batch, const uint64_t* x_mont, uint64_t* out) try {
     API_LOCK;
     if (!x_mont || (batch > 0 && (!out || (n > 0 && !d_coefs)))) { set_error("uzk_poly_eval_batch_device: null pointer"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
     return poly_eval_batch(ctx(), static_cast<const Fp*>(d_coefs), n, batch, *as_fp(x_mont), reinterpret_cast<Fp*>(out));
-}
+} catch (...) { return uzk::on_exception("uzk_poly_eval_batch_device"); }
 int uzk_z_poly_device(const void* d_w, const uint32_t* d_perm, const void* d_group, const uint64_t* k, const uint64_t* beta_mont,
-                      const uint64_t* gamma_mont, uint32_t n, uint32_t n_wires, void* d_z) {
+                      const uint64_t* gamma_mont, uint32_t n, uint32_t n_wires, void* d_z) try {
     API_LOCK;
     if (n > 0 && (!d_w || !d_perm || !d_group || !k || !beta_mont || !gamma_mont || !d_z)) { set_error("uzk_z_poly_device: null pointer"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
     return z_poly_device(ctx(), static_cast<const Fp*>(d_w), d_perm, static_cast<const Fp*>(d_group), as_fp(k), *as_fp(beta_mont),
                          *as_fp(gamma_mont), n, n_wires, static_cast<Fp*>(d_z));
-}
+} catch (...) { return uzk::on_exception("uzk_z_poly_device"); }
 
 int uzk_open_quotient_device(const void* d_polys, uint64_t n, uint32_t batch, const uint64_t* z_mont,
-                             const uint64_t* alpha_mont, void* d_q, uint64_t* evals_out) {
+                             const uint64_t* alpha_mont, void* d_q, uint64_t* evals_out) try {
     API_LOCK;
     if (!d_polys || !z_mont || !alpha_mont || !d_q || !evals_out) { set_error("uzk_open_quotient_device: null pointer"); return UZK_ERR_PARAMETER; }
     if (d_q == d_polys) { set_error("uzk_open_quotient_device: output aliases the input"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
     return open_quotient_run(ctx(), static_cast<const Fp*>(d_polys), n, batch, *as_fp(z_mont), *as_fp(alpha_mont),
                              static_cast<Fp*>(d_q), reinterpret_cast<Fp*>(evals_out));
-}
+} catch (...) { return uzk::on_exception("uzk_open_quotient_device"); }
 
 int uzk_open_quotient(const uint64_t* polys, uint64_t n, uint32_t batch, const uint64_t* z_mont, const uint64_t* alpha_mont,
-                      uint64_t* q_out, uint64_t* evals_out) {
+                      uint64_t* q_out, uint64_t* evals_out) try {
     API_LOCK;
     if (!polys || !z_mont || !alpha_mont || !q_out || !evals_out) { set_error("uzk_open_quotient: null pointer"); return UZK_ERR_PARAMETER; }
     if (n == 0 || batch == 0) { set_error("uzk_open_quotient: need batch > 0 and n > 0"); return UZK_ERR_PARAMETER; }
@@ -904,48 +918,48 @@ int uzk_open_quotient(const uint64_t* polys, uint64_t n, uint32_t batch, const u
     UZK_HIP(hipMemcpyAsync(q_out, d_q, (size_t)n * sizeof(Fp), hipMemcpyDeviceToHost, c.stream));
     UZK_HIP(hipStreamSynchronize(c.stream));
     return UZK_OK;
-}
+} catch (...) { return uzk::on_exception("uzk_open_quotient"); }
 
-int uzk_fold_blinds_device(const void* d_coefs, uint64_t len, uint64_t n_fold, void* d_out, uint64_t* blinds_out) {
+int uzk_fold_blinds_device(const void* d_coefs, uint64_t len, uint64_t n_fold, void* d_out, uint64_t* blinds_out) try {
     API_LOCK;
     if (!d_coefs || !d_out || (len > n_fold && !blinds_out)) { set_error("uzk_fold_blinds_device: null pointer"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
     return fold_blinds_run(ctx(), static_cast<const Fp*>(d_coefs), len, n_fold, static_cast<Fp*>(d_out), reinterpret_cast<Fp*>(blinds_out));
-}
+} catch (...) { return uzk::on_exception("uzk_fold_blinds_device"); }
 
 int uzk_poly_lincomb_device(const void* const* d_polys, const uint64_t* lens, const uint64_t* scalars_mont, uint32_t count,
-                            void* d_out, uint64_t out_len) {
+                            void* d_out, uint64_t out_len) try {
     API_LOCK;
     if (!d_polys || !lens || !scalars_mont || (out_len > 0 && !d_out)) { set_error("uzk_poly_lincomb_device: null pointer"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
     return poly_lincomb_run(ctx(), d_polys, lens, as_fp(scalars_mont), count, static_cast<Fp*>(d_out), out_len);
-}
+} catch (...) { return uzk::on_exception("uzk_poly_lincomb_device"); }
 
-int uzk_hide_polynomial_device(void* d_coefs, uint64_t len, const uint64_t* blinds_mont, uint32_t hiding_degree, uint64_t zeroing_degree) {
+int uzk_hide_polynomial_device(void* d_coefs, uint64_t len, const uint64_t* blinds_mont, uint32_t hiding_degree, uint64_t zeroing_degree) try {
     API_LOCK;
     if (!d_coefs || (hiding_degree > 0 && !blinds_mont)) { set_error("uzk_hide_polynomial_device: null pointer"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
     return poly_hide_run(ctx(), static_cast<Fp*>(d_coefs), len, as_fp(blinds_mont), hiding_degree, zeroing_degree);
-}
+} catch (...) { return uzk::on_exception("uzk_hide_polynomial_device"); }
 
 int uzk_hide_polynomial_batch_device(void* d_coefs, uint64_t stride, uint64_t len_in, uint32_t count, const uint64_t* blinds_mont,
-                                     uint32_t hiding_degree, uint64_t zeroing_degree) {
+                                     uint32_t hiding_degree, uint64_t zeroing_degree) try {
     API_LOCK;
     if (count > 0 && hiding_degree > 0 && (!d_coefs || !blinds_mont)) { set_error("uzk_hide_polynomial_batch_device: null pointer"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
     return poly_hide_batch_run(ctx(), static_cast<Fp*>(d_coefs), stride, len_in, count, as_fp(blinds_mont), hiding_degree, zeroing_degree);
-}
+} catch (...) { return uzk::on_exception("uzk_hide_polynomial_batch_device"); }
 
 int uzk_fold_blinds_batch_device(const void* d_polys, uint64_t in_stride, const uint64_t* lens, uint64_t n_fold, uint32_t batch, void* d_out,
-                                 uint64_t out_stride, void* d_tail, uint32_t tail_n, uint64_t* blinds_out) {
+                                 uint64_t out_stride, void* d_tail, uint32_t tail_n, uint64_t* blinds_out) try {
     API_LOCK;
     if (batch > 0 && (!d_polys || !lens || !d_out || (tail_n > 0 && !d_tail))) { set_error("uzk_fold_blinds_batch_device: null pointer"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
     return fold_blinds_batch_run(ctx(), static_cast<const Fp*>(d_polys), in_stride, lens, n_fold, batch, static_cast<Fp*>(d_out), out_stride,
                                  static_cast<Fp*>(d_tail), tail_n, reinterpret_cast<Fp*>(blinds_out));
-}
+} catch (...) { return uzk::on_exception("uzk_fold_blinds_batch_device"); }
 
-int uzk_poly_trimmed_len_device(const void* d_polys, uint64_t stride, const uint64_t* lens, uint32_t batch, uint64_t* out_lens, int sync) {
+int uzk_poly_trimmed_len_device(const void* d_polys, uint64_t stride, const uint64_t* lens, uint32_t batch, uint64_t* out_lens, int sync) try {
     API_LOCK;
     if (batch > 0 && (!d_polys || !lens || !out_lens)) { set_error("uzk_poly_trimmed_len_device: null pointer"); return UZK_ERR_PARAMETER; }
     if (!sync && batch > 0 && !is_pinned_block(out_lens, batch * sizeof(uint64_t))) {
@@ -954,35 +968,35 @@ int uzk_poly_trimmed_len_device(const void* d_polys, uint64_t stride, const uint
     }
     UZK_TRY(require_ready());
     return poly_trimmed_len_run(ctx(), static_cast<const Fp*>(d_polys), stride, lens, batch, out_lens, sync != 0);
-}
+} catch (...) { return uzk::on_exception("uzk_poly_trimmed_len_device"); }
 
 int uzk_split_t_device(const void* d_t, uint64_t t_len, uint64_t chunk, uint32_t n_chunks, const uint64_t* rands_mont, void* d_chunks,
-                       uint64_t chunk_stride, uint64_t* lens_out) {
+                       uint64_t chunk_stride, uint64_t* lens_out) try {
     API_LOCK;
     if (!d_t || !rands_mont || !d_chunks) { set_error("uzk_split_t_device: null pointer"); return UZK_ERR_PARAMETER; }
     if (d_t == d_chunks) { set_error("uzk_split_t_device: output aliases the input"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
     return split_t_run(ctx(), static_cast<const Fp*>(d_t), t_len, chunk, n_chunks, as_fp(rands_mont), static_cast<Fp*>(d_chunks), chunk_stride, lens_out);
-}
+} catch (...) { return uzk::on_exception("uzk_split_t_device"); }
 
 int uzk_poly_eval_ptrs_device(const void* const* d_polys, const uint64_t* lens, const uint32_t* point_idx, uint32_t count,
-                              const uint64_t* points_mont, uint32_t n_points, uint64_t* out) {
+                              const uint64_t* points_mont, uint32_t n_points, uint64_t* out) try {
     API_LOCK;
     if (count > 0 && (!d_polys || !lens || !point_idx || !points_mont || !out)) { set_error("uzk_poly_eval_ptrs_device: null pointer"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
     return poly_eval_ptrs(ctx(), d_polys, lens, point_idx, count, as_fp(points_mont), n_points, reinterpret_cast<Fp*>(out));
-}
+} catch (...) { return uzk::on_exception("uzk_poly_eval_ptrs_device"); }
 
 int uzk_open_quotient_ptrs_device(const void* const* d_polys, const uint64_t* lens, uint32_t count, const uint64_t* z_mont,
-                                  const uint64_t* alpha_mont, void* d_q, uint64_t q_cap, uint64_t* evals_out) {
+                                  const uint64_t* alpha_mont, void* d_q, uint64_t q_cap, uint64_t* evals_out) try {
     API_LOCK;
     if (!d_polys || !lens || !z_mont || !alpha_mont || !d_q) { set_error("uzk_open_quotient_ptrs_device: null pointer"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
     return open_quotient_ptrs(ctx(), d_polys, lens, count, *as_fp(z_mont), *as_fp(alpha_mont), static_cast<Fp*>(d_q), q_cap,
                               reinterpret_cast<Fp*>(evals_out));
-}
+} catch (...) { return uzk::on_exception("uzk_open_quotient_ptrs_device"); }
 
-int uzk_t_quotient_device(const uzk_quotient_args* args, void* d_out, int sync) {
+int uzk_t_quotient_device(const uzk_quotient_args* args, void* d_out, int sync) try {
     API_LOCK;
     if (!args || !d_out) { set_error("uzk_t_quotient_device: null pointer"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
@@ -990,85 +1004,85 @@ int uzk_t_quotient_device(const uzk_quotient_args* args, void* d_out, int sync) 
     UZK_TRY(t_quotient_run(ctx(), args, static_cast<Fp*>(d_out)));
     if (sync) UZK_HIP(hipStreamSynchronize(ctx().stream));
     return UZK_OK;
-}
+} catch (...) { return uzk::on_exception("uzk_t_quotient_device"); }
 
 int uzk_z_poly(const uint64_t* w, const uint32_t* perm, const uint64_t* group, const uint64_t* k, const uint64_t* beta_mont,
-               const uint64_t* gamma_mont, uint32_t n, uint32_t n_wires, uint64_t* z_out) {
+               const uint64_t* gamma_mont, uint32_t n, uint32_t n_wires, uint64_t* z_out) try {
     API_LOCK;
     if (!w || !perm || !group || !k || !beta_mont || !gamma_mont || !z_out) { set_error("uzk_z_poly: null pointer"); return UZK_ERR_PARAMETER; }
     if (n_wires == 0 || n_wires > 8 || (uint64_t)n * n_wires >= (1ull << 32)) { set_error("uzk_z_poly: bad shape"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
     return z_poly_run(ctx(), as_fp(w), perm, as_fp(group), as_fp(k), *as_fp(beta_mont), *as_fp(gamma_mont), n, n_wires,
                       reinterpret_cast<Fp*>(z_out));
-}
+} catch (...) { return uzk::on_exception("uzk_z_poly"); }
 
 /* ---- synthetic workloads ------------------------------------------------------------------ */
-int uzk_synth_points_arith(void* d_points, size_t n, const uint64_t* seed_scalar_mont) {
+int uzk_synth_points_arith(void* d_points, size_t n, const uint64_t* seed_scalar_mont) try {
     API_LOCK;
     if ((n > 0 && !d_points) || !seed_scalar_mont) { set_error("uzk_synth_points_arith: null pointer"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
     return synth_points_arith(ctx(), static_cast<Affine*>(d_points), n, *as_fp(seed_scalar_mont));
-}
-int uzk_synth_points_random(void* d_points, size_t n, uint64_t seed) {
+} catch (...) { return uzk::on_exception("uzk_synth_points_arith"); }
+int uzk_synth_points_random(void* d_points, size_t n, uint64_t seed) try {
     API_LOCK;
     if (n > 0 && !d_points) { set_error("uzk_synth_points_random: null pointer"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
     UZK_TRY(synth_points_random(ctx(), static_cast<Affine*>(d_points), n, seed));
     UZK_HIP(hipStreamSynchronize(ctx().stream));
     return UZK_OK;
-}
-int uzk_synth_scalars(void* d_scalars, size_t n, uint64_t seed) {
+} catch (...) { return uzk::on_exception("uzk_synth_points_random"); }
+int uzk_synth_scalars(void* d_scalars, size_t n, uint64_t seed) try {
     API_LOCK;
     if (n > 0 && !d_scalars) { set_error("uzk_synth_scalars: null pointer"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
     UZK_TRY(synth_scalars(ctx(), static_cast<Fp*>(d_scalars), n, seed));
     UZK_HIP(hipStreamSynchronize(ctx().stream));
     return UZK_OK;
-}
+} catch (...) { return uzk::on_exception("uzk_synth_scalars"); }
 
-int uzk_synth_scalars_mix(void* d_scalars, size_t n, uint64_t seed) {
+int uzk_synth_scalars_mix(void* d_scalars, size_t n, uint64_t seed) try {
     API_LOCK;
     if (n > 0 && !d_scalars) { set_error("uzk_synth_scalars_mix: null pointer"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
     UZK_TRY(synth_scalars_mix(ctx(), static_cast<Fp*>(d_scalars), n, seed));
     UZK_HIP(hipStreamSynchronize(ctx().stream));
     return UZK_OK;
-}
+} catch (...) { return uzk::on_exception("uzk_synth_scalars_mix"); }
 
 /* ---- known-answer entry points (device primitives on host arrays) ------------------------- */
-int uzk_field_op_device(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+int uzk_field_op_device(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) try {
     API_LOCK;
     if (n > 0 && (!a || !b || !out)) { set_error("uzk_field_op_device: null pointer"); return UZK_ERR_PARAMETER; }
     if (field < 0 || field > 1 || op < 0 || op > 27) { set_error("uzk_field_op_device: bad field/op"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
     return field_op_device(ctx(), field, op, as_fp(a), as_fp(b), reinterpret_cast<Fp*>(out), n);
-}
-int uzk_g1_op_device(int op, const uzk_g1_affine* a, const uzk_g1_affine* b, uzk_g1_jac* out, size_t n) {
+} catch (...) { return uzk::on_exception("uzk_field_op_device"); }
+int uzk_g1_op_device(int op, const uzk_g1_affine* a, const uzk_g1_affine* b, uzk_g1_jac* out, size_t n) try {
     API_LOCK;
     if (n > 0 && (!a || !b || !out)) { set_error("uzk_g1_op_device: null pointer"); return UZK_ERR_PARAMETER; }
     if (op < 0 || op > 13) { set_error("uzk_g1_op_device: bad op"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
     return g1_op_device(ctx(), op, reinterpret_cast<const Affine*>(a), reinterpret_cast<const Affine*>(b),
                         reinterpret_cast<Jac*>(out), n);
-}
+} catch (...) { return uzk::on_exception("uzk_g1_op_device"); }
 
 /* ---- measurement -------------------------------------------------------------------------- */
-int uzk_profile_enable(int on) {
+int uzk_profile_enable(int on) try {
     API_LOCK;
     UZK_TRY(require_ready());
     Ctx& c = ctx();
     UZK_TRY(c.prof_collect());
     c.prof_on = on != 0;
     return UZK_OK;
-}
-int uzk_profile_reset(void) {
+} catch (...) { return uzk::on_exception("uzk_profile_enable"); }
+int uzk_profile_reset(void) try {
     API_LOCK;
     Ctx& c = ctx();
     if (c.ready) UZK_TRY(c.prof_collect());
     c.prof_totals.clear();
     return UZK_OK;
-}
-int uzk_profile_get(const char* name, double* total_ms, uint64_t* launches) {
+} catch (...) { return uzk::on_exception("uzk_profile_reset"); }
+int uzk_profile_get(const char* name, double* total_ms, uint64_t* launches) try {
     API_LOCK;
     Ctx& c = ctx();
     if (!name) { set_error("uzk_profile_get: null name"); return UZK_ERR_PARAMETER; }
@@ -1077,8 +1091,8 @@ int uzk_profile_get(const char* name, double* total_ms, uint64_t* launches) {
     if (total_ms) *total_ms = (it == c.prof_totals.end()) ? 0.0 : it->second.first;
     if (launches) *launches = (it == c.prof_totals.end()) ? 0 : it->second.second;
     return UZK_OK;
-}
-int uzk_profile_dump(char* buf, size_t cap) {
+} catch (...) { return uzk::on_exception("uzk_profile_get"); }
+int uzk_profile_dump(char* buf, size_t cap) try {
     API_LOCK;
     Ctx& c = ctx();
     if (!buf || cap == 0) { set_error("uzk_profile_dump: null buffer"); return UZK_ERR_PARAMETER; }
@@ -1092,33 +1106,33 @@ int uzk_profile_dump(char* buf, size_t cap) {
         off += (size_t)w;
     }
     return UZK_OK;
-}
-int uzk_sync(void) {
+} catch (...) { return uzk::on_exception("uzk_profile_dump"); }
+int uzk_sync(void) try {
     API_LOCK;
     UZK_TRY(require_ready());
     UZK_HIP(hipStreamSynchronize(ctx().stream));
     return UZK_OK;
-}
+} catch (...) { return uzk::on_exception("uzk_sync"); }
 void* uzk_stream(void) {
     API_LOCK;
     if (require_ready() != UZK_OK) return nullptr;
     return ctx().stream;
 }
-int uzk_msm_set_window_bits(int c) {
+int uzk_msm_set_window_bits(int c) try {
     API_LOCK;
     if (c != 0 && (c < 4 || c > 22)) { set_error("window bits must be 0 (auto) or 4..22"); return UZK_ERR_PARAMETER; }
     ctx().msm_window_bits = c;
     return UZK_OK;
-}
+} catch (...) { return uzk::on_exception("uzk_msm_set_window_bits"); }
 
-int uzk_msm_plan_info(size_t n, int* window_bits, int* windows) {
+int uzk_msm_plan_info(size_t n, int* window_bits, int* windows) try {
     API_LOCK;
     if (!window_bits || !windows || n == 0) { set_error("uzk_msm_plan_info: bad arguments"); return UZK_ERR_PARAMETER; }
     msm_plan_info(ctx(), n, window_bits, windows);
     return UZK_OK;
-}
+} catch (...) { return uzk::on_exception("uzk_msm_plan_info"); }
 
-int uzk_tune(const char* key, int value) {
+int uzk_tune(const char* key, int value) try {
     API_LOCK;
     if (!key) { set_error("uzk_tune: null key"); return UZK_ERR_PARAMETER; }
     Ctx& c = ctx();
@@ -1158,6 +1172,6 @@ int uzk_tune(const char* key, int value) {
     else if (!std::strcmp(key, "msm_chunk_log")) c.tune_chunk_log = (value >= 8 && value <= 26) ? value : 26;
     else { set_error("uzk_tune: unknown key %s", key); return UZK_ERR_PARAMETER; }
     return UZK_OK;
-}
+} catch (...) { return uzk::on_exception("uzk_tune"); }
 
 }  // extern "C"

@@ -18,6 +18,7 @@
 namespace uzk {
 
 void set_error(const char* fmt, ...);
+int on_exception(const char* fn) noexcept;   // the catch (...) of every extern "C" entry point: message + UZK_ERR_DEVICE
 
 #define UZK_HIP(expr)                                                                      \
     do {                                                                                   \

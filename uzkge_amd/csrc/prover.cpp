@@ -304,7 +304,7 @@ using namespace uzk;
 
 extern "C" {
 
-int uzk_circuit_create(const uzk_circuit_desc* desc, uint64_t* circuit_out) {
+int uzk_circuit_create(const uzk_circuit_desc* desc, uint64_t* circuit_out) try {
     if (!desc || !circuit_out) { set_error("uzk_circuit_create: null pointer"); return UZK_ERR_PARAMETER; }
     const uint32_t n = desc->n;
     if (n < 16 || n > (1u << 20) || (n & (n - 1))) { set_error("uzk_circuit_create: n must be a power of two in 16 .. 2^20 (n = %u)", n); return UZK_ERR_PARAMETER; }
@@ -386,9 +386,9 @@ int uzk_circuit_create(const uzk_circuit_desc* desc, uint64_t* circuit_out) {
     r.circuits[h] = cir;
     *circuit_out = h;
     return UZK_OK;
-}
+} catch (...) { return uzk::on_exception("uzk_circuit_create"); }
 
-int uzk_circuit_update_tables(uint64_t circuit, uint32_t first_slot, uint32_t count, const uint64_t* const* polys, const uint64_t* lens) {
+int uzk_circuit_update_tables(uint64_t circuit, uint32_t first_slot, uint32_t count, const uint64_t* const* polys, const uint64_t* lens) try {
     API_LOCK;
     auto cir = find_circuit(circuit);
     if (!cir) { set_error("uzk_circuit_update_tables: unknown circuit %llu", (unsigned long long)circuit); return UZK_ERR_PARAMETER; }
@@ -396,10 +396,10 @@ int uzk_circuit_update_tables(uint64_t circuit, uint32_t first_slot, uint32_t co
     if (!slot_range_ok(*cir, first_slot, count)) { set_error("uzk_circuit_update_tables: slots %u .. %u of %u", first_slot, first_slot + count, cir->n_slots); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
     return upload_and_install(ctx(), *cir, first_slot, count, polys, lens);
-}
+} catch (...) { return uzk::on_exception("uzk_circuit_update_tables"); }
 
 int uzk_circuit_refresh_tables(uint64_t circuit, uint32_t first_slot, uint32_t count, const uint64_t* evals, uint64_t* polys_out,
-                               uint64_t* lens_out, uint64_t* coset_out, uzk_g1_jac* commitments_out) {
+                               uint64_t* lens_out, uint64_t* coset_out, uzk_g1_jac* commitments_out) try {
     API_LOCK;
     auto cir = find_circuit(circuit);
     if (!cir) { set_error("uzk_circuit_refresh_tables: unknown circuit %llu", (unsigned long long)circuit); return UZK_ERR_PARAMETER; }
@@ -424,10 +424,10 @@ int uzk_circuit_refresh_tables(uint64_t circuit, uint32_t first_slot, uint32_t c
     if (polys_out || coset_out) UZK_HIP(hipStreamSynchronize(c.stream));
     if (lens_out) std::memcpy(lens_out, lens.data(), (size_t)count * sizeof(uint64_t));
     return UZK_OK;
-}
+} catch (...) { return uzk::on_exception("uzk_circuit_refresh_tables"); }
 
 int uzk_preprocess_tables(uint64_t lagrange_srs, uint32_t n, uint32_t count, const uint64_t* evals, const uint64_t* k1_mont, uint64_t* polys_out,
-                          uint64_t* lens_out, uint64_t* coset_out, uzk_g1_jac* commitments_out) {
+                          uint64_t* lens_out, uint64_t* coset_out, uzk_g1_jac* commitments_out) try {
     API_LOCK;
     if (!evals || (coset_out && !k1_mont)) { set_error("uzk_preprocess_tables: null pointer"); return UZK_ERR_PARAMETER; }
     if (n < 2 || n > (1u << 24) || (n & (n - 1)) || count == 0 || count > 4096) { set_error("uzk_preprocess_tables: n must be a power of two in 2 .. 2^24, 1 <= count <= 4096"); return UZK_ERR_PARAMETER; }
@@ -455,9 +455,9 @@ int uzk_preprocess_tables(uint64_t lagrange_srs, uint32_t n, uint32_t count, con
     UZK_HIP(hipStreamSynchronize(c.stream));
     if (lens_out) std::memcpy(lens_out, lens.data(), (size_t)count * sizeof(uint64_t));
     return UZK_OK;
-}
+} catch (...) { return uzk::on_exception("uzk_preprocess_tables"); }
 
-int uzk_circuit_table(uint64_t circuit, uint32_t slot, int which, const void** d_out, uint64_t* len_out) {
+int uzk_circuit_table(uint64_t circuit, uint32_t slot, int which, const void** d_out, uint64_t* len_out) try {
     auto cir = find_circuit(circuit);
     if (!cir || !d_out || slot >= cir->n_slots || (which != 0 && which != 1)) { set_error("uzk_circuit_table: bad arguments"); return UZK_ERR_PARAMETER; }
     std::lock_guard<std::mutex> lk(cir->mu);
@@ -465,9 +465,9 @@ int uzk_circuit_table(uint64_t circuit, uint32_t slot, int which, const void** d
     *d_out = which ? static_cast<const void*>(s.coset) : static_cast<const void*>(s.poly);
     if (len_out) *len_out = which ? cir->m : s.len;
     return UZK_OK;
-}
+} catch (...) { return uzk::on_exception("uzk_circuit_table"); }
 
-int uzk_circuit_release(uint64_t circuit) {
+int uzk_circuit_release(uint64_t circuit) try {
     API_LOCK;
     std::shared_ptr<Circuit> cir;
     {
@@ -482,9 +482,9 @@ int uzk_circuit_release(uint64_t circuit) {
     if (c.ready) { (void)hipSetDevice(c.device); (void)hipStreamSynchronize(c.stream); }
     release_circuit_srs(*cir);
     return UZK_OK;                                                 // tables and the fixed block go with the last reference
-}
+} catch (...) { return uzk::on_exception("uzk_circuit_release"); }
 
-int uzk_prover_create(uint32_t n, uint32_t batch, uint64_t* prover_out) {
+int uzk_prover_create(uint32_t n, uint32_t batch, uint64_t* prover_out) try {
     API_LOCK;
     if (!prover_out) { set_error("uzk_prover_create: null pointer"); return UZK_ERR_PARAMETER; }
     if (n < 16 || n > (1u << 20) || (n & (n - 1)) || batch == 0 || batch > kMaxBatch) {
@@ -520,9 +520,9 @@ int uzk_prover_create(uint32_t n, uint32_t batch, uint64_t* prover_out) {
     r.provers[h] = p;
     *prover_out = h;
     return UZK_OK;
-}
+} catch (...) { return uzk::on_exception("uzk_prover_create"); }
 
-int uzk_prover_destroy(uint64_t prover) {
+int uzk_prover_destroy(uint64_t prover) try {
     API_LOCK;
     std::shared_ptr<Prover> p;
     {
@@ -537,9 +537,9 @@ int uzk_prover_destroy(uint64_t prover) {
     if (c.ready) { (void)hipSetDevice(c.device); (void)hipStreamSynchronize(c.stream); }
     std::lock_guard<std::mutex> lk(p->mu);                         // a round in flight on another thread finishes first
     return UZK_OK;
-}
+} catch (...) { return uzk::on_exception("uzk_prover_destroy"); }
 
-int uzk_prover_buffer(uint64_t prover, int which, void** d_out, uint64_t* elems_out) {
+int uzk_prover_buffer(uint64_t prover, int which, void** d_out, uint64_t* elems_out) try {
     auto pp = find_prover(prover);
     if (!pp || !d_out || !elems_out) { set_error("uzk_prover_buffer: bad arguments"); return UZK_ERR_PARAMETER; }
     Prover& p = *pp;
@@ -558,12 +558,12 @@ int uzk_prover_buffer(uint64_t prover, int which, void** d_out, uint64_t* elems_
         default: set_error("uzk_prover_buffer: which = %d", which); return UZK_ERR_PARAMETER;
     }
     return UZK_OK;
-}
+} catch (...) { return uzk::on_exception("uzk_prover_buffer"); }
 
 /* ---- round 1 (prover.rs:151-192) ----------------------------------------------------------------------------------------- */
 int uzk_prove_round1(uint64_t prover, uint64_t circuit, const void* witness, const void* wsel, int inputs_on_device,
                      const uint32_t* pi_index, const uint64_t* pi_value, uint32_t pi_count, const uint32_t* hiding,
-                     const uint64_t* blinds, uzk_g1_jac* cm_out) {
+                     const uint64_t* blinds, uzk_g1_jac* cm_out) try {
     API_LOCK;
     auto pp = find_prover(prover);
     auto cir = find_circuit(circuit);
@@ -654,10 +654,10 @@ int uzk_prove_round1(uint64_t prover, uint64_t circuit, const void* witness, con
     std::memcpy(cm_out, cm.data(), cm.size() * sizeof(Jac));
     p.round = 1;
     return UZK_OK;
-}
+} catch (...) { return uzk::on_exception("uzk_prove_round1"); }
 
 /* ---- round 2 (prover.rs:194-209) ----------------------------------------------------------------------------------------- */
-int uzk_prove_round2(uint64_t prover, const uint64_t* beta, const uint64_t* gamma, const uint64_t* blinds_z, uzk_g1_jac* cm_z_out) {
+int uzk_prove_round2(uint64_t prover, const uint64_t* beta, const uint64_t* gamma, const uint64_t* blinds_z, uzk_g1_jac* cm_z_out) try {
     API_LOCK;
     auto pp = find_prover(prover);
     if (!pp) { set_error("uzk_prove_round2: unknown prover"); return UZK_ERR_PARAMETER; }
@@ -687,10 +687,10 @@ int uzk_prove_round2(uint64_t prover, const uint64_t* beta, const uint64_t* gamm
     std::memcpy(cm_z_out, cm.data(), cm.size() * sizeof(Jac));
     p.round = 2;
     return UZK_OK;
-}
+} catch (...) { return uzk::on_exception("uzk_prove_round2"); }
 
 /* ---- round 3 (prover.rs:211-239) ----------------------------------------------------------------------------------------- */
-int uzk_prove_round3(uint64_t prover, const uint64_t* alpha, const uint64_t* t_rands, uzk_g1_jac* cm_t_out) {
+int uzk_prove_round3(uint64_t prover, const uint64_t* alpha, const uint64_t* t_rands, uzk_g1_jac* cm_t_out) try {
     API_LOCK;
     auto pp = find_prover(prover);
     if (!pp) { set_error("uzk_prove_round3: unknown prover"); return UZK_ERR_PARAMETER; }
@@ -763,10 +763,10 @@ int uzk_prove_round3(uint64_t prover, const uint64_t* alpha, const uint64_t* t_r
     std::memcpy(cm_t_out, cm.data(), cm.size() * sizeof(Jac));
     p.round = 3;
     return UZK_OK;
-}
+} catch (...) { return uzk::on_exception("uzk_prove_round3"); }
 
 /* ---- round 4 (prover.rs:241-273) ----------------------------------------------------------------------------------------- */
-int uzk_prove_round4(uint64_t prover, const uint64_t* zeta, uint64_t* evals_out) {
+int uzk_prove_round4(uint64_t prover, const uint64_t* zeta, uint64_t* evals_out) try {
     API_LOCK;
     auto pp = find_prover(prover);
     if (!pp) { set_error("uzk_prove_round4: unknown prover"); return UZK_ERR_PARAMETER; }
@@ -805,11 +805,11 @@ int uzk_prove_round4(uint64_t prover, const uint64_t* zeta, uint64_t* evals_out)
     }
     p.round = 4;
     return UZK_OK;
-}
+} catch (...) { return uzk::on_exception("uzk_prove_round4"); }
 
 /* ---- round 5 (prover.rs:296-372) ----------------------------------------------------------------------------------------- */
 int uzk_prove_round5(uint64_t prover, const uint64_t* r_scalars, const uint64_t* alpha_zeta, const uint64_t* alpha_zeta_omega,
-                     uzk_g1_jac* openings_out) {
+                     uzk_g1_jac* openings_out) try {
     API_LOCK;
     auto pp = find_prover(prover);
     if (!pp) { set_error("uzk_prove_round5: unknown prover"); return UZK_ERR_PARAMETER; }
@@ -891,6 +891,6 @@ int uzk_prove_round5(uint64_t prover, const uint64_t* r_scalars, const uint64_t*
     p.snap.reset();
     p.circuit.reset();
     return UZK_OK;
-}
+} catch (...) { return uzk::on_exception("uzk_prove_round5"); }
 
 }  // extern "C"
