@@ -311,14 +311,9 @@ def dry_run_rank(args, rank, world, dist, np) -> None:
     one_q = np.array([0xd35d438dc58f0d9d, 0x0a78eb28f5c70b3d, 0x666ea36f7879462c, 0x0e0a77c19a07df2f], dtype=np.uint64)
     two_q = np.array([0xa6ba871b8b1e1b3a, 0x14f1d651eb8e167b, 0xccdd46def0f28c58, 0x1c14ef83340fbe5e], dtype=np.uint64)
     g = np.concatenate([one_q, two_q, one_q])                      # G = (1, 2, 1) in Montgomery form
+    from uzkge_amd.sharded import ShardedCommitter
     part = b.g1_fold(np.stack([g] * (rank + 1)))
-    send = torch.from_numpy(part.view(np.uint8).copy())
-    recv = torch.zeros(96 * world, dtype=torch.uint8)
-    if world > 1:
-        dist.all_gather_into_tensor(recv, send)
-    else:
-        recv.copy_(send)
-    total = b.g1_fold(recv.numpy().view(np.uint64).reshape(world, 12))
+    total = ShardedCommitter(None).exchange(part)                  # the product's exchange: all-gather + fold on every rank
     aff = b.g1_to_affine(total)
     # the proofs-per-device extra of a real N > 1 run: every rank reports its own rate, rank 0 prints the sum (here: 100 (r + 1))
     proofs = _gather_proofs(dist, world, {"rank": rank, "proofs_per_s": 100.0 * (rank + 1)})
@@ -398,26 +393,13 @@ def run_rank(args) -> None:
     else:
         b.synth_scalars(sc.data_ptr(), n, seed ^ 0x5CA1AB1E)
     srs = b.Srs.from_device(pts.data_ptr(), n)
-    gather_in = torch.zeros(96, dtype=torch.uint8, device=coll_dev)
-    gather_out = torch.zeros(96 * world, dtype=torch.uint8, device=coll_dev)
-
-    split = {"msm_s": 0.0, "exchange_s": 0.0}     # where a step's time goes on THIS rank (wall clock, accumulated over the steps)
+    # the product's sharded commit (uzkge_amd/sharded.py): this rank's MSM, the 96-byte all-gather over RCCL / xGMI, the fold
+    # of the N partial sums on every rank; it keeps the two wall clocks that say where a step's time goes on THIS rank
+    from uzkge_amd.sharded import ShardedCommitter
+    committer = ShardedCommitter(srs, device=dev, force_collective=use_dist)
 
     def step():
-        # the rank's partial sum arrives in host memory (the window sums are combined there); the exchange is
-        # the 96-byte all-gather over RCCL / xGMI and every rank folds the N partials
-        t_a = time.perf_counter()
-        part = b.msm_device(srs, sc.data_ptr(), n)
-        t_b = time.perf_counter()
-        split["msm_s"] += t_b - t_a
-        if not use_dist:
-            return part
-        gather_in.copy_(torch.from_numpy(part.view(np.uint8)))
-        dist.all_gather_into_tensor(gather_out, gather_in)
-        allp = gather_out.cpu().numpy().view(np.uint64).reshape(world, 12)
-        res = b.g1_fold(allp)
-        split["exchange_s"] += time.perf_counter() - t_b      # includes waiting for the slowest rank's partial
-        return res
+        return committer.commit_device(sc.data_ptr(), n)
 
     def fence():
         b.sync()
@@ -445,7 +427,7 @@ def run_rank(args) -> None:
         step()
     b.profile_reset()
     b.profile_enable(True)
-    split["msm_s"] = split["exchange_s"] = 0.0
+    committer.reset_clocks()
     sampler = _ClockSampler(local_rank).start() if rank == 0 else None
     t_local = time.perf_counter()
     elapsed, result = timed_steps(step, args.steps)
@@ -455,8 +437,8 @@ def run_rank(args) -> None:
     prof = b.profile_table()
     # per-rank view of the timed region, so that a multi-GPU run explains itself: every rank's ms per step, its MSM share and
     # its exchange share (all-gather of the 96-byte partials + fold; expected << 0.1 ms, i.e. flat weak scaling)
-    mine = {"rank": rank, "ms_per_step": round(local_elapsed / args.steps * 1e3, 4), "msm_ms_per_step": round(split["msm_s"] / args.steps * 1e3, 4),
-            "exchange_ms_per_step": round(split["exchange_s"] / args.steps * 1e3, 4)}
+    mine = {"rank": rank, "ms_per_step": round(local_elapsed / args.steps * 1e3, 4), "msm_ms_per_step": round(committer.msm_s / args.steps * 1e3, 4),
+            "exchange_ms_per_step": round(committer.exchange_s / args.steps * 1e3, 4)}
     per_rank = [mine]
     if use_dist:
         objs = [None] * world
@@ -543,10 +525,7 @@ def run_rank(args) -> None:
         m5 = (1 << 26) // world
 
         def step5():
-            part = b.msm_device(srs, sc.data_ptr(), m5)
-            gather_in.copy_(torch.from_numpy(part.view(np.uint8)))
-            dist.all_gather_into_tensor(gather_out, gather_in)
-            return b.g1_fold(gather_out.cpu().numpy().view(np.uint64).reshape(world, 12))
+            return committer.commit_device(sc.data_ptr(), m5)
         step5()
         el5, _ = timed_steps(step5, max(3, args.steps // 2))
         extra["strong_2p26"] = {"what": "BASELINE config #5: 2^26 points in total, point-chunk sharded over the ranks, "

@@ -1,6 +1,6 @@
-"""Multi-GPU path on CPU: world_size-2 gloo rendezvous of the exact exchange bench.py performs
-(all_gather of each rank's 96-byte Jacobian partial, then a local fold through the C ABI's
-host-side `uzk_g1_fold`).  The partials come from the oracle here (no GPU); on the GPU box the
+"""Multi-GPU path on CPU: world_size-2 / -3 gloo rendezvous of the product's sharded commit
+(uzkge_amd/sharded.py, the class bench.py --gpus N runs: all_gather of each rank's 96-byte Jacobian partial,
+then a local fold through the C ABI's host-side `uzk_g1_fold`).  The partials come from the oracle here (no GPU); on the GPU box the
 same code path runs with RCCL and partials from `uzk_msm_g1_device`."""
 import os
 import socket
@@ -37,11 +37,12 @@ def _worker(rank, world, port, n, q):
     scal = rand_fr_wire(n, 4242)
     lo, hi = rank * n // world, (rank + 1) * n // world          # contiguous point chunk per rank
     part = oc.msm_pippenger(wire[lo:hi], scal[lo:hi], 0, 1)      # stand-in for the rank's GPU partial
-    send = torch.from_numpy(part.view(np.uint8).copy())
-    recv = torch.zeros(96 * world, dtype=torch.uint8)
-    dist.all_gather_into_tensor(recv, send)
-    allp = recv.numpy().view(np.uint64).reshape(world, 12)
-    folded = b.g1_fold(allp)                                       # product code: C ABI host fold
+    from uzkge_amd.sharded import ShardedCommitter, chunk_bounds
+    assert (lo, hi) == chunk_bounds(n, rank, world)
+    sc = ShardedCommitter(None)                                    # product code: all-gather of the partials + C ABI host fold
+    assert (sc.world, sc.rank, sc.backend, sc.exchanging) == (world, rank, "gloo", True)
+    folded = sc.exchange(part)
+    assert sc.exchange_s > 0.0
     q.put((rank, oc.jac_to_affine_ints(folded)))
     dist.barrier()
     dist.destroy_process_group()
