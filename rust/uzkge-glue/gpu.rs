@@ -4,6 +4,8 @@
 //!   * `commit`  replaces `normalize_batch` + `G1Projective::msm`   (poly_commit/kzg_poly_commitment.rs:287-290)
 //!   * `fft`     replaces `domain.fft(..)` / `domain.ifft(..)`      (poly_commit/field_polynomial.rs:585, 595)
 //!     and fuses the serial `mul_var` of the coset pair                 (field_polynomial.rs:589-591, 601-607)
+//!   * `preprocess_tables`  one indexer step's tables (iFFT, coset FFT over the quotient domain, Lagrange commit) as one
+//!     device call                                                      (plonk/indexer.rs:316-470)
 //!
 //! Both return `None` when the device cannot serve the call (no GPU, a HIP failure, out of device memory, a field that is
 //! not BN254's Fr): the caller then takes the arkworks path it always had.  Nothing here panics on a device error -- the
@@ -24,6 +26,7 @@ use lazy_static::lazy_static;
 use uzkge_gpu_sys as sys;
 
 use crate::errors::UzkgeError;
+use crate::poly_commit::{field_polynomial::FpPolynomial, pcs::PolyComScheme};
 
 pub(crate) fn map_err(e: sys::Error) -> UzkgeError {
     match e {
@@ -232,4 +235,40 @@ pub fn fft<F: PrimeField, E: EvaluationDomain<F>>(domain: &E, input: &[F], inver
         return None; // UZK_ERR_DEVICE (or an unsupported size): arkworks computes the same vector
     }
     Some(from_fr_vec(buf.into_iter().map(fr_from_limbs).collect()))
+}
+
+/// What the indexer keeps of one table: its polynomial, its coset evaluations over the quotient domain, its commitment.
+pub type TableTriple<PCS> = (FpPolynomial<<PCS as PolyComScheme>::Field>, Vec<<PCS as PolyComScheme>::Field>, <PCS as PolyComScheme>::Commitment);
+
+/// The per-table loop of one indexer step (plonk/indexer.rs:316-470: `ifft_with_domain`, `coset_fft_with_domain(&domain_m, &k[1])`,
+/// the Lagrange branch of the `commit` closure) for `evals.len()` tables as ONE device call (`uzk_preprocess_tables`), in order.
+/// `commit == false` (verifier parameters were handed in): the commitments are `Default`, as the reference leaves them.
+/// `None` = not BN254 KZG with a Lagrange SRS of this size, other roots of unity than the library's, or no device: the caller's
+/// loop runs on the CPU.
+pub fn preprocess_tables<PCS: PolyComScheme>(
+    lagrange_pcs: Option<&PCS>, root: &PCS::Field, root_m: &PCS::Field, k1: &PCS::Field, evals: &[&[PCS::Field]], commit: bool,
+) -> Option<Vec<TableTriple<PCS>>> {
+    let lagrange = &lagrange_pcs?.as_kzg_bn254()?.public_parameter_group_1;
+    let n = lagrange.len();
+    if n < 2 || evals.is_empty() || evals.iter().any(|e| e.len() != n) {
+        return None;
+    }
+    let scalars = as_fr_slice(&[*root, *root_m, *k1])?.to_vec();
+    if !same_generator(n as u64, &scalars[0]) || !same_generator(6 * n as u64, &scalars[1]) {
+        return None; // the coefficient forms and coset evaluations come back in the library's enumeration of the two domains
+    }
+    let srs = resident_srs(lagrange).ok()?;
+    let mut flat: Vec<[u64; 4]> = Vec::with_capacity(evals.len() * n);
+    for e in evals {
+        flat.extend(as_fr_slice(e)?.iter().map(fr_limbs));
+    }
+    let (polys, lens, coset, cms) = srs.preprocess_tables(&flat, n, &fr_limbs(&scalars[2]), commit).ok()?;
+    let field_of = |l: &[[u64; 4]]| from_fr_vec::<PCS::Field>(l.iter().map(|x| fr_from_limbs(*x)).collect());
+    let mut out = Vec::with_capacity(evals.len());
+    for t in 0..evals.len() {
+        let cm = if commit { PCS::commitment_from_g1(jac_from_wire(cms.get(t)?))? } else { PCS::Commitment::default() };
+        let len = (*lens.get(t)? as usize).min(n);
+        out.push((FpPolynomial::from_coefs(field_of(&polys[t * n..t * n + len])), field_of(&coset[t * 6 * n..(t + 1) * 6 * n]), cm));
+    }
+    Some(out)
 }

@@ -83,6 +83,29 @@ impl Srs {
     }
 }
 
+impl Srs {
+    /// The indexer's per-table loop without a circuit (`uzk_preprocess_tables`): `evals.len() / n` evaluation vectors of n elements
+    /// -> (coefficient forms: n each, zero padded; their trimmed lengths; coset evaluations over the 6n domain shifted by `k1`:
+    /// 6n each; the commitments over this Lagrange SRS of n bases, empty unless `want_commit`).
+    #[allow(clippy::type_complexity)]
+    pub fn preprocess_tables(&self, evals: &[[u64; 4]], n: usize, k1: &[u64; 4], want_commit: bool) -> Result<(Vec<[u64; 4]>, Vec<u64>, Vec<[u64; 4]>, Vec<uzk_g1_jac>), Error> {
+        if n == 0 || evals.is_empty() || evals.len() % n != 0 || n > u32::MAX as usize {
+            return Err(Error::Parameter);
+        }
+        let count = evals.len() / n;
+        let mut polys = vec![[0u64; 4]; evals.len()];
+        let mut lens = vec![0u64; count];
+        let mut coset = vec![[0u64; 4]; 6 * evals.len()];
+        let mut cms = vec![uzk_g1_jac::default(); if want_commit { count } else { 0 }];
+        let cms_ptr = if want_commit { cms.as_mut_ptr() } else { std::ptr::null_mut() };
+        check(unsafe {
+            uzk_preprocess_tables(self.handle, n as u32, count as u32, evals.as_ptr() as *const u64, k1.as_ptr(), polys.as_mut_ptr() as *mut u64, lens.as_mut_ptr(),
+                                  coset.as_mut_ptr() as *mut u64, cms_ptr)
+        })?;
+        Ok((polys, lens, coset, cms))
+    }
+}
+
 impl Drop for Srs {
     fn drop(&mut self) {
         unsafe { uzk_srs_release(self.handle) };

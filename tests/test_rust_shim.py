@@ -171,11 +171,13 @@ def test_patch_targets_the_cited_call_sites():
     assert "super::gpu_prover::prove(" in patch and "fn as_kzg_bn254" in patch and "fn commitment_from_g1" in patch
     assert "pub(super) fn r_poly_or_comm" in patch and "mod gpu_prover;" in patch
     assert "uzkge::plonk::gpu_refresh_public_key(" in patch and 'gpu = ["uzkge/gpu"]' in patch          # the refresh loop's device hook
+    # the indexer's six per-table steps each ask the device once (and fall through to their CPU code on None)
+    assert patch.count("crate::gpu::preprocess_tables(") == 1 and patch.count("gpu_tables(") == 6 and patch.count("let gpu_tables = ") == 2
     added = "\n".join(l for l in patch.splitlines() if l.startswith("+") and not l.startswith("+++"))
     assert "panic!" not in added and ".unwrap()" not in added
 
 
-PATCHED = ("Cargo.toml", "shuffle/Cargo.toml", "shuffle/src/gen_params/params.rs", "uzkge/Cargo.toml", "uzkge/src/lib.rs", "uzkge/src/plonk/mod.rs", "uzkge/src/plonk/helpers.rs", "uzkge/src/plonk/prover.rs",
+PATCHED = ("Cargo.toml", "shuffle/Cargo.toml", "shuffle/src/gen_params/params.rs", "uzkge/Cargo.toml", "uzkge/src/lib.rs", "uzkge/src/plonk/mod.rs", "uzkge/src/plonk/helpers.rs", "uzkge/src/plonk/prover.rs", "uzkge/src/plonk/indexer.rs",
            "uzkge/src/poly_commit/pcs.rs", "uzkge/src/poly_commit/kzg_poly_commitment.rs", "uzkge/src/poly_commit/field_polynomial.rs")
 
 

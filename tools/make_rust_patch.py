@@ -55,6 +55,70 @@ EDITS = {
          '        params\n            .prover_params\n            .verifier_params\n            .cm_shuffle_public_key_vec = cms;\n'
          '        return Ok(res);\n    }\n'),
     ],
+    # The indexer's six per-table steps (indexer.rs:316-470) each as one device call.  `gpu_tables` is defined for both settings of the
+    # feature (without it: always None), so the six hook sites are ordinary code that both builds type-check.
+    "uzkge/src/plonk/indexer.rs": [
+        ('    // Step 1: compute permutation polynomials and commit them.\n',
+         '    // MI355X: the per-table loop of each step below (iFFT, coset FFT over the quotient domain, Lagrange commit) as ONE device\n'
+         '    // call per step; `None` = not BN254 KZG over a Lagrange SRS of this size, or no device: the step\'s CPU code runs as before.\n'
+         '    #[cfg(feature = "gpu")]\n'
+         '    let gpu_tables = |evals: &[&[PCS::Field]]| {\n'
+         '        crate::gpu::preprocess_tables(\n            lagrange_pcs,\n            &domain.group_gen,\n            &domain_m.group_gen,\n'
+         '            &k[1],\n            evals,\n            no_verifier,\n        )\n    };\n'
+         '    #[cfg(not(feature = "gpu"))]\n'
+         '    let gpu_tables = |_evals: &[&[PCS::Field]]| -> Option<\n        Vec<(\n            FpPolynomial<PCS::Field>,\n            Vec<PCS::Field>,\n            PCS::Commitment,\n        )>,\n    > { None };\n\n'
+         '    // Step 1: compute permutation polynomials and commit them.\n'),
+        ('    let mut cm_s_vec = vec![];\n    for i in 0..n_wires_per_gate {\n',
+         '    let mut cm_s_vec = vec![];\n'
+         '    let mut s_on_device = gpu_tables(\n        &(0..n_wires_per_gate)\n            .map(|i| &encoded_perm[i * n..(i + 1) * n])\n            .collect::<Vec<_>>(),\n    )\n    .map(|t| t.into_iter());\n'
+         '    for i in 0..n_wires_per_gate {\n'
+         '        if let Some((s_coefs, coset, cm_s)) = s_on_device.as_mut().and_then(|t| t.next()) {\n'
+         '            s_coset_evals[i].extend(coset);\n            if no_verifier {\n                cm_s_vec.push(cm_s);\n            }\n'
+         '            s_polys.push(s_coefs);\n            continue;\n        }\n'),
+        ('    let mut cm_q_vec = vec![];\n    for (i, q_coset_eval) in q_coset_evals.iter_mut().enumerate() {\n',
+         '    let mut cm_q_vec = vec![];\n'
+         '    let mut q_on_device = {\n        let mut selectors = Vec::with_capacity(CS::num_selectors());\n'
+         '        for i in 0..CS::num_selectors() {\n            selectors.push(cs.selector(i)?);\n        }\n'
+         '        gpu_tables(&selectors).map(|t| t.into_iter())\n    };\n'
+         '    for (i, q_coset_eval) in q_coset_evals.iter_mut().enumerate() {\n'
+         '        if let Some((q_coefs, coset, cm_q)) = q_on_device.as_mut().and_then(|t| t.next()) {\n'
+         '            q_coset_eval.extend(coset);\n            if no_verifier {\n                cm_q_vec.push(cm_q);\n            }\n'
+         '            q_polys.push(q_coefs);\n            continue;\n        }\n'),
+        ('            qb[*i] = PCS::Field::one();\n        }\n',
+         '            qb[*i] = PCS::Field::one();\n        }\n'
+         '        let qb_on_device = gpu_tables(&[qb.as_slice()]).and_then(|t| t.into_iter().next());\n'
+         '        if let Some((qb_coef, qb_coset_eval, cm_qb)) = qb_on_device {\n'
+         '            (qb_coset_eval, qb_coef, cm_qb)\n        } else {\n'),
+        ('        (qb_coset_eval, qb_coef, cm_qb)\n    };\n',
+         '        (qb_coset_eval, qb_coef, cm_qb)\n        }\n    };\n'),
+        ('        let q_prk_evals = cs.compute_anemoi_jive_selectors().to_vec();\n',
+         '        let q_prk_evals = cs.compute_anemoi_jive_selectors().to_vec();\n'
+         '        let on_device = gpu_tables(&q_prk_evals.iter().map(|p| p.as_slice()).collect::<Vec<_>>());\n'
+         '        if let Some(tables) = on_device {\n'
+         '            let (mut coset_evals, mut polys, mut cms) = (vec![], vec![], vec![]);\n'
+         '            for (poly, coset_eval, cm) in tables {\n                coset_evals.push(coset_eval);\n                polys.push(poly);\n'
+         '                if no_verifier {\n                    cms.push(cm);\n                }\n            }\n'
+         '            (coset_evals, polys, cms)\n        } else {\n'),
+        ('        (q_prk_coset_evals, q_prk_polys, cm_prk_vec)\n    };\n',
+         '        (q_prk_coset_evals, q_prk_polys, cm_prk_vec)\n        }\n    };\n'),
+        ('                q_ecc[*i + j] = PCS::Field::one();\n            }\n        }\n',
+         '                q_ecc[*i + j] = PCS::Field::one();\n            }\n        }\n'
+         '        let q_ecc_on_device = gpu_tables(&[q_ecc.as_slice()]).and_then(|t| t.into_iter().next());\n'
+         '        if let Some((q_ecc_coef, q_ecc_coset_eval, cm_q_ecc)) = q_ecc_on_device {\n'
+         '            (q_ecc_coset_eval, q_ecc_coef, cm_q_ecc)\n        } else {\n'),
+        ('        (q_ecc_coset_eval, q_ecc_coef, cm_q_ecc)\n    };\n',
+         '        (q_ecc_coset_eval, q_ecc_coef, cm_q_ecc)\n        }\n    };\n'),
+        ('        let q_shuffle_generator_evals = cs.compute_shuffle_generator_selectors();\n',
+         '        let q_shuffle_generator_evals = cs.compute_shuffle_generator_selectors();\n'
+         '        let on_device = gpu_tables(\n            &q_shuffle_generator_evals\n                .iter()\n                .map(|p| p.as_slice())\n                .collect::<Vec<_>>(),\n        );\n'
+         '        if let Some(tables) = on_device {\n'
+         '            let (mut coset_evals, mut polys, mut cms) = (vec![], vec![], vec![]);\n'
+         '            for (poly, coset_eval, cm) in tables {\n                coset_evals.push(coset_eval);\n                polys.push(poly);\n'
+         '                if no_verifier {\n                    cms.push(cm);\n                }\n            }\n'
+         '            (coset_evals, polys, cms)\n        } else {\n'),
+        ('            cm_shuffle_generator_vec,\n        )\n    };\n',
+         '            cm_shuffle_generator_vec,\n        )\n        }\n    };\n'),
+    ],
     "uzkge/src/plonk/helpers.rs": [
         ('fn r_poly_or_comm<F: PrimeField, PCSType: HomomorphicPolyComElem<Scalar = F>>(',
          'pub(super) fn r_poly_or_comm<F: PrimeField, PCSType: HomomorphicPolyComElem<Scalar = F>>('),
