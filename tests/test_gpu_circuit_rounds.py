@@ -358,6 +358,39 @@ def test_preprocess_tables_without_a_circuit(gpu):
         srs.release()
 
 
+def test_preprocess_tables_in_the_shapes_of_the_indexers_steps(gpu):
+    """What the Rust hook in uzkge/src/plonk/indexer.rs does (rust/uzkge-glue/gpu.rs preprocess_tables): one call per step with
+    5, 9, 1, 4, 1 and 12 tables -- boolean selector vectors (qb, q_ecc: a handful of ones), an all-zero vector (an unused
+    selector trims to the zero polynomial) -- and, when verifier parameters were handed in, no commitments and no SRS handle."""
+    b = gpu
+    n = 4096
+    wire, _ = load_srs("lagrange-srs-4096.bin")
+    srs = b.Srs.from_host(wire)
+    k1 = rand_fr_wire(1, 91)[0]
+    one = np.frombuffer(opy.to_mont(1, opy.R).to_bytes(32, "little"), dtype=np.uint64)
+    try:
+        for step, count in enumerate((5, 9, 1, 4, 1, 12)):
+            evals = rand_fr_wire(count * n, 100 + step).reshape(count, n, 4)
+            if count == 1:                                   # indicator vectors: ones on a few rows
+                evals[:] = 0
+                evals[0, [3, 17, 1000, n - 1]] = one
+            if count == 9:
+                evals[4] = 0                                 # the zero polynomial
+            polys, lens, coset, cms = b.preprocess_tables_device(srs, evals, k1=k1, want_coset=True)
+            polys2, lens2, coset2, none = b.preprocess_tables_device(None, evals, k1=k1, want_coset=True, want_commit=False)
+            assert none is None and np.array_equal(polys, polys2) and np.array_equal(lens, lens2) and np.array_equal(coset, coset2)
+            for t in range(count):
+                want = oc.ntt(np.ascontiguousarray(evals[t]), inverse=True)
+                assert np.array_equal(polys[t], want), (step, t)
+                nz = np.nonzero(want.any(axis=1))[0]
+                assert int(lens[t]) == (int(nz[-1]) + 1 if nz.size else 0), (step, t)
+                pad = np.zeros((6 * n, 4), dtype=np.uint64); pad[:n] = want
+                assert np.array_equal(coset[t], oc.ntt(oc.mul_var(pad, k1), threads=4)), (step, t)
+                assert affine_of(cms[t]) == oc.jac_to_affine_ints(oc.msm_pippenger(wire, np.ascontiguousarray(evals[t]), 0, 4)), (step, t)
+    finally:
+        srs.release()
+
+
 def test_provers_on_several_contexts_while_the_tables_are_being_swapped(gpu):
     """Three prover threads (one context and one prover each, one shared circuit) prove in a loop while the main thread keeps
     swapping the twelve public-key tables between two sets: every proof must be, as a whole, the proof of set A or the proof of

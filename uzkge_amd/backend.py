@@ -611,16 +611,17 @@ class Circuit:
             self.handle = 0
 
 
-def preprocess_tables_device(srs: Srs, evals: np.ndarray, k1=None, want_coset: bool = False):
-    """uzk_preprocess_tables: [count, n, 4] evaluation vectors -> (polys [count, n, 4], lens, coset [count, 6n, 4] | None, commitments [count, 12])."""
+def preprocess_tables_device(srs: Srs, evals: np.ndarray, k1=None, want_coset: bool = False, want_commit: bool = True):
+    """uzk_preprocess_tables: [count, n, 4] evaluation vectors -> (polys [count, n, 4], lens, coset [count, 6n, 4] | None,
+    commitments [count, 12] | None).  Without commitments the SRS handle is not looked at (srs may be None)."""
     e = np.ascontiguousarray(evals, dtype=np.uint64)
     cnt, n = e.shape[0], e.shape[1]
     polys = np.zeros((cnt, n, 4), dtype=np.uint64)
     lens = np.zeros(cnt, dtype=np.uint64)
     coset = np.zeros((cnt, 6 * n, 4), dtype=np.uint64) if want_coset else None
-    cms = np.zeros((cnt, 12), dtype=np.uint64)
-    check(lib.uzk_preprocess_tables(srs.handle, n, cnt, _ptr(e), _ptr(_fr4(k1)) if k1 is not None else None, _ptr(polys), _ptr(lens),
-                                    _ptr(coset) if want_coset else None, _ptr(cms)))
+    cms = np.zeros((cnt, 12), dtype=np.uint64) if want_commit else None
+    check(lib.uzk_preprocess_tables(srs.handle if srs is not None else 0, n, cnt, _ptr(e), _ptr(_fr4(k1)) if k1 is not None else None, _ptr(polys), _ptr(lens),
+                                    _ptr(coset) if want_coset else None, _ptr(cms) if want_commit else None))
     return polys, lens, coset, cms
 
 
