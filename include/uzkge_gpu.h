@@ -485,7 +485,7 @@ int uzk_msm_set_window_bits(int c);
 int uzk_msm_plan_info(size_t n, int* window_bits, int* windows);
 /* Experiment switches for A/B measurements in one process (keys: "msm_acc_variant",
  * "msm_task_len", "msm_no_precompute", "msm_fold_group", "msm_overlap", "msm_sort_packed", "msm_fused_hist", "msm_reduce_seg", "msm_scan_reduce", "msm_quad_reduce", "ntt_tile",
- * "msm_chunk_log", "msm_stream_log", "msm_stream_min_log", "msm_small", "msm_fold_mode", "ntt_l29", "ntt_fused", "ntt_mulc", "ntt_planes", "ntt_stagger",
+ * "msm_chunk_log", "msm_stream_log", "msm_stream_min_log", "msm_small", "msm_fold_mode", "ntt_l29", "ntt_fused", "ntt_mulc", "ntt_planes",
  * "msm_seg_sort", "msm_chunk_sort", "msm_class_reduce", "msm_fold_big", "msm_bucket_fill", "msm_direct", "msm_scan_nb_log", "ntt_prio", "ntt_order",
  * "prover_t_cap": round 3 reads t as its first 5n - 2 + sum(hiding) coefficients -- for the timing / parity chains on synthetic circuits
  * whose witness satisfies nothing); never needed for correctness. */

@@ -293,7 +293,7 @@ static void copy_tuning(const Ctx& from, Ctx& to) {
     to.tune_fused_hist = from.tune_fused_hist; to.tune_sort_packed = from.tune_sort_packed; to.tune_ntt_fused = from.tune_ntt_fused;
     to.tune_ntt_tile = from.tune_ntt_tile; to.tune_ntt_l29 = from.tune_ntt_l29; to.tune_small = from.tune_small;
     to.tune_fold_mode = from.tune_fold_mode; to.tune_chunk_log = from.tune_chunk_log; to.tune_overlap = from.tune_overlap;
-    to.tune_seg_sort = from.tune_seg_sort; to.tune_direct = from.tune_direct; to.tune_bucket_fill = from.tune_bucket_fill; to.tune_fold_big = from.tune_fold_big; to.tune_scan_nb_log = from.tune_scan_nb_log; to.tune_ntt_prio = from.tune_ntt_prio; to.tune_ntt_order = from.tune_ntt_order; to.tune_class_reduce = from.tune_class_reduce; to.tune_chunk_sort = from.tune_chunk_sort; to.tune_scatter4 = from.tune_scatter4; to.tune_stream_log = from.tune_stream_log; to.tune_stream_min_log = from.tune_stream_min_log; to.tune_prover_t_cap = from.tune_prover_t_cap; to.tune_ntt_mulc = from.tune_ntt_mulc; to.tune_ntt_planes = from.tune_ntt_planes; to.tune_ntt_stagger = from.tune_ntt_stagger;
+    to.tune_seg_sort = from.tune_seg_sort; to.tune_direct = from.tune_direct; to.tune_bucket_fill = from.tune_bucket_fill; to.tune_fold_big = from.tune_fold_big; to.tune_scan_nb_log = from.tune_scan_nb_log; to.tune_ntt_prio = from.tune_ntt_prio; to.tune_ntt_order = from.tune_ntt_order; to.tune_class_reduce = from.tune_class_reduce; to.tune_chunk_sort = from.tune_chunk_sort; to.tune_scatter4 = from.tune_scatter4; to.tune_stream_log = from.tune_stream_log; to.tune_stream_min_log = from.tune_stream_min_log; to.tune_prover_t_cap = from.tune_prover_t_cap; to.tune_ntt_mulc = from.tune_ntt_mulc; to.tune_ntt_planes = from.tune_ntt_planes;
 }
 int uzk_ctx_create(uint64_t* ctx_out) try {
     if (!ctx_out) { set_error("uzk_ctx_create: null pointer"); return UZK_ERR_PARAMETER; }
@@ -1143,7 +1143,6 @@ int uzk_tune(const char* key, int value) try {
     else if (!std::strcmp(key, "msm_overlap")) c.tune_overlap = value;
     else if (!std::strcmp(key, "ntt_l29")) c.tune_ntt_l29 = value;
     else if (!std::strcmp(key, "ntt_fused")) c.tune_ntt_fused = value;
-    else if (!std::strcmp(key, "ntt_stagger")) c.tune_ntt_stagger = (value >= 0 && value <= 16) ? value : 4;
     else if (!std::strcmp(key, "ntt_mulc")) c.tune_ntt_mulc = (value >= 0 && value <= 2) ? value : 1;
     else if (!std::strcmp(key, "ntt_planes")) c.tune_ntt_planes = value;
     else if (!std::strcmp(key, "ntt_tile")) c.tune_ntt_tile = value;

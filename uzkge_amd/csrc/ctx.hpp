@@ -95,7 +95,6 @@ struct Ctx {
     int tune_ntt_tile = 0;    // elements per workgroup of an NTT pass: 2048 (512 threads), 1024 (256 threads), 0 = by size
     int tune_ntt_order = 0;   // experiment: the passes' radix bits as decimal digits (868 = 2^8, 2^6, 2^8); 0 = the plan's choice
     int tune_ntt_prio = 0;    // experiment: wave priorities in the NTT passes (ntt.hip ntt_prio_start / ntt_prio_step)
-    int tune_ntt_stagger = 4; // > 0: NTT launches of >= 768 workgroups start their first generation staggered, this many 0.5 us steps per position on the CU (ntt.hip ntt_stagger_start); 0: off
     int tune_ntt_planes = 1;  // 1: the intermediate vectors of a plain multi-pass transform of <= 2^20 elements are limb planes (36 B per element), 2: at every size, 0: 8 x 32-bit words
     int tune_ntt_mulc = 1;    // 1: the tile twiddles of the NTT passes go through the constant-operand product (fp29.hpp mulc), 0: Montgomery products throughout, 2: as 1 with the full reduce() for the untwiddled butterfly outputs (A/B)
     int tune_ntt_l29 = 1;     // 1: NTT passes on the 29-bit-limb representation (0: 8x32-bit relaxed Montgomery)

@@ -180,7 +180,6 @@ struct PassArgs {
     // store nor the 8 -> 9 unpacking of the next load (~47 instructions per element and boundary) for 12 % more bytes there.
     uint32_t in_planes, out_planes;
     uint64_t plane_count;
-    uint32_t stagger;      // staggered start of the first generation of workgroups, in 0.5 us per position on the CU (ntt_stagger_start)
     uint32_t shrink_full;  // MULC kernels: F9::reduce instead of F9::reduce3 for the untwiddled butterfly output (uzk_tune("ntt_mulc", 2))
 };
 
@@ -189,20 +188,6 @@ struct PassArgs {
 __device__ __forceinline__ void ntt_prio_start(uint32_t mode) {
     if (mode == 1) { if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(2); }
     else if (mode == 2) { if (blockIdx.x & 1) __builtin_amdgcn_s_setprio(2); }
-}
-// A launch that fills the chip in ONE generation of workgroups (768 .. 1024 of them: 2^20 elements, the prover's ten coset
-// transforms over the 6n domain) starts all four workgroups of a CU in the same cycle, and they stay in step -- loading together,
-// computing together -- until the launch ends; launches of several generations fall out of step by themselves at the first
-// turnover.  So the first 1024 workgroups of a launch start staggered: the k-th workgroup of a CU (whichever way the dispatcher
-// deals them out: consecutively or round-robin) sleeps k * units * 0.5 us first.  Measured (profiles/r04_ab_ntt_stagger.txt): 2^20
-// 106.5 -> 100.4 us with 2 us steps, nothing at 2^22 and 2^24; the host sets `units` only for launches of >= 768 workgroups (below
-// that the CUs are not full and the sleep would be pure delay).
-__device__ __forceinline__ void ntt_stagger_start(uint32_t units) {
-    if (units == 0) return;
-    const uint32_t lin = blockIdx.x + gridDim.x * blockIdx.y;
-    if (lin >= 1024) return;
-    const uint32_t k = ((lin >> 3) + (lin >> 8)) & 3;
-    for (uint32_t i = 0; i < k * units; ++i) __builtin_amdgcn_s_sleep(16);
 }
 __device__ __forceinline__ void ntt_prio_step(uint32_t mode, int k) {
     if (mode != 3) return;
@@ -503,7 +488,6 @@ __global__ __launch_bounds__(TILE / 4) __attribute__((amdgpu_waves_per_eu(4))) v
     };
 
     ntt_prio_start(a.prio);
-    ntt_stagger_start(a.stagger);
     L29 w4, w4q;
     if constexpr (MULC) { tw29_load_pair(a.tw256c, 256, 64, w4, w4q); w4 = F9::uniform(w4); w4q = F9::uniform(w4q); }
     else w4 = tw29_load(a.tw256, 256, 64);
@@ -838,13 +822,11 @@ static void launch_pass(Ctx& c, bool l29, bool first, const Fp* in, Fp* out, con
     } else if (l29 && small_tile) {
         KernelScope ks(c, first ? "ntt_pass_first" : "ntt_pass");
         const unsigned g2 = (unsigned)((n / R) / (1024 / R));
-        PassArgs w = a;
-        if (c.tune_ntt_stagger > 0 && (uint64_t)g2 * batch >= 768) w.stagger = (uint32_t)c.tune_ntt_stagger;
         const bool mulc = a.tw256c != nullptr;
-        if (first && mulc) hipLaunchKernelGGL((ntt_pass29_kernel<B, true, 1024, true>), dim3(g2, batch), dim3(256), 0, c.stream, in, out, w);
-        else if (mulc) hipLaunchKernelGGL((ntt_pass29_kernel<B, false, 1024, true>), dim3(g2, batch), dim3(256), 0, c.stream, in, out, w);
-        else if (first) hipLaunchKernelGGL((ntt_pass29_kernel<B, true, 1024, false>), dim3(g2, batch), dim3(256), 0, c.stream, in, out, w);
-        else hipLaunchKernelGGL((ntt_pass29_kernel<B, false, 1024, false>), dim3(g2, batch), dim3(256), 0, c.stream, in, out, w);
+        if (first && mulc) hipLaunchKernelGGL((ntt_pass29_kernel<B, true, 1024, true>), dim3(g2, batch), dim3(256), 0, c.stream, in, out, a);
+        else if (mulc) hipLaunchKernelGGL((ntt_pass29_kernel<B, false, 1024, true>), dim3(g2, batch), dim3(256), 0, c.stream, in, out, a);
+        else if (first) hipLaunchKernelGGL((ntt_pass29_kernel<B, true, 1024, false>), dim3(g2, batch), dim3(256), 0, c.stream, in, out, a);
+        else hipLaunchKernelGGL((ntt_pass29_kernel<B, false, 1024, false>), dim3(g2, batch), dim3(256), 0, c.stream, in, out, a);
     } else if (l29) {
         KernelScope ks(c, first ? "ntt_pass_first" : "ntt_pass");
         const bool mulc = a.tw256c != nullptr;
