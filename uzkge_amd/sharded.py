@@ -25,7 +25,7 @@ def chunk_bounds(n_total: int, rank: int, world: int) -> tuple[int, int]:
 
 
 class ShardedCommitter:
-    """`srs`: this rank's chunk of the bases (backend.Srs, device resident).  `group`: a torch.distributed process group
+    """`srs`: this rank's chunk of the bases (backend.Srs, device resident; None = exchange only).  `group`: a torch.distributed process group
     (None = the default group; not initialised or world size 1 = no exchange).  `device`: the torch device of this rank's GPU
     (needed by the "nccl" backend, whose collectives take device tensors)."""
 
@@ -70,6 +70,8 @@ class ShardedCommitter:
 
     def commit_device(self, d_scalars: int, n_local: int) -> np.ndarray:
         """MSM of this rank's scalar chunk (device pointer, `n_local` elements matching the rank's bases), then the exchange."""
+        if self.srs is None:
+            raise ValueError("ShardedCommitter: made without bases (exchange-only); commit_device needs this rank's Srs")
         t0 = time.perf_counter()
         part = b.msm_device(self.srs, d_scalars, n_local)
         self.msm_s += time.perf_counter() - t0
