@@ -11,6 +11,7 @@ use std::collections::HashMap;
 use std::sync::{Arc, Mutex};
 
 use ark_bn254::{Fr, G1Projective};
+use ark_ec::CurveGroup;
 use ark_ff::{PrimeField, UniformRand};
 use ark_poly::Radix2EvaluationDomain;
 use ark_std::rand::{CryptoRng, RngCore};
