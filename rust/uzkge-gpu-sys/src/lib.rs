@@ -75,7 +75,9 @@ impl Srs {
     }
     /// `batch` vectors of `n` scalars each against the same bases (the prover's independent commits in one call).
     pub fn msm_batch(&self, offset: usize, scalars_mont: &[[u64; 4]], n: usize) -> Result<Vec<uzk_g1_jac>, Error> {
-        assert!(n > 0 && scalars_mont.len() % n == 0);
+        if n == 0 || scalars_mont.len() % n != 0 {
+            return Err(Error::Parameter);
+        }
         let batch = scalars_mont.len() / n;
         let mut out = vec![uzk_g1_jac::default(); batch];
         check(unsafe { uzk_msm_g1_batch(self.handle, offset, scalars_mont.as_ptr() as *const u64, n, batch as u32, out.as_mut_ptr()) })?;
