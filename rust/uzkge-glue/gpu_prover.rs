@@ -288,19 +288,19 @@ fn rounds<R: CryptoRng + RngCore, PCS: PolyComScheme, CS: ConstraintSystem<PCS::
     let gamma: PCS::Field = transcript.get_challenge_field_elem(b"gamma");
     challenges.insert_beta_gamma(beta, gamma).unwrap(); // safe unwrap
     let z_blinds: Vec<Limbs> = (0..3).map(|_| fr_limbs(&Fr::rand(prng))).collect();
-    let cm_z = wrap(&prover.round2(&one(&beta)?, &one(&gamma)?, &z_blinds).map_err(dev)?)?;
+    let cm_z = wrap(prover.round2(&[one(&beta)?], &[one(&gamma)?], &z_blinds).map_err(dev)?.first().ok_or(UzkgeError::ProofError)?)?;
     transcript.append_commitment::<PCS::Commitment>(&cm_z);
     // 6.-7. alpha; t, split_t_and_commit: one rand per chunk, drawn in chunk order (helpers.rs:1351)
     let alpha: PCS::Field = transcript.get_challenge_field_elem(b"alpha");
     challenges.insert_alpha(alpha).unwrap();
     let t_rands: Vec<Limbs> = (0..N_WIRES).map(|_| fr_limbs(&Fr::rand(prng))).collect();
-    let cm_t_vec: Vec<PCS::Commitment> = prover.round3(&one(&alpha)?, &t_rands).map_err(dev)?.iter().map(wrap).collect::<Result<_, _>>()?;
+    let cm_t_vec: Vec<PCS::Commitment> = prover.round3(&[one(&alpha)?], &t_rands).map_err(dev)?.iter().map(wrap).collect::<Result<_, _>>()?;
     for cm_t in cm_t_vec.iter() { transcript.append_commitment::<PCS::Commitment>(cm_t); }
     // 8.-9. zeta; the evaluations (prover.rs:241-273) and their transcript order (prover.rs:275-294)
     let zeta: PCS::Field = transcript.get_challenge_field_elem(b"zeta");
     challenges.insert_zeta(zeta).unwrap();
     let zeta_omega = domain.group_gen * zeta;
-    let ev: Vec<PCS::Field> = field_of(&prover.round4(&one(&zeta)?).map_err(dev)?);
+    let ev: Vec<PCS::Field> = field_of(&prover.round4(&[one(&zeta)?], cfg!(feature = "shuffle")).map_err(dev)?);
     let (w_polys_eval_zeta, s_polys_eval_zeta) = (ev[0..5].to_vec(), ev[5..9].to_vec());
     let (prk_3_poly_eval_zeta, prk_4_poly_eval_zeta, z_eval_zeta_omega) = (ev[9], ev[10], ev[11]);
     let w_polys_eval_zeta_omega = ev[12..15].to_vec();
@@ -351,7 +351,7 @@ fn rounds<R: CryptoRng + RngCore, PCS: PolyComScheme, CS: ConstraintSystem<PCS::
     let alpha_1: PCS::Field = transcript.get_challenge_field_elem(b"alpha");
     PCS::init_pcs_batch_eval_transcript(transcript, n + 2, &zeta_omega);
     let alpha_2: PCS::Field = transcript.get_challenge_field_elem(b"alpha");
-    let openings = prover.round5(&r_scalars, &one(&alpha_1)?, &one(&alpha_2)?).map_err(dev)?;
+    let openings = prover.round5(&r_scalars, &[one(&alpha_1)?], &[one(&alpha_2)?]).map_err(dev)?;
     Ok(PlonkProof {
         cm_w_vec,
         #[cfg(feature = "shuffle")]

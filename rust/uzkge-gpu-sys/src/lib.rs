@@ -235,42 +235,48 @@ impl Prover {
         })?;
         Ok(out)
     }
-    /// prover.rs:194-209 for one proof (batch 1).
-    pub fn round2(&self, beta: &Limbs, gamma: &Limbs, blinds_z: &[Limbs]) -> Result<uzk_g1_jac, Error> {
-        if self.batch != 1 || blinds_z.len() != 3 {
+    /// prover.rs:194-209 for every proof of the batch: beta, gamma: one each; blinds_z: three each; returns cm_z per proof.
+    pub fn round2(&self, beta: &[Limbs], gamma: &[Limbs], blinds_z: &[Limbs]) -> Result<Vec<uzk_g1_jac>, Error> {
+        if beta.len() != self.batch || gamma.len() != self.batch || blinds_z.len() != 3 * self.batch {
             return Err(Error::Parameter);
         }
-        let mut out = uzk_g1_jac::default();
-        check(unsafe { uzk_prove_round2(self.handle, beta.as_ptr(), gamma.as_ptr(), blinds_z.as_ptr() as *const u64, &mut out) })?;
+        let mut out = vec![uzk_g1_jac::default(); self.batch];
+        check(unsafe { uzk_prove_round2(self.handle, beta.as_ptr() as *const u64, gamma.as_ptr() as *const u64, blinds_z.as_ptr() as *const u64, out.as_mut_ptr()) })?;
         Ok(out)
     }
-    /// prover.rs:211-239 for one proof: the five commitments of t's chunks.
-    pub fn round3(&self, alpha: &Limbs, t_rands: &[Limbs]) -> Result<Vec<uzk_g1_jac>, Error> {
-        if self.batch != 1 || t_rands.len() != 5 {
+    /// prover.rs:211-239: alpha: one per proof; t_rands: five per proof; returns the five commitments of t's chunks per proof.
+    pub fn round3(&self, alpha: &[Limbs], t_rands: &[Limbs]) -> Result<Vec<uzk_g1_jac>, Error> {
+        if alpha.len() != self.batch || t_rands.len() != 5 * self.batch {
             return Err(Error::Parameter);
         }
-        let mut out = vec![uzk_g1_jac::default(); 5];
-        check(unsafe { uzk_prove_round3(self.handle, alpha.as_ptr(), t_rands.as_ptr() as *const u64, out.as_mut_ptr()) })?;
+        let mut out = vec![uzk_g1_jac::default(); 5 * self.batch];
+        check(unsafe { uzk_prove_round3(self.handle, alpha.as_ptr() as *const u64, t_rands.as_ptr() as *const u64, out.as_mut_ptr()) })?;
         Ok(out)
     }
-    /// prover.rs:241-273 for one proof: 19 evaluations (the first 15 are meaningful for a circuit without the shuffle feature).
-    pub fn round4(&self, zeta: &Limbs) -> Result<Vec<Limbs>, Error> {
-        if self.batch != 1 {
+    /// prover.rs:241-273: zeta: one per proof; returns `per` evaluations per proof, packed: 19 for a circuit with the shuffle
+    /// feature's terms (`shuffle`), 15 without.
+    pub fn round4(&self, zeta: &[Limbs], shuffle: bool) -> Result<Vec<Limbs>, Error> {
+        if zeta.len() != self.batch {
             return Err(Error::Parameter);
         }
-        let mut out = vec![[0u64; 4]; 19];
-        check(unsafe { uzk_prove_round4(self.handle, zeta.as_ptr(), out.as_mut_ptr() as *mut u64) })?;
+        let per = if shuffle { 19 } else { 15 };
+        let mut out = vec![[0u64; 4]; per * self.batch];
+        check(unsafe { uzk_prove_round4(self.handle, zeta.as_ptr() as *const u64, out.as_mut_ptr() as *mut u64) })?;
         Ok(out)
     }
-    /// prover.rs:296-372 for one proof: r_scalars (19 | 43, the order of uzk_prove_round5), the two opening commitments.
-    pub fn round5(&self, r_scalars: &[Limbs], alpha_zeta: &Limbs, alpha_zeta_omega: &Limbs) -> Result<Vec<uzk_g1_jac>, Error> {
-        if self.batch != 1 || (r_scalars.len() != 19 && r_scalars.len() != 43) {
+    /// prover.rs:296-372: r_scalars: 19 | 43 per proof (the order of uzk_prove_round5); the two opening challenges: one each per
+    /// proof; returns the two opening commitments per proof.
+    pub fn round5(&self, r_scalars: &[Limbs], alpha_zeta: &[Limbs], alpha_zeta_omega: &[Limbs]) -> Result<Vec<uzk_g1_jac>, Error> {
+        if alpha_zeta.len() != self.batch || alpha_zeta_omega.len() != self.batch || (r_scalars.len() != 19 * self.batch && r_scalars.len() != 43 * self.batch) {
             return Err(Error::Parameter);
         }
-        let mut out = vec![uzk_g1_jac::default(); 2];
-        check(unsafe { uzk_prove_round5(self.handle, r_scalars.as_ptr() as *const u64, alpha_zeta.as_ptr(), alpha_zeta_omega.as_ptr(), out.as_mut_ptr()) })?;
+        let mut out = vec![uzk_g1_jac::default(); 2 * self.batch];
+        check(unsafe {
+            uzk_prove_round5(self.handle, r_scalars.as_ptr() as *const u64, alpha_zeta.as_ptr() as *const u64, alpha_zeta_omega.as_ptr() as *const u64, out.as_mut_ptr())
+        })?;
         Ok(out)
     }
+    pub fn batch(&self) -> usize { self.batch }
 }
 impl Drop for Prover {
     fn drop(&mut self) {
