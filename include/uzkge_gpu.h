@@ -70,6 +70,13 @@ const char* uzk_version(void);
  * precompute them before the contexts start sharing them. */
 /* The new context starts with the creator's current tuning (uzk_tune, uzk_msm_set_window_bits). */
 int uzk_ctx_create(uint64_t* ctx_out);
+/* A context on a named device ("uzk_init(n_devices)"): one process can then drive several GPUs -- prover threads
+ * with a context, circuits and provers each on their own device, or the point chunks of one MSM (uzk_msm_g1_sharded).
+ * uzk_init keeps its meaning: the device of the default context and of uzk_ctx_create.  SRS handles, circuits and provers
+ * live on the device of the context that made them; using one from a context on another device is UZK_ERR_PARAMETER. */
+int uzk_ctx_create_on(int device, uint64_t* ctx_out);
+/* the device context `ctx` (0: the default context) lives on */
+int uzk_ctx_device(uint64_t ctx, int* device_out);
 /* Makes `ctx` (0 = the default context) the calling thread's current context. */
 int uzk_ctx_set_current(uint64_t ctx);
 /* Frees the context's stream, plans and workspaces; no thread may be inside a call on it.  A thread whose current
@@ -341,7 +348,7 @@ enum {
     UZK_CS_QECC = 45            /* q_ecc_poly */
 };
 typedef struct {
-    uint32_t n;                 /* cs.size(): a power of two, 8 <= n <= 2^20 */
+    uint32_t n;                 /* cs.size(): a power of two, 16 <= n <= 2^20 */
     uint32_t shuffle;           /* != 0: built with the "shuffle" feature -- all 46 slots; 0: slots 0..20 only (zmatchmaking) */
     uint32_t precompute;        /* window tables over the commit bases (uzk_srs_precompute): 0 none; 1 automatic -- two tables, 8-bit
                                    windows for provers of one proof (shortest chain of dependent additions) and 15-bit windows for
@@ -384,15 +391,46 @@ int uzk_preprocess_tables(uint64_t lagrange_srs, uint32_t n, uint32_t count, con
 /* Device address and coefficient count of a slot's polynomial (which = 0; n elements allocated) or coset table (which = 1; 6n
  * elements) as of now -- tests and diagnostics. */
 int uzk_circuit_table(uint64_t circuit, uint32_t slot, int which, const void** d_out, uint64_t* len_out);
-/* Waits for the calling context's stream; tables still held by a proof in flight are freed when that proof ends. */
+/* Forgets the handle.  Tables, commit bases and window tables are freed with the last proof that still holds them: a proof in
+ * flight (between its round 1 and its round 5) finishes with what it started with. */
 int uzk_circuit_release(uint64_t circuit);
+/* n, the evaluations round 4 writes per proof (15, or 19 for a shuffle circuit), the r_poly scalars round 5 reads per proof
+ * (19 or 43) and the device the circuit lives on; every output optional (NULL). */
+int uzk_circuit_info(uint64_t circuit, uint32_t* n_out, uint32_t* evals_per_proof_out, uint32_t* r_scalars_per_proof_out, int* device_out);
+/* TEST / TIMING ONLY -- changes results.  Marks the circuit as synthetic (random polynomials no witness satisfies, the frozen
+ * parity vectors and the timing chains): round 3 then takes t as its first 5 n - 2 + sum(hiding) coefficients, as
+ * tests/chain_oracle.py does, and the unsatisfied-witness check is off.  Never set it on a real circuit. */
+int uzk_test_circuit_truncate_t(uint64_t circuit, int on);
 
-/* A prover = the device buffers of `batch` proofs over circuits of size n that advance in lockstep (batch = 1: one proof; a
- * server with several witnesses of one circuit waiting runs them as ONE sequence of wider launches -- commits of 8 x batch
- * vectors, transforms of 10 x batch).  Use a prover from one thread at a time; give concurrent prover threads their own
- * context (uzk_ctx_create) and their own prover. */
+/* A prover = the device buffers of `batch` proofs over circuits of size n that advance in lockstep (a server with several
+ * witnesses of one circuit waiting runs them as ONE sequence of wider launches -- commits of 8 x batch vectors, transforms of
+ * 10 x batch).  Use a prover from one thread at a time.  It lives on the calling context's device; all five rounds of a proof
+ * must come from the context that ran its round 1 (else UZK_ERR_PARAMETER: they are ordered on that context's stream).
+ *
+ * batch = 1 is the reference's shape -- prover_with_lagrange proves one proof per call from whatever thread the application
+ * runs (prover.rs:88-100; shuffle/src/sdk.rs:196-214) -- and at n = 2^14 one proof leaves most of the chip idle.  Provers of
+ * one proof are therefore SHARED by default: when several threads stand at the same round of proofs over the same circuit, the
+ * library runs their calls as one lockstep launch sequence on a pooled workspace with its own stream and hands each caller its
+ * own outputs -- bit for bit what the call alone would have returned (tests/test_gpu_coalesce.py).  No new API: each thread
+ * keeps calling uzk_prove_round1..5 on its own prover, from any context.  A thread whose prover is the only idle one never
+ * waits; see uzk_coalesce_config. */
 int uzk_prover_create(uint32_t n, uint32_t batch, uint64_t* prover_out);
+/* The same, but the prover owns its lanes whatever `batch` and the sharing configuration are: its proofs run on the calling
+ * context's stream, alone, and uzk_prover_buffer can show its buffers (tests, diagnostics, latency measurements). */
+int uzk_prover_create_private(uint32_t n, uint32_t batch, uint64_t* prover_out);
 int uzk_prover_destroy(uint64_t prover);
+/* How provers of one proof made FROM NOW ON are shared (process-wide; existing provers keep their kind):
+ *   max_lanes          most proofs per lockstep launch (default 8; <= 64).  0 or 1: off -- such provers own their lane, as
+ *                      provers with batch >= 2 and those of uzk_prover_create_private always do
+ *   gather_wait_us     how long the first caller of a round 1 waits for company (default 50); it does not wait at all when no
+ *                      other shared prover of its size and device is idle
+ *   straggler_wait_us  how long the callers of rounds 2..5 wait for a member of their group before its proof is moved to a
+ *                      workspace of its own and the rest go on (default 2000; 0 = default) */
+int uzk_coalesce_config(uint32_t max_lanes, uint32_t gather_wait_us, uint32_t straggler_wait_us);
+/* What sharing has done since the last uzk_coalesce_config: out[0] shared rounds run, out[1] round calls they served (out[1] /
+ * out[0] = proofs per launch sequence), out[2] the most calls one round served, out[3] proofs moved to a workspace of their own
+ * because their caller stayed away, out[4] groups formed at a round 1. */
+int uzk_coalesce_stats(uint64_t out[5]);
 /* Per-proof arrays below are [batch][...]: element b of every input / output belongs to proof b.
  *
  * Round 1 (prover.rs:151-192): PI polynomial, wire and wire-selector polynomials: iFFT(n), hide_polynomial, commit with blinds.
@@ -420,16 +458,19 @@ int uzk_prove_round3(uint64_t prover, const uint64_t* alpha, const uint64_t* t_r
 /* Round 4 (prover.rs:241-273): the opening evaluations, in the reference's order of computation:
  *   w_polys_eval_zeta (5), s_polys_eval_zeta (4), prk_3, prk_4, z_eval_zeta_omega, w_polys_eval_zeta_omega (3)
  *   and, for a shuffle circuit, q_ecc_poly_eval_zeta, w_sel_polys_eval_zeta (3):  15 or 19 elements per proof.
- * zeta: batch x 4 limbs; zeta * omega is formed here. */
-int uzk_prove_round4(uint64_t prover, const uint64_t* zeta, uint64_t* evals_out);
+ * zeta: batch x 4 limbs; zeta * omega is formed here.  evals_cap: the elements evals_out can hold (>= batch x 15 or 19:
+ * uzk_circuit_info; less is UZK_ERR_PARAMETER, nothing is written past it). */
+int uzk_prove_round4(uint64_t prover, const uint64_t* zeta, uint64_t* evals_out, size_t evals_cap);
 /* Round 5 (prover.rs:296-372): r(X) = sum_k r_scalars[k] * p_k over (in this order) q_polys (9), z, s_polys[4], qb, q_prk1,
  * q_prk2, [q_shuffle_public_key (12), q_shuffle_generator (12)], t chunks (5): 19 or 43 scalars per proof, which the caller gets
  * from the reference's r_poly_or_comm (helpers.rs:681-1002); then both batch_prove calls (pcs.rs:107-168) with their transcript
  * challenges alpha_zeta / alpha_zeta_omega: quotient, fold, FFT(n), Lagrange commit, blind factors.
+ * r_count: the elements r_scalars holds -- exactly batch x 19 or 43 (uzk_circuit_info), else UZK_ERR_PARAMETER.
  * openings_out: batch x 2 (opening_witness_zeta, opening_witness_zeta_omega).  Ends the proof: the circuit tables are released. */
-int uzk_prove_round5(uint64_t prover, const uint64_t* r_scalars, const uint64_t* alpha_zeta, const uint64_t* alpha_zeta_omega,
+int uzk_prove_round5(uint64_t prover, const uint64_t* r_scalars, size_t r_count, const uint64_t* alpha_zeta, const uint64_t* alpha_zeta_omega,
                      uzk_g1_jac* openings_out);
-/* Device address and element count (per proof: proof b's part starts b * elems_out elements in) of a prover buffer -- tests:
+/* Device address and element count (per proof: proof b's part starts b * elems_out elements in) of a prover buffer -- tests
+ * (provers that own their lanes only: batch >= 2, or uzk_prover_create_private):
  *   0 evals (10 n: w0..4, w_sel0..2, pi, z)  1 coefs (10 x 6n slots, same order)  2 coset evaluations (10 x 6n)
  *   3 quotient evaluations (6n)  4 t (6n)  5 t chunks (5 x (n + 8))  6 folded (5 n)  7 tails (5 x 6)
  *   8 opening quotients (2 x (n + 8))  9 r (n + 8).

@@ -145,6 +145,18 @@ impl Context {
         check(unsafe { uzk_ctx_create(&mut h) })?;
         Ok(Context(h))
     }
+    /// A context on a named device (`uzk_ctx_create_on`): circuits, provers and SRS handles made while it is current live there,
+    /// so one process can run a pool of prover threads over all the GPUs of a node.
+    pub fn on_device(device: c_int) -> Result<Self, Error> {
+        let mut h = 0u64;
+        check(unsafe { uzk_ctx_create_on(device, &mut h) })?;
+        Ok(Context(h))
+    }
+    pub fn device(&self) -> Result<c_int, Error> {
+        let mut d: c_int = 0;
+        check(unsafe { uzk_ctx_device(self.0, &mut d) })?;
+        Ok(d)
+    }
     /// Makes this context the calling thread's current one.
     pub fn make_current(&self) -> Result<(), Error> {
         check(unsafe { uzk_ctx_set_current(self.0) })
@@ -198,6 +210,12 @@ impl Circuit {
         })?;
         Ok((polys, lens, coset, cms))
     }
+    /// (n, evaluations round 4 writes per proof, r_poly scalars round 5 reads per proof, device) -- `uzk_circuit_info`.
+    pub fn info(&self) -> Result<(u32, u32, u32, c_int), Error> {
+        let (mut n, mut ev, mut rs, mut dev) = (0u32, 0u32, 0u32, 0 as c_int);
+        check(unsafe { uzk_circuit_info(self.handle, &mut n, &mut ev, &mut rs, &mut dev) })?;
+        Ok((n, ev, rs, dev))
+    }
     pub fn handle(&self) -> u64 { self.handle }
 }
 impl Drop for Circuit {
@@ -206,8 +224,17 @@ impl Drop for Circuit {
     }
 }
 
+/// How provers of ONE proof made from now on are shared between threads (`uzk_coalesce_config`): the library runs round calls of
+/// several threads that stand at the same round of proofs over the same circuit as one lockstep launch sequence.  On by default
+/// (8 lanes, 50 us gathering wait); `max_lanes` <= 1 switches it off.
+pub fn coalesce_config(max_lanes: u32, gather_wait_us: u32, straggler_wait_us: u32) -> Result<(), Error> {
+    check(unsafe { uzk_coalesce_config(max_lanes, gather_wait_us, straggler_wait_us) })
+}
+
 /// The device buffers of `batch` proofs in lockstep over circuits of size n (`uzk_prover_create`) and the five rounds.  Per-proof
-/// arrays are [batch][..]; lengths are checked by the library (a short slice is a `Parameter` error here, never a read past it).
+/// arrays are [batch][..]; lengths are checked here and again by the library (a short slice is a `Parameter` error, never a read
+/// or write past it).  `batch` = 1 is a SHARED prover: each thread keeps its own and calls the rounds of its own proof, and the
+/// library merges the calls of threads that prove over the same circuit at the same time.
 pub struct Prover {
     handle: u64,
     n: usize,
@@ -217,6 +244,13 @@ impl Prover {
     pub fn new(n: u32, batch: u32) -> Result<Self, Error> {
         let mut handle = 0u64;
         check(unsafe { uzk_prover_create(n, batch, &mut handle) })?;
+        Ok(Prover { handle, n: n as usize, batch: batch as usize })
+    }
+    /// A prover that owns its lanes whatever `batch` is (`uzk_prover_create_private`): its proofs run alone on the calling
+    /// context's stream (latency measurements, diagnostics).
+    pub fn new_private(n: u32, batch: u32) -> Result<Self, Error> {
+        let mut handle = 0u64;
+        check(unsafe { uzk_prover_create_private(n, batch, &mut handle) })?;
         Ok(Prover { handle, n: n as usize, batch: batch as usize })
     }
     /// prover.rs:151-192.  witness: batch x 5n; wsel: batch x 3n or empty; hiding: 5 (+3); blinds: batch x (5 | 8) x 3.
@@ -254,25 +288,27 @@ impl Prover {
         Ok(out)
     }
     /// prover.rs:241-273: zeta: one per proof; returns `per` evaluations per proof, packed: 19 for a circuit with the shuffle
-    /// feature's terms (`shuffle`), 15 without.
+    /// feature's terms (`shuffle`), 15 without.  The library is told how many elements the buffer holds and refuses the round
+    /// (`Parameter`) when the circuit of the proof gives more.
     pub fn round4(&self, zeta: &[Limbs], shuffle: bool) -> Result<Vec<Limbs>, Error> {
         if zeta.len() != self.batch {
             return Err(Error::Parameter);
         }
         let per = if shuffle { 19 } else { 15 };
         let mut out = vec![[0u64; 4]; per * self.batch];
-        check(unsafe { uzk_prove_round4(self.handle, zeta.as_ptr() as *const u64, out.as_mut_ptr() as *mut u64) })?;
+        check(unsafe { uzk_prove_round4(self.handle, zeta.as_ptr() as *const u64, out.as_mut_ptr() as *mut u64, out.len()) })?;
         Ok(out)
     }
     /// prover.rs:296-372: r_scalars: 19 | 43 per proof (the order of uzk_prove_round5); the two opening challenges: one each per
-    /// proof; returns the two opening commitments per proof.
+    /// proof; returns the two opening commitments per proof.  The library checks the count against the circuit of the proof.
     pub fn round5(&self, r_scalars: &[Limbs], alpha_zeta: &[Limbs], alpha_zeta_omega: &[Limbs]) -> Result<Vec<uzk_g1_jac>, Error> {
         if alpha_zeta.len() != self.batch || alpha_zeta_omega.len() != self.batch || (r_scalars.len() != 19 * self.batch && r_scalars.len() != 43 * self.batch) {
             return Err(Error::Parameter);
         }
         let mut out = vec![uzk_g1_jac::default(); 2 * self.batch];
         check(unsafe {
-            uzk_prove_round5(self.handle, r_scalars.as_ptr() as *const u64, alpha_zeta.as_ptr() as *const u64, alpha_zeta_omega.as_ptr() as *const u64, out.as_mut_ptr())
+            uzk_prove_round5(self.handle, r_scalars.as_ptr() as *const u64, r_scalars.len(), alpha_zeta.as_ptr() as *const u64, alpha_zeta_omega.as_ptr() as *const u64,
+                             out.as_mut_ptr())
         })?;
         Ok(out)
     }

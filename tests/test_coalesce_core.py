@@ -1,0 +1,41 @@
+"""The synchronisation core of the shared provers (uzkge_amd/csrc/coalesce_core.hpp) on the CPU: built with plain g++ -- it has
+no HIP in it -- and driven by a fake backend from many threads with stragglers, abandoned proofs, lanes that fail alone and
+provers that come and go (tests/cpp/coalesce_core_test.cpp).  Once plain, once under ThreadSanitizer: the host-side concurrency
+of the library's busiest lock is checked by a race detector, not only by GPU stress runs."""
+import json
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "cpp", "coalesce_core_test.cpp")
+
+
+def _build(tmp_path, flags):
+    exe = os.path.join(str(tmp_path), "coalesce_core_test")
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-pthread", *flags, "-o", exe, SRC], check=True)
+    return exe
+
+
+def _run(exe, args, timeout):
+    r = subprocess.run([exe, *map(str, args)], capture_output=True, text=True, timeout=timeout)
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, (lines[0] if lines else {})
+
+
+@pytest.mark.parametrize("threads,proofs,lanes", [(12, 300, 4), (5, 400, 8), (16, 150, 2)])
+def test_every_caller_gets_its_own_proof(tmp_path, threads, proofs, lanes):
+    r, res = _run(_build(tmp_path, []), (threads, proofs, lanes), 300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+    assert res["bad"] == 0 and res["proofs"] > 0 and res["cohorts_opened"] == res["cohorts_closed"]
+    assert 1 < res["widest_round"] <= lanes                      # callers did share rounds, never more than the configured lanes
+    assert res["lanes_run"] > res["rounds_run"]
+    assert res["moved_out"] > 0 and res["failed_on_purpose"] > 0 and res["abandoned"] > 0      # every path was taken
+
+
+def test_no_data_race_under_thread_sanitizer(tmp_path):
+    r, res = _run(_build(tmp_path, ["-fsanitize=thread"]), (8, 120, 4), 600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+    assert "ThreadSanitizer" not in r.stderr, r.stderr[:4000]
+    assert res["bad"] == 0 and res["widest_round"] > 1

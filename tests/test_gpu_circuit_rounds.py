@@ -138,10 +138,11 @@ def _run_rounds(b, circuit, prover, lanes_in, shuffle=True, with_wsel=True):
     return o
 
 
-def _circuit_of(b, inp, shuffle=True, precompute=False):
+def _circuit_of(b, inp, shuffle=True, precompute=False, synthetic=True):
+    """synthetic: random table polynomials no witness satisfies (tools/prover_chain.py) -- round 3 reads t as its expected length"""
     import prover_chain as pch
     return b.Circuit(inp.n, inp.lagrange_wire, inp.bases[inp.n:], inp.perm, inp.k, inp.anemoi_g, inp.anemoi_g_inv, inp.edwards_a,
-                     [inp.table_polys[i] for i in range(pch.N_TABLES)], shuffle=shuffle, precompute=precompute)
+                     [inp.table_polys[i] for i in range(pch.N_TABLES)], shuffle=shuffle, precompute=precompute, synthetic=synthetic)
 
 
 @pytest.mark.parametrize("precompute", [0, 1, 11])
@@ -155,9 +156,8 @@ def test_lockstep_batch_equals_single_proofs(gpu, precompute):
     n = 1 << 12
     inp = pch.ChainInputs(n, 31)
     lanes = _round_inputs(inp, 3)
-    b.tune("prover_t_cap", 1)                    # random circuits: see tools/prover_chain.py
     cir = _circuit_of(b, inp, precompute=precompute)
-    p3, p1 = b.Prover(n, 3), b.Prover(n, 1)
+    p3, p1 = b.Prover(n, 3), b.Prover(n, 1, shared=False)
     try:
         o3 = _run_rounds(b, cir, p3, lanes)
         snap3 = {w: [p3.download(w, lane) for lane in range(3)] for w in (b.PB_COEFS, b.PB_T, b.PB_R, b.PB_Q)}
@@ -170,7 +170,6 @@ def test_lockstep_batch_equals_single_proofs(gpu, precompute):
                 assert np.array_equal(snap3[w][lane], p1.download(w)), (lane, w)
     finally:
         p3.destroy(); p1.destroy(); cir.release()
-        b.tune("prover_t_cap", 0)
 
 
 def test_tables_are_copy_on_write_for_a_proof_in_flight(gpu):
@@ -180,7 +179,6 @@ def test_tables_are_copy_on_write_for_a_proof_in_flight(gpu):
     b = gpu
     n = 1 << 12
     inp = pch.ChainInputs(n, 41)
-    b.tune("prover_t_cap", 1)
     cir = _circuit_of(b, inp)
     pr = b.Prover(n, 1)
     try:
@@ -217,7 +215,6 @@ def test_tables_are_copy_on_write_for_a_proof_in_flight(gpu):
             cir2.release()
     finally:
         pr.destroy(); cir.release()
-        b.tune("prover_t_cap", 0)
 
 
 def test_circuit_without_wire_selectors_and_with_built_coset_quotient(gpu):
@@ -227,10 +224,9 @@ def test_circuit_without_wire_selectors_and_with_built_coset_quotient(gpu):
     b = gpu
     n = 1 << 12
     inp = pch.ChainInputs(n, 51)
-    b.tune("prover_t_cap", 1)
     polys = [inp.table_polys[i] for i in range(pch.N_TABLES)]
     polys[pch.T_CQ] = None
-    cir = b.Circuit(n, inp.lagrange_wire, inp.bases[n:], inp.perm, inp.k, inp.anemoi_g, inp.anemoi_g_inv, inp.edwards_a, polys, shuffle=False)
+    cir = b.Circuit(n, inp.lagrange_wire, inp.bases[n:], inp.perm, inp.k, inp.anemoi_g, inp.anemoi_g_inv, inp.edwards_a, polys, shuffle=False, synthetic=True)
     pr = b.Prover(n, 1)
     try:
         m = 6 * n
@@ -250,7 +246,6 @@ def test_circuit_without_wire_selectors_and_with_built_coset_quotient(gpu):
         assert np.array_equal(o5["evals"], o8["evals"]) and o5["evals"].shape[0] == 15
     finally:
         pr.destroy(); cir.release()
-        b.tune("prover_t_cap", 0)
 
 
 def test_public_input_polynomial_and_argument_errors(gpu):
@@ -262,9 +257,8 @@ def test_public_input_polynomial_and_argument_errors(gpu):
     b = gpu
     n = 1 << 12
     inp = pch.ChainInputs(n, 61)
-    b.tune("prover_t_cap", 1)
     cir = _circuit_of(b, inp)
-    pr = b.Prover(n, 1)
+    pr = b.Prover(n, 1, shared=False)
     try:
         idx = np.array([7, 3, 4000, 3, 19], dtype=np.uint32)
         val = rand_fr_wire(5, 62)
@@ -300,7 +294,6 @@ def test_public_input_polynomial_and_argument_errors(gpu):
             cir.update_tables(40, [inp.table_polys[0]] * 7)                 # slots 40 .. 47 of 46
     finally:
         pr.destroy(); cir.release()
-        b.tune("prover_t_cap", 0)
 
 
 @pytest.mark.parametrize("n", [4096, 16384])
@@ -400,7 +393,6 @@ def test_provers_on_several_contexts_while_the_tables_are_being_swapped(gpu):
     b = gpu
     n = 1 << 12
     inp = pch.ChainInputs(n, 91)
-    b.tune("prover_t_cap", 1)
     cir = _circuit_of(b, inp)
     set_a = [np.ascontiguousarray(inp.table_polys[pch.T_QPK + t]) for t in range(12)]
     set_b = [rand_fr_wire(n, 950 + t) for t in range(12)]
@@ -418,7 +410,6 @@ def test_provers_on_several_contexts_while_the_tables_are_being_swapped(gpu):
             try:
                 ctx = b.ctx_create()
                 b.ctx_set_current(ctx)
-                b.tune("prover_t_cap", 1)                     # tuning is per context
                 pr = b.Prover(n, 1)
                 try:
                     while not stop.is_set():
@@ -444,7 +435,6 @@ def test_provers_on_several_contexts_while_the_tables_are_being_swapped(gpu):
         assert kinds <= {"a", "b"}, kinds
     finally:
         pr0.destroy(); cir.release()
-        b.tune("prover_t_cap", 0)
 
 
 @pytest.mark.parametrize("n", [64, 1024])
@@ -476,8 +466,7 @@ def test_small_circuits_are_self_consistent(gpu, n):
     k, polys = rand_fr_wire(5, 9), [rand_fr_wire(n, 300 + i) for i in range(pch.N_TABLES)]
     g = rand_fr_wire(1, 10)[0]
     ginv = oc.fr_inv(g)
-    b.tune("prover_t_cap", 1)
-    mk = lambda pre: b.Circuit(n, bases[:n], bases[n:], perm, k, g, ginv, rand_fr_wire(1, 11)[0], polys, precompute=pre)
+    mk = lambda pre: b.Circuit(n, bases[:n], bases[n:], perm, k, g, ginv, rand_fr_wire(1, 11)[0], polys, precompute=pre, synthetic=True)
     c0, c1 = mk(0), mk(1)
     p1, p2 = b.Prover(n, 1), b.Prover(n, 2)
     try:
@@ -495,4 +484,3 @@ def test_small_circuits_are_self_consistent(gpu, n):
             assert np.array_equal(oc.poly_eval(np.ascontiguousarray(coefs2[i][9, : n + 3]), zw).reshape(4), o2["evals"][i * 19 + 11])
     finally:
         p1.destroy(); p2.destroy(); c0.release(); c1.release()
-        b.tune("prover_t_cap", 0)

@@ -1,0 +1,253 @@
+"""Provers of ONE proof called from several host threads at once -- the reference's call pattern (prover_with_lagrange proves one
+proof per call from application threads: uzkge/src/plonk/prover.rs:88-100, shuffle/src/sdk.rs:196-214).  The library runs the
+calls that stand at the same round of proofs over the same circuit as one lockstep launch sequence (uzk_coalesce_config); every
+caller must get, commitment by commitment and evaluation by evaluation, the proof a prover that owns its lane makes of the same
+inputs alone -- also when a caller dawdles between rounds (its proof is moved to a workspace of its own), gives its proof up, or
+hands in a witness that does not satisfy the circuit (its proof fails alone).
+
+Also here: the throughput setting of the explicit lockstep API on the witness classes real circuits have, held
+to single proofs and to the CPU oracle chain."""
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+import pytest
+
+import bn254_py as opy
+import oracle_c as oc
+import plonk_verifier_oracle as pv
+from util import affine_of, rand_fr_wire
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+from test_gpu_circuit_rounds import _circuit_of, _round_inputs, _run_rounds      # noqa: E402
+
+
+def _digest(o):
+    return tuple(tuple(affine_of(j) for j in o[k]) for k in ("cm1", "cm_z", "cm_t", "cm_q")) + (o["evals"].tobytes(),)
+
+
+def _alone(b, cir, x):
+    p = b.Prover(x.n, 1, shared=False)
+    try:
+        return _digest(_run_rounds(b, cir, p, [x]))
+    finally:
+        p.destroy()
+
+
+@pytest.fixture
+def sharing(gpu):
+    gpu.coalesce_config(8, 50, 2000)
+    yield gpu
+    gpu.coalesce_config(8, 50, 2000)
+
+
+def test_a_shared_prover_alone_equals_a_private_one(sharing):
+    """No other thread around: the shared prover runs on its own one-lane workspace without waiting for anyone."""
+    import prover_chain as pch
+    b = sharing
+    n = 1 << 12
+    inp = pch.ChainInputs(n, 31)
+    cir = _circuit_of(b, inp, precompute=1)
+    p = b.Prover(n, 1)
+    try:
+        want = _alone(b, cir, inp)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            assert _digest(_run_rounds(b, cir, p, [inp])) == want
+        assert b.coalesce_stats()["widest"] == 1
+        with pytest.raises(Exception):
+            p.buffer(b.PB_COEFS)                              # pooled lanes have no fixed address to show
+        assert time.perf_counter() - t0 < 30
+    finally:
+        p.destroy(); cir.release()
+
+
+@pytest.mark.parametrize("threads,precompute", [(6, 1), (3, 0)])
+def test_threads_with_their_own_provers_share_rounds_and_get_their_own_proofs(sharing, threads, precompute):
+    """`threads` host threads on the default context, one shared prover and one witness / blinds / challenges each, proving in a
+    loop: rounds are shared (the statistics say so) and every proof equals the private prover's of the same inputs."""
+    import prover_chain as pch
+    b = sharing
+    n = 1 << 12
+    inp = pch.ChainInputs(n, 131)
+    lanes = _round_inputs(inp, threads)
+    cir = _circuit_of(b, inp, precompute=precompute)
+    want = [_alone(b, cir, x) for x in lanes]
+    b.coalesce_config(4, 2000, 5000)                          # a patient gathering wait: the Python threads are slow to come back
+    errors, seen = [], [0] * threads
+    start = threading.Barrier(threads)
+
+    def worker(t):
+        try:
+            p = b.Prover(n, 1)
+            try:
+                start.wait()
+                for _ in range(6):
+                    assert _digest(_run_rounds(b, cir, p, [lanes[t]])) == want[t], t
+                    seen[t] += 1
+            finally:
+                p.destroy()
+        except Exception as e:         # surfaced by the main thread
+            errors.append((t, repr(e)))
+    try:
+        ths = [threading.Thread(target=worker, args=(t,)) for t in range(threads)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        assert not errors, errors
+        assert seen == [6] * threads
+        st = b.coalesce_stats()
+        assert 2 <= st["widest"] <= 4 and st["calls"] > st["rounds"], st            # rounds were shared, never wider than configured
+        assert st["calls"] == threads * 6 * 5
+    finally:
+        cir.release()
+
+
+def test_a_caller_that_stays_away_is_moved_out_and_both_proofs_are_right(sharing):
+    import prover_chain as pch
+    b = sharing
+    n = 1 << 12
+    inp = pch.ChainInputs(n, 231)
+    lanes = _round_inputs(inp, 2)
+    cir = _circuit_of(b, inp)
+    want = [_alone(b, cir, x) for x in lanes]
+    b.coalesce_config(4, 200000, 20000)                       # gather for 0.2 s (both threads join), wait 20 ms for a straggler
+    errors, times = [], {}
+    start = threading.Barrier(2)
+    hiding = list(pch.HIDE_W) + [pch.HIDE_WSEL] * 3
+
+    def worker(t):
+        try:
+            x = lanes[t]
+            p = b.Prover(n, 1)
+            try:
+                start.wait()
+                o = {}
+                o["cm1"] = p.round1(cir, x.w_evals.reshape(1, 5 * n, 4), x.wsel_evals.reshape(1, 3 * n, 4), np.arange(8, dtype=np.uint32), x.pi_evals[:8].reshape(1, 8, 4),
+                                    hiding, np.concatenate([x.blinds_w, x.blinds_wsel]))
+                o["cm_z"] = p.round2(x.beta, x.gamma, x.blinds_z)
+                if t == 1:
+                    time.sleep(0.5)                           # far beyond the straggler wait: thread 0 must not wait for this
+                t0 = time.perf_counter()
+                o["cm_t"] = p.round3(x.alpha, x.t_rands)
+                times[t] = time.perf_counter() - t0
+                o["evals"] = p.round4(x.zeta)
+                o["cm_q"] = p.round5(x.r_scalars, x.alpha_open, x.alpha_open2)
+                assert _digest(o) == want[t], t
+            finally:
+                p.destroy()
+        except Exception as e:
+            errors.append((t, repr(e)))
+    try:
+        ths = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        assert not errors, errors
+        st = b.coalesce_stats()
+        assert st["widest"] == 2 and st["moved_out"] == 1, st
+        assert times[0] < 0.4, times                            # round 3 of thread 0 went ahead after the 20 ms, not after 0.5 s
+    finally:
+        cir.release()
+
+
+def test_an_unsatisfied_witness_fails_alone_and_an_abandoned_proof_blocks_nobody(sharing):
+    """A real (satisfiable) circuit: thread 1's witness has one wrong wire -- its round 3 is refused (UZK_ERR_COMMITMENT, as for a
+    prover of its own), thread 0's proof of the same group goes through unchanged; thread 2 starts a proof and never comes back
+    to it (then starts another): nobody waits for it longer than the straggler wait."""
+    import prover_chain as pch
+    from uzkge_amd import UzkgeError
+    from uzkge_amd import _native as N
+    b = sharing
+    n = 1 << 12
+    good = pv.make_satisfiable(pch.ChainInputs(n, 21), seed=4)
+    bad = pv.make_satisfiable(pch.ChainInputs(n, 21), seed=4)
+    bad.w_evals[2, 777] = oc.fr_from_ints([(pv._ints(bad.w_evals[2, 777:778])[0] + 1) % opy.R])[0]
+    cir = _circuit_of(b, good, synthetic=False)
+    want = _alone(b, cir, good)
+    b.coalesce_config(4, 200000, 20000)
+    errors, result = [], {}
+    start = threading.Barrier(3)
+    hiding = list(pch.HIDE_W) + [pch.HIDE_WSEL] * 3
+
+    def worker(t):
+        try:
+            x = bad if t == 1 else good
+            p = b.Prover(n, 1)
+            try:
+                start.wait()
+                if t == 2:
+                    p.round1(cir, x.w_evals.reshape(1, 5 * n, 4), x.wsel_evals.reshape(1, 3 * n, 4), np.arange(8, dtype=np.uint32), x.pi_evals[:8].reshape(1, 8, 4),
+                             hiding, np.concatenate([x.blinds_w, x.blinds_wsel]))
+                    time.sleep(0.3)                            # gives the proof up ...
+                    result[t] = _digest(_run_rounds(b, cir, p, [x]))      # ... and proves again
+                    return
+                try:
+                    result[t] = _digest(_run_rounds(b, cir, p, [x]))
+                except UzkgeError as e:
+                    result[t] = (e.code, str(e))
+            finally:
+                p.destroy()
+        except Exception as e:
+            errors.append((t, repr(e)))
+    try:
+        ths = [threading.Thread(target=worker, args=(t,)) for t in range(3)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        assert not errors, errors
+        assert result[0] == want and result[2] == want
+        assert result[1][0] == N.UZK_ERR_COMMITMENT and "does not satisfy" in result[1][1], result[1]
+        assert b.coalesce_stats()["widest"] == 3
+    finally:
+        cir.release()
+
+
+def _skewed(rng, count):
+    """The classes real witnesses consist of (constraint_system/turbo/mod.rs:968-977,1371-1391 -- booleans from range
+    checks, zero padding, small constants): 50 % zero, 20 % one, 10 % minus one, 10 % below 2^16, 10 % uniform."""
+    cls = rng.integers(0, 10, count)
+    small = rng.integers(0, 1 << 16, count)
+    uni = pv._ints(rand_fr_wire(count, int(rng.integers(1, 1 << 30))))
+    vals = [0 if c < 5 else 1 if c < 7 else opy.R - 1 if c == 7 else int(s) if c == 8 else u for c, s, u in zip(cls, small, uni)]
+    return np.asarray(oc.fr_from_ints(vals), dtype=np.uint64).reshape(count, 4)
+
+
+def test_lockstep_of_eight_skewed_witnesses_over_the_wide_table_equals_single_proofs_and_the_oracle(gpu):
+    """The throughput setting -- n = 2^14, uzk_prover_create(n, 8), precompute = 1 (the 15-bit window table under the lockstep
+    commits) -- on eight DIFFERENT witnesses drawn from the skewed classes: every lane equals the proof a prover of one proof makes
+    of it over the plain bases (no table), and lane 0's commitments equal the CPU oracle's Pippenger over the reference's SRS
+    (tests/chain_oracle.py's chain on that witness)."""
+    import chain_oracle
+    import prover_chain as pch
+    b = gpu
+    n = 1 << 14
+    inp = pch.ChainInputs(n, 11)
+    rng = np.random.default_rng(5)
+    lanes = _round_inputs(inp, 8)
+    for x in lanes:
+        x.w_evals = _skewed(rng, 5 * n).reshape(5, n, 4)
+        x.wsel_evals = _skewed(rng, 3 * n).reshape(3, n, 4)
+    cir_wide, cir_plain = _circuit_of(b, inp, precompute=1), _circuit_of(b, inp, precompute=0)
+    p8, p1 = b.Prover(n, 8), b.Prover(n, 1, shared=False)
+    try:
+        o8 = _run_rounds(b, cir_wide, p8, lanes)
+        for lane, x in enumerate(lanes):
+            o1 = _run_rounds(b, cir_plain, p1, [x])
+            for key, per in (("cm1", 8), ("cm_z", 1), ("cm_t", 5), ("cm_q", 2)):
+                assert [affine_of(j) for j in o8[key][lane * per:(lane + 1) * per]] == [affine_of(j) for j in o1[key]], (lane, key)
+            assert np.array_equal(o8["evals"][lane * 19:(lane + 1) * 19], o1["evals"]), lane
+        # lane 0 against the CPU oracle's chain: commitments and evaluations
+        want = chain_oracle.oracle_chain(lanes[0])
+        for key, mine in (("cm_w_wsel", o8["cm1"][:8]), ("cm_z", o8["cm_z"][:1]), ("cm_t", o8["cm_t"][:5]), ("cm_q", o8["cm_q"][:2])):
+            assert np.array_equal(oc.points_from_affine([affine_of(j) for j in mine]), want[key]), key
+        assert np.array_equal(o8["evals"][:19], want["evals"])
+    finally:
+        p8.destroy(); p1.destroy(); cir_wide.release(); cir_plain.release()

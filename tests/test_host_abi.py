@@ -132,7 +132,13 @@ def test_circuit_and_prover_entry_points_check_their_arguments_before_the_device
     z = np.zeros(64, dtype=np.uint64)
     p = z.ctypes.data_as(ctypes.c_void_p)
     assert N.lib.uzk_prove_round2(12345, p, p, p, p) == N.UZK_ERR_PARAMETER               # unknown prover
-    assert N.lib.uzk_prove_round5(12345, p, p, p, p) == N.UZK_ERR_PARAMETER
+    assert N.lib.uzk_prove_round5(12345, p, 43, p, p, p) == N.UZK_ERR_PARAMETER
+    assert N.lib.uzk_prove_round4((1 << 62) | 77, p, p, 19) == N.UZK_ERR_PARAMETER        # ... also one shaped like a shared prover's handle
+    assert N.lib.uzk_prover_create_private(4096, 65, ctypes.byref(h)) == N.UZK_ERR_PARAMETER   # more lanes than a prover can hold
+    assert N.lib.uzk_coalesce_config(65, 50, 0) == N.UZK_ERR_PARAMETER
+    assert N.lib.uzk_coalesce_config(8, 50, 0) == N.UZK_OK
+    assert N.lib.uzk_circuit_info(999, None, None, None, None) == N.UZK_ERR_PARAMETER
+    assert N.lib.uzk_test_circuit_truncate_t(999, 1) == N.UZK_ERR_PARAMETER
     assert N.lib.uzk_circuit_release(999) == N.UZK_ERR_PARAMETER
     assert N.lib.uzk_circuit_update_tables(999, 21, 12, p, p) == N.UZK_ERR_PARAMETER
     if b.device_count() == 0:
@@ -150,7 +156,7 @@ def test_no_cpp_exception_can_leave_an_entry_point():
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     defined = set()
-    for name in ("api.cpp", "prover.cpp"):
+    for name in ("api.cpp", "prover.cpp", "coalesce.cpp"):
         src = open(os.path.join(root, "uzkge_amd", "csrc", name)).read()
         for m in re.finditer(r"^int (uzk_[a-z0-9_]+)\([^;{]*\)\s*(try\s*)?\{", src, re.M):
             assert m.group(2), f"{name}: {m.group(1)} is not a function-try-block"

@@ -123,7 +123,7 @@ def test_rust_prover_drives_the_library_rounds_like_the_cpp_driver():
     per proof, and nothing else between them that touches the device; the Rust wrappers they go through call exactly those
     entry points."""
     cpp = re.sub(r"//.*", "", open(os.path.join(ROOT, "tests", "cpp", "prover_rounds.cpp")).read())
-    body = cpp[cpp.index("auto chain = [&]() {"):cpp.index("want_blinds = write_outputs;")]
+    body = cpp[cpp.index("void chain(int source"):cpp.index("std::vector<uint64_t> digest()")]
     assert _round_sequence(body, r"\buzk_prove_round(\d)\(") == list("12345")
     lib = open(os.path.join(RUST, "uzkge-gpu-sys", "src", "lib.rs")).read()
     for k in "12345":                                           # wrapper roundK -> uzk_prove_roundK and nothing else
@@ -134,10 +134,32 @@ def test_rust_prover_drives_the_library_rounds_like_the_cpp_driver():
     assert _round_sequence(rounds, r"prover\.round(\d)\(") == list("12345")
     # no device call of the old call-by-call flow is left in the glue: the only sys:: items it names are the three handles' types,
     # their constructors and the slot constants
-    assert set(re.findall(r"sys::([A-Za-z_0-9]+)", glue)) <= {"Circuit", "Prover", "Error", "uzk_g1_affine", "uzk_g1_jac", "uzk_circuit_desc",
+    assert set(re.findall(r"sys::([A-Za-z_0-9]+)", glue)) <= {"Circuit", "Prover", "Context", "Error", "uzk_g1_affine", "uzk_g1_jac", "uzk_circuit_desc",
                                                                "UZK_CIRCUIT_SLOTS", "UZK_CS_Q", "UZK_CS_S", "UZK_CS_L1", "UZK_CS_QB", "UZK_CS_QPRK",
                                                                "UZK_CS_QPK", "UZK_CS_QG", "UZK_CS_QECC", "domain_group_gen"}
-    assert len(glue.splitlines()) < 400                        # marshalling, not orchestration (was 786 lines of it)
+    assert len(glue.splitlines()) < 520                        # marshalling for any number of lanes, not orchestration (was 786 lines of it)
+
+
+def test_every_prover_thread_gets_a_context_and_a_shared_prover():
+    """the reference proves one proof per call from application threads (prover.rs:88-100, shuffle/src/sdk.rs:196-214).
+    The glue gives each such thread its own context (made current before anything else touches the device) and a prover of ONE
+    proof -- the kind the library shares between threads that prove at the same time (uzk_coalesce_config) -- and a host that holds
+    several witnesses can pass them together (prove_batch: one prng and one transcript per proof)."""
+    glue = _strip_rust_comments(open(os.path.join(RUST, "uzkge-glue", "gpu_prover.rs")).read())
+    assert "static CONTEXT: RefCell<Option<sys::Context>>" in glue
+    ctx_fn = glue[glue.index("fn thread_context()"):glue.index("fn thread_prover(")]
+    assert "sys::Context::new()" in ctx_fn and "make_current()" in ctx_fn
+    lanes_fn = glue[glue.index("fn prove_lanes<"):glue.index("fn rounds<")]
+    assert lanes_fn.index("thread_context()") < lanes_fn.index("resident(") < lanes_fn.index("thread_prover(n, lanes)")
+    assert "sys::Prover::new(n as u32, batch as u32)" in glue                       # batch = 1: uzk_prover_create's shared kind
+    prove = glue[glue.index("pub(super) fn prove<"):glue.index("pub fn prove_batch<")]
+    assert "prove_lanes::<R, PCS, CS>(&mut prngs, &mut transcripts" in prove and "&[cs]" in prove
+    batch = glue[glue.index("pub fn prove_batch<"):glue.index("fn prove_lanes<")]
+    assert "prngs: &mut [R]" in batch and "transcripts: &mut [Transcript]" in batch
+    lib = open(os.path.join(RUST, "uzkge-gpu-sys", "src", "lib.rs")).read()
+    assert "pub fn coalesce_config(" in lib and "pub fn on_device(" in lib and "pub fn new_private(" in lib
+    patch = open(os.path.join(RUST, "uzkge-gpu.patch")).read()
+    assert "prove_batch as gpu_prove_batch" in patch
 
 
 def test_circuit_identity_is_the_verifier_key_not_an_address():
@@ -209,7 +231,7 @@ def test_patch_applies_to_the_reference(tmp_path):
     params_rs = open(tmp_path / "shuffle/src/gen_params/params.rs").read()
     hook = params_rs.index("uzkge::plonk::gpu_refresh_public_key(")
     assert params_rs.index("compute_shuffle_public_key_selectors()") < hook < params_rs.index("let q_shuffle_public_key_polys: Vec<FpPolynomial<Fr>>")
-    proof_fields = re.findall(r"^        ([a-z_0-9]+)[,:]", glue[glue.index("Ok(PlonkProof {"):], flags=re.M)
+    proof_fields = re.findall(r"^            ([a-z_0-9]+)[,:]", glue[glue.index("proofs.push(PlonkProof {"):glue.index("Ok(proofs)")], flags=re.M)
     for field in proof_fields:
         assert re.search(rf"pub {field}:", indexer), f"PlonkProof has no field {field}"
     assert len(proof_fields) == 14

@@ -34,7 +34,7 @@ EDITS = {
         ('/// Module for help functions.\npub(crate) mod helpers;\n',
          '/// Module for help functions.\npub(crate) mod helpers;\n\n'
          '/// `prover_with_lagrange` with the proof\'s polynomials resident on the MI355X.\n#[cfg(feature = "gpu")]\nmod gpu_prover;\n'
-         '#[cfg(feature = "gpu")]\npub use gpu_prover::release_circuits;\n'
+         '#[cfg(feature = "gpu")]\npub use gpu_prover::{prove_batch as gpu_prove_batch, release_circuits};\n'
          '#[cfg(all(feature = "gpu", feature = "shuffle"))]\npub use gpu_prover::refresh_public_key as gpu_refresh_public_key;\n'),
     ],
     "shuffle/Cargo.toml": [

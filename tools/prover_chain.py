@@ -145,16 +145,15 @@ class ProverChain:
         self.inputs, self.shuffle = inp, shuffle
         n = self.n
         b.tune("msm_no_precompute", 0)
-        # a random circuit is satisfied by nothing: its t fills all 6n coefficients, and round 3 would refuse it (as the reference
-        # aborts on it).  The timing / parity chains take t as its first t_len coefficients (tests/chain_oracle.py does the same);
-        # circuits made satisfiable (tests/plonk_verifier_oracle.py) run the real check.
-        b.tune("prover_t_cap", 0 if getattr(inp, "satisfiable", False) else 1)
         polys = [self.table_polys[i] for i in range(N_TABLES)]
         if getattr(inp, "satisfiable", False):
             polys[T_CQ] = None               # coset_quotient: the library builds it (the random circuits keep their arbitrary slot 20)
+        # a random circuit is satisfied by nothing: its t fills all 6n coefficients, and round 3 would refuse it (as the reference
+        # aborts on it).  The timing / parity chains mark it synthetic: t is taken as its first t_len coefficients
+        # (tests/chain_oracle.py does the same); circuits made satisfiable (tests/plonk_verifier_oracle.py) run the real check.
         self.circuit = b.Circuit(n, self.lagrange_wire, self.bases[n:], self.perm, self.k, self.anemoi_g, self.anemoi_g_inv, self.edwards_a,
-                                 polys, shuffle=shuffle, precompute=precompute)
-        self.prover = b.Prover(n, 1)
+                                 polys, shuffle=shuffle, precompute=precompute, synthetic=not getattr(inp, "satisfiable", False))
+        self.prover = b.Prover(n, 1, shared=False)       # its buffers are read back (snapshot, tq_ptrs)
         self.cs = n + 8
         self._srs = None
         self.witness = np.ascontiguousarray(self.w_evals.reshape(1, N_WIRES * n, 4))

@@ -19,7 +19,7 @@ import prover_chain as pch
 
 def run(B, inp, cir, reps):
     n = inp.n
-    pr = b.Prover(n, B)
+    pr = b.Prover(n, B, shared=False)        # profiled on the calling context
     rep = lambda a: np.concatenate([np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)] * B)
     hiding = list(pch.HIDE_W) + [pch.HIDE_WSEL] * 3
     w, s = rep(inp.w_evals).reshape(B, 5 * n, 4), rep(inp.wsel_evals).reshape(B, 3 * n, 4)
@@ -60,9 +60,8 @@ if __name__ == "__main__":
     a = ap.parse_args()
     b.init(0)
     inp = pch.ChainInputs(1 << a.log_n, 11)
-    b.tune("prover_t_cap", 1)
     cir = b.Circuit(inp.n, inp.lagrange_wire, inp.bases[inp.n:], inp.perm, inp.k, inp.anemoi_g, inp.anemoi_g_inv, inp.edwards_a,
-                    [inp.table_polys[i] for i in range(pch.N_TABLES)], precompute=True)
+                    [inp.table_polys[i] for i in range(pch.N_TABLES)], precompute=True, synthetic=True)
     for B in [int(x) for x in a.batch.split(",")]:
         print(json.dumps(run(B, inp, cir, a.reps)))
     cir.release()

@@ -13,11 +13,10 @@ ap = argparse.ArgumentParser(); ap.add_argument("--log-n", type=int, default=14)
 a = ap.parse_args()
 b.init(0)
 inp = pch.ChainInputs(1 << a.log_n, 11)
-b.tune("prover_t_cap", 1)
 n = inp.n
 cir = b.Circuit(n, inp.lagrange_wire, inp.bases[n:], inp.perm, inp.k, inp.anemoi_g, inp.anemoi_g_inv, inp.edwards_a,
-                [inp.table_polys[i] for i in range(pch.N_TABLES)], precompute=a.precompute)
-pr = b.Prover(n, 1)
+                [inp.table_polys[i] for i in range(pch.N_TABLES)], precompute=a.precompute, synthetic=True)
+pr = b.Prover(n, 1, shared=False)          # profiled on the calling context
 hiding = list(pch.HIDE_W) + [pch.HIDE_WSEL] * 3
 w, s = inp.w_evals.reshape(1, 5 * n, 4), inp.wsel_evals.reshape(1, 3 * n, 4)
 bl = np.concatenate([inp.blinds_w, inp.blinds_wsel])

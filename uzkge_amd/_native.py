@@ -26,6 +26,8 @@ PROTOTYPES = {
     "uzk_last_error": (ctypes.c_char_p, []),
     "uzk_version": (ctypes.c_char_p, []),
     "uzk_ctx_create": (_I, [ctypes.POINTER(_U64)]),
+    "uzk_ctx_create_on": (_I, [_I, ctypes.POINTER(_U64)]),
+    "uzk_ctx_device": (_I, [_U64, ctypes.POINTER(_I)]),
     "uzk_ctx_set_current": (_I, [_U64]),
     "uzk_ctx_destroy": (_I, [_U64]),
     "uzk_ctx_wait": (_I, [_U64]),
@@ -80,13 +82,18 @@ PROTOTYPES = {
     "uzk_preprocess_tables": (_I, [_U64, ctypes.c_uint32, ctypes.c_uint32, _P, _P, _P, _P, _P, _P]),
     "uzk_circuit_table": (_I, [_U64, ctypes.c_uint32, _I, ctypes.POINTER(_P), ctypes.POINTER(_U64)]),
     "uzk_circuit_release": (_I, [_U64]),
+    "uzk_circuit_info": (_I, [_U64, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(_I)]),
+    "uzk_test_circuit_truncate_t": (_I, [_U64, _I]),
     "uzk_prover_create": (_I, [ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_U64)]),
+    "uzk_prover_create_private": (_I, [ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_U64)]),
+    "uzk_coalesce_config": (_I, [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]),
+    "uzk_coalesce_stats": (_I, [ctypes.POINTER(_U64)]),
     "uzk_prover_destroy": (_I, [_U64]),
     "uzk_prove_round1": (_I, [_U64, _U64, _P, _P, _I, _P, _P, ctypes.c_uint32, _P, _P, _P]),
     "uzk_prove_round2": (_I, [_U64, _P, _P, _P, _P]),
     "uzk_prove_round3": (_I, [_U64, _P, _P, _P]),
-    "uzk_prove_round4": (_I, [_U64, _P, _P]),
-    "uzk_prove_round5": (_I, [_U64, _P, _P, _P, _P]),
+    "uzk_prove_round4": (_I, [_U64, _P, _P, _SZ]),
+    "uzk_prove_round5": (_I, [_U64, _P, _SZ, _P, _P, _P]),
     "uzk_prover_buffer": (_I, [_U64, _I, ctypes.POINTER(_P), ctypes.POINTER(_U64)]),
     "uzk_synth_points_arith": (_I, [_P, _SZ, _P]),
     "uzk_synth_points_random": (_I, [_P, _SZ, _U64]),

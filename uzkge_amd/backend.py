@@ -548,7 +548,7 @@ class Circuit:
     """A circuit resident in HBM (uzk_circuit_create): commit bases, permutation, the 46 (21) polynomials and their coset tables."""
 
     def __init__(self, n: int, lagrange_bases: np.ndarray, blind_bases: np.ndarray, permutation: np.ndarray, k: np.ndarray, anemoi_g, anemoi_g_inv,
-                 edwards_a, polys, shuffle: bool = True, precompute: bool = False, group_gen=None, lens=None):
+                 edwards_a, polys, shuffle: bool = True, precompute: bool = False, group_gen=None, lens=None, synthetic: bool = False):
         d = N.CircuitDesc()
         d.n, d.shuffle, d.precompute = n, int(shuffle), int(precompute)
         keep = []
@@ -579,6 +579,19 @@ class Circuit:
         h = ctypes.c_uint64(0)
         check(lib.uzk_circuit_create(ctypes.byref(d), ctypes.byref(h)))
         self.handle, self.n, self.shuffle, self.n_slots = h.value, n, shuffle, n_slots
+        if synthetic:
+            self.truncate_t(True)
+
+    def truncate_t(self, on: bool) -> None:
+        """TESTS / TIMING ONLY (uzk_test_circuit_truncate_t): a synthetic circuit no witness satisfies -- round 3 reads t as its
+        first 5n - 2 + sum(hiding) coefficients, as tests/chain_oracle.py does."""
+        check(lib.uzk_test_circuit_truncate_t(self.handle, int(on)))
+
+    def info(self):
+        """(n, evaluations per proof in round 4, r_poly scalars per proof in round 5, device)."""
+        a, e, r, dv = ctypes.c_uint32(0), ctypes.c_uint32(0), ctypes.c_uint32(0), ctypes.c_int(0)
+        check(lib.uzk_circuit_info(self.handle, ctypes.byref(a), ctypes.byref(e), ctypes.byref(r), ctypes.byref(dv)))
+        return a.value, e.value, r.value, dv.value
 
     def update_tables(self, first_slot: int, polys, lens=None) -> None:
         arrs = [np.ascontiguousarray(p, dtype=np.uint64).reshape(-1, 4) for p in polys]
@@ -625,12 +638,26 @@ def preprocess_tables_device(srs: Srs, evals: np.ndarray, k1=None, want_coset: b
     return polys, lens, coset, cms
 
 
-class Prover:
-    """The device buffers of `batch` proofs in lockstep (uzk_prover_create) and the five rounds."""
+def coalesce_config(max_lanes: int = 8, gather_wait_us: int = 50, straggler_wait_us: int = 2000) -> None:
+    """uzk_coalesce_config: how provers of one proof made from now on are shared (max_lanes <= 1: not at all)."""
+    check(lib.uzk_coalesce_config(max_lanes, gather_wait_us, straggler_wait_us))
 
-    def __init__(self, n: int, batch: int = 1):
+
+def coalesce_stats() -> dict:
+    """uzk_coalesce_stats since the last coalesce_config."""
+    a = (ctypes.c_uint64 * 5)()
+    check(lib.uzk_coalesce_stats(a))
+    return dict(rounds=a[0], calls=a[1], widest=a[2], moved_out=a[3], groups=a[4])
+
+
+class Prover:
+    """The device buffers of `batch` proofs in lockstep (uzk_prover_create) and the five rounds.  shared=True with batch == 1 is
+    the library's default kind -- a prover of one proof whose concurrent round calls the library may run together with other
+    threads' (uzk_coalesce_config); shared=False (uzk_prover_create_private) owns its lanes and can show its buffers."""
+
+    def __init__(self, n: int, batch: int = 1, shared: bool = True):
         h = ctypes.c_uint64(0)
-        check(lib.uzk_prover_create(n, batch, ctypes.byref(h)))
+        check((lib.uzk_prover_create if shared else lib.uzk_prover_create_private)(n, batch, ctypes.byref(h)))
         self.handle, self.n, self.batch = h.value, n, batch
 
     def round1(self, circuit: Circuit, witness, wsel, pi_index, pi_value, hiding, blinds, on_device: bool = False) -> np.ndarray:
@@ -666,14 +693,14 @@ class Prover:
     def round4(self, zeta, shuffle: bool = True) -> np.ndarray:
         B, per = self.batch, 19 if shuffle else 15
         out = np.zeros((B * per, 4), dtype=np.uint64)
-        check(lib.uzk_prove_round4(self.handle, _ptr(_frs(zeta, B)), _ptr(out)))
+        check(lib.uzk_prove_round4(self.handle, _ptr(_frs(zeta, B)), _ptr(out), B * per))
         return out
 
     def round5(self, r_scalars, alpha_zeta, alpha_zeta_omega) -> np.ndarray:
         B = self.batch
         rs = np.ascontiguousarray(r_scalars, dtype=np.uint64).reshape(-1, 4)
         out = np.zeros((2 * B, 12), dtype=np.uint64)
-        check(lib.uzk_prove_round5(self.handle, _ptr(rs), _ptr(_frs(alpha_zeta, B)), _ptr(_frs(alpha_zeta_omega, B)), _ptr(out)))
+        check(lib.uzk_prove_round5(self.handle, _ptr(rs), rs.shape[0], _ptr(_frs(alpha_zeta, B)), _ptr(_frs(alpha_zeta_omega, B)), _ptr(out)))
         return out
 
     def buffer(self, which: int):

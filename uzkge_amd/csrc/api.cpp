@@ -42,7 +42,9 @@ int on_exception(const char* fn) noexcept {
 struct Shared {
     std::mutex mu;
     bool bound = false;
-    int device = -1, num_cus = 256;
+    int device = -1;                       // the process's default device (uzk_init); contexts of uzk_ctx_create_on name their own
+    std::map<int, int> num_cus;            // per device that a context has been made ready on
+
     std::map<uint64_t, Ctx::Srs> srs;
     uint64_t next_handle = 1;
     std::map<uint64_t, Ctx*> contexts;
@@ -64,8 +66,13 @@ static Ctx& default_ctx() {
 static thread_local uint64_t t_handle = 0;          // 0: the default context
 static thread_local Ctx* t_cached = nullptr;
 static thread_local uint64_t t_epoch = 0;
+static thread_local Ctx* t_scope = nullptr;         // CtxScope: a library-internal context while a shared round runs on this thread
+
+CtxScope::CtxScope(Ctx* c) : prev(t_scope) { t_scope = c; }
+CtxScope::~CtxScope() { t_scope = prev; }
 
 Ctx& ctx() {
+    if (t_scope) return *t_scope;
     if (t_handle == 0) return default_ctx();
     Shared& s = shared();
     if (t_cached && t_epoch == s.epoch.load(std::memory_order_acquire)) return *t_cached;
@@ -146,12 +153,22 @@ int Ctx::prof_collect() {
 // returns to it instead of silently moving to device 0.
 static int g_last_device = 0;
 
-// binds the process to `device` (Shared::mu held by the caller)
+// compute units of `device` (Shared::mu held by the caller); the device becomes one uzk_shutdown synchronises
+static int device_cus_locked(Shared& s, int device, int* cus) {
+    auto it = s.num_cus.find(device);
+    if (it == s.num_cus.end()) {
+        int v = 0;
+        UZK_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device));
+        it = s.num_cus.emplace(device, v > 0 ? v : 256).first;
+    }
+    *cus = it->second;
+    return UZK_OK;
+}
+// binds the process's default device (Shared::mu held by the caller)
 static int bind_device_locked(Shared& s, int device) {
     UZK_HIP(hipSetDevice(device));
-    hipDeviceProp_t prop;
-    UZK_HIP(hipGetDeviceProperties(&prop, device));
-    s.num_cus = prop.multiProcessorCount;
+    int cus = 0;
+    UZK_TRY(device_cus_locked(s, device, &cus));
     s.device = device;
     s.bound = true;
     g_last_device = device;
@@ -175,11 +192,11 @@ int require_ready() {
             }
             UZK_TRY(bind_device_locked(s, g_last_device < n ? g_last_device : 0));
         }
-        device = s.device;
-        c.num_cus = s.num_cus;
+        device = c.want_device >= 0 ? c.want_device : s.device;
+        UZK_TRY(device_cus_locked(s, device, &c.num_cus));
     }
     // HIP's current device is per thread: a prover thread that never called uzk_init would otherwise
-    // allocate and launch on device 0 while the streams and the SRS live on the bound device
+    // allocate and launch on device 0 while the streams and the SRS live on the context's device
     UZK_HIP(hipSetDevice(device));
     if (!c.ready) {
         UZK_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
@@ -189,9 +206,20 @@ int require_ready() {
     return UZK_OK;
 }
 
+void devices_synchronize() {
+    Shared& s = shared();
+    std::vector<int> devs;
+    {
+        std::lock_guard<std::mutex> lk(s.mu);
+        for (auto& kv : s.num_cus) devs.push_back(kv.first);
+    }
+    for (int d : devs) { (void)hipSetDevice(d); (void)hipDeviceSynchronize(); }
+}
+
 // frees everything a context owns (its mutex held, or no other user left)
 static void ctx_release(Ctx& c) {
     if (!c.ready) return;
+    (void)hipSetDevice(c.device);
     (void)hipStreamSynchronize(c.stream);
     ntt_free_plans(c);
     msm_free(c);
@@ -210,6 +238,22 @@ static void ctx_release(Ctx& c) {
 }
 
 static const Fp* as_fp(const uint64_t* p) { return reinterpret_cast<const Fp*>(p); }
+
+static void copy_tuning(const Ctx& from, Ctx& to);
+int ctx_init_internal(Ctx& c, int device) {
+    c.want_device = device;
+    {
+        std::lock_guard<std::mutex> lk(default_ctx().mu);
+        copy_tuning(default_ctx(), c);
+    }
+    CtxScope scope(&c);
+    std::lock_guard<std::mutex> lk(c.mu);
+    return require_ready();
+}
+void ctx_release_internal(Ctx& c) {
+    std::lock_guard<std::mutex> lk(c.mu);
+    ctx_release(c);
+}
 
 }  // namespace uzk
 
@@ -262,10 +306,10 @@ int uzk_init(int device) try {
 // belongs to the caller and is not touched.
 int uzk_shutdown(void) try {
     Shared& s = shared();
-    prover_release_all();                  // circuits and provers own device memory and SRS entries (takes Shared::mu itself)
+    coalesce_release_all();                // shared provers, their workspaces and internal contexts
+    prover_release_all();                  // circuits and provers own device memory (takes Shared::mu itself)
     std::lock_guard<std::mutex> lk(s.mu);
     if (!s.bound) return UZK_OK;
-    (void)hipSetDevice(s.device);
     ctx_release(default_ctx());
     for (auto& kv : s.contexts) { ctx_release(*kv.second); delete kv.second; }
     s.contexts.clear();
@@ -273,10 +317,12 @@ int uzk_shutdown(void) try {
     t_handle = 0;
     t_cached = nullptr;
     for (auto& kv : s.srs) {
+        (void)hipSetDevice(kv.second.device);
         if (kv.second.owned && kv.second.d_points) (void)hipFree(kv.second.d_points);
         if (kv.second.d_table) (void)hipFree(kv.second.d_table);
     }
     s.srs.clear();
+    s.num_cus.clear();
     s.bound = false;
     s.device = -1;
     return UZK_OK;
@@ -285,6 +331,7 @@ int uzk_shutdown(void) try {
 /* ---- contexts ------------------------------------------------------------------------------- */
 // the experiment switches and the forced window width travel with the creator: a tool that tunes the default context
 // and then starts prover threads measures what it configured
+namespace uzk {
 static void copy_tuning(const Ctx& from, Ctx& to) {
     to.msm_window_bits = from.msm_window_bits;
     to.tune_acc_variant = from.tune_acc_variant; to.tune_task_len = from.tune_task_len; to.tune_no_precompute = from.tune_no_precompute;
@@ -295,6 +342,7 @@ static void copy_tuning(const Ctx& from, Ctx& to) {
     to.tune_fold_mode = from.tune_fold_mode; to.tune_chunk_log = from.tune_chunk_log; to.tune_overlap = from.tune_overlap;
     to.tune_seg_sort = from.tune_seg_sort; to.tune_direct = from.tune_direct; to.tune_bucket_fill = from.tune_bucket_fill; to.tune_fold_big = from.tune_fold_big; to.tune_scan_nb_log = from.tune_scan_nb_log; to.tune_ntt_prio = from.tune_ntt_prio; to.tune_ntt_order = from.tune_ntt_order; to.tune_class_reduce = from.tune_class_reduce; to.tune_chunk_sort = from.tune_chunk_sort; to.tune_scatter4 = from.tune_scatter4; to.tune_stream_log = from.tune_stream_log; to.tune_stream_min_log = from.tune_stream_min_log; to.tune_prover_t_cap = from.tune_prover_t_cap; to.tune_ntt_mulc = from.tune_ntt_mulc; to.tune_ntt_planes = from.tune_ntt_planes;
 }
+}  // namespace uzk
 int uzk_ctx_create(uint64_t* ctx_out) try {
     if (!ctx_out) { set_error("uzk_ctx_create: null pointer"); return UZK_ERR_PARAMETER; }
     Ctx* c = new Ctx();
@@ -311,6 +359,41 @@ int uzk_ctx_create(uint64_t* ctx_out) try {
     *ctx_out = h;
     return UZK_OK;
 } catch (...) { return uzk::on_exception("uzk_ctx_create"); }
+// A context on a named device: one process can then drive several GPUs -- a pool of prover threads, each with a context (and its
+// circuits and provers) on its own device, or the point chunks of one MSM (uzk_msm_g1_sharded).  uzk_init keeps its meaning: the
+// device of the default context and of uzk_ctx_create.
+int uzk_ctx_create_on(int device, uint64_t* ctx_out) try {
+    if (!ctx_out) { set_error("uzk_ctx_create_on: null pointer"); return UZK_ERR_PARAMETER; }
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { set_error("no HIP device visible: the MI355X backend has no CPU fallback"); return UZK_ERR_DEVICE; }
+    if (device < 0 || device >= n) { set_error("uzk_ctx_create_on(%d): %d device(s) visible", device, n); return UZK_ERR_PARAMETER; }
+    Ctx* c = new Ctx();
+    {
+        API_LOCK;
+        copy_tuning(ctx(), *c);
+    }
+    c->want_device = device;
+    Shared& s = shared();
+    std::lock_guard<std::mutex> lk(s.mu);
+    const uint64_t h = s.next_ctx++;
+    s.contexts[h] = c;
+    *ctx_out = h;
+    return UZK_OK;
+} catch (...) { return uzk::on_exception("uzk_ctx_create_on"); }
+int uzk_ctx_device(uint64_t handle, int* device_out) try {
+    if (!device_out) { set_error("uzk_ctx_device: null pointer"); return UZK_ERR_PARAMETER; }
+    Shared& s = shared();
+    std::lock_guard<std::mutex> lk(s.mu);
+    Ctx* c = nullptr;
+    if (handle == 0) c = &default_ctx();
+    else {
+        auto it = s.contexts.find(handle);
+        if (it == s.contexts.end()) { set_error("uzk_ctx_device: unknown context %llu", (unsigned long long)handle); return UZK_ERR_PARAMETER; }
+        c = it->second;
+    }
+    *device_out = c->ready ? c->device : (c->want_device >= 0 ? c->want_device : (s.bound ? s.device : g_last_device));
+    return UZK_OK;
+} catch (...) { return uzk::on_exception("uzk_ctx_device"); }
 int uzk_ctx_set_current(uint64_t handle) try {
     if (handle == 0) { t_handle = 0; t_cached = nullptr; return UZK_OK; }
     Shared& s = shared();
@@ -332,7 +415,6 @@ int uzk_ctx_destroy(uint64_t handle) try {
         c = it->second;
         s.contexts.erase(it);
         s.epoch.fetch_add(1, std::memory_order_acq_rel);   // every thread's cached pointer is looked up again
-        if (s.bound) (void)hipSetDevice(s.device);
     }
     if (t_handle == handle) { t_handle = 0; t_cached = nullptr; }
     { std::lock_guard<std::mutex> lk(c->mu); ctx_release(*c); }
@@ -417,17 +499,25 @@ int uzk_host_free(void* h_ptr) try {
     API_LOCK;
     if (!h_ptr) return UZK_OK;
     UZK_TRY(require_ready());
+    Shared& s = shared();
+    size_t bytes = 0;
     {
-        Shared& s = shared();
+        // the entry goes BEFORE the memory does: once hipHostFree has run, another context's uzk_host_alloc may be handed the same
+        // address and register it -- an erase after the free would then remove the new block's entry
         std::lock_guard<std::mutex> lk(s.mu);
-        if (s.pinned.find(h_ptr) == s.pinned.end()) { set_error("uzk_host_free: %p is not a block of uzk_host_alloc", h_ptr); return UZK_ERR_PARAMETER; }
+        auto it = s.pinned.find(h_ptr);
+        if (it == s.pinned.end()) { set_error("uzk_host_free: %p is not a block of uzk_host_alloc", h_ptr); return UZK_ERR_PARAMETER; }
+        bytes = it->second;
+        s.pinned.erase(it);
     }
-    UZK_HIP(hipStreamSynchronize(ctx().stream));
-    UZK_HIP(hipHostFree(h_ptr));
-    {   // only now is the block gone: a failure above leaves it registered (still pinned, still freeable)
-        Shared& s = shared();
+    hipError_t e = hipStreamSynchronize(ctx().stream);
+    if (e == hipSuccess) e = hipHostFree(h_ptr);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
         std::lock_guard<std::mutex> lk(s.mu);
-        s.pinned.erase(h_ptr);
+        s.pinned[h_ptr] = bytes;            // still allocated: still pinned, still freeable
+        set_error("uzk_host_free: %s", hipGetErrorString(e));
+        return UZK_ERR_DEVICE;
     }
     return UZK_OK;
 } catch (...) { return uzk::on_exception("uzk_host_free"); }
@@ -517,11 +607,6 @@ bool srs_erase(uint64_t handle, Ctx::Srs* out) {
     s.srs.erase(it);
     return true;
 }
-int bound_device() {
-    Shared& s = shared();
-    std::lock_guard<std::mutex> lk(s.mu);
-    return s.bound ? s.device : -1;
-}
 }  // namespace uzk
 extern "C" {
 
@@ -533,6 +618,7 @@ int uzk_srs_register(const uzk_g1_affine* points, size_t n, uint64_t* handle_out
     Ctx::Srs s;
     s.n = n;
     s.owned = true;
+    s.device = c.device;
     if (n > 0) {
         UZK_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_points), n * sizeof(Affine)));
         UZK_HIP(hipMemcpyAsync(s.d_points, points, n * sizeof(Affine), hipMemcpyHostToDevice, c.stream));
@@ -549,6 +635,7 @@ int uzk_srs_register_device(const void* d_points, size_t n, uint64_t* handle_out
     Ctx::Srs s;
     s.n = n;
     s.owned = false;
+    s.device = ctx().device;
     s.d_points = const_cast<Affine*>(static_cast<const Affine*>(d_points));
     *handle_out = srs_insert(s);
     return UZK_OK;
@@ -566,9 +653,9 @@ int uzk_srs_release(uint64_t handle) try {
         if (it == sh.srs.end()) { set_error("uzk_srs_release: unknown handle %llu", (unsigned long long)handle); return UZK_ERR_PARAMETER; }
         e = it->second;
         sh.srs.erase(it);
-        if (sh.bound) (void)hipSetDevice(sh.device);
     }
     if (c.ready) (void)hipStreamSynchronize(c.stream);
+    (void)hipSetDevice(e.device);
     if (e.owned && e.d_points) (void)hipFree(e.d_points);
     if (e.d_table) (void)hipFree(e.d_table);
     return UZK_OK;
@@ -586,6 +673,7 @@ int uzk_srs_precompute(uint64_t handle, int window_bits) try {
         return UZK_ERR_PARAMETER;
     }
     if (s.n == 0) return UZK_OK;
+    if (s.device != c.device) { set_error("uzk_srs_precompute: the SRS lives on device %d, the calling context on device %d", s.device, c.device); return UZK_ERR_PARAMETER; }
     const int cb = msm_precompute_window_bits(s.n, window_bits);
     if (s.d_table && s.pre_c == cb) return UZK_OK;
     Affine* old_table = s.d_table;
@@ -620,6 +708,7 @@ static int msm_checked(uint64_t srs_handle, size_t offset, size_t n, Ctx::Srs* s
         set_error("msm: offset %zu + n %zu exceeds SRS length %zu", offset, n, srs_out->n);
         return UZK_ERR_DEGREE;
     }
+    if (srs_out->device != ctx().device) { set_error("msm: the SRS lives on device %d, the calling context on device %d", srs_out->device, ctx().device); return UZK_ERR_PARAMETER; }
     return UZK_OK;
 }
 }  // extern "C"

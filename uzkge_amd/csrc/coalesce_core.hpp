@@ -1,0 +1,305 @@
+// Gathering concurrent one-proof callers into lockstep launches: the synchronisation core, free of HIP so that it also builds
+// with plain g++ under ThreadSanitizer (tests/cpp/coalesce_core_test.cpp drives it with a fake backend).
+//
+// The reference proves ONE proof per call from whatever thread the application runs (prover_with_lagrange,
+// uzkge/src/plonk/prover.rs:88-100; zshuffle's SDK, shuffle/src/sdk.rs:196-214), and at n = 2^14 one proof leaves most of an
+// MI355X idle.  The library therefore merges callers that stand at the same round of proofs over the same circuit:
+//
+//   * round 1: the first caller opens a COHORT and waits a bounded time (gather_wait) for others -- not at all when no other
+//     prover of its kind is idle; whoever completes the cohort (it is full, the wait is over, nobody else can come) runs the
+//     round for every lane on its own thread and wakes the rest;
+//   * rounds 2..R: the cohort's members meet again; the last to arrive runs the round.  A member that stays away longer than
+//     straggler_wait is MOVED OUT: the backend copies its lane into the member's own workspace, where its proof goes on alone;
+//   * a lane whose own data is at fault fails alone; a member that abandons its proof (destroys the prover, starts another
+//     proof) leaves the cohort, which goes on without it.
+// Every caller gets exactly the result a prover of one proof would have given it.
+//
+// Backend (template parameter), all called WITHOUT the core's lock held, from the thread that runs the round:
+//   struct CohortData;  struct MemberData;                              opaque to the core
+//   int  open (CohortData&, MemberData& leader, uint32_t lanes);          choose the workspace of a new cohort (lanes == 1: the leader's own)
+//   int  run  (CohortData&, int round, uint32_t lanes, void* const* args, const uint8_t* present, int* lane_rc, std::string* lane_msg);
+//                                                                         one round over lanes [0, lanes); args[l] null <=> !present[l];
+//                                                                         a non-zero return fails every lane
+//   int  move_out(CohortData& from, uint32_t lane, MemberData& to, CohortData& solo);   lane -> the member's own workspace, as a cohort of one
+//   void close(CohortData&);                                              the cohort is over (last round done, failed, or everyone left)
+#pragma once
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <cstdint>
+#include <cstring>
+#include <list>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace uzk {
+
+template <class Backend>
+class CoalesceCore {
+public:
+    using Clock = std::chrono::steady_clock;
+    static constexpr int kErrParameter = 1;      // UZK_ERR_PARAMETER (static_assert in coalesce.cpp)
+
+    struct Cohort;
+    struct Member {
+        typename Backend::MemberData data;
+        uint64_t group = 0;                      // members of one group can share a cohort at all (same n, same device)
+        std::shared_ptr<Cohort> cohort;
+        uint32_t lane = 0;
+        int round = 0;                           // rounds completed of the proof in flight
+        bool in_call = false, moving = false;
+        std::chrono::steady_clock::time_point last_seen{};   // when it last left a call
+    };
+    // what must agree for two round-1 calls to share a cohort; `blob` is compared bytewise (circuit, hiding degrees, public-input indices ...)
+    struct Key {
+        uint64_t group = 0;
+        std::string blob;
+        bool operator==(const Key& o) const { return group == o.group && blob == o.blob; }
+    };
+    struct LaneRec {
+        Member* m = nullptr;                     // null: the member has left, the lane is dead
+        bool here = false;
+        void* args = nullptr;
+        int done_round = 0, rc = 0;
+        std::string msg;
+    };
+    struct Cohort {
+        Key key;
+        bool gathering = true, running = false;
+        int next_round = 1;
+        uint32_t alive = 0, arrived = 0;
+        std::vector<LaneRec> lanes;
+        Clock::time_point deadline;
+        std::condition_variable cv;
+        typename Backend::CohortData data;
+    };
+
+    CoalesceCore(Backend& b, int rounds) : backend_(b), rounds_(rounds) {}
+
+    void configure(uint32_t max_lanes, uint32_t gather_wait_us, uint32_t straggler_wait_us) {
+        std::lock_guard<std::mutex> lk(mu_);
+        max_lanes_ = std::max<uint32_t>(1, max_lanes);
+        gather_wait_ = std::chrono::microseconds(gather_wait_us);
+        straggler_wait_ = std::chrono::microseconds(std::max<uint32_t>(1, straggler_wait_us));
+        stats_ = Stats();
+    }
+    uint32_t max_lanes() { std::lock_guard<std::mutex> lk(mu_); return max_lanes_; }
+    // rounds run, lanes (callers) served by them, the widest round, lanes moved out, cohorts opened -- since the last configure()
+    struct Stats { uint64_t rounds = 0, lanes = 0, widest = 0, moved_out = 0, cohorts = 0; };
+    Stats stats() { std::lock_guard<std::mutex> lk(mu_); return stats_; }
+
+    void add(Member* m) { std::lock_guard<std::mutex> lk(mu_); members_.push_back(m); }
+    // false: the member is inside a call on another thread (it stays registered)
+    bool remove(Member* m) {
+        std::unique_lock<std::mutex> lk(mu_);
+        if (m->in_call) return false;
+        leave_locked(m, lk);
+        members_.remove(m);
+        return true;
+    }
+    // the member gives up the proof it has in flight, if any
+    void abandon(Member* m) {
+        std::unique_lock<std::mutex> lk(mu_);
+        if (!m->in_call) leave_locked(m, lk);
+    }
+    int rounds_done(Member* m) { std::lock_guard<std::mutex> lk(mu_); return m->round; }
+
+    // One round of one member's proof.  Returns the lane's result code; *msg receives its error text.  key: round 1 only.
+    int enter(Member* m, int round, const Key* key, void* args, std::string* msg) {
+        std::unique_lock<std::mutex> lk(mu_);
+        if (m->in_call) { *msg = "the prover is inside another call (one thread at a time per prover)"; return kErrParameter; }
+        m->in_call = true;
+        struct Out { Member* m; ~Out() { m->in_call = false; m->last_seen = Clock::now(); } } out{m};     // runs with the lock held (lk is destroyed after it)
+        while (m->moving) move_cv_.wait(lk);
+        std::shared_ptr<Cohort> g;
+        if (round == 1) {
+            leave_locked(m, lk);                 // a proof in flight is abandoned
+            for (auto& c : gathering_)
+                if (c->key == *key && c->lanes.size() < max_lanes_) { g = c; break; }
+            if (!g) {
+                g = std::make_shared<Cohort>();
+                g->key = *key;
+                g->deadline = Clock::now() + gather_wait_;
+                gathering_.push_back(g);
+            }
+            m->cohort = g;
+            m->lane = (uint32_t)g->lanes.size();
+            m->round = 0;
+            g->lanes.emplace_back();
+            g->alive++;
+        } else {
+            if (!m->cohort || m->round != round - 1) {
+                *msg = "the prover has completed " + std::to_string(m->cohort ? m->round : 0) + " round(s) of its proof, this call needs " + std::to_string(round - 1);
+                return kErrParameter;
+            }
+            g = m->cohort;
+        }
+        {
+            LaneRec& l = g->lanes[m->lane];
+            l.m = m; l.args = args; l.here = true;
+            g->arrived++;
+        }
+        const uint32_t lane = m->lane;
+        for (;;) {
+            // (an ejected member's cohort changes under it only while it is NOT in a call, so g stays m's cohort here)
+            LaneRec& l = g->lanes[lane];
+            if (l.done_round >= round) break;
+            if (!g->running) {
+                if (g->gathering) {
+                    const auto now = Clock::now();
+                    if (g->lanes.size() >= max_lanes_ || now >= g->deadline || company_in_sight(g.get(), now) == 0) { run_round(g, lk, false); continue; }
+                    wait(g->cv, lk, g->deadline - now);
+                    continue;
+                }
+                if (g->arrived == g->alive) { run_round(g, lk, false); continue; }
+                if (wait(g->cv, lk, straggler_wait_) && !g->running && !g->gathering && g->lanes[lane].done_round < round && g->arrived < g->alive)
+                    run_round(g, lk, true);
+                continue;
+            }
+            g->cv.wait(lk);
+        }
+        LaneRec& l = g->lanes[lane];
+        const int rc = l.rc;
+        if (rc != 0) *msg = l.msg;
+        return rc;
+    }
+
+private:
+    // true: the wait timed out.  (ThreadSanitizer builds wait on the system clock: GCC 11's runtime does not know
+    // pthread_cond_clockwait, which the steady-clock waits use, and would report the mutex as held throughout.)
+    template <class Dur>
+    static bool wait(std::condition_variable& cv, std::unique_lock<std::mutex>& lk, Dur d) {
+#if defined(__SANITIZE_THREAD__)
+        return cv.wait_until(lk, std::chrono::system_clock::now() + d) == std::cv_status::timeout;
+#else
+        return cv.wait_for(lk, d) == std::cv_status::timeout;
+#endif
+    }
+
+    // Members of g's group that could still join it before its wait is over: provers between two proofs that were at work a moment
+    // ago (their threads are probably about to start the next proof), and provers in the LAST round of a proof (they come back
+    // for the next one when it ends).  Provers in the middle of a proof cannot arrive within gather_wait; provers that have been
+    // idle for long belong to threads that are doing something else.
+    uint32_t company_in_sight(const Cohort* g, Clock::time_point now) const {
+        uint32_t c = 0;
+        for (const Member* o : members_) {
+            if (o->group != g->key.group || o->cohort.get() == g) continue;
+            if (!o->cohort) { if (o->in_call || now - o->last_seen < recent_) ++c; }
+            else if (!o->cohort->gathering && o->cohort->next_round >= rounds_) ++c;
+        }
+        return c;
+    }
+
+    void finish_cohort(const std::shared_ptr<Cohort>& g, std::unique_lock<std::mutex>& lk) {
+        gathering_.remove(g);
+        g->gathering = false;
+        lk.unlock();
+        backend_.close(g->data);
+        lk.lock();
+    }
+
+    void leave_locked(Member* m, std::unique_lock<std::mutex>& lk) {
+        while (m->moving) move_cv_.wait(lk);
+        std::shared_ptr<Cohort> g = m->cohort;
+        if (!g) return;
+        LaneRec& l = g->lanes[m->lane];
+        if (l.here) { l.here = false; g->arrived--; }
+        l.m = nullptr;
+        g->alive--;
+        m->cohort.reset();
+        m->round = 0;
+        if (g->alive == 0 && !g->running) finish_cohort(g, lk);
+        else g->cv.notify_all();                 // the rest may be complete now: a waiter runs the round
+    }
+
+    // Runs the cohort's next round on the calling thread.  eject: alive members that have not arrived are moved out first.
+    void run_round(const std::shared_ptr<Cohort>& g, std::unique_lock<std::mutex>& lk, bool eject) {
+        const bool first = g->gathering;
+        if (first) { g->gathering = false; gathering_.remove(g); }
+        g->running = true;
+        const int r = g->next_round;
+        const uint32_t k = (uint32_t)g->lanes.size();
+        std::vector<void*> args(k, nullptr);
+        std::vector<uint8_t> present(k, 0);
+        std::vector<uint32_t> out_lanes;
+        for (uint32_t i = 0; i < k; ++i) {
+            LaneRec& l = g->lanes[i];
+            if (!l.m) continue;
+            if (l.here) { args[i] = l.args; present[i] = 1; }
+            else if (eject) { l.m->moving = true; out_lanes.push_back(i); }
+        }
+        std::vector<int> lane_rc(k, 0);
+        std::vector<std::string> lane_msg(k);
+        std::vector<std::shared_ptr<Cohort>> solos(out_lanes.size());
+        std::vector<int> move_rc(out_lanes.size(), 0);
+        typename Backend::MemberData* leader = nullptr;
+        for (uint32_t i = 0; i < k && !leader; ++i) if (present[i]) leader = &g->lanes[i].m->data;
+        lk.unlock();
+        int rc = 0;
+        if (first) rc = backend_.open(g->data, *leader, k);
+        for (size_t j = 0; j < out_lanes.size(); ++j) {
+            solos[j] = std::make_shared<Cohort>();
+            move_rc[j] = rc ? rc : backend_.move_out(g->data, out_lanes[j], g->lanes[out_lanes[j]].m->data, solos[j]->data);
+        }
+        if (rc == 0) rc = backend_.run(g->data, r, k, args.data(), present.data(), lane_rc.data(), lane_msg.data());
+        std::string all_msg;
+        if (rc != 0) all_msg = backend_.last_error();
+        lk.lock();
+        {
+            uint64_t served = 0;
+            for (uint32_t i = 0; i < k; ++i) served += present[i];
+            stats_.rounds++; stats_.lanes += served; stats_.widest = std::max(stats_.widest, served);
+            stats_.moved_out += out_lanes.size();
+            if (first) stats_.cohorts++;
+        }
+        for (size_t j = 0; j < out_lanes.size(); ++j) {
+            LaneRec& l = g->lanes[out_lanes[j]];
+            Member* m = l.m;
+            l.m = nullptr;
+            g->alive--;
+            m->moving = false;
+            if (move_rc[j] == 0) {
+                std::shared_ptr<Cohort>& h = solos[j];
+                h->key = g->key; h->gathering = false; h->next_round = r; h->alive = 1;
+                h->lanes.emplace_back();
+                h->lanes[0].m = m;
+                m->cohort = h; m->lane = 0;
+            } else {
+                m->cohort.reset(); m->round = 0;  // its proof is lost: the next round call reports the wrong order
+            }
+        }
+        bool over = rc != 0 || r == rounds_;
+        for (uint32_t i = 0; i < k; ++i) {
+            LaneRec& l = g->lanes[i];
+            if (!present[i] || !l.m) { l.here = false; continue; }
+            l.here = false;
+            l.done_round = r;
+            l.rc = rc ? rc : lane_rc[i];
+            l.msg = rc ? all_msg : lane_msg[i];
+            Member* m = l.m;
+            if (l.rc != 0 || over) { m->cohort.reset(); m->round = 0; l.m = nullptr; g->alive--; }
+            else m->round = r;
+        }
+        g->arrived = 0;
+        for (uint32_t i = 0; i < k; ++i) if (g->lanes[i].m && g->lanes[i].here) g->arrived++;
+        g->next_round = r + 1;
+        g->running = false;
+        if (g->alive == 0) finish_cohort(g, lk);
+        g->cv.notify_all();
+        if (!out_lanes.empty()) move_cv_.notify_all();
+    }
+
+    Backend& backend_;
+    const int rounds_;
+    std::mutex mu_;
+    std::condition_variable move_cv_;
+    std::list<Member*> members_;
+    std::list<std::shared_ptr<Cohort>> gathering_;
+    Stats stats_;
+    uint32_t max_lanes_ = 8;
+    std::chrono::microseconds gather_wait_{50}, straggler_wait_{2000}, recent_{5000};
+};
+
+}  // namespace uzk

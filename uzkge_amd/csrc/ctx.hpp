@@ -44,6 +44,27 @@ struct DevBuf {
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// Small per-round arguments of the prover's lane kernels (challenges, blinds, lengths, pointer lists): the host writes them into
+// pinned memory, ONE copy per round puts them into HBM, the kernels read them with scalar loads.  A round ends with a
+// synchronisation (its commitments or evaluations are results), so the next round may overwrite the block.
+struct ArgArena {
+    char* h = nullptr;
+    char* d = nullptr;
+    size_t cap = 0, used = 0, uploaded = 0;
+    int init(size_t bytes);
+    void release();
+    void reset() { used = 0; uploaded = 0; }
+    // `count` objects of T: host pointer to fill, device pointer for the kernels (nullptr when the block is full: callers size it)
+    template <class T> T* push(size_t count, const T** dev) {
+        const size_t at = (used + 15) & ~(size_t)15, bytes = count * sizeof(T);
+        if (at + bytes > cap) { *dev = nullptr; return nullptr; }
+        used = at + bytes;
+        *dev = reinterpret_cast<const T*>(d + at);
+        return reinterpret_cast<T*>(h + at);
+    }
+    int upload(hipStream_t s);   // what was pushed since the last upload
+};
+
 struct ProfEntry {
     std::string name;
     hipEvent_t e0, e1;
@@ -59,7 +80,8 @@ struct MsmWork;   // msm.hip
 struct Ctx {
     std::mutex mu;
     bool ready = false;
-    int device = -1;
+    int want_device = -1;              // uzk_ctx_create_on: the device this context lives on; -1: the process's default device (uzk_init)
+    int device = -1;                   // the device it was made ready on
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;     // second pipeline instance of large MSMs
     hipStream_t cur_stream = nullptr;  // stream the profiling events are recorded on
@@ -114,7 +136,7 @@ struct Ctx {
     int tune_prover_t_cap = 0; // tests / timing chains on synthetic (unsatisfied) circuits: round 3 takes t as its first 5n - 2 + sum(hiding) coefficients and ignores what lies beyond
     int tune_overlap = 0;     // 1: run large MSMs as two overlapping pipeline instances (experiment)  // 1: force one lane per bucket in the fold kernels
     // poly.hip workspaces (grow-only)
-    DevBuf poly_tmp, poly_tmp2, poly_io, zpoly_tmp, open_tmp;
+    DevBuf poly_tmp, poly_tmp2, poly_io, zpoly_tmp, open_tmp, poly_args;
     DevBuf poly_cnt;                 // per-polynomial arrival counters of poly_eval_small (zero between calls); trimmed-length results
     uint32_t trim_flip = 0;          // which of the two trimmed-length result sets the next call uses
     void* poly_host = nullptr;       // pinned, device-visible: small results written by the kernels themselves
@@ -131,6 +153,7 @@ struct Ctx {
         Affine* d_points = nullptr;
         size_t n = 0;
         bool owned = false;
+        int device = 0;
         // optional window table (uzk_srs_precompute): table[j*n + i] = 2^(pre_c*j) * P_i
         Affine* d_table = nullptr;
         int pre_c = 0;
@@ -167,13 +190,25 @@ struct ScalarView {
 Ctx& ctx();
 std::mutex& ctx_mutex();
 int require_ready();
+// While one lives, ctx() on this thread is `c`: a round that several callers share runs on a library-internal context
+// (coalesce.cpp), whatever context the thread that happens to run it has made current.
+struct CtxScope {
+    Ctx* prev;
+    explicit CtxScope(Ctx* c);
+    ~CtxScope();
+    CtxScope(const CtxScope&) = delete;
+    CtxScope& operator=(const CtxScope&) = delete;
+};
+int ctx_init_internal(Ctx& c, int device);     // a context no handle names, ready on `device`, tuned like the default context
+void ctx_release_internal(Ctx& c);
+void devices_synchronize();                    // every device a context has been made ready on
+void coalesce_release_all();                   // coalesce.cpp (uzk_shutdown)
 // api.cpp: the process-wide SRS registry and the pinned-block table, for prover.cpp
 uint64_t srs_insert(const Ctx::Srs& e);
 bool srs_lookup(uint64_t handle, Ctx::Srs* out);
 bool srs_erase(uint64_t handle, Ctx::Srs* out);
 bool is_pinned_block(const void* p, size_t bytes);
 int msm_dispatch_view(const Ctx::Srs& s, size_t offset, const ScalarView& sv, size_t n, uint32_t batch, Jac* out);
-int bound_device();            // the device the process is bound to, -1 when unbound
 // prover.cpp: frees every circuit and prover (uzk_shutdown)
 void prover_release_all();
 
@@ -238,6 +273,30 @@ struct QuotientDev;
 int t_quotient_run(Ctx& c, const void* args_c_abi, Fp* d_out);
 int z_poly_device(Ctx& c, const Fp* d_w, const uint32_t* d_perm, const Fp* d_group, const Fp* k_host, const Fp& beta,
                   const Fp& gamma, uint32_t n, uint32_t n_wires, Fp* d_z);
+int z_poly_lanes(Ctx& c, ArgArena& args, const Fp* d_w, uint64_t w_lane_stride, const uint32_t* d_perm, const Fp* d_group, const Fp* k_host,
+                 const Fp* d_bg, uint32_t n, uint32_t n_wires, uint32_t lanes, Fp* d_z, uint64_t z_lane_stride, uint8_t* lane_ok);
+int t_quotient_lanes(Ctx& c, const void* args_c_abi, uint64_t own_stride, const void* d_lanes, uint32_t lanes, Fp* d_out, uint64_t out_stride);
+void quotient_lane(const Fp& alpha, const Fp& beta, const Fp& gamma, const Fp* k, void* lane_out);
+size_t quotient_lane_bytes();
+// rounds.hip: the lane kernels of the prover's rounds (device-resident argument entries are filled through the *_fill helpers)
+int hide_lanes(Ctx& c, Fp* d_coefs, uint64_t lane_stride, uint64_t slot_stride, uint32_t n, uint32_t slots, uint32_t lanes, const Fp* d_blinds);
+int poly_eval_lanes(Ctx& c, const void* d_polys, uint32_t count, uint64_t max_len, const Fp* d_points, uint32_t lanes, uint32_t* d_counters, Fp* out_host_pinned);
+void eval_poly_fill(void* host_entry, const void* p, uint64_t lane_stride, uint64_t len, uint32_t pt);
+size_t eval_poly_bytes();
+int poly_lincomb_lanes(Ctx& c, const void* d_polys, uint32_t count, const uint32_t* d_lens, const Fp* d_scalars, uint32_t lanes, Fp* d_out, uint64_t out_stride,
+                       uint64_t out_len);
+void lin_poly_fill(void* host_entry, const void* p, uint64_t lane_stride);
+size_t lin_poly_bytes();
+int open_div_lanes(Ctx& c, const Fp* d_h, uint64_t h_stride, uint64_t n, const void* d_pows, uint32_t count, Fp* d_q, uint64_t q_stride, uint64_t q_cap);
+void div_pows_fill(void* host_entry, const Fp& z, int per);
+size_t div_pows_bytes();
+int open_div_per(uint64_t n);
+int split_t_lanes(Ctx& c, const Fp* d_t, uint64_t t_stride, const uint32_t* d_t_lens, uint64_t chunk, uint32_t n_chunks, const Fp* d_rands, uint32_t lanes,
+                  Fp* d_chunks, uint64_t chunk_stride);
+int fold_blinds_lanes(Ctx& c, const Fp* d_polys, uint64_t in_stride, const uint32_t* d_lens, uint64_t N, uint32_t count, Fp* d_out, uint64_t out_stride, Fp* d_tail,
+                      uint32_t tail_n);
+int trimmed_len_lanes(Ctx& c, const Fp* d_polys, uint64_t stride, uint64_t cap, uint32_t count, uint64_t* d_sets, uint32_t count_max, uint32_t* flip,
+                      uint64_t* out_host_pinned);
 int z_poly_run(Ctx& c, const Fp* w_host, const uint32_t* perm_host, const Fp* group_host, const Fp* k_host,
                const Fp& beta, const Fp& gamma, uint32_t n, uint32_t n_wires, Fp* z_host);
 void poly_free(Ctx& c);

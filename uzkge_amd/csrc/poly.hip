@@ -65,13 +65,15 @@ __global__ __launch_bounds__(256) void fr_scan_apply_kernel(Fp* __restrict__ out
 }
 
 // The two scans of z_poly (prefix products of the numerators, suffix products of the denominators, same length) as ONE launch
-// sequence: blockIdx.y picks the array.  in / out: [2][n] contiguous; array 0 forward, array 1 reverse.
+// sequence: blockIdx.y picks the array, blockIdx.z the lane of a lockstep batch (lane_stride elements apart).  in / out: [2][n]
+// contiguous per lane; array 0 forward, array 1 reverse.  total_host (optional, pinned): the full product of array 1 of every
+// lane -- the denominator z_poly inverts -- written by the lane that produces it.
 __global__ __launch_bounds__(256) void fr_scan_block2_kernel(const Fp* __restrict__ in, Fp* __restrict__ out, Fp* __restrict__ block_tot,
-                                                             uint64_t n, uint64_t nb) {
+                                                             uint64_t n, uint64_t nb, uint64_t lane_stride, Fp* __restrict__ total_host) {
     __shared__ Fp sh[256];
     const uint32_t tid = threadIdx.x, which = blockIdx.y;
     const int reverse = which;
-    in += (uint64_t)which * n; out += (uint64_t)which * n;
+    in += (uint64_t)blockIdx.z * lane_stride + (uint64_t)which * n; out += (uint64_t)blockIdx.z * lane_stride + (uint64_t)which * n;
     const uint64_t base = (uint64_t)blockIdx.x * kScanBlock + (uint64_t)tid * kScanPer;
     Fp v[kScanPer];
     Fp run = Fr::one();
@@ -97,31 +99,37 @@ __global__ __launch_bounds__(256) void fr_scan_block2_kernel(const Fp* __restric
         const uint64_t i = base + e;
         if (i < n) out[reverse ? n - 1 - i : i] = tid ? Fr::mul(v[e], pre) : v[e];
     }
-    if (tid == 255) block_tot[(uint64_t)which * nb + blockIdx.x] = sh[255];
+    if (tid == 255) {
+        block_tot[((uint64_t)blockIdx.z * 2 + which) * nb + blockIdx.x] = sh[255];
+        if (nb == 1 && which == 1 && total_host) total_host[blockIdx.z] = sh[255];
+    }
 }
 // second level for both arrays (nb <= 256 blocks each: n <= 2^19) and the fix-up of every element, in one kernel: each
 // workgroup rebuilds the exclusive prefix of the block totals it needs (nb - 1 dependent products at most, nb = 8 at n = 2^14)
-__global__ __launch_bounds__(256) void fr_scan_apply2_kernel(Fp* __restrict__ out, const Fp* __restrict__ block_tot, uint64_t n, uint64_t nb) {
+__global__ __launch_bounds__(256) void fr_scan_apply2_kernel(Fp* __restrict__ out, const Fp* __restrict__ block_tot, uint64_t n, uint64_t nb,
+                                                             uint64_t lane_stride, Fp* __restrict__ total_host) {
     const uint32_t which = blockIdx.y;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t blk = i / kScanBlock;
     if (blk == 0) return;
-    const Fp* tot = block_tot + (uint64_t)which * nb;
+    const Fp* tot = block_tot + ((uint64_t)blockIdx.z * 2 + which) * nb;
     Fp pre = tot[0];
     for (uint64_t b = 1; b < blk; ++b) pre = Fr::mul(pre, tot[b]);
-    Fp* o = out + (uint64_t)which * n;
+    Fp* o = out + (uint64_t)blockIdx.z * lane_stride + (uint64_t)which * n;
     const uint64_t pos = which ? n - 1 - i : i;
-    o[pos] = Fr::mul(o[pos], pre);
+    const Fp v = Fr::mul(o[pos], pre);
+    o[pos] = v;
+    if (which == 1 && i == n - 1 && total_host) total_host[blockIdx.z] = v;     // nb > 1: the last element of the reversed scan lies in the last block
 }
-// d_in / d_out: [2][n]; n <= 32 * kScanBlock (the fix-up walks the block totals serially)
-static int fr_scan_mul2(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, DevBuf& tmp) {
+// d_in / d_out: [lanes][..][2][n] (lane_stride apart); n <= 32 * kScanBlock (the fix-up walks the block totals serially)
+static int fr_scan_mul2(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, DevBuf& tmp, uint32_t lanes = 1, uint64_t lane_stride = 0, Fp* total_host = nullptr) {
     const uint64_t nb = (n + kScanBlock - 1) / kScanBlock;
-    UZK_TRY(tmp.reserve(2 * nb * sizeof(Fp)));
+    UZK_TRY(tmp.reserve(2 * nb * lanes * sizeof(Fp)));
     KernelScope ks(c, "fr_scan");
-    hipLaunchKernelGGL(fr_scan_block2_kernel, dim3((unsigned)nb, 2), dim3(256), 0, c.stream, d_in, d_out, tmp.as<Fp>(), n, nb);
+    hipLaunchKernelGGL(fr_scan_block2_kernel, dim3((unsigned)nb, 2, lanes), dim3(256), 0, c.stream, d_in, d_out, tmp.as<Fp>(), n, nb, lane_stride, total_host);
     if (nb > 1)
-        hipLaunchKernelGGL(fr_scan_apply2_kernel, dim3((unsigned)((n + 255) / 256), 2), dim3(256), 0, c.stream, d_out, tmp.as<Fp>(), n, nb);
+        hipLaunchKernelGGL(fr_scan_apply2_kernel, dim3((unsigned)((n + 255) / 256), 2, lanes), dim3(256), 0, c.stream, d_out, tmp.as<Fp>(), n, nb, lane_stride, total_host);
     UZK_HIP(hipGetLastError());
     return UZK_OK;
 }
@@ -355,39 +363,49 @@ int poly_eval_ptrs(Ctx& c, const void* const* d_polys, const uint64_t* lens, con
 
 // ---- z_poly -------------------------------------------------------------------------------------
 struct ZPolyArgs {
-    const Fp* w;            // [n_wires][n] wire values
+    const Fp* w;            // [n_wires][n] wire values (lane b: w + b * w_lane_stride)
     const uint32_t* perm;   // [n_wires][n] permutation (values < n_wires * n)
     const Fp* group;        // [n] omega^i
     Fp k[8];                // coset representatives k_j (n_wires <= 8)
-    Fp beta, gamma;
+    Fp beta, gamma;         // one lane: by value
+    const Fp* bg;           // lanes: beta, gamma of lane b at bg[2 b], bg[2 b + 1] (device memory); null: the values above
+    uint64_t w_lane_stride;
     uint32_t n, n_wires;
 };
 // i < n-1: num[i] = prod_j (f_j(i) + gamma + beta k_j w^i), den[i] = prod_j (f_j(i) + gamma + beta perm_j(i))
-__global__ __launch_bounds__(256) void z_poly_terms_kernel(ZPolyArgs a, Fp* __restrict__ num, Fp* __restrict__ den) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+// work: [lanes][4][n] = num | den | P | S per lane
+__global__ __launch_bounds__(256) void z_poly_terms_kernel(ZPolyArgs a, Fp* __restrict__ work) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     if (i >= a.n) return;
+    Fp* num = work + (uint64_t)b * 4 * a.n;
+    Fp* den = num + a.n;
     if (i + 1 == a.n) { num[i] = Fr::one(); den[i] = Fr::one(); return; }     // pads the two scans to n elements (fr_scan_mul2)
+    const Fp beta = a.bg ? a.bg[2 * b] : a.beta, gamma = a.bg ? a.bg[2 * b + 1] : a.gamma;
+    const Fp* w = a.w + (uint64_t)b * a.w_lane_stride;
     const Fp gi = a.group[i];
     Fp nm = Fr::one(), dn = Fr::one();
     for (uint32_t j = 0; j < a.n_wires; ++j) {
-        const Fp f = a.w[(size_t)j * a.n + i];
-        const Fp fg = Fr::add(f, a.gamma);
-        nm = Fr::mul(nm, Fr::add(fg, Fr::mul(a.beta, Fr::mul(a.k[j], gi))));
+        const Fp f = w[(size_t)j * a.n + i];
+        const Fp fg = Fr::add(f, gamma);
+        nm = Fr::mul(nm, Fr::add(fg, Fr::mul(beta, Fr::mul(a.k[j], gi))));
         const uint32_t pv = a.perm[(size_t)j * a.n + i];
         const Fp px = Fr::mul(a.k[pv / a.n], a.group[pv % a.n]);      // p_of_x, helpers.rs:174-182
-        dn = Fr::mul(dn, Fr::add(fg, Fr::mul(a.beta, px)));
+        dn = Fr::mul(dn, Fr::add(fg, Fr::mul(beta, px)));
     }
     num[i] = nm;
     den[i] = dn;
 }
 // z[0] = 1; z[i+1] = P[i] * S[i+1] * inv_total  (P = prefix products of num, S = suffix products of den,
-// S[n-1] = 1, inv_total = 1 / S[0])
-__global__ __launch_bounds__(256) void z_poly_combine_kernel(const Fp* __restrict__ P, const Fp* __restrict__ S, Fp inv_total,
-                                                             uint32_t n, Fp* __restrict__ z) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+// S[n-1] = 1, inv_total = 1 / S[0]); lane b: inv_total = inv[b], z at z + b * z_lane_stride
+__global__ __launch_bounds__(256) void z_poly_combine_kernel(const Fp* __restrict__ work, const Fp* __restrict__ inv, Fp inv_one,
+                                                             uint32_t n, Fp* __restrict__ z, uint64_t z_lane_stride) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     if (i >= n) return;
+    z += (uint64_t)b * z_lane_stride;
     if (i == 0) { z[0] = Fr::one(); return; }
-    Fp v = Fr::mul(P[i - 1], inv_total);
+    const Fp* P = work + (uint64_t)b * 4 * n + 2 * (uint64_t)n;
+    const Fp* S = P + n;
+    Fp v = Fr::mul(P[i - 1], inv ? inv[b] : inv_one);
     if (i < n - 1) v = Fr::mul(v, S[i]);
     z[i] = v;
 }
@@ -410,19 +428,19 @@ int z_poly_device(Ctx& c, const Fp* d_w, const uint32_t* d_perm, const Fp* d_gro
     Fp* d_P = d_den + n;
     Fp* d_S = d_P + n;
     ZPolyArgs a;
-    a.w = d_w; a.perm = d_perm; a.group = d_group;
+    a.w = d_w; a.perm = d_perm; a.group = d_group; a.bg = nullptr; a.w_lane_stride = 0;
     for (uint32_t j = 0; j < 8; ++j) a.k[j] = j < n_wires ? k_host[j] : Fr::zero();
     a.beta = beta; a.gamma = gamma; a.n = n; a.n_wires = n_wires;
     const uint32_t m = n - 1;
     {
         KernelScope ks(c, "z_poly_terms");
-        hipLaunchKernelGGL(z_poly_terms_kernel, dim3((n + 255) / 256), dim3(256), 0, c.stream, a, d_num, d_den);
+        hipLaunchKernelGGL(z_poly_terms_kernel, dim3((n + 255) / 256), dim3(256), 0, c.stream, a, d_num);
     }
     if (m <= 32ull * kScanBlock) {
         // num | den and P | S are adjacent pairs of the workspace: both scans in two launches instead of six.  The pairs are n
         // apart while the scans run over m = n - 1 elements: the kernels take the array distance from their `n`, so scan
         // n elements each -- the extra last element (index n - 1 of num / den) is never read by the combine step, it only has to be
-        // defined: z_poly_terms leaves it untouched, so give it a one.
+        // defined: z_poly_terms gives it a one.
         UZK_TRY(fr_scan_mul2(c, d_num, d_P, n, c.poly_tmp));
     } else {
         UZK_TRY(fr_scan_mul(c, d_num, d_P, m, false, c.poly_tmp));
@@ -440,7 +458,54 @@ int z_poly_device(Ctx& c, const Fp* d_w, const uint32_t* d_perm, const Fp* d_gro
     const Fp inv_total = fr_inv(total);     // the single inversion, on the host (~15 us)
     {
         KernelScope ks(c, "z_poly_combine");
-        hipLaunchKernelGGL(z_poly_combine_kernel, dim3((n + 255) / 256), dim3(256), 0, c.stream, d_P, d_S, inv_total, n, d_z);
+        hipLaunchKernelGGL(z_poly_combine_kernel, dim3((n + 255) / 256), dim3(256), 0, c.stream, d_num, (const Fp*)nullptr, inv_total, n, d_z, (uint64_t)0);
+    }
+    UZK_HIP(hipGetLastError());
+    return UZK_OK;
+}
+
+// The grand products of the `lanes` proofs of a lockstep batch (prover round 2): lane b's wires at d_w + b * w_lane_stride, its
+// beta / gamma at d_bg[2 b], d_bg[2 b + 1] (device memory), z to d_z + b * z_lane_stride.  Three launches, ONE synchronisation
+// and one host inversion (Montgomery's trick over the lanes' totals) for the whole batch; the inverses return to the device
+// through `args`.  lane_ok[b] = 0 marks a lane whose denominator product is zero (its z is not written).  n <= 2^16.
+int z_poly_lanes(Ctx& c, ArgArena& args, const Fp* d_w, uint64_t w_lane_stride, const uint32_t* d_perm, const Fp* d_group, const Fp* k_host,
+                 const Fp* d_bg, uint32_t n, uint32_t n_wires, uint32_t lanes, Fp* d_z, uint64_t z_lane_stride, uint8_t* lane_ok) {
+    if (n < 2 || (uint64_t)n > 32ull * kScanBlock || n_wires == 0 || n_wires > 8 || lanes == 0) { set_error("z_poly_lanes: bad shape"); return UZK_ERR_PARAMETER; }
+    UZK_TRY(c.zpoly_tmp.reserve(4 * (size_t)n * lanes * sizeof(Fp)));
+    UZK_TRY(poly_host_reserve(c, (size_t)lanes * sizeof(Fp)));
+    Fp* work = c.zpoly_tmp.as<Fp>();
+    Fp* totals = static_cast<Fp*>(c.poly_host);
+    ZPolyArgs a;
+    a.w = d_w; a.perm = d_perm; a.group = d_group; a.bg = d_bg; a.w_lane_stride = w_lane_stride;
+    for (uint32_t j = 0; j < 8; ++j) a.k[j] = j < n_wires ? k_host[j] : Fr::zero();
+    a.beta = Fr::zero(); a.gamma = Fr::zero(); a.n = n; a.n_wires = n_wires;
+    {
+        KernelScope ks(c, "z_poly_terms");
+        hipLaunchKernelGGL(z_poly_terms_kernel, dim3((n + 255) / 256, lanes), dim3(256), 0, c.stream, a, work);
+    }
+    UZK_TRY(fr_scan_mul2(c, work, work + 2 * (uint64_t)n, n, c.poly_tmp, lanes, 4 * (uint64_t)n, totals));
+    UZK_HIP(hipStreamSynchronize(c.stream));
+    // 1 / total_b for every lane with one inversion: prefix products, invert the last, walk back
+    const Fp* d_inv = nullptr;
+    Fp* inv = args.push<Fp>(lanes, &d_inv);
+    if (!inv) { set_error("z_poly_lanes: argument block full"); return UZK_ERR_PARAMETER; }
+    std::vector<Fp> pre(lanes);
+    Fp acc = Fr::one();
+    for (uint32_t b = 0; b < lanes; ++b) {
+        lane_ok[b] = Fr::is_zero(totals[b]) ? 0 : 1;
+        pre[b] = acc;
+        if (lane_ok[b]) acc = Fr::mul(acc, totals[b]);
+    }
+    Fp run = fr_inv(acc);
+    for (uint32_t b = lanes; b-- > 0;) {
+        if (!lane_ok[b]) { inv[b] = Fr::zero(); continue; }
+        inv[b] = Fr::mul(run, pre[b]);
+        run = Fr::mul(run, totals[b]);
+    }
+    UZK_TRY(args.upload(c.stream));
+    {
+        KernelScope ks(c, "z_poly_combine");
+        hipLaunchKernelGGL(z_poly_combine_kernel, dim3((n + 255) / 256, lanes), dim3(256), 0, c.stream, work, d_inv, Fr::zero(), n, d_z, z_lane_stride);
     }
     UZK_HIP(hipGetLastError());
     return UZK_OK;
@@ -474,12 +539,19 @@ int z_poly_run(Ctx& c, const Fp* w_host, const uint32_t* perm_host, const Fp* gr
 // fifth powers are shared by terms 8/10 and 9/11.  About 140 products per point (the reference
 // spends about 330) and 60 coalesced 32-byte loads: 1.9 KB/point, HBM-stream bound.
 // ---------------------------------------------------------------------------------------------
+// What every lane of a launch shares (by value), and one lane's challenges (device memory, read with scalar loads).  The first
+// ten vectors (the proof's own: w0..4, w_sel0..2, pi, z) of lane b start own_stride * b elements behind vec[0..9]; the 46 circuit
+// tables are the same for every lane.
 struct QuotientDev {
     uint32_t m, factor;
     const Fp* vec[56];
-    Fp ap[17];          // alpha^1 .. alpha^16
-    Fp beta, gamma, bk[5], g, g_inv, g2p1, ea;     // bk[j] = beta * k[j]
+    uint64_t own_stride;
+    Fp g, g_inv, g2p1, ea;
     Fp zhi[16];
+};
+struct QuotientLane {
+    Fp ap[17];          // alpha^0 .. alpha^16
+    Fp beta, gamma, bk[5];     // bk[j] = beta * k[j]
 };
 
 // The reference's loop body (helpers.rs:284-656) in four groups of terms of about equal length (34 / 43 / 36 / 38 products), so
@@ -487,12 +559,13 @@ struct QuotientDev {
 // 1 = terms 4-11 (L1, booleanity, Anemoi round), 2 = terms 12, 13 (public-key curve addition), 3 = terms 14-18 (generator
 // curve addition, ECC / wire-selector booleanity).  Parts 2 and 3 exist only with the "shuffle" feature.
 template <int PART>
-__device__ __forceinline__ Fp tq_part(const QuotientDev& a, uint32_t point, uint32_t nxt) {
+__device__ __forceinline__ Fp tq_part(const QuotientDev& a, const QuotientLane& l, uint64_t own, uint32_t point, uint32_t nxt) {
     const Fp one = Fr::one();
-    auto L = [&](int slot) -> Fp { return a.vec[slot][point]; };
+    auto L = [&](int slot) -> Fp { return slot < 10 ? a.vec[slot][own + point] : a.vec[slot][point]; };
+    auto N = [&](int slot) -> Fp { return a.vec[slot][own + nxt]; };          // own vectors at the next row
     if constexpr (PART == 0) {
         const Fp w0 = L(0), w1 = L(1), w2 = L(2), w3 = L(3), w4 = L(4);
-        const Fp z = L(9), zn = a.vec[9][nxt];
+        const Fp z = L(9), zn = N(9);
         const Fp w0w1 = Fr::mul(w0, w1), w2w3 = Fr::mul(w2, w3);
         // term1: gate
         Fp acc = Fr::mul(L(10), w0);
@@ -506,25 +579,25 @@ __device__ __forceinline__ Fp tq_part(const QuotientDev& a, uint32_t point, uint
         acc = Fr::sub(acc, Fr::mul(L(18), w4));
         // term2 - term3: permutation
         const Fp cq = L(30);
-        const Fp wg[5] = {Fr::add(w0, a.gamma), Fr::add(w1, a.gamma), Fr::add(w2, a.gamma), Fr::add(w3, a.gamma), Fr::add(w4, a.gamma)};
-        Fp t2 = Fr::mul(a.ap[1], z), t3 = Fr::mul(a.ap[1], zn);
+        const Fp wg[5] = {Fr::add(w0, l.gamma), Fr::add(w1, l.gamma), Fr::add(w2, l.gamma), Fr::add(w3, l.gamma), Fr::add(w4, l.gamma)};
+        Fp t2 = Fr::mul(l.ap[1], z), t3 = Fr::mul(l.ap[1], zn);
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
-            t2 = Fr::mul(t2, Fr::add(wg[j], Fr::mul(a.bk[j], cq)));
-            t3 = Fr::mul(t3, Fr::add(wg[j], Fr::mul(a.beta, L(19 + j))));
+            t2 = Fr::mul(t2, Fr::add(wg[j], Fr::mul(l.bk[j], cq)));
+            t3 = Fr::mul(t3, Fr::add(wg[j], Fr::mul(l.beta, L(19 + j))));
         }
         return Fr::add(acc, Fr::sub(t2, t3));
     } else if constexpr (PART == 1) {
         const Fp w0 = L(0), w1 = L(1), w2 = L(2), w3 = L(3), w4 = L(4);
-        const Fp w0n = a.vec[0][nxt], w1n = a.vec[1][nxt], w2n = a.vec[2][nxt];
+        const Fp w0n = N(0), w1n = N(1), w2n = N(2);
         const Fp z = L(9);
         // term4: alpha^2 L1 (z - 1)
-        Fp acc = Fr::mul(Fr::mul(a.ap[2], L(24)), Fr::sub(z, one));
+        Fp acc = Fr::mul(Fr::mul(l.ap[2], L(24)), Fr::sub(z, one));
         // terms 5..7: qb * sum alpha^(2+i) w_i (w_i - 1)
         {
-            Fp s = Fr::mul(a.ap[3], Fr::mul(w1, Fr::sub(w1, one)));
-            s = Fr::add(s, Fr::mul(a.ap[4], Fr::mul(w2, Fr::sub(w2, one))));
-            s = Fr::add(s, Fr::mul(a.ap[5], Fr::mul(w3, Fr::sub(w3, one))));
+            Fp s = Fr::mul(l.ap[3], Fr::mul(w1, Fr::sub(w1, one)));
+            s = Fr::add(s, Fr::mul(l.ap[4], Fr::mul(w2, Fr::sub(w2, one))));
+            s = Fr::add(s, Fr::mul(l.ap[5], Fr::mul(w3, Fr::sub(w3, one))));
             acc = Fr::add(acc, Fr::mul(L(25), s));
         }
         // terms 8..11: Anemoi round, all weighted by q_prk3 and subtracted
@@ -541,10 +614,10 @@ __device__ __forceinline__ Fp tq_part(const QuotientDev& a, uint32_t point, uint
         Fp e9 = Fr::sub(Fr::add(dB, Fr::mul(a.g, Fr::sqr(tB))),
                         Fr::add(Fr::add(Fr::mul(a.g, w3_2w0), Fr::mul(a.g2p1, w2_2w1)), prk2));
         Fp e11 = Fr::sub(Fr::add(Fr::add(dB, Fr::mul(a.g, Fr::sqr(w4))), a.g_inv), w1n);
-        Fp s = Fr::mul(a.ap[6], e8);
-        s = Fr::add(s, Fr::mul(a.ap[7], e9));
-        s = Fr::add(s, Fr::mul(a.ap[8], e10));
-        s = Fr::add(s, Fr::mul(a.ap[9], e11));
+        Fp s = Fr::mul(l.ap[6], e8);
+        s = Fr::add(s, Fr::mul(l.ap[7], e9));
+        s = Fr::add(s, Fr::mul(l.ap[8], e10));
+        s = Fr::add(s, Fr::mul(l.ap[9], e11));
         return Fr::sub(acc, Fr::mul(prk3, s));
     } else {
         // the four selector weights of the curve-addition constraints, shared by terms 12..15
@@ -568,26 +641,26 @@ __device__ __forceinline__ Fp tq_part(const QuotientDev& a, uint32_t point, uint
         }
         const Fp ws2Y = Fr::mul(ws2, sums[1]);
         if constexpr (PART == 2) {
-            const Fp w0 = L(0), w1 = L(1), w0n = a.vec[0][nxt], w1n = a.vec[1][nxt];
+            const Fp w0 = L(0), w1 = L(1), w0n = N(0), w1n = N(1);
             const Fp w01SD = Fr::mul(Fr::mul(w0, w1), sums[2]);
             // 12: ws2 w0n S - ws2 w0 SY - w1 SX + w0 w1 w0n SD
             Fp t12 = Fr::sub(Fr::add(Fr::mul(ws2S, w0n), Fr::mul(w01SD, w0n)), Fr::add(Fr::mul(ws2Y, w0), Fr::mul(w1, sums[0])));
             // 13: ws2 w1n S + a w0 SX - ws2 w1 SY - w0 w1 w1n SD
             Fp t13 = Fr::sub(Fr::add(Fr::mul(ws2S, w1n), Fr::mul(Fr::mul(a.ea, w0), sums[0])), Fr::add(Fr::mul(ws2Y, w1), Fr::mul(w01SD, w1n)));
-            return Fr::add(Fr::mul(a.ap[10], t12), Fr::mul(a.ap[11], t13));
+            return Fr::add(Fr::mul(l.ap[10], t12), Fr::mul(l.ap[11], t13));
         } else {
-            const Fp w2 = L(2), w3 = L(3), w4 = L(4), w2n = a.vec[2][nxt];
+            const Fp w2 = L(2), w3 = L(3), w4 = L(4), w2n = N(2);
             const Fp w23GD = Fr::mul(Fr::mul(w2, w3), sums[2]);
             // 14: ws2 w2n S - ws2 w2 GY - w3 GX + w2 w3 w2n GD
             Fp t14 = Fr::sub(Fr::add(Fr::mul(ws2S, w2n), Fr::mul(w23GD, w2n)), Fr::add(Fr::mul(ws2Y, w2), Fr::mul(w3, sums[0])));
             // 15: ws2 w4 S + a w2 GX - ws2 w3 GY - w2 w3 w4 GD
             Fp t15 = Fr::sub(Fr::add(Fr::mul(ws2S, w4), Fr::mul(Fr::mul(a.ea, w2), sums[0])), Fr::add(Fr::mul(ws2Y, w3), Fr::mul(w23GD, w4)));
-            Fp s = Fr::add(Fr::mul(a.ap[12], t14), Fr::mul(a.ap[13], t15));
+            Fp s = Fr::add(Fr::mul(l.ap[12], t14), Fr::mul(l.ap[13], t15));
             const Fp omq = Fr::sub(one, qecc);
             // 16, 17: q_ecc ws (1 - ws) + (1 - q_ecc) ws ; 18: q_ecc (1 + ws2)(1 - ws2)
-            s = Fr::add(s, Fr::mul(a.ap[14], Fr::mul(ws0, Fr::add(Fr::mul(qecc, om0), omq))));
-            s = Fr::add(s, Fr::mul(a.ap[15], Fr::mul(ws1, Fr::add(Fr::mul(qecc, om1), omq))));
-            return Fr::add(s, Fr::mul(a.ap[16], Fr::mul(qecc, Fr::mul(Fr::add(one, ws2), Fr::sub(one, ws2)))));
+            s = Fr::add(s, Fr::mul(l.ap[14], Fr::mul(ws0, Fr::add(Fr::mul(qecc, om0), omq))));
+            s = Fr::add(s, Fr::mul(l.ap[15], Fr::mul(ws1, Fr::add(Fr::mul(qecc, om1), omq))));
+            return Fr::add(s, Fr::mul(l.ap[16], Fr::mul(qecc, Fr::mul(Fr::add(one, ws2), Fr::sub(one, ws2)))));
         }
     }
 }
@@ -595,35 +668,40 @@ __device__ __forceinline__ Fp tq_part(const QuotientDev& a, uint32_t point, uint
 // SHUFFLE = false: the circuit has no shuffle / ECC selectors (uzkge built without the "shuffle" feature, e.g.
 // zmatchmaking): terms 12..18 of helpers.rs:437-655 do not exist and their 28 vectors are not read.
 template <bool SHUFFLE>
-__global__ __launch_bounds__(256) void t_quotient_kernel(QuotientDev a, Fp* __restrict__ out) {
+__global__ __launch_bounds__(256) void t_quotient_kernel(QuotientDev a, const QuotientLane* __restrict__ lanes, Fp* __restrict__ out, uint64_t out_stride) {
     const uint32_t point = blockIdx.x * blockDim.x + threadIdx.x;
     if (point >= a.m) return;
+    const QuotientLane& l = lanes[blockIdx.y];
+    const uint64_t own = (uint64_t)blockIdx.y * a.own_stride;
     uint32_t nxt = point + a.factor;
     if (nxt >= a.m) nxt -= a.m;
-    Fp acc = Fr::add(tq_part<0>(a, point, nxt), tq_part<1>(a, point, nxt));
-    if constexpr (SHUFFLE) acc = Fr::add(acc, Fr::add(tq_part<2>(a, point, nxt), tq_part<3>(a, point, nxt)));
-    out[point] = Fr::mul(acc, a.zhi[point % a.factor]);
+    Fp acc = Fr::add(tq_part<0>(a, l, own, point, nxt), tq_part<1>(a, l, own, point, nxt));
+    if constexpr (SHUFFLE) acc = Fr::add(acc, Fr::add(tq_part<2>(a, l, own, point, nxt), tq_part<3>(a, l, own, point, nxt)));
+    out[(uint64_t)blockIdx.y * out_stride + point] = Fr::mul(acc, a.zhi[point % a.factor]);
 }
 // The same with the groups of terms on the WAVES of a workgroup (64 points per workgroup, NPARTS waves): at the prover's size
 // the loop has only 6n = 98 304 points -- 1.5 waves per SIMD, every lane a chain of ~150 dependent-latency products -- so the
 // kernel is bound by the length of one lane's chain, not by issue slots or HBM; cutting the chain in four parts of 34..43
 // products quadruples the waves (measured at n = 2^14, tools/ab_tq_split.py: 200 us in one piece, 143 us in two, 126 us in four --
 // about 90 % of what 98 304 x 150 products cost in issue slots on the whole chip).  Field arithmetic is exact: the
-// sum is the same element.  NPARTS = 4 with the shuffle-feature terms, 2 without.
+// sum is the same element.  NPARTS = 4 with the shuffle-feature terms, 2 without.  blockIdx.y = the lane of a lockstep batch.
 template <int NPARTS, int WPE>
-__global__ __launch_bounds__(64 * NPARTS) __attribute__((amdgpu_waves_per_eu(WPE))) void t_quotient_split_kernel(QuotientDev a, Fp* __restrict__ out) {
+__global__ __launch_bounds__(64 * NPARTS) __attribute__((amdgpu_waves_per_eu(WPE))) void t_quotient_split_kernel(QuotientDev a, const QuotientLane* __restrict__ lanes,
+                                                                                                                  Fp* __restrict__ out, uint64_t out_stride) {
     __shared__ Fp part[NPARTS - 1][64];
     const uint32_t lane = threadIdx.x & 63, which = threadIdx.x >> 6;
     const uint32_t point = blockIdx.x * 64 + lane;
     const bool live = point < a.m;
+    const QuotientLane& l = lanes[blockIdx.y];
+    const uint64_t own = (uint64_t)blockIdx.y * a.own_stride;
     uint32_t nxt = point + a.factor;
     if (nxt >= a.m) nxt -= a.m;
     Fp acc = Fr::zero();
     if (live) {
-        if (which == 0) acc = tq_part<0>(a, point, nxt);
-        else if (which == 1) acc = tq_part<1>(a, point, nxt);
-        else if (NPARTS > 2 && which == 2) acc = tq_part<2>(a, point, nxt);
-        else if (NPARTS > 2) acc = tq_part<3>(a, point, nxt);
+        if (which == 0) acc = tq_part<0>(a, l, own, point, nxt);
+        else if (which == 1) acc = tq_part<1>(a, l, own, point, nxt);
+        else if (NPARTS > 2 && which == 2) acc = tq_part<2>(a, l, own, point, nxt);
+        else if (NPARTS > 2) acc = tq_part<3>(a, l, own, point, nxt);
     }
     if (which) part[which - 1][lane] = acc;
     __syncthreads();
@@ -631,13 +709,13 @@ __global__ __launch_bounds__(64 * NPARTS) __attribute__((amdgpu_waves_per_eu(WPE
 #pragma unroll
         for (int p = 0; p < NPARTS - 1; ++p) acc = Fr::add(acc, part[p][lane]);
         // 1 / Z_H of this point's coset class, by selects: a dynamic index into the by-value argument block would make the compiler
-        // copy all 1.9 KB of it to scratch in every lane
+        // copy all of it to scratch in every lane
         const uint32_t cls = point % a.factor;
         Fp zhi = a.zhi[0];
 #pragma unroll
         for (int i = 1; i < 16; ++i)
             if (cls == (uint32_t)i) zhi = a.zhi[i];
-        out[point] = Fr::mul(acc, zhi);
+        out[(uint64_t)blockIdx.y * out_stride + point] = Fr::mul(acc, zhi);
     }
 }
 
@@ -649,15 +727,15 @@ struct QuotientArgsAbi {      // byte-for-byte uzk_quotient_args (include/uzkge_
 };
 static inline Fp fp_from_words(const uint64_t* w) { Fp r; std::memcpy(&r, w, sizeof(Fp)); return r; }
 
-int t_quotient_run(Ctx& c, const void* args_c_abi, Fp* d_out) {
-    const QuotientArgsAbi& A = *static_cast<const QuotientArgsAbi*>(args_c_abi);
+// the shared part of a launch from the C ABI's argument block; the lane part (one lane) into *lane
+static int quotient_args(const QuotientArgsAbi& A, const void* d_out, QuotientDev& d, QuotientLane* lane, int* shuffle) {
     if (A.n == 0 || A.factor == 0 || A.factor > 16 || (uint64_t)A.n * A.factor >= (1ull << 31)) {
         set_error("t_quotient: need n > 0, 1 <= factor <= 16, n * factor < 2^31");
         return UZK_ERR_PARAMETER;
     }
-    QuotientDev d;
     d.m = A.n * A.factor;
     d.factor = A.factor;
+    d.own_stride = 0;
     // the 28 vectors of the "shuffle" feature (w_sel, q_shuffle_public_key, q_shuffle_generator, q_ecc) are either all
     // given or all null (a circuit without them: terms 12..18 vanish)
     auto is_shuffle_slot = [](int i) { return (i >= UZK_TQ_WSEL && i < UZK_TQ_PI) || i >= UZK_TQ_QPK; };
@@ -672,28 +750,60 @@ int t_quotient_run(Ctx& c, const void* args_c_abi, Fp* d_out) {
         if (A.vec[i] && A.vec[i] == d_out) { set_error("t_quotient: output aliases vec[%d]", i); return UZK_ERR_PARAMETER; }
         d.vec[i] = static_cast<const Fp*>(A.vec[i]);
     }
-    const Fp alpha = fp_from_words(A.alpha), beta = fp_from_words(A.beta), g = fp_from_words(A.anemoi_g);
-    d.ap[0] = Fr::one();
-    d.ap[1] = alpha;
-    for (int i = 2; i <= 16; ++i) d.ap[i] = Fr::mul(d.ap[i - 1], alpha);
-    d.beta = beta; d.gamma = fp_from_words(A.gamma);
-    for (int j = 0; j < 5; ++j) d.bk[j] = Fr::mul(beta, fp_from_words(A.k[j]));
+    const Fp g = fp_from_words(A.anemoi_g);
     d.g = g; d.g_inv = fp_from_words(A.anemoi_g_inv); d.ea = fp_from_words(A.edwards_a);
     d.g2p1 = Fr::add(Fr::sqr(g), Fr::one());
     for (int i = 0; i < 16; ++i) d.zhi[i] = fp_from_words(A.z_h_inv[i]);
-    KernelScope ks(c, "t_quotient");
-    // small domains (the prover's 6n = 98 304 points): the two term groups on two waves per 64 points; large ones fill the chip
-    // with one lane per point
-    const bool split = c.tune_tq_split && d.m <= (1u << 19);
-    if (shuffle_present && split) {
-        if (c.tune_tq_split == 3) hipLaunchKernelGGL((t_quotient_split_kernel<4, 3>), dim3((d.m + 63) / 64), dim3(256), 0, c.stream, d, d_out);
-        else hipLaunchKernelGGL((t_quotient_split_kernel<4, 2>), dim3((d.m + 63) / 64), dim3(256), 0, c.stream, d, d_out);
+    if (lane) {
+        Fp k[5];
+        for (int j = 0; j < 5; ++j) k[j] = fp_from_words(A.k[j]);
+        quotient_lane(fp_from_words(A.alpha), fp_from_words(A.beta), fp_from_words(A.gamma), k, lane);
     }
-    else if (split) hipLaunchKernelGGL((t_quotient_split_kernel<2, 3>), dim3((d.m + 63) / 64), dim3(128), 0, c.stream, d, d_out);
-    else if (shuffle_present) hipLaunchKernelGGL(t_quotient_kernel<true>, dim3((d.m + 255) / 256), dim3(256), 0, c.stream, d, d_out);
-    else hipLaunchKernelGGL(t_quotient_kernel<false>, dim3((d.m + 255) / 256), dim3(256), 0, c.stream, d, d_out);
+    *shuffle = shuffle_present ? 1 : 0;
+    return UZK_OK;
+}
+void quotient_lane(const Fp& alpha, const Fp& beta, const Fp& gamma, const Fp* k, void* lane_out) {
+    QuotientLane& l = *static_cast<QuotientLane*>(lane_out);
+    l.ap[0] = Fr::one();
+    l.ap[1] = alpha;
+    for (int i = 2; i <= 16; ++i) l.ap[i] = Fr::mul(l.ap[i - 1], alpha);
+    l.beta = beta; l.gamma = gamma;
+    for (int j = 0; j < 5; ++j) l.bk[j] = Fr::mul(beta, k[j]);
+}
+size_t quotient_lane_bytes() { return sizeof(QuotientLane); }
+
+static int quotient_launch(Ctx& c, const QuotientDev& d, int shuffle_present, const QuotientLane* d_lanes, uint32_t lanes, Fp* d_out, uint64_t out_stride) {
+    KernelScope ks(c, "t_quotient");
+    // small domains (the prover's 6n = 98 304 points): the term groups on separate waves per 64 points; large ones fill the chip
+    // with one lane per point
+    const bool split = d.m <= (1u << 19);
+    if (shuffle_present && split) hipLaunchKernelGGL((t_quotient_split_kernel<4, 3>), dim3((d.m + 63) / 64, lanes), dim3(256), 0, c.stream, d, d_lanes, d_out, out_stride);
+    else if (split) hipLaunchKernelGGL((t_quotient_split_kernel<2, 3>), dim3((d.m + 63) / 64, lanes), dim3(128), 0, c.stream, d, d_lanes, d_out, out_stride);
+    else if (shuffle_present) hipLaunchKernelGGL(t_quotient_kernel<true>, dim3((d.m + 255) / 256, lanes), dim3(256), 0, c.stream, d, d_lanes, d_out, out_stride);
+    else hipLaunchKernelGGL(t_quotient_kernel<false>, dim3((d.m + 255) / 256, lanes), dim3(256), 0, c.stream, d, d_lanes, d_out, out_stride);
     UZK_HIP(hipGetLastError());
     return UZK_OK;
+}
+
+// one lane, everything from the C ABI's argument block (uzk_t_quotient_device)
+int t_quotient_run(Ctx& c, const void* args_c_abi, Fp* d_out) {
+    QuotientDev d;
+    QuotientLane lane;
+    int shuffle = 0;
+    UZK_TRY(quotient_args(*static_cast<const QuotientArgsAbi*>(args_c_abi), d_out, d, &lane, &shuffle));
+    UZK_TRY(c.poly_args.reserve(sizeof lane));
+    UZK_HIP(hipMemcpyAsync(c.poly_args.p, &lane, sizeof lane, hipMemcpyHostToDevice, c.stream));    // ordinary memory: staged before the call returns
+    return quotient_launch(c, d, shuffle, c.poly_args.as<QuotientLane>(), 1, d_out, 0);
+}
+
+// `lanes` proofs of a lockstep batch (prover round 3): the argument block names lane 0's vectors, lane b's own ten lie
+// own_stride * b elements behind them, its challenges at d_lanes[b] (quotient_lane), its output at d_out + b * out_stride.
+int t_quotient_lanes(Ctx& c, const void* args_c_abi, uint64_t own_stride, const void* d_lanes, uint32_t lanes, Fp* d_out, uint64_t out_stride) {
+    QuotientDev d;
+    int shuffle = 0;
+    UZK_TRY(quotient_args(*static_cast<const QuotientArgsAbi*>(args_c_abi), d_out, d, nullptr, &shuffle));
+    d.own_stride = own_stride;
+    return quotient_launch(c, d, shuffle, static_cast<const QuotientLane*>(d_lanes), lanes, d_out, out_stride);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1235,6 +1345,7 @@ void poly_free(Ctx& c) {
     c.poly_io.release();
     c.zpoly_tmp.release();
     c.open_tmp.release();
+    c.poly_args.release();
     c.poly_cnt.release();
     if (c.poly_host) { (void)hipHostFree(c.poly_host); c.poly_host = nullptr; c.poly_host_cap = 0; }
 }
