@@ -422,11 +422,15 @@ int uzk_prover_destroy(uint64_t prover);
 /* How provers of one proof made FROM NOW ON are shared (process-wide; existing provers keep their kind):
  *   max_lanes          most proofs per lockstep launch (default 8; <= 64).  0 or 1: off -- such provers own their lane, as
  *                      provers with batch >= 2 and those of uzk_prover_create_private always do
- *   gather_wait_us     how long the first caller of a round 1 waits for company (default 50); it does not wait at all when no
- *                      other shared prover of its size and device is idle
+ *   gather_wait_us     how long the first caller of a round 1 waits for company (0 = the default, 500); it does not wait at all
+ *                      unless another shared prover of its size and device is about to start a proof too (one that finished a
+ *                      proof within the last 5 ms, or stands in the last round of one)
  *   straggler_wait_us  how long the callers of rounds 2..5 wait for a member of their group before its proof is moved to a
- *                      workspace of its own and the rest go on (default 2000; 0 = default) */
-int uzk_coalesce_config(uint32_t max_lanes, uint32_t gather_wait_us, uint32_t straggler_wait_us);
+ *                      workspace of its own and the rest go on (0 = the default, 20000)
+ *   groups             the provers at work are spread over this many launch sequences side by side (0 = the default, 4: measured
+ *                      best at n = 2^14 -- four streams of B proofs each beat one of 4 B): a group takes at most
+ *                      ceil(provers at work / groups) proofs, so two or four threads keep a stream each and are never merged */
+int uzk_coalesce_config(uint32_t max_lanes, uint32_t gather_wait_us, uint32_t straggler_wait_us, uint32_t groups);
 /* What sharing has done since the last uzk_coalesce_config: out[0] shared rounds run, out[1] round calls they served (out[1] /
  * out[0] = proofs per launch sequence), out[2] the most calls one round served, out[3] proofs moved to a workspace of their own
  * because their caller stayed away, out[4] groups formed at a round 1. */

@@ -80,7 +80,7 @@ int main(int argc, char** argv) {
     const int max_lanes = argc > 3 ? std::atoi(argv[3]) : 4;
     Fake backend;
     Core core(backend, kRounds);
-    core.configure((uint32_t)max_lanes, 100, 400);
+    core.configure((uint32_t)max_lanes, 100, 400, 2);
     std::atomic<uint64_t> good{0}, failed_on_purpose{0}, abandoned{0}, bad{0}, misuse{0};
     auto worker = [&](int t) {
         std::mt19937_64 rng(1234 + t);

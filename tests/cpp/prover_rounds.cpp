@@ -333,8 +333,9 @@ int main(int argc, char** argv) {
     if ((threads > 1 || lanes > 1) && reps > 0) {
         const uint32_t B = mode == kLockstep ? (uint32_t)lanes : 1;
         if (mode == kShared) {
-            const char* gw = std::getenv("UZK_GATHER_US");
-            CK(uzk_coalesce_config(lanes > 1 ? (uint32_t)lanes : 8, gw ? (uint32_t)std::atoi(gw) : 50, 0));
+            const char *gw = std::getenv("UZK_GATHER_US"), *sw = std::getenv("UZK_STRAGGLER_US");      // 0 = the library's defaults
+            const char* gr = std::getenv("UZK_GROUPS");
+            CK(uzk_coalesce_config(lanes > 1 ? (uint32_t)lanes : 8, gw ? (uint32_t)std::atoi(gw) : 0, sw ? (uint32_t)std::atoi(sw) : 0, gr ? (uint32_t)std::atoi(gr) : 0));
         }
         // every thread's proofs and what a single-threaded prover of one proof makes of each of them
         std::vector<std::vector<Proof>> proofs(threads);
@@ -388,10 +389,14 @@ int main(int argc, char** argv) {
         bool agree = true;
         for (int t = 0; t < threads; ++t) { slowest = std::max(slowest, res[t].seconds); agree = agree && res[t].agree; }
         const double total = (double)threads * B * reps * 5;
+        uint64_t cs[5] = {0, 0, 0, 0, 0};
+        if (mode == kShared) CK(uzk_coalesce_stats(cs));       // since uzk_coalesce_config above: warm-up, timed and checked proofs
         std::printf("{\"mode\": \"%s\", \"threads\": %d, \"lanes\": %d, \"proofs_per_s\": %.1f, \"ms_per_proof_slowest_thread\": %.4f, \"single_thread_proofs_per_s\": %.1f, "
-                    "\"witness\": \"%s, its own per proof, uploaded from pinned host memory every proof\", \"proofs_timed\": %.0f, \"threads_agree_with_single\": %s}\n",
+                    "\"witness\": \"%s, its own per proof, uploaded from pinned host memory every proof\", \"proofs_timed\": %.0f, \"threads_agree_with_single\": %s, "
+                    "\"proofs_per_shared_round\": %.2f, \"widest_shared_round\": %llu, \"moved_out\": %llu}\n",
                     mode == kShared ? "shared" : mode == kLockstep ? "lockstep" : "private", threads, lanes, total / wall, slowest * 1e3 / (B * reps * 5), 1e3 / ms,
-                    skew ? "skewed classes" : "uniform", total, agree ? "true" : "false");
+                    skew ? "skewed classes" : "uniform", total, agree ? "true" : "false", cs[0] ? (double)cs[1] / (double)cs[0] : 0.0, (unsigned long long)cs[2],
+                    (unsigned long long)cs[3]);
         if (!agree) { std::printf("FAILED: a thread's commitments / evaluations differ from the single-threaded proof of the same inputs\n"); return 1; }
     }
     std::printf("OK\n");

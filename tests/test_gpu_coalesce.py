@@ -40,9 +40,9 @@ def _alone(b, cir, x):
 
 @pytest.fixture
 def sharing(gpu):
-    gpu.coalesce_config(8, 50, 2000)
+    gpu.coalesce_config(8, 0, 0, 0)
     yield gpu
-    gpu.coalesce_config(8, 50, 2000)
+    gpu.coalesce_config(8, 0, 0, 0)
 
 
 def test_a_shared_prover_alone_equals_a_private_one(sharing):
@@ -77,7 +77,7 @@ def test_threads_with_their_own_provers_share_rounds_and_get_their_own_proofs(sh
     lanes = _round_inputs(inp, threads)
     cir = _circuit_of(b, inp, precompute=precompute)
     want = [_alone(b, cir, x) for x in lanes]
-    b.coalesce_config(4, 2000, 5000)                          # a patient gathering wait: the Python threads are slow to come back
+    b.coalesce_config(4, 2000, 50000, 1)                      # a patient gathering wait (the Python threads are slow to come back), one group
     errors, seen = [], [0] * threads
     start = threading.Barrier(threads)
 
@@ -116,7 +116,7 @@ def test_a_caller_that_stays_away_is_moved_out_and_both_proofs_are_right(sharing
     lanes = _round_inputs(inp, 2)
     cir = _circuit_of(b, inp)
     want = [_alone(b, cir, x) for x in lanes]
-    b.coalesce_config(4, 200000, 20000)                       # gather for 0.2 s (both threads join), wait 20 ms for a straggler
+    b.coalesce_config(4, 200000, 20000, 1)                    # gather for 0.2 s (both threads join), wait 20 ms for a straggler
     errors, times = [], {}
     start = threading.Barrier(2)
     hiding = list(pch.HIDE_W) + [pch.HIDE_WSEL] * 3
@@ -169,9 +169,11 @@ def test_an_unsatisfied_witness_fails_alone_and_an_abandoned_proof_blocks_nobody
     good = pv.make_satisfiable(pch.ChainInputs(n, 21), seed=4)
     bad = pv.make_satisfiable(pch.ChainInputs(n, 21), seed=4)
     bad.w_evals[2, 777] = oc.fr_from_ints([(pv._ints(bad.w_evals[2, 777:778])[0] + 1) % opy.R])[0]
-    cir = _circuit_of(b, good, synthetic=False)
+    polys = [good.table_polys[i] for i in range(pch.N_TABLES)]
+    polys[pch.T_CQ] = None                                     # coset_quotient: the library builds it, as for every real circuit
+    cir = b.Circuit(n, good.lagrange_wire, good.bases[n:], good.perm, good.k, good.anemoi_g, good.anemoi_g_inv, good.edwards_a, polys)
     want = _alone(b, cir, good)
-    b.coalesce_config(4, 200000, 20000)
+    b.coalesce_config(4, 200000, 20000, 1)
     errors, result = [], {}
     start = threading.Barrier(3)
     hiding = list(pch.HIDE_W) + [pch.HIDE_WSEL] * 3

@@ -135,8 +135,8 @@ def test_circuit_and_prover_entry_points_check_their_arguments_before_the_device
     assert N.lib.uzk_prove_round5(12345, p, 43, p, p, p) == N.UZK_ERR_PARAMETER
     assert N.lib.uzk_prove_round4((1 << 62) | 77, p, p, 19) == N.UZK_ERR_PARAMETER        # ... also one shaped like a shared prover's handle
     assert N.lib.uzk_prover_create_private(4096, 65, ctypes.byref(h)) == N.UZK_ERR_PARAMETER   # more lanes than a prover can hold
-    assert N.lib.uzk_coalesce_config(65, 50, 0) == N.UZK_ERR_PARAMETER
-    assert N.lib.uzk_coalesce_config(8, 50, 0) == N.UZK_OK
+    assert N.lib.uzk_coalesce_config(65, 50, 0, 0) == N.UZK_ERR_PARAMETER
+    assert N.lib.uzk_coalesce_config(8, 0, 0, 0) == N.UZK_OK
     assert N.lib.uzk_circuit_info(999, None, None, None, None) == N.UZK_ERR_PARAMETER
     assert N.lib.uzk_test_circuit_truncate_t(999, 1) == N.UZK_ERR_PARAMETER
     assert N.lib.uzk_circuit_release(999) == N.UZK_ERR_PARAMETER

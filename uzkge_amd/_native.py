@@ -86,7 +86,7 @@ PROTOTYPES = {
     "uzk_test_circuit_truncate_t": (_I, [_U64, _I]),
     "uzk_prover_create": (_I, [ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_U64)]),
     "uzk_prover_create_private": (_I, [ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_U64)]),
-    "uzk_coalesce_config": (_I, [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]),
+    "uzk_coalesce_config": (_I, [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]),
     "uzk_coalesce_stats": (_I, [ctypes.POINTER(_U64)]),
     "uzk_prover_destroy": (_I, [_U64]),
     "uzk_prove_round1": (_I, [_U64, _U64, _P, _P, _I, _P, _P, ctypes.c_uint32, _P, _P, _P]),

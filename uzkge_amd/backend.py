@@ -638,9 +638,9 @@ def preprocess_tables_device(srs: Srs, evals: np.ndarray, k1=None, want_coset: b
     return polys, lens, coset, cms
 
 
-def coalesce_config(max_lanes: int = 8, gather_wait_us: int = 50, straggler_wait_us: int = 2000) -> None:
-    """uzk_coalesce_config: how provers of one proof made from now on are shared (max_lanes <= 1: not at all)."""
-    check(lib.uzk_coalesce_config(max_lanes, gather_wait_us, straggler_wait_us))
+def coalesce_config(max_lanes: int = 8, gather_wait_us: int = 0, straggler_wait_us: int = 0, groups: int = 0) -> None:
+    """uzk_coalesce_config: how provers of one proof made from now on are shared (max_lanes <= 1: not at all; 0 = the defaults)."""
+    check(lib.uzk_coalesce_config(max_lanes, gather_wait_us, straggler_wait_us, groups))
 
 
 def coalesce_stats() -> dict:

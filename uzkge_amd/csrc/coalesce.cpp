@@ -7,6 +7,7 @@
 // hands every caller its own outputs.  The reference's call pattern -- one proof per call, from whatever threads the
 // application has (uzkge/src/plonk/prover.rs:88-100; shuffle/src/sdk.rs:196-214) -- reaches the lockstep throughput this way
 // without a new API.  Alone, a shared prover runs on its own one-lane workspace exactly as a prover of one proof always did.
+#include <condition_variable>
 #include <cstring>
 #include <map>
 
@@ -29,6 +30,7 @@ int explicit_round5(uint64_t prover, const uint64_t* r_scalars, size_t r_count, 
 namespace {
 
 constexpr uint64_t kSharedBit = 1ull << 62;              // handles of shared provers (the explicit ones count up from 1)
+constexpr uint32_t kGatherWaitUs = 500, kStragglerWaitUs = 20000, kGroups = 4;      // the defaults of uzk_coalesce_config (profiles/r05_gather_sweep.txt)
 
 // A lockstep workspace and the internal context its launches are ordered on.
 struct Slot {
@@ -42,6 +44,10 @@ struct Slot {
     }
 };
 int make_slot(uint32_t n, uint32_t cap, int device, std::shared_ptr<Slot>* out) {
+    // one at a time: the runtime picks a stream's hardware queue when the stream is first used, and streams that are born in the
+    // same instant on several threads have been seen to end up on one queue, where their launch sequences take turns
+    static std::mutex birth;
+    std::lock_guard<std::mutex> one(birth);
     auto s = std::make_shared<Slot>();
     s->n = n; s->cap = cap; s->device = device;
     UZK_TRY(ctx_init_internal(s->ctx, device));
@@ -65,7 +71,9 @@ struct A1 {
 
 struct Backend {
     struct MemberData {
-        std::shared_ptr<Slot> home;                      // one lane: the proofs this prover runs alone, and where a straggler's lane moves
+        uint32_t n = 0;
+        int device = 0;
+        std::shared_ptr<Slot> home;                      // one lane, made on first need: the proofs this prover runs alone, and where a straggler's lane moves
         hipEvent_t ev = nullptr;                         // orders device-resident inputs of the caller's context before the shared stream
     };
     struct CohortData {
@@ -73,16 +81,26 @@ struct Backend {
         bool pooled = false;
     };
 
-    std::mutex mu;                                       // the pool
+    std::mutex mu;                                       // the pool, the turns
     std::vector<std::shared_ptr<Slot>> pool;
     uint32_t pool_cap = 8;                               // lanes of the workspaces made from now on
+    // Rounds under way at the same time.  More than a handful of streams with work queued at once cost the chip dearly (five
+    // lockstep provers of four proofs: 900 proofs/s where four make 1300, profiles/r04_rounds_matrix_wide.txt), so when callers
+    // have not (yet) merged into `max_running` cohorts, the surplus cohorts take turns round by round.
+    uint32_t running = 0, max_running = 4;
+    std::condition_variable turn;
 
     std::string last_error() { return uzk_last_error(); }
 
+    static int home_of(MemberData& m) {
+        if (m.home) return UZK_OK;
+        return make_slot(m.n, 1, m.device, &m.home);
+    }
+
     int open(CohortData& cd, MemberData& leader, uint32_t lanes) {
-        if (lanes == 1) { cd.slot = leader.home; cd.pooled = false; return UZK_OK; }
-        const uint32_t n = leader.home->n;
-        const int device = leader.home->device;
+        if (lanes == 1) { UZK_TRY(home_of(leader)); cd.slot = leader.home; cd.pooled = false; return UZK_OK; }
+        const uint32_t n = leader.n;
+        const int device = leader.device;
         uint32_t cap;
         {
             std::lock_guard<std::mutex> lk(mu);
@@ -114,6 +132,7 @@ struct Backend {
     }
 
     int move_out(CohortData& from, uint32_t lane, MemberData& to, CohortData& solo) {
+        UZK_TRY(home_of(to));
         Slot& s = *from.slot;
         CtxScope scope(&s.ctx);
         std::lock_guard<std::mutex> lk(s.ctx.mu);
@@ -132,6 +151,11 @@ struct Backend {
     }
 
     int run(CohortData& cd, int round, uint32_t lanes, void* const* args, const uint8_t* present, int* lane_rc, std::string* lane_msg) {
+        struct Turn {
+            Backend& b;
+            explicit Turn(Backend& b_) : b(b_) { std::unique_lock<std::mutex> lk(b.mu); while (b.running >= b.max_running) b.turn.wait(lk); ++b.running; }
+            ~Turn() { { std::lock_guard<std::mutex> lk(b.mu); --b.running; } b.turn.notify_one(); }
+        } my_turn(*this);
         Slot& s = *cd.slot;
         Ctx& c = s.ctx;
         CtxScope scope(&c);
@@ -179,7 +203,7 @@ struct Shared1 {                                         // a shared prover
 
 struct State {
     Backend backend;
-    Core core{backend, 5};
+    Core core{backend, 5, 8, kGatherWaitUs, kStragglerWaitUs, kGroups};
     std::mutex mu;                                       // the handle table and the switches
     std::map<uint64_t, std::shared_ptr<Shared1>> provers;
     uint64_t next = 1;
@@ -232,7 +256,7 @@ using namespace uzk;
 
 extern "C" {
 
-int uzk_coalesce_config(uint32_t max_lanes, uint32_t gather_wait_us, uint32_t straggler_wait_us) try {
+int uzk_coalesce_config(uint32_t max_lanes, uint32_t gather_wait_us, uint32_t straggler_wait_us, uint32_t groups) try {
     if (max_lanes > kMaxBatch) { set_error("uzk_coalesce_config: at most %u lanes", kMaxBatch); return UZK_ERR_PARAMETER; }
     State& s = st();
     {
@@ -240,9 +264,10 @@ int uzk_coalesce_config(uint32_t max_lanes, uint32_t gather_wait_us, uint32_t st
         s.enabled = max_lanes >= 2;
     }
     if (max_lanes >= 2) {
-        s.core.configure(max_lanes, gather_wait_us, straggler_wait_us ? straggler_wait_us : 2000);
+        s.core.configure(max_lanes, gather_wait_us ? gather_wait_us : kGatherWaitUs, straggler_wait_us ? straggler_wait_us : kStragglerWaitUs, groups ? groups : kGroups);
         std::lock_guard<std::mutex> lk(s.backend.mu);
         s.backend.pool_cap = max_lanes;
+        s.backend.max_running = groups ? groups : kGroups;
         s.backend.pool.clear();                          // workspaces of another width: made again on demand
     }
     return UZK_OK;
@@ -277,7 +302,7 @@ int uzk_prover_create(uint32_t n, uint32_t batch, uint64_t* prover_out) try {
     auto sp = std::make_shared<Shared1>();
     sp->n = n; sp->device = device;
     sp->member.group = ((uint64_t)n << 8) | (uint64_t)(device & 0xff);
-    UZK_TRY(make_slot(n, 1, device, &sp->member.data.home));
+    sp->member.data.n = n; sp->member.data.device = device;
     UZK_HIP(hipSetDevice(device));
     UZK_HIP(hipEventCreateWithFlags(&sp->member.data.ev, hipEventDisableTiming));
     s.core.add(&sp->member);

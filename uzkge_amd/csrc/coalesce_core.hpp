@@ -76,12 +76,17 @@ public:
         typename Backend::CohortData data;
     };
 
-    CoalesceCore(Backend& b, int rounds) : backend_(b), rounds_(rounds) {}
+    CoalesceCore(Backend& b, int rounds, uint32_t max_lanes = 8, uint32_t gather_wait_us = 500, uint32_t straggler_wait_us = 20000, uint32_t groups = 4)
+        : backend_(b), rounds_(rounds), max_lanes_(max_lanes), groups_(groups), gather_wait_(gather_wait_us), straggler_wait_(straggler_wait_us) {}
 
-    void configure(uint32_t max_lanes, uint32_t gather_wait_us, uint32_t straggler_wait_us) {
+    // groups: how many cohorts the active provers of a kind are spread over (a cohort takes at most ceil(active / groups) lanes):
+    // a few independent launch sequences side by side fill the chip better than one wide one
+    void configure(uint32_t max_lanes, uint32_t gather_wait_us, uint32_t straggler_wait_us, uint32_t groups) {
         std::lock_guard<std::mutex> lk(mu_);
         max_lanes_ = std::max<uint32_t>(1, max_lanes);
+        groups_ = std::max<uint32_t>(1, groups);
         gather_wait_ = std::chrono::microseconds(gather_wait_us);
+        merge_wait_ = 20 * gather_wait_;
         straggler_wait_ = std::chrono::microseconds(std::max<uint32_t>(1, straggler_wait_us));
         stats_ = Stats();
     }
@@ -90,7 +95,7 @@ public:
     struct Stats { uint64_t rounds = 0, lanes = 0, widest = 0, moved_out = 0, cohorts = 0; };
     Stats stats() { std::lock_guard<std::mutex> lk(mu_); return stats_; }
 
-    void add(Member* m) { std::lock_guard<std::mutex> lk(mu_); members_.push_back(m); }
+    void add(Member* m) { std::lock_guard<std::mutex> lk(mu_); m->last_seen = Clock::now(); members_.push_back(m); }
     // false: the member is inside a call on another thread (it stays registered)
     bool remove(Member* m) {
         std::unique_lock<std::mutex> lk(mu_);
@@ -116,13 +121,15 @@ public:
         std::shared_ptr<Cohort> g;
         if (round == 1) {
             leave_locked(m, lk);                 // a proof in flight is abandoned
+            const uint32_t cap = lane_cap(key->group, Clock::now());
             for (auto& c : gathering_)
-                if (c->key == *key && c->lanes.size() < max_lanes_) { g = c; break; }
+                if (c->key == *key && c->lanes.size() < cap) { g = c; break; }
             if (!g) {
                 g = std::make_shared<Cohort>();
                 g->key = *key;
                 g->deadline = Clock::now() + gather_wait_;
                 gathering_.push_back(g);
+                live_.push_back(g);
             }
             m->cohort = g;
             m->lane = (uint32_t)g->lanes.size();
@@ -148,9 +155,14 @@ public:
             if (l.done_round >= round) break;
             if (!g->running) {
                 if (g->gathering) {
+                    // Enough launch sequences of this kind are under way already (`crowded`): rather than add an under-filled one,
+                    // the cohort stays open -- the members of the next cohort to finish fill it -- for up to merge_wait_.  That is what
+                    // makes callers with unrelated phases converge on `groups_` full cohorts instead of many small ones.
                     const auto now = Clock::now();
-                    if (g->lanes.size() >= max_lanes_ || now >= g->deadline || company_in_sight(g.get(), now) == 0) { run_round(g, lk, false); continue; }
-                    wait(g->cv, lk, g->deadline - now);
+                    const bool crowded = others_live(g.get()) >= groups_;
+                    const auto deadline = crowded ? g->deadline + merge_wait_ : g->deadline;
+                    if (g->lanes.size() >= lane_cap(g->key.group, now) || now >= deadline || (!crowded && company_in_sight(g.get(), now) == 0)) { run_round(g, lk, false); continue; }
+                    wait(g->cv, lk, deadline - now);
                     continue;
                 }
                 if (g->arrived == g->alive) { run_round(g, lk, false); continue; }
@@ -178,6 +190,15 @@ private:
 #endif
     }
 
+    // Lanes a cohort of this group takes at most right now: the provers at work (in a proof, in a call, or seen within `recent_`)
+    // spread over groups_ cohorts, never more than max_lanes_.
+    uint32_t lane_cap(uint64_t group, Clock::time_point now) const {
+        uint32_t active = 0;
+        for (const Member* o : members_)
+            if (o->group == group && (o->cohort || o->in_call || now - o->last_seen < recent_)) ++active;
+        return std::min(max_lanes_, std::max<uint32_t>(1, (active + groups_ - 1) / groups_));
+    }
+
     // Members of g's group that could still join it before its wait is over: provers between two proofs that were at work a moment
     // ago (their threads are probably about to start the next proof), and provers in the LAST round of a proof (they come back
     // for the next one when it ends).  Provers in the middle of a proof cannot arrive within gather_wait; provers that have been
@@ -192,9 +213,19 @@ private:
         return c;
     }
 
+    // live cohorts of g's kind (same group, same key) besides g
+    uint32_t others_live(const Cohort* g) const {
+        uint32_t c = 0;
+        for (const auto& o : live_)
+            if (o.get() != g && o->key == g->key) ++c;
+        return c;
+    }
+
     void finish_cohort(const std::shared_ptr<Cohort>& g, std::unique_lock<std::mutex>& lk) {
         gathering_.remove(g);
+        live_.remove(g);
         g->gathering = false;
+        for (auto& o : gathering_) o->cv.notify_all();      // one launch sequence fewer: a cohort held open may go now
         lk.unlock();
         backend_.close(g->data);
         lk.lock();
@@ -262,6 +293,7 @@ private:
             m->moving = false;
             if (move_rc[j] == 0) {
                 std::shared_ptr<Cohort>& h = solos[j];
+                live_.push_back(h);
                 h->key = g->key; h->gathering = false; h->next_round = r; h->alive = 1;
                 h->lanes.emplace_back();
                 h->lanes[0].m = m;
@@ -296,10 +328,10 @@ private:
     std::mutex mu_;
     std::condition_variable move_cv_;
     std::list<Member*> members_;
-    std::list<std::shared_ptr<Cohort>> gathering_;
+    std::list<std::shared_ptr<Cohort>> gathering_, live_;      // cohorts still taking members; every cohort that is not over
     Stats stats_;
-    uint32_t max_lanes_ = 8;
-    std::chrono::microseconds gather_wait_{50}, straggler_wait_{2000}, recent_{5000};
+    uint32_t max_lanes_, groups_;
+    std::chrono::microseconds gather_wait_, straggler_wait_, recent_{5000}, merge_wait_{10000};
 };
 
 }  // namespace uzk

@@ -487,6 +487,7 @@ int round3_lanes(Ctx& c, Prover& p, const Lane3* L, LaneStatus* st) {
         quotient_lane(*L[b].alpha, p.beta[b], p.gamma[b], cir.k, ql + (size_t)b * lane_bytes);
         for (uint32_t i = 0; i < 5; ++i) rands[b * 5 + i] = L[b].t_rands[i];
     }
+    ROUND_TRY(p.args.upload(c.stream));
     // t_poly (helpers.rs:223-678): coset FFTs of the proof's polynomials over the 6n domain, the quotient kernel against the
     // circuit's coset tables, the inverse coset transform
     if (p.np == kProofSlots) ROUND_TRY(ntt_run(c, p.d_coefs, p.d_coset, m, false, &cir.k[1], k * kProofSlots));
