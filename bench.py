@@ -416,12 +416,12 @@ def run_rank(args) -> None:
         for _ in range(steps):
             res = fn()
         fence()
-        el = time.perf_counter() - t0
+        mine = el = time.perf_counter() - t0           # this rank's clock around the steps and their fences -- nothing else
         if use_dist:
             t = torch.tensor([el], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
-        return el, res
+        return el, mine, res
 
     for _ in range(args.warmup):
         step()
@@ -430,8 +430,7 @@ def run_rank(args) -> None:
     committer.reset_clocks()
     sampler = _ClockSampler(local_rank).start() if rank == 0 else None
     t_local = time.perf_counter()
-    elapsed, result = timed_steps(step, args.steps)
-    local_elapsed = time.perf_counter() - t_local             # this rank's own clock around the same region (incl. the fences)
+    elapsed, local_elapsed, result = timed_steps(step, args.steps)     # local_elapsed: this rank's own clock, taken BEFORE the MAX all-reduce
     clocks_timed = sampler.stop(t_local, t_local + local_elapsed) if sampler else None
     b.profile_enable(False)
     prof = b.profile_table()

@@ -422,7 +422,7 @@ int uzk_prover_destroy(uint64_t prover);
 /* How provers of one proof made FROM NOW ON are shared (process-wide; existing provers keep their kind):
  *   max_lanes          most proofs per lockstep launch (default 8; <= 64).  0 or 1: off -- such provers own their lane, as
  *                      provers with batch >= 2 and those of uzk_prover_create_private always do
- *   gather_wait_us     how long the first caller of a round 1 waits for company (0 = the default, 500); it does not wait at all
+ *   gather_wait_us     how long the first caller of a round 1 waits for company (0 = the default, 2000); it does not wait at all
  *                      unless another shared prover of its size and device is about to start a proof too (one that finished a
  *                      proof within the last 5 ms, or stands in the last round of one)
  *   straggler_wait_us  how long the callers of rounds 2..5 wait for a member of their group before its proof is moved to a
@@ -431,10 +431,13 @@ int uzk_prover_destroy(uint64_t prover);
  *                      best at n = 2^14 -- four streams of B proofs each beat one of 4 B): a group takes at most
  *                      ceil(provers at work / groups) proofs, so two or four threads keep a stream each and are never merged */
 int uzk_coalesce_config(uint32_t max_lanes, uint32_t gather_wait_us, uint32_t straggler_wait_us, uint32_t groups);
-/* What sharing has done since the last uzk_coalesce_config: out[0] shared rounds run, out[1] round calls they served (out[1] /
+/* What sharing has done since the last uzk_coalesce_config or the last reset (out == NULL resets the counters): out[0] shared rounds run, out[1] round calls they served (out[1] /
  * out[0] = proofs per launch sequence), out[2] the most calls one round served, out[3] proofs moved to a workspace of their own
- * because their caller stayed away, out[4] groups formed at a round 1. */
-int uzk_coalesce_stats(uint64_t out[5]);
+ * because their caller stayed away, out[4] groups formed at a round 1, out[5] / out[6] the average host time in microseconds
+ * between the end of a group's round and the start of its next (its callers wake, take their results and come back with the next
+ * challenges: the price of keeping the one-proof API), out[7] / out[4] the average time in microseconds a group stayed open before
+ * its first round, out[8 + i] how many groups started with i + 1 callers (the last entry: 8 or more). */
+int uzk_coalesce_stats(uint64_t out[16]);
 /* Per-proof arrays below are [batch][...]: element b of every input / output belongs to proof b.
  *
  * Round 1 (prover.rs:151-192): PI polynomial, wire and wire-selector polynomials: iFFT(n), hide_polynomial, commit with blinds.

@@ -378,6 +378,7 @@ int main(int argc, char** argv) {
         std::vector<std::thread> pool;
         for (int t = 0; t < threads; ++t) pool.emplace_back(worker, t);
         while (gate.load() < threads) std::this_thread::yield();
+        if (mode == kShared) CK(uzk_coalesce_stats(nullptr));          // the statistics below cover the timed and the checked proofs, not the warm-up
         t_start = std::chrono::steady_clock::now();
         go.store(true);
         while (done.load() < threads) std::this_thread::sleep_for(std::chrono::microseconds(200));
@@ -389,14 +390,15 @@ int main(int argc, char** argv) {
         bool agree = true;
         for (int t = 0; t < threads; ++t) { slowest = std::max(slowest, res[t].seconds); agree = agree && res[t].agree; }
         const double total = (double)threads * B * reps * 5;
-        uint64_t cs[5] = {0, 0, 0, 0, 0};
-        if (mode == kShared) CK(uzk_coalesce_stats(cs));       // since uzk_coalesce_config above: warm-up, timed and checked proofs
+        uint64_t cs[16] = {};
+        if (mode == kShared) CK(uzk_coalesce_stats(cs));
         std::printf("{\"mode\": \"%s\", \"threads\": %d, \"lanes\": %d, \"proofs_per_s\": %.1f, \"ms_per_proof_slowest_thread\": %.4f, \"single_thread_proofs_per_s\": %.1f, "
                     "\"witness\": \"%s, its own per proof, uploaded from pinned host memory every proof\", \"proofs_timed\": %.0f, \"threads_agree_with_single\": %s, "
-                    "\"proofs_per_shared_round\": %.2f, \"widest_shared_round\": %llu, \"moved_out\": %llu}\n",
+                    "\"proofs_per_shared_round\": %.2f, \"widest_shared_round\": %llu, \"moved_out\": %llu, \"host_gap_us_between_shared_rounds\": %.1f, \"gather_us_per_group\": %.1f, \"groups_by_size\": [%llu, %llu, %llu, %llu, %llu, %llu, %llu, %llu]}\n",
                     mode == kShared ? "shared" : mode == kLockstep ? "lockstep" : "private", threads, lanes, total / wall, slowest * 1e3 / (B * reps * 5), 1e3 / ms,
                     skew ? "skewed classes" : "uniform", total, agree ? "true" : "false", cs[0] ? (double)cs[1] / (double)cs[0] : 0.0, (unsigned long long)cs[2],
-                    (unsigned long long)cs[3]);
+                    (unsigned long long)cs[3], cs[6] ? (double)cs[5] / (double)cs[6] : 0.0, cs[4] ? (double)cs[7] / (double)cs[4] : 0.0, (unsigned long long)cs[8], (unsigned long long)cs[9], (unsigned long long)cs[10], (unsigned long long)cs[11],
+                    (unsigned long long)cs[12], (unsigned long long)cs[13], (unsigned long long)cs[14], (unsigned long long)cs[15]);
         if (!agree) { std::printf("FAILED: a thread's commitments / evaluations differ from the single-threaded proof of the same inputs\n"); return 1; }
     }
     std::printf("OK\n");

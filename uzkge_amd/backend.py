@@ -645,9 +645,10 @@ def coalesce_config(max_lanes: int = 8, gather_wait_us: int = 0, straggler_wait_
 
 def coalesce_stats() -> dict:
     """uzk_coalesce_stats since the last coalesce_config."""
-    a = (ctypes.c_uint64 * 5)()
+    a = (ctypes.c_uint64 * 16)()
     check(lib.uzk_coalesce_stats(a))
-    return dict(rounds=a[0], calls=a[1], widest=a[2], moved_out=a[3], groups=a[4])
+    return dict(rounds=a[0], calls=a[1], widest=a[2], moved_out=a[3], groups=a[4], gap_us_avg=(a[5] / a[6] if a[6] else 0.0),
+                gather_us_avg=(a[7] / a[4] if a[4] else 0.0), group_sizes=[a[8 + i] for i in range(8)])
 
 
 class Prover:

@@ -30,33 +30,15 @@ int explicit_round5(uint64_t prover, const uint64_t* r_scalars, size_t r_count, 
 namespace {
 
 constexpr uint64_t kSharedBit = 1ull << 62;              // handles of shared provers (the explicit ones count up from 1)
-constexpr uint32_t kGatherWaitUs = 500, kStragglerWaitUs = 20000, kGroups = 4;      // the defaults of uzk_coalesce_config (profiles/r05_gather_sweep.txt)
+constexpr uint32_t kGatherWaitUs = 2000, kStragglerWaitUs = 20000, kGroups = 4;      // the defaults of uzk_coalesce_config (profiles/r05_gather_sweep.txt)
 
-// A lockstep workspace and the internal context its launches are ordered on.
+// A lockstep workspace: the buffers of up to `cap` proofs.  It has no stream of its own: a round runs on whichever of the few
+// internal contexts is free (Turns below) -- rounds end synchronised, so nothing of a proof is in flight between two of them.
 struct Slot {
-    Ctx ctx;
     std::shared_ptr<Prover> prover;
     uint32_t n = 0, cap = 0;
     int device = 0;
-    ~Slot() {
-        prover.reset();
-        ctx_release_internal(ctx);
-    }
 };
-int make_slot(uint32_t n, uint32_t cap, int device, std::shared_ptr<Slot>* out) {
-    // one at a time: the runtime picks a stream's hardware queue when the stream is first used, and streams that are born in the
-    // same instant on several threads have been seen to end up on one queue, where their launch sequences take turns
-    static std::mutex birth;
-    std::lock_guard<std::mutex> one(birth);
-    auto s = std::make_shared<Slot>();
-    s->n = n; s->cap = cap; s->device = device;
-    UZK_TRY(ctx_init_internal(s->ctx, device));
-    CtxScope scope(&s->ctx);
-    std::lock_guard<std::mutex> lk(s->ctx.mu);
-    UZK_TRY(prover_alloc(s->ctx, n, cap, &s->prover));
-    *out = s;
-    return UZK_OK;
-}
 
 // one lane's arguments of a round, on the caller's stack while it is inside the call
 struct A1 {
@@ -81,18 +63,67 @@ struct Backend {
         bool pooled = false;
     };
 
+    // The internal contexts: `max_running` per device, each one stream with its workspaces, made once and one after the other
+    // (streams born in the same instant on several threads have been seen to share a hardware queue, where their launch sequences
+    // then take turns).  A round takes a free one for its duration.  So at most `max_running` streams of the library's own are
+    // ever busy: more than a handful of busy streams cost the chip dearly (five lockstep provers of four proofs make 900 proofs/s
+    // where four make 1300, profiles/r04_rounds_matrix_wide.txt), and cohorts beyond that number take turns round by round.
+    struct Turns {
+        std::vector<std::unique_ptr<Ctx>> ctx;
+        std::vector<uint8_t> busy;
+    };
     std::mutex mu;                                       // the pool, the turns
+    std::condition_variable turn_cv;
+    std::map<int, Turns> turns;
+    uint32_t max_running = 4;
     std::vector<std::shared_ptr<Slot>> pool;
     uint32_t pool_cap = 8;                               // lanes of the workspaces made from now on
-    // Rounds under way at the same time.  More than a handful of streams with work queued at once cost the chip dearly (five
-    // lockstep provers of four proofs: 900 proofs/s where four make 1300, profiles/r04_rounds_matrix_wide.txt), so when callers
-    // have not (yet) merged into `max_running` cohorts, the surplus cohorts take turns round by round.
-    uint32_t running = 0, max_running = 4;
-    std::condition_variable turn;
+
+    struct Turn {
+        Backend& b;
+        int device;
+        size_t at = 0;
+        Ctx* c = nullptr;
+        int rc = UZK_OK;
+        Turn(Backend& b_, int device_) : b(b_), device(device_) {
+            std::unique_lock<std::mutex> lk(b.mu);
+            Turns& t = b.turns[device];
+            for (;;) {
+                for (size_t i = 0; i < t.ctx.size(); ++i)
+                    if (!t.busy[i]) { at = i; c = t.ctx[i].get(); t.busy[i] = 1; return; }
+                if (t.ctx.size() < b.max_running) {
+                    auto nc = std::make_unique<Ctx>();
+                    rc = ctx_init_internal(*nc, device);
+                    if (rc != UZK_OK) return;
+                    t.ctx.push_back(std::move(nc));
+                    t.busy.push_back(0);
+                    continue;
+                }
+                b.turn_cv.wait(lk);
+            }
+        }
+        ~Turn() {
+            if (!c) return;
+            { std::lock_guard<std::mutex> lk(b.mu); b.turns[device].busy[at] = 0; }
+            b.turn_cv.notify_one();
+        }
+    };
 
     std::string last_error() { return uzk_last_error(); }
 
-    static int home_of(MemberData& m) {
+    int make_slot(uint32_t n, uint32_t cap, int device, std::shared_ptr<Slot>* out) {
+        Turn t(*this, device);
+        UZK_TRY(t.rc);
+        auto s = std::make_shared<Slot>();
+        s->n = n; s->cap = cap; s->device = device;
+        CtxScope scope(t.c);
+        std::lock_guard<std::mutex> lk(t.c->mu);
+        UZK_TRY(require_ready());
+        UZK_TRY(prover_alloc(*t.c, n, cap, &s->prover));
+        *out = s;
+        return UZK_OK;
+    }
+    int home_of(MemberData& m) {
         if (m.home) return UZK_OK;
         return make_slot(m.n, 1, m.device, &m.home);
     }
@@ -134,16 +165,17 @@ struct Backend {
     int move_out(CohortData& from, uint32_t lane, MemberData& to, CohortData& solo) {
         UZK_TRY(home_of(to));
         Slot& s = *from.slot;
-        CtxScope scope(&s.ctx);
-        std::lock_guard<std::mutex> lk(s.ctx.mu);
+        Turn t(*this, s.device);
+        UZK_TRY(t.rc);
+        CtxScope scope(t.c);
+        std::lock_guard<std::mutex> lk(t.c->mu);
         UZK_TRY(require_ready());
         std::lock_guard<std::mutex> p1(s.prover->mu);
         std::lock_guard<std::mutex> p2(to.home->prover->mu);
         Prover& dst = *to.home->prover;
         prover_end_proof(dst);
-        UZK_TRY(prover_move_lane(s.ctx, *s.prover, lane, dst, 0));
+        UZK_TRY(prover_move_lane(*t.c, *s.prover, lane, dst, 0));
         dst.k = 1;
-        dst.owner = &to.home->ctx;
         dst.dead.assign(1, 0);
         solo.slot = to.home;
         solo.pooled = false;
@@ -151,13 +183,10 @@ struct Backend {
     }
 
     int run(CohortData& cd, int round, uint32_t lanes, void* const* args, const uint8_t* present, int* lane_rc, std::string* lane_msg) {
-        struct Turn {
-            Backend& b;
-            explicit Turn(Backend& b_) : b(b_) { std::unique_lock<std::mutex> lk(b.mu); while (b.running >= b.max_running) b.turn.wait(lk); ++b.running; }
-            ~Turn() { { std::lock_guard<std::mutex> lk(b.mu); --b.running; } b.turn.notify_one(); }
-        } my_turn(*this);
         Slot& s = *cd.slot;
-        Ctx& c = s.ctx;
+        Turn t(*this, s.device);
+        UZK_TRY(t.rc);
+        Ctx& c = *t.c;
         CtxScope scope(&c);
         std::lock_guard<std::mutex> lk(c.mu);
         UZK_TRY(require_ready());
@@ -178,7 +207,8 @@ struct Backend {
             }
             rc = round1_lanes(c, p, a0.cir, lanes, L.data(), a0.on_device, a0.pi_index, a0.pi_count, a0.hiding, st.data());
         } else {
-            if (p.k != lanes || p.round != round - 1 || p.owner != &c) { set_error("shared round %d: the workspace holds %u lane(s) after round %d", round, p.k, p.round); return UZK_ERR_PARAMETER; }
+            if (p.k != lanes || p.round != round - 1) { set_error("shared round %d: the workspace holds %u lane(s) after round %d", round, p.k, p.round); return UZK_ERR_PARAMETER; }
+            p.owner = &c;                                // the round before ended synchronised: any internal context may run this one
             // a lane whose caller has gone keeps computing on a neighbour's challenges: nothing of it is ever read
             for (uint32_t b = 0; b < lanes; ++b) if (!present[b]) p.dead[b] = 1;
             auto arg = [&](uint32_t b) { return args[present[b] ? b : first]; };
@@ -189,6 +219,14 @@ struct Backend {
         }
         for (uint32_t b = 0; b < lanes; ++b) { lane_rc[b] = st[b].rc; lane_msg[b] = st[b].msg; }
         return rc;
+    }
+
+    void release_all() {
+        std::lock_guard<std::mutex> lk(mu);
+        pool.clear();
+        for (auto& kv : turns)
+            for (auto& c : kv.second.ctx) ctx_release_internal(*c);
+        turns.clear();
     }
 };
 
@@ -246,8 +284,7 @@ void coalesce_release_all() {
         (void)s.core.remove(&kv.second->member);
         destroy_shared(*kv.second);
     }
-    std::lock_guard<std::mutex> lk(s.backend.mu);
-    s.backend.pool.clear();
+    s.backend.release_all();
 }
 
 }  // namespace uzk
@@ -273,10 +310,11 @@ int uzk_coalesce_config(uint32_t max_lanes, uint32_t gather_wait_us, uint32_t st
     return UZK_OK;
 } catch (...) { return uzk::on_exception("uzk_coalesce_config"); }
 
-int uzk_coalesce_stats(uint64_t out[5]) try {
-    if (!out) { set_error("uzk_coalesce_stats: null pointer"); return UZK_ERR_PARAMETER; }
+int uzk_coalesce_stats(uint64_t out[16]) try {
+    if (!out) { st().core.reset_stats(); return UZK_OK; }
     const Core::Stats s = st().core.stats();
-    out[0] = s.rounds; out[1] = s.lanes; out[2] = s.widest; out[3] = s.moved_out; out[4] = s.cohorts;
+    out[0] = s.rounds; out[1] = s.lanes; out[2] = s.widest; out[3] = s.moved_out; out[4] = s.cohorts; out[5] = s.gap_us; out[6] = s.gaps; out[7] = s.gather_us;
+    for (int i = 0; i < 8; ++i) out[8 + i] = s.first_round_sizes[i];
     return UZK_OK;
 } catch (...) { return uzk::on_exception("uzk_coalesce_stats"); }
 

@@ -5,9 +5,13 @@
 // uzkge/src/plonk/prover.rs:88-100; zshuffle's SDK, shuffle/src/sdk.rs:196-214), and at n = 2^14 one proof leaves most of an
 // MI355X idle.  The library therefore merges callers that stand at the same round of proofs over the same circuit:
 //
-//   * round 1: the first caller opens a COHORT and waits a bounded time (gather_wait) for others -- not at all when no other
-//     prover of its kind is idle; whoever completes the cohort (it is full, the wait is over, nobody else can come) runs the
-//     round for every lane on its own thread and wakes the rest;
+//   * the provers of a kind (same size, same device) are dealt into `groups` TEAMS -- a few launch sequences side by side fill the
+//     chip better than one wide one, and more than a handful of busy streams cost it dearly; with up to `groups` provers every
+//     one is its own team and nothing is ever merged;
+//   * round 1: the first caller of a team opens a COHORT and waits a bounded time (gather_wait) for its team-mates -- not at all
+//     when none of them is about to start a proof; whoever completes the cohort (it is full, the wait is over, nobody else can
+//     come) runs the round for every lane on its own thread and wakes the rest.  Team-mates that proved together finish together
+//     and come back together, so in the steady state a cohort re-forms within microseconds;
 //   * rounds 2..R: the cohort's members meet again; the last to arrive runs the round.  A member that stays away longer than
 //     straggler_wait is MOVED OUT: the backend copies its lane into the member's own workspace, where its proof goes on alone;
 //   * a lane whose own data is at fault fails alone; a member that abandons its proof (destroys the prover, starts another
@@ -25,6 +29,8 @@
 #pragma once
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <condition_variable>
 #include <cstdint>
 #include <cstring>
@@ -46,6 +52,7 @@ public:
     struct Member {
         typename Backend::MemberData data;
         uint64_t group = 0;                      // members of one group can share a cohort at all (same n, same device)
+        int team = -1;                           // which of the group's teams it gathers with (dealt at its first proof, re-dealt when the teams get lopsided)
         std::shared_ptr<Cohort> cohort;
         uint32_t lane = 0;
         int round = 0;                           // rounds completed of the proof in flight
@@ -67,33 +74,36 @@ public:
     };
     struct Cohort {
         Key key;
+        int team = 0;
         bool gathering = true, running = false;
         int next_round = 1;
         uint32_t alive = 0, arrived = 0;
         std::vector<LaneRec> lanes;
-        Clock::time_point deadline;
+        Clock::time_point deadline, last_done{}, born{};
         std::condition_variable cv;
         typename Backend::CohortData data;
     };
 
-    CoalesceCore(Backend& b, int rounds, uint32_t max_lanes = 8, uint32_t gather_wait_us = 500, uint32_t straggler_wait_us = 20000, uint32_t groups = 4)
+    CoalesceCore(Backend& b, int rounds, uint32_t max_lanes = 8, uint32_t gather_wait_us = 2000, uint32_t straggler_wait_us = 20000, uint32_t groups = 4)
         : backend_(b), rounds_(rounds), max_lanes_(max_lanes), groups_(groups), gather_wait_(gather_wait_us), straggler_wait_(straggler_wait_us) {}
 
-    // groups: how many cohorts the active provers of a kind are spread over (a cohort takes at most ceil(active / groups) lanes):
-    // a few independent launch sequences side by side fill the chip better than one wide one
+    // groups: how many teams the provers of a kind are dealt into
     void configure(uint32_t max_lanes, uint32_t gather_wait_us, uint32_t straggler_wait_us, uint32_t groups) {
         std::lock_guard<std::mutex> lk(mu_);
         max_lanes_ = std::max<uint32_t>(1, max_lanes);
         groups_ = std::max<uint32_t>(1, groups);
         gather_wait_ = std::chrono::microseconds(gather_wait_us);
-        merge_wait_ = 20 * gather_wait_;
         straggler_wait_ = std::chrono::microseconds(std::max<uint32_t>(1, straggler_wait_us));
         stats_ = Stats();
     }
     uint32_t max_lanes() { std::lock_guard<std::mutex> lk(mu_); return max_lanes_; }
     // rounds run, lanes (callers) served by them, the widest round, lanes moved out, cohorts opened -- since the last configure()
-    struct Stats { uint64_t rounds = 0, lanes = 0, widest = 0, moved_out = 0, cohorts = 0; };
+    // gap_us: host time between the end of a cohort's round and the start of its next one (its callers wake, take their
+    // results, come back with the next challenges), summed over the `gaps` rounds that had a predecessor; gather_us: time cohorts
+    // spent open, from their first caller's arrival to the start of their first round
+    struct Stats { uint64_t rounds = 0, lanes = 0, widest = 0, moved_out = 0, cohorts = 0, gap_us = 0, gaps = 0, gather_us = 0, first_round_sizes[8] = {}; };
     Stats stats() { std::lock_guard<std::mutex> lk(mu_); return stats_; }
+    void reset_stats() { std::lock_guard<std::mutex> lk(mu_); stats_ = Stats(); }
 
     void add(Member* m) { std::lock_guard<std::mutex> lk(mu_); m->last_seen = Clock::now(); members_.push_back(m); }
     // false: the member is inside a call on another thread (it stays registered)
@@ -121,15 +131,24 @@ public:
         std::shared_ptr<Cohort> g;
         if (round == 1) {
             leave_locked(m, lk);                 // a proof in flight is abandoned
-            const uint32_t cap = lane_cap(key->group, Clock::now());
+            const auto now = Clock::now();
+            const int team_before = m->team;
+            deal(m, now);
+            trace("arrive", m, nullptr, team_before);
             for (auto& c : gathering_)
-                if (c->key == *key && c->lanes.size() < cap) { g = c; break; }
+                if (c->team == m->team && c->key == *key && c->lanes.size() < max_lanes_) { g = c; break; }
+            // whoever joins brings its companions of the last proof a moment behind it: the cohort's time starts again (a cohort
+            // that has been held open for the rest of its team would otherwise leave with the first of them)
+            if (g) g->deadline = std::max(g->deadline, now + gather_wait_);
             if (!g) {
                 g = std::make_shared<Cohort>();
                 g->key = *key;
-                g->deadline = Clock::now() + gather_wait_;
+                g->team = m->team;
+                g->born = now;
+                g->deadline = now + gather_wait_;
                 gathering_.push_back(g);
                 live_.push_back(g);
+                trace("open", m, g.get(), 0);
             }
             m->cohort = g;
             m->lane = (uint32_t)g->lanes.size();
@@ -155,13 +174,20 @@ public:
             if (l.done_round >= round) break;
             if (!g->running) {
                 if (g->gathering) {
-                    // Enough launch sequences of this kind are under way already (`crowded`): rather than add an under-filled one,
-                    // the cohort stays open -- the members of the next cohort to finish fill it -- for up to merge_wait_.  That is what
-                    // makes callers with unrelated phases converge on `groups_` full cohorts instead of many small ones.
+                    // Go when the cohort is full, when its time is up, or when no team-mate can be expected soon.  While the team has
+                    // ANOTHER cohort under way that is at least as large (team-mates whose phases differ: the start, or after one of
+                    // them came late) this one stays open until that cohort's proof ends -- its members then join, and from then on
+                    // the team stays together; the wait is bounded by three times the wait for a straggler (a proof of a full cohort
+                    // on a busy chip takes longer than one straggler_wait).  The larger part never waits for the smaller one beyond
+                    // gather_wait.
                     const auto now = Clock::now();
-                    const bool crowded = others_live(g.get()) >= groups_;
-                    const auto deadline = crowded ? g->deadline + merge_wait_ : g->deadline;
-                    if (g->lanes.size() >= lane_cap(g->key.group, now) || now >= deadline || (!crowded && company_in_sight(g.get(), now) == 0)) { run_round(g, lk, false); continue; }
+                    const bool hold = larger_part_under_way(g.get());
+                    const auto deadline = hold ? g->born + 3 * straggler_wait_ : g->deadline;
+                    if (g->lanes.size() >= max_lanes_ || now >= deadline || (!hold && mates_in_sight(g.get(), now) == 0)) {
+                        trace(now >= deadline ? "go-deadline" : hold ? "go-full" : "go-complete", m, g.get(), (int)hold);
+                        run_round(g, lk, false);
+                        continue;
+                    }
                     wait(g->cv, lk, deadline - now);
                     continue;
                 }
@@ -190,35 +216,49 @@ private:
 #endif
     }
 
-    // Lanes a cohort of this group takes at most right now: the provers at work (in a proof, in a call, or seen within `recent_`)
-    // spread over groups_ cohorts, never more than max_lanes_.
-    uint32_t lane_cap(uint64_t group, Clock::time_point now) const {
-        uint32_t active = 0;
-        for (const Member* o : members_)
-            if (o->group == group && (o->cohort || o->in_call || now - o->last_seen < recent_)) ++active;
-        return std::min(max_lanes_, std::max<uint32_t>(1, (active + groups_ - 1) / groups_));
+    // UZK_COALESCE_TRACE=1: the gathering decisions on stderr (microseconds since the first event, member, team, cohort, its size)
+    void trace(const char* what, const Member* m, const Cohort* g, int extra) {
+        static const bool on = std::getenv("UZK_COALESCE_TRACE") != nullptr;
+        if (!on) return;
+        static const auto t0 = Clock::now();
+        std::fprintf(stderr, "[coalesce %8lld] %-11s member %p team %d cohort %p size %zu extra %d\n",
+                     (long long)std::chrono::duration_cast<std::chrono::microseconds>(Clock::now() - t0).count(), what, (const void*)m, m ? m->team : -1, (const void*)g,
+                     g ? g->lanes.size() : 0, extra);
     }
 
-    // Members of g's group that could still join it before its wait is over: provers between two proofs that were at work a moment
-    // ago (their threads are probably about to start the next proof), and provers in the LAST round of a proof (they come back
-    // for the next one when it ends).  Provers in the middle of a proof cannot arrive within gather_wait; provers that have been
-    // idle for long belong to threads that are doing something else.
-    uint32_t company_in_sight(const Cohort* g, Clock::time_point now) const {
+    static bool at_work(const Member* o, Clock::time_point now, std::chrono::microseconds recent) { return o->cohort || o->in_call || now - o->last_seen < recent; }
+
+    // Teams of m's group: as many as `groups_`, more when a team would exceed max_lanes_.  m keeps its team unless it has none or
+    // the teams have become lopsided (provers came or went): then it moves to the emptiest one.
+    void deal(Member* m, Clock::time_point now) {
+        uint32_t active = 0;
+        for (const Member* o : members_) if (o->group == m->group && (o == m || at_work(o, now, recent_))) ++active;
+        const uint32_t teams = std::max<uint32_t>(groups_, (active + max_lanes_ - 1) / max_lanes_);
+        std::vector<uint32_t> load(teams, 0);
+        for (const Member* o : members_)
+            if (o != m && o->group == m->group && o->team >= 0 && (uint32_t)o->team < teams && at_work(o, now, recent_)) load[o->team]++;
+        uint32_t best = 0;
+        for (uint32_t t = 1; t < teams; ++t) if (load[t] < load[best]) best = t;
+        if (m->team < 0 || (uint32_t)m->team >= teams || load[m->team] > load[best]) m->team = (int)best;      // (loads without m: equal teams stay as they are)
+    }
+
+    // Team-mates of g's members that could still join before its wait is over: provers between two proofs that were at work a
+    // moment ago, and provers in the LAST round of a proof.  Provers in the middle of a proof cannot arrive within gather_wait;
+    // provers idle for long belong to threads that are doing something else.
+    uint32_t mates_in_sight(const Cohort* g, Clock::time_point now) const {
         uint32_t c = 0;
         for (const Member* o : members_) {
-            if (o->group != g->key.group || o->cohort.get() == g) continue;
+            if (o->group != g->key.group || o->team != g->team || o->cohort.get() == g) continue;
             if (!o->cohort) { if (o->in_call || now - o->last_seen < recent_) ++c; }
-            else if (!o->cohort->gathering && o->cohort->next_round >= rounds_) ++c;
+            else if (!o->cohort->gathering && o->cohort->next_round >= rounds_ && o->cohort->key == g->key) ++c;
         }
         return c;
     }
-
-    // live cohorts of g's kind (same group, same key) besides g
-    uint32_t others_live(const Cohort* g) const {
-        uint32_t c = 0;
+    // the team has another cohort of this kind under way with at least as many members as g
+    bool larger_part_under_way(const Cohort* g) const {
         for (const auto& o : live_)
-            if (o.get() != g && o->key == g->key) ++c;
-        return c;
+            if (o.get() != g && o->team == g->team && o->key == g->key && !o->gathering && o->alive >= g->lanes.size()) return true;
+        return false;
     }
 
     void finish_cohort(const std::shared_ptr<Cohort>& g, std::unique_lock<std::mutex>& lk) {
@@ -250,6 +290,11 @@ private:
         const bool first = g->gathering;
         if (first) { g->gathering = false; gathering_.remove(g); }
         g->running = true;
+        const auto started = Clock::now();
+        if (g->last_done != Clock::time_point{}) {
+            stats_.gap_us += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(started - g->last_done).count();
+            stats_.gaps++;
+        }
         const int r = g->next_round;
         const uint32_t k = (uint32_t)g->lanes.size();
         std::vector<void*> args(k, nullptr);
@@ -278,12 +323,13 @@ private:
         std::string all_msg;
         if (rc != 0) all_msg = backend_.last_error();
         lk.lock();
+        g->last_done = Clock::now();
         {
             uint64_t served = 0;
             for (uint32_t i = 0; i < k; ++i) served += present[i];
             stats_.rounds++; stats_.lanes += served; stats_.widest = std::max(stats_.widest, served);
             stats_.moved_out += out_lanes.size();
-            if (first) stats_.cohorts++;
+            if (first) { stats_.first_round_sizes[std::min<uint64_t>(served, 8) - 1]++; stats_.cohorts++; stats_.gather_us += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(started - g->born).count(); }
         }
         for (size_t j = 0; j < out_lanes.size(); ++j) {
             LaneRec& l = g->lanes[out_lanes[j]];
@@ -294,7 +340,7 @@ private:
             if (move_rc[j] == 0) {
                 std::shared_ptr<Cohort>& h = solos[j];
                 live_.push_back(h);
-                h->key = g->key; h->gathering = false; h->next_round = r; h->alive = 1;
+                h->key = g->key; h->team = g->team; h->gathering = false; h->next_round = r; h->alive = 1;
                 h->lanes.emplace_back();
                 h->lanes[0].m = m;
                 m->cohort = h; m->lane = 0;
@@ -331,7 +377,7 @@ private:
     std::list<std::shared_ptr<Cohort>> gathering_, live_;      // cohorts still taking members; every cohort that is not over
     Stats stats_;
     uint32_t max_lanes_, groups_;
-    std::chrono::microseconds gather_wait_, straggler_wait_, recent_{5000}, merge_wait_{10000};
+    std::chrono::microseconds gather_wait_, straggler_wait_, recent_{5000};
 };
 
 }  // namespace uzk
