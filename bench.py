@@ -272,8 +272,9 @@ def _gather_proofs(dist, world, mine):
         dist.all_gather_object(objs, mine)
         per = objs
     rates = [p.get("proofs_per_s") for p in per]
-    return {"what": "every rank runs tests/cpp/prover_rounds on its own GPU (4 host threads x 8 proofs in lockstep, one circuit resident "
-                    "per process): whole proofs' device work through uzk_prove_round1..5, no collective",
+    return {"what": "every rank runs tests/cpp/prover_rounds on its own GPU in the reference's call pattern -- 32 host threads, each calling "
+                    "uzk_prove_round1..5 on its own prover of ONE proof from the default context, its own witness uploaded from pinned memory "
+                    "every proof; the library shares the rounds (uzk_coalesce_config defaults) -- one circuit resident per process, no collective",
             "per_rank": per, "proofs_per_s_total": (sum(rates) if all(r is not None for r in rates) else None)}
 
 
@@ -536,9 +537,9 @@ def run_rank(args) -> None:
     # ---- proofs per second, one prover process per device (the realistic scaling mode at n = 2^14) --------
     if world > 1 and not args.no_extras:
         try:
-            lines = _run_prover_rounds([15, 4, 8], visible_device=dev_index)
+            lines = _run_prover_rounds([10, 32, 1, "shared", 0], visible_device=dev_index)
             mine_p = {"rank": rank, "device": dev_index, "proofs_per_s": lines[-1]["proofs_per_s"], "ms_per_proof_single": lines[0]["ms_per_chain"],
-                      "threads_agree_with_single": lines[-1]["threads_agree_with_single"]}
+                      "proofs_per_shared_round": lines[-1].get("proofs_per_shared_round"), "threads_agree_with_single": lines[-1]["threads_agree_with_single"]}
         except Exception as e:
             mine_p = {"rank": rank, "device": dev_index, "error": str(e)[-300:]}
         proofs = _gather_proofs(dist, world, mine_p)
@@ -755,20 +756,25 @@ def run_rank(args) -> None:
         except Exception as e:
             extra["prover_chain"] = {"error": str(e)}
         try:     # the same chain issued from compiled host code (tests/cpp/prover_rounds.cpp, built by __graft_entry__.build())
-            lines = _run_prover_rounds([20, 4])
-            extra["prover_rounds_cpp"] = dict(lines[0], what="one proof's device work through uzk_circuit_create / uzk_prove_round1..5 from C++ (plain "
-                                              "g++, the C ABI only); median of five timed blocks after 0.5 s of warm-up; ms_per_chain = witness resident, "
-                                              "ms_per_chain_with_witness_upload = the 8n witness elements uploaded from pinned memory every proof; "
-                                              "four_threads = four host threads (one context and one prover each, one shared circuit); lockstep = four "
-                                              "threads x four proofs per uzk_prove_round call (uzk_prover_create(n, 4): commits over the 15-bit window table); lockstep8 = four "
-                                              "threads x eight proofs per call (the throughput setting; proofs_per_s_total takes the better of the two)")
+            lines = _run_prover_rounds([20, 4, 1, "private", 0])
+            extra["prover_rounds_cpp"] = dict(lines[0], what="proofs through uzk_circuit_create / uzk_prove_round1..5 from C++ (plain g++, the C ABI only).  First "
+                                              "the latency of ONE proof on a prover that owns its lane: median of five timed blocks after 0.5 s of warm-up; "
+                                              "ms_per_chain = witness resident, ms_per_chain_with_witness_upload = the 8n witness elements uploaded from pinned "
+                                              "memory every proof.  Then throughput, where EVERY proof has its own witness, public inputs, blinds, challenges and "
+                                              "r_poly scalars, its witness is uploaded from pinned memory at the start of every proof, and every thread's proofs are "
+                                              "compared with the single-threaded proof of the same inputs: shared_N = N host threads, each calling round 1..5 on its own "
+                                              "prover of one proof from the default context -- the reference's call pattern (prover.rs:88-100, sdk.rs:196-214), the "
+                                              "library shares the rounds (uzk_coalesce_config defaults; proofs_per_shared_round says how well); shared_32_skewed = the "
+                                              "same on the witness classes of SURVEY F7 (50 % zero, 20 % one, 10 % minus one, 10 % < 2^16, 10 % uniform); lockstep8 = the "
+                                              "explicit API, four threads x eight witnesses per uzk_prove_round call (uzk_prover_create(n, 8)), and lockstep8_skewed; "
+                                              "private_4 = four threads, each a prover that owns its lane on its own context.  proofs_per_s_total = shared_32: what a "
+                                              "caller of prover_with_lagrange gets.")
             if len(lines) > 1:
-                extra["prover_rounds_cpp"]["four_threads"] = lines[1]
-            lines = _run_prover_rounds([20, 4, 4])
-            extra["prover_rounds_cpp"]["lockstep"] = lines[-1]
-            lines = _run_prover_rounds([15, 4, 8])
-            extra["prover_rounds_cpp"]["lockstep8"] = lines[-1]              # four threads x EIGHT proofs per round call: the throughput setting
-            extra["proofs_per_s_total"] = max(extra["prover_rounds_cpp"]["lockstep"]["proofs_per_s"], lines[-1]["proofs_per_s"])
+                extra["prover_rounds_cpp"]["private_4"] = lines[1]
+            for key, a in (("shared_8", [10, 8, 1, "shared", 0]), ("shared_16", [10, 16, 1, "shared", 0]), ("shared_32", [10, 32, 1, "shared", 0]),
+                           ("shared_32_skewed", [10, 32, 1, "shared", 1]), ("lockstep8", [10, 4, 8, "lockstep", 0]), ("lockstep8_skewed", [10, 4, 8, "lockstep", 1])):
+                extra["prover_rounds_cpp"][key] = _run_prover_rounds(a)[-1]
+            extra["proofs_per_s_total"] = extra["prover_rounds_cpp"]["shared_32"]["proofs_per_s"]
         except Exception as e:
             extra["prover_rounds_cpp"] = {"error": str(e)}
         try:     # the per-game refresh of the twelve public-key tables (params.rs:88-121) as one device call

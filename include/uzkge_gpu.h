@@ -130,6 +130,22 @@ int uzk_srs_release(uint64_t handle);
 int uzk_srs_precompute(uint64_t handle, int window_bits);
 int uzk_srs_len(uint64_t handle, size_t* n_out);
 
+/* ---- sharded SRS: one MSM over several GPUs from one process ------------------------------------------------------------------
+ * north_star / SURVEY.md 8e: "MSM shards by point-chunk across the 8 GPUs of one node".  The bases are cut into n_devices
+ * contiguous chunks (chunk i = [i n / N, (i + 1) n / N)), chunk i is copied to the HBM of devices[i] once and stays there; an MSM
+ * call runs the chunks side by side (one host thread each, each uploading only its part of the scalars) and folds the N 96-byte
+ * partial sums on the host (uzk_g1_fold).  Bases and scalars never move between devices.  devices[] may name an ordinal more
+ * than once (several chunks on one GPU: what the single-GPU tests do).  window_bits: -1 no window table, 0 automatic, 4 .. 24.
+ * (One process per GPU with the partial sums exchanged by RCCL is the other form of the same split: uzkge_amd/sharded.py,
+ * bench.py --gpus N.) */
+int uzk_srs_register_sharded(const uzk_g1_affine* points, size_t n, const int* devices, uint32_t n_devices, int window_bits, uint64_t* handle_out);
+int uzk_srs_release_sharded(uint64_t handle);
+/* sum_i scalars[i] * SRS[i], i < n <= the SRS length (a short vector touches the first chunks only).  partials_out (optional):
+ * the n_devices partial sums in chunk order. */
+int uzk_msm_g1_sharded(uint64_t handle, const uint64_t* scalars_mont, size_t n, uzk_g1_jac* partials_out, uzk_g1_jac* out);
+/* length, number of chunks, their devices (n_chunks entries) and bounds (2 n_chunks entries: lo, hi); every output optional */
+int uzk_srs_sharded_info(uint64_t handle, size_t* n_out, uint32_t* n_chunks_out, int* devices_out, size_t* bounds_out);
+
 /* ---- MSM: replaces G1Projective::msm (kzg_poly_commitment.rs:290) ---------------------- */
 /* out = sum_{i<n} scalars[i] * SRS[offset + i].  n == 0 -> infinity.  offset + n > len ->
  * UZK_ERR_DEGREE.  Zero scalars and infinity bases contribute the identity. */
@@ -531,12 +547,18 @@ int uzk_msm_set_window_bits(int c);
 /* What a general-mode MSM over n points will use: signed window width and window count (every
  * point is added into one bucket per window: n * windows mixed additions). */
 int uzk_msm_plan_info(size_t n, int* window_bits, int* windows);
-/* Experiment switches for A/B measurements in one process (keys: "msm_acc_variant",
- * "msm_task_len", "msm_no_precompute", "msm_fold_group", "msm_overlap", "msm_sort_packed", "msm_fused_hist", "msm_reduce_seg", "msm_scan_reduce", "msm_quad_reduce", "ntt_tile",
- * "msm_chunk_log", "msm_stream_log", "msm_stream_min_log", "msm_small", "msm_fold_mode", "ntt_l29", "ntt_fused", "ntt_mulc", "ntt_planes",
- * "msm_seg_sort", "msm_chunk_sort", "msm_class_reduce", "msm_fold_big", "msm_bucket_fill", "msm_direct", "msm_scan_nb_log", "ntt_prio", "ntt_order",
- * "prover_t_cap": round 3 reads t as its first 5n - 2 + sum(hiding) coefficients -- for the timing / parity chains on synthetic circuits
- * whose witness satisfies nothing); never needed for correctness. */
+/* The switches of the calling thread's current context (a context made afterwards inherits them).  None changes a result.
+ *   "msm_no_precompute"   1: ignore window tables (uzk_srs_precompute): the general pipeline over the plain bases -- what a host
+ *                         sets when HBM is short; the A/B of table against no table
+ *   "msm_stream_log"      log2 of the point chunk in which the host scalars of a large MSM are uploaded while the previous chunk
+ *                         is accumulated (0 = 21); -1: never stream -- upload, then one MSM
+ *   "msm_stream_min_log"  host-scalar MSMs of at least 2^this points are streamed (default 22)
+ *   "msm_chunk_log"       points per sort pass of one MSM (default 26, the index space of the sort; lower = less workspace)
+ *   "msm_small"           0: n <= 2^15 takes the general pipeline too (default 1: one workgroup per (vector, window))
+ *   "msm_seg_sort"        0: the generic last sort pass instead of one workgroup per segment; 10 + k: segment kernel k at any size
+ *   "ntt_tile"            1024 / 2048: elements per workgroup of an NTT pass at every size (default 0: by size)
+ * The last three exist so that the tests reach every pipeline and instantiation at sizes the CPU oracle can check
+ * (tests/test_gpu_variants.py).  Unknown keys are UZK_ERR_PARAMETER. */
 int uzk_tune(const char* key, int value);
 
 #ifdef __cplusplus

@@ -114,6 +114,35 @@ impl Drop for Srs {
     }
 }
 
+/// An SRS cut into contiguous point chunks over the GPUs of a node, driven from this one process (`uzk_srs_register_sharded`):
+/// chunk i = [i n / N, (i + 1) n / N) lives on `devices[i]`; `msm` runs the chunks side by side and folds the 96-byte partial
+/// sums on the host -- north_star's "MSM shards by point-chunk across the 8 GPUs of one node" behind one call.
+pub struct ShardedSrs {
+    handle: u64,
+    len: usize,
+}
+impl ShardedSrs {
+    /// `window_bits`: -1 no window table, 0 automatic, 4..24.
+    pub fn register(points: &[uzk_g1_affine], devices: &[c_int], window_bits: c_int) -> Result<Self, Error> {
+        let mut handle = 0u64;
+        check(unsafe { uzk_srs_register_sharded(points.as_ptr(), points.len(), devices.as_ptr(), devices.len() as u32, window_bits, &mut handle) })?;
+        Ok(ShardedSrs { handle, len: points.len() })
+    }
+    pub fn len(&self) -> usize { self.len }
+    pub fn is_empty(&self) -> bool { self.len == 0 }
+    /// sum_i scalars[i] * SRS[i]
+    pub fn msm(&self, scalars_mont: &[[u64; 4]]) -> Result<uzk_g1_jac, Error> {
+        let mut out = uzk_g1_jac::default();
+        check(unsafe { uzk_msm_g1_sharded(self.handle, scalars_mont.as_ptr() as *const u64, scalars_mont.len(), std::ptr::null_mut(), &mut out) })?;
+        Ok(out)
+    }
+}
+impl Drop for ShardedSrs {
+    fn drop(&mut self) {
+        unsafe { uzk_srs_release_sharded(self.handle) };
+    }
+}
+
 /// In-place transform over the size-`data.len()` domain, natural order (`EvaluationDomain::{fft, ifft}`);
 /// `coset_shift`: forward = pre-scale by shift^j, inverse = post-scale by shift^j (pass k^-1).
 pub fn ntt(data: &mut [[u64; 4]], inverse: bool, coset_shift: Option<&[u64; 4]>) -> Result<(), Error> {

@@ -206,9 +206,9 @@ def test_precomputed_mode_matches_oracle(gpu, c):
         srs.release()
 
 
-def test_experiment_switches_do_not_change_the_result(gpu):
-    """uzk_tune knobs (canonical-arithmetic accumulate loop, two overlapping pipeline groups, forced
-    one-lane folds) are speed experiments: the commitment must be identical with each of them."""
+def test_switches_do_not_change_the_result(gpu):
+    """uzk_tune's remaining switches choose a pipeline, never a result: without the window table, with the generic last sort pass,
+    with a forced segment-sort instantiation."""
     n = 1 << 20
     pts = torch.empty((n, 8), dtype=torch.int64, device="cuda")
     sc = torch.empty((n, 4), dtype=torch.int64, device="cuda")
@@ -218,12 +218,14 @@ def test_experiment_switches_do_not_change_the_result(gpu):
     srs = gpu.Srs.from_device(pts.data_ptr(), n)
     try:
         ref = gpu.g1_to_affine(gpu.msm_device(srs, sc.data_ptr(), n))
-        for key in ("msm_acc_variant", "msm_overlap", "msm_fold_group"):
-            gpu.tune(key, 1)
+        for key, val, back in (("msm_seg_sort", 0, 1), ("msm_seg_sort", 12, 1), ("msm_no_precompute", 1, 0)):
+            gpu.tune(key, val)
             try:
-                assert np.array_equal(gpu.g1_to_affine(gpu.msm_device(srs, sc.data_ptr(), n)), ref), key
+                assert np.array_equal(gpu.g1_to_affine(gpu.msm_device(srs, sc.data_ptr(), n)), ref), (key, val)
             finally:
-                gpu.tune(key, 0)
+                gpu.tune(key, back)
+        with pytest.raises(Exception):
+            gpu.tune("msm_acc_variant", 1)          # the experiment switches of earlier rounds are gone from the ABI
     finally:
         srs.release()
 

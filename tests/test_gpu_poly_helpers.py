@@ -15,19 +15,15 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("n,batch", [(1, 1), (3, 2), (17, 5), (1024, 2), (1025, 2), (4096, 3), (16384, 9), (16387, 20), (65536, 3), (65537, 2),
                                      (98304, 6), (100000, 2), (262144, 1), (262145, 2)])
 def test_poly_eval_batch(gpu, n, batch):
-    """Both evaluation paths -- the one-launch kernel for <= 256 blocks of 1024 coefficients and the table-driven one -- against
-    the oracle; repeated calls (the one-launch kernel's arrival counters must come back to zero) and the forced other path."""
+    """Both evaluation paths -- the one-launch kernel for <= 256 blocks of 1024 coefficients (n <= 2^18) and the table-driven one
+    beyond -- against the oracle; repeated calls (the one-launch kernel's arrival counters must come back to zero)."""
     c = rand_fr_wire(n * batch, 10 + n).reshape(batch, n, 4)
     x = rand_fr_wire(1, 77)[0]
     want = [oc.poly_eval(c[b], x) for b in range(batch)]
-    try:
-        for small in (1, 1, 0, 1):
-            gpu.tune("poly_small", small)
-            got = gpu.poly_eval_batch(c, x)
-            for b in range(batch):
-                assert np.array_equal(got[b], want[b]), (n, b, small)
-    finally:
-        gpu.tune("poly_small", 1)
+    for rep in range(3):
+        got = gpu.poly_eval_batch(c, x)
+        for b in range(batch):
+            assert np.array_equal(got[b], want[b]), (n, b, rep)
 
 
 def test_poly_eval_special_points(gpu):

@@ -156,8 +156,8 @@ def test_random_2p20_points_vs_oracle(gpu):
 
 def test_headline_paths_2p23_variants_agree(gpu):
     """The code paths only the large configurations reach -- digits + first histogram in one kernel (needs >= 256
-    sort chunks, i.e. n >= 2^23), the 512-lane scatter of sorts with >= 2^26 entries -- against the separate
-    kernels and the canonical accumulator, on the same device-generated input."""
+    sort chunks, i.e. n >= 2^23), the 512-lane scatter of sorts with >= 2^26 entries -- against the generic last sort pass
+    and, through the split property, against smaller sizes the oracle checks."""
     n = 1 << 23
     pts = torch.empty((n, 8), dtype=torch.int64, device="cuda")
     sc = torch.empty((n, 4), dtype=torch.int64, device="cuda")
@@ -167,12 +167,11 @@ def test_headline_paths_2p23_variants_agree(gpu):
     srs = gpu.Srs.from_device(pts.data_ptr(), n)
     try:
         ref = affine_of(gpu.msm_device(srs, sc.data_ptr(), n))
-        for key, val in (("msm_fused_hist", 0), ("msm_acc_variant", 2), ("msm_sort_packed", 0)):
-            gpu.tune(key, val)
-            try:
-                assert affine_of(gpu.msm_device(srs, sc.data_ptr(), n)) == ref, key
-            finally:
-                gpu.tune(key, {"msm_fused_hist": 1, "msm_acc_variant": 0, "msm_sort_packed": 1}[key])
+        gpu.tune("msm_seg_sort", 0)
+        try:
+            assert affine_of(gpu.msm_device(srs, sc.data_ptr(), n)) == ref
+        finally:
+            gpu.tune("msm_seg_sort", 1)
         # split property ties the value to smaller, oracle-checked sizes
         h1 = gpu.msm_device(srs, sc.data_ptr(), n // 2)
         h2 = gpu.msm_device(srs, sc.data_ptr() + (n // 2) * 32, n // 2, offset=n // 2)
@@ -200,18 +199,17 @@ def test_point_chunk_loop_small(gpu):
     assert chunked == one == affine_of(oc.msm_pippenger(wire[:3000], s, 0, 2))
 
 
-@pytest.mark.parametrize("cfg,chunk,fold_big", [(1, 1, 1), (10, 1, 1), (13, 1, 1), (15, 1, 1), (0, 1, 1), (1, 0, 1), (0, 0, 1), (1, 1, 0)])
-def test_segment_sort_skewed_segments(gpu, cfg, chunk, fold_big):
+@pytest.mark.parametrize("cfg", [1, 10, 13, 15, 0])
+def test_segment_sort_skewed_segments(gpu, cfg):
     """The one-workgroup-per-segment last sort pass (msm_radix_segment_kernel) next to the generic kernels it leaves the
     long segments to: 2^20 points whose scalars are uniform except for runs that put (a) 40000 entries into one bucket
     (longer than any instantiation holds: the generic path), (b) 30000 into one bucket (fits the registers of the largest
     instantiation but not its LDS buffer: written directly), (c) 2 x 12500 into two buckets of one segment (two LDS
     rounds), (d) 3000 into one bucket (beyond the small instantiations).  Every instantiation forced in turn (10 + k),
     the automatic choice (1) and the generic path alone (0) give the closed-form result.  The same runs reach the first
-    pass's one-workgroup-per-chunk kernel (msm_radix_chunk_kernel; `chunk` = 0: the generic tile scatter): run (a) fills
-    one bin of chunk 0 beyond the LDS buffer (direct writes), the uniform rest goes out in rounds of whole bins.
-    The planted buckets hold hundreds of partial sums, so the extra fold levels run: with one wave per long fold
-    (msm_fold_big_kernel, `fold_big` = 1) and with the one-lane-per-output kernels alone (0)."""
+    pass's one-workgroup-per-chunk kernel (msm_radix_chunk_kernel): run (a) fills one bin of chunk 0 beyond the LDS buffer
+    (direct writes), the uniform rest goes out in rounds of whole bins.  The planted buckets hold hundreds of partial sums, so
+    the extra fold levels run, with one wave per long fold (msm_fold_big_kernel)."""
     n = 1 << 20
     pts = torch.empty((n, 8), dtype=torch.int64, device="cuda")
     sc = torch.empty((n, 4), dtype=torch.int64, device="cuda")
@@ -229,14 +227,10 @@ def test_segment_sort_skewed_segments(gpu, cfg, chunk, fold_big):
     torch.cuda.synchronize()
     srs = gpu.Srs.from_device(pts.data_ptr(), n)
     gpu.tune("msm_seg_sort", cfg)
-    gpu.tune("msm_chunk_sort", chunk)
-    gpu.tune("msm_fold_big", fold_big)
     try:
         got = affine_of(gpu.msm_device(srs, sc.data_ptr(), n))
     finally:
         gpu.tune("msm_seg_sort", 1)
-        gpu.tune("msm_chunk_sort", 1)
-        gpu.tune("msm_fold_big", 1)
         srs.release()
     k = weighted_index_sum(host)
     assert got == opy.g1_mul(opy.g1_mul(opy.G1_GEN, seed_int), k)

@@ -1,7 +1,7 @@
-"""Every selectable code path of the MSM gives the same commitment: accumulator variants (29-bit limbs,
-8 x 32-bit relaxed, canonical), packed / unpacked sort entries, fused / separate first histogram,
-both bucket reductions, forced task lengths and fold-group widths, window sizes on either side of the
-automatic choice -- and the two NTT arithmetic variants give identical bytes."""
+"""The pipelines the library chooses between by size give the same commitment / the same bytes: window widths on either side of
+the automatic choice (the scan, quad and class-sum bucket reductions, one / two / three sort passes), the segment sort and the
+generic last sort pass, the small-problem pipeline against the general one, both NTT tile sizes -- reached at sizes the CPU
+oracle can check through the switches uzk_tune keeps for exactly that (include/uzkge_gpu.h)."""
 import numpy as np
 import pytest
 import torch
@@ -12,17 +12,11 @@ from util import affine_of
 pytestmark = pytest.mark.gpu
 
 KNOBS = [
-    {}, {"msm_acc_variant": 1}, {"msm_acc_variant": 2}, {"msm_sort_packed": 0}, {"msm_fused_hist": 0},
-    {"msm_quad_reduce": 0}, {"msm_scan_reduce": 0}, {"msm_scan_reduce": 2}, {"msm_scan_reduce": 3}, {"msm_scan_reduce": 3, "msm_reduce_seg": 16},
-    {"msm_scan_reduce": 3, "window_bits": 17}, {"msm_scan_reduce": 3, "window_bits": 9}, {"msm_reduce_seg": 4}, {"msm_task_len": 5}, {"msm_task_len": 300},
-    {"msm_fold_group": 1}, {"msm_fold_group": 16}, {"window_bits": 9}, {"window_bits": 12}, {"window_bits": 16}, {"window_bits": 17},
-    # round 3: segment / chunk sort kernels and the class-sum reduction, off one at a time and at window widths on either side
-    {"msm_seg_sort": 0}, {"msm_chunk_sort": 0}, {"msm_class_reduce": 0}, {"msm_class_reduce": 0, "window_bits": 13}, {"window_bits": 13},
-    {"window_bits": 14}, {"window_bits": 18}, {"window_bits": 19}, {"msm_class_reduce": 0, "window_bits": 19}, {"msm_seg_sort": 15, "window_bits": 15},
-    {"msm_bucket_fill": 0}, {"msm_bucket_fill": 0, "msm_task_len": 5}, {"msm_task_len": 3}, {"msm_fold_big": 0, "msm_task_len": 2}, {"msm_direct": 0}, {"msm_direct": 0, "msm_task_len": 2}, {"msm_acc_variant": 1, "msm_task_len": 40},
+    {}, {"window_bits": 9}, {"window_bits": 12}, {"window_bits": 13}, {"window_bits": 14}, {"window_bits": 16}, {"window_bits": 17},
+    {"window_bits": 18}, {"window_bits": 19}, {"msm_seg_sort": 0}, {"msm_seg_sort": 0, "window_bits": 13}, {"msm_seg_sort": 15, "window_bits": 15},
+    {"msm_small": 0}, {"msm_small": 0, "window_bits": 9},
 ]
-DEFAULTS = {"msm_small": 1, "msm_fold_mode": 0, "msm_acc_variant": 0, "msm_sort_packed": 1, "msm_fused_hist": 1, "msm_scan_reduce": 1, "msm_quad_reduce": 1, "msm_x29": 1, "msm_reduce_seg": 0,
-            "msm_task_len": 0, "msm_fold_group": 0, "window_bits": 0, "msm_seg_sort": 1, "msm_chunk_sort": 1, "msm_class_reduce": 1, "msm_bucket_fill": 1, "msm_fold_big": 1, "msm_direct": 1}
+DEFAULTS = {"msm_small": 1, "window_bits": 0, "msm_seg_sort": 1}
 
 
 def _apply(gpu, cfg):
@@ -58,37 +52,34 @@ def test_msm_variants_agree(gpu, log_n):
 
 
 @pytest.mark.parametrize("n", [4096, 1 << 15, 3 << 13, 1 << 19])
-def test_ntt_variants_agree(gpu, n):
+def test_ntt_tiles_agree_and_match_the_oracle(gpu, n):
+    """Both workgroup tile sizes of the pass kernels (1024 / 2048 elements; 0 = chosen by size), out of place and in place (the
+    limb-plane buffers between the passes), forward and inverse: the same bytes, and they are the oracle's."""
     x = torch.empty((n, 4), dtype=torch.int64, device="cuda")
     a = torch.empty((n, 4), dtype=torch.int64, device="cuda")
-    b_ = torch.empty((n, 4), dtype=torch.int64, device="cuda")
     torch.cuda.synchronize()
     gpu.synth_scalars(x.data_ptr(), n, 9)
+    hx = x.cpu().numpy().view(np.uint64).reshape(-1, 4)
     try:
         for inv in (False, True):
-            gpu.tune("ntt_l29", 0); gpu.ntt_device(x.data_ptr(), a.data_ptr(), n, inverse=inv, sync=True)
-            gpu.tune("ntt_l29", 1); gpu.ntt_device(x.data_ptr(), b_.data_ptr(), n, inverse=inv, sync=True)
-            assert torch.equal(a, b_)
-            for tile in (1024, 2048):      # both workgroup tile sizes of the pass kernels (0 = chosen by size)
-                for mulc, planes in ((1, 2), (0, 2), (1, 0), (0, 0), (2, 0), (2, 2)):   # tile twiddles by the constant-operand product (default; 2: with the full reduce) /
-                    gpu.tune("ntt_tile", tile); gpu.tune("ntt_mulc", mulc)     # Montgomery products throughout; limb planes (default) / 8 x 32-bit
-                    gpu.tune("ntt_planes", planes)                             # words between the passes
-                    gpu.ntt_device(x.data_ptr(), a.data_ptr(), n, inverse=inv, sync=True)
-                    assert torch.equal(a, b_), (tile, mulc, planes)
-                    if planes:             # in place and batched through the plane buffers
-                        y = x.clone()
-                        gpu.ntt_device(y.data_ptr(), y.data_ptr(), n, inverse=inv, sync=True)
-                        assert torch.equal(y, b_), (tile, mulc, "in place")
-            gpu.tune("ntt_tile", 0); gpu.tune("ntt_mulc", 1); gpu.tune("ntt_planes", 1)
+            want = torch.from_numpy(oc.ntt(hx, inverse=inv, threads=4).view(np.int64)).reshape(n, 4).cuda()
+            for tile in (0, 1024, 2048):
+                gpu.tune("ntt_tile", tile)
+                gpu.ntt_device(x.data_ptr(), a.data_ptr(), n, inverse=inv, sync=True)
+                assert torch.equal(a, want), (inv, tile)
+                y = x.clone()
+                torch.cuda.synchronize()
+                gpu.ntt_device(y.data_ptr(), y.data_ptr(), n, inverse=inv, sync=True)
+                assert torch.equal(y, want), (inv, tile, "in place")
     finally:
-        gpu.tune("ntt_l29", 1); gpu.tune("ntt_tile", 0); gpu.tune("ntt_mulc", 1); gpu.tune("ntt_planes", 1)
+        gpu.tune("ntt_tile", 0)
 
 
 @pytest.mark.parametrize("n", [1, 2, 33, 1000, 4096, 16384, 32768])
 def test_small_pipeline_agrees_with_general(gpu, n):
     """n <= 2^15 takes the one-workgroup-per-slot pipeline (msm_small_*): same commitments as the general
     pipeline for uniform, prover-mix, all-equal and all-zero scalar vectors, single and batched, at every
-    window size the small path accepts, and for forced task lengths on both sides of the automatic one."""
+    window size the small path accepts, with and without a window table."""
     B = 3
     pts = torch.empty((n, 8), dtype=torch.int64, device="cuda")
     sc = torch.empty((4 * B * n, 4), dtype=torch.int64, device="cuda")
@@ -114,9 +105,7 @@ def test_small_pipeline_agrees_with_general(gpu, n):
             assert want[0] == oc.jac_to_affine_ints(oc.msm_pippenger(hp, hs, 0, 8))
         assert want[-1] is None and want[-2] is None               # all-zero scalars commit to infinity
         gpu.tune("msm_small", 1)
-        for cfg in ({}, {"window_bits": 5}, {"window_bits": 9}, {"window_bits": 10}, {"msm_task_len": 2}, {"msm_task_len": 3}, {"msm_task_len": 200},
-                    {"msm_acc_variant": 1}, {"msm_acc_variant": 2}, {"msm_x29": 0}, {"msm_x29": 0, "window_bits": 10}, {"msm_fold_mode": 1 + 16 + 8}, {"msm_fold_mode": 1 + 16 + 2},
-                    {"msm_fold_mode": 1 + 8}, {"msm_fold_mode": 1 + 4}, {"msm_fold_mode": 1 + 2}, {"msm_fold_mode": 1 + 1}):
+        for cfg in ({}, {"window_bits": 5}, {"window_bits": 9}, {"window_bits": 10}):
             _apply(gpu, cfg)
             gpu.tune("msm_small", 1)
             assert run() == want, cfg
@@ -126,8 +115,6 @@ def test_small_pipeline_agrees_with_general(gpu, n):
         for c in (0, 6, 9):
             srs.precompute(c)
             assert run() == want, ("precompute", c)
-        gpu.tune("msm_small", 2)                                   # one lane per addition in the folds and scans
-        assert run() == want
     finally:
         _apply(gpu, {})
         gpu.tune("msm_small", 1)
@@ -135,37 +122,39 @@ def test_small_pipeline_agrees_with_general(gpu, n):
 
 
 @pytest.mark.parametrize("n", [4096, 1 << 14, 3 << 12, 3 << 13, 98304, 1 << 17, 3 << 16])
-def test_ntt_fused_stages_agree_with_separate_kernels(gpu, n):
-    """Coset scaling and the radix-3 stage of 3 * 2^k domains run inside the first / last Stockham pass
-    (uzk_tune("ntt_fused", 1), the default); the separate scaling / decimation / combination kernels remain behind
-    ntt_fused = 0.  Same bytes for forward and inverse, with and without a coset shift, single and batched, in place
-    and out of place -- and the small sizes are anchored on the oracle."""
+def test_ntt_fused_stages_match_the_oracle(gpu, n):
+    """Coset scaling and the radix-3 stage of 3 * 2^k domains run inside the first / last Stockham pass (sub-transforms of at
+    least 4096 elements; smaller ones keep separate scaling / decimation kernels).  Forward and inverse, with and without a coset
+    shift, single and batched, in place and out of place, both tile sizes: the oracle's bytes."""
     B = 3
     x = torch.empty((B * n, 4), dtype=torch.int64, device="cuda")
     a = torch.empty((B * n, 4), dtype=torch.int64, device="cuda")
     b_ = torch.empty((B * n, 4), dtype=torch.int64, device="cuda")
     torch.cuda.synchronize()
     gpu.synth_scalars(x.data_ptr(), B * n, 90 + n % 7)
+    hx = x.cpu().numpy().view(np.uint64).reshape(B, n, 4)
     shift = oc.fr_from_ints([7, 12345678901234567890123])      # two different coset shifts
     try:
         for inv in (False, True):
             for cs in (None, shift[0], shift[1]):
+                # the reference's wrappers (field_polynomial.rs:589-607): forward = scale by shift^j, then FFT; inverse = iFFT, then
+                # scale by shift^j (the caller passes k^-1)
+                if cs is None:
+                    want = np.stack([oc.ntt(np.ascontiguousarray(hx[k]), inverse=inv, threads=4) for k in range(B)])
+                elif not inv:
+                    want = np.stack([oc.ntt(oc.mul_var(np.ascontiguousarray(hx[k]), cs), threads=4) for k in range(B)])
+                else:
+                    want = np.stack([oc.mul_var(oc.ntt(np.ascontiguousarray(hx[k]), inverse=True, threads=4), cs) for k in range(B)])
+                want_t = torch.from_numpy(want.view(np.int64)).reshape(B * n, 4).cuda()
                 for batch in (1, B):
-                    gpu.tune("ntt_tile", 2048 if (n // 4096) % 2 else 1024)
-                    gpu.tune("ntt_fused", 0)
-                    gpu.ntt_batch_device(x.data_ptr(), a.data_ptr(), n, batch, inverse=inv, coset_shift=cs, sync=True)
-                    gpu.tune("ntt_fused", 1); gpu.tune("ntt_tile", 1024 if (n // 4096) % 2 else 2048)      # the other tile size
-                    gpu.ntt_batch_device(x.data_ptr(), b_.data_ptr(), n, batch, inverse=inv, coset_shift=cs, sync=True)
-                    assert torch.equal(a[:batch * n], b_[:batch * n]), (inv, cs is not None, batch)
+                    for tile in (1024, 2048):
+                        gpu.tune("ntt_tile", tile)
+                        gpu.ntt_batch_device(x.data_ptr(), a.data_ptr(), n, batch, inverse=inv, coset_shift=cs, sync=True)
+                        assert torch.equal(a[:batch * n], want_t[:batch * n]), (inv, cs is not None, batch, tile)
                     gpu.tune("ntt_tile", 0)
                     b_[:batch * n] = x[:batch * n]                           # in place
                     torch.cuda.synchronize()                                 # torch's copy runs on torch's stream, the library on its own
                     gpu.ntt_batch_device(b_.data_ptr(), b_.data_ptr(), n, batch, inverse=inv, coset_shift=cs, sync=True)
-                    assert torch.equal(a[:batch * n], b_[:batch * n]), ("in place", inv, cs is not None, batch)
-        if n <= 98304:
-            hx = x[:n].cpu().numpy().view(np.uint64).reshape(-1, 4)
-            gpu.ntt_device(x.data_ptr(), a.data_ptr(), n, coset_shift=shift[0], sync=True)
-            want = oc.ntt(oc.mul_var(hx, shift[0]))
-            assert np.array_equal(a[:n].cpu().numpy().view(np.uint64).reshape(-1, 4), want)
+                    assert torch.equal(b_[:batch * n], want_t[:batch * n]), ("in place", inv, cs is not None, batch)
     finally:
-        gpu.tune("ntt_fused", 1); gpu.tune("ntt_tile", 0)
+        gpu.tune("ntt_tile", 0)

@@ -138,6 +138,18 @@ def test_circuit_and_prover_entry_points_check_their_arguments_before_the_device
     assert N.lib.uzk_coalesce_config(65, 50, 0, 0) == N.UZK_ERR_PARAMETER
     assert N.lib.uzk_coalesce_config(8, 0, 0, 0) == N.UZK_OK
     assert N.lib.uzk_circuit_info(999, None, None, None, None) == N.UZK_ERR_PARAMETER
+    # several devices behind the ABI: argument errors before anything touches a device
+    dev = (ctypes.c_int * 2)(0, 0)
+    assert N.lib.uzk_srs_register_sharded(p, 4, dev, 0, -1, ctypes.byref(h)) == N.UZK_ERR_PARAMETER       # no chunk
+    assert N.lib.uzk_srs_register_sharded(p, 4, dev, 2, 3, ctypes.byref(h)) == N.UZK_ERR_PARAMETER        # a window width that does not exist
+    assert N.lib.uzk_srs_register_sharded(p, 4, None, 2, -1, ctypes.byref(h)) == N.UZK_ERR_PARAMETER
+    assert N.lib.uzk_msm_g1_sharded((1 << 61) | 5, p, 4, None, p) == N.UZK_ERR_PARAMETER                  # unknown handle
+    assert N.lib.uzk_srs_release_sharded(12345) == N.UZK_ERR_PARAMETER
+    d = ctypes.c_int(-7)
+    assert N.lib.uzk_ctx_device(999, ctypes.byref(d)) == N.UZK_ERR_PARAMETER
+    if b.device_count() == 0:
+        assert N.lib.uzk_ctx_create_on(0, ctypes.byref(h)) == N.UZK_ERR_DEVICE
+        assert N.lib.uzk_srs_register_sharded(p, 4, dev, 2, -1, ctypes.byref(h)) == N.UZK_ERR_DEVICE
     assert N.lib.uzk_test_circuit_truncate_t(999, 1) == N.UZK_ERR_PARAMETER
     assert N.lib.uzk_circuit_release(999) == N.UZK_ERR_PARAMETER
     assert N.lib.uzk_circuit_update_tables(999, 21, 12, p, p) == N.UZK_ERR_PARAMETER
@@ -156,7 +168,7 @@ def test_no_cpp_exception_can_leave_an_entry_point():
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     defined = set()
-    for name in ("api.cpp", "prover.cpp", "coalesce.cpp"):
+    for name in ("api.cpp", "prover.cpp", "coalesce.cpp", "sharded.cpp"):
         src = open(os.path.join(root, "uzkge_amd", "csrc", name)).read()
         for m in re.finditer(r"^int (uzk_[a-z0-9_]+)\([^;{]*\)\s*(try\s*)?\{", src, re.M):
             assert m.group(2), f"{name}: {m.group(1)} is not a function-try-block"

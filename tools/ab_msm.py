@@ -17,7 +17,7 @@ pts = torch.empty((n, 8), dtype=torch.int64, device="cuda"); sc = torch.empty((n
 torch.cuda.synchronize()
 b.synth_points_random(pts.data_ptr(), n, 1); b.synth_scalars(sc.data_ptr(), n, 2)
 srs = b.Srs.from_device(pts.data_ptr(), n)
-DEFAULTS = {"msm_acc_variant": 0, "msm_task_len": 0, "window_bits": 0, "precompute": -1, "msm_overlap": 0, "msm_sort_packed": 1, "msm_reduce_seg": 0, "msm_fused_hist": 1, "msm_scan_reduce": 1, "msm_quad_reduce": 1, "msm_scatter4": 0, "msm_seg_sort": 1, "msm_chunk_sort": 1, "msm_class_reduce": 1, "msm_scan_nb_log": 15, "msm_chunk_log": 26, "msm_bucket_fill": 1, "msm_fold_big": 1, "msm_direct": 1}
+DEFAULTS = {"window_bits": 0, "precompute": -1, "msm_seg_sort": 1, "msm_chunk_log": 26, "msm_small": 1}
 def apply(v):
     cfg = dict(DEFAULTS)
     for kv in v.split(","):

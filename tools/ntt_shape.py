@@ -24,8 +24,7 @@ cases = [("coset fft 98304 x10", lambda: b.ntt_batch_device(buf.data_ptr(), out.
          ("fft 2^22", lambda: b.ntt_device(big.data_ptr(), bout.data_ptr(), 1 << 22)),
          ("coset fft 2^22", lambda: b.ntt_device(big.data_ptr(), bout.data_ptr(), 1 << 22, coset_shift=k)),
          ("coset ifft 2^22", lambda: b.ntt_device(big.data_ptr(), bout.data_ptr(), 1 << 22, inverse=True, coset_shift=k))]
-for fused in (1, 0):
-    b.tune("ntt_fused", fused)
+for fused in (1,):
     for name, fn in cases:
         fn(); b.sync(); t = time.perf_counter()
         for _ in range(a.reps): fn()
@@ -34,4 +33,3 @@ for fused in (1, 0):
         tab = b.profile_table()
         ks = " ".join(f"{kn.replace('ntt_', '')}={ms * 1e3:.0f}x{cnt}" for kn, (cnt, ms) in sorted(tab.items()))
         print(f"fused={fused} {name:22s} {dt * 1e3:8.1f} us | {ks}", flush=True)
-b.tune("ntt_fused", 1)

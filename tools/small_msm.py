@@ -22,7 +22,7 @@ mx = torch.empty((B * n, 4), dtype=torch.int64, device="cuda")
 torch.cuda.synchronize()
 b.synth_points_random(pts.data_ptr(), n, 1); b.synth_scalars(sc.data_ptr(), B * n, 2); b.synth_scalars_mix(mx.data_ptr(), B * n, 3)
 srs = b.Srs.from_device(pts.data_ptr(), n)
-DEF = {"msm_small": 1, "msm_task_len": 0, "window_bits": 0, "precompute": -1, "msm_fold_mode": 0, "msm_x29": 1}
+DEF = {"msm_small": 1, "window_bits": 0, "precompute": -1}
 def apply(v):
     cfg = dict(DEF)
     for kv in v.split(","):

@@ -40,13 +40,9 @@ for t in range(cases):
     elif smode == 3: sc[:] = sc[0]                                  # identical scalars (with repeated points: doublings)
     elif smode == 4: sc[nrng.integers(0, 2, n) == 1] = 0
     c = rng.choice([0, 0, 0, 4, 5, 7, 8, 9, 10, 11, 13, 14, 15, 16, 17, 18])
-    b.tune("msm_quad_reduce", rng.choice([1, 1, 0])); b.tune("msm_scan_reduce", rng.choice([1, 1, 1, 0, 2, 3]))
     b.set_msm_window_bits(c)
-    # round 3: the segment / chunk sort kernels (any instantiation) and the class-sum reduction, on and off
-    b.tune("msm_seg_sort", rng.choice([1, 1, 1, 0, 10, 11, 12, 13, 14, 15])); b.tune("msm_chunk_sort", rng.choice([1, 1, 0]))
-    b.tune("msm_class_reduce", rng.choice([1, 1, 0])); b.tune("msm_bucket_fill", rng.choice([1, 1, 0])); b.tune("msm_fold_big", rng.choice([1, 1, 0])); b.tune("msm_direct", rng.choice([1, 1, 0]))
-    b.tune("msm_small", rng.choice([1, 1, 1, 2, 0]))               # small pipeline (quads / plain lanes) or the general one
-    b.tune("msm_task_len", rng.choice([0, 0, 2, 3, 40]))
+    b.tune("msm_seg_sort", rng.choice([1, 1, 1, 0, 10, 11, 12, 13, 14, 15]))      # the segment sort kernels (any instantiation) or the generic pass
+    b.tune("msm_small", rng.choice([1, 1, 1, 0]))                   # small pipeline or the general one
     if rng.random() < 0.3:                                           # batched entry point: the same vector three times over
         h = b.Srs.from_host(pts)
         if rng.random() < 0.5: h.precompute(rng.choice([0, 5, 8, 10]))
@@ -59,7 +55,7 @@ for t in range(cases):
     if oc.jac_to_affine_ints(got) != oc.jac_to_affine_ints(want):
         bad += 1
         print(f"MISMATCH case {t}: n={n} mode={mode} smode={smode} c={c}", flush=True)
-b.tune("msm_seg_sort", 1); b.tune("msm_chunk_sort", 1); b.tune("msm_class_reduce", 1); b.tune("msm_bucket_fill", 1); b.tune("msm_fold_big", 1); b.tune("msm_direct", 1)
-b.set_msm_window_bits(0); b.tune("msm_small", 1); b.tune("msm_task_len", 0); b.tune("msm_quad_reduce", 1); b.tune("msm_scan_reduce", 1)
+b.tune("msm_seg_sort", 1)
+b.set_msm_window_bits(0); b.tune("msm_small", 1)
 print(f"{cases} cases, {bad} mismatches")
 sys.exit(1 if bad else 0)

@@ -43,10 +43,7 @@ for t in range(cases):
     if batch == 2: sc[n:2 * n].copy_(sc[:n])
     torch.cuda.synchronize()
     c = rng.choice([0, 0, 0, 12, 13, 14, 15, 16, 17])
-    knobs = {"msm_seg_sort": rng.choice([1, 1, 1, 0, 12, 13, 14, 15]), "msm_chunk_sort": rng.choice([1, 1, 0]),
-             "msm_class_reduce": rng.choice([1, 1, 0]), "msm_sort_packed": rng.choice([1, 1, 1, 0]), "msm_fused_hist": rng.choice([1, 1, 0]),
-             "msm_fold_big": rng.choice([1, 1, 0]), "msm_bucket_fill": rng.choice([1, 1, 0]), "msm_direct": rng.choice([1, 1, 0]),
-             "msm_task_len": rng.choice([0, 0, 0, 7, 40])}
+    knobs = {"msm_seg_sort": rng.choice([1, 1, 1, 0, 12, 13, 14, 15])}
     b.set_msm_window_bits(c)
     for k, v in knobs.items(): b.tune(k, v)
     if batch == 2: got = [affine_of(j) for j in b.msm_batch_device(srs, sc.data_ptr(), n, 2)]
@@ -57,7 +54,6 @@ for t in range(cases):
         print(f"MISMATCH case {t}: n={n} kind={kind} batch={batch} c={c} {knobs}", flush=True)
     elif t % 10 == 0: print(f"case {t}: n={n} kind={kind} batch={batch} c={c} ok", flush=True)
 b.set_msm_window_bits(0)
-for k in ("msm_seg_sort", "msm_chunk_sort", "msm_class_reduce", "msm_sort_packed", "msm_fused_hist", "msm_fold_big", "msm_bucket_fill", "msm_direct"): b.tune(k, 1)
-b.tune("msm_task_len", 0)
+b.tune("msm_seg_sort", 1)
 srs.release()
 print(f"{cases} cases, {bad} mismatches")

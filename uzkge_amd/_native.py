@@ -45,6 +45,10 @@ PROTOTYPES = {
     "uzk_srs_release": (_I, [_U64]),
     "uzk_srs_precompute": (_I, [_U64, _I]),
     "uzk_srs_len": (_I, [_U64, ctypes.POINTER(_SZ)]),
+    "uzk_srs_register_sharded": (_I, [_P, _SZ, ctypes.POINTER(_I), ctypes.c_uint32, _I, ctypes.POINTER(_U64)]),
+    "uzk_srs_release_sharded": (_I, [_U64]),
+    "uzk_msm_g1_sharded": (_I, [_U64, _P, _SZ, _P, _P]),
+    "uzk_srs_sharded_info": (_I, [_U64, ctypes.POINTER(_SZ), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(_I), ctypes.POINTER(_SZ)]),
     "uzk_msm_g1": (_I, [_U64, _SZ, _P, _SZ, _P]),
     "uzk_msm_g1_device": (_I, [_U64, _SZ, _P, _SZ, _P]),
     "uzk_msm_g1_batch": (_I, [_U64, _SZ, _P, _SZ, ctypes.c_uint32, _P]),

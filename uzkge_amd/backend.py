@@ -42,6 +42,20 @@ def ctx_create() -> int:
     return h.value
 
 
+def ctx_create_on(device: int) -> int:
+    """A new context on HIP device `device` (uzk_ctx_create_on): SRS handles, circuits and provers made while it is current live
+    there, so one process can drive several GPUs."""
+    h = ctypes.c_uint64(0)
+    check(lib.uzk_ctx_create_on(device, ctypes.byref(h)))
+    return h.value
+
+
+def ctx_device(ctx: int = 0) -> int:
+    d = ctypes.c_int(0)
+    check(lib.uzk_ctx_device(ctx, ctypes.byref(d)))
+    return d.value
+
+
 def ctx_set_current(ctx: int) -> None:
     """Make `ctx` (0 = default) the calling thread's current context."""
     check(lib.uzk_ctx_set_current(ctx))
@@ -60,6 +74,38 @@ def ctx_current() -> int:
 def ctx_wait(other: int) -> None:
     """The calling thread's current context waits on the device for everything queued so far on context `other`."""
     check(lib.uzk_ctx_wait(other))
+
+
+class ShardedSrs:
+    """An SRS cut into contiguous point chunks over several devices of ONE process (uzk_srs_register_sharded): `devices` names the
+    device of every chunk (an ordinal may repeat).  msm() runs the chunks side by side and folds the partial sums on the host."""
+
+    def __init__(self, points: np.ndarray, devices, window_bits: int = -1):
+        pts = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 8)
+        dev = (ctypes.c_int * len(devices))(*devices)
+        h = ctypes.c_uint64(0)
+        check(lib.uzk_srs_register_sharded(_ptr(pts), pts.shape[0], dev, len(devices), window_bits, ctypes.byref(h)))
+        self.handle, self.n, self.n_chunks = h.value, pts.shape[0], len(devices)
+
+    def msm(self, scalars: np.ndarray, want_partials: bool = False):
+        s = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros(12, dtype=np.uint64)
+        parts = np.zeros((self.n_chunks, 12), dtype=np.uint64)
+        check(lib.uzk_msm_g1_sharded(self.handle, _ptr(s), s.shape[0], _ptr(parts) if want_partials else None, _ptr(out)))
+        return (out, parts) if want_partials else out
+
+    def info(self):
+        """(n, [(device, lo, hi) per chunk])"""
+        n, k = ctypes.c_size_t(0), ctypes.c_uint32(0)
+        dev = (ctypes.c_int * self.n_chunks)()
+        bounds = (ctypes.c_size_t * (2 * self.n_chunks))()
+        check(lib.uzk_srs_sharded_info(self.handle, ctypes.byref(n), ctypes.byref(k), dev, bounds))
+        return n.value, [(dev[i], bounds[2 * i], bounds[2 * i + 1]) for i in range(k.value)]
+
+    def release(self) -> None:
+        if self.handle:
+            check(lib.uzk_srs_release_sharded(self.handle))
+            self.handle = 0
 
 
 class Srs:

@@ -307,6 +307,7 @@ int uzk_init(int device) try {
 int uzk_shutdown(void) try {
     Shared& s = shared();
     coalesce_release_all();                // shared provers, their workspaces and internal contexts
+    sharded_release_all();                 // sharded SRSs: their chunks' contexts and registry entries
     prover_release_all();                  // circuits and provers own device memory (takes Shared::mu itself)
     std::lock_guard<std::mutex> lk(s.mu);
     if (!s.bound) return UZK_OK;
@@ -334,13 +335,9 @@ int uzk_shutdown(void) try {
 namespace uzk {
 static void copy_tuning(const Ctx& from, Ctx& to) {
     to.msm_window_bits = from.msm_window_bits;
-    to.tune_acc_variant = from.tune_acc_variant; to.tune_task_len = from.tune_task_len; to.tune_no_precompute = from.tune_no_precompute;
-    to.tune_fold_group = from.tune_fold_group; to.tune_scan_reduce = from.tune_scan_reduce; to.tune_poly_small = from.tune_poly_small; to.tune_tq_split = from.tune_tq_split;
-    to.tune_x29 = from.tune_x29; to.tune_quad_reduce = from.tune_quad_reduce; to.tune_reduce_seg = from.tune_reduce_seg;
-    to.tune_fused_hist = from.tune_fused_hist; to.tune_sort_packed = from.tune_sort_packed; to.tune_ntt_fused = from.tune_ntt_fused;
-    to.tune_ntt_tile = from.tune_ntt_tile; to.tune_ntt_l29 = from.tune_ntt_l29; to.tune_small = from.tune_small;
-    to.tune_fold_mode = from.tune_fold_mode; to.tune_chunk_log = from.tune_chunk_log; to.tune_overlap = from.tune_overlap;
-    to.tune_seg_sort = from.tune_seg_sort; to.tune_direct = from.tune_direct; to.tune_bucket_fill = from.tune_bucket_fill; to.tune_fold_big = from.tune_fold_big; to.tune_scan_nb_log = from.tune_scan_nb_log; to.tune_ntt_prio = from.tune_ntt_prio; to.tune_ntt_order = from.tune_ntt_order; to.tune_class_reduce = from.tune_class_reduce; to.tune_chunk_sort = from.tune_chunk_sort; to.tune_scatter4 = from.tune_scatter4; to.tune_stream_log = from.tune_stream_log; to.tune_stream_min_log = from.tune_stream_min_log; to.tune_prover_t_cap = from.tune_prover_t_cap; to.tune_ntt_mulc = from.tune_ntt_mulc; to.tune_ntt_planes = from.tune_ntt_planes;
+    to.tune_no_precompute = from.tune_no_precompute; to.tune_ntt_tile = from.tune_ntt_tile; to.tune_small = from.tune_small;
+    to.tune_chunk_log = from.tune_chunk_log; to.tune_stream_log = from.tune_stream_log; to.tune_stream_min_log = from.tune_stream_min_log;
+    to.tune_seg_sort = from.tune_seg_sort;
 }
 }  // namespace uzk
 int uzk_ctx_create(uint64_t* ctx_out) try {
@@ -1225,40 +1222,13 @@ int uzk_tune(const char* key, int value) try {
     API_LOCK;
     if (!key) { set_error("uzk_tune: null key"); return UZK_ERR_PARAMETER; }
     Ctx& c = ctx();
-    if (!std::strcmp(key, "msm_acc_variant")) c.tune_acc_variant = value;
-    else if (!std::strcmp(key, "msm_task_len")) c.tune_task_len = value;
-    else if (!std::strcmp(key, "msm_no_precompute")) c.tune_no_precompute = value;
-    else if (!std::strcmp(key, "msm_fold_group")) c.tune_fold_group = value;
-    else if (!std::strcmp(key, "msm_overlap")) c.tune_overlap = value;
-    else if (!std::strcmp(key, "ntt_l29")) c.tune_ntt_l29 = value;
-    else if (!std::strcmp(key, "ntt_fused")) c.tune_ntt_fused = value;
-    else if (!std::strcmp(key, "ntt_mulc")) c.tune_ntt_mulc = (value >= 0 && value <= 2) ? value : 1;
-    else if (!std::strcmp(key, "ntt_planes")) c.tune_ntt_planes = value;
-    else if (!std::strcmp(key, "ntt_tile")) c.tune_ntt_tile = value;
-    else if (!std::strcmp(key, "ntt_prio")) c.tune_ntt_prio = value;
-    else if (!std::strcmp(key, "ntt_order")) c.tune_ntt_order = value;
-    else if (!std::strcmp(key, "msm_sort_packed")) c.tune_sort_packed = value;
-    else if (!std::strcmp(key, "msm_fused_hist")) c.tune_fused_hist = value;
-    else if (!std::strcmp(key, "msm_reduce_seg")) c.tune_reduce_seg = value;
-    else if (!std::strcmp(key, "msm_scan_reduce")) c.tune_scan_reduce = value;
-    else if (!std::strcmp(key, "msm_small")) c.tune_small = value;
-    else if (!std::strcmp(key, "msm_fold_mode")) c.tune_fold_mode = value;
-    else if (!std::strcmp(key, "msm_quad_reduce")) c.tune_quad_reduce = value;
-    else if (!std::strcmp(key, "msm_x29")) c.tune_x29 = value;
-    else if (!std::strcmp(key, "poly_small")) c.tune_poly_small = value;
-    else if (!std::strcmp(key, "tq_split")) c.tune_tq_split = value;
-    else if (!std::strcmp(key, "msm_scatter4")) c.tune_scatter4 = value;
-    else if (!std::strcmp(key, "msm_seg_sort")) c.tune_seg_sort = value;
-    else if (!std::strcmp(key, "msm_direct")) c.tune_direct = value;
-    else if (!std::strcmp(key, "msm_bucket_fill")) c.tune_bucket_fill = value;
-    else if (!std::strcmp(key, "msm_fold_big")) c.tune_fold_big = value;
-    else if (!std::strcmp(key, "msm_scan_nb_log")) c.tune_scan_nb_log = value;
-    else if (!std::strcmp(key, "msm_class_reduce")) c.tune_class_reduce = value;
-    else if (!std::strcmp(key, "msm_chunk_sort")) c.tune_chunk_sort = value;
+    if (!std::strcmp(key, "msm_no_precompute")) c.tune_no_precompute = value;
     else if (!std::strcmp(key, "msm_stream_log")) c.tune_stream_log = (value >= -1 && value <= 26) ? value : 0;
-    else if (!std::strcmp(key, "prover_t_cap")) c.tune_prover_t_cap = value;
     else if (!std::strcmp(key, "msm_stream_min_log")) c.tune_stream_min_log = (value >= 4 && value <= 26) ? value : 22;
     else if (!std::strcmp(key, "msm_chunk_log")) c.tune_chunk_log = (value >= 8 && value <= 26) ? value : 26;
+    else if (!std::strcmp(key, "msm_small")) c.tune_small = value ? 1 : 0;
+    else if (!std::strcmp(key, "msm_seg_sort")) c.tune_seg_sort = value;
+    else if (!std::strcmp(key, "ntt_tile")) c.tune_ntt_tile = (value == 1024 || value == 2048) ? value : 0;
     else { set_error("uzk_tune: unknown key %s", key); return UZK_ERR_PARAMETER; }
     return UZK_OK;
 } catch (...) { return uzk::on_exception("uzk_tune"); }

@@ -85,7 +85,8 @@ public:
     };
 
     CoalesceCore(Backend& b, int rounds, uint32_t max_lanes = 8, uint32_t gather_wait_us = 2000, uint32_t straggler_wait_us = 20000, uint32_t groups = 4)
-        : backend_(b), rounds_(rounds), max_lanes_(max_lanes), groups_(groups), gather_wait_(gather_wait_us), straggler_wait_(straggler_wait_us) {}
+        : backend_(b), rounds_(rounds), max_lanes_(max_lanes), groups_(groups), gather_wait_(gather_wait_us), straggler_wait_(straggler_wait_us),
+          recent_(std::max(std::chrono::microseconds(5000), 4 * std::chrono::microseconds(gather_wait_us))) {}
 
     // groups: how many teams the provers of a kind are dealt into
     void configure(uint32_t max_lanes, uint32_t gather_wait_us, uint32_t straggler_wait_us, uint32_t groups) {
@@ -93,6 +94,7 @@ public:
         max_lanes_ = std::max<uint32_t>(1, max_lanes);
         groups_ = std::max<uint32_t>(1, groups);
         gather_wait_ = std::chrono::microseconds(gather_wait_us);
+        recent_ = std::max(std::chrono::microseconds(5000), 4 * gather_wait_);
         straggler_wait_ = std::chrono::microseconds(std::max<uint32_t>(1, straggler_wait_us));
         stats_ = Stats();
     }
@@ -243,7 +245,7 @@ private:
     }
 
     // Team-mates of g's members that could still join before its wait is over: provers between two proofs that were at work a
-    // moment ago, and provers in the LAST round of a proof.  Provers in the middle of a proof cannot arrive within gather_wait;
+    // moment ago (within a few gathering waits), and provers in the LAST round of a proof.  Provers in the middle of a proof cannot arrive within gather_wait;
     // provers idle for long belong to threads that are doing something else.
     uint32_t mates_in_sight(const Cohort* g, Clock::time_point now) const {
         uint32_t c = 0;
@@ -377,7 +379,7 @@ private:
     std::list<std::shared_ptr<Cohort>> gathering_, live_;      // cohorts still taking members; every cohort that is not over
     Stats stats_;
     uint32_t max_lanes_, groups_;
-    std::chrono::microseconds gather_wait_, straggler_wait_, recent_{5000};
+    std::chrono::microseconds gather_wait_, straggler_wait_, recent_;      // recent_: how long after its last call a prover still counts as at work
 };
 
 }  // namespace uzk

@@ -101,40 +101,14 @@ struct Ctx {
     Fp* msm_tail_host = nullptr;   // pinned: the tail scalars of the current call (uzk_msm_g1_batch_tail_device)
     size_t msm_tail_cap = 0;
     int msm_window_bits = 0;  // 0 = auto
-    int tune_acc_variant = 0; // experiments (uzk_tune)
-    int tune_task_len = 0;
-    int tune_no_precompute = 0;
-    int tune_fold_group = 0;
-    int tune_scan_reduce = 1; // bucket reduction by suffix scans: 1 = for windows of <= 2^14 buckets, 2 = always, 3 = always with quads, 0 = never
-    int tune_tq_split = 3;    // small domains: the quotient kernel's term groups on separate waves per 64 points; 3 / 1: at three / two waves per SIMD, 0: one lane per point
-    int tune_poly_small = 1;  // 1: one-launch kernels for small polynomials (evaluation)
-    int tune_x29 = 1;         // 1: quad reductions on the 29-bit-limb form (ecquad29.hpp), 0: on the 8 x 32-bit arithmetic
-    int tune_quad_reduce = 1; // 1: up to 2^19 buckets the scan reduction runs on quads (ecquad.hpp); 0: lanes only
-    int tune_reduce_seg = 0;  // experiment: buckets per lane in the bucket reduction (0 = default)
-    int tune_fused_hist = 1;  // 1: the digit kernel also produces the first sort pass's histograms (large n)
-    int tune_sort_packed = 1; // 1: 4-byte entries between the two sort passes when the fields fit
-    int tune_ntt_fused = 1;   // 1: coset scaling and the radix-3 stage inside the first / last pass (0: separate kernels)
-    int tune_ntt_tile = 0;    // elements per workgroup of an NTT pass: 2048 (512 threads), 1024 (256 threads), 0 = by size
-    int tune_ntt_order = 0;   // experiment: the passes' radix bits as decimal digits (868 = 2^8, 2^6, 2^8); 0 = the plan's choice
-    int tune_ntt_prio = 0;    // experiment: wave priorities in the NTT passes (ntt.hip ntt_prio_start / ntt_prio_step)
-    int tune_ntt_planes = 1;  // 1: the intermediate vectors of a plain multi-pass transform of <= 2^20 elements are limb planes (36 B per element), 2: at every size, 0: 8 x 32-bit words
-    int tune_ntt_mulc = 1;    // 1: the tile twiddles of the NTT passes go through the constant-operand product (fp29.hpp mulc), 0: Montgomery products throughout, 2: as 1 with the full reduce() for the untwiddled butterfly outputs (A/B)
-    int tune_ntt_l29 = 1;     // 1: NTT passes on the 29-bit-limb representation (0: 8x32-bit relaxed Montgomery)
-    int tune_small = 1;       // 1: n <= 2^15 takes the one-workgroup-per-slot pipeline (msm_small_*)
-    int tune_fold_mode = 0;   // experiment: level-1 fold of the small pipeline = 1 + 16 * quad + lanes per chunk
-    int tune_chunk_log = 26;  // point-chunk size of one sort pass (tests lower it to reach the chunk loop at small n)
-    int tune_stream_log = 0;  // log2 of the point chunk of a streamed host-scalar MSM (0 = 21); -1: never stream (upload, then one MSM)
+    // uzk_tune: switches with a production use, and three that let the tests reach every pipeline at small sizes
+    int tune_no_precompute = 0;    // 1: ignore window tables (uzk_srs_precompute) -- the general pipeline over the plain bases
+    int tune_ntt_tile = 0;         // elements per workgroup of an NTT pass: 2048 (512 threads), 1024 (256 threads), 0 = by size
+    int tune_small = 1;            // 1: n <= 2^15 takes the one-workgroup-per-slot pipeline (msm_small_*); 0: the general pipeline at every size
+    int tune_chunk_log = 26;       // point-chunk size of one sort pass (tests lower it to reach the chunk loop at small n)
+    int tune_stream_log = 0;       // log2 of the point chunk of a streamed host-scalar MSM (0 = 21); -1: never stream (upload, then one MSM)
     int tune_stream_min_log = 22;  // host-scalar MSMs of at least 2^this points are streamed (tests lower it)
-    int tune_seg_sort = 1;    // 1: last pass of a packed two-pass sort = one workgroup per segment (msm_radix_segment_kernel); 10 + k: instantiation k whatever the size (tests)
-    int tune_chunk_sort = 1;  // 1: first pass of a packed two-pass sort = one workgroup per 32768-digit chunk in registers (msm_radix_chunk_kernel)
-    int tune_class_reduce = 1; // 1: bucket windows of >= 2^12 buckets are reduced through class sums (msm_class_sums_kernel)
-    int tune_scan_nb_log = 15; // log2 of the bucket windows of the task scans (msm_scan_win: one workgroup per window)
-    int tune_fold_big = 1;    // 1: outputs that fold many partial sums (skewed scalars) take one wave each (msm_fold_big_kernel)
-    int tune_bucket_fill = 1; // 1: the task schedule is written by one lane per bucket (msm_bucket_fill_kernel), 0: one search per task
-    int tune_direct = 1;      // 1: a bucket that is one task is written by the accumulator itself (msm.hip task_dst)
-    int tune_scatter4 = 0;    // experiment: large packed sorts scatter 8192-entry tiles of 4-byte words (msm_radix_scatter4_kernel): measured slower
-    int tune_prover_t_cap = 0; // tests / timing chains on synthetic (unsatisfied) circuits: round 3 takes t as its first 5n - 2 + sum(hiding) coefficients and ignores what lies beyond
-    int tune_overlap = 0;     // 1: run large MSMs as two overlapping pipeline instances (experiment)  // 1: force one lane per bucket in the fold kernels
+    int tune_seg_sort = 1;         // 1: last pass of a packed two-pass sort = one workgroup per segment (msm_radix_segment_kernel); 0: the generic kernels; 10 + k: instantiation k whatever the size (tests)
     // poly.hip workspaces (grow-only)
     DevBuf poly_tmp, poly_tmp2, poly_io, zpoly_tmp, open_tmp, poly_args;
     DevBuf poly_cnt;                 // per-polynomial arrival counters of poly_eval_small (zero between calls); trimmed-length results
@@ -203,6 +177,7 @@ int ctx_init_internal(Ctx& c, int device);     // a context no handle names, rea
 void ctx_release_internal(Ctx& c);
 void devices_synchronize();                    // every device a context has been made ready on
 void coalesce_release_all();                   // coalesce.cpp (uzk_shutdown)
+void sharded_release_all();                    // sharded.cpp (uzk_shutdown)
 // api.cpp: the process-wide SRS registry and the pinned-block table, for prover.cpp
 uint64_t srs_insert(const Ctx::Srs& e);
 bool srs_lookup(uint64_t handle, Ctx::Srs* out);

@@ -430,82 +430,6 @@ __global__ __launch_bounds__(TB) void msm_radix_scatter_kernel(RadixArgs a) {
     }
 }
 
-// EXPERIMENT (uzk_tune("msm_scatter4", 1); off by default -- a negative result, profiles/r03_ab_scatter4.txt): the same scatter for
-// passes whose OUTPUT is a 4-byte word (the packed intermediate entry, or the final index | sign), i.e. every pass of the large
-// sorts, with a tile of TB * E = 8192 entries: with 512 bins a tile leaves 16 entries = 64 bytes per bin, a whole memory line
-// (the 4096-entry tile's 32-byte runs cost 1.85x write traffic at 2^24, rocprofv3 WRITE_SIZE); the tile is kept in LDS as the
-// output word plus a 16-bit bin (6 bytes per entry instead of 8), and the destination of entry k is one table lookup
-// (pos = delta[bin] + k).  Measured per pass at 2^24: 1.11 ms against 1.01 ms for the 4096-entry tile, 2^23: 0.55 vs 0.50, 2^26:
-// equal -- the scatter is bound by its LDS round trips and their barriers, not by the partial-line writes.
-template <int TB, int E, bool FROM_DIGITS, bool OUT_VAL, bool PK_IN>
-__global__ __launch_bounds__(TB) void msm_radix_scatter4_kernel(RadixArgs a) {
-    constexpr int TILE = TB * E;
-    __shared__ uint32_t ebuf[TILE];
-    __shared__ uint16_t bbuf[TILE];
-    __shared__ uint32_t tcnt[512], toff[512], gcur[512], wsum[16];
-    const uint32_t tid = threadIdx.x;
-    for (uint32_t item = blockIdx.x;; item += gridDim.x) {   // later passes: grid-stride over the work items
-    uint32_t seg, base, lo, hi;
-    size_t cidx;
-    if (!radix_work<FROM_DIGITS>(a, item, seg, cidx, base, lo, hi)) return;
-    const uint32_t* coff = a.prefix + cidx;
-    for (uint32_t b = tid; b < a.bins; b += TB) gcur[b] = a.bin_base[(size_t)seg * a.bins + b] + coff[b];
-    uint32_t* out = OUT_VAL ? a.out_vals : reinterpret_cast<uint32_t*>(a.out_entries);
-    const uint32_t low_mask = (1u << a.shift) - 1;
-    for (uint32_t t0 = lo; t0 < hi; t0 += TILE) {
-        for (uint32_t b = tid; b < a.bins; b += TB) tcnt[b] = 0;
-        __syncthreads();
-        uint32_t word[E], rank[E];
-        uint16_t bin[E];
-        bool ok[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const uint32_t k = t0 + tid + e * TB;
-            uint32_t key = 0, val = 0;
-            ok[e] = (k < hi) && radix_load<FROM_DIGITS, PK_IN>(a, seg, base, k, key, val);
-            bin[e] = (uint16_t)((key >> a.shift) & a.mask);
-            word[e] = OUT_VAL ? val : pk_make(key & low_mask, val, a.pk_out_bits);
-            if (ok[e]) rank[e] = atomicAdd(&tcnt[bin[e]], 1u);
-        }
-        __syncthreads();
-        {   // exclusive scan of tcnt[0..bins) -> toff: each wave scans whole 64-bin groups
-            const uint32_t ngroups = (a.bins + 63) / 64, lane = tid & 63;
-            for (uint32_t g = tid >> 6; g < ngroups; g += TB / 64) {
-                const uint32_t b = g * 64 + lane;
-                const uint32_t v = (b < a.bins) ? tcnt[b] : 0;
-                uint32_t incl = v;
-                for (int o = 1; o < 64; o <<= 1) {
-                    const uint32_t t = __shfl_up((int)incl, o);
-                    if ((int)lane >= o) incl += t;
-                }
-                if (b < a.bins) toff[b] = incl - v;
-                if (lane == 63) wsum[g] = incl;
-            }
-            __syncthreads();
-            for (uint32_t b = tid; b < a.bins; b += TB) {
-                uint32_t pre = 0;
-                for (uint32_t g = 0; g < (b >> 6); ++g) pre += wsum[g];
-                toff[b] += pre;
-            }
-            __syncthreads();
-        }
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            if (ok[e]) { const uint32_t at = toff[bin[e]] + rank[e]; ebuf[at] = word[e]; bbuf[at] = bin[e]; }
-        }
-        const uint32_t last = a.bins - 1;
-        const uint32_t total = toff[last] + tcnt[last];
-        __syncthreads();
-        // toff becomes delta = global cursor - tile offset (wraps harmlessly), the cursor moves on
-        for (uint32_t b = tid; b < a.bins; b += TB) { const uint32_t g0 = gcur[b]; gcur[b] = g0 + tcnt[b]; toff[b] = g0 - toff[b]; }
-        __syncthreads();
-        for (uint32_t k = tid; k < total; k += TB) out[toff[bbuf[k]] + k] = ebuf[k];
-        __syncthreads();
-    }
-    if constexpr (FROM_DIGITS) return;
-    }
-}
-
 // Last pass of a packed two-pass sort, ONE workgroup per segment (round 3).  After the first pass a segment -- the entries of
 // one window that share the key's high bits -- is n / 512 entries long (32768 at n = 2^24): short enough to sit in one
 // workgroup's registers (E entries per lane).  The workgroup then does the whole pass by itself: histogram of the low key bits
@@ -825,37 +749,6 @@ __device__ __forceinline__ void find_task(uint32_t tid, const uint32_t* __restri
 struct TaskDesc { uint32_t start, cnt, task; uint32_t pad; };
 constexpr uint32_t kLenBins = 256;
 
-__device__ __forceinline__ void task_extent(uint32_t tid, const uint32_t* __restrict__ win_base, uint32_t W,
-                                            const uint32_t* __restrict__ task_off, const uint32_t* __restrict__ bucket_start,
-                                            const uint32_t* __restrict__ bucket_count, uint32_t NB, uint32_t L,
-                                            uint32_t& start, uint32_t& cnt) {
-    uint32_t w, b, j;
-    find_task(tid, win_base, W, task_off, NB, w, b, j);
-    // balanced split: the bucket's T = ceil(total / L) tasks get floor(total/T) or +1 points each
-    const uint32_t total = bucket_count[(size_t)w * NB + b];
-    const uint32_t T = (total + L - 1) / L;
-    const uint32_t q = total / T, r = total - q * T;
-    start = bucket_start[(size_t)w * NB + b] + j * q + min(j, r);
-    cnt = q + (j < r ? 1u : 0u);
-}
-// hist[len] += number of tasks of that length
-__global__ __launch_bounds__(256) void msm_task_hist_kernel(const uint32_t* __restrict__ win_base, uint32_t W,
-                                                            const uint32_t* __restrict__ task_off,
-                                                            const uint32_t* __restrict__ bucket_start,
-                                                            const uint32_t* __restrict__ bucket_count, uint32_t NB, uint32_t L,
-                                                            uint32_t* __restrict__ hist) {
-    __shared__ uint32_t h[kLenBins];
-    h[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid < win_base[W]) {
-        uint32_t start, cnt;
-        task_extent(tid, win_base, W, task_off, bucket_start, bucket_count, NB, L, start, cnt);
-        atomicAdd(&h[min(cnt, kLenBins - 1)], 1u);
-    }
-    __syncthreads();
-    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
-}
 // cursor[len] = number of tasks strictly longer than len  (longest first)
 __global__ __launch_bounds__(256) void msm_task_scan_kernel(const uint32_t* __restrict__ hist, uint32_t* __restrict__ cursor) {
     __shared__ uint32_t h[kLenBins];
@@ -868,38 +761,12 @@ __global__ __launch_bounds__(256) void msm_task_scan_kernel(const uint32_t* __re
     __syncthreads();
     cursor[threadIdx.x] = h[threadIdx.x];
 }
-__global__ __launch_bounds__(256) void msm_task_fill_kernel(const uint32_t* __restrict__ win_base, uint32_t W,
-                                                            const uint32_t* __restrict__ task_off,
-                                                            const uint32_t* __restrict__ bucket_start,
-                                                            const uint32_t* __restrict__ bucket_count, uint32_t NB, uint32_t L,
-                                                            uint32_t* __restrict__ cursor, TaskDesc* __restrict__ desc) {
-    __shared__ uint32_t h[kLenBins], base[kLenBins];
-    h[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = tid < win_base[W];
-    uint32_t start = 0, cnt = 0, key = 0, rank = 0;
-    if (live) {
-        task_extent(tid, win_base, W, task_off, bucket_start, bucket_count, NB, L, start, cnt);
-        key = min(cnt, kLenBins - 1);
-        rank = atomicAdd(&h[key], 1u);
-    }
-    __syncthreads();
-    if (h[threadIdx.x]) base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], h[threadIdx.x]);
-    __syncthreads();
-    if (live) {
-        TaskDesc d;
-        d.start = start; d.cnt = cnt; d.task = tid; d.pad = 0;
-        desc[base[key] + rank] = d;
-    }
-}
-
 // The same schedule without a search per task (round 3): one lane per BUCKET.  A bucket's tasks are two runs of equal lengths
 // (r of q + 1 points, T - r of q), so the lane reserves two ranges of the schedule (LDS-aggregated counters, as above) and
 // writes its descriptors; task ids are win_base[w] + task_off[bucket] + j as everywhere.  Buckets with more than kFillInline
 // tasks (skewed scalars) are appended to a list and written by one wave each (msm_task_fill_big_kernel).  The histogram of
-// the lengths comes from msm_scan_win_kernel.  Replaces msm_task_hist_kernel + msm_task_fill_kernel (one binary search over
-// the window's 2^15 prefixes per task, twice: 0.18 ms at 2^24).
+// the lengths comes from msm_scan_win_kernel.  (Round 3; it replaced a histogram and a fill kernel that did one binary search over
+// the window's 2^15 prefixes per task, twice: 0.18 ms at 2^24.)
 constexpr uint32_t kFillInline = 4;
 struct BigBucket { uint32_t start, total, T, tid0; };
 __global__ __launch_bounds__(256) void msm_bucket_fill_kernel(const uint32_t* __restrict__ win_base, const uint32_t* __restrict__ task_cnt,
@@ -976,34 +843,6 @@ __global__ __launch_bounds__(64) void msm_task_fill_big_kernel(const uint32_t* _
 __device__ __forceinline__ XYZZ& task_dst(XYZZ* __restrict__ partials, XYZZ* __restrict__ direct, uint32_t task) {
     return (task & kSignBit) ? direct[task & ~kSignBit] : partials[task];
 }
-template <int MINW, bool RELAXED>
-__global__ __launch_bounds__(256, MINW) void msm_accumulate_kernel(const Affine* __restrict__ points,
-                                                             const uint32_t* __restrict__ sorted,
-                                                             const TaskDesc* __restrict__ desc,
-                                                             const uint32_t* __restrict__ win_base,
-                                                             XYZZ* __restrict__ partials, uint32_t W, XYZZ* __restrict__ direct = nullptr) {
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= win_base[W]) return;
-    const TaskDesc d = desc[slot];
-    const uint32_t cnt = d.cnt;
-    const uint32_t* run = sorted + d.start;
-    XYZZ acc = xyzz_inf();
-    uint32_t e = run[0];
-    Affine p = load_point(points, e & ~kSignBit);
-    for (uint32_t k = 0; k < cnt; ++k) {
-        const Affine cur = p;
-        const bool neg = (e & kSignBit) != 0;
-        if (k + 1 < cnt) {
-            e = run[k + 1];
-            p = load_point(points, e & ~kSignBit);
-        }
-        if constexpr (RELAXED) xyzz_madd_rx(acc, cur, neg);
-        else xyzz_madd(acc, cur, neg);
-    }
-    if constexpr (RELAXED) xyzz_canon(acc);
-    task_dst(partials, direct, d.task) = acc;
-}
-
 // The same loop on the 29-bit-limb accumulator (ec29.hpp).  A task whose additions degenerate
 // (the next point equals +-the running sum) is appended to exc_list and left to
 // msm_accumulate_exc_kernel; for SRS-like inputs that list is empty.
@@ -2011,8 +1850,8 @@ static int msm_group_plan(Ctx& c, MsmGroup& g, size_t n, uint32_t batch, int cb,
     g.NBL = 1u << g.kb;
     g.S0 = pre ? batch : batch * W;                         // sort segments
     g.seg_n = pre ? (uint32_t)g.per_poly : g.n32;
-    // bucket windows of <= 2^scan_nb_log (<= 2^15) buckets for the task scans, as many of them as the 1024-entry window table holds
-    g.NB = std::min<uint32_t>(g.NBL, 1u << std::max(10, std::min(15, c.tune_scan_nb_log)));
+    // bucket windows of <= 2^15 buckets for the task scans, as many of them as the 1024-entry window table holds
+    g.NB = std::min<uint32_t>(g.NBL, 1u << 15);
     while (((uint64_t)g.S0 * g.NBL) / g.NB > 1024 && g.NB < (1u << 15)) g.NB <<= 1;
     g.Wd = (uint32_t)(((uint64_t)g.S0 * g.NBL) / g.NB);
     g.TBK = (uint64_t)g.Wd * g.NB;
@@ -2025,46 +1864,44 @@ static int msm_group_plan(Ctx& c, MsmGroup& g, size_t n, uint32_t batch, int cb,
     // 0.16 -> 0.09 ms at n = 2^16, 0.55 -> 0.35 ms at 2^19; beyond that the segments get long or the quads queue behind
     // each other, and the lane form is as fast (measured at 2^20 and 2^24: 0.59 vs 0.61 ms at best).
     const uint64_t total_buckets = (uint64_t)g.RW * g.NBL;
-    const bool auto_quad = c.tune_scan_reduce == 1 && c.tune_quad_reduce && total_buckets <= (1u << 19);
-    g.quad_reduce = c.tune_scan_reduce == 3 || auto_quad;
-    g.scan_reduce = c.tune_scan_reduce >= 2 || g.quad_reduce || (c.tune_scan_reduce == 1 && g.NBL <= (1u << 14));
+    g.quad_reduce = total_buckets <= (1u << 19);
+    g.scan_reduce = g.quad_reduce || g.NBL <= (1u << 14);
     if (g.scan_reduce) {
-        uint32_t sg = c.tune_reduce_seg > 0 ? (uint32_t)c.tune_reduce_seg : 8u;
-        if (g.quad_reduce && c.tune_reduce_seg <= 0) {
+        uint32_t sg = 8u;
+        if (g.quad_reduce) {
             sg = 1;
             while ((uint64_t)sg * 32768 < total_buckets) sg <<= 1;
         }
         while (sg & (sg - 1)) sg &= sg - 1;                                  // power of two
         g.rl = g.quad_reduce ? kQuadLanes : 256u;
         // small windows (c = 8: 128 buckets): one workgroup per window, its partial needs no folding (0.094 -> 0.071 ms)
-        if (g.quad_reduce && c.tune_reduce_seg <= 0 && g.NBL <= 4 * g.rl) sg = std::max<uint32_t>(sg, g.NBL / g.rl);
+        if (g.quad_reduce && g.NBL <= 4 * g.rl) sg = std::max<uint32_t>(sg, g.NBL / g.rl);
         sg = std::max<uint32_t>(1, std::min<uint32_t>(sg, g.NBL / g.rl));
         while ((g.NBL + sg * g.rl - 1) / (sg * g.rl) > g.rl) sg <<= 1;
         g.seg = sg;
     } else {
-        g.seg = std::max<uint32_t>(1, std::min<uint32_t>(c.tune_reduce_seg > 0 ? (uint32_t)c.tune_reduce_seg : kSeg, g.NBL / 256));
+        g.seg = std::max<uint32_t>(1, std::min<uint32_t>(kSeg, g.NBL / 256));
     }
     g.groups = (g.NBL + g.seg * g.rl - 1) / (g.seg * g.rl);
     // windows of >= 2^12 buckets: class sums first (2 x 256 sums per window), the scans above on those
     g.class_s = 0; g.nb2 = 0;
-    if (c.tune_class_reduce && g.NBL >= 4096 && g.NBL <= (1u << 18) && (uint64_t)g.RW * 2 <= 65535) {
+    if (g.NBL >= 4096 && g.NBL <= (1u << 18) && (uint64_t)g.RW * 2 <= 65535) {
         g.class_s = 8;
         g.nb2 = std::max<uint32_t>(256, g.NBL >> 8);
     }
     const uint64_t all_entries = (uint64_t)W_total * n * batch;
     // Task length: long enough that a typical bucket (4x the mean population) is ONE task -- its partial
     // sum then needs no folding -- but short enough that there are >= ~200k tasks to fill the chip
-    // (measured, tools/ab_msm.py msm_task_len sweeps at 2^14 .. 2^24).  Larger buckets are split evenly.
+    // (measured: task-length sweeps at 2^14 .. 2^24, profiles/r01*_sweep*.txt).  Larger buckets are split evenly.
     const uint64_t mean_pop = (pre ? (uint64_t)W_total * n : (uint64_t)n) >> g.kb;
-    g.L = c.tune_task_len > 0 ? (uint32_t)c.tune_task_len
-                              : (uint32_t)std::max<uint64_t>(16, std::min<uint64_t>(256, std::min<uint64_t>(4 * mean_pop, all_entries / 200000)));
+    g.L = (uint32_t)std::max<uint64_t>(16, std::min<uint64_t>(256, std::min<uint64_t>(4 * mean_pop, all_entries / 200000)));
     g.bound0 = g.entries / g.L + g.TBK;                     // upper bound on level-0 tasks
     g.part_cap = g.bound0 + 2 * g.TBK;                      // every later level fits too
     g.P = g.kb <= 9 ? 1 : (g.kb <= 18 ? 2 : 3);             // radix passes of <= 9 bits, high bits first
     // Two-pass sorts: take 9 bits first when that lets {remaining key bits, sign, index} fit 32 bits --
     // the entries between the passes are then 4 bytes instead of 8 (a third of the sort's traffic less).
     g.pk_bits = 0;
-    if (g.P == 2 && !pre && c.tune_sort_packed) {
+    if (g.P == 2 && !pre) {
         uint32_t ib = 1;
         while ((1ull << ib) < g.seg_n) ++ib;
         const uint32_t first_bits = std::min<uint32_t>(9, g.kb - 1);
@@ -2140,7 +1977,7 @@ static int msm_group_phase1(Ctx& c, MsmGroup& g, const Affine* points, const Sca
     uint32_t* d_max = sm + 3200;
     UZK_HIP(hipMemsetAsync(d_max, 0, 4, st));
     // general mode, whole window range, chunks of >= 32768 scalars: digits and pass-0 histograms in one kernel
-    const bool fused_hist = !g.pre && g.w0 == 0 && g.W == g.W_total && g.sp[0].nch >= 256 && c.tune_fused_hist &&
+    const bool fused_hist = !g.pre && g.w0 == 0 && g.W == g.W_total && g.sp[0].nch >= 256 &&
                             (size_t)g.W * g.sp[0].bins * 4 <= 64 * 1024;
     if (fused_hist) {
         KernelScope ks(c, "msm_digits");
@@ -2240,14 +2077,10 @@ static int msm_group_phase1(Ctx& c, MsmGroup& g, const Affine* points, const Sca
         }
         {
             KernelScope ks(c, "msm_sort_scatter");
-            // large two-pass sorts with packed entries: both passes write 4-byte words -- the line-sized-run scatter (tune: msm_scatter4)
-            const bool four = c.tune_scatter4 && g.pk_bits != 0 && g.entries >= (1ull << 26);
             const uint32_t cs0 = first ? (g.seg_n + sp.nch - 1) / sp.nch : 0u;
-            if (first && !last && a.pk_out_bits && c.tune_chunk_sort && sp.bins <= 512 && cs0 <= 32768 && !g.pre)
+            if (first && !last && a.pk_out_bits && sp.bins <= 512 && cs0 <= 32768 && !g.pre)
                 hipLaunchKernelGGL((msm_radix_chunk_kernel<512, 64, 18176>), grid, dim3(512), 0, st, a);
             else if (first && last) hipLaunchKernelGGL((msm_radix_scatter_kernel<1024, 8, true, true, false>), grid, dim3(1024), 0, st, a);
-            else if (first && four) hipLaunchKernelGGL((msm_radix_scatter4_kernel<512, 16, true, false, false>), grid, dim3(512), 0, st, a);
-            else if (last && four) hipLaunchKernelGGL((msm_radix_scatter4_kernel<512, 16, false, true, true>), grid, dim3(512), 0, st, a);
             else if (first && g.entries >= (1ull << 26))   // large sorts: 512 lanes, 4096-entry tiles (measured)
                 hipLaunchKernelGGL((msm_radix_scatter_kernel<512, 8, true, false, false>), grid, dim3(512), 0, st, a);
             else if (first) hipLaunchKernelGGL((msm_radix_scatter_kernel<1024, 8, true, false, false>), grid, dim3(1024), 0, st, a);
@@ -2263,18 +2096,17 @@ static int msm_group_phase1(Ctx& c, MsmGroup& g, const Affine* points, const Sca
     g.part_cur = m.lvl_part[0].as<XYZZ>();
     uint32_t* len_hist = sm + 3328;
     uint32_t* len_cur = sm + 3328 + kLenBins;
-    const bool bucket_fill = c.tune_bucket_fill != 0;
-    g.direct = bucket_fill && direct_ok && c.tune_direct;
+    g.direct = direct_ok;
     XYZZ* direct_buckets = g.direct ? m.buckets.as<XYZZ>() : nullptr;
     {
         KernelScope ks(c, "msm_scan_win");
-        if (bucket_fill) UZK_HIP(hipMemsetAsync(len_hist, 0, kLenBins * 4, st));
+        UZK_HIP(hipMemsetAsync(len_hist, 0, kLenBins * 4, st));
         hipLaunchKernelGGL(msm_scan_win_kernel, dim3(g.Wd), dim3(1024), scan_win_lds(g.NB), st, bcount, g.L, g.cnt_cur, g.off_cur, win_tot,
-                           d_max, g.NB, bucket_fill ? len_hist : (uint32_t*)nullptr);
+                           d_max, g.NB, len_hist);
         hipLaunchKernelGGL(msm_win_base_kernel, dim3(1), dim3(1024), 0, st, win_tot, g.base_cur, g.Wd);
     }
     TaskDesc* desc = m.task_desc.as<TaskDesc>();
-    if (bucket_fill) {
+    {
         // one lane per bucket; the lengths' histogram came out of msm_scan_win_kernel
         KernelScope ks(c, "msm_task_order");
         uint32_t* big_count = sm + 3908;
@@ -2284,34 +2116,18 @@ static int msm_group_phase1(Ctx& c, MsmGroup& g, const Affine* points, const Sca
         hipLaunchKernelGGL(msm_bucket_fill_kernel, dim3((unsigned)((g.TBK + 255) / 256)), dim3(256), 0, st, g.base_cur, g.cnt_cur, g.off_cur,
                            bstart, bcount, g.NB, g.TBK, len_cur, desc, big_count, m.big.as<BigBucket>(), g.direct ? 1u : 0u);
         hipLaunchKernelGGL(msm_task_fill_big_kernel, dim3(1024), dim3(64), 0, st, big_count, m.big.as<BigBucket>(), len_cur, desc);
-    } else {
-        KernelScope ks(c, "msm_task_order");
-        UZK_HIP(hipMemsetAsync(len_hist, 0, kLenBins * 4, st));
-        const dim3 tgrid((unsigned)((g.bound0 + 255) / 256));
-        hipLaunchKernelGGL(msm_task_hist_kernel, tgrid, dim3(256), 0, st, g.base_cur, g.Wd, g.off_cur, bstart, bcount, g.NB,
-                           g.L, len_hist);
-        hipLaunchKernelGGL(msm_task_scan_kernel, dim3(1), dim3(256), 0, st, len_hist, len_cur);
-        hipLaunchKernelGGL(msm_task_fill_kernel, tgrid, dim3(256), 0, st, g.base_cur, g.Wd, g.off_cur, bstart, bcount, g.NB,
-                           g.L, len_cur, desc);
     }
     {
         KernelScope ks(c, "msm_accumulate");
         const dim3 grid((unsigned)((g.bound0 + 255) / 256));
-        if (c.tune_acc_variant == 1)        // canonical arithmetic throughout (cross-check of the other loops)
-            hipLaunchKernelGGL((msm_accumulate_kernel<1, false>), grid, dim3(256), 0, st, points, sorted, desc, g.base_cur,
-                               g.part_cur, g.Wd, direct_buckets);
-        else if (c.tune_acc_variant == 0) { // default: 29-bit-limb accumulator + (normally empty) exception pass
-            uint32_t* exc_count = sm + 3900;
-            uint32_t* exc_list = m.exc.as<uint32_t>();
-            UZK_HIP(hipMemsetAsync(exc_count, 0, 4, st));
-            hipLaunchKernelGGL(msm_accumulate29_kernel, grid, dim3(256), 0, st, points, sorted, desc, g.base_cur, g.part_cur,
-                               g.Wd, exc_count, exc_list, direct_buckets);
-            hipLaunchKernelGGL(msm_accumulate_exc_kernel, grid, dim3(256), 0, st, points, sorted, desc, g.part_cur,
-                               exc_count, exc_list, direct_buckets);
-        }
-        else                                // 2: 8 x 32-bit relaxed Montgomery
-            hipLaunchKernelGGL((msm_accumulate_kernel<1, true>), grid, dim3(256), 0, st, points, sorted, desc, g.base_cur,
-                               g.part_cur, g.Wd, direct_buckets);
+        // the 29-bit-limb accumulator + the (normally empty) exception pass
+        uint32_t* exc_count = sm + 3900;
+        uint32_t* exc_list = m.exc.as<uint32_t>();
+        UZK_HIP(hipMemsetAsync(exc_count, 0, 4, st));
+        hipLaunchKernelGGL(msm_accumulate29_kernel, grid, dim3(256), 0, st, points, sorted, desc, g.base_cur, g.part_cur,
+                           g.Wd, exc_count, exc_list, direct_buckets);
+        hipLaunchKernelGGL(msm_accumulate_exc_kernel, grid, dim3(256), 0, st, points, sorted, desc, g.part_cur,
+                           exc_count, exc_list, direct_buckets);
     }
     UZK_HIP(hipGetLastError());
     // the largest bucket decides how many fold levels are needed (one tiny read-back)
@@ -2336,13 +2152,12 @@ static int msm_group_phase2(Ctx& c, MsmGroup& g, bool accumulate = false, bool r
     uint64_t tmax = ((uint64_t)m.h_max[0] + g.L - 1) / g.L;
     // lanes per fold group: latency mode for small problems, one lane per bucket for large ones
     // (measured at n = 2^14, batch 1..8: four lanes per bucket beat sixteen by 2..20 %)
-    const uint32_t gs = (c.tune_fold_group == 4 || c.tune_fold_group == 16) ? (uint32_t)c.tune_fold_group
-                      : (g.TBK >= (1u << 18) || c.tune_fold_group == 1) ? 1u : (tmax > 2 ? 4u : 1u);
+    const uint32_t gs = g.TBK >= (1u << 18) ? 1u : (tmax > 2 ? 4u : 1u);
     // skewed inputs (the extra levels exist only for them; a last level that still folds more than kBigThresh partial sums
     // somewhere): the one-lane-per-output kernels hand their long folds to msm_fold_big_kernel, one wave each
     constexpr uint32_t kBigThresh = 4;
     static_assert(sizeof(BigFold) == sizeof(BigBucket), "the two lists share one buffer");
-    const bool big_mode = gs == 1 && c.tune_fold_big && tmax > kBigThresh;
+    const bool big_mode = gs == 1 && tmax > kBigThresh;
     uint32_t* big_count = sm + 3904;
     BigFold* big_list = nullptr;
     if (big_mode) {
@@ -2591,8 +2406,7 @@ static int msm_run_small(Ctx& c, const Affine* points, const ScalarView& d_scala
     // SIMD's 64-bit multiplier busy), so the shortest dependent chain comes from filling k = 1..4 waves per
     // SIMD almost exactly: L = entries / (0.93 * 65536 * k) for the smallest k that keeps L <= 12.
     uint32_t L = 0;
-    if (c.tune_task_len > 0) L = (uint32_t)c.tune_task_len;
-    else {
+    {
         const double lanes = 0.93 * 64.0 * 4.0 * (double)c.num_cus;
         for (int k = 1; k <= 4; ++k) {
             L = (uint32_t)((double)entries / (lanes * k)) + 1;
@@ -2669,29 +2483,21 @@ static int msm_run_small(Ctx& c, const Affine* points, const ScalarView& d_scala
         {
             KernelScope ks(c, "msm_accumulate");
             const dim3 grid((unsigned)((task_cap + 255) / 256));
-            if (c.tune_acc_variant == 1)
-                hipLaunchKernelGGL((msm_accumulate_kernel<1, false>), grid, dim3(256), 0, st, points, sorted, desc, counters, P, 0u);
-            else if (c.tune_acc_variant == 0) {
-                hipLaunchKernelGGL(msm_accumulate29_kernel, grid, dim3(256), 0, st, points, sorted, desc, counters, P, 0u,
-                                   counters + 6, m.exc.as<uint32_t>());
-                hipLaunchKernelGGL(msm_accumulate_exc_kernel, dim3(256), dim3(256), 0, st, points, sorted, desc, P, counters + 6,
-                                   m.exc.as<uint32_t>());
-            } else
-                hipLaunchKernelGGL((msm_accumulate_kernel<1, true>), grid, dim3(256), 0, st, points, sorted, desc, counters, P, 0u);
+            hipLaunchKernelGGL(msm_accumulate29_kernel, grid, dim3(256), 0, st, points, sorted, desc, counters, P, 0u,
+                               counters + 6, m.exc.as<uint32_t>());
+            hipLaunchKernelGGL(msm_accumulate_exc_kernel, dim3(256), dim3(256), 0, st, points, sorted, desc, P, counters + 6,
+                               m.exc.as<uint32_t>());
         }
         // Fold mode per level: quads (four lanes per addition) while a level is latency-bound -- about one chunk per
         // non-empty bucket at level 1, far fewer later -- plain lanes once the chunks alone fill the chip.
-        // uzk_tune("msm_fold_mode", 1 + 16 * quad + lanes): experiment override for level 1.
         const uint64_t lanes_chip = (uint64_t)c.num_cus * 4 * 64;
         for (uint32_t k = 1; k <= std::min<uint32_t>(lv.nl, 1); ++k) {     // later levels: inside the reduction kernel
             KernelScope ks(c, "msm_small_fold");
             const uint64_t est = k == 1 ? (uint64_t)S * NBL : (uint64_t)S * 2;      // chunks that really exist (estimate)
-            // measured (tools/small_msm.py, msm_fold_mode sweep, n = 2^14): quads of 4 logical lanes match or beat plain lanes up
+            // measured (profiles/r02_small_msm_2e14.txt, n = 2^14): quads of 4 logical lanes match or beat plain lanes up
             // to batch 8 (uniform: 75-89 vs 77-96 us, skewed scalars: 27-38 vs 62-63 us); beyond, plain lanes fill the chip
-            bool quad = est * 16 <= 10 * lanes_chip;
-            int gs = quad ? 4 : (est * 4 <= 4 * lanes_chip ? 4 : 2);
-            if (k == 1 && c.tune_fold_mode > 0) { quad = ((c.tune_fold_mode - 1) & 16) != 0; gs = (c.tune_fold_mode - 1) & 15; }
-            if (c.tune_small == 2) quad = false;
+            const bool quad = est * 16 <= 10 * lanes_chip;
+            const int gs = quad ? 4 : (est * 4 <= 4 * lanes_chip ? 4 : 2);
             const uint64_t lanes = cap[k] * (uint64_t)gs * (quad ? 4 : 1);
             const dim3 grid((unsigned)((lanes + 255) / 256));
             const SmallChunk* cd = cdesc + lv.dbase[k];
@@ -2703,15 +2509,8 @@ static int msm_run_small(Ctx& c, const Affine* points, const ScalarView& d_scala
         {
             KernelScope ks(c, "msm_small_reduce");
             const uint32_t Q = std::min<uint32_t>(NBL, 64);
-            if (c.tune_small != 2 && c.tune_x29)
-                hipLaunchKernelGGL((msm_small_reduce_kernel<2, 256>), dim3(S), dim3(4 * Q), (size_t)Q * 144, st, P, bucket_ref, cdesc,
-                                   slot_chunks, lv, win_sums, NBL);
-            else if (c.tune_small != 2)
-                hipLaunchKernelGGL((msm_small_reduce_kernel<1, 256>), dim3(S), dim3(4 * Q), (size_t)Q * sizeof(XYZZ), st, P, bucket_ref, cdesc,
-                                   slot_chunks, lv, win_sums, NBL);
-            else
-                hipLaunchKernelGGL((msm_small_reduce_kernel<0, 512>), dim3(S), dim3(NBL), (size_t)NBL * sizeof(XYZZ), st, P, bucket_ref, cdesc,
-                                   slot_chunks, lv, win_sums, NBL);
+            hipLaunchKernelGGL((msm_small_reduce_kernel<2, 256>), dim3(S), dim3(4 * Q), (size_t)Q * 144, st, P, bucket_ref, cdesc,
+                               slot_chunks, lv, win_sums, NBL);
         }
         UZK_HIP(hipGetLastError());
     }
@@ -2850,25 +2649,10 @@ int msm_run(Ctx& c, const Affine* points, const ScalarView& d_scalars, size_t n,
     if (msm_small_applies(c, n, batch, pre_c)) return msm_run_small(c, points, d_scalars, n, batch, out_host, pre_c, pre_stride, pre_off);
     const int cb = pre ? pre_c : choose_window_bits(n, c.msm_window_bits);
     const uint32_t W = (uint32_t)msm_num_windows(cb);
-    // Optional: two overlapping groups (a quarter of the windows first).  Measured on MI355X it buys
-    // 0.2 ms of 26 at 2^24 and loses at 2^22 and below -- the sort's workgroups and the accumulation
-    // compete for the same CUs -- so it is off unless asked for (uzk_tune("msm_overlap", 1)).
-    const bool split = c.tune_overlap && !pre && batch == 1 && n >= (1u << 20) && W >= 4;
-    const int ngroups = split ? 2 : 1;
-    MsmGroup g[2];
-    const uint32_t wa = split ? std::max<uint32_t>(1, W / 4) : W;
-    if (split && !c.stream2) UZK_HIP(hipStreamCreateWithFlags(&c.stream2, hipStreamNonBlocking));
+    MsmGroup g[1];
+    const int ngroups = 1;
     g[0].m = &c.msm[0]; g[0].st = c.stream;
-    UZK_TRY(msm_group_plan(c, g[0], n, batch, cb, pre, W, 0, wa));
-    if (split) {
-        g[1].m = &c.msm[1]; g[1].st = c.stream2;
-        UZK_TRY(msm_group_plan(c, g[1], n, batch, cb, pre, W, wa, W - wa));
-        // the second stream starts after whatever the caller queued on the library stream (scalar upload)
-        hipEvent_t ev = c.get_event();
-        UZK_HIP(hipEventRecord(ev, c.stream));
-        UZK_HIP(hipStreamWaitEvent(c.stream2, ev, 0));
-        c.event_pool.push_back(ev);
-    }
+    UZK_TRY(msm_group_plan(c, g[0], n, batch, cb, pre, W, 0, W));
     int rc = UZK_OK;
     { HostScope hs(c, "host_msm_enqueue1");
       for (int k = 0; k < ngroups && rc == UZK_OK; ++k) rc = msm_group_phase1(c, g[k], points, d_scalars, pre_stride, pre_off); }
@@ -2882,11 +2666,10 @@ int msm_run(Ctx& c, const Affine* points, const ScalarView& d_scalars, size_t n,
     // 7. host: per scalar vector, Horner over its logical windows (c doublings per step); one window
     //    each when precomputed.  Window w of vector b lives in the group that owns w.
     const uint32_t wpp = pre ? 1u : W;
-    const uint32_t per = g[0].class_s ? 2u : 1u;            // both groups of a split share the window width, hence the mode
+    const uint32_t per = g[0].class_s ? 2u : 1u;
     auto window_sum = [&](uint32_t b, uint32_t w) -> const XYZZ& {
         if (pre) return g[0].m->h_sums[(size_t)b * per];
-        const int k = (split && w >= wa) ? 1 : 0;
-        return g[k].m->h_sums[((size_t)b * g[k].W + (w - g[k].w0)) * per];
+        return g[0].m->h_sums[((size_t)b * g[0].W + (w - g[0].w0)) * per];
     };
     msm_horner_host(c, batch, wpp, cb, window_sum, out_host, (int)g[0].class_s);
     return UZK_OK;

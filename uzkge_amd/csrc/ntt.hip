@@ -34,7 +34,6 @@ struct NttPlan {
     int log_n = 0;
     bool inverse = false;
     bool scaled = false;     // inverse only: fold 1/n in
-    bool l29 = false;        // twiddle tables in 2^261-form for the 29-bit-limb pass kernels
     int npass = 0;
     int bits[4] = {0, 0, 0, 0};
     Fp* d_tw256 = nullptr;        // omega_256^e (direction-specific), e < 256   (n >= 4096)
@@ -133,21 +132,6 @@ __device__ __forceinline__ void radix4(Fp& x0, Fp& x1, Fp& x2, Fp& x3, const Fp&
     swap_fp(x1, x2);
 }
 
-// The pass kernels keep their data in the relaxed domain [0, 2M) (fp256.hpp): every product skips
-// its final conditional subtraction; only the LAST pass canonicalises, on its way to memory.
-__device__ __forceinline__ void bf2_rx(Fp& a, Fp& b) {
-    Fp s = Fr::add_rx(a, b);
-    b = Fr::sub_rx(a, b);
-    a = s;
-}
-__device__ __forceinline__ void radix4_rx(Fp& x0, Fp& x1, Fp& x2, Fp& x3, const Fp& w4) {
-    bf2_rx(x0, x2);
-    bf2_rx(x1, x3); x3 = Fr::mul_rx(x3, w4);
-    bf2_rx(x0, x1);
-    bf2_rx(x2, x3);
-    swap_fp(x1, x2);
-}
-
 struct PassArgs {
     uint64_t batch_stride; // elements between consecutive (sub-)transforms in the scratch buffers, and the size of the fused tables (= N)
     // Elements between consecutive FULL vectors where the caller's memory is touched: the first pass's input and the last
@@ -157,7 +141,7 @@ struct PassArgs {
     uint64_t stride;       // N / R
     int log_S;             // log2 of the product of earlier radices
     const Fp* tw256;       // omega_256^e, direction-specific
-    const Fp* tw256c;      // the same as (w, wq) pairs for the constant-operand product (ntt_pass29_kernel<.., MULC = true>)
+    const Fp* tw256c;      // the same as (w, wq) pairs for the constant-operand product
     const Fp* twp;         // pass table [m'][sigma] (nullptr on the last pass)
     uint64_t twp_count;    // entries of twp (29-bit-limb kernels: tables are limb planes, see tw29_load)
     // ---- fused coset scaling and radix-3 stage (29-bit-limb kernels only; all zero = plain transform) ----
@@ -173,149 +157,16 @@ struct PassArgs {
     uint32_t use_ab;       // alpha / beta present (else plain sums for every r is NOT implied: r != 0 always needs them)
     const Fp* out_tw[3];
     uint32_t out_mul;      // 0 / 1: contiguous
-    uint32_t prio;         // experiment (uzk_tune("ntt_prio")): wave priorities that de-synchronise the workgroups sharing a CU
-    // Limb planes between the passes (uzk_tune("ntt_planes"), plain power-of-two transforms): the intermediate vectors live in the
+    // Limb planes between the passes (plain power-of-two transforms of up to 2^20 elements per launch): the intermediate vectors live in the
     // two scratch buffers as three planes over plane_count = batch * N entries (limbs 0-3, 4-7, 8: 36 bytes per element, the
     // layout of the twiddle tables) instead of 8 x 32-bit words, so a pass boundary costs neither the 9 -> 8 word packing of the
     // store nor the 8 -> 9 unpacking of the next load (~47 instructions per element and boundary) for 12 % more bytes there.
     uint32_t in_planes, out_planes;
     uint64_t plane_count;
-    uint32_t shrink_full;  // MULC kernels: F9::reduce instead of F9::reduce3 for the untwiddled butterfly output (uzk_tune("ntt_mulc", 2))
 };
 
-// ntt_prio: 1 = every other generation of workgroups runs at a higher priority; 2 = every other workgroup; 3 = a workgroup's
-// priority rises with the sub-pass it is in (oldest first)
-__device__ __forceinline__ void ntt_prio_start(uint32_t mode) {
-    if (mode == 1) { if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(2); }
-    else if (mode == 2) { if (blockIdx.x & 1) __builtin_amdgcn_s_setprio(2); }
-}
-__device__ __forceinline__ void ntt_prio_step(uint32_t mode, int k) {
-    if (mode != 3) return;
-    if (k == 1) __builtin_amdgcn_s_setprio(1);
-    else if (k == 2) __builtin_amdgcn_s_setprio(2);
-    else if (k >= 3) __builtin_amdgcn_s_setprio(3);
-}
-
-constexpr int kPlane = 2048 + 64;   // uint4 slots per LDS plane (transposed layout needs T*(R+1))
-
-__device__ __forceinline__ void lds_put(uint4* lds, int idx, const Fp& v) {
-    const uint4* p = reinterpret_cast<const uint4*>(&v);
-    lds[idx] = p[0];
-    lds[kPlane + idx] = p[1];
-}
-__device__ __forceinline__ Fp lds_get(const uint4* lds, int idx) {
-    Fp v;
-    uint4* p = reinterpret_cast<uint4*>(&v);
-    p[0] = lds[idx];
-    p[1] = lds[kPlane + idx];
-    return v;
-}
-
-// One Stockham pass of radix R = 2^B over a tile of T = 2048/R adjacent columns.  512 threads, four
-// elements per lane (32 VGPRs of data, so four waves per SIMD fit): the size-R transform of a column
-// is itself a Stockham chain of radix-4 register butterflies (plus one radix-2 step when B is odd)
-// whose exchanges go through LDS.  Sub-pass k (radix g, S = product of earlier sub-radices):
-// butterfly ib reads rows ib + t*R/g, writes rows m'*S*g + sigma*S + s (ib = m'*S + s) times
-// omega_R^(S*m'*sigma).
-template <int B, bool FIRST>
-__global__ __launch_bounds__(512) void ntt_pass_kernel(const Fp* __restrict__ in, Fp* __restrict__ out,
-                                                       PassArgs a) {
-    constexpr int R = 1 << B, T = 2048 / R, Q = R / 4, SH = 8 - B;
-    constexpr int N4 = B / 2;            // radix-4 sub-passes
-    constexpr bool TAIL2 = (B & 1) != 0; // one final radix-2 sub-pass
-    __shared__ uint4 lds[2 * kPlane];
-    const int tid = threadIdx.x;
-    const int col = tid % T, q = tid / T;
-    const uint64_t i0 = (uint64_t)blockIdx.x * T;
-    const uint64_t i = i0 + col;
-    // batch of independent transforms: the first pass reads / the last pass writes the caller's (possibly strided) vectors
-    in += (uint64_t)blockIdx.y * (FIRST ? a.in_vec_stride : a.batch_stride);
-    out += (uint64_t)blockIdx.y * (a.twp == nullptr ? a.out_vec_stride : a.batch_stride);
-
-    const Fp w4 = a.tw256[64];
-    Fp x[4];
-    int rows[4];
-
-    // ---- sub-pass 0: radix 4 on rows q + t*Q, straight from global memory (S = 1: m' = q, s = 0)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) x[t] = in[i + (uint64_t)(q + t * Q) * a.stride];
-    radix4_rx(x[0], x[1], x[2], x[3], w4);
-    if constexpr (N4 > 1 || TAIL2) {
-#pragma unroll
-        for (int s = 1; s < 4; ++s) x[s] = Fr::mul_rx(x[s], a.tw256[(q * s) << SH]);
-    }
-#pragma unroll
-    for (int s = 0; s < 4; ++s) rows[s] = q * 4 + s;
-
-    // ---- radix-4 sub-passes 1 .. N4-1
-#pragma unroll
-    for (int k = 1; k < N4; ++k) {
-        const int S = 1 << (2 * k);
-        __syncthreads();
-#pragma unroll
-        for (int s = 0; s < 4; ++s) lds_put(lds, rows[s] * T + col, x[s]);
-        __syncthreads();
-#pragma unroll
-        for (int t = 0; t < 4; ++t) x[t] = lds_get(lds, (q + t * Q) * T + col);
-        radix4_rx(x[0], x[1], x[2], x[3], w4);
-        const int mp = q >> (2 * k), sl = q & (S - 1);
-        const bool more = (R >> (2 * k + 2)) > 1;    // M' = R / (S*4) > 1: further sub-passes follow
-        if (more) {
-#pragma unroll
-            for (int s = 1; s < 4; ++s) x[s] = Fr::mul_rx(x[s], a.tw256[((S * mp * s)) << SH]);
-        }
-#pragma unroll
-        for (int s = 0; s < 4; ++s) rows[s] = (mp << (2 * k + 2)) + s * S + sl;
-    }
-    // ---- final radix-2 sub-pass (B odd): S = R/2, butterflies ib = q + u*Q, rows ib and ib + R/2
-    if constexpr (TAIL2) {
-        __syncthreads();
-#pragma unroll
-        for (int s = 0; s < 4; ++s) lds_put(lds, rows[s] * T + col, x[s]);
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int ib = q + u * Q;
-            x[2 * u] = lds_get(lds, ib * T + col);
-            x[2 * u + 1] = lds_get(lds, (ib + R / 2) * T + col);
-            bf2_rx(x[2 * u], x[2 * u + 1]);
-            rows[2 * u] = ib;
-            rows[2 * u + 1] = ib + R / 2;
-        }
-    }
-
-    // ---- write back
-    if constexpr (FIRST) {
-        // S = 1: out[i*R + row] -- transpose through LDS so the tile's T*R outputs leave as one
-        // contiguous run, multiplied by the streamed pass-0 twiddles.
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 4; ++j) lds_put(lds, col * (R + 1) + rows[j], x[j]);
-        __syncthreads();
-        const uint64_t base = i0 * R;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int e = tid + j * 512;
-            const int ce = e / R, re = e % R;
-            Fp v = lds_get(lds, ce * (R + 1) + re);
-            v = Fr::mul_rx(v, a.twp[base + e]);      // FIRST is never the last pass: stays relaxed
-            out[base + e] = v;
-        }
-    } else {
-        const uint64_t mp = i >> a.log_S, sp = i & ((1ull << a.log_S) - 1);
-        const uint64_t base = (mp << (a.log_S + B)) + sp;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            Fp v = x[j];
-            if (a.twp != nullptr) v = Fr::mul_rx(v, a.twp[(mp << B) + rows[j]]);
-            else v = Fr::canon(v);                 // last pass: back to [0, M)
-            out[base + ((uint64_t)rows[j] << a.log_S)] = v;
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
-// The same pass on the 29-bit-limb representation (fp29.hpp): data stays in 2^256-form, every
+// One Stockham pass of radix R = 2^B on the 29-bit-limb representation (fp29.hpp): data stays in 2^256-form, every
 // twiddle table is in 2^261-form, so a twiddle product is one carry-free 9x9 product.  Additions and
 // subtractions are 9 independent 32-bit adds; the bounds below (limb size / multiple of M) are what
 // keeps every product inside its contract (limb product < 2^60.6):
@@ -405,15 +256,7 @@ __device__ __forceinline__ void bf2_l(L29& a, L29& b) {
     b = F9::sub<4>(a, b);
     a = s;
 }
-__device__ __forceinline__ void radix4_l(L29& x0, L29& x1, L29& x2, L29& x3, const L29& w4) {
-    bf2_l(x0, x2);
-    bf2_l(x1, x3); x3 = F9::mul(x3, w4);
-    bf2_l(x0, x1);
-    bf2_l(x2, x3);
-    L29 t = x1; x1 = x2; x2 = t;
-}
-
-// The same butterfly around the constant-operand product (F9::mulc: plain product, value < 3M out, value < 2^261 in).  Inputs
+// The radix-4 butterfly around the constant-operand product (F9::mulc: plain product, value < 3M out, value < 2^261 in).  Inputs
 // < 3M (a mulc result, or a loaded element): first layer sums < 6M, differences < 7M; the second layer subtracts a sum of two
 // (value < 6M, limbs < 2^30), hence the 8M offset; outputs < 12M / 14M / 10M / 11M, limbs < 2^31.4.
 __device__ __forceinline__ void radix4_c(L29& x0, L29& x1, L29& x2, L29& x3, const L29& w4, const L29& w4q) {
@@ -447,11 +290,11 @@ __device__ __forceinline__ L29 lds_get29(const uint4* lds, int idx) {
 }
 
 // TILE elements per workgroup (TILE / 4 threads): 2048 (two workgroups per CU) or 1024 (four, shorter turnover bubbles)
-// MULC: the twiddles of the tile (omega_4 inside the butterflies, omega_256^e between the sub-passes -- 8.75 of the 10.75 products per
+// The twiddles of the tile (omega_4 inside the butterflies, omega_256^e between the sub-passes -- 8.75 of the 10.75 products per
 // element of a 2^22 transform) are multiplied in by the constant-operand product over the pair table a.tw256c; the pass
-// twiddles and the fused coset / radix-3 tables stay Montgomery products over their 2^261-form tables (streamed tables: a pair
+// twiddles and the fused coset / radix-3 tables are Montgomery products over their 2^261-form tables (streamed tables: a pair
 // would double their traffic).  Both forms compute x * w mod M up to the lazy multiple of M, so they mix freely.
-template <int B, bool FIRST, int TILE, bool MULC>
+template <int B, bool FIRST, int TILE>
 __global__ __launch_bounds__(TILE / 4) __attribute__((amdgpu_waves_per_eu(4))) void ntt_pass29_kernel(const Fp* __restrict__ in, Fp* __restrict__ out,
                                                              PassArgs a) {
     constexpr int R = 1 << B, T = TILE / R, Q = R / 4, SH = 8 - B, NT = TILE / 4, PL = TILE + (TILE >= 1024 ? 64 : 16);
@@ -466,11 +309,8 @@ __global__ __launch_bounds__(TILE / 4) __attribute__((amdgpu_waves_per_eu(4))) v
     // to 128 they spill, and the transform lost a third of what the constant-operand product had won (2^22: 0.947 -> 0.963 of the
     // Montgomery path's time).
     // Round 4, kept: with the constant-operand product the butterflies take inputs < 3M, so the untwiddled output only needs
-    // F9::reduce3 (one MAD chain from the raw top limb, 37 instructions against ~65; a.shrink_full: the A/B switch back).
-    auto shrink = [&](L29& v) {
-        if constexpr (MULC) { if (a.shrink_full) v = F9::reduce(v); else v = F9::reduce3(v); }
-        else v = F9::reduce(v);
-    };
+    // F9::reduce3 (one MAD chain from the raw top limb, 37 instructions against ~65 of the full reduce()).
+    auto shrink = [&](L29& v) { v = F9::reduce3(v); };
     const uint64_t i0 = (uint64_t)blockIdx.x * T;
     const uint64_t i = i0 + col;
     const Fp* in_base = in;
@@ -487,24 +327,17 @@ __global__ __launch_bounds__(TILE / 4) __attribute__((amdgpu_waves_per_eu(4))) v
         else out[idx] = F9::to_fp(v);
     };
 
-    ntt_prio_start(a.prio);
     L29 w4, w4q;
-    if constexpr (MULC) { tw29_load_pair(a.tw256c, 256, 64, w4, w4q); w4 = F9::uniform(w4); w4q = F9::uniform(w4q); }
-    else w4 = tw29_load(a.tw256, 256, 64);
+    tw29_load_pair(a.tw256c, 256, 64, w4, w4q);
+    w4 = F9::uniform(w4); w4q = F9::uniform(w4q);
     // one twiddled output of a butterfly: x * omega_256^e
-    auto twiddle = [&](L29& v, int e) {
-        if constexpr (MULC) { L29 w, wq; tw29_load_pair(a.tw256c, 256, e, w, wq); v = F9::mulc(v, w, wq); }
-        else v = F9::mul(v, tw29_load(a.tw256, 256, e));
-    };
+    auto twiddle = [&](L29& v, int e) { L29 w, wq; tw29_load_pair(a.tw256c, 256, e, w, wq); v = F9::mulc(v, w, wq); };
     // The twiddle between two passes stays a Montgomery product over the 2^261-form table.  Measured and not kept (round 4,
     // profiles/r04_ab_ntt_reduce3_pairs.txt): (w, wq) pair tables for pass tables of up to 2^18 entries, i.e. the constant-operand
     // product here too -- no difference at any size (2^14 24.5 / 24.4 us, 2^22 370.0 / 375.0), the 36 instructions saved per product
     // against twice the table bytes per load.
     auto pass_twiddle = [&](const L29& v, uint64_t idx) -> L29 { return F9::mul(v, tw29_load(a.twp, a.twp_count, idx)); };
-    auto butterfly = [&](L29& y0, L29& y1, L29& y2, L29& y3) {
-        if constexpr (MULC) radix4_c(y0, y1, y2, y3, w4, w4q);
-        else radix4_l(y0, y1, y2, y3, w4);
-    };
+    auto butterfly = [&](L29& y0, L29& y1, L29& y2, L29& y3) { radix4_c(y0, y1, y2, y3, w4, w4q); };
     L29 x[4];
     int rows[4];
 
@@ -554,7 +387,6 @@ __global__ __launch_bounds__(TILE / 4) __attribute__((amdgpu_waves_per_eu(4))) v
 #pragma unroll
     for (int k = 1; k < N4; ++k) {
         const int S = 1 << (2 * k);
-        ntt_prio_step(a.prio, k);
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < 4; ++s) lds_put29<PL>(lds, rows[s] * T + col, x[s]);
@@ -683,15 +515,13 @@ static int upload(Fp** dst, const std::vector<Fp>& src, hipStream_t st) {
 }
 
 static int get_plan(Ctx& c, uint64_t n, bool inverse, bool scaled, NttPlan** out) {
-    const bool l29 = c.tune_ntt_l29 != 0;
-    const uint64_t key = (n << 3) | (inverse ? 1u : 0u) | (scaled ? 2u : 0u) | (l29 ? 4u : 0u) | ((uint64_t)(c.tune_ntt_order & 0xFFFF) << 44);
+    const uint64_t key = (n << 3) | (inverse ? 1u : 0u) | (scaled ? 2u : 0u);
     auto it = c.ntt_plans.find(key);
     if (it != c.ntt_plans.end()) { *out = it->second; return UZK_OK; }
     NttPlan* p = new NttPlan();
     p->n = n;
     p->inverse = inverse;
     p->scaled = scaled;
-    p->l29 = l29;
     int k = 0;
     while ((1ull << k) < n) ++k;
     p->log_n = k;
@@ -727,16 +557,6 @@ static int get_plan(Ctx& c, uint64_t n, bool inverse, bool scaled, NttPlan** out
                             if (cst < best_cost) { best_cost = cst; for (int j = 0; j < 4; ++j) p->bits[j] = cur[j]; }
                         }
             if (best_cost == (1 << 30)) { delete p; set_error("ntt: no radix split for 2^%d", k); return UZK_ERR_FFT; }
-            // experiment (uzk_tune("ntt_order", 868) = passes of 2^8, 2^6, 2^8): the decimal digits give the passes' radix
-            // bits in order, taken only when they are 5..8 each and add up to k
-            if (c.tune_ntt_order > 0) {
-                int d[4] = {0, 0, 0, 0}, nd = 0, sum = 0, v = c.tune_ntt_order;
-                int rev[4], nr = 0;
-                while (v > 0 && nr < 4) { rev[nr++] = v % 10; v /= 10; }
-                bool ok = v == 0 && nr >= 1;
-                for (int j = nr - 1; j >= 0 && ok; --j) { d[nd++] = rev[j]; sum += rev[j]; ok = rev[j] >= 5 && rev[j] <= 8; }
-                if (ok && sum == k) { p->npass = nd; for (int j = 0; j < 4; ++j) p->bits[j] = d[j]; }
-            }
         }
         std::vector<Fp> pw;
         host_pow_tables(w, pw);
@@ -745,9 +565,8 @@ static int get_plan(Ctx& c, uint64_t n, bool inverse, bool scaled, NttPlan** out
         std::vector<Fp> t256(256);
         Fp w256 = f_pow_u64<Fr>(w, n / 256), cur = Fr::one();
         for (int e = 0; e < 256; ++e) { t256[e] = cur; cur = Fr::mul(cur, w256); }
-        if (l29)
-            for (auto& t : t256)
-                for (int d = 0; d < 5; ++d) t = Fr::add(t, t);     // 2^261-form
+        for (auto& t : t256)
+            for (int d = 0; d < 5; ++d) t = Fr::add(t, t);     // 2^261-form
         UZK_TRY(upload(&p->d_tw256, t256, c.stream));
         // 29-bit-limb kernels read their twiddles as limb planes (36 B per entry): repack a table in place of
         // the 8 x 32-bit one
@@ -761,12 +580,10 @@ static int get_plan(Ctx& c, uint64_t n, bool inverse, bool scaled, NttPlan** out
             *tab = planes;
             return UZK_OK;
         };
-        if (l29) {
-            // the 256 tile twiddles once more as (w, floor(w 2^261 / M)) pairs for the constant-operand product
-            UZK_HIP(hipMalloc(reinterpret_cast<void**>(&p->d_tw256c), 2 * 256 * 36 + 64));
-            hipLaunchKernelGGL(ntt_pair_tw_kernel, dim3(1), dim3(256), 0, c.stream, p->d_tw256, p->d_tw256c, (uint64_t)256);
-            UZK_TRY(to_planes(&p->d_tw256, 256));
-        }
+        // the 256 tile twiddles once more as (w, floor(w 2^261 / M)) pairs for the constant-operand product
+        UZK_HIP(hipMalloc(reinterpret_cast<void**>(&p->d_tw256c), 2 * 256 * 36 + 64));
+        hipLaunchKernelGGL(ntt_pair_tw_kernel, dim3(1), dim3(256), 0, c.stream, p->d_tw256, p->d_tw256c, (uint64_t)256);
+        UZK_TRY(to_planes(&p->d_tw256, 256));
         int log_S = 0;
         for (int j = 0; j + 1 < p->npass; ++j) {
             const uint64_t count = n >> log_S;   // (N / (S R)) * R
@@ -776,10 +593,10 @@ static int get_plan(Ctx& c, uint64_t n, bool inverse, bool scaled, NttPlan** out
                 KernelScope ks(c, "ntt_gen_pass_tw");
                 hipLaunchKernelGGL(ntt_gen_pass_tw_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0,
                                    c.stream, p->d_tw_pass[j], count, log_S, p->bits[j], p->d_pow, p->scale,
-                                   fold ? 1 : 0, l29 ? 5 : 0);
+                                   fold ? 1 : 0, 5);
             }
             p->tw_count[j] = count;
-            if (l29) UZK_TRY(to_planes(&p->d_tw_pass[j], count));
+            UZK_TRY(to_planes(&p->d_tw_pass[j], count));
             log_S += p->bits[j];
         }
         UZK_HIP(hipStreamSynchronize(c.stream));
@@ -805,41 +622,24 @@ void ntt_free_plans(Ctx& c) {
 }
 
 template <int B>
-static void launch_pass(Ctx& c, bool l29, bool first, const Fp* in, Fp* out, const PassArgs& a, uint64_t n, uint32_t batch) {
-    constexpr int R = 1 << B, T = 2048 / R;
-    const unsigned grid = (unsigned)((n / R) / T);
+static void launch_pass(Ctx& c, bool first, const Fp* in, Fp* out, const PassArgs& a, uint64_t n, uint32_t batch) {
+    constexpr int R = 1 << B;
     // Tiles of 1024 elements (256 threads, four workgroups per CU) up to 2^24 elements in all: twice as many workgroups
     // on a chip the launch does not fill, shorter load / compute / store phases -- 25..32 % faster from 2^12 to 2^18 and
     // for the prover's shapes (10 x 2^14: 36 -> 26 us, 98304 on a coset: 48 -> 34 us); re-measured at the end of round 3
-    // (tools/ab_ntt_knob.py ntt_tile 0 1024, two boxes): 2^22 413 -> 391 / 392 -> 380 us, 2^23 851 -> 813 / 828 -> 809,
+    // (profiles/r03f_ab_ntt_tile.txt, two boxes): 2^22 413 -> 391 / 392 -> 380 us, 2^23 851 -> 813 / 828 -> 809,
     // 2^24 1711 -> 1682 / 1682 -> 1673, 2^20 and below equal -- the finer turnover of four workgroups per CU wins there too.
-    const bool small_tile = c.tune_ntt_tile == 1024 || (c.tune_ntt_tile == 0 && n * (uint64_t)batch <= (1ull << 24));
-    if (l29 && c.tune_ntt_tile == 512) {          // experiment: two waves per workgroup (uzk_tune("ntt_tile", 512))
-        KernelScope ks(c, first ? "ntt_pass_first" : "ntt_pass");
-        const unsigned g5 = (unsigned)((n / R) / (512 / R));
-        if (first) hipLaunchKernelGGL((ntt_pass29_kernel<B, true, 512, false>), dim3(g5, batch), dim3(128), 0, c.stream, in, out, a);
-        else hipLaunchKernelGGL((ntt_pass29_kernel<B, false, 512, false>), dim3(g5, batch), dim3(128), 0, c.stream, in, out, a);
-    } else if (l29 && small_tile) {
-        KernelScope ks(c, first ? "ntt_pass_first" : "ntt_pass");
+    // uzk_tune("ntt_tile", 1024 | 2048) forces a tile (tests: both instantiations at every size).
+    const bool small_tile = c.tune_ntt_tile == 1024 || (c.tune_ntt_tile != 2048 && n * (uint64_t)batch <= (1ull << 24));
+    KernelScope ks(c, first ? "ntt_pass_first" : "ntt_pass");
+    if (small_tile) {
         const unsigned g2 = (unsigned)((n / R) / (1024 / R));
-        const bool mulc = a.tw256c != nullptr;
-        if (first && mulc) hipLaunchKernelGGL((ntt_pass29_kernel<B, true, 1024, true>), dim3(g2, batch), dim3(256), 0, c.stream, in, out, a);
-        else if (mulc) hipLaunchKernelGGL((ntt_pass29_kernel<B, false, 1024, true>), dim3(g2, batch), dim3(256), 0, c.stream, in, out, a);
-        else if (first) hipLaunchKernelGGL((ntt_pass29_kernel<B, true, 1024, false>), dim3(g2, batch), dim3(256), 0, c.stream, in, out, a);
-        else hipLaunchKernelGGL((ntt_pass29_kernel<B, false, 1024, false>), dim3(g2, batch), dim3(256), 0, c.stream, in, out, a);
-    } else if (l29) {
-        KernelScope ks(c, first ? "ntt_pass_first" : "ntt_pass");
-        const bool mulc = a.tw256c != nullptr;
-        if (first && mulc) hipLaunchKernelGGL((ntt_pass29_kernel<B, true, 2048, true>), dim3(grid, batch), dim3(512), 0, c.stream, in, out, a);
-        else if (mulc) hipLaunchKernelGGL((ntt_pass29_kernel<B, false, 2048, true>), dim3(grid, batch), dim3(512), 0, c.stream, in, out, a);
-        else if (first) hipLaunchKernelGGL((ntt_pass29_kernel<B, true, 2048, false>), dim3(grid, batch), dim3(512), 0, c.stream, in, out, a);
-        else hipLaunchKernelGGL((ntt_pass29_kernel<B, false, 2048, false>), dim3(grid, batch), dim3(512), 0, c.stream, in, out, a);
-    } else if (first) {
-        KernelScope ks(c, "ntt_pass_first");
-        hipLaunchKernelGGL((ntt_pass_kernel<B, true>), dim3(grid, batch), dim3(512), 0, c.stream, in, out, a);
+        if (first) hipLaunchKernelGGL((ntt_pass29_kernel<B, true, 1024>), dim3(g2, batch), dim3(256), 0, c.stream, in, out, a);
+        else hipLaunchKernelGGL((ntt_pass29_kernel<B, false, 1024>), dim3(g2, batch), dim3(256), 0, c.stream, in, out, a);
     } else {
-        KernelScope ks(c, "ntt_pass");
-        hipLaunchKernelGGL((ntt_pass_kernel<B, false>), dim3(grid, batch), dim3(512), 0, c.stream, in, out, a);
+        const unsigned grid = (unsigned)((n / R) / (2048 / R));
+        if (first) hipLaunchKernelGGL((ntt_pass29_kernel<B, true, 2048>), dim3(grid, batch), dim3(512), 0, c.stream, in, out, a);
+        else hipLaunchKernelGGL((ntt_pass29_kernel<B, false, 2048>), dim3(grid, batch), dim3(512), 0, c.stream, in, out, a);
     }
 }
 
@@ -865,9 +665,8 @@ static int ntt_pow2(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse,
     }
     // limb planes between the passes: plain transforms on the 29-bit-limb kernels with at least one intermediate vector
     // (measured, profiles/r04_ab_ntt_planes.txt: 3..5 % faster up to 2^20 elements per launch, 5 % SLOWER from 2^21 on -- three
-    // plane streams and 12 % more bytes where the passes start to feel HBM; uzk_tune("ntt_planes", 2) forces them at every size)
-    const bool planes = p->l29 && fx == nullptr && p->npass >= 2 &&
-                        (c.tune_ntt_planes == 2 || (c.tune_ntt_planes == 1 && n * (uint64_t)batch <= (1ull << 20)));
+    // plane streams and 12 % more bytes where the passes start to feel HBM)
+    const bool planes = fx == nullptr && p->npass >= 2 && n * (uint64_t)batch <= (1ull << 20);
     const size_t bytes = (size_t)n * batch * (planes ? 36 : sizeof(Fp)) + 64;
     UZK_TRY(c.ntt_scratch[0].reserve(bytes));
     Fp* s0 = c.ntt_scratch[0].as<Fp>();
@@ -883,7 +682,6 @@ static int ntt_pow2(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse,
     // never write the buffer they read.
     const Fp* src = d_in;
     int log_S = 0;
-    const bool mulc_kernels = c.tune_ntt_mulc != 0 && p->l29 && c.tune_ntt_tile != 512;   // the 512-element tiles are Montgomery only
     for (int j = 0; j < p->npass; ++j) {
         const int remaining = p->npass - 1 - j;
         Fp* dst = (remaining % 2 == 0) ? d_out : s0;
@@ -900,20 +698,18 @@ static int ntt_pow2(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse,
         a.stride = n >> p->bits[j];
         a.log_S = log_S;
         a.tw256 = p->d_tw256;
-        a.tw256c = mulc_kernels ? p->d_tw256c : nullptr;
-        a.shrink_full = c.tune_ntt_mulc == 2;
+        a.tw256c = p->d_tw256c;
         a.twp = p->d_tw_pass[j];
         a.twp_count = p->tw_count[j];
-        a.prio = (uint32_t)c.tune_ntt_prio;
         a.in_planes = planes && j > 0;
         a.out_planes = planes && remaining > 0;
         a.plane_count = (uint64_t)n * batch;
         const bool first = (j == 0);
         switch (p->bits[j]) {
-            case 5: launch_pass<5>(c, p->l29, first, src, dst, a, n, batch); break;
-            case 6: launch_pass<6>(c, p->l29, first, src, dst, a, n, batch); break;
-            case 7: launch_pass<7>(c, p->l29, first, src, dst, a, n, batch); break;
-            case 8: launch_pass<8>(c, p->l29, first, src, dst, a, n, batch); break;
+            case 5: launch_pass<5>(c, first, src, dst, a, n, batch); break;
+            case 6: launch_pass<6>(c, first, src, dst, a, n, batch); break;
+            case 7: launch_pass<7>(c, first, src, dst, a, n, batch); break;
+            case 8: launch_pass<8>(c, first, src, dst, a, n, batch); break;
             default: set_error("ntt: bad radix bits %d", p->bits[j]); return UZK_ERR_FFT;
         }
         UZK_HIP(hipGetLastError());
@@ -1070,7 +866,7 @@ int ntt_run(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse, const F
     // 29-bit-limb pass kernels: coset scaling and the radix-3 stage of 3 * 2^k domains run inside the first / last pass
     // (no separate scaling, decimation or combination kernels; 2 launches for the prover's 98304-point coset FFTs)
     const uint64_t sub_n = n % 3 == 0 ? n / 3 : n;
-    if (c.tune_ntt_l29 && c.tune_ntt_fused && sub_n >= 4096 && (n % 3 == 0 || coset_shift_host != nullptr)) {
+    if (sub_n >= 4096 && (n % 3 == 0 || coset_shift_host != nullptr)) {
         NttFused* f = nullptr;
         UZK_TRY(get_fused(c, n, inverse, coset_shift_host, &f));
         if (n % 3 == 0) return ntt_pow2(c, d_in, d_out, sub_n, inverse, false, 3 * batch, &f->fx, in_stride, out_stride);

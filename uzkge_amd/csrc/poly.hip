@@ -310,7 +310,7 @@ int poly_eval_batch(Ctx& c, const Fp* d_coefs, uint64_t n, uint32_t batch, const
     if (n == 0) { for (uint32_t b = 0; b < batch; ++b) out_host[b] = Fr::zero(); return UZK_OK; }
     if (batch > 65535) { set_error("poly_eval: batch %u exceeds 65535", batch); return UZK_ERR_PARAMETER; }
     const uint64_t nb_small = (n + kEvalSmallBlock - 1) / kEvalSmallBlock;
-    if (nb_small <= (uint64_t)kEvalSmallMaxBlocks && c.tune_poly_small) {
+    if (nb_small <= (uint64_t)kEvalSmallMaxBlocks) {
         for (uint32_t b0 = 0; b0 < batch; b0 += kEvalMaxPolys) {
             const uint32_t cnt = std::min<uint32_t>(kEvalMaxPolys, batch - b0);
             EvalArgs a{};
@@ -350,7 +350,7 @@ int poly_eval_ptrs(Ctx& c, const void* const* d_polys, const uint64_t* lens, con
         max_len = std::max(max_len, lens[k]);
     }
     const uint64_t max_blocks = (max_len + kEvalSmallBlock - 1) / kEvalSmallBlock;
-    if (count <= kEvalMaxPolys && n_points <= kEvalMaxPoints && max_blocks <= (uint64_t)kEvalSmallMaxBlocks && max_len > 0 && c.tune_poly_small) {
+    if (count <= kEvalMaxPolys && n_points <= kEvalMaxPoints && max_blocks <= (uint64_t)kEvalSmallMaxBlocks && max_len > 0) {
         EvalArgs a{};
         for (uint32_t j = 0; j < n_points; ++j) a.x[j] = points_host[j];
         for (uint32_t k = 0; k < count; ++k) { a.p[k] = static_cast<const Fp*>(d_polys[k]); a.len[k] = (uint32_t)lens[k]; a.pt[k] = (uint8_t)point_idx[k]; }
@@ -849,7 +849,7 @@ __global__ __launch_bounds__(256) void poly_lincomb_kernel(LincombArgs a, Fp* __
     if (live && sub == 0) out[j] = acc;
 }
 static void launch_lincomb(Ctx& c, const LincombArgs& a, Fp* d_out, uint64_t out_len, int accumulate) {
-    if (out_len <= (1ull << 17) && a.count >= 8 && c.tune_poly_small)
+    if (out_len <= (1ull << 17) && a.count >= 8)
         hipLaunchKernelGGL(poly_lincomb_kernel<4>, dim3((unsigned)((out_len * 4 + 255) / 256)), dim3(256), 0, c.stream, a, d_out, out_len, accumulate);
     else
         hipLaunchKernelGGL(poly_lincomb_kernel<1>, dim3((unsigned)((out_len + 255) / 256)), dim3(256), 0, c.stream, a, d_out, out_len, accumulate);
@@ -971,7 +971,7 @@ int open_quotient_ptrs(Ctx& c, const void* const* d_polys, const uint64_t* lens,
         std::vector<uint32_t> pt(count, 0u);
         UZK_TRY(poly_eval_ptrs(c, d_polys, lens, pt.data(), count, &z, 1, evals_host));     // p_k(z), returned to the caller
     }
-    const int per = (n <= (1ull << 16) && c.tune_poly_small) ? 4 : 16;       // coefficients per lane of the division kernels
+    const int per = (n <= (1ull << 16)) ? 4 : 16;       // coefficients per lane of the division kernels
     const int log_per = per == 4 ? 2 : 4;
     const uint64_t div_block = 256ull * per;
     const uint32_t nblocks = (uint32_t)((n + div_block - 1) / div_block);
