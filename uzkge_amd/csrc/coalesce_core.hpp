@@ -250,7 +250,7 @@ private:
     uint32_t mates_in_sight(const Cohort* g, Clock::time_point now) const {
         uint32_t c = 0;
         for (const Member* o : members_) {
-            if (o->group != g->key.group || o->team != g->team || o->cohort.get() == g) continue;
+            if (o->group != g->key.group || (o->team != g->team && o->team >= 0) || o->cohort.get() == g) continue;     // (team < 0: not dealt yet -- it may come here)
             if (!o->cohort) { if (o->in_call || now - o->last_seen < recent_) ++c; }
             else if (!o->cohort->gathering && o->cohort->next_round >= rounds_ && o->cohort->key == g->key) ++c;
         }

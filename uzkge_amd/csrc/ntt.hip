@@ -331,6 +331,10 @@ __global__ __launch_bounds__(TILE / 4) __attribute__((amdgpu_waves_per_eu(4))) v
     tw29_load_pair(a.tw256c, 256, 64, w4, w4q);
     w4 = F9::uniform(w4); w4q = F9::uniform(w4q);
     // one twiddled output of a butterfly: x * omega_256^e
+    // Measured and not kept (round 5, profiles/r05_ab_ntt_split_mulc.txt): the product in two steps -- the companion wq first, the
+    // quotient estimate from it, and only then the load of w, nine registers fewer alive across the product -- is 5..6 % SLOWER at
+    // every size (2^22: 370.7 -> 390.4 us): the kernels no longer spill (profiles/r05_ntt_kernel_registers.txt: 104..114 VGPRs since the
+    // experiment branches left them) and the second load's latency now sits in the middle of the product.
     auto twiddle = [&](L29& v, int e) { L29 w, wq; tw29_load_pair(a.tw256c, 256, e, w, wq); v = F9::mulc(v, w, wq); };
     // The twiddle between two passes stays a Montgomery product over the 2^261-form table.  Measured and not kept (round 4,
     // profiles/r04_ab_ntt_reduce3_pairs.txt): (w, wq) pair tables for pass tables of up to 2^18 entries, i.e. the constant-operand
