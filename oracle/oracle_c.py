@@ -11,10 +11,14 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "liboracle_bn254.so")
+# UZK_ORACLE_LIB: another build of the same source (oracle/Makefile `asan`: tests/test_oracle_sanitized.py runs the checks under
+# AddressSanitizer / UBSan in a child process)
+_LIB = os.environ.get("UZK_ORACLE_LIB") or os.path.join(_HERE, "liboracle_bn254.so")
 
 
 def build(force: bool = False) -> str:
+    if os.environ.get("UZK_ORACLE_LIB"):
+        return _LIB
     src = os.path.join(_HERE, "bn254_oracle.c")
     if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
         subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle_bn254.so"])

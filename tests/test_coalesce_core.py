@@ -39,3 +39,18 @@ def test_no_data_race_under_thread_sanitizer(tmp_path):
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
     assert "ThreadSanitizer" not in r.stderr, r.stderr[:4000]
     assert res["bad"] == 0 and res["widest_round"] > 1
+
+
+@pytest.mark.parametrize("threads", [8, 16, 32])
+def test_callers_with_unrelated_phases_converge_on_full_teams(tmp_path, threads):
+    """tests/cpp/coalesce_core_sim.cpp: a backend that only takes time the way the GPU does (a round costs base + per-lane time,
+    four at once), threads that start out of phase and prove back to back.  After a warm-up every round must serve (nearly) a
+    whole team -- threads / 4 callers -- and gathering must cost next to nothing: the one-proof API then runs as few, full
+    lockstep sequences."""
+    exe = os.path.join(str(tmp_path), "coalesce_core_sim")
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-o", exe, os.path.join(ROOT, "tests", "cpp", "coalesce_core_sim.cpp")], check=True)
+    r = subprocess.run([exe, str(threads), "8", "4", "2000", "1.0"], capture_output=True, text=True, timeout=120)
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res["ideal_lanes_per_round"] == threads / 4
+    assert res["lanes_per_round"] >= 0.9 * res["ideal_lanes_per_round"], res
+    assert res["gather_us_per_cohort"] < 1000 and res["moved_out"] == 0, res
