@@ -72,12 +72,15 @@ int hide_lanes(Ctx& c, Fp* d_coefs, uint64_t lane_stride, uint64_t slot_stride, 
 // ---- evaluations ----------------------------------------------------------------------------------------------------------
 // Polynomial k of lane b: len[k] coefficients at p[k] + b * lane_stride[k] (0 for a circuit polynomial every lane shares),
 // evaluated at points[2 b + pt[k]].  grid (blocks, count, lanes); the value goes straight to pinned host memory,
-// out_host[b * count + k].  Same scheme as poly_eval_small_kernel (poly.hip): 1024 coefficients per workgroup, a power table in
-// LDS, the last workgroup of a polynomial adds the block sums.  Lengths <= 2^18.
+// out_host[b * count + k].  Same scheme as poly_eval_small_kernel (poly.hip): 256 * PER coefficients per workgroup, a power table
+// in LDS, the last workgroup of a polynomial adds the block sums.  The table and the block's weight cost every lane ~25 products
+// whatever PER is: at PER = 4 (one proof: many small workgroups, short chains) that is six times the Horner steps themselves, at
+// PER = 16 (several lanes fill the chip anyway) one and a half times -- 158 -> 60 us for 8 lanes x 19 evaluations at n = 2^14.
 struct EvalPoly { const Fp* p; uint64_t lane_stride; uint32_t len, pt; };
+template <int PER>
 __global__ __launch_bounds__(256) void poly_eval_lanes_kernel(const EvalPoly* __restrict__ polys, const Fp* __restrict__ points, Fp* __restrict__ partial,
                                                               uint32_t* __restrict__ counters, Fp* __restrict__ out_host) {
-    constexpr int PER = 4, BLOCK = 256 * PER;
+    constexpr int BLOCK = 256 * PER;
     __shared__ Fp pw[256];
     __shared__ Fp sh[256];
     __shared__ uint32_t last;
@@ -98,7 +101,9 @@ __global__ __launch_bounds__(256) void poly_eval_lanes_kernel(const EvalPoly* __
         h = Fr::mul(h, x);
         if (j < n) h = Fr::add(h, c[j]);
     }
-    Fp s = Fr::sqr(Fr::sqr(x));
+    Fp s = x;                                  // x^PER
+#pragma unroll
+    for (int e = 1; e < PER; e <<= 1) s = Fr::sqr(s);
     if (tid == 0) pw[0] = Fr::one();
     __syncthreads();
 #pragma unroll
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(256) void poly_eval_lanes_kernel(const EvalPoly* __
         s = Fr::sqr(s);
         __syncthreads();
     }
-    Fp wblk = Fr::one(), sp = s;              // s = x^1024: the block's weight is s^blk
+    Fp wblk = Fr::one(), sp = s;              // s = x^BLOCK: the block's weight is s^blk
     for (uint32_t e = blk; e; e >>= 1) {
         if (e & 1) wblk = Fr::mul(wblk, sp);
         sp = Fr::sqr(sp);
@@ -136,12 +141,14 @@ __global__ __launch_bounds__(256) void poly_eval_lanes_kernel(const EvalPoly* __
 // d_polys: `count` EvalPoly in device memory; d_counters: lanes * count zeroed words; out_host: pinned.  Asynchronous.
 int poly_eval_lanes(Ctx& c, const void* d_polys, uint32_t count, uint64_t max_len, const Fp* d_points, uint32_t lanes, uint32_t* d_counters, Fp* out_host_pinned) {
     if (count == 0 || lanes == 0) return UZK_OK;
-    const uint64_t blocks = (max_len + 1023) / 1024;
-    if (max_len == 0 || blocks > 256) { set_error("poly_eval_lanes: lengths must be 1 .. 2^18"); return UZK_ERR_PARAMETER; }
+    if (max_len == 0 || max_len > (1ull << 18)) { set_error("poly_eval_lanes: lengths must be 1 .. 2^18"); return UZK_ERR_PARAMETER; }
+    const bool wide = lanes >= 4 && max_len >= 4096;
+    const uint64_t per_block = wide ? 4096 : 1024, blocks = (max_len + per_block - 1) / per_block;
     UZK_TRY(c.poly_tmp.reserve((size_t)lanes * count * blocks * sizeof(Fp)));
     KernelScope ks(c, "poly_eval");
-    hipLaunchKernelGGL(poly_eval_lanes_kernel, dim3((unsigned)blocks, count, lanes), dim3(256), 0, c.stream, static_cast<const EvalPoly*>(d_polys), d_points,
-                       c.poly_tmp.as<Fp>(), d_counters, out_host_pinned);
+    const dim3 grid((unsigned)blocks, count, lanes);
+    if (wide) hipLaunchKernelGGL(poly_eval_lanes_kernel<16>, grid, dim3(256), 0, c.stream, static_cast<const EvalPoly*>(d_polys), d_points, c.poly_tmp.as<Fp>(), d_counters, out_host_pinned);
+    else hipLaunchKernelGGL(poly_eval_lanes_kernel<4>, grid, dim3(256), 0, c.stream, static_cast<const EvalPoly*>(d_polys), d_points, c.poly_tmp.as<Fp>(), d_counters, out_host_pinned);
     UZK_HIP(hipGetLastError());
     return UZK_OK;
 }
