@@ -1840,8 +1840,10 @@ struct MsmGroup {
     XYZZ* part_cur = nullptr;
 };
 
+// idx_span (precomputed mode): the sorted values are table indices pre_stride * j + pre_off + i < idx_span, not positions in the
+// scalar vector -- the packed sort entries must have room for those (0: no bound known, unpacked entries)
 static int msm_group_plan(Ctx& c, MsmGroup& g, size_t n, uint32_t batch, int cb, bool pre, uint32_t W_total, uint32_t w0,
-                          uint32_t W) {
+                          uint32_t W, uint64_t idx_span = 0) {
     g.pre = pre; g.cb = cb; g.W_total = W_total; g.w0 = w0; g.W = W; g.n32 = (uint32_t)n; g.batch = batch;
     g.per_poly = (uint64_t)W * n;
     g.entries = g.per_poly * batch;
@@ -1901,9 +1903,9 @@ static int msm_group_plan(Ctx& c, MsmGroup& g, size_t n, uint32_t batch, int cb,
     // Two-pass sorts: take 9 bits first when that lets {remaining key bits, sign, index} fit 32 bits --
     // the entries between the passes are then 4 bytes instead of 8 (a third of the sort's traffic less).
     g.pk_bits = 0;
-    if (g.P == 2 && !pre) {
+    if (g.P == 2 && (!pre || idx_span)) {
         uint32_t ib = 1;
-        while ((1ull << ib) < g.seg_n) ++ib;
+        while ((1ull << ib) < (pre ? idx_span : (uint64_t)g.seg_n)) ++ib;
         const uint32_t first_bits = std::min<uint32_t>(9, g.kb - 1);
         if (ib + 1 + (g.kb - first_bits) <= 32) g.pk_bits = ib;
     }
@@ -2652,7 +2654,7 @@ int msm_run(Ctx& c, const Affine* points, const ScalarView& d_scalars, size_t n,
     MsmGroup g[1];
     const int ngroups = 1;
     g[0].m = &c.msm[0]; g[0].st = c.stream;
-    UZK_TRY(msm_group_plan(c, g[0], n, batch, cb, pre, W, 0, W));
+    UZK_TRY(msm_group_plan(c, g[0], n, batch, cb, pre, W, 0, W, pre ? (uint64_t)pre_stride * (W - 1) + pre_off + n : 0));
     int rc = UZK_OK;
     { HostScope hs(c, "host_msm_enqueue1");
       for (int k = 0; k < ngroups && rc == UZK_OK; ++k) rc = msm_group_phase1(c, g[k], points, d_scalars, pre_stride, pre_off); }
