@@ -30,7 +30,8 @@ int explicit_round5(uint64_t prover, const uint64_t* r_scalars, size_t r_count, 
 namespace {
 
 constexpr uint64_t kSharedBit = 1ull << 62;              // handles of shared provers (the explicit ones count up from 1)
-constexpr uint32_t kGatherWaitUs = 2000, kStragglerWaitUs = 20000, kGroups = 4;      // the defaults of uzk_coalesce_config (profiles/r05_gather_sweep.txt)
+constexpr uint32_t kGatherWaitUs = 2000, kStragglerWaitUs = 20000, kGroups = 4;      // the defaults of uzk_coalesce_config (profiles/r05_gather_sweep*.txt)
+constexpr uint32_t kMaxStreams = 4;                      // busy streams of the library's own per device, whatever `groups` is (Turns below)
 
 // A lockstep workspace: the buffers of up to `cap` proofs.  It has no stream of its own: a round runs on whichever of the few
 // internal contexts is free (Turns below) -- rounds end synchronised, so nothing of a proof is in flight between two of them.
@@ -65,9 +66,11 @@ struct Backend {
 
     // The internal contexts: `max_running` per device, each one stream with its workspaces, made once and one after the other
     // (streams born in the same instant on several threads have been seen to share a hardware queue, where their launch sequences
-    // then take turns).  A round takes a free one for its duration.  So at most `max_running` streams of the library's own are
-    // ever busy: more than a handful of busy streams cost the chip dearly (five lockstep provers of four proofs make 900 proofs/s
-    // where four make 1300, profiles/r04_rounds_matrix_wide.txt), and cohorts beyond that number take turns round by round.
+    // then take turns).  A round takes a free one for its duration.  So at most `max_running` <= 4 streams of the library's own
+    // are ever busy: the chip's compute front end has four pipes, and a fifth busy queue shares one with the first -- the two then
+    // run at 0.6 of the others' rate and the whole at 0.75 of four streams' throughput (profiles/r05_gaps_lockstep_5x8.txt: 1100
+    // proofs/s from five lockstep provers of eight proofs where four make 1450).  Cohorts beyond that number take turns round by
+    // round.
     struct Turns {
         std::vector<std::unique_ptr<Ctx>> ctx;
         std::vector<uint8_t> busy;
@@ -304,7 +307,7 @@ int uzk_coalesce_config(uint32_t max_lanes, uint32_t gather_wait_us, uint32_t st
         s.core.configure(max_lanes, gather_wait_us ? gather_wait_us : kGatherWaitUs, straggler_wait_us ? straggler_wait_us : kStragglerWaitUs, groups ? groups : kGroups);
         std::lock_guard<std::mutex> lk(s.backend.mu);
         s.backend.pool_cap = max_lanes;
-        s.backend.max_running = groups ? groups : kGroups;
+        s.backend.max_running = std::min<uint32_t>(groups ? groups : kGroups, kMaxStreams);
         s.backend.pool.clear();                          // workspaces of another width: made again on demand
     }
     return UZK_OK;
