@@ -559,7 +559,8 @@ int uzk_msm_plan_info(size_t n, int* window_bits, int* windows);
  *   "msm_small"           0: n <= 2^15 takes the general pipeline too (default 1: one workgroup per (vector, window))
  *   "msm_seg_sort"        0: the generic last sort pass instead of one workgroup per segment; 10 + k: segment kernel k at any size
  *   "ntt_tile"            1024 / 2048: elements per workgroup of an NTT pass at every size (default 0: by size)
- * The last three exist so that the tests reach every pipeline and instantiation at sizes the CPU oracle can check
+ *   "ntt_two_pass"        0: transforms of 2^17 .. 2^21 elements in three passes of 5 .. 8 bits (default 1: two passes of 9 .. 11)
+ * The last four exist so that the tests reach every pipeline and instantiation at sizes the CPU oracle can check
  * (tests/test_gpu_variants.py).  Unknown keys are UZK_ERR_PARAMETER. */
 int uzk_tune(const char* key, int value);
 

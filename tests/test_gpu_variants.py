@@ -51,10 +51,12 @@ def test_msm_variants_agree(gpu, log_n):
         srs.release()
 
 
-@pytest.mark.parametrize("n", [4096, 1 << 15, 3 << 13, 1 << 19])
-def test_ntt_tiles_agree_and_match_the_oracle(gpu, n):
+@pytest.mark.parametrize("n", [4096, 1 << 15, 3 << 13, 1 << 17, 1 << 18, 1 << 19, 1 << 20, 1 << 21])
+def test_ntt_tiles_and_splits_agree_and_match_the_oracle(gpu, n):
     """Both workgroup tile sizes of the pass kernels (1024 / 2048 elements; 0 = chosen by size), out of place and in place (the
-    limb-plane buffers between the passes), forward and inverse: the same bytes, and they are the oracle's."""
+    limb-plane buffers between the passes), forward and inverse: the same bytes, and they are the oracle's.  2^17 .. 2^21 run as
+    two passes of 9 .. 11 bits (9 + 8, 9 + 9, 10 + 9, 10 + 10, 11 + 10: one- and two-column tiles with the XCD-neighbour workgroup
+    mapping) and, with uzk_tune("ntt_two_pass", 0), as the three passes of 5 .. 8 bits they had: both forms at every such size."""
     x = torch.empty((n, 4), dtype=torch.int64, device="cuda")
     a = torch.empty((n, 4), dtype=torch.int64, device="cuda")
     torch.cuda.synchronize()
@@ -63,16 +65,19 @@ def test_ntt_tiles_agree_and_match_the_oracle(gpu, n):
     try:
         for inv in (False, True):
             want = torch.from_numpy(oc.ntt(hx, inverse=inv, threads=4).view(np.int64)).reshape(n, 4).cuda()
-            for tile in (0, 1024, 2048):
-                gpu.tune("ntt_tile", tile)
-                gpu.ntt_device(x.data_ptr(), a.data_ptr(), n, inverse=inv, sync=True)
-                assert torch.equal(a, want), (inv, tile)
-                y = x.clone()
-                torch.cuda.synchronize()
-                gpu.ntt_device(y.data_ptr(), y.data_ptr(), n, inverse=inv, sync=True)
-                assert torch.equal(y, want), (inv, tile, "in place")
+            for two in ((1, 0) if (1 << 17) <= n <= (1 << 21) else (1,)):
+                gpu.tune("ntt_two_pass", two)
+                for tile in (0, 1024, 2048):
+                    gpu.tune("ntt_tile", tile)
+                    gpu.ntt_device(x.data_ptr(), a.data_ptr(), n, inverse=inv, sync=True)
+                    assert torch.equal(a, want), (inv, tile, two)
+                    y = x.clone()
+                    torch.cuda.synchronize()
+                    gpu.ntt_device(y.data_ptr(), y.data_ptr(), n, inverse=inv, sync=True)
+                    assert torch.equal(y, want), (inv, tile, two, "in place")
     finally:
         gpu.tune("ntt_tile", 0)
+        gpu.tune("ntt_two_pass", 1)
 
 
 @pytest.mark.parametrize("n", [1, 2, 33, 1000, 4096, 16384, 32768])
@@ -121,7 +126,7 @@ def test_small_pipeline_agrees_with_general(gpu, n):
         srs.release()
 
 
-@pytest.mark.parametrize("n", [4096, 1 << 14, 3 << 12, 3 << 13, 98304, 1 << 17, 3 << 16])
+@pytest.mark.parametrize("n", [4096, 1 << 14, 3 << 12, 3 << 13, 98304, 1 << 17, 3 << 16, 3 << 17])
 def test_ntt_fused_stages_match_the_oracle(gpu, n):
     """Coset scaling and the radix-3 stage of 3 * 2^k domains run inside the first / last Stockham pass (sub-transforms of at
     least 4096 elements; smaller ones keep separate scaling / decimation kernels).  Forward and inverse, with and without a coset
@@ -147,11 +152,13 @@ def test_ntt_fused_stages_match_the_oracle(gpu, n):
                     want = np.stack([oc.mul_var(oc.ntt(np.ascontiguousarray(hx[k]), inverse=True, threads=4), cs) for k in range(B)])
                 want_t = torch.from_numpy(want.view(np.int64)).reshape(B * n, 4).cuda()
                 for batch in (1, B):
-                    for tile in (1024, 2048):
+                    for tile, two in ((1024, 1), (2048, 1), (0, 0)):      # (0, 0): sub-transforms of 2^17 in three passes instead of two
                         gpu.tune("ntt_tile", tile)
+                        gpu.tune("ntt_two_pass", two)
                         gpu.ntt_batch_device(x.data_ptr(), a.data_ptr(), n, batch, inverse=inv, coset_shift=cs, sync=True)
-                        assert torch.equal(a[:batch * n], want_t[:batch * n]), (inv, cs is not None, batch, tile)
+                        assert torch.equal(a[:batch * n], want_t[:batch * n]), (inv, cs is not None, batch, tile, two)
                     gpu.tune("ntt_tile", 0)
+                    gpu.tune("ntt_two_pass", 1)
                     b_[:batch * n] = x[:batch * n]                           # in place
                     torch.cuda.synchronize()                                 # torch's copy runs on torch's stream, the library on its own
                     gpu.ntt_batch_device(b_.data_ptr(), b_.data_ptr(), n, batch, inverse=inv, coset_shift=cs, sync=True)

@@ -103,6 +103,7 @@ struct Ctx {
     int msm_window_bits = 0;  // 0 = auto
     // uzk_tune: switches with a production use, and three that let the tests reach every pipeline at small sizes
     int tune_no_precompute = 0;    // 1: ignore window tables (uzk_srs_precompute) -- the general pipeline over the plain bases
+    int tune_ntt_two_pass = 1;     // 2^17 .. 2^21 as two passes of 9 .. 11 bits (0: the three passes of 5 .. 8 bits -- tests reach both)
     int tune_ntt_tile = 0;         // elements per workgroup of an NTT pass: 2048 (512 threads), 1024 (256 threads), 0 = by size
     int tune_small = 1;            // 1: n <= 2^15 takes the one-workgroup-per-slot pipeline (msm_small_*); 0: the general pipeline at every size
     int tune_chunk_log = 26;       // point-chunk size of one sort pass (tests lower it to reach the chunk loop at small n)

@@ -37,6 +37,7 @@ struct NttPlan {
     int npass = 0;
     int bits[4] = {0, 0, 0, 0};
     Fp* d_tw256 = nullptr;        // omega_256^e (direction-specific), e < 256   (n >= 4096)
+    Fp* d_tw2048c = nullptr;      // two-pass plans (2^17 .. 2^21): omega_2048^e as pairs for their passes of 9 .. 11 bits
     Fp* d_tw256c = nullptr;       // the same 256 twiddles as pairs (w, floor(w 2^261 / M)) for the constant-operand product: two
                                   // sets of limb planes, the second 256 * 36 bytes behind the first (uzk_tune("ntt_mulc"))
     Fp* d_tw_pass[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -141,7 +142,7 @@ struct PassArgs {
     uint64_t stride;       // N / R
     int log_S;             // log2 of the product of earlier radices
     const Fp* tw256;       // omega_256^e, direction-specific
-    const Fp* tw256c;      // the same as (w, wq) pairs for the constant-operand product
+    const Fp* tw256c;      // the same as (w, wq) pairs for the constant-operand product; a pass of 9 .. 11 bits: omega_2048^e, e < 2048
     const Fp* twp;         // pass table [m'][sigma] (nullptr on the last pass)
     uint64_t twp_count;    // entries of twp (29-bit-limb kernels: tables are limb planes, see tw29_load)
     // ---- fused coset scaling and radix-3 stage (29-bit-limb kernels only; all zero = plain transform) ----
@@ -297,7 +298,7 @@ __device__ __forceinline__ L29 lds_get29(const uint4* lds, int idx) {
 template <int B, bool FIRST, int TILE>
 __global__ __launch_bounds__(TILE / 4) __attribute__((amdgpu_waves_per_eu(4))) void ntt_pass29_kernel(const Fp* __restrict__ in, Fp* __restrict__ out,
                                                              PassArgs a) {
-    constexpr int R = 1 << B, T = TILE / R, Q = R / 4, SH = 8 - B, NT = TILE / 4, PL = TILE + (TILE >= 1024 ? 64 : 16);
+    constexpr int R = 1 << B, T = TILE / R, Q = R / 4, TWN = B > 8 ? 2048 : 256, SH = (B > 8 ? 11 : 8) - B, NT = TILE / 4, PL = TILE + (TILE >= 1024 ? 64 : 16);
     constexpr int N4 = B / 2;
     constexpr bool TAIL2 = (B & 1) != 0;
     __shared__ uint4 lds[(9 * PL + 3) / 4];
@@ -311,7 +312,18 @@ __global__ __launch_bounds__(TILE / 4) __attribute__((amdgpu_waves_per_eu(4))) v
     // Round 4, kept: with the constant-operand product the butterflies take inputs < 3M, so the untwiddled output only needs
     // F9::reduce3 (one MAD chain from the raw top limb, 37 instructions against ~65 of the full reduce()).
     auto shrink = [&](L29& v) { v = F9::reduce3(v); };
-    const uint64_t i0 = (uint64_t)blockIdx.x * T;
+    // Passes of 10 / 11 bits: a tile of one or two columns reads 32 / 64 bytes of a 128-byte line; the workgroups that read the
+    // rest of the line are made neighbours ON ONE XCD (workgroup ids go round the eight XCDs), so that the line is fetched into
+    // one L2 once instead of into four (2^20: 111.5 -> 97.8 us, profiles/r05_ab_ntt_two_pass.txt columns 1 and 2)
+    uint32_t bx = blockIdx.x;
+    if constexpr (T < 4) {
+        if ((gridDim.x % (8 * (4 / T))) == 0) {
+            constexpr uint32_t G = 4 / T;
+            const uint32_t xcd = bx & 7, k = bx >> 3;
+            bx = ((k / G) * 8 + xcd) * G + (k % G);
+        }
+    }
+    const uint64_t i0 = (uint64_t)bx * T;
     const uint64_t i = i0 + col;
     const Fp* in_base = in;
     Fp* out_base = out;
@@ -328,14 +340,14 @@ __global__ __launch_bounds__(TILE / 4) __attribute__((amdgpu_waves_per_eu(4))) v
     };
 
     L29 w4, w4q;
-    tw29_load_pair(a.tw256c, 256, 64, w4, w4q);
+    tw29_load_pair(a.tw256c, TWN, TWN / 4, w4, w4q);
     w4 = F9::uniform(w4); w4q = F9::uniform(w4q);
     // one twiddled output of a butterfly: x * omega_256^e
     // Measured and not kept (round 5, profiles/r05_ab_ntt_split_mulc.txt): the product in two steps -- the companion wq first, the
     // quotient estimate from it, and only then the load of w, nine registers fewer alive across the product -- is 5..6 % SLOWER at
     // every size (2^22: 370.7 -> 390.4 us): the kernels no longer spill (profiles/r05_ntt_kernel_registers.txt: 104..114 VGPRs since the
     // experiment branches left them) and the second load's latency now sits in the middle of the product.
-    auto twiddle = [&](L29& v, int e) { L29 w, wq; tw29_load_pair(a.tw256c, 256, e, w, wq); v = F9::mulc(v, w, wq); };
+    auto twiddle = [&](L29& v, int e) { L29 w, wq; tw29_load_pair(a.tw256c, TWN, e, w, wq); v = F9::mulc(v, w, wq); };
     // The twiddle between two passes stays a Montgomery product over the 2^261-form table.  Measured and not kept (round 4,
     // profiles/r04_ab_ntt_reduce3_pairs.txt): (w, wq) pair tables for pass tables of up to 2^18 entries, i.e. the constant-operand
     // product here too -- no difference at any size (2^14 24.5 / 24.4 us, 2^22 370.0 / 375.0), the 36 instructions saved per product
@@ -519,7 +531,11 @@ static int upload(Fp** dst, const std::vector<Fp>& src, hipStream_t st) {
 }
 
 static int get_plan(Ctx& c, uint64_t n, bool inverse, bool scaled, NttPlan** out) {
-    const uint64_t key = (n << 3) | (inverse ? 1u : 0u) | (scaled ? 2u : 0u);
+    int k_of_n = 0;
+    while ((1ull << k_of_n) < n) ++k_of_n;
+    // 2^17 .. 2^21 in TWO passes of 9 .. 11 bits (round 5; uzk_tune("ntt_two_pass", 0): the three passes of 5 .. 8 bits they had)
+    const bool two_pass = c.tune_ntt_two_pass && k_of_n >= 17 && k_of_n <= 21;
+    const uint64_t key = (n << 3) | (inverse ? 1u : 0u) | (scaled ? 2u : 0u) | (two_pass ? 4u : 0u);
     auto it = c.ntt_plans.find(key);
     if (it != c.ntt_plans.end()) { *out = it->second; return UZK_OK; }
     NttPlan* p = new NttPlan();
@@ -542,7 +558,14 @@ static int get_plan(Ctx& c, uint64_t n, bool inverse, bool scaled, NttPlan** out
         // a pass of radix 2^b costs floor(b/2) radix-4 sub-passes of one product per element each,
         // except that the last sub-pass of an even b carries no twiddles (a quarter of a product).
         p->npass = (k + 7) / 8;
-        {
+        // Two passes instead of three for 2^17 .. 2^21 (round 5): a pass costs its products plus ~1.7
+        // product-equivalents per element of load / re-limbing / exchanges / store, so one pass fewer pays as long as the tile
+        // keeps >= 2 columns (64-byte accesses) in at least one of the two passes: interleaved A/B, identical bytes
+        // (profiles/r05_ab_ntt_two_pass.txt, _shapes.txt): 2^17 36.6 -> 32.5 us, 2^19 62.5 -> 57.8, 2^20 104.3 -> 97.8, 2^21 192.4 ->
+        // 181.9; eight transforms of 2^20: 701 -> 637.  2^22 = 11 + 11 has ONE column per tile in both passes and LOSES: 379.5 ->
+        // 406.5 us (462 without the XCD mapping of the pass kernel): it keeps 8 + 8 + 6.
+        if (two_pass) { p->npass = 2; p->bits[0] = (k + 1) / 2; p->bits[1] = k / 2; }
+        else {
             int best_cost = 1 << 30, cur[4] = {0, 0, 0, 0};
             const int P = p->npass;
             // enumerate non-increasing b_0 >= b_1 >= ... (order does not change the cost), smallest
@@ -566,9 +589,23 @@ static int get_plan(Ctx& c, uint64_t n, bool inverse, bool scaled, NttPlan** out
         host_pow_tables(w, pw);
         UZK_TRY(upload(&p->d_pow, pw, c.stream));
         // omega_256^e = w^(e * n/256)
-        std::vector<Fp> t256(256);
-        Fp w256 = f_pow_u64<Fr>(w, n / 256), cur = Fr::one();
-        for (int e = 0; e < 256; ++e) { t256[e] = cur; cur = Fr::mul(cur, w256); }
+        if (two_pass) {                         // passes of more than 8 bits: omega_2048^e as (w, wq) pairs
+            std::vector<Fp> t2k(2048);
+            Fp w2k = f_pow_u64<Fr>(w, n / 2048), cur2 = Fr::one();
+            for (uint32_t e = 0; e < 2048; ++e) { t2k[e] = cur2; cur2 = Fr::mul(cur2, w2k); }
+            for (auto& t : t2k)
+                for (int d = 0; d < 5; ++d) t = Fr::add(t, t);
+            Fp* d_t2k = nullptr;
+            UZK_TRY(upload(&d_t2k, t2k, c.stream));
+            UZK_HIP(hipMalloc(reinterpret_cast<void**>(&p->d_tw2048c), 2 * (size_t)2048 * 36 + 64));
+            hipLaunchKernelGGL(ntt_pair_tw_kernel, dim3(8), dim3(256), 0, c.stream, d_t2k, p->d_tw2048c, (uint64_t)2048);
+            UZK_HIP(hipStreamSynchronize(c.stream));
+            UZK_HIP(hipFree(d_t2k));
+        }
+        const uint32_t TW = 256;
+        std::vector<Fp> t256(TW);
+        Fp w256 = f_pow_u64<Fr>(w, n / TW), cur = Fr::one();
+        for (uint32_t e = 0; e < TW; ++e) { t256[e] = cur; cur = Fr::mul(cur, w256); }
         for (auto& t : t256)
             for (int d = 0; d < 5; ++d) t = Fr::add(t, t);     // 2^261-form
         UZK_TRY(upload(&p->d_tw256, t256, c.stream));
@@ -585,9 +622,9 @@ static int get_plan(Ctx& c, uint64_t n, bool inverse, bool scaled, NttPlan** out
             return UZK_OK;
         };
         // the 256 tile twiddles once more as (w, floor(w 2^261 / M)) pairs for the constant-operand product
-        UZK_HIP(hipMalloc(reinterpret_cast<void**>(&p->d_tw256c), 2 * 256 * 36 + 64));
-        hipLaunchKernelGGL(ntt_pair_tw_kernel, dim3(1), dim3(256), 0, c.stream, p->d_tw256, p->d_tw256c, (uint64_t)256);
-        UZK_TRY(to_planes(&p->d_tw256, 256));
+        UZK_HIP(hipMalloc(reinterpret_cast<void**>(&p->d_tw256c), 2 * (size_t)TW * 36 + 64));
+        hipLaunchKernelGGL(ntt_pair_tw_kernel, dim3(TW / 256), dim3(256), 0, c.stream, p->d_tw256, p->d_tw256c, (uint64_t)TW);
+        UZK_TRY(to_planes(&p->d_tw256, TW));
         int log_S = 0;
         for (int j = 0; j + 1 < p->npass; ++j) {
             const uint64_t count = n >> log_S;   // (N / (S R)) * R
@@ -616,6 +653,7 @@ void ntt_free_plans(Ctx& c) {
         NttPlan* p = kv.second;
         if (p->d_tw256) (void)hipFree(p->d_tw256);
         if (p->d_tw256c) (void)hipFree(p->d_tw256c);
+        if (p->d_tw2048c) (void)hipFree(p->d_tw2048c);
         if (p->d_small_tw) (void)hipFree(p->d_small_tw);
         if (p->d_pow) (void)hipFree(p->d_pow);
         for (auto* t : p->d_tw_pass) if (t) (void)hipFree(t);
@@ -636,11 +674,15 @@ static void launch_pass(Ctx& c, bool first, const Fp* in, Fp* out, const PassArg
     // uzk_tune("ntt_tile", 1024 | 2048) forces a tile (tests: both instantiations at every size).
     const bool small_tile = c.tune_ntt_tile == 1024 || (c.tune_ntt_tile != 2048 && n * (uint64_t)batch <= (1ull << 24));
     KernelScope ks(c, first ? "ntt_pass_first" : "ntt_pass");
+    if constexpr (B <= 9) {
     if (small_tile) {
         const unsigned g2 = (unsigned)((n / R) / (1024 / R));
         if (first) hipLaunchKernelGGL((ntt_pass29_kernel<B, true, 1024>), dim3(g2, batch), dim3(256), 0, c.stream, in, out, a);
         else hipLaunchKernelGGL((ntt_pass29_kernel<B, false, 1024>), dim3(g2, batch), dim3(256), 0, c.stream, in, out, a);
-    } else {
+        return;
+    }
+    }
+    {
         const unsigned grid = (unsigned)((n / R) / (2048 / R));
         if (first) hipLaunchKernelGGL((ntt_pass29_kernel<B, true, 2048>), dim3(grid, batch), dim3(512), 0, c.stream, in, out, a);
         else hipLaunchKernelGGL((ntt_pass29_kernel<B, false, 2048>), dim3(grid, batch), dim3(512), 0, c.stream, in, out, a);
@@ -702,7 +744,7 @@ static int ntt_pow2(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse,
         a.stride = n >> p->bits[j];
         a.log_S = log_S;
         a.tw256 = p->d_tw256;
-        a.tw256c = p->d_tw256c;
+        a.tw256c = p->bits[j] > 8 ? p->d_tw2048c : p->d_tw256c;
         a.twp = p->d_tw_pass[j];
         a.twp_count = p->tw_count[j];
         a.in_planes = planes && j > 0;
@@ -714,6 +756,9 @@ static int ntt_pow2(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse,
             case 6: launch_pass<6>(c, first, src, dst, a, n, batch); break;
             case 7: launch_pass<7>(c, first, src, dst, a, n, batch); break;
             case 8: launch_pass<8>(c, first, src, dst, a, n, batch); break;
+            case 9: launch_pass<9>(c, first, src, dst, a, n, batch); break;         // two-pass plans (2^17 .. 2^21)
+            case 10: launch_pass<10>(c, first, src, dst, a, n, batch); break;
+            case 11: launch_pass<11>(c, first, src, dst, a, n, batch); break;
             default: set_error("ntt: bad radix bits %d", p->bits[j]); return UZK_ERR_FFT;
         }
         UZK_HIP(hipGetLastError());
