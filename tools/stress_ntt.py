@@ -14,12 +14,13 @@ rng = random.Random(int(os.environ.get("SEED", "1")))
 cases = int(os.environ.get("CASES", "120"))
 bad = 0
 for t in range(cases):
-    k = rng.randrange(0, 19)
-    n = (1 << k) if rng.random() < 0.6 else 3 * (1 << min(k, 16))
+    k = rng.randrange(0, 21)            # up to 2^20 and 3 * 2^18: the two-pass plans of 2^17 .. 2^21 and their three-pass form
+    n = (1 << k) if rng.random() < 0.6 else 3 * (1 << min(k, 18))
     batch = rng.choice([1, 1, 2, 5])
     inv = rng.random() < 0.5
     shift = rand_fr_wire(1, rng.randrange(1 << 30))[0] if rng.random() < 0.4 else None
     b.tune("ntt_tile", rng.choice([0, 0, 1024, 2048]))
+    b.tune("ntt_two_pass", rng.choice([1, 1, 0]))
     x = rand_fr_wire(n * batch, rng.randrange(1 << 30)).reshape(batch, n, 4)
     got = b.ntt_batch(x, inverse=inv, coset_shift=shift)
     for j in range(batch):
@@ -31,5 +32,6 @@ for t in range(cases):
         if not np.array_equal(got[j], w):
             bad += 1; print(f"MISMATCH case {t}: n={n} batch={batch} inv={inv} shift={shift is not None}", flush=True); break
 b.tune("ntt_tile", 0)
+b.tune("ntt_two_pass", 1)
 print(f"{cases} cases, {bad} mismatches")
 sys.exit(1 if bad else 0)
