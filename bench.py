@@ -601,6 +601,18 @@ def run_rank(args) -> None:
         }
         if sq is not None and "ntt_pass" in sq:
             extra["ntt"]["sq_counters"] = sq["ntt_pass"]
+        if not args.no_extras:
+            # the sizes below the headline: 2^17 .. 2^21 run in two passes of 9 .. 11 bits, 2^22 keeps three
+            sizes = {}
+            for lg in (18, 20, 21):
+                m = 1 << lg
+                b.ntt_device(x.data_ptr(), y.data_ptr(), m, sync=True)
+                t1 = time.perf_counter()
+                for _ in range(100):
+                    b.ntt_device(x.data_ptr(), y.data_ptr(), m)
+                b.sync()
+                sizes[f"2^{lg}"] = round((time.perf_counter() - t1) / 100 * 1e3, 4)
+            extra["ntt"]["ms_per_transform_other_sizes"] = sizes
 
     # ---- sustained shader clock under this workload (rank 0, N = 1 only) --------------------------
     # The MAD peak above was measured with sub-millisecond kernels at the boost clock; the 18 ms
