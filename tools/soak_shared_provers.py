@@ -13,7 +13,7 @@ round together, uzkge_amd/csrc/coalesce.cpp) while everything that can happen ar
 Every finished proof is compared, commitment by commitment and evaluation by evaluation, with what a private prover made of the
 same inputs single-threaded before the threads started.
 
-usage: python tools/soak_shared_provers.py [seconds=40] [threads=12]
+usage: python tools/soak_shared_provers.py [seconds=40] [threads=12] [log_n=12]
 """
 import os
 import sys
@@ -43,7 +43,7 @@ def digest(o, with_tables=True):
 def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 40.0
     n_threads = int(sys.argv[2]) if len(sys.argv) > 2 else 12
-    n = 1 << 12
+    n = 1 << (int(sys.argv[3]) if len(sys.argv) > 3 else 12)
     inp_a, inp_b = pch.ChainInputs(n, 91), pch.ChainInputs(n, 191)
     cir = {"A": T._circuit_of(b, inp_a, precompute=1), "B": T._circuit_of(b, inp_b, precompute=1)}
     lanes = {"A": T._round_inputs(inp_a, 4), "B": T._round_inputs(inp_b, 4)}
