@@ -1977,7 +1977,9 @@ static int msm_group_phase1(Ctx& c, MsmGroup& g, const Affine* points, const Sca
     uint32_t* sm = m.small.as<uint32_t>();
     uint32_t* win_tot = sm;
     uint32_t* d_max = sm + 3200;
-    UZK_HIP(hipMemsetAsync(d_max, 0, 4, st));
+    // ONE fill for everything this phase counts in: [3200] max, [3328, 3584) the task-length histogram, [3584, 3840) its cursors,
+    // [3900] the exception count, [3908] the big-bucket count (four fills before round 5: three launches less per MSM)
+    UZK_HIP(hipMemsetAsync(d_max, 0, (3912 - 3200) * 4, st));
     // general mode, whole window range, chunks of >= 32768 scalars: digits and pass-0 histograms in one kernel
     const bool fused_hist = !g.pre && g.w0 == 0 && g.W == g.W_total && g.sp[0].nch >= 256 &&
                             (size_t)g.W * g.sp[0].bins * 4 <= 64 * 1024;
@@ -2102,7 +2104,6 @@ static int msm_group_phase1(Ctx& c, MsmGroup& g, const Affine* points, const Sca
     XYZZ* direct_buckets = g.direct ? m.buckets.as<XYZZ>() : nullptr;
     {
         KernelScope ks(c, "msm_scan_win");
-        UZK_HIP(hipMemsetAsync(len_hist, 0, kLenBins * 4, st));
         hipLaunchKernelGGL(msm_scan_win_kernel, dim3(g.Wd), dim3(1024), scan_win_lds(g.NB), st, bcount, g.L, g.cnt_cur, g.off_cur, win_tot,
                            d_max, g.NB, len_hist);
         hipLaunchKernelGGL(msm_win_base_kernel, dim3(1), dim3(1024), 0, st, win_tot, g.base_cur, g.Wd);
@@ -2113,7 +2114,6 @@ static int msm_group_phase1(Ctx& c, MsmGroup& g, const Affine* points, const Sca
         KernelScope ks(c, "msm_task_order");
         uint32_t* big_count = sm + 3908;
         UZK_TRY(m.big.reserve((size_t)(g.TBK + 1) * sizeof(BigBucket)));        // (shared with the fold lists of phase 2)
-        UZK_HIP(hipMemsetAsync(big_count, 0, 4, st));
         hipLaunchKernelGGL(msm_task_scan_kernel, dim3(1), dim3(256), 0, st, len_hist, len_cur);
         hipLaunchKernelGGL(msm_bucket_fill_kernel, dim3((unsigned)((g.TBK + 255) / 256)), dim3(256), 0, st, g.base_cur, g.cnt_cur, g.off_cur,
                            bstart, bcount, g.NB, g.TBK, len_cur, desc, big_count, m.big.as<BigBucket>(), g.direct ? 1u : 0u);
@@ -2125,7 +2125,6 @@ static int msm_group_phase1(Ctx& c, MsmGroup& g, const Affine* points, const Sca
         // the 29-bit-limb accumulator + the (normally empty) exception pass
         uint32_t* exc_count = sm + 3900;
         uint32_t* exc_list = m.exc.as<uint32_t>();
-        UZK_HIP(hipMemsetAsync(exc_count, 0, 4, st));
         hipLaunchKernelGGL(msm_accumulate29_kernel, grid, dim3(256), 0, st, points, sorted, desc, g.base_cur, g.part_cur,
                            g.Wd, exc_count, exc_list, direct_buckets);
         hipLaunchKernelGGL(msm_accumulate_exc_kernel, grid, dim3(256), 0, st, points, sorted, desc, g.part_cur,
