@@ -7,6 +7,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <shared_mutex>
 #include <thread>
 
 #include "ctx.hpp"
@@ -25,6 +26,7 @@ struct Chunk {
 struct ShardedSrs {
     size_t n = 0;
     std::vector<std::unique_ptr<Chunk>> chunks;
+    std::shared_mutex use;         // calls hold it shared; a release waits for the calls in flight (their threads still hold the object)
 };
 struct Registry {
     std::mutex mu;
@@ -38,6 +40,7 @@ Registry& reg() {
 constexpr uint64_t kShardedBit = 1ull << 61;
 
 void release(ShardedSrs& s) {
+    std::unique_lock<std::shared_mutex> ul(s.use);
     for (auto& c : s.chunks) {
         if (c->srs) {
             CtxScope scope(&c->ctx);
@@ -123,6 +126,8 @@ int uzk_msm_g1_sharded(uint64_t handle, const uint64_t* scalars_mont, size_t n, 
         if (it == r.all.end()) { set_error("uzk_msm_g1_sharded: unknown handle %llu", (unsigned long long)handle); return UZK_ERR_PARAMETER; }
         s = it->second;
     }
+    std::shared_lock<std::shared_mutex> in_use(s->use);
+    if (s->chunks.empty()) { set_error("uzk_msm_g1_sharded: the handle was released"); return UZK_ERR_PARAMETER; }
     // KZG commit: degree + 1 > SRS length (kzg_poly_commitment.rs:283-285)
     if (n > s->n) { set_error("msm: n %zu exceeds SRS length %zu", n, s->n); return UZK_ERR_DEGREE; }
     const size_t N = s->chunks.size();
@@ -157,6 +162,7 @@ int uzk_srs_sharded_info(uint64_t handle, size_t* n_out, uint32_t* n_chunks_out,
         if (it == r.all.end()) { set_error("uzk_srs_sharded_info: unknown handle %llu", (unsigned long long)handle); return UZK_ERR_PARAMETER; }
         s = it->second;
     }
+    std::shared_lock<std::shared_mutex> in_use(s->use);
     if (n_out) *n_out = s->n;
     if (n_chunks_out) *n_chunks_out = (uint32_t)s->chunks.size();
     for (size_t i = 0; i < s->chunks.size(); ++i) {
