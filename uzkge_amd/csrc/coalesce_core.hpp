@@ -76,6 +76,7 @@ public:
         Key key;
         int team = 0;
         bool gathering = true, running = false;
+        bool held = false;                       // it has been kept open for the larger part of its team
         int next_round = 1;
         uint32_t alive = 0, arrived = 0;
         std::vector<LaneRec> lanes;
@@ -184,6 +185,12 @@ public:
                     // gather_wait.
                     const auto now = Clock::now();
                     const bool hold = larger_part_under_way(g.get());
+                    // the part it was held for has just finished: its members come back within microseconds -- a fresh gathering
+                    // wait for them (without it the cohort left the moment the hold ended, its own deadline long past, and the
+                    // team-mates, arriving a moment later, held for IT: five provers over four teams made 670 proofs/s where four
+                    // make 850)
+                    if (hold) g->held = true;
+                    else if (g->held) { g->held = false; g->deadline = std::max(g->deadline, now + gather_wait_); }
                     const auto deadline = hold ? g->born + 3 * straggler_wait_ : g->deadline;
                     if (g->lanes.size() >= max_lanes_ || now >= deadline || (!hold && mates_in_sight(g.get(), now) == 0)) {
                         trace(now >= deadline ? "go-deadline" : hold ? "go-full" : "go-complete", m, g.get(), (int)hold);
