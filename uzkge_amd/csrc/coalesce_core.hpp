@@ -237,12 +237,18 @@ private:
 
     static bool at_work(const Member* o, Clock::time_point now, std::chrono::microseconds recent) { return o->cohort || o->in_call || now - o->last_seen < recent; }
 
-    // Teams of m's group: as many as `groups_`, more when a team would exceed max_lanes_.  m keeps its team unless it has none or
+    // Teams of m's group: as many as `groups_` (fewer while that would leave a prover alone in its team), more when a team would
+    // exceed max_lanes_.  m keeps its team unless it has none or
     // the teams have become lopsided (provers came or went): then it moves to the emptiest one.
     void deal(Member* m, Clock::time_point now) {
         uint32_t active = 0;
         for (const Member* o : members_) if (o->group == m->group && (o == m || at_work(o, now, recent_))) ++active;
-        const uint32_t teams = std::max<uint32_t>(groups_, (active + max_lanes_ - 1) / max_lanes_);
+        // More provers than teams: no team of ONE -- a lone prover runs the one-proof pipeline (its commits' host part and all),
+        // and a mix of such with pairs over the same streams is slower than either (five provers over four teams: 630-700
+        // proofs/s, over two: 945; six: 830 / 1000; seven: 990 / 1050 -- profiles/r05_shared_odd_thread_counts.txt).
+        uint32_t teams = groups_;
+        if (active > groups_) teams = std::min<uint32_t>(groups_, std::max<uint32_t>(1, active / 2));
+        teams = std::max<uint32_t>(teams, (active + max_lanes_ - 1) / max_lanes_);
         std::vector<uint32_t> load(teams, 0);
         for (const Member* o : members_)
             if (o != m && o->group == m->group && o->team >= 0 && (uint32_t)o->team < teams && at_work(o, now, recent_)) load[o->team]++;
