@@ -54,3 +54,16 @@ def test_callers_with_unrelated_phases_converge_on_full_teams(tmp_path, threads)
     assert res["ideal_lanes_per_round"] == threads / 4
     assert res["lanes_per_round"] >= 0.9 * res["ideal_lanes_per_round"], res
     assert res["gather_us_per_cohort"] < 1000 and res["moved_out"] == 0, res
+
+
+@pytest.mark.parametrize("threads,want", [(5, 2.5), (6, 2.0), (7, 7 / 3)])
+def test_no_team_of_one_once_provers_outnumber_teams(tmp_path, threads, want):
+    """Five to seven provers over four teams: a lone prover beside pairs made the whole slower than four threads on the GPU
+    (profiles/r05_shared_odd_thread_counts.txt), so the teams become min(groups, provers / 2) -- 5 -> (3, 2), 6 -> (2, 2, 2),
+    7 -> (3, 2, 2) -- and the rounds serve provers / teams callers on average."""
+    exe = os.path.join(str(tmp_path), "coalesce_core_sim")
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-o", exe, os.path.join(ROOT, "tests", "cpp", "coalesce_core_sim.cpp")], check=True)
+    r = subprocess.run([exe, str(threads), "8", "4", "2000", "1.0"], capture_output=True, text=True, timeout=120)
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res["lanes_per_round"] >= 0.9 * want, res
+    assert res["moved_out"] == 0, res
