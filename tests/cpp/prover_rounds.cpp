@@ -32,6 +32,8 @@
 //     lockstep  (default when lanes > 1) each thread holds `lanes` witnesses and a prover of that many proofs
 //               (uzk_prover_create(n, lanes)) on its own context
 //     private   each thread a prover that owns its lane on its own context: no sharing, the streams overlap
+//   UZK_THINK_US=<us> (environment): every thread pauses a random time in [0, 2 x us) between two proofs -- a host that spends
+//   time on its own work (witness generation) between proofs; the rate then counts that time too.
 //   skew = 1: witness columns drawn from the classes real witnesses consist of (50 % zero, 20 % one,
 //   10 % minus one, 10 % < 2^16, 10 % uniform) instead of uniform field elements.
 #include <algorithm>
@@ -363,7 +365,13 @@ int main(int argc, char** argv) {
                 gate.fetch_add(1);
                 while (!go.load()) std::this_thread::yield();
                 const auto t0 = std::chrono::steady_clock::now();
-                for (int r = 0; r < reps * 5; ++r) bn.chain(2);
+                // UZK_THINK_US: the host's own work between two proofs (witness generation), uniform in [0, 2 x that) per thread
+                static const long think_us = std::getenv("UZK_THINK_US") ? std::atol(std::getenv("UZK_THINK_US")) : 0;
+                Rng pause{0x7715ull + (uint64_t)t};
+                for (int r = 0; r < reps * 5; ++r) {
+                    bn.chain(2);
+                    if (think_us > 0) std::this_thread::sleep_for(std::chrono::microseconds((long)(pause.next() % (uint64_t)(2 * think_us))));
+                }
                 res[t].seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                 done.fetch_add(1);
                 // keep the others company until all are through (a thread that stops early would change what the rest measure), then
