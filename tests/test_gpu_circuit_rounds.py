@@ -244,6 +244,20 @@ def test_circuit_without_wire_selectors_and_with_built_coset_quotient(gpu):
             assert [affine_of(j) for j in o5[key]] == [affine_of(j) for j in o8[key]], key
         assert [affine_of(j) for j in o5["cm1"]] == [affine_of(j) for j in o8["cm1"][:5]]
         assert np.array_equal(o5["evals"], o8["evals"]) and o5["evals"].shape[0] == 15
+        # three lanes in lockstep without wire selectors, on a prover whose idle slots hold what proofs WITH selectors left there:
+        # round 3 transforms all ten slots of every lane in one launch sequence, seven of them in use
+        lanes = _round_inputs(inp, 3)
+        p3 = b.Prover(n, 3)
+        try:
+            _run_rounds(b, cir, p3, lanes, shuffle=False, with_wsel=True)
+            o3 = _run_rounds(b, cir, p3, lanes, shuffle=False, with_wsel=False)
+            for lane, x in enumerate(lanes):
+                o1 = _run_rounds(b, cir, pr, [x], shuffle=False, with_wsel=False)
+                for key, per in (("cm1", 5), ("cm_z", 1), ("cm_t", 5), ("cm_q", 2)):
+                    assert [affine_of(j) for j in o3[key][lane * per:(lane + 1) * per]] == [affine_of(j) for j in o1[key]], (lane, key)
+                assert np.array_equal(o3["evals"][lane * 15:(lane + 1) * 15], o1["evals"]), lane
+        finally:
+            p3.destroy()
     finally:
         pr.destroy(); cir.release()
 
