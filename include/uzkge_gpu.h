@@ -445,8 +445,8 @@ int uzk_prover_destroy(uint64_t prover);
  *                      workspace of its own and the rest go on (0 = the default, 20000)
  *   groups             the provers at work are spread over this many launch sequences side by side (0 = the default, 4: measured
  *                      best at n = 2^14 -- four streams of B proofs each beat one of 4 B): a group takes at most
- *                      ceil(provers at work / groups) proofs, so two or four threads keep a stream each and are never merged;
- *                      with more provers than groups nobody is left alone (five provers run as 3 + 2, seven as 3 + 2 + 2).
+ *                      ceil(provers at work / groups) proofs; up to three provers keep a stream each and are never merged,
+ *                      from four on nobody is left alone (four provers run as 2 + 2, five as 3 + 2, seven as 3 + 2 + 2).
  *                      At most four of the library's own streams are busy on a device whatever `groups` is: the compute front
  *                      end has four pipes (a fifth busy queue shares one: profiles/r05_gaps_lockstep_5x8.txt) */
 int uzk_coalesce_config(uint32_t max_lanes, uint32_t gather_wait_us, uint32_t straggler_wait_us, uint32_t groups);

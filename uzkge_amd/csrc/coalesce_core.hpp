@@ -247,7 +247,7 @@ private:
         // and a mix of such with pairs over the same streams is slower than either (five provers over four teams: 630-700
         // proofs/s, over two: 945; six: 830 / 1000; seven: 990 / 1050 -- profiles/r05_shared_odd_thread_counts.txt).
         uint32_t teams = groups_;
-        if (active > groups_) teams = std::min<uint32_t>(groups_, std::max<uint32_t>(1, active / 2));
+        if (active > groups_ || active >= 4) teams = std::min<uint32_t>(groups_, std::max<uint32_t>(1, active / 2));     // (four provers: two pairs make 900, four alone 855)
         teams = std::max<uint32_t>(teams, (active + max_lanes_ - 1) / max_lanes_);
         std::vector<uint32_t> load(teams, 0);
         for (const Member* o : members_)
