@@ -58,6 +58,7 @@ public:
         int round = 0;                           // rounds completed of the proof in flight
         bool in_call = false, moving = false;
         std::chrono::steady_clock::time_point last_seen{};   // when it last left a call
+        std::string last_blob;                   // the key of its last proof: a prover between two proofs is expected back with the same one
     };
     // what must agree for two round-1 calls to share a cohort; `blob` is compared bytewise (circuit, hiding degrees, public-input indices ...)
     struct Key {
@@ -134,6 +135,7 @@ public:
         std::shared_ptr<Cohort> g;
         if (round == 1) {
             leave_locked(m, lk);                 // a proof in flight is abandoned
+            if (m->last_blob != key->blob) m->last_blob = key->blob;
             const auto now = Clock::now();
             const int team_before = m->team;
             deal(m, now);
@@ -264,7 +266,8 @@ private:
         uint32_t c = 0;
         for (const Member* o : members_) {
             if (o->group != g->key.group || (o->team != g->team && o->team >= 0) || o->cohort.get() == g) continue;     // (team < 0: not dealt yet -- it may come here)
-            if (!o->cohort) { if (o->in_call || now - o->last_seen < recent_) ++c; }
+            // (a team-mate whose last proof was over another circuit is not waited for: it cannot join this group)
+            if (!o->cohort) { if ((o->in_call || now - o->last_seen < recent_) && (o->last_blob.empty() || o->last_blob == g->key.blob)) ++c; }
             else if (!o->cohort->gathering && o->cohort->next_round >= rounds_ && o->cohort->key == g->key) ++c;
         }
         return c;
