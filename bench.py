@@ -785,7 +785,19 @@ def run_rank(args) -> None:
                 extra["prover_rounds_cpp"]["private_4"] = lines[1]
             for key, a in (("shared_8", [10, 8, 1, "shared", 0]), ("shared_16", [10, 16, 1, "shared", 0]), ("shared_32", [10, 32, 1, "shared", 0]),
                            ("shared_32_skewed", [10, 32, 1, "shared", 1]), ("lockstep8", [10, 4, 8, "lockstep", 0]), ("lockstep8_skewed", [10, 4, 8, "lockstep", 1])):
-                extra["prover_rounds_cpp"][key] = _run_prover_rounds(a)[-1]
+                # clock and socket power while the throughput section runs (the last 40 % of the driver's run: after its single-proof
+                # part and the threads' warm-up): joules per proof beside proofs per second
+                smp = _ClockSampler(dev_index).start() if key in ("shared_32", "lockstep8") else None
+                t_a = time.perf_counter()
+                res_k = _run_prover_rounds(a)[-1]
+                t_b = time.perf_counter()
+                if smp is not None:
+                    st_k = smp.stop(t_a + 0.6 * (t_b - t_a), t_b)
+                    if st_k and st_k.get("power_w_timed") and res_k.get("proofs_per_s"):
+                        res_k["sclk_mhz"] = st_k["sclk_mhz_timed"]
+                        res_k["socket_power_w"] = st_k["power_w_timed"]
+                        res_k["joules_per_proof_socket"] = round(st_k["power_w_timed"] / res_k["proofs_per_s"], 4)
+                extra["prover_rounds_cpp"][key] = res_k
             extra["proofs_per_s_total"] = extra["prover_rounds_cpp"]["shared_32"]["proofs_per_s"]
         except Exception as e:
             extra["prover_rounds_cpp"] = {"error": str(e)}
