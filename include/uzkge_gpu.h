@@ -182,10 +182,17 @@ int uzk_g1_fold(const uzk_g1_jac* partials, size_t count, uzk_g1_jac* out);
 int uzk_g1_to_affine(const uzk_g1_jac* p, uzk_g1_affine* out);
 
 /* ---- NTT: replaces EvaluationDomain::{fft, ifft} (field_polynomial.rs:585,595) --------- */
-/* 1 if an evaluation domain of size n exists (n = 2^k, k <= 28, or n = 3 * 2^k), else 0
- * (FpPolynomial::{evaluation_domain, quotient_evaluation_domain}, field_polynomial.rs:554-567). */
+/* The largest transforms this library runs: n = 2^k with k <= UZK_NTT_MAX_LOG2, n = 3 * 2^k with k <= UZK_NTT_MAX_LOG2_MIXED.
+ * These are exactly the largest sizes the parity suite compares with the CPU oracle on the whole vector
+ * (tests/test_gpu_ntt_large.py: 2^25 is the first four-pass plan); a size is accepted only if its result is checked.
+ * (Fr has domains up to 2^28 / 3 * 2^28; the prover of the reference uses n = 2^14 and 6n = 3 * 2^15.) */
+#define UZK_NTT_MAX_LOG2 25
+#define UZK_NTT_MAX_LOG2_MIXED 22
+/* 1 if this library transforms over the size-n domain (n = 2^k, k <= UZK_NTT_MAX_LOG2, or n = 3 * 2^k,
+ * k <= UZK_NTT_MAX_LOG2_MIXED), else 0: the shim's FpPolynomial::{evaluation_domain, quotient_evaluation_domain}
+ * (field_polynomial.rs:554-567) returns None on 0, which its callers turn into UzkgeError::FFTError. */
 int uzk_domain_supported(uint64_t n);
-/* group_gen of the size-n domain (5^((r-1)/n)), Montgomery form. */
+/* group_gen of the size-n domain (5^((r-1)/n)), Montgomery form; answers for every domain Fr has (2^k, 3 * 2^k, k <= 28). */
 int uzk_domain_group_gen(uint64_t n, uint64_t out_mont[4]);
 /* In-place transform of `n` elements in natural order over <group_gen(n)>.
  * inverse != 0: includes the 1/n scaling.  coset_shift (4 limbs, Montgomery) or NULL:

@@ -26,12 +26,23 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 
 def test_domain_queries_match_oracle():
+    """uzk_domain_supported = "this library transforms it" (bounded by the largest oracle-checked sizes, the header's
+    UZK_NTT_MAX_LOG2 / _MIXED); uzk_domain_group_gen answers for every domain Fr has."""
     from uzkge_amd import backend as b
-    for n in (1, 2, 3, 4, 48, 1 << 14, 98304, 1 << 22, 1 << 28):
+    hdr = open(os.path.join(ROOT, "include", "uzkge_gpu.h")).read()
+    kmax = int(re.search(r"#define UZK_NTT_MAX_LOG2 (\d+)", hdr).group(1))
+    kmix = int(re.search(r"#define UZK_NTT_MAX_LOG2_MIXED (\d+)", hdr).group(1))
+    assert (kmax, kmix) == (25, 22)         # == the sizes tests/test_gpu_ntt_large.py compares with the oracle
+    for n in (1, 2, 3, 4, 48, 1 << 14, 98304, 1 << 22, 1 << kmax, 3 << kmix):
         assert b.domain_supported(n)
         assert np.array_equal(b.domain_group_gen(n), oc.root_of_unity(n))
-    for n in (0, 5, 9, 1 << 29):
+    for n in (0, 5, 9, 1 << (kmax + 1), 3 << (kmix + 1), 1 << 28, 1 << 29):
         assert not b.domain_supported(n)
+    for n in (1 << 28, 3 << 28):
+        assert np.array_equal(b.domain_group_gen(n), oc.root_of_unity(n))
+    from uzkge_amd import UzkgeError
+    with pytest.raises(UzkgeError):
+        b.domain_group_gen(1 << 29)
 
 
 def test_host_fold_and_to_affine_match_oracle():

@@ -14,9 +14,9 @@ rng = random.Random(int(os.environ.get("SEED", "1")))
 cases = int(os.environ.get("CASES", "120"))
 bad = 0
 for t in range(cases):
-    k = rng.randrange(0, 21)            # up to 2^20 and 3 * 2^18: the two-pass plans of 2^17 .. 2^21 and their three-pass form
-    n = (1 << k) if rng.random() < 0.6 else 3 * (1 << min(k, 18))
-    batch = rng.choice([1, 1, 2, 5])
+    k = rng.randrange(0, 25)            # up to 2^24 and 3 * 2^22: two-pass plans of 2^17 .. 2^21, their three-pass form, 8 + 8 + 7 / 8
+    n = (1 << k) if rng.random() < 0.6 else 3 * (1 << min(k, 22))
+    batch = rng.choice([1, 1, 2, 5]) if n <= (1 << 21) else 1
     inv = rng.random() < 0.5
     shift = rand_fr_wire(1, rng.randrange(1 << 30))[0] if rng.random() < 0.4 else None
     b.tune("ntt_tile", rng.choice([0, 0, 1024, 2048]))
@@ -26,7 +26,7 @@ for t in range(cases):
     for j in range(batch):
         v = x[j]
         if shift is not None and not inv: v = oc.mul_var(v, shift)
-        w = oc.ntt(v, inverse=inv, threads=4)
+        w = oc.ntt(v, inverse=inv, threads=int(os.environ.get("THREADS", "16")))
         if shift is not None and inv:
             w = oc.mul_var(w, shift)      # the ABI post-scales by shift^j on the inverse (caller passes k^-1)
         if not np.array_equal(got[j], w):

@@ -884,7 +884,7 @@ int uzk_domain_supported(uint64_t n) try { return domain_supported(n) ? 1 : 0; }
 
 int uzk_domain_group_gen(uint64_t n, uint64_t out_mont[4]) try {
     if (!out_mont) { set_error("uzk_domain_group_gen: null pointer"); return UZK_ERR_PARAMETER; }
-    if (!domain_supported(n)) { set_error("no evaluation domain of size %llu", (unsigned long long)n); return UZK_ERR_FFT; }
+    if (!domain_exists(n)) { set_error("no evaluation domain of size %llu", (unsigned long long)n); return UZK_ERR_FFT; }
     Fp w = fr_root_of_unity(n);
     std::memcpy(out_mont, &w, sizeof w);
     return UZK_OK;
@@ -893,7 +893,7 @@ int uzk_domain_group_gen(uint64_t n, uint64_t out_mont[4]) try {
 static int ntt_device_common(const void* d_in, void* d_out, uint64_t n, uint32_t batch, int inverse,
                              const uint64_t* coset_shift_mont, int sync) {
     if (!domain_supported(n)) {
-        set_error("no evaluation domain of size %llu (need 2^k, k<=28, or 3*2^k)", (unsigned long long)n);
+        set_error("no evaluation domain of size %llu (need 2^k, k <= %d, or 3 * 2^k, k <= %d)", (unsigned long long)n, UZK_NTT_MAX_LOG2, UZK_NTT_MAX_LOG2_MIXED);
         return UZK_ERR_FFT;
     }
     if (!d_in || !d_out) { set_error("uzk_ntt_fr*_device: null pointer"); return UZK_ERR_PARAMETER; }
@@ -906,7 +906,7 @@ static int ntt_device_common(const void* d_in, void* d_out, uint64_t n, uint32_t
 }
 static int ntt_host_common(uint64_t* data, uint64_t n, uint32_t batch, int inverse, const uint64_t* coset_shift_mont) {
     if (!domain_supported(n)) {
-        set_error("no evaluation domain of size %llu (need 2^k, k<=28, or 3*2^k)", (unsigned long long)n);
+        set_error("no evaluation domain of size %llu (need 2^k, k <= %d, or 3 * 2^k, k <= %d)", (unsigned long long)n, UZK_NTT_MAX_LOG2, UZK_NTT_MAX_LOG2_MIXED);
         return UZK_ERR_FFT;
     }
     if (!data) { set_error("uzk_ntt_fr*: null pointer"); return UZK_ERR_PARAMETER; }
@@ -936,7 +936,7 @@ int uzk_ntt_fr_batch_strided_device(const void* d_in, uint64_t in_stride, void* 
                                     int inverse, const uint64_t* coset_shift_mont, int sync) try {
     API_LOCK;
     if (!domain_supported(n)) {
-        set_error("no evaluation domain of size %llu (need 2^k, k<=28, or 3*2^k)", (unsigned long long)n);
+        set_error("no evaluation domain of size %llu (need 2^k, k <= %d, or 3 * 2^k, k <= %d)", (unsigned long long)n, UZK_NTT_MAX_LOG2, UZK_NTT_MAX_LOG2_MIXED);
         return UZK_ERR_FFT;
     }
     if (!d_in || !d_out) { set_error("uzk_ntt_fr_batch_strided_device: null pointer"); return UZK_ERR_PARAMETER; }

@@ -3,6 +3,7 @@
 // combination of an MSM, folding <= 8 partial sums); the data-parallel work is in the .hip files.
 #pragma once
 #include "ec.hpp"
+#include "../../include/uzkge_gpu.h"
 
 namespace uzk {
 
@@ -42,12 +43,20 @@ inline Fp fr_from_u64(uint64_t v) {
     t.v[0] = (uint32_t)v; t.v[1] = (uint32_t)(v >> 32);
     return Fr::to_mont(t);
 }
-// 1 if a size-n evaluation domain exists: n = 2^k (k <= 28) or 3 * 2^k
+// 1 if Fr has a size-n evaluation domain: n = 2^k (k <= 28) or 3 * 2^k
 // (FpPolynomial::{evaluation_domain, quotient_evaluation_domain}, field_polynomial.rs:554-567).
-inline bool domain_supported(uint64_t n) {
+inline bool domain_exists(uint64_t n) {
     if (n == 0) return false;
     uint64_t m = (n % 3 == 0) ? n / 3 : n;
     return (m & (m - 1)) == 0 && m <= (1ull << 28);
+}
+// 1 if the library TRANSFORMS over the size-n domain: bounded by the largest sizes the parity suite checks against the oracle
+// (UZK_NTT_MAX_LOG2 / UZK_NTT_MAX_LOG2_MIXED, include/uzkge_gpu.h; tests/test_gpu_ntt_large.py).
+inline bool domain_supported(uint64_t n) {
+    if (n == 0) return false;
+    const bool mixed = n % 3 == 0;
+    const uint64_t m = mixed ? n / 3 : n;
+    return (m & (m - 1)) == 0 && m <= (1ull << (mixed ? UZK_NTT_MAX_LOG2_MIXED : UZK_NTT_MAX_LOG2));
 }
 // group_gen of the size-n domain: 5^((r-1)/n), Montgomery form.
 inline Fp fr_root_of_unity(uint64_t n) {

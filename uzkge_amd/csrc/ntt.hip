@@ -902,7 +902,7 @@ static int get_fused(Ctx& c, uint64_t n, bool inverse, const Fp* shift, NttFused
 int ntt_run(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse, const Fp* coset_shift_host, uint32_t batch,
             uint64_t in_stride, uint64_t out_stride) {
     if (!domain_supported(n)) {
-        set_error("no evaluation domain of size %llu (need 2^k, k<=28, or 3*2^k)", (unsigned long long)n);
+        set_error("no evaluation domain of size %llu (need 2^k, k <= %d, or 3 * 2^k, k <= %d)", (unsigned long long)n, UZK_NTT_MAX_LOG2, UZK_NTT_MAX_LOG2_MIXED);
         return UZK_ERR_FFT;
     }
     if (batch == 0) return UZK_OK;
