@@ -272,7 +272,7 @@ def _gather_proofs(dist, world, mine):
         dist.all_gather_object(objs, mine)
         per = objs
     rates = [p.get("proofs_per_s") for p in per]
-    return {"what": "every rank runs tests/cpp/prover_rounds on its own GPU in the reference's call pattern -- 32 host threads, each calling "
+    return {"what": "every rank runs tests/cpp/prover_rounds on its own GPU in the reference's call pattern -- host_threads_per_rank host threads (min(32, 2 x host_cores / ranks)), each calling "
                     "uzk_prove_round1..5 on its own prover of ONE proof from the default context, its own witness uploaded from pinned memory "
                     "every proof; the library shares the rounds (uzk_coalesce_config defaults) -- one circuit resident per process, no collective",
             "per_rank": per, "proofs_per_s_total": (sum(rates) if all(r is not None for r in rates) else None)}
@@ -304,6 +304,64 @@ def _run_prover_rounds(extra_args, visible_device=None, n_log=14, timeout=300):
     return lines
 
 
+SQ_MEASURED_LOG_N, SQ_MEASURED_WINDOWS = 24, 15     # the launch the SQ counter pass of tools/profile_round.sh measures (bench.py defaults)
+
+
+def _alu_roofline(n: int, cbits: int, nwin: int, acc_avg_ms: float, plain_workload: bool, clocks_timed=None) -> dict:
+    """The binding roofline of msm_accumulate: vector-instruction issue (see _issue_peak_t).  Vector instructions per mixed addition come
+    from the stamped SQ counter pass (profiles/sq_counters.json: measured on ONE launch of 2^24 points x 15 windows); they are a property
+    of the addition, not of the launch, so they price any launch of the same kernel on uniform scalars with the automatic window plan --
+    `valu_insts_measured_at` says where they were counted.  The achieved rate uses THIS run's mean kernel duration."""
+    adds = float(n) * nwin
+    sq, why = _load_counters("sq_counters.json")
+    alu = {"unit": "T lane vector-instructions/s (issue: one per SIMD per 4 cycles)", "mixed_adds_per_launch": int(adds),
+           "window_bits": cbits, "windows": nwin, "mads_per_mixed_add": MADS_PER_MIXED_ADD,
+           "peak_at_boost_clock": round(_issue_peak_t(BOOST_SCLK_MHZ), 2), "boost_sclk_mhz": BOOST_SCLK_MHZ}
+    insts_per_add = None
+    if sq is not None and "msm_accumulate" in sq and plain_workload and nwin > 0:
+        ent = sq["msm_accumulate"]
+        at_adds = float(ent.get("measured_mixed_adds", (1 << SQ_MEASURED_LOG_N) * SQ_MEASURED_WINDOWS))
+        insts_per_add = ent["SQ_INSTS_VALU"] * LANES / at_adds        # wave instructions x 64 lanes / lane-additions
+        alu["valu_insts_measured_at"] = (f"2^{ent.get('measured_log_n', SQ_MEASURED_LOG_N)} points x {ent.get('measured_windows', SQ_MEASURED_WINDOWS)} windows "
+                                         f"({sq.get('profile_tag')}); this launch: {n} points x {nwin} windows of {cbits} bits")
+    alu_achieved = 0.0
+    if insts_per_add:
+        alu_achieved = adds * insts_per_add / (acc_avg_ms * 1e-3) / 1e12 if acc_avg_ms > 0 else 0.0
+        alu.update({"valu_insts_per_mixed_add": round(insts_per_add, 1), "achieved": round(alu_achieved, 3),
+                    "frac_at_boost_clock": round(alu_achieved / _issue_peak_t(BOOST_SCLK_MHZ), 4),
+                    "mad_share_of_instructions": round(MADS_PER_MIXED_ADD / insts_per_add, 4),
+                    "sq_counters": sq["msm_accumulate"]})
+    else:
+        alu["sq_counters_note"] = why or "no SQ counter pass for this configuration"
+    if clocks_timed:
+        alu.update(clocks_timed)
+        alu["peak_at_timed_clock"] = round(_issue_peak_t(clocks_timed["sclk_mhz_timed"]), 2)
+        if alu_achieved:
+            alu["frac_at_timed_clock"] = round(alu_achieved / _issue_peak_t(clocks_timed["sclk_mhz_timed"]), 4)
+    alu["_achieved"] = alu_achieved
+    return alu
+
+
+def _cpu_threads(world: int) -> int:
+    """Host threads of the CPU baseline leg: every CPU this process may use at N = 1; under N > 1 ranks the other ranks wait at the
+    closing barrier while rank 0 times the port -- one CPU is left to each of them (a waiting rank may spin)."""
+    return max(1, _host_cores() - (world - 1))
+
+
+def _cpu_baseline_msm(oc, hp, hs, threads: int, world: int):
+    """The C port (oracle/bn254_oracle.c: Pippenger, own restatement, NOT arkworks) timed on a bounded sample of the workload."""
+    m = hp.shape[0]
+    tc = time.perf_counter()
+    ref = oc.msm_pippenger(hp, hs, 0, threads)
+    cpu_s = time.perf_counter() - tc
+    lg = m.bit_length() - 1
+    return ref, {"value": m / cpu_s, "unit": "points/s", "cores": threads, "kind": "port",
+                 "sample": f"first 2^{lg} points/scalars of rank 0's workload, Pippenger in oracle/bn254_oracle.c (own CPU restatement, not arkworks), "
+                           + ("one thread per host CPU this process may use (affinity mask capped by the cgroup quota)" if world == 1 else
+                              f"timed on rank 0 while the other {world - 1} ranks wait at the closing barrier; threads = host CPUs - {world - 1}"),
+                 "host_cores": _host_cores(), "seconds": round(cpu_s, 3)}
+
+
 def dry_run_rank(args, rank, world, dist, np) -> None:
     """--dry-run: the launcher, the rendezvous, the all-gather of 96-byte partials and the fold, with no GPU:
     rank r contributes (r + 1) * G (built with the host-side fold of the C ABI)."""
@@ -319,10 +377,25 @@ def dry_run_rank(args, rank, world, dist, np) -> None:
     # the proofs-per-device extra of a real N > 1 run: every rank reports its own rate, rank 0 prints the sum (here: 100 (r + 1))
     proofs = _gather_proofs(dist, world, {"rank": rank, "proofs_per_s": 100.0 * (rank + 1)})
     if rank == 0:
+        # the two objects an N > 1 line must carry, built by the SAME code as a real run while the other ranks wait at the barrier:
+        # cpu_baseline (the C port on the reference's 2^14-point Lagrange SRS here -- no device points exist) and roofline.alu
+        # (strong-scaling shape of config #5 on 8 GPUs: 2^23 points per GPU; nominal duration and clock, nothing was timed)
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import bn254_py as opy
+        import oracle_c as oc   # checker / reported baseline only
+        with open(os.path.join(ROOT, "tests", "golden", "lagrange-srs-16384.bin"), "rb") as f:
+            hp = oc.points_from_affine(opy.parse_srs_g1(f.read()))
+        rng = np.random.default_rng(5)
+        hs = rng.integers(0, 1 << 62, size=(hp.shape[0], 4), dtype=np.uint64)
+        _, cpu_baseline = _cpu_baseline_msm(oc, hp, hs, _cpu_threads(world), world)
+        alu = _alu_roofline(1 << 23, 17, 15, 8.5, True, {"sclk_mhz_timed": 2050, "source": "dry run: nominal duration (8.5 ms) and clock, nothing was timed"})
+        alu.pop("_achieved")
         print(json.dumps({"metric": "bn254_g1_msm_points_per_sec", "value": 0.0, "unit": "points/s", "n_gpus": world,
                           "dry_run": True, "dist_world_size": dist.get_world_size() if world > 1 else 1,
                           "fold_of_rank_partials_affine": [int(x) for x in aff],
-                          "expect": f"{world * (world + 1) // 2} * G", "extra": {"proofs_per_device": proofs}}))
+                          "expect": f"{world * (world + 1) // 2} * G", "host_cores": _host_cores(),
+                          "roofline": {"bound": "hbm", "kernel": "msm_accumulate", "alu": alu}, "cpu_baseline": cpu_baseline,
+                          "extra": {"proofs_per_device": proofs}}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -472,33 +545,16 @@ def run_rank(args) -> None:
             traffic = ent["traffic_bytes"]
         else:
             traffic_note = "no PMC pass for this configuration"
-    # The kernel's real bound is vector-instruction issue (see _issue_peak_t): every mixed addition is ~2090 vector
-    # instructions per lane, 1467 of them v_mad_u64_u32 (ec29.hpp); the count per addition and the measured issue
-    # utilisation come from the SQ counter pass of the same kernel (profiles/sq_counters.json, separate rocprofv3 --pmc
-    # runs), the achieved rate from the kernel's mean duration in THIS run.
+    # The kernel's real bound is vector-instruction issue (_alu_roofline): ~2090 vector instructions per mixed addition, 1467 of
+    # them v_mad_u64_u32 (ec29.hpp), counted by the SQ pass of the same kernel; the achieved rate uses THIS run's mean duration.
     cbits, nwin = (args.window_bits, 0)
     try:
         cbits, nwin = b.msm_plan_info(n)
     except Exception:
         pass
-    adds = float(n) * nwin
-    sq, why = _load_counters("sq_counters.json")
-    insts_per_add = None
-    if sq is not None and "msm_accumulate" in sq and n == (1 << 24) and args.scalars == "uniform" and not args.window_bits:
-        ent = sq["msm_accumulate"]
-        insts_per_add = ent["SQ_INSTS_VALU"] * LANES / adds        # wave instructions x 64 lanes / lane-additions
-    alu = {"unit": "T lane vector-instructions/s (issue: one per SIMD per 4 cycles)", "mixed_adds_per_launch": int(adds),
-           "window_bits": cbits, "windows": nwin, "mads_per_mixed_add": MADS_PER_MIXED_ADD,
-           "peak_at_boost_clock": round(_issue_peak_t(BOOST_SCLK_MHZ), 2), "boost_sclk_mhz": BOOST_SCLK_MHZ}
-    if insts_per_add:
-        alu_achieved = adds * insts_per_add / (acc_avg_ms * 1e-3) / 1e12 if acc_cnt else 0.0
-        alu.update({"valu_insts_per_mixed_add": round(insts_per_add, 1), "achieved": round(alu_achieved, 3),
-                    "frac_at_boost_clock": round(alu_achieved / _issue_peak_t(BOOST_SCLK_MHZ), 4),
-                    "mad_share_of_instructions": round(MADS_PER_MIXED_ADD / insts_per_add, 4),
-                    "sq_counters": sq["msm_accumulate"]})
-    else:
-        alu_achieved = 0.0
-        alu["sq_counters_note"] = why or "no SQ counter pass for this configuration"
+    plain = args.scalars == "uniform" and not args.window_bits and n & (n - 1) == 0 and n >= (1 << 21)     # the c = 17 plan of the counted launch
+    alu = _alu_roofline(n, cbits, nwin, acc_avg_ms if acc_cnt else 0.0, plain, clocks_timed)
+    alu_achieved = alu.pop("_achieved")
     roofline = {
         "bound": "hbm", "kernel": "msm_accumulate", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
@@ -509,11 +565,6 @@ def run_rank(args) -> None:
     }
     if traffic_note:
         roofline["traffic_note"] = traffic_note
-    if clocks_timed:
-        alu.update(clocks_timed)
-        alu["peak_at_timed_clock"] = round(_issue_peak_t(clocks_timed["sclk_mhz_timed"]), 2)
-        if alu_achieved:
-            alu["frac_at_timed_clock"] = round(alu_achieved / _issue_peak_t(clocks_timed["sclk_mhz_timed"]), 4)
     # device kernels (HIP events) and, prefixed host_, the host-side sections of the call (wall clock)
     kernels = {k: {"launches": v[0], "avg_ms": round(v[1] / max(v[0], 1), 4)} for k, v in sorted(prof.items())}
 
@@ -536,14 +587,20 @@ def run_rank(args) -> None:
 
     # ---- proofs per second, one prover process per device (the realistic scaling mode at n = 2^14) --------
     if world > 1 and not args.no_extras:
+        # host threads per rank: the reference's call pattern needs a caller thread per proof in flight; 32 per device when the host
+        # has them, never more than twice this rank's share of the CPUs the job may use (8 ranks x 32 threads on a 16-CPU grant would
+        # measure the host, not the GPUs) -- the line prints the host budget beside the rate
+        p_threads = max(2, min(32, 2 * _host_cores() // world))
         try:
-            lines = _run_prover_rounds([10, 32, 1, "shared", 0], visible_device=dev_index)
-            mine_p = {"rank": rank, "device": dev_index, "proofs_per_s": lines[-1]["proofs_per_s"], "ms_per_proof_single": lines[0]["ms_per_chain"],
+            lines = _run_prover_rounds([10, p_threads, 1, "shared", 0], visible_device=dev_index)
+            mine_p = {"rank": rank, "device": dev_index, "host_threads": p_threads, "proofs_per_s": lines[-1]["proofs_per_s"], "ms_per_proof_single": lines[0]["ms_per_chain"],
                       "proofs_per_shared_round": lines[-1].get("proofs_per_shared_round"), "threads_agree_with_single": lines[-1]["threads_agree_with_single"]}
         except Exception as e:
             mine_p = {"rank": rank, "device": dev_index, "error": str(e)[-300:]}
         proofs = _gather_proofs(dist, world, mine_p)
         if rank == 0:
+            proofs["host_cores"] = _host_cores()
+            proofs["host_threads_per_rank"] = p_threads
             extra["proofs_per_device"] = proofs
             extra["proofs_per_s_total"] = proofs["proofs_per_s_total"]
 
@@ -599,8 +656,9 @@ def run_rank(args) -> None:
                          "traffic": ntt_traffic},
             "kernels": {k: {"launches": v[0], "avg_ms": round(v[1] / max(v[0], 1), 4)} for k, v in sorted(p2.items())},
         }
-        if sq is not None and "ntt_pass" in sq:
-            extra["ntt"]["sq_counters"] = sq["ntt_pass"]
+        sq_ntt, _ = _load_counters("sq_counters.json")
+        if sq_ntt is not None and "ntt_pass" in sq_ntt:
+            extra["ntt"]["sq_counters"] = sq_ntt["ntt_pass"]
         if not args.no_extras:
             # the sizes below the headline: 2^17 .. 2^21 run in two passes of 9 .. 11 bits, 2^22 keeps three
             sizes = {}
@@ -824,27 +882,20 @@ def run_rank(args) -> None:
         except Exception as e:
             extra["public_key_refresh"] = {"error": str(e)}
 
-    # ---- CPU baseline + parity on a bounded sample (rank 0, N = 1 only) -----------------------
+    # ---- CPU baseline + parity on a bounded sample (rank 0; under N > 1 the other ranks wait at the closing barrier) ----------
     cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle_c as oc   # checker / reported baseline only
 
-        m = min(n, 1 << 24)   # the whole default workload: a few seconds on the node's host cores
+        # N = 1: the whole default workload (a few seconds on the node's host cores); N > 1: the first 2^22 points (about a second)
+        m = min(n, 1 << 24) if world == 1 else min(n, 1 << 22)
         hp = pts[:m].cpu().numpy().view(np.uint64).reshape(-1, 8)
         hs = sc[:m].cpu().numpy().view(np.uint64).reshape(-1, 4)
-        cores = _host_cores()
-        tc = time.perf_counter()
-        ref = oc.msm_pippenger(hp, hs, 0, cores)
-        cpu_s = time.perf_counter() - tc
+        cores = _cpu_threads(world)
+        ref, cpu_baseline = _cpu_baseline_msm(oc, hp, hs, cores, world)
         got = b.msm_device(srs, sc.data_ptr(), m)
-        parity = oc.jac_to_affine_ints(ref) == oc.jac_to_affine_ints(got)
-        cpu_baseline = {
-            "value": m / cpu_s, "unit": "points/s", "cores": cores, "kind": "port",
-            "sample": f"first 2^{m.bit_length() - 1} points/scalars of the same workload, Pippenger in oracle/bn254_oracle.c "
-                      f"(own CPU restatement, not arkworks), one thread per host CPU this process may use (affinity mask capped by the cgroup quota)",
-            "seconds": round(cpu_s, 3), "gpu_matches_cpu_on_sample": parity,
-        }
+        cpu_baseline["gpu_matches_cpu_on_sample"] = oc.jac_to_affine_ints(ref) == oc.jac_to_affine_ints(got)
         if "ntt" in extra:
             nn = 1 << args.ntt_log_n
             hx = x.cpu().numpy().view(np.uint64).reshape(-1, 4)
@@ -872,7 +923,7 @@ def run_rank(args) -> None:
                        "points_per_gpu": n, "total_points": n * world,
                        "sharding": "point-chunk per rank, all-gather of 96-byte partial sums, host fold" if world > 1 else "single GPU"},
             "dist_world_size": dist.get_world_size() if use_dist else 1,
-            "collective_backend": (dist.get_backend() if use_dist else None),
+            "collective_backend": (dist.get_backend() if use_dist else None), "host_cores": _host_cores(),
             "device_ids": dev_ids, "device_uuids": dev_uuids,
             # every rank's own view of the timed region: ms per step, of which its MSM and of which the exchange (the 96-byte
             # all-gather + the fold, including the wait for the slowest rank).  `ms_per_step` above is the maximum over ranks.

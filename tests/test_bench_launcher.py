@@ -14,6 +14,8 @@ import bn254_py as opy
 import oracle_c as oc
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
 
 def _run(args, env_extra=None, timeout=240):
@@ -38,6 +40,17 @@ def test_gpus_flag_spawns_that_many_ranks(world):
     pd = out["extra"]["proofs_per_device"]
     assert [p["rank"] for p in pd["per_rank"]] == list(range(world))
     assert pd["proofs_per_s_total"] == sum(100.0 * (r + 1) for r in range(world))
+    # what makes an N > 1 line gradeable: the CPU baseline is timed under world > 1 too (rank 0, the others wait at the barrier)
+    # and the issue roofline is priced for a per-GPU size other than 2^24 (instructions per mixed addition from the stamped
+    # counter file -- when that file was measured on other kernel sources the line must say so instead)
+    cb = out["cpu_baseline"]
+    assert cb is not None and cb["kind"] == "port" and cb["value"] > 0 and 1 <= cb["cores"] <= out["host_cores"]
+    alu = out["roofline"]["alu"]
+    import bench
+    if bench._load_counters("sq_counters.json")[0] is not None:
+        assert 0 < alu["frac_at_timed_clock"] < 1.1 and "2^24" in alu["valu_insts_measured_at"] and alu["mixed_adds_per_launch"] == 15 << 23
+    else:
+        assert "stale" in alu["sq_counters_note"] or "no counter file" in alu["sq_counters_note"]
 
 
 def test_a_failing_rank_fails_the_launcher():
