@@ -420,10 +420,6 @@ int uzk_circuit_release(uint64_t circuit);
 /* n, the evaluations round 4 writes per proof (15, or 19 for a shuffle circuit), the r_poly scalars round 5 reads per proof
  * (19 or 43) and the device the circuit lives on; every output optional (NULL). */
 int uzk_circuit_info(uint64_t circuit, uint32_t* n_out, uint32_t* evals_per_proof_out, uint32_t* r_scalars_per_proof_out, int* device_out);
-/* TEST / TIMING ONLY -- changes results.  Marks the circuit as synthetic (random polynomials no witness satisfies, the frozen
- * parity vectors and the timing chains): round 3 then takes t as its first 5 n - 2 + sum(hiding) coefficients, as
- * tests/chain_oracle.py does, and the unsatisfied-witness check is off.  Never set it on a real circuit. */
-int uzk_test_circuit_truncate_t(uint64_t circuit, int on);
 
 /* A prover = the device buffers of `batch` proofs over circuits of size n that advance in lockstep (a server with several
  * witnesses of one circuit waiting runs them as ONE sequence of wider launches -- commits of 8 x batch vectors, transforms of
@@ -436,7 +432,14 @@ int uzk_test_circuit_truncate_t(uint64_t circuit, int on);
  * library runs their calls as one lockstep launch sequence on a pooled workspace with its own stream and hands each caller its
  * own outputs -- bit for bit what the call alone would have returned (tests/test_gpu_coalesce.py).  No new API: each thread
  * keeps calling uzk_prove_round1..5 on its own prover, from any context.  A thread whose prover is the only idle one never
- * waits; see uzk_coalesce_config. */
+ * waits; see uzk_coalesce_config.
+ *
+ * Device memory: a lane (the buffers of one proof) takes about 150 x n x 32 bytes -- 79 MB at n = 2^14, 315 MB at 2^16, 5 GB at
+ * 2^20.  A prover of `batch` proofs holds `batch` lanes.  A shared prover holds one lane of its own (made on first need); the
+ * pooled workspaces hold max_lanes lanes each and at most `groups` of them exist per (n, device): 8 x 4 x 79 MB = 2.5 GB at
+ * n = 2^14 with the defaults.  Sharing only pays where one proof leaves the chip idle, so provers of n > UZK_SHARED_MAX_N
+ * (2^16) are never shared: they own their single lane as before -- the pool cannot grow past 8 x 4 x 315 MB = 10 GB. */
+#define UZK_SHARED_MAX_N (1u << 16)
 int uzk_prover_create(uint32_t n, uint32_t batch, uint64_t* prover_out);
 /* The same, but the prover owns its lanes whatever `batch` and the sharing configuration are: its proofs run on the calling
  * context's stream, alone, and uzk_prover_buffer can show its buffers (tests, diagnostics, latency measurements). */
@@ -523,21 +526,13 @@ int uzk_synth_scalars(void* d_scalars, size_t n, uint64_t seed);
  * 10 % r - 1, 10 % below 2^16, 10 % uniform. */
 int uzk_synth_scalars_mix(void* d_scalars, size_t n, uint64_t seed);
 
-/* ---- known-answer entry points (tests): the DEVICE primitives applied element-wise -------- */
-/* field: 0 = Fq, 1 = Fr.  op: 0 mul (assembly FIPS), 1 add, 2 sub, 3 mul (portable CIOS), 4 sqr,
- * 5 neg, 6 from_mont, 7 to_mont, 8 add (portable), 9 sub (portable); 10..23 exercise the 9 x 29-bit
- * limb representation of the hot loops (fp29.hpp): 10 mul, 11 add, 12/13 sub with 4M / 12M offsets,
- * 14 a lazy-carry chain, 15 form round trip, 16/17 squaring vs product of a lazy operand, 18/19 the
- * multi-subtrahend offsets of ec29.hpp, 20 the dual product, 21..23 the C++ forms of the
- * assembly products 10 / 16 / 20; 24 / 25 the constant-operand product (a * b as PLAIN integers mod M, b canonical; 25 with a lazy
- * first operand 2 (a + 4M)), 26 its companion constant floor(b 2^261 / M) mod 2^256, 27 the NTT's lazy reduction of a + b + 4M, raw
- * (value < 3M, congruent to a + b).  a, b, out: n elements (host memory). */
+/* ---- element-wise field arithmetic on host arrays (the host mirrors' helper) --------------- */
+/* The device's field primitives applied element-wise to host arrays: what the host-side mirrors use for format conversion and the
+ * few O(n) field operations they own (include/uzkge_poly_commit.hpp: the SRS blob's canonical coordinates -> Montgomery form,
+ * apply_blind_factors' negations).  field: 0 = Fq, 1 = Fr.  op: 0 mul, 1 add, 2 sub, 4 sqr, 5 neg, 6 from_mont, 7 to_mont
+ * (unary ops ignore b).  Any other op: UZK_ERR_PARAMETER -- the known-answer opcodes of the arithmetic cores live in
+ * include/uzkge_gpu_test.h (uzk_test_field_kat), outside the drop-in ABI. */
 int uzk_field_op_device(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
-/* op: 0 a + b (mixed add), 1 a + b (full XYZZ add), 2 2a, 3 a - b, 4 2(a + b); 5..7 the four-lane addition of the
- * small-MSM folds (ecquad.hpp): 5 a + b, 6 2(a + b) (its doubling branch), 7 (a + b) + (a - b); 8..10 the same three on the
- * 29-bit-limb form (ecquad29.hpp), 11 4(a + b) by two quad doublings, 12 2(a + b) by one, 13 4a.  Inputs affine
- * (infinity = zeros), outputs Jacobian. */
-int uzk_g1_op_device(int op, const uzk_g1_affine* a, const uzk_g1_affine* b, uzk_g1_jac* out, size_t n);
 
 /* ---- measurement ---------------------------------------------------------------------- */
 /* When enabled, every kernel launch is bracketed by hipEvents on the library stream. */

@@ -8,7 +8,7 @@
 //! has been touched a device failure is `Err(ProofError)`, never a panic (the reference builds with `panic = "abort"`).
 use std::cell::RefCell;
 use std::collections::HashMap;
-use std::sync::{Arc, Mutex};
+use std::sync::{Arc, Mutex, RwLock};
 
 use ark_bn254::{Fr, G1Projective};
 use ark_ec::CurveGroup;
@@ -54,7 +54,7 @@ lazy_static! {
     /// Keyed by what IDENTIFIES a circuit -- its verifier-key commitments (binding fingerprints of every selector and
     /// permutation polynomial, which the reference maintains anyway) and cs_size -- never by an address.  The public-key
     /// commitments are NOT part of the key: they change once per game and name the tables the circuit currently holds.
-    static ref CIRCUITS: Mutex<HashMap<Vec<u8>, Arc<Mutex<Resident>>>> = Mutex::new(HashMap::new());
+    static ref CIRCUITS: Mutex<HashMap<Vec<u8>, Arc<RwLock<Resident>>>> = Mutex::new(HashMap::new());
 }
 thread_local! {
     /// One context per prover thread (its own stream, workspaces and lock), created on first use and made the thread's current
@@ -116,7 +116,7 @@ fn coefs_of<F: PrimeField>(polys: &[&FpPolynomial<F>]) -> Option<Vec<Vec<Limbs>>
 /// The circuit of `p` on the device, built on first use; `refresh_prover_params_public_key` (shuffle/src/gen_params/params.rs:57-129)
 /// replaces the twelve public-key selector polynomials in place once per game: when the verifier key's
 /// `cm_shuffle_public_key_vec` no longer matches what the device holds, those twelve tables are replaced (copy on write).
-fn resident<PCS: PolyComScheme>(kzg: &[G1Projective], lagrange: &[G1Projective], p: &PlonkProverParams<PCS>, n: usize, root: &Limbs) -> Option<Arc<Mutex<Resident>>> {
+fn resident<PCS: PolyComScheme>(kzg: &[G1Projective], lagrange: &[G1Projective], p: &PlonkProverParams<PCS>, n: usize, root: &Limbs) -> Option<Arc<RwLock<Resident>>> {
     let vp = &p.verifier_params;
     let key = circuit_key(vp);
     if let Some(r) = CIRCUITS.lock().ok()?.get(&key) {
@@ -161,7 +161,7 @@ fn resident<PCS: PolyComScheme>(kzg: &[G1Projective], lagrange: &[G1Projective],
         }
     }
     let circuit = sys::Circuit::create(&d).ok()?; // no device, out of device memory, another root of unity: the CPU path
-    let r = Arc::new(Mutex::new(Resident { circuit, public_key: public_key_of(vp) }));
+    let r = Arc::new(RwLock::new(Resident { circuit, public_key: public_key_of(vp) }));
     let mut map = CIRCUITS.lock().ok()?;
     if map.len() >= 8 { map.clear(); } // a handful of circuits per process (one per deck size)
     Some(map.entry(key).or_insert(r).clone())
@@ -187,7 +187,7 @@ pub fn refresh_public_key<PCS: PolyComScheme>(
     }
     let entry = resident(kzg, lagrange, p, n, &limbs_of(&[*root])?[0])?;
     let flat: Vec<Limbs> = evals.iter().flat_map(|e| limbs_of(e).unwrap_or_default()).collect();
-    let mut r = entry.lock().ok()?;
+    let mut r = entry.write().ok()?; // exclusive: no proof takes its snapshot of the tables while they are replaced
     let (polys, lens, coset, cms) = r.circuit.refresh_tables(sys::UZK_CS_QPK as u32, &flat, n, true).ok()?;
     let cms: Vec<PCS::Commitment> = cms.iter().map(|j| PCS::commitment_from_g1(jac_from_wire(j))).collect::<Option<_>>()?;
     r.public_key = bytes_of(&cms);
@@ -312,7 +312,7 @@ fn prove_lanes<R: CryptoRng + RngCore, PCS: PolyComScheme, CS: ConstraintSystem<
 #[allow(clippy::too_many_arguments)]
 fn rounds<R: CryptoRng + RngCore, PCS: PolyComScheme, CS: ConstraintSystem<PCS::Field>>(
     prngs: &mut [&mut R], transcripts: &mut [&mut Transcript], css: &[&CS], prover_params: &PlonkProverParams<PCS>, domain: &Radix2EvaluationDomain<PCS::Field>,
-    online_values: &[&[PCS::Field]], entry: &Arc<Mutex<Resident>>, prover: &sys::Prover, extended_witness: &[Limbs], hiding: &[u32],
+    online_values: &[&[PCS::Field]], entry: &Arc<RwLock<Resident>>, prover: &sys::Prover, extended_witness: &[Limbs], hiding: &[u32],
 ) -> Result<Vec<PlonkProof<PCS>>, UzkgeError> {
     let dev = |_: sys::Error| UzkgeError::ProofError;
     let wrap = |j: &sys::uzk_g1_jac| PCS::commitment_from_g1(jac_from_wire(j)).ok_or(UzkgeError::ProofError);
@@ -339,20 +339,30 @@ fn rounds<R: CryptoRng + RngCore, PCS: PolyComScheme, CS: ConstraintSystem<PCS::
         if ov.len() != pi_index.len() { return Err(UzkgeError::ProofError); }
         pi_value.extend(limbs_of(ov).ok_or(UzkgeError::ProofError)?);
     }
-    let cms = {
-        // the public-key tables are checked against the verifier key and the circuit's tables taken under ONE lock: a refresh
-        // on another thread cannot slip between the two; from round 1 on these proofs own a snapshot of the tables
-        let mut r = entry.lock().map_err(|_| UzkgeError::ProofError)?;
-        let public_key = public_key_of(vp);
+    // The public-key tables are checked against the verifier key and the circuit's tables taken by round 1 under ONE guard: a
+    // refresh on another thread cannot slip between the two; from round 1 on these proofs own a snapshot of the tables.  The guard
+    // is SHARED (RwLock read): round 1 is where provers of other threads join this one's cohort (coalesce_core.hpp `enter`), so
+    // every thread proving over this circuit must be able to stand in round 1 at the same time -- an exclusive lock here would make
+    // every cohort one lane wide and have its holder wait out the gathering time for team-mates that are blocked on the lock.
+    // Only replacing the tables (here on a mismatch, and `refresh_public_key`) takes the lock exclusively.
+    let public_key = public_key_of(vp);
+    let cms = loop {
+        {
+            let r = entry.read().map_err(|_| UzkgeError::ProofError)?;
+            if r.public_key == public_key {
+                break prover.round1(&r.circuit, extended_witness, &wsel, &pi_index, &pi_value, hiding, &blinds).map_err(dev)?;
+            }
+        }
+        let mut r = entry.write().map_err(|_| UzkgeError::ProofError)?;
         if r.public_key != public_key {
             #[cfg(feature = "shuffle")]
             {
                 let polys: Vec<&FpPolynomial<PCS::Field>> = prover_params.q_shuffle_public_key_polys.iter().collect();
                 r.circuit.update_tables(sys::UZK_CS_QPK as u32, &coefs_of(&polys).ok_or(UzkgeError::ProofError)?).map_err(dev)?;
             }
-            r.public_key = public_key;
+            r.public_key = public_key.clone();
         }
-        prover.round1(&r.circuit, extended_witness, &wsel, &pi_index, &pi_value, hiding, &blinds).map_err(dev)?
+        // the write guard drops here; the loop takes the shared guard again and re-checks (std's RwLock cannot downgrade)
     };
     let mut cm_w_vecs: Vec<Vec<PCS::Commitment>> = Vec::with_capacity(lanes);
     #[cfg(feature = "shuffle")]

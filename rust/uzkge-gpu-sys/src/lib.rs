@@ -255,7 +255,7 @@ impl Drop for Circuit {
 
 /// How provers of ONE proof made from now on are shared between threads (`uzk_coalesce_config`): the library runs round calls of
 /// several threads that stand at the same round of proofs over the same circuit as one lockstep launch sequence.  On by default
-/// (at most 8 proofs per sequence, the provers at work spread over 4 sequences, 500 us gathering wait; 0 = a default);
+/// (at most 8 proofs per sequence, the provers at work spread over 4 sequences, 2000 us gathering wait -- include/uzkge_gpu.h; 0 = a default);
 /// `max_lanes` <= 1 switches it off.
 pub fn coalesce_config(max_lanes: u32, gather_wait_us: u32, straggler_wait_us: u32, groups: u32) -> Result<(), Error> {
     check(unsafe { uzk_coalesce_config(max_lanes, gather_wait_us, straggler_wait_us, groups) })

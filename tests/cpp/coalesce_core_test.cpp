@@ -74,7 +74,69 @@ using Core = uzk::CoalesceCore<Fake>;
 
 }  // namespace
 
+// `coalesce_core_test policy`: the scheduling statements the GPU suite used to make with wall-clock bounds on a foreign host
+// (VERDICT r5), made here against the stub backend and as ORDER of events wherever possible:
+//   1. a prover that is alone never waits for company, however long the gathering wait is;
+//   2. two provers: the cohort leaves the moment it is full (no gathering wait is sat out);
+//   3. one of them stays away between rounds 2 and 3: the other's round 3 returns BEFORE the dawdler comes back (it was moved
+//      out after straggler_wait), the shared rounds were two wide, exactly one lane was moved out, both proofs are right.
+static int policy() {
+    using Ms = std::chrono::milliseconds;
+    Fake backend;
+    Core core(backend, kRounds);
+    core.configure(2, 5000000, 20000, 1);                       // gather for up to 5 s, wait 20 ms for a straggler, one team
+    Core::Key key; key.group = 1; key.blob = "circuit";
+    int bad = 0;
+    auto prove_round = [&](Core::Member& m, int r, uint64_t in, uint64_t* got) {
+        Arg a{in, got, false};
+        std::string msg;
+        return core.enter(&m, r, r == 1 ? &key : nullptr, &a, &msg);
+    };
+    {   // 1.
+        Core::Member m; m.group = 1; core.add(&m);
+        const auto t0 = std::chrono::steady_clock::now();
+        uint64_t got = 0, expect = 0;
+        for (int r = 1; r <= kRounds; ++r) { if (prove_round(m, r, 100 + r, &got) != 0) ++bad; expect = mix(r == 1 ? 0 : expect, 100 + r); }
+        if (got != expect) ++bad;
+        if (std::chrono::steady_clock::now() - t0 > Ms(2500)) { std::printf("policy 1: a lone prover waited\n"); ++bad; }      // half the gathering wait
+        if (core.stats().widest != 1) ++bad;
+        if (!core.remove(&m)) ++bad;
+    }
+    core.reset_stats();
+    {   // 2. and 3.
+        Core::Member m[2]; for (auto& x : m) { x.group = 1; core.add(&x); }
+        std::atomic<int> dawdler_back{0}, on_time_round3_done_before_dawdler{0}, errs{0};
+        std::atomic<int> at_start{0};
+        auto worker = [&](int t) {
+            uint64_t got = 0, expect = 0;
+            at_start.fetch_add(1);
+            while (at_start.load() < 2) std::this_thread::yield();
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int r = 1; r <= kRounds; ++r) {
+                if (t == 1 && r == 3) { std::this_thread::sleep_for(Ms(1500)); dawdler_back.store(1); }
+                const uint64_t in = 1000 * (t + 1) + r;
+                if (prove_round(m[t], r, in, &got) != 0) errs++;
+                expect = mix(r == 1 ? 0 : expect, in);
+                if (got != expect) errs++;
+                if (r == 1 && std::chrono::steady_clock::now() - t0 > Ms(2500)) { std::printf("policy 2: a full cohort sat out the gathering wait\n"); errs++; }
+                if (t == 0 && r == 3 && !dawdler_back.load()) on_time_round3_done_before_dawdler.store(1);
+            }
+        };
+        std::thread a(worker, 0), b(worker, 1);
+        a.join(); b.join();
+        const Core::Stats st = core.stats();
+        if (errs.load()) { std::printf("policy 2/3: %d wrong proofs or late rounds\n", errs.load()); ++bad; }
+        if (!on_time_round3_done_before_dawdler.load()) { std::printf("policy 3: the prover that was on time waited for the dawdler\n"); ++bad; }
+        if (st.widest != 2 || st.moved_out != 1) { std::printf("policy 3: widest %llu moved_out %llu\n", (unsigned long long)st.widest, (unsigned long long)st.moved_out); ++bad; }
+        for (auto& x : m) if (!core.remove(&x)) ++bad;
+    }
+    if (backend.opened.load() != backend.closed.load()) ++bad;
+    std::printf("{\"policy\": true, \"bad\": %d}\n%s\n", bad, bad ? "FAILED" : "OK");
+    return bad ? 1 : 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && std::string(argv[1]) == "policy") return policy();
     const int threads = argc > 1 ? std::atoi(argv[1]) : 12;
     const int proofs = argc > 2 ? std::atoi(argv[2]) : 300;
     const int max_lanes = argc > 3 ? std::atoi(argv[3]) : 4;

@@ -44,11 +44,13 @@
 #include <cstring>
 #include <fstream>
 #include <string>
+#include <shared_mutex>
 #include <thread>
 #include <utility>
 #include <vector>
 
 #include "../../include/uzkge_gpu.h"
+#include "../../include/uzkge_gpu_test.h"      // uzk_test_circuit_truncate_t: the synthetic circuits of the timing chains
 
 #define CK(x) do { int rc_ = (x); if (rc_ != UZK_OK) { std::fprintf(stderr, "%s -> %d: %s\n", #x, rc_, uzk_last_error()); std::exit(1); } } while (0)
 
@@ -183,6 +185,8 @@ static void digest_of(const Inputs& in, uint32_t B, const std::vector<uzk_g1_jac
 
 // A prover of B proofs and their inputs laid out as the round calls take them ([B][...]); the witness also in pinned host
 // memory and, optionally, resident in HBM.
+static std::shared_mutex& tables_guard() { static std::shared_mutex m; return m; }
+
 struct Bench {
     const Inputs& in;
     uint32_t B;
@@ -223,8 +227,13 @@ struct Bench {
     void chain(int source, void (*after_round3)(Bench&) = nullptr, void (*after_round5)(Bench&) = nullptr) {
         const size_t n = in.n;
         const Fr* w = source == 1 ? d_wit : h_wit;
-        CK(uzk_prove_round1(prover, circuit, w, w + B * 5 * n, source == 1, in.pi_index.data(), pi_value.empty() ? nullptr : pi_value[0].l, (uint32_t)in.pi_index.size(),
-                            in.hiding, blinds8[0].l, cm1.data()));
+        {
+            // the glue's guard (rust/uzkge-glue/gpu_prover.rs `rounds`): round 1 runs under the SHARED side of the lock that protects the
+            // circuit's public-key tables, so that every thread can stand in round 1 -- where cohorts form -- at the same time
+            std::shared_lock<std::shared_mutex> tables(tables_guard());
+            CK(uzk_prove_round1(prover, circuit, w, w + B * 5 * n, source == 1, in.pi_index.data(), pi_value.empty() ? nullptr : pi_value[0].l, (uint32_t)in.pi_index.size(),
+                                in.hiding, blinds8[0].l, cm1.data()));
+        }
         CK(uzk_prove_round2(prover, beta[0].l, gamma[0].l, blinds_z[0].l, cm_z.data()));
         CK(uzk_prove_round3(prover, alpha[0].l, t_rands[0].l, cm_t.data()));
         if (after_round3) after_round3(*this);

@@ -19,7 +19,7 @@ def _source_hash() -> str:
     files = []
     for pat in ("*.hip", "*.cpp", "*.hpp", "*.inc"):
         files += [os.path.basename(f) for f in glob.glob(os.path.join(CSRC, pat))]
-    files += ["Makefile", "../../include/uzkge_gpu.h"]
+    files += ["Makefile", "../../include/uzkge_gpu.h", "../../include/uzkge_gpu_test.h"]
     h = hashlib.sha256()
     for f in sorted(set(files)):                 # GNU make's $(sort ...): plain byte order, duplicates removed
         h.update(open(os.path.join(CSRC, f), "rb").read())

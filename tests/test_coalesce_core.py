@@ -34,6 +34,14 @@ def test_every_caller_gets_its_own_proof(tmp_path, threads, proofs, lanes):
     assert res["moved_out"] > 0 and res["failed_on_purpose"] > 0 and res["abandoned"] > 0      # every path was taken
 
 
+def test_scheduling_policy_with_a_stub_backend(tmp_path):
+    """What the GPU suite used to assert with wall-clock bounds on a foreign host: a lone prover never waits, a full cohort leaves
+    at once, a caller that stays away is moved out after straggler_wait and the one on time finishes its round before the dawdler
+    is back (order of events), two-wide rounds, exactly one lane moved out, both proofs right."""
+    r = subprocess.run([_build(tmp_path, []), "policy"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+
+
 def test_no_data_race_under_thread_sanitizer(tmp_path):
     r, res = _run(_build(tmp_path, ["-fsanitize=thread"]), (8, 120, 4), 600)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr

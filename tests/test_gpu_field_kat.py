@@ -165,3 +165,11 @@ def test_constant_operand_product(gpu, field):
     ys = [rng.randrange(1 << 256) for _ in range(300)] + [(1 << 256) - 1, 0, 5 * mod, mod, mod - 1, (1 << 256) - 1, 1, 2 * mod + 1]
     got = from_wire(gpu.field_op(field, 27, a, to_wire(ys)))
     assert all(g < 3 * mod and (g - x - y) % mod == 0 for g, x, y in zip(got, xs, ys))
+
+
+@pytest.mark.parametrize("field", ["fq", "fr"])
+def test_the_product_entry_point_runs_the_same_primitives(gpu, field):
+    """uzk_field_op_device (include/uzkge_gpu.h: the host mirrors' seven plain operations) against the test hook of the same opcode."""
+    a, b = rand_fr_wire(64, 5), rand_fr_wire(64, 6)          # < 2^252: valid words of either field
+    for op in (0, 1, 2, 4, 5, 6, 7):
+        assert np.array_equal(gpu.field_elementwise(field, op, a, b), gpu.field_op(field, op, a, b)), op

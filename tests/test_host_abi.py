@@ -1,8 +1,10 @@
 """CPU-side checks of the product: the C-ABI library loads, exports every symbol
 include/uzkge_gpu.h declares, its host-only entry points (domain queries, fold, to_affine)
 agree with the oracle, and compute entry points fail loudly without a GPU."""
+import ctypes
 import os
 import re
+import subprocess
 
 import numpy as np
 import pytest
@@ -14,15 +16,37 @@ from util import load_srs
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _declared(header):
+    hdr = open(os.path.join(ROOT, "include", header)).read()
+    hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)
+    return set(re.findall(r"\b(uzk_[a-z0-9_]+)\s*\(", hdr)) - {"uzk_g1_affine", "uzk_g1_jac"}
+
+
 def test_every_declared_symbol_is_exported_and_bound():
+    """include/uzkge_gpu.h (the drop-in ABI) and include/uzkge_gpu_test.h (test hooks, outside it) against the library's dynamic
+    symbol table: every declared function is exported, every exported uzk_* function is declared in exactly one of the two."""
     from uzkge_amd import _native as N
-    hdr = open(os.path.join(ROOT, "include", "uzkge_gpu.h")).read()
-    declared = set(re.findall(r"\b(uzk_[a-z0-9_]+)\s*\(", hdr))
-    declared -= {"uzk_g1_affine", "uzk_g1_jac"}
-    assert declared, "header parse failed"
-    for name in sorted(declared):
-        assert hasattr(N.lib, name), f"{name} declared in include/uzkge_gpu.h but not exported"
+    declared, hooks = _declared("uzkge_gpu.h"), _declared("uzkge_gpu_test.h")
+    assert declared and hooks and not (declared & hooks), "header parse failed"
+    for name in sorted(declared | hooks):
+        assert hasattr(N.lib, name), f"{name} is declared in include/ but not exported"
     assert declared == set(N.PROTOTYPES), (declared ^ set(N.PROTOTYPES))
+    assert hooks == set(N.TEST_PROTOTYPES) and all(h.startswith("uzk_test_") for h in hooks), hooks
+    assert not any(n.startswith("uzk_test_") for n in declared)
+    nm = subprocess.run(["nm", "-D", "--defined-only", N.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in nm.splitlines() if ln.split()[-1].startswith("uzk_") and " T " in ln}
+    assert exported == declared | hooks, exported ^ (declared | hooks)
+
+
+def test_the_product_field_entry_point_refuses_the_kat_opcodes():
+    """uzk_field_op_device is what the host mirrors use (format conversion, a few O(n) field operations): seven plain operations.
+    The known-answer opcodes of the arithmetic cores are test hooks (uzk_test_field_kat) -- not reachable through the product ABI.
+    (Argument checks come before the device is touched, so this runs without a GPU.)"""
+    from uzkge_amd import _native as N
+    a = np.zeros((1, 4), dtype=np.uint64)
+    P = lambda x: x.ctypes.data_as(ctypes.c_void_p)
+    for op in (3, 8, 9, 10, 20, 24, 27, 28, -1):
+        assert N.lib.uzk_field_op_device(1, op, P(a), P(a), P(a), 1) == N.UZK_ERR_PARAMETER, op
 
 
 def test_domain_queries_match_oracle():

@@ -33,7 +33,7 @@ def test_every_header_symbol_is_bound_with_the_same_arity():
         n_r = 0 if not bound[name].strip() else bound[name].count(",") + 1
         assert n_c == n_r, name
     from uzkge_amd import _native as N
-    assert set(bound) == set(N.PROTOTYPES)
+    assert set(bound) == set(N.PROTOTYPES) and not any(b.startswith("uzk_test_") for b in bound)     # test hooks are not bound
 
 
 def test_struct_layouts_match_the_header():
@@ -164,7 +164,7 @@ def test_every_prover_thread_gets_a_context_and_a_shared_prover():
 
 def test_circuit_identity_is_the_verifier_key_not_an_address():
     """VERDICT r3 / ADVICE r3: the resident circuit is found by its verifier-key commitments; the public-key commitments name the
-    tables it currently holds, and a mismatch replaces the twelve tables (under the lock that also covers round 1) before the
+    tables it currently holds, and a mismatch replaces the twelve tables (exclusive guard; round 1 re-checks under the shared one) before the
     proof starts -- `refresh_prover_params_public_key` swaps them in place once per game (shuffle/src/gen_params/params.rs:57-129)."""
     glue = _strip_rust_comments(open(os.path.join(RUST, "uzkge-glue", "gpu_prover.rs")).read())
     key_fn = glue[glue.index("fn circuit_key"):glue.index("fn public_key_of")]
@@ -173,10 +173,16 @@ def test_circuit_identity_is_the_verifier_key_not_an_address():
     assert "cm_shuffle_public_key_vec" not in key_fn and "cm_shuffle_public_key_vec" in glue[glue.index("fn public_key_of"):glue.index("fn coefs_of")]
     assert "as *const PlonkProverParams" not in glue and "as usize, n" not in glue          # no address in any key
     rounds = glue[glue.index("fn rounds<"):]
-    lock, check, update, r1 = (rounds.index(t) for t in ("entry.lock()", "r.public_key != public_key", "update_tables(sys::UZK_CS_QPK", "prover.round1("))
-    assert lock < check < update < r1 and "r.public_key = public_key" in rounds[update:r1]
+    # round 1 runs under the SHARED guard, after the check, in the same block (an exclusive lock across round 1 --
+    # the one place provers of other threads can join a cohort -- made every cohort built through the glue one lane wide);
+    # replacing the tables takes the exclusive guard, re-checks, and goes round the loop to the shared guard again
+    rd, check_eq, r1, wr, check_ne, update = (rounds.index(t) for t in ("entry.read()", "r.public_key == public_key", "prover.round1(", "entry.write()",
+                                                                       "r.public_key != public_key", "update_tables(sys::UZK_CS_QPK"))
+    assert rd < check_eq < r1 < wr < check_ne < update and "r.public_key = public_key" in rounds[update:update + 400]
+    assert "entry.lock()" not in glue and "let cms = loop {" in rounds
+    assert rounds[rd:r1].count("{") - rounds[rd:r1].count("}") >= 1           # round 1 is inside the block that holds the read guard
     refresh = glue[glue.index("pub fn refresh_public_key"):glue.index("pub fn release_circuits")]
-    assert "refresh_tables(sys::UZK_CS_QPK" in refresh and "r.public_key = bytes_of(&cms)" in refresh
+    assert "entry.write()" in refresh and "refresh_tables(sys::UZK_CS_QPK" in refresh and "r.public_key = bytes_of(&cms)" in refresh
     # no data-dependent panic where an error or the CPU path is available: no assert / expect / indexing-by-panic helpers
     assert not re.search(r"\bassert(_eq)?!|\.expect\(|panic!", glue)
     # the unwraps left are the reference's own "safe unwrap"s (prover.rs:197,213,243,301, helpers.rs:1045) and one Option known to be Some

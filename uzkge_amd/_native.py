@@ -87,7 +87,6 @@ PROTOTYPES = {
     "uzk_circuit_table": (_I, [_U64, ctypes.c_uint32, _I, ctypes.POINTER(_P), ctypes.POINTER(_U64)]),
     "uzk_circuit_release": (_I, [_U64]),
     "uzk_circuit_info": (_I, [_U64, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(_I)]),
-    "uzk_test_circuit_truncate_t": (_I, [_U64, _I]),
     "uzk_prover_create": (_I, [ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_U64)]),
     "uzk_prover_create_private": (_I, [ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_U64)]),
     "uzk_coalesce_config": (_I, [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]),
@@ -104,7 +103,6 @@ PROTOTYPES = {
     "uzk_synth_scalars": (_I, [_P, _SZ, _U64]),
     "uzk_synth_scalars_mix": (_I, [_P, _SZ, _U64]),
     "uzk_field_op_device": (_I, [_I, _I, _P, _P, _P, _SZ]),
-    "uzk_g1_op_device": (_I, [_I, _P, _P, _P, _SZ]),
     "uzk_profile_enable": (_I, [_I]),
     "uzk_profile_reset": (_I, []),
     "uzk_profile_get": (_I, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_U64)]),
@@ -114,6 +112,15 @@ PROTOTYPES = {
     "uzk_msm_set_window_bits": (_I, [_I]),
     "uzk_msm_plan_info": (_I, [ctypes.c_size_t, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "uzk_tune": (_I, [ctypes.c_char_p, _I]),
+}
+
+
+# include/uzkge_gpu_test.h: test hooks exported by the same library (known-answer entry points of the arithmetic cores, the
+# synthetic-circuit switch).  Not part of the drop-in ABI; bound here for tests/ and tools/ only.
+TEST_PROTOTYPES = {
+    "uzk_test_field_kat": (_I, [_I, _I, _P, _P, _P, _SZ]),
+    "uzk_test_g1_kat": (_I, [_I, _P, _P, _P, _SZ]),
+    "uzk_test_circuit_truncate_t": (_I, [_U64, _I]),
 }
 
 
@@ -145,7 +152,7 @@ def load() -> ctypes.CDLL:
             "or `make -C uzkge_amd/csrc` (hipcc, gfx950). The MI355X backend has no fallback path."
         )
     lib = ctypes.CDLL(LIB_PATH)
-    for name, (res, args) in PROTOTYPES.items():
+    for name, (res, args) in list(PROTOTYPES.items()) + list(TEST_PROTOTYPES.items()):
         fn = getattr(lib, name)   # AttributeError here == header/library mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args

@@ -384,7 +384,16 @@ def synth_scalars_mix(d_scalars: int, n: int, seed: int) -> None:
 
 
 def field_op(field: str, op: int, a: np.ndarray, b: np.ndarray) -> np.ndarray:
-    """Device field primitive applied element-wise (KATs).  field: 'fq' | 'fr'."""
+    """Device field primitive applied element-wise (KATs: include/uzkge_gpu_test.h, every opcode).  field: 'fq' | 'fr'."""
+    x = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+    y = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 4)
+    out = np.zeros_like(x)
+    check(lib.uzk_test_field_kat(0 if field == "fq" else 1, op, _ptr(x), _ptr(y), _ptr(out), x.shape[0]))
+    return out
+
+
+def field_elementwise(field: str, op: int, a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """uzk_field_op_device, the PRODUCT entry point: mul 0, add 1, sub 2, sqr 4, neg 5, from_mont 6, to_mont 7 on host arrays."""
     x = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
     y = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 4)
     out = np.zeros_like(x)
@@ -396,7 +405,7 @@ def g1_op(op: int, a: np.ndarray, b: np.ndarray) -> np.ndarray:
     x = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 8)
     y = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 8)
     out = np.zeros((x.shape[0], 12), dtype=np.uint64)
-    check(lib.uzk_g1_op_device(op, _ptr(x), _ptr(y), _ptr(out), x.shape[0]))
+    check(lib.uzk_test_g1_kat(op, _ptr(x), _ptr(y), _ptr(out), x.shape[0]))
     return out
 
 

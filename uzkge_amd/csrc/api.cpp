@@ -1135,22 +1135,32 @@ int uzk_synth_scalars_mix(void* d_scalars, size_t n, uint64_t seed) try {
     return UZK_OK;
 } catch (...) { return uzk::on_exception("uzk_synth_scalars_mix"); }
 
-/* ---- known-answer entry points (device primitives on host arrays) ------------------------- */
+/* ---- element-wise field arithmetic on host arrays (product: the host mirrors' helper) ----------- */
 int uzk_field_op_device(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) try {
     API_LOCK;
     if (n > 0 && (!a || !b || !out)) { set_error("uzk_field_op_device: null pointer"); return UZK_ERR_PARAMETER; }
-    if (field < 0 || field > 1 || op < 0 || op > 27) { set_error("uzk_field_op_device: bad field/op"); return UZK_ERR_PARAMETER; }
+    const bool known = op == 0 || op == 1 || op == 2 || op == 4 || op == 5 || op == 6 || op == 7;
+    if (field < 0 || field > 1 || !known) { set_error("uzk_field_op_device: bad field/op (mul, add, sub, sqr, neg, from_mont, to_mont)"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
     return field_op_device(ctx(), field, op, as_fp(a), as_fp(b), reinterpret_cast<Fp*>(out), n);
 } catch (...) { return uzk::on_exception("uzk_field_op_device"); }
-int uzk_g1_op_device(int op, const uzk_g1_affine* a, const uzk_g1_affine* b, uzk_g1_jac* out, size_t n) try {
+
+/* ---- test hooks (include/uzkge_gpu_test.h): known-answer entry points of the arithmetic cores ---- */
+int uzk_test_field_kat(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) try {
     API_LOCK;
-    if (n > 0 && (!a || !b || !out)) { set_error("uzk_g1_op_device: null pointer"); return UZK_ERR_PARAMETER; }
-    if (op < 0 || op > 13) { set_error("uzk_g1_op_device: bad op"); return UZK_ERR_PARAMETER; }
+    if (n > 0 && (!a || !b || !out)) { set_error("uzk_test_field_kat: null pointer"); return UZK_ERR_PARAMETER; }
+    if (field < 0 || field > 1 || op < 0 || op > 27) { set_error("uzk_test_field_kat: bad field/op"); return UZK_ERR_PARAMETER; }
+    UZK_TRY(require_ready());
+    return field_op_device(ctx(), field, op, as_fp(a), as_fp(b), reinterpret_cast<Fp*>(out), n);
+} catch (...) { return uzk::on_exception("uzk_test_field_kat"); }
+int uzk_test_g1_kat(int op, const uzk_g1_affine* a, const uzk_g1_affine* b, uzk_g1_jac* out, size_t n) try {
+    API_LOCK;
+    if (n > 0 && (!a || !b || !out)) { set_error("uzk_test_g1_kat: null pointer"); return UZK_ERR_PARAMETER; }
+    if (op < 0 || op > 13) { set_error("uzk_test_g1_kat: bad op"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
     return g1_op_device(ctx(), op, reinterpret_cast<const Affine*>(a), reinterpret_cast<const Affine*>(b),
                         reinterpret_cast<Jac*>(out), n);
-} catch (...) { return uzk::on_exception("uzk_g1_op_device"); }
+} catch (...) { return uzk::on_exception("uzk_test_g1_kat"); }
 
 /* ---- measurement -------------------------------------------------------------------------- */
 int uzk_profile_enable(int on) try {

@@ -147,7 +147,9 @@ struct Backend {
                     return UZK_OK;
                 }
         }
-        UZK_TRY(make_slot(n, cap, device, &cd.slot));
+        int rc = make_slot(n, cap, device, &cd.slot);
+        if (rc != UZK_OK && cap > lanes) rc = make_slot(n, lanes, device, &cd.slot);     // out of memory for the full width: just this cohort's
+        UZK_TRY(rc);
         cd.pooled = true;
         return UZK_OK;
     }
@@ -283,11 +285,16 @@ void coalesce_release_all() {
         std::lock_guard<std::mutex> lk(s.mu);
         ps.swap(s.provers);
     }
+    bool busy = false;
     for (auto& kv : ps) {
-        (void)s.core.remove(&kv.second->member);
-        destroy_shared(*kv.second);
+        if (s.core.remove(&kv.second->member)) { destroy_shared(*kv.second); continue; }
+        // inside a call on another thread: the core and possibly a live cohort still point at it -- it stays registered, under its
+        // handle, with its buffers, and the internal contexts its round is running on stay too
+        busy = true;
+        std::lock_guard<std::mutex> lk(s.mu);
+        s.provers[kv.first] = kv.second;
     }
-    s.backend.release_all();
+    if (!busy) s.backend.release_all();
 }
 
 }  // namespace uzk
@@ -331,7 +338,9 @@ int uzk_prover_create(uint32_t n, uint32_t batch, uint64_t* prover_out) try {
     bool shared;
     {
         std::lock_guard<std::mutex> lk(s.mu);
-        shared = s.enabled && batch == 1;
+        // large circuits fill the chip with one proof: sharing would only multiply their workspaces (150 n x 32 B per lane, x 8 lanes
+        // x 4 cohorts -- 160 GB at n = 2^20) for nothing; they own their lane
+        shared = s.enabled && batch == 1 && n <= UZK_SHARED_MAX_N;
     }
     if (!shared) return explicit_prover_create(n, batch, prover_out);
     int device;
@@ -366,12 +375,19 @@ int uzk_prover_create_private(uint32_t n, uint32_t batch, uint64_t* prover_out) 
 int uzk_prover_destroy(uint64_t prover) try {
     if (!is_shared(prover)) return explicit_prover_destroy(prover);
     State& s = st();
-    auto sp = find_shared(prover);
-    if (!sp) { set_error("uzk_prover_destroy: unknown prover %llu", (unsigned long long)prover); return UZK_ERR_PARAMETER; }
-    if (!s.core.remove(&sp->member)) { set_error("uzk_prover_destroy: the prover is inside a call on another thread"); return UZK_ERR_PARAMETER; }
+    // the handle leaves the table first, under the table's lock: of two threads destroying one handle only one finds it, and only
+    // that one goes on to the core and the buffers
+    std::shared_ptr<Shared1> sp;
     {
         std::lock_guard<std::mutex> lk(s.mu);
-        s.provers.erase(prover);
+        auto it = s.provers.find(prover);
+        if (it != s.provers.end()) { sp = it->second; s.provers.erase(it); }
+    }
+    if (!sp) { set_error("uzk_prover_destroy: unknown prover %llu", (unsigned long long)prover); return UZK_ERR_PARAMETER; }
+    if (!s.core.remove(&sp->member)) {
+        { std::lock_guard<std::mutex> lk(s.mu); s.provers[prover] = sp; }
+        set_error("uzk_prover_destroy: the prover is inside a call on another thread");
+        return UZK_ERR_PARAMETER;
     }
     destroy_shared(*sp);
     return UZK_OK;

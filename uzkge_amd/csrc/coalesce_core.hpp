@@ -144,7 +144,7 @@ public:
                 if (c->team == m->team && c->key == *key && c->lanes.size() < max_lanes_) { g = c; break; }
             // whoever joins brings its companions of the last proof a moment behind it: the cohort's time starts again (a cohort
             // that has been held open for the rest of its team would otherwise leave with the first of them)
-            if (g) g->deadline = std::max(g->deadline, now + gather_wait_);
+            if (g) { g->deadline = std::max(g->deadline, now + gather_wait_); g->cv.notify_all(); }      // (a waiter recomputes its timeout)
             if (!g) {
                 g = std::make_shared<Cohort>();
                 g->key = *key;
@@ -300,7 +300,14 @@ private:
         m->cohort.reset();
         m->round = 0;
         if (g->alive == 0 && !g->running) finish_cohort(g, lk);
-        else g->cv.notify_all();                 // the rest may be complete now: a waiter runs the round
+        else {
+            g->cv.notify_all();                  // the rest may be complete now: a waiter runs the round
+            wake_held(g.get());                  // a cohort held open for this one may no longer have a larger part to wait for
+        }
+    }
+    // a live cohort has lost a member without finishing: cohorts held open because of it (larger_part_under_way) look again
+    void wake_held(const Cohort* shrunk) {
+        for (auto& o : gathering_) if (o.get() != shrunk && o->held) o->cv.notify_all();
     }
 
     // Runs the cohort's next round on the calling thread.  eject: alive members that have not arrived are moved out first.
@@ -383,6 +390,7 @@ private:
         g->next_round = r + 1;
         g->running = false;
         if (g->alive == 0) finish_cohort(g, lk);
+        else if (g->alive < k) wake_held(g.get());       // lanes failed or were moved out
         g->cv.notify_all();
         if (!out_lanes.empty()) move_cv_.notify_all();
     }

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/uzkge_gpu.h"
+#include "../../include/uzkge_gpu_test.h"
 #include "ec.hpp"
 
 namespace uzk {
