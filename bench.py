@@ -362,6 +362,46 @@ def _cpu_baseline_msm(oc, hp, hs, threads: int, world: int):
                  "host_cores": _host_cores(), "seconds": round(cpu_s, 3)}
 
 
+def _cpu_baseline_proof(oc, np, threads: int, reps: int = 2) -> dict:
+    """One proof's MSMs and transforms (16 MSM of n = 2^14 points over the reference's Lagrange SRS, 10 iFFT(n) +
+    7 FFT(n), 10 FFT(6n) + 1 iFFT(6n)) through the C port on the host cores -- the part of `prover_with_lagrange` this backend replaces
+    call for call (about 78 % of the reference's modular multiplications).  A LOWER bound of a CPU prover's time: the
+    quotient evaluation, z_poly, the openings' divisions and the transcript are not in it.  Not arkworks."""
+    import bn254_py as opy
+    with open(os.path.join(ROOT, "tests", "golden", "lagrange-srs-16384.bin"), "rb") as f:
+        hp = oc.points_from_affine(opy.parse_srs_g1(f.read()))
+    n = hp.shape[0]
+    rng = np.random.default_rng(14)
+
+    def rand(m):
+        a = rng.integers(0, 1 << 63, size=(m, 4), dtype=np.uint64)
+        a[:, 3] &= np.uint64(0x0FFFFFFFFFFFFFFF)
+        return a
+    sc16 = [rand(n) for _ in range(16)]
+    vn = [rand(n) for _ in range(17)]
+    v6 = [rand(6 * n) for _ in range(11)]
+    best = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        for v in sc16:
+            oc.msm_pippenger(hp, v, 0, threads)
+        t_msm = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for i, v in enumerate(vn):
+            oc.ntt(v, inverse=i < 10, threads=threads)
+        for i, v in enumerate(v6):
+            oc.ntt(v, inverse=i == 10, threads=threads)
+        t_ntt = time.perf_counter() - t0
+        if best is None or t_msm + t_ntt < best[0] + best[1]:
+            best = (t_msm, t_ntt)
+    total = best[0] + best[1]
+    return {"value": round(total * 1e3, 2), "unit": "ms per proof (MSM + NTT part only)", "cores": threads, "kind": "port",
+            "covers": "MSM + NTT only (about 78 % of the reference's modular multiplications, SURVEY.md 3.5): a lower bound of a CPU proof",
+            "msm_ms": round(best[0] * 1e3, 2), "ntt_ms": round(best[1] * 1e3, 2), "proofs_per_s_upper_bound": round(1.0 / total, 2),
+            "sample": f"one proof's 16 MSM(2^14, reference Lagrange SRS, uniform scalars) + 17 NTT(2^14) + 11 NTT(6 x 2^14) through oracle/bn254_oracle.c, "
+                      f"best of {reps} passes; uniform scalars are the MSM's worst case (a real witness is mostly 0 / 1)"}
+
+
 def dry_run_rank(args, rank, world, dist, np) -> None:
     """--dry-run: the launcher, the rendezvous, the all-gather of 96-byte partials and the fold, with no GPU:
     rank r contributes (r + 1) * G (built with the host-side fold of the C ABI)."""
@@ -773,6 +813,48 @@ def run_rank(args) -> None:
         except Exception as e:
             extra["pcie_inclusive"] = {"error": str(e)}
 
+    # ---- the single-process sharded MSM of the C ABI (uzk_msm_g1_sharded: what ONE Rust process with several GPUs links) ----------
+    if solo:
+        try:
+            m22 = min(n, 1 << 22)
+            hp22 = pts[:m22].cpu().numpy().view(np.uint64).reshape(-1, 8)
+            hs22 = sc[:m22].cpu().numpy().view(np.uint64).reshape(-1, 4)
+            one22 = b.Srs.from_host(hp22)
+
+            def wall(fn, reps=5):
+                fn(); fn()
+                t = time.perf_counter()
+                for _ in range(reps):
+                    r = fn()
+                return (time.perf_counter() - t) / reps, r
+            # the same plan on both sides: a 2^22-point vector is streamed in point chunks by uzk_msm_g1, its 2^21-point halves are
+            # not (msm_stream_min_log) -- with streaming off everywhere the comparison is the sharding alone
+            b.tune("msm_stream_log", -1)
+            single_s, single_r = wall(lambda: b.msm(one22, hs22))
+            b.tune("msm_stream_log", 0)
+            single_streamed_s, _ = wall(lambda: b.msm(one22, hs22))
+            ent = {"what": "uzk_msm_g1_sharded at 2^22 points, host scalars (pageable), VIRTUAL shards -- every chunk on device 0, a context, a stream and a "
+                           "persistent host thread each, host fold of the 96-byte partials -- against uzk_msm_g1 over the same vector on one "
+                           "context; one GPU does all the work either way, so the difference is what the sharded form costs: per-chunk fixed "
+                           "work (bucket reduction, sort set-up), the threads' hand-over, the fold",
+                   "log_n": m22.bit_length() - 1, "single_ms": round(single_s * 1e3, 3), "single_streamed_ms": round(single_streamed_s * 1e3, 3)}
+            for chunks in (2, 8):
+                sh = b.ShardedSrs(hp22, [0] * chunks, -1)
+                try:
+                    sh_s, sh_r = wall(lambda: sh.msm(hs22))
+                    ent[f"shards_{chunks}_ms"] = round(sh_s * 1e3, 3)
+                    ent[f"shards_{chunks}_overhead"] = round(sh_s / single_s - 1.0, 4)
+                    ent[f"shards_{chunks}_same_commitment"] = bool(np.array_equal(b.g1_to_affine(sh_r), b.g1_to_affine(single_r)))
+                finally:
+                    sh.release()
+            one22.release()
+            extra["msm_sharded_c_abi"] = ent
+            del hp22, hs22
+        except Exception as e:
+            extra["msm_sharded_c_abi"] = {"error": str(e)[-300:]}
+        finally:
+            b.tune("msm_stream_log", 0)
+
     # ---- opt-in window-table mode and the real prover's call mix (rank 0, N = 1 only) ----------
     if solo:
         try:
@@ -908,6 +990,13 @@ def run_rank(args) -> None:
                 "sample": f"one full 2^{args.ntt_log_n} forward transform", "seconds": round(ntt_cpu_s, 3),
                 "gpu_matches_cpu": bool(np.array_equal(y.cpu().numpy().view(np.uint64).reshape(-1, 4), ref_ntt)),
             }
+
+        # ---- CPU baseline of the third metric (prove ms at n = 2^14): the MSM + NTT part of ONE proof on the C port -------------------
+        if isinstance(extra.get("prover_rounds_cpp"), dict) and "error" not in extra["prover_rounds_cpp"]:
+            try:
+                extra["prover_rounds_cpp"]["cpu_baseline"] = _cpu_baseline_proof(oc, np, cores)
+            except Exception as e:
+                extra["prover_rounds_cpp"]["cpu_baseline"] = {"error": str(e)[-300:]}
 
     if rank == 0:
         lg = n.bit_length() - 1 if n & (n - 1) == 0 else None

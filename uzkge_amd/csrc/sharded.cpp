@@ -4,7 +4,10 @@
 // per chunk, each uploading only its part of the scalars -- and folds the N 96-byte partial sums on the host (uzk_g1_fold's
 // arithmetic).  Nothing moves between devices.  The process-per-GPU form of the same split, with the partial sums exchanged by
 // RCCL, is uzkge_amd/sharded.py (bench.py --gpus N); this is the form a single Rust process links.
+#include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <functional>
 #include <map>
 #include <memory>
 #include <shared_mutex>
@@ -17,11 +20,57 @@
 namespace uzk {
 namespace {
 
+// One host thread per chunk, alive as long as the sharded SRS (round 6: a call used to create and join N - 1 std::threads -- 30 to
+// 60 us each on this host, every call, and a cold thread's first HIP call on a device pays that runtime's per-thread set-up again).
+// Calls on one handle from several threads queue per chunk: the chunk has ONE context (one stream, one set of workspaces) anyway.
+struct Worker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::function<void()>> jobs;
+    bool stop = false;
+    void post(std::function<void()> f) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!th.joinable()) th = std::thread([this] { loop(); });
+            jobs.push_back(std::move(f));
+        }
+        cv.notify_one();
+    }
+    void loop() {
+        for (;;) {
+            std::function<void()> f;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || !jobs.empty(); });
+                if (jobs.empty()) return;
+                f = std::move(jobs.front());
+                jobs.pop_front();
+            }
+            f();
+        }
+    }
+    void join() {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+    }
+};
 struct Chunk {
     int device = 0;
     size_t lo = 0, hi = 0;
     Ctx ctx;                       // internal: this chunk's stream and workspaces on its device
     uint64_t srs = 0;              // its bases in the process-wide registry (they live on `device`)
+    Worker worker;                 // runs this chunk's part of every call (chunk 0 runs on the caller's thread)
+};
+// counts the chunks of one call that are still out
+struct Latch {
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t left;
+    explicit Latch(size_t n) : left(n) {}
+    void done() { std::lock_guard<std::mutex> lk(mu); if (--left == 0) cv.notify_all(); }
+    void wait() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return left == 0; }); }
 };
 struct ShardedSrs {
     size_t n = 0;
@@ -42,6 +91,7 @@ constexpr uint64_t kShardedBit = 1ull << 61;
 void release(ShardedSrs& s) {
     std::unique_lock<std::shared_mutex> ul(s.use);
     for (auto& c : s.chunks) {
+        c->worker.join();          // (no call is in flight: the lock above is exclusive)
         if (c->srs) {
             CtxScope scope(&c->ctx);
             (void)uzk_srs_release(c->srs);
@@ -143,10 +193,10 @@ int uzk_msm_g1_sharded(uint64_t handle, const uint64_t* scalars_mont, size_t n, 
         rc[i] = uzk_msm_g1(c.srs, 0, scalars_mont + 4 * lo, hi - lo, &part[i]);
         if (rc[i] != UZK_OK) msg[i] = uzk_last_error();
     };
-    std::vector<std::thread> pool;
-    for (size_t i = 1; i < N; ++i) pool.emplace_back(work, i);
+    Latch out_standing(N - 1);
+    for (size_t i = 1; i < N; ++i) s->chunks[i]->worker.post([&, i] { work(i); out_standing.done(); });
     work(0);
-    for (auto& t : pool) t.join();
+    out_standing.wait();
     for (size_t i = 0; i < N; ++i)
         if (rc[i] != UZK_OK) { set_error("uzk_msm_g1_sharded: chunk %zu (device %d): %s", i, s->chunks[i]->device, msg[i].c_str()); return rc[i]; }
     if (partials_out) std::memcpy(partials_out, part.data(), N * sizeof(uzk_g1_jac));
