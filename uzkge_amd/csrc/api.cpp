@@ -337,7 +337,7 @@ static void copy_tuning(const Ctx& from, Ctx& to) {
     to.msm_window_bits = from.msm_window_bits;
     to.tune_no_precompute = from.tune_no_precompute; to.tune_ntt_tile = from.tune_ntt_tile; to.tune_ntt_two_pass = from.tune_ntt_two_pass; to.tune_small = from.tune_small;
     to.tune_chunk_log = from.tune_chunk_log; to.tune_stream_log = from.tune_stream_log; to.tune_stream_min_log = from.tune_stream_min_log;
-    to.tune_seg_sort = from.tune_seg_sort;
+    to.tune_seg_sort = from.tune_seg_sort; to.tune_arith29 = from.tune_arith29;
 }
 }  // namespace uzk
 int uzk_ctx_create(uint64_t* ctx_out) try {
@@ -1240,6 +1240,7 @@ int uzk_tune(const char* key, int value) try {
     else if (!std::strcmp(key, "msm_seg_sort")) c.tune_seg_sort = value;
     else if (!std::strcmp(key, "ntt_tile")) c.tune_ntt_tile = (value == 1024 || value == 2048) ? value : 0;
     else if (!std::strcmp(key, "ntt_two_pass")) c.tune_ntt_two_pass = value ? 1 : 0;
+    else if (!std::strcmp(key, "arith29")) c.tune_arith29 = value & 7;
     else { set_error("uzk_tune: unknown key %s", key); return UZK_ERR_PARAMETER; }
     return UZK_OK;
 } catch (...) { return uzk::on_exception("uzk_tune"); }

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <cstdio>
 #include <chrono>
 #include <map>
@@ -110,6 +111,14 @@ struct Ctx {
     int tune_chunk_log = 26;       // point-chunk size of one sort pass (tests lower it to reach the chunk loop at small n)
     int tune_stream_log = 0;       // log2 of the point chunk of a streamed host-scalar MSM (0 = 21); -1: never stream (upload, then one MSM)
     int tune_stream_min_log = 22;  // host-scalar MSMs of at least 2^this points are streamed (tests lower it)
+    // bit 0: the quotient kernel, bit 1: evaluations / linear combinations, bit 2: the bucket-side group additions of the MSM on the lazy
+    // 29-bit arithmetic (lz29.hpp) instead of 8 x 32-bit Montgomery words; same bytes either way.  Default: all on (UZK_ARITH29 in the
+    // environment changes the default of every context of the process: the A/B runs of tests/cpp/prover_rounds); uzk_tune("arith29", mask).
+    int tune_arith29 = default_arith29();
+    static int default_arith29() {
+        static const int v = [] { const char* e = std::getenv("UZK_ARITH29"); return e ? std::atoi(e) : 7; }();
+        return v;
+    }
     int tune_seg_sort = 1;         // 1: last pass of a packed two-pass sort = one workgroup per segment (msm_radix_segment_kernel); 0: the generic kernels; 10 + k: instantiation k whatever the size (tests)
     // poly.hip workspaces (grow-only)
     DevBuf poly_tmp, poly_tmp2, poly_io, zpoly_tmp, open_tmp, poly_args;

@@ -2127,7 +2127,9 @@ static int msm_group_phase1(Ctx& c, MsmGroup& g, const Affine* points, const Sca
         uint32_t* exc_list = m.exc.as<uint32_t>();
         hipLaunchKernelGGL(msm_accumulate29_kernel, grid, dim3(256), 0, st, points, sorted, desc, g.base_cur, g.part_cur,
                            g.Wd, exc_count, exc_list, direct_buckets);
-        hipLaunchKernelGGL(msm_accumulate_exc_kernel, grid, dim3(256), 0, st, points, sorted, desc, g.part_cur,
+        // (grid-stride over a list that is normally EMPTY: a launch of the accumulator's own grid was 66 us of idle workgroups per
+        // MSM in the prover's lockstep commits -- 3.3 % of a proof's kernel time, profiles/r05d_lockstep8_kernel_stats.csv)
+        hipLaunchKernelGGL(msm_accumulate_exc_kernel, dim3(std::min<unsigned>(grid.x, 128u)), dim3(256), 0, st, points, sorted, desc, g.part_cur,
                            exc_count, exc_list, direct_buckets);
     }
     UZK_HIP(hipGetLastError());

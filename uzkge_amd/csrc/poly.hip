@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "ctx.hpp"
+#include "lz29.hpp"
 #include "host_math.hpp"
 
 namespace uzk {
@@ -665,6 +666,114 @@ __device__ __forceinline__ Fp tq_part(const QuotientDev& a, const QuotientLane& 
     }
 }
 
+// The same four groups of terms on the 29-bit lazy-limb arithmetic (lz29.hpp; round 6): every loaded value enters the 2^261-form
+// by re-limbing alone (32 a = x 2^261), a product is 162 multiply-adds with no carry chain instead of 128 + 128 add-with-carry,
+// sums of two products share one reduction (mul2), additions and subtractions are nine independent 32-bit operations, and the
+// bounds every operation needs are checked by the compiler (the Lz<K, V> types).  Exact field arithmetic throughout: the
+// result is the same canonical element as tq_part's, bit for bit (tests/test_gpu_variants.py compares the two kernels).
+// Returns the group's sum normalized, value < kTqPartV * M.
+constexpr int kTqPartV = 160;
+template <int PART>
+__device__ __forceinline__ Lz<Fr29, 1, kTqPartV> tq_part29(const QuotientDev& a, const QuotientLane& l, uint64_t own, uint32_t point, uint32_t nxt) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using Z = LzOps<Fr29>;
+    auto L = [&](int slot) { return Z::ld(slot < 10 ? a.vec[slot][own + point] : a.vec[slot][point]); };
+    auto N = [&](int slot) { return Z::ld(a.vec[slot][own + nxt]); };          // own vectors at the next row
+    const auto one = Z::one();
+    if constexpr (PART == 0) {
+        const auto w0 = L(0), w1 = L(1), w2 = L(2), w3 = L(3), w4 = L(4);
+        const auto z = L(9), zn = N(9);
+        const auto w0w1 = Z::mul(w0, w1), w2w3 = Z::mul(w2, w3);
+        // term1: gate -- pairs of products under one reduction
+        const auto g1 = Z::mul2(L(10), w0, L(11), w1);
+        const auto g2 = Z::mul2(L(12), w2, L(13), w3);
+        const auto g3 = Z::mul2(L(14), w0w1, L(15), w2w3);
+        const auto nw4 = Z::sub(Z::zero(), w4);                                 // -w4 (+ 33 M), limbs < 4 * 2^29
+        const auto g4 = Z::mul2(L(17), Z::mul(Z::mul(w0w1, w2w3), w4), L(18), nw4);
+        const auto gate = Z::norm(Z::add(Z::add(Z::add(g1, g2), Z::add(g3, g4)), Z::add(L(16), L(8))));
+        // term2 - term3: permutation
+        const auto cq = L(30);
+        const auto gamma = Z::ld(l.gamma), beta = Z::ld(l.beta), ap1 = Z::ld(l.ap[1]);
+        auto t2 = Z::template relax<1, 8>(Z::mul(ap1, z));
+        auto t3 = Z::template relax<1, 8>(Z::mul(ap1, zn));
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const auto wg = Z::add(j == 0 ? w0 : j == 1 ? w1 : j == 2 ? w2 : j == 3 ? w3 : w4, gamma);
+            t2 = Z::template relax<1, 8>(Z::mul(t2, Z::add(wg, Z::mul(Z::ld(l.bk[j]), cq))));
+            t3 = Z::template relax<1, 8>(Z::mul(t3, Z::add(wg, Z::mul(beta, L(19 + j)))));
+        }
+        return Z::template relax<1, kTqPartV>(Z::norm(Z::add(gate, Z::sub(t2, t3))));
+    } else if constexpr (PART == 1) {
+        const auto w0 = L(0), w1 = L(1), w2 = L(2), w3 = L(3), w4 = L(4);
+        const auto w0n = N(0), w1n = N(1), w2n = N(2);
+        const auto z = L(9);
+        // term4: alpha^2 L1 (z - 1)
+        const auto t4 = Z::mul(Z::mul(Z::ld(l.ap[2]), L(24)), Z::sub(z, one));
+        // terms 5..7: qb * sum alpha^(2+i) w_i (w_i - 1)
+        const auto b1 = Z::mul(w1, Z::sub(w1, one)), b2 = Z::mul(w2, Z::sub(w2, one)), b3 = Z::mul(w3, Z::sub(w3, one));
+        const auto bs = Z::add(Z::mul2(Z::ld(l.ap[3]), b1, Z::ld(l.ap[4]), b2), Z::mul(Z::ld(l.ap[5]), b3));
+        const auto t57 = Z::mul(L(25), bs);
+        // terms 8..11: Anemoi round, all weighted by q_prk3 and subtracted
+        const auto prk1 = L(26), prk2 = L(27), prk3 = L(28), prk4 = L(29);
+        const auto g = Z::ld(a.g), g_inv = Z::ld(a.g_inv), g2p1 = Z::ld(a.g2p1);
+        const auto w3w0 = Z::add(w0, w3), w2w1 = Z::add(w1, w2);
+        const auto w3_2w0 = Z::add(w0, w3w0), w2_2w1 = Z::add(w1, w2w1);
+        auto pow5 = [](const auto& x) { const auto x2 = Z::sqr(x); return Z::mul(Z::sqr(x2), x); };
+        const auto tA = Z::norm(Z::add(Z::add(w3w0, Z::mul(g, w2w1)), prk3));
+        const auto dA = pow5(Z::norm(Z::sub(tA, w2n)));
+        const auto e8 = Z::norm(Z::sub(Z::add(dA, Z::mul(g, Z::sqr(tA))), Z::norm(Z::add(Z::add(w3_2w0, Z::mul(g, w2_2w1)), prk1))));
+        const auto e10 = Z::norm(Z::sub(Z::add(Z::add(dA, Z::mul(g, Z::sqr(w2n))), g_inv), w0n));
+        const auto tB = Z::norm(Z::add(Z::mul2(g, w3w0, g2p1, w2w1), prk4));
+        const auto dB = pow5(Z::norm(Z::sub(tB, w4)));
+        const auto e9 = Z::norm(Z::sub(Z::add(dB, Z::mul(g, Z::sqr(tB))), Z::norm(Z::add(Z::mul2(g, w3_2w0, g2p1, w2_2w1), prk2))));
+        const auto e11 = Z::norm(Z::sub(Z::add(Z::add(dB, Z::mul(g, Z::sqr(w4))), g_inv), w1n));
+        const auto s = Z::add(Z::mul2(Z::ld(l.ap[6]), e8, Z::ld(l.ap[7]), e9), Z::mul2(Z::ld(l.ap[8]), e10, Z::ld(l.ap[9]), e11));
+        return Z::template relax<1, kTqPartV>(Z::norm(Z::sub(Z::add(t4, t57), Z::mul(prk3, s))));
+    } else {
+        // the four selector weights of the curve-addition constraints, shared by terms 12..15
+        const auto ws0 = L(5), ws1 = L(6), ws2 = L(7), qecc = L(55);
+        const auto om0 = Z::norm(Z::sub(one, ws0)), om1 = Z::norm(Z::sub(one, ws1));
+        const auto sel0 = Z::norm(Z::sub(Z::add(Z::mul(om0, om1), qecc), one));
+        const auto sel1 = Z::mul(ws0, om1), sel2 = Z::mul(om0, ws1), sel3 = Z::mul(ws0, ws1);
+        const auto S = Z::norm(Z::add(Z::add(sel0, sel1), Z::add(sel2, sel3)));
+        const auto ws2S = Z::mul(ws2, S);
+        constexpr int V0 = PART == 2 ? 0 : 3;           // sums of sel_ab * {x, y, dxy}_ab: the public key's (slots 31..42) or the generator's (43..54)
+        auto sum4 = [&](int v) {
+            return Z::norm(Z::add(Z::mul2(sel0, L(31 + 4 * (V0 + v)), sel1, L(31 + 4 * (V0 + v) + 1)),
+                                  Z::mul2(sel2, L(31 + 4 * (V0 + v) + 2), sel3, L(31 + 4 * (V0 + v) + 3))));
+        };
+        const auto SX = sum4(0), SY = sum4(1), SD = sum4(2);
+        const auto ws2Y = Z::mul(ws2, SY);
+        if constexpr (PART == 2) {
+            const auto w0 = L(0), w1 = L(1), w0n = N(0), w1n = N(1);
+            const auto w01SD = Z::mul(Z::mul(w0, w1), SD);
+            // 12: ws2 w0n S + w0 w1 w0n SD - (ws2 w0 SY + w1 SX)
+            const auto t12 = Z::norm(Z::sub(Z::mul2(ws2S, w0n, w01SD, w0n), Z::mul2(ws2Y, w0, w1, SX)));
+            // 13: ws2 w1n S + a w0 SX - (ws2 w1 SY + w0 w1 w1n SD)
+            const auto t13 = Z::norm(Z::sub(Z::mul2(ws2S, w1n, Z::mul(Z::ld(a.ea), w0), SX), Z::mul2(ws2Y, w1, w01SD, w1n)));
+            return Z::template relax<1, kTqPartV>(Z::mul2(Z::ld(l.ap[10]), t12, Z::ld(l.ap[11]), t13));
+        } else {
+            const auto w2 = L(2), w3 = L(3), w4 = L(4), w2n = N(2);
+            const auto w23GD = Z::mul(Z::mul(w2, w3), SD);
+            // 14: ws2 w2n S + w2 w3 w2n GD - (ws2 w2 GY + w3 GX)
+            const auto t14 = Z::norm(Z::sub(Z::mul2(ws2S, w2n, w23GD, w2n), Z::mul2(ws2Y, w2, w3, SX)));
+            // 15: ws2 w4 S + a w2 GX - (ws2 w3 GY + w2 w3 w4 GD)
+            const auto t15 = Z::norm(Z::sub(Z::mul2(ws2S, w4, Z::mul(Z::ld(a.ea), w2), SX), Z::mul2(ws2Y, w3, w23GD, w4)));
+            const auto s1 = Z::mul2(Z::ld(l.ap[12]), t14, Z::ld(l.ap[13]), t15);
+            const auto omq = Z::norm(Z::sub(one, qecc));
+            // 16, 17: q_ecc ws (1 - ws) + (1 - q_ecc) ws ; 18: q_ecc (1 + ws2)(1 - ws2)
+            const auto u16 = Z::mul(ws0, Z::norm(Z::add(Z::mul(qecc, om0), omq)));
+            const auto u17 = Z::mul(ws1, Z::norm(Z::add(Z::mul(qecc, om1), omq)));
+            const auto u18 = Z::mul(qecc, Z::mul(Z::add(one, ws2), Z::norm(Z::sub(one, ws2))));
+            const auto s2 = Z::add(Z::mul2(Z::ld(l.ap[14]), u16, Z::ld(l.ap[15]), u17), Z::mul(Z::ld(l.ap[16]), u18));
+            return Z::template relax<1, kTqPartV>(Z::norm(Z::add(s1, s2)));
+        }
+    }
+#else
+    return Lz<Fr29, 1, kTqPartV>{};
+#endif
+}
+
 // SHUFFLE = false: the circuit has no shuffle / ECC selectors (uzkge built without the "shuffle" feature, e.g.
 // zmatchmaking): terms 12..18 of helpers.rs:437-655 do not exist and their 28 vectors are not read.
 template <bool SHUFFLE>
@@ -717,6 +826,77 @@ __global__ __launch_bounds__(64 * NPARTS) __attribute__((amdgpu_waves_per_eu(WPE
             if (cls == (uint32_t)i) zhi = a.zhi[i];
         out[(uint64_t)blockIdx.y * out_stride + point] = Fr::mul(acc, zhi);
     }
+}
+
+// The two kernels above on the lazy 29-bit arithmetic (tq_part29): same launch shapes, same outputs.
+template <bool SHUFFLE>
+__global__ __launch_bounds__(256) void t_quotient29_kernel(QuotientDev a, const QuotientLane* __restrict__ lanes, Fp* __restrict__ out, uint64_t out_stride) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using Z = LzOps<Fr29>;
+    const uint32_t point = blockIdx.x * blockDim.x + threadIdx.x;
+    if (point >= a.m) return;
+    const QuotientLane& l = lanes[blockIdx.y];
+    const uint64_t own = (uint64_t)blockIdx.y * a.own_stride;
+    uint32_t nxt = point + a.factor;
+    if (nxt >= a.m) nxt -= a.m;
+    const uint32_t cls = point % a.factor;
+    Fp zhi = a.zhi[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i)
+        if (cls == (uint32_t)i) zhi = a.zhi[i];
+    const auto s01 = Z::add(tq_part29<0>(a, l, own, point, nxt), tq_part29<1>(a, l, own, point, nxt));
+    if constexpr (SHUFFLE) {
+        const auto s = Z::add(s01, Z::add(tq_part29<2>(a, l, own, point, nxt), tq_part29<3>(a, l, own, point, nxt)));
+        out[(uint64_t)blockIdx.y * out_stride + point] = Z::canon(Z::mul(s, Z::ldp(zhi)));
+    } else {
+        out[(uint64_t)blockIdx.y * out_stride + point] = Z::canon(Z::mul(s01, Z::ldp(zhi)));
+    }
+#endif
+}
+template <int NPARTS, int WPE>
+__global__ __launch_bounds__(64 * NPARTS) __attribute__((amdgpu_waves_per_eu(WPE))) void t_quotient_split29_kernel(QuotientDev a, const QuotientLane* __restrict__ lanes,
+                                                                                                                    Fp* __restrict__ out, uint64_t out_stride) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using Z = LzOps<Fr29>;
+    __shared__ uint32_t part[NPARTS - 1][9][64];         // limb planes: lane-contiguous, no bank conflicts
+    const uint32_t lane = threadIdx.x & 63, which = threadIdx.x >> 6;
+    const uint32_t point = blockIdx.x * 64 + lane;
+    const bool live = point < a.m;
+    const QuotientLane& l = lanes[blockIdx.y];
+    const uint64_t own = (uint64_t)blockIdx.y * a.own_stride;
+    uint32_t nxt = point + a.factor;
+    if (nxt >= a.m) nxt -= a.m;
+    Lz<Fr29, 1, kTqPartV> acc = Z::template relax<1, kTqPartV>(Z::zero());
+    if (live) {
+        if (which == 0) acc = tq_part29<0>(a, l, own, point, nxt);
+        else if (which == 1) acc = tq_part29<1>(a, l, own, point, nxt);
+        else if (NPARTS > 2 && which == 2) acc = tq_part29<2>(a, l, own, point, nxt);
+        else if (NPARTS > 2) acc = tq_part29<3>(a, l, own, point, nxt);
+    }
+    if (which) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) part[which - 1][i][lane] = acc.v.l[i];
+    }
+    __syncthreads();
+    if (which == 0 && live) {
+        Lz<Fr29, NPARTS, NPARTS * kTqPartV> sum;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            uint32_t t = acc.v.l[i];
+#pragma unroll
+            for (int p = 0; p < NPARTS - 1; ++p) t += part[p][i][lane];
+            sum.v.l[i] = t;
+        }
+        // 1 / Z_H of this point's coset class, by selects (see t_quotient_split_kernel); it stays in plain 2^256-form, so the
+        // product of the 2^261-form sum with it is the quotient in the wire's 2^256-form
+        const uint32_t cls = point % a.factor;
+        Fp zhi = a.zhi[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i)
+            if (cls == (uint32_t)i) zhi = a.zhi[i];
+        out[(uint64_t)blockIdx.y * out_stride + point] = Z::canon(Z::mul(sum, Z::ldp(zhi)));
+    }
+#endif
 }
 
 struct QuotientArgsAbi {      // byte-for-byte uzk_quotient_args (include/uzkge_gpu.h): 8-byte aligned limbs
@@ -777,6 +957,14 @@ static int quotient_launch(Ctx& c, const QuotientDev& d, int shuffle_present, co
     // small domains (the prover's 6n = 98 304 points): the term groups on separate waves per 64 points; large ones fill the chip
     // with one lane per point
     const bool split = d.m <= (1u << 19);
+    if (c.tune_arith29 & 1) {           // the lazy 29-bit arithmetic (default); uzk_tune("arith29", 0): the 8 x 32-bit kernels below
+        if (shuffle_present && split) hipLaunchKernelGGL((t_quotient_split29_kernel<4, 3>), dim3((d.m + 63) / 64, lanes), dim3(256), 0, c.stream, d, d_lanes, d_out, out_stride);
+        else if (split) hipLaunchKernelGGL((t_quotient_split29_kernel<2, 3>), dim3((d.m + 63) / 64, lanes), dim3(128), 0, c.stream, d, d_lanes, d_out, out_stride);
+        else if (shuffle_present) hipLaunchKernelGGL(t_quotient29_kernel<true>, dim3((d.m + 255) / 256, lanes), dim3(256), 0, c.stream, d, d_lanes, d_out, out_stride);
+        else hipLaunchKernelGGL(t_quotient29_kernel<false>, dim3((d.m + 255) / 256, lanes), dim3(256), 0, c.stream, d, d_lanes, d_out, out_stride);
+        UZK_HIP(hipGetLastError());
+        return UZK_OK;
+    }
     if (shuffle_present && split) hipLaunchKernelGGL((t_quotient_split_kernel<4, 3>), dim3((d.m + 63) / 64, lanes), dim3(256), 0, c.stream, d, d_lanes, d_out, out_stride);
     else if (split) hipLaunchKernelGGL((t_quotient_split_kernel<2, 3>), dim3((d.m + 63) / 64, lanes), dim3(128), 0, c.stream, d, d_lanes, d_out, out_stride);
     else if (shuffle_present) hipLaunchKernelGGL(t_quotient_kernel<true>, dim3((d.m + 255) / 256, lanes), dim3(256), 0, c.stream, d, d_lanes, d_out, out_stride);
