@@ -21,8 +21,10 @@ extern "C" {
 int uzk_test_field_kat(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 /* op: 0 a + b (mixed add), 1 a + b (full XYZZ add), 2 2a, 3 a - b, 4 2(a + b); 5..7 the four-lane addition of the
  * small-MSM folds (ecquad.hpp): 5 a + b, 6 2(a + b) (its doubling branch), 7 (a + b) + (a - b); 8..10 the same three on the
- * 29-bit-limb form (ecquad29.hpp), 11 4(a + b) by two quad doublings, 12 2(a + b) by one, 13 4a.  Inputs affine
- * (infinity = zeros), outputs Jacobian. */
+ * 29-bit-limb form (ecquad29.hpp), 11 4(a + b) by two quad doublings, 12 2(a + b) by one, 13 4a; 14..17 the one-lane additions on
+ * the lazy 29-bit limbs with re-limbed operands (ec29l.hpp): 14 a + b, 15 2(a + b) (doubling branch), 16 (a + b) + (a - b),
+ * 17 ((a + b) - (a + b)) + a + (b + infinity) (cancellation, infinity on either side); 18..21 the same four by quads.
+ * Inputs affine (infinity = zeros), outputs Jacobian. */
 int uzk_test_g1_kat(int op, const uzk_g1_affine* a, const uzk_g1_affine* b, uzk_g1_jac* out, size_t n);
 
 /* ---- synthetic circuits ----

@@ -9,7 +9,7 @@ import torch
 
 import bn254_py as opy
 import oracle_c as oc
-from util import rand_fr_wire
+from util import affine_of, rand_fr_wire
 
 pytestmark = pytest.mark.gpu
 
@@ -76,3 +76,39 @@ def test_quotient_kernels_agree_and_match_the_oracle(both, n, edge, shuffle):
         got[mask] = out.cpu().numpy().view(np.uint64).reshape(m, 4)
     assert np.array_equal(got[7], got[0]), "29-bit lazy kernel and 8 x 32-bit kernel differ"
     assert np.array_equal(got[7], want), "quotient differs from the oracle"
+
+
+@pytest.mark.parametrize("log_n,batch,mix", [(14, 8, False), (14, 3, True), (12, 5, True), (16, 2, False)])
+def test_msm_bucket_side_kernels_agree(both, log_n, batch, mix):
+    """The bucket-side additions (class sums of the general pipeline, the quad folds of the small one) on the lazy 29-bit limbs against
+    the 8 x 32-bit words: the same commitments, with and without the window table, uniform and skewed scalars (skew makes deep
+    fold levels and all-equal buckets: the doubling and infinity branches)."""
+    gpu = both
+    n = 1 << log_n
+    pts = torch.empty((n, 8), dtype=torch.int64, device="cuda")
+    sc = torch.empty((batch * n, 4), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    gpu.synth_points_random(pts.data_ptr(), n, 31)
+    (gpu.synth_scalars_mix if mix else gpu.synth_scalars)(sc.data_ptr(), batch * n, 32)
+    if mix:
+        sc[n // 2: n // 2 + 64] = sc[0:1].expand(64, 4)          # one value 64 times in a row: equal buckets meet in the folds
+    srs = gpu.Srs.from_device(pts.data_ptr(), n)
+    try:
+        res = {}
+        for table in (0, 1):
+            if table:
+                srs.precompute(0)
+            for small in (1, 0):
+                gpu.tune("msm_small", small)
+                for mask in (7, 0):
+                    gpu.tune("arith29", mask)
+                    res[(table, small, mask)] = [affine_of(x) for x in gpu.msm_batch_device(srs, sc.data_ptr(), n, batch)]
+        ref = res[(0, 1, 0)]
+        for key, val in res.items():
+            assert val == ref, key
+        if log_n <= 12:      # anchor on the oracle
+            hp = pts.cpu().numpy().view(np.uint64); hs = sc[:n].cpu().numpy().view(np.uint64)
+            assert ref[0] == oc.jac_to_affine_ints(oc.msm_pippenger(hp, hs, 0, 8))
+    finally:
+        gpu.tune("msm_small", 1)
+        srs.release()

@@ -88,8 +88,14 @@ def test_group_ops_match_oracle(gpu):
     twice = gpu.g1_op(4, a, b)
     qadd, qtwice, qmix = gpu.g1_op(5, a, b), gpu.g1_op(6, a, b), gpu.g1_op(7, a, b)     # four-lane addition (ecquad.hpp)
     q29 = [gpu.g1_op(op, a, b) for op in (8, 9, 10, 11, 12, 13)]                                # ... on 29-bit limbs (ecquad29.hpp)
+    l29 = [gpu.g1_op(op, a, b) for op in range(14, 22)]        # the re-limbed operands and typed bounds of ec29l.hpp: one lane (14..17), quads (18..21)
     for i in range(n):
         s = opy.g1_add(pa[i], pb[i])
+        for base in (0, 4):
+            assert aff(l29[base][i]) == s, (base, i)
+            assert aff(l29[base + 1][i]) == opy.g1_add(s, s), (base, i)
+            assert aff(l29[base + 2][i]) == opy.g1_add(s, opy.g1_add(pa[i], opy.g1_neg(pb[i]))), (base, i)
+            assert aff(l29[base + 3][i]) == s, (base, i)                # ((a + b) - (a + b)) + a + (b + infinity)
         assert aff(qadd[i]) == s, i
         assert aff(qtwice[i]) == opy.g1_add(s, s), i
         assert aff(qmix[i]) == opy.g1_add(s, opy.g1_add(pa[i], opy.g1_neg(pb[i]))), i

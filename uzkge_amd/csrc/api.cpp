@@ -1156,7 +1156,7 @@ int uzk_test_field_kat(int field, int op, const uint64_t* a, const uint64_t* b, 
 int uzk_test_g1_kat(int op, const uzk_g1_affine* a, const uzk_g1_affine* b, uzk_g1_jac* out, size_t n) try {
     API_LOCK;
     if (n > 0 && (!a || !b || !out)) { set_error("uzk_test_g1_kat: null pointer"); return UZK_ERR_PARAMETER; }
-    if (op < 0 || op > 13) { set_error("uzk_test_g1_kat: bad op"); return UZK_ERR_PARAMETER; }
+    if (op < 0 || op > 21) { set_error("uzk_test_g1_kat: bad op"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
     return g1_op_device(ctx(), op, reinterpret_cast<const Affine*>(a), reinterpret_cast<const Affine*>(b),
                         reinterpret_cast<Jac*>(out), n);

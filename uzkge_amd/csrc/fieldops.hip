@@ -4,6 +4,7 @@
 #include "ctx.hpp"
 #include "ecquad.hpp"
 #include "ecquad29.hpp"
+#include "ec29l.hpp"
 #include "fp29.hpp"
 
 namespace uzk {
@@ -189,6 +190,64 @@ int field_op_device(Ctx& c, int field, int op, const Fp* a, const Fp* b, Fp* out
     return UZK_OK;
 }
 
+// ops 14..21: the additions of ec29l.hpp (lazy 29-bit limbs, operands re-limbed from the wire form, bounds in the types).
+// one lane per element: 14 a + b, 15 2(a + b) through the addition's doubling branch, 16 (a + b) + (a - b) (non-trivial ZZ on both
+// sides), 17 (a + b) - (a + b) = infinity (cancellation) ... then + a; four lanes per element: 18..21 the same four by quads.
+__global__ __launch_bounds__(256) void g1_p29_op_kernel(int op, const Affine* __restrict__ a, const Affine* __restrict__ b,
+                                                        Jac* __restrict__ out, size_t n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const bool quad = op >= 18;
+    const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t i = quad ? gt >> 2 : gt;
+    const uint32_t q = (uint32_t)(gt & 3);
+    if (i >= n) return;
+    const Affine p = a[i], r = b[i];
+    XYZZ s = xyzz_from_affine(p), t = xyzz_from_affine(r);
+    const int f = quad ? op - 18 : op - 14;
+    auto add = [&](P29& x, const P29& y) { if (quad) p29_add_quad(x, y, q); else p29_add(x, y); };
+    P29 acc;
+    if (f == 0) {
+        acc = p29_load(s);
+        add(acc, p29_load(t));
+    } else if (f == 1) {
+        xyzz_madd(s, r, false);
+        acc = p29_load(s);
+        const P29 same = acc;
+        add(acc, same);
+    } else if (f == 2) {
+        XYZZ u = s;
+        xyzz_madd(s, r, false);
+        xyzz_madd(u, r, true);
+        acc = p29_load(s);
+        add(acc, p29_load(u));
+    } else {
+        XYZZ u = s;
+        xyzz_madd(u, r, false);                          // a + b
+        XYZZ v = u;
+        v.y = Fq::neg(v.y);                              // -(a + b), same ZZ / ZZZ
+        acc = p29_load(u);
+        add(acc, p29_load(v));                           // infinity
+        add(acc, p29_load(s));                           // + a
+        P29 w = p29_load(t);
+        add(w, p29_inf());                               // b + infinity
+        add(acc, w);                                     // a + b
+    }
+    if (quad) {
+        const Fp c = p29_is_inf(acc) ? Fq::zero() : p29_coord_to_fp(acc, q);
+        __shared__ Fp sh[64][4];
+        sh[threadIdx.x >> 2][q] = c;
+        __syncthreads();
+        if (q == 0) {
+            XYZZ o;
+            o.x = sh[threadIdx.x >> 2][0]; o.y = sh[threadIdx.x >> 2][1]; o.zz = sh[threadIdx.x >> 2][2]; o.zzz = sh[threadIdx.x >> 2][3];
+            out[i] = xyzz_to_jac(o);
+        }
+    } else {
+        out[i] = xyzz_to_jac(p29_store(acc));
+    }
+#endif
+}
+
 int g1_op_device(Ctx& c, int op, const Affine* a, const Affine* b, Jac* out, size_t n) {
     if (n == 0) return UZK_OK;
     Affine *da = nullptr, *db = nullptr;
@@ -198,7 +257,9 @@ int g1_op_device(Ctx& c, int op, const Affine* a, const Affine* b, Jac* out, siz
     UZK_HIP(hipMalloc(reinterpret_cast<void**>(&dout), n * sizeof(Jac)));
     UZK_HIP(hipMemcpyAsync(da, a, n * sizeof(Affine), hipMemcpyHostToDevice, c.stream));
     UZK_HIP(hipMemcpyAsync(db, b, n * sizeof(Affine), hipMemcpyHostToDevice, c.stream));
-    if (op >= 8) hipLaunchKernelGGL(g1_quad29_op_kernel, dim3((unsigned)((4 * n + 255) / 256)), dim3(256), 0, c.stream, op, da, db, dout, n);
+    if (op >= 18) hipLaunchKernelGGL(g1_p29_op_kernel, dim3((unsigned)((4 * n + 255) / 256)), dim3(256), 0, c.stream, op, da, db, dout, n);
+    else if (op >= 14) hipLaunchKernelGGL(g1_p29_op_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, op, da, db, dout, n);
+    else if (op >= 8) hipLaunchKernelGGL(g1_quad29_op_kernel, dim3((unsigned)((4 * n + 255) / 256)), dim3(256), 0, c.stream, op, da, db, dout, n);
     else if (op >= 5) hipLaunchKernelGGL(g1_quad_op_kernel, dim3((unsigned)((4 * n + 255) / 256)), dim3(256), 0, c.stream, op, da, db, dout, n);
     else hipLaunchKernelGGL(g1_op_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, op, da, db, dout, n);
     hipError_t e = hipGetLastError();

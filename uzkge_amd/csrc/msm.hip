@@ -46,6 +46,7 @@
 #include "ec29.hpp"
 #include "ecquad.hpp"
 #include "ecquad29.hpp"
+#include "ec29l.hpp"
 #include "host_ec64.hpp"
 #include "host_math.hpp"
 
@@ -1178,7 +1179,7 @@ __global__ __launch_bounds__(256) void msm_fold_scan_kernel(const XYZZ* __restri
 // grid (tiles, logical windows, 2): z = 0 rows, z = 1 columns; a tile = 2048 buckets: 8 rows, or 2048 / H columns of all H
 // rows.  out: [window][2][nb2] with rows at index h - 1 (weight h; R_0 has weight 0 and is dropped) and columns at l.
 __global__ __launch_bounds__(256, 3) void msm_class_sums_kernel(const XYZZ* __restrict__ buckets, XYZZ* __restrict__ out, uint32_t nbk,
-                                                              uint32_t log_s, uint32_t nb2) {
+                                                              uint32_t log_s, uint32_t nb2, int arith29) {
     __shared__ XYZZ sh[256];
     const uint32_t tile = blockIdx.x, w = blockIdx.y, cols = blockIdx.z, t = threadIdx.x;
     const uint32_t Lc = 1u << log_s, H = nbk >> log_s;
@@ -1186,17 +1187,21 @@ __global__ __launch_bounds__(256, 3) void msm_class_sums_kernel(const XYZZ* __re
     XYZZ* ow = out + ((size_t)w * 2 + cols) * nb2;
     // G = partial sums per class inside the workgroup: a row is 2^s / 8 lanes, a column H / 8
     const uint32_t G = cols ? H / 8 : Lc / 8;
-    XYZZ acc = xyzz_inf();
-    if (!cols) {
-        const XYZZ* src = bw + (size_t)tile * 2048 + (size_t)t * 8;
+    // Every lane's eight additions -- nine tenths of the kernel's arithmetic -- on the lazy 29-bit limbs (ec29l.hpp: the buckets
+    // enter by re-limbing, the lane's sum leaves through one product per coordinate); `arith29` = 0: the 8 x 32-bit words.
+    const XYZZ* src = cols ? bw + (tile * (256 / G) + t / G) : bw + (size_t)tile * 2048 + (size_t)t * 8;
+    const size_t step = cols ? Lc : 1, first = cols ? (size_t)(t % G) * 8 * Lc : 0;
+    if (arith29) {
+        P29 acc = p29_inf();
 #pragma unroll 1
-        for (uint32_t k = 0; k < 8; ++k) { XYZZ q = src[k]; xyzz_add(acc, q); }
+        for (uint32_t k = 0; k < 8; ++k) { const P29 q = p29_load(src[first + k * step]); p29_add(acc, q); }
+        sh[t] = p29_store(acc);
     } else {
-        const uint32_t col = tile * (256 / G) + t / G, hg = t % G;
+        XYZZ acc = xyzz_inf();
 #pragma unroll 1
-        for (uint32_t k = 0; k < 8; ++k) { XYZZ q = bw[(size_t)(hg * 8 + k) * Lc + col]; xyzz_add(acc, q); }
+        for (uint32_t k = 0; k < 8; ++k) { XYZZ q = src[first + k * step]; xyzz_add(acc, q); }
+        sh[t] = acc;
     }
-    sh[t] = acc;
     __syncthreads();
     // fold groups of G consecutive partial sums, 4 (or 2) to one per step; lane j takes partial sums j*f .. j*f + f - 1
     // From 64 outputs per step on, a QUAD takes each output (ecquad.hpp): these steps are chains of dependent additions on a
@@ -1462,12 +1467,36 @@ __global__ __launch_bounds__(1024) void msm_small_sort_kernel(const uint32_t* __
 // 2.5x shorter dependent chains for 1.6x the work, for launches that cannot fill the chip anyway.
 template <bool QUAD, int GS>
 __global__ __launch_bounds__(256) void msm_small_fold_kernel(XYZZ* __restrict__ P, const SmallChunk* __restrict__ cdesc,
-                                                             const uint32_t* __restrict__ count, uint32_t out_base) {
+                                                             const uint32_t* __restrict__ count, uint32_t out_base, int arith29) {
     constexpr uint32_t LPL = QUAD ? 4 : 1;         // lanes per logical lane
     const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t group = gt / (LPL * GS), sub = (gt / LPL) % GS, q = gt & 3;
     if (group >= *count) return;               // whole groups leave together
     const SmallChunk cd = cdesc[group];
+    if constexpr (QUAD) {
+        if (arith29) {
+            // the quad additions on the lazy 29-bit limbs (ec29l.hpp): operands enter by re-limbing, the sums travel between lanes
+            // as 4 x 9 limbs, lane q of the quad turns coordinate q back into wire words at the end
+            P29 acc = p29_inf();
+            for (uint32_t k = sub; k < cd.cnt; k += GS) { const P29 v = p29_load(P[cd.first + k]); p29_add_quad(acc, v, q); }
+#pragma unroll
+            for (int o = GS / 2; o > 0; o >>= 1) {
+                P29 v;
+                const uint32_t* sp = reinterpret_cast<const uint32_t*>(&acc);
+                uint32_t* dp = reinterpret_cast<uint32_t*>(&v);
+#pragma unroll
+                for (int w = 0; w < 36; ++w) dp[w] = (uint32_t)__shfl_down((int)sp[w], (int)LPL * o);
+                if (sub + (uint32_t)o < (uint32_t)GS) p29_add_quad(acc, v, q);        // see fold_partials
+            }
+            if (sub == 0) {
+                // (every lane of the quad holds the same sum; infinity: all four coordinates zero)
+                const bool inf = p29_is_inf(acc);
+                const Fp cq = inf ? Fq::zero() : p29_coord_to_fp(acc, q);
+                reinterpret_cast<Fp*>(&P[out_base + group])[q] = cq;
+            }
+            return;
+        }
+    }
     XYZZ acc = xyzz_inf();
     for (uint32_t k = sub; k < cd.cnt; k += GS) {
         const XYZZ v = P[cd.first + k];
@@ -2239,7 +2268,7 @@ static int msm_group_phase2(Ctx& c, MsmGroup& g, bool accumulate = false, bool r
         const uint32_t RW2 = g.RW * 2;
         {
             KernelScope ks(c, "msm_reduce_class");
-            hipLaunchKernelGGL(msm_class_sums_kernel, dim3(g.NBL / 2048, g.RW, 2), dim3(256), 0, st, buckets, cls, g.NBL, g.class_s, g.nb2);
+            hipLaunchKernelGGL(msm_class_sums_kernel, dim3(g.NBL / 2048, g.RW, 2), dim3(256), 0, st, buckets, cls, g.NBL, g.class_s, g.nb2, (c.tune_arith29 >> 2) & 1);
         }
         {
             KernelScope ks(c, "msm_reduce");
@@ -2504,7 +2533,7 @@ static int msm_run_small(Ctx& c, const Affine* points, const ScalarView& d_scala
             const uint64_t lanes = cap[k] * (uint64_t)gs * (quad ? 4 : 1);
             const dim3 grid((unsigned)((lanes + 255) / 256));
             const SmallChunk* cd = cdesc + lv.dbase[k];
-#define UZK_FOLD(QD, G) hipLaunchKernelGGL((msm_small_fold_kernel<QD, G>), grid, dim3(256), 0, st, P, cd, counters + k, lv.pbase[k])
+#define UZK_FOLD(QD, G) hipLaunchKernelGGL((msm_small_fold_kernel<QD, G>), grid, dim3(256), 0, st, P, cd, counters + k, lv.pbase[k], (c.tune_arith29 >> 2) & 1)
             if (quad) { if (gs >= 8) UZK_FOLD(true, 8); else if (gs >= 4) UZK_FOLD(true, 4); else UZK_FOLD(true, 2); }
             else { if (gs >= 8) UZK_FOLD(false, 8); else if (gs >= 4) UZK_FOLD(false, 4); else if (gs >= 2) UZK_FOLD(false, 2); else UZK_FOLD(false, 1); }
 #undef UZK_FOLD
