@@ -35,8 +35,9 @@ __device__ __forceinline__ Acc29 acc29_inf() {
 }
 // affine point (canonical, 2^256-form; ZZ = ZZZ = 1) -> accumulator forms
 __device__ __forceinline__ void acc29_set(Acc29& a, const Fp& x, const Fp& y) {
-    a.x = Fq29::to_261(Fq29::from_fp(x));
-    a.y = Fq29::to_261(Fq29::from_fp(y));
+    // x 2^261 = 32 x_wire by re-limbing, then one reduction to < 2 M each: 2 x 65 instructions where two products by 2^266 took 410
+    a.x = Fq29::reduce(Fq29::from_fp_x32(x));
+    a.y = Fq29::reduce(Fq29::from_fp_x32(y));
     a.nzz = Fq29::constant(Fq29Cfg::NR266);
     a.z3 = Fq29::constant(Fq29Cfg::R266);
     a.inf = false;
@@ -83,10 +84,12 @@ __device__ __forceinline__ XYZZ acc29_to_xyzz(const Acc29& a) {
     using F = Fq29;
     if (a.inf) return xyzz_inf();
     XYZZ r;
-    r.x = F::to_fp(F::canon(F::to_256(a.x)));
-    r.y = F::to_fp(F::canon(F::to_256(a.y)));
-    r.zz = Fq::neg(F::to_fp(F::canon(F::mul(a.nzz, F::constant(Fq29Cfg::R251)))));
-    r.zzz = F::to_fp(F::canon(F::mul(a.z3, F::constant(Fq29Cfg::R251))));
+    // exact divisions by 2^5 (x, y: 2^261-form, values < 7 M / 2 M) and 2^10 (nzz, z3: 2^266-form, < 1.1 M) instead of four products by
+    // constants and four canon() (round 6): (v + k M) / 2^S < 2 M, one conditional subtraction each
+    r.x = Fq::canon(F::template to_fp_div<5>(a.x));
+    r.y = Fq::canon(F::template to_fp_div<5>(a.y));
+    r.zz = Fq::neg(Fq::canon(F::template to_fp_div<10>(a.nzz)));
+    r.zzz = Fq::canon(F::template to_fp_div<10>(a.z3));
     if (a.zneg) r.zzz = Fq::neg(r.zzz);
     return r;
 }

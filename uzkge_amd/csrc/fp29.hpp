@@ -62,6 +62,48 @@ struct Field29 {
         r.l[8] = a.v[7] >> 8;
         return r;
     }
+    // 8 x 32-bit words -> 9 limbs of the value TIMES 32 (re-limbing at bit offset -5): a canonical wire element a = x 2^256 enters
+    // the 2^261-form as 32 a = x 2^261 exactly, at the cost of from_fp -- no conversion product.  Normalized, value < 32 * (value of a).
+    __device__ __forceinline__ static L29 from_fp_x32(const Fp& a) {
+        L29 r;
+        r.l[0] = (a.v[0] << 5) & MASK;
+#pragma unroll
+        for (int k = 1; k < 8; ++k) {
+            const int bit = 29 * k - 5, w = bit >> 5, s = bit & 31;
+            uint32_t v = a.v[w] >> s;
+            if (s > 3) v |= a.v[w + 1] << (32 - s);     // the limb straddles two words (w + 1 <= 7 for k <= 7)
+            r.l[k] = v & MASK;
+        }
+        r.l[8] = a.v[7] >> 3;
+        return r;
+    }
+    // The way back: value / 2^S mod M as 8 x 32-bit words, by EXACT division -- add the multiple k M (k < 2^S) that clears the low
+    // S bits, shift.  S = 5 maps the 2^261-form to the wire's 2^256-form, S = 10 the 2^266-form; ~90 instructions against a product
+    // by a constant plus canon (~300).  a: limbs < 2^32, value < V M with (V + 2^S) / 2^S <= 2: the result is < 2 M (and < 2^256);
+    // the caller's canon (one conditional subtraction) makes it canonical.
+    template <int S>
+    __device__ __forceinline__ static Fp to_fp_div(const L29& a) {
+        static_assert(S >= 1 && S <= 10, "k M must stay below 2^10 M");
+        const uint32_t k = (a.l[0] * C::INV) & ((1u << S) - 1);        // a + k M = 0 mod 2^S  (INV = -M^-1 mod 2^29)
+        uint32_t t[9];
+        uint64_t acc = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            acc += (uint64_t)a.l[i] + (uint64_t)k * C::M[i];
+            t[i] = i < 8 ? ((uint32_t)acc & MASK) : (uint32_t)acc;
+            acc >>= 29;
+        }
+        Fp r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int bit = 32 * j + S, i = bit / 29, o = bit - 29 * i;
+            uint64_t w = (uint64_t)t[i] >> o;
+            if (i + 1 < 9) w |= (uint64_t)t[i + 1] << (29 - o);
+            if (58 - o < 32 && i + 2 < 9) w |= (uint64_t)t[i + 2] << (58 - o);
+            r.v[j] = (uint32_t)w;
+        }
+        return r;
+    }
     // normalized limbs, value < 2^256 -> 8 x 32-bit words
     __device__ __forceinline__ static Fp to_fp(const L29& a) {
         Fp r;

@@ -52,6 +52,11 @@ struct Off29 {
     static_assert(ok(), "offset constant out of range");
 };
 
+// the 8 x 32-bit configuration of the same field (for the final conditional subtraction on wire words)
+template <class C> struct WireCfg;
+template <> struct WireCfg<Fq29Cfg> { using type = FqCfg; };
+template <> struct WireCfg<Fr29Cfg> { using type = FrCfg; };
+
 template <class F, int K, int V>
 struct Lz {
     L29 v;
@@ -66,19 +71,7 @@ struct LzOps {
     template <int K, int V> using E = Lz<F, K, V>;
 
     // canonical wire element a = x 2^256  ->  x 2^261 = 32 a, re-limbed: normalized, value < 32 M
-    __device__ __forceinline__ static E<1, 32> ld(const Fp& a) {
-        E<1, 32> r;
-        r.v.l[0] = (a.v[0] << 5) & MASK;
-#pragma unroll
-        for (int k = 1; k < 8; ++k) {
-            const int bit = 29 * k - 5, w = bit >> 5, s = bit & 31;
-            uint32_t v = a.v[w] >> s;
-            if (s > 3) v |= a.v[w + 1] << (32 - s);     // the limb straddles two words (w + 1 <= 7 for k <= 7)
-            r.v.l[k] = v & MASK;
-        }
-        r.v.l[8] = a.v[7] >> 3;
-        return r;
-    }
+    __device__ __forceinline__ static E<1, 32> ld(const Fp& a) { E<1, 32> r; r.v = F::from_fp_x32(a); return r; }
     // the same words taken as they are: a constant c in 2^256-form; mul(x in 2^261-form, ldp(c)) is x c in 2^256-form
     __device__ __forceinline__ static E<1, 1> ldp(const Fp& a) { E<1, 1> r; r.v = F::from_fp(a); return r; }
     __device__ __forceinline__ static E<1, 1> one() { E<1, 1> r; r.v = F::constant(C::ONE261); return r; }
@@ -144,11 +137,17 @@ struct LzOps {
         static_assert(V <= 16, "canon() takes values below 16 M");
         return F::to_fp(F::canon(a.v));
     }
-    // x 2^261 (value < 16 M ... any product) -> canonical x 2^256
+    // x 2^261 -> the canonical wire words of x 2^256: exact division by 32 and one conditional subtraction when the value is small
+    // enough for that (V <= 33: (V M + 31 M) / 32 < 2 M), otherwise one product by 2^256 and canon
     template <int K, int V>
     __device__ __forceinline__ static Fp to_wire(const E<K, V>& a) {
         static_assert(K <= 6, "limb bound");
-        return F::to_fp(F::canon(F::to_256(a.v)));
+        if constexpr (V <= 33) {
+            return Field<typename WireCfg<C>::type>::canon(F::template to_fp_div<5>(a.v));
+        } else {
+            static_assert(V <= 169 * 14, "value bound of to_wire");
+            return F::to_fp(F::canon(F::to_256(a.v)));
+        }
     }
 };
 
