@@ -910,6 +910,21 @@ __device__ __forceinline__ XYZZ xyzz_shfl_down(const XYZZ& p, int delta) {
     for (int k = 0; k < 32; ++k) d[k] = (uint32_t)__shfl_down((int)s[k], delta);
     return r;
 }
+// the same on the lazy 29-bit limbs (ec29l.hpp): partial sums enter by re-limbing, the sum leaves by one exact division per coordinate
+template <int GS>
+__device__ __forceinline__ XYZZ fold_partials29(const XYZZ* __restrict__ src, uint32_t cnt, uint32_t sub) {
+    P29 acc = p29_inf();
+    for (uint32_t k = sub; k < cnt; k += GS) { const P29 q = p29_load(src[k]); p29_add(acc, q); }
+    for (int o = GS / 2; o > 0; o >>= 1) {
+        P29 q;
+        const uint32_t* sp = reinterpret_cast<const uint32_t*>(&acc);
+        uint32_t* dp = reinterpret_cast<uint32_t*>(&q);
+#pragma unroll
+        for (int w = 0; w < 36; ++w) dp[w] = (uint32_t)__shfl_down((int)sp[w], o);
+        if (sub + (uint32_t)o < (uint32_t)GS) p29_add(acc, q);          // see fold_partials
+    }
+    return sub == 0 ? p29_store(acc) : xyzz_inf();   // valid in lane sub == 0
+}
 template <int GS>
 __device__ __forceinline__ XYZZ fold_partials(const XYZZ* __restrict__ src, uint32_t cnt, uint32_t sub) {
     XYZZ acc = xyzz_inf();
@@ -934,7 +949,7 @@ __global__ __launch_bounds__(256) void msm_combine_kernel(const XYZZ* __restrict
                                                           const uint32_t* __restrict__ task_off,
                                                           const uint32_t* __restrict__ win_base, XYZZ* __restrict__ out,
                                                           uint32_t NB, uint32_t W, uint32_t G, uint32_t* __restrict__ big_count,
-                                                          BigFold* __restrict__ big, uint32_t big_thresh) {
+                                                          BigFold* __restrict__ big, uint32_t big_thresh, int arith29) {
     const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t tid = gt / GS, sub = gt % GS;
     if (tid >= win_base[W]) return;          // whole groups leave together
@@ -949,7 +964,7 @@ __global__ __launch_bounds__(256) void msm_combine_kernel(const XYZZ* __restrict
         big[atomicAdd(big_count, 1u)] = e;
         return;
     }
-    XYZZ acc = fold_partials<GS>(in + at, cnt, sub);
+    XYZZ acc = arith29 ? fold_partials29<GS>(in + at, cnt, sub) : fold_partials<GS>(in + at, cnt, sub);
     if (sub == 0) out[tid] = acc;
 }
 // Skewed scalar sets (a real witness is full of 0 / 1 / -1) put thousands of partial sums into a few buckets while everything
@@ -982,7 +997,7 @@ __global__ __launch_bounds__(256) void msm_finalize_kernel(const XYZZ* __restric
                                                            const uint32_t* __restrict__ in_base,
                                                            XYZZ* __restrict__ buckets, uint32_t NB, uint32_t W, int accumulate,
                                                            uint32_t* __restrict__ big_count, BigFold* __restrict__ big, uint32_t big_thresh,
-                                                           int skip_single) {
+                                                           int skip_single, int arith29) {
     const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t t = gt / GS;
     const uint32_t sub = (uint32_t)(gt % GS);
@@ -995,7 +1010,7 @@ __global__ __launch_bounds__(256) void msm_finalize_kernel(const XYZZ* __restric
         big[atomicAdd(big_count, 1u)] = e;
         return;
     }
-    XYZZ acc = fold_partials<GS>(in + in_base[w] + in_off[t], cnt, sub);
+    XYZZ acc = arith29 ? fold_partials29<GS>(in + in_base[w] + in_off[t], cnt, sub) : fold_partials<GS>(in + in_base[w] + in_off[t], cnt, sub);
     if (sub == 0) {
         // streamed MSMs (msm_run_streamed) add every later point chunk's bucket sums onto the first one's
         if (accumulate && cnt != 0) { XYZZ prev = buckets[t]; xyzz_add(prev, acc); buckets[t] = prev; }
@@ -1525,6 +1540,7 @@ __global__ __launch_bounds__(MAXT) void msm_small_reduce_kernel(XYZZ* __restrict
                                                                 const uint2* __restrict__ slot_chunks, SmallLevels lv,
                                                                 XYZZ* __restrict__ win_sums, uint32_t NBL) {
     constexpr bool QUAD = QMODE != 0;
+    static_assert(sizeof(P29) == 144 && sizeof(X29) == 144, "dynamic LDS: 144 bytes per quad in the 29-bit modes");
     extern __shared__ uint4 sm_red[];
     XYZZ* sh = reinterpret_cast<XYZZ*>(sm_red);
     const uint32_t slot = blockIdx.x, tid = threadIdx.x;
@@ -1555,7 +1571,50 @@ __global__ __launch_bounds__(MAXT) void msm_small_reduce_kernel(XYZZ* __restrict
         }
         __syncthreads();
     }
-    if constexpr (QMODE == 2) {
+    if constexpr (QMODE == 3) {
+        // (QMODE 2's scheme with the buckets re-limbed into the 2^261-form instead of converted by a product: ec29l.hpp)
+        // Q = min(NBL, 64) quads -- 256 lanes, ONE wave per SIMD (a second wave on the SIMD doubles the time of every
+        // dependent step) -- quad t owns the r = NBL / Q consecutive buckets t r .. t r + r - 1 (array index i = b - 1):
+        //   run_t = sum_j B, acc_t = sum_j (j + 1) B            (running sums from the top bucket down: 2 (r - 1) additions)
+        //   sum_b b B_b = sum_t acc_t + r sum_{t >= 1} Suf_t,   Suf_t = run_t + run_(t+1) + ...   (log2 Q scan steps)
+        // then a tree over V_t = acc_t + r Suf_t (t >= 1), V_0 = acc_0.
+        const uint32_t Q = blockDim.x >> 2, r = NBL / Q;
+        P29* sh29 = reinterpret_cast<P29*>(sm_red);
+        P29 run = p29_inf(), acc = p29_inf();
+        for (uint32_t j = r; j-- > 0;) {
+            const uint32_t ref = bucket_ref[(size_t)slot * NBL + t * r + j];
+            if (ref != kSmallNone) { const XYZZ bk = P[ref]; p29_add_quad(run, p29_load(bk), q); }
+            if (r > 1) p29_add_quad(acc, run, q); else acc = run;
+        }
+        if (writer) sh29[t] = run;
+        __syncthreads();
+        for (uint32_t off = 1; off < Q; off <<= 1) {
+            const bool has = t + off < Q;
+            P29 v;
+            if (has) v = sh29[t + off];
+            __syncthreads();
+            if (has) {
+                p29_add_quad(run, v, q);
+                if (writer) sh29[t] = run;
+            }
+            __syncthreads();
+        }
+        if (t >= 1) {
+            for (uint32_t d = 1; d < r; d <<= 1) p29_dbl_quad(run, q);
+            p29_add_quad(acc, run, q);
+        }
+        if (writer) sh29[t] = acc;
+        __syncthreads();
+        for (uint32_t s2 = Q >> 1; s2 > 0; s2 >>= 1) {
+            if (t < s2) {
+                const P29 v = sh29[t + s2];
+                p29_add_quad(acc, v, q);
+                if (writer) sh29[t] = acc;
+            }
+            __syncthreads();
+        }
+        if (t == 0) reinterpret_cast<Fp*>(&win_sums[slot])[q] = p29_coord_to_fp(acc, q);      // x | y | zz | zzz by the quad's four lanes
+    } else     if constexpr (QMODE == 2) {
         // Q = min(NBL, 64) quads -- 256 lanes, ONE wave per SIMD (a second wave on the SIMD doubles the time of every
         // dependent step) -- quad t owns the r = NBL / Q consecutive buckets t r .. t r + r - 1 (array index i = b - 1):
         //   run_t = sum_j B, acc_t = sum_j (j + 1) B            (running sums from the top bucket down: 2 (r - 1) additions)
@@ -2170,6 +2229,7 @@ static int msm_group_phase1(Ctx& c, MsmGroup& g, const Affine* points, const Sca
 // Phase 2: wait for the read-back, fold the partial sums into the bucket array (`accumulate`: onto what an earlier point
 // chunk left there), and -- unless more chunks follow -- reduce the buckets and copy the window sums.
 static int msm_group_phase2(Ctx& c, MsmGroup& g, bool accumulate = false, bool reduce = true) {
+    const int a29 = (c.tune_arith29 >> 2) & 1;       // the folds' additions on the lazy 29-bit limbs (ec29l.hpp)
     MsmWork& m = *g.m;
     hipStream_t st = g.st;
     c.cur_stream = st;
@@ -2225,14 +2285,14 @@ static int msm_group_phase2(Ctx& c, MsmGroup& g, bool accumulate = false, bool r
             const dim3 grid((unsigned)((bound_nx * gs + 255) / 256));
             if (gs == 16)
                 hipLaunchKernelGGL(msm_combine_kernel<16>, grid, dim3(256), 0, st, g.part_cur, g.cnt_cur, g.off_cur, g.base_cur,
-                                   off_nx, base_nx, part_nx, g.NB, g.Wd, G, (uint32_t*)nullptr, (BigFold*)nullptr, 0u);
+                                   off_nx, base_nx, part_nx, g.NB, g.Wd, G, (uint32_t*)nullptr, (BigFold*)nullptr, 0u, a29);
             else if (gs == 4)
                 hipLaunchKernelGGL(msm_combine_kernel<4>, grid, dim3(256), 0, st, g.part_cur, g.cnt_cur, g.off_cur, g.base_cur,
-                                   off_nx, base_nx, part_nx, g.NB, g.Wd, G, (uint32_t*)nullptr, (BigFold*)nullptr, 0u);
+                                   off_nx, base_nx, part_nx, g.NB, g.Wd, G, (uint32_t*)nullptr, (BigFold*)nullptr, 0u, a29);
             else {
                 if (big_mode) UZK_HIP(hipMemsetAsync(big_count, 0, 4, st));
                 hipLaunchKernelGGL(msm_combine_kernel<1>, grid, dim3(256), 0, st, g.part_cur, g.cnt_cur, g.off_cur, g.base_cur,
-                                   off_nx, base_nx, part_nx, g.NB, g.Wd, G, big_count, big_list, kBigThresh);
+                                   off_nx, base_nx, part_nx, g.NB, g.Wd, G, big_count, big_list, kBigThresh, a29);
                 if (big_mode)
                     hipLaunchKernelGGL(msm_fold_big_kernel, dim3(2048), dim3(64), 0, st, g.part_cur, big_count, big_list, part_nx, 0);
             }
@@ -2247,15 +2307,15 @@ static int msm_group_phase2(Ctx& c, MsmGroup& g, bool accumulate = false, bool r
         const dim3 grid((unsigned)((g.TBK * gs + 255) / 256));
         if (gs == 16)
             hipLaunchKernelGGL(msm_finalize_kernel<16>, grid, dim3(256), 0, st, g.part_cur, g.cnt_cur, g.off_cur, g.base_cur,
-                               buckets, g.NB, g.Wd, accumulate ? 1 : 0, (uint32_t*)nullptr, (BigFold*)nullptr, 0u, skip_single);
+                               buckets, g.NB, g.Wd, accumulate ? 1 : 0, (uint32_t*)nullptr, (BigFold*)nullptr, 0u, skip_single, a29);
         else if (gs == 4)
             hipLaunchKernelGGL(msm_finalize_kernel<4>, grid, dim3(256), 0, st, g.part_cur, g.cnt_cur, g.off_cur, g.base_cur,
-                               buckets, g.NB, g.Wd, accumulate ? 1 : 0, (uint32_t*)nullptr, (BigFold*)nullptr, 0u, skip_single);
+                               buckets, g.NB, g.Wd, accumulate ? 1 : 0, (uint32_t*)nullptr, (BigFold*)nullptr, 0u, skip_single, a29);
         else {
             const bool big_last = big_mode && tmax > kBigThresh;
             if (big_last) UZK_HIP(hipMemsetAsync(big_count, 0, 4, st));
             hipLaunchKernelGGL(msm_finalize_kernel<1>, grid, dim3(256), 0, st, g.part_cur, g.cnt_cur, g.off_cur, g.base_cur,
-                               buckets, g.NB, g.Wd, accumulate ? 1 : 0, big_count, big_last ? big_list : (BigFold*)nullptr, kBigThresh, skip_single);
+                               buckets, g.NB, g.Wd, accumulate ? 1 : 0, big_count, big_last ? big_list : (BigFold*)nullptr, kBigThresh, skip_single, a29);
             if (big_last)
                 hipLaunchKernelGGL(msm_fold_big_kernel, dim3(2048), dim3(64), 0, st, g.part_cur, big_count, big_list, buckets, accumulate ? 1 : 0);
         }
@@ -2541,7 +2601,9 @@ static int msm_run_small(Ctx& c, const Affine* points, const ScalarView& d_scala
         {
             KernelScope ks(c, "msm_small_reduce");
             const uint32_t Q = std::min<uint32_t>(NBL, 64);
-            hipLaunchKernelGGL((msm_small_reduce_kernel<2, 256>), dim3(S), dim3(4 * Q), (size_t)Q * 144, st, P, bucket_ref, cdesc,
+            if ((c.tune_arith29 >> 2) & 1) hipLaunchKernelGGL((msm_small_reduce_kernel<3, 256>), dim3(S), dim3(4 * Q), (size_t)Q * 144, st, P, bucket_ref, cdesc,
+                               slot_chunks, lv, win_sums, NBL);
+            else hipLaunchKernelGGL((msm_small_reduce_kernel<2, 256>), dim3(S), dim3(4 * Q), (size_t)Q * 144, st, P, bucket_ref, cdesc,
                                slot_chunks, lv, win_sums, NBL);
         }
         UZK_HIP(hipGetLastError());
