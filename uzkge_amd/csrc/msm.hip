@@ -2588,6 +2588,8 @@ static int msm_run_small(Ctx& c, const Affine* points, const ScalarView& d_scala
             const uint64_t est = k == 1 ? (uint64_t)S * NBL : (uint64_t)S * 2;      // chunks that really exist (estimate)
             // measured (profiles/r02_small_msm_2e14.txt, n = 2^14): quads of 4 logical lanes match or beat plain lanes up
             // to batch 8 (uniform: 75-89 vs 77-96 us, skewed scalars: 27-38 vs 62-63 us); beyond, plain lanes fill the chip
+            // (round 6, four lockstep provers keeping the chip busy: plain lanes here -- 1 / 1.6 of the quads' instructions -- made no
+            // measurable difference, 1602 / 1583 against 1620 / 1576 proofs/s lockstep8 / shared_32, profiles/r06_ab_arith29.txt)
             const bool quad = est * 16 <= 10 * lanes_chip;
             const int gs = quad ? 4 : (est * 4 <= 4 * lanes_chip ? 4 : 2);
             const uint64_t lanes = cap[k] * (uint64_t)gs * (quad ? 4 : 1);
