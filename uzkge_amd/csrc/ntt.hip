@@ -295,8 +295,12 @@ __device__ __forceinline__ L29 lds_get29(const uint4* lds, int idx) {
 // element of a 2^22 transform) are multiplied in by the constant-operand product over the pair table a.tw256c; the pass
 // twiddles and the fused coset / radix-3 tables are Montgomery products over their 2^261-form tables (streamed tables: a pair
 // would double their traffic).  Both forms compute x * w mod M up to the lazy multiple of M, so they mix freely.
+// Waves per SIMD: four for the first pass (114 .. 117 VGPRs).  The later passes of 6 .. 9 bits on 1024-element tiles need 139 .. 146 VGPRs:
+// held to 128 (four waves) they spill 4 .. 10 words; compiled for THREE waves per SIMD they do not, and the transform is 3 % faster
+// (round 6, profiles/r06_ntt_bounds.txt: 2^22 396 -> 381 us, ten transforms of 2^14 26.1 -> 25.5 us; the 2048-element tiles
+// keep four: at three their 76 KB of LDS would leave one workgroup per CU).
 template <int B, bool FIRST, int TILE>
-__global__ __launch_bounds__(TILE / 4) __attribute__((amdgpu_waves_per_eu(4))) void ntt_pass29_kernel(const Fp* __restrict__ in, Fp* __restrict__ out,
+__global__ __launch_bounds__(TILE / 4) __attribute__((amdgpu_waves_per_eu((!FIRST && TILE == 1024 && B >= 6 && B <= 9) ? 3 : 4))) void ntt_pass29_kernel(const Fp* __restrict__ in, Fp* __restrict__ out,
                                                              PassArgs a) {
     constexpr int R = 1 << B, T = TILE / R, Q = R / 4, TWN = B > 8 ? 2048 : 256, SH = (B > 8 ? 11 : 8) - B, NT = TILE / 4, PL = TILE + (TILE >= 1024 ? 64 : 16);
     constexpr int N4 = B / 2;
