@@ -563,8 +563,11 @@ int uzk_msm_plan_info(size_t n, int* window_bits, int* windows);
  *   "msm_seg_sort"        0: the generic last sort pass instead of one workgroup per segment; 10 + k: segment kernel k at any size
  *   "ntt_tile"            1024 / 2048: elements per workgroup of an NTT pass at every size (default 0: by size)
  *   "ntt_two_pass"        0: transforms of 2^17 .. 2^21 elements in three passes of 5 .. 8 bits (default 1: two passes of 9 .. 11)
- * The last four exist so that the tests reach every pipeline and instantiation at sizes the CPU oracle can check
- * (tests/test_gpu_variants.py).  Unknown keys are UZK_ERR_PARAMETER. */
+ *   "arith29"             bit mask, default 7: which of the prover's kernels run on the lazy 29-bit limbs (csrc/lz29.hpp) instead of
+ *                         8 x 32-bit Montgomery words -- 1: the quotient kernel, 2: the lane evaluations and linear combinations,
+ *                         4: the MSM's bucket-side additions (class sums, folds, the small pipeline's quads).  Same bytes either way
+ * The last five exist so that the tests reach every pipeline and instantiation at sizes the CPU oracle can check
+ * (tests/test_gpu_variants.py, tests/test_gpu_arith29.py).  Unknown keys are UZK_ERR_PARAMETER. */
 int uzk_tune(const char* key, int value);
 
 #ifdef __cplusplus

@@ -112,3 +112,31 @@ def test_msm_bucket_side_kernels_agree(both, log_n, batch, mix):
     finally:
         gpu.tune("msm_small", 1)
         srs.release()
+
+
+@pytest.mark.parametrize("lanes", [1, 3])
+def test_whole_proofs_agree_between_the_arithmetics(both, lanes):
+    """Five rounds of `lanes` proofs in lockstep (commitments, the 19 evaluations, both openings): every mask of uzk_tune("arith29")
+    gives the same proof -- the quotient (bit 0), the lane evaluations and linear combinations (bit 1: 19 evaluations, r(X) over 43
+    polynomials, the opening's combinations), the commits' bucket-side additions (bit 2)."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import prover_chain as pch
+    from test_gpu_circuit_rounds import _circuit_of, _round_inputs, _run_rounds
+    gpu = both
+    n = 1 << 12
+    inp = pch.ChainInputs(n, 77)
+    xs = _round_inputs(inp, lanes)
+    cir = _circuit_of(gpu, inp, precompute=1)
+    p = gpu.Prover(n, lanes, shared=False)
+    try:
+        ref = None
+        for mask in (0, 7, 1, 2, 4):
+            gpu.tune("arith29", mask)
+            o = _run_rounds(gpu, cir, p, xs)
+            d = tuple(tuple(affine_of(j) for j in o[k]) for k in ("cm1", "cm_z", "cm_t", "cm_q")) + (o["evals"].tobytes(),)
+            if ref is None:
+                ref = d
+            assert d == ref, mask
+    finally:
+        p.destroy(); cir.release()

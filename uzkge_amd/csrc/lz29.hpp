@@ -100,6 +100,14 @@ struct LzOps {
         r.v = a.v;
         return r;
     }
+    // UNCHECKED restatement of the bounds, for values whose bound rests on an argument the types cannot see (a running sum over a
+    // run-time number of terms that the host has limited): every use states that argument in a comment
+    template <int K2, int V2, int K, int V>
+    __device__ __forceinline__ static E<K2, V2> assume(const E<K, V>& a) {
+        E<K2, V2> r;
+        r.v = a.v;
+        return r;
+    }
     // one parallel carry step: limbs < 2^32 in, < 2^29 + 2^3 out (the top limb takes the rest)
     template <int K, int V>
     __device__ __forceinline__ static E<1, V> norm(const E<K, V>& a) {

@@ -12,10 +12,12 @@
 //   split_t_lanes         split_t_and_commit's chunks, helpers.rs:1335-1363         round 3
 //   fold_blinds_lanes     fold modulo X^N - 1 + the blind scalars, pcs.rs:137-156   rounds 3, 5
 //   trimmed_len_lanes     FpPolynomial::from_coefs' trim, field_polynomial.rs:86-90 rounds 3, 5
+#include <algorithm>
 #include <cstring>
 
 #include "ctx.hpp"
 #include "host_math.hpp"
+#include "lz29.hpp"
 
 namespace uzk {
 
@@ -67,6 +69,40 @@ int hide_lanes(Ctx& c, Fp* d_coefs, uint64_t lane_stride, uint64_t slot_stride, 
     hipLaunchKernelGGL(hide_lanes_kernel, dim3(slots, lanes), dim3(64), 0, c.stream, d_coefs, lane_stride, slot_stride, n, d_blinds);
     UZK_HIP(hipGetLastError());
     return UZK_OK;
+}
+
+// ---- witness upload ------------------------------------------------------------------------------------------------------
+// Round 1's inputs from PINNED host memory (uzk_host_alloc: mapped, readable by the device): ONE kernel reads every lane's witness
+// [5n] and wire selectors [3n] over PCIe into the lane's evaluation slots and zeroes the public-input slot, instead of 2 k
+// hipMemcpyAsync + one hipMemset2DAsync -- each of which is a staging step of the runtime with a gap behind it on the stream
+// (profiles/r05f_gaps_*: a tenth of a queue's time sat between those copies).  16 bytes per lane per access, grid-stride.
+struct WitnessSrc { const uint4* w; const uint4* s; };
+__global__ __launch_bounds__(256) void witness_gather_kernel(const WitnessSrc* __restrict__ srcs, uint4* __restrict__ evals, uint64_t lane_stride16,
+                                                             uint32_t w16, uint32_t s16, uint32_t pi_off16, uint32_t pi16) {
+    const WitnessSrc src = srcs[blockIdx.y];
+    uint4* dst = evals + (uint64_t)blockIdx.y * lane_stride16;
+    const uint32_t total = w16 + s16 + pi16, step = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+        if (i < w16) dst[i] = src.w[i];
+        else if (i < w16 + s16) dst[i] = src.s[i - w16];                     // the selectors' slots follow the wires'
+        else dst[pi_off16 + (i - w16 - s16)] = make_uint4(0, 0, 0, 0);
+    }
+}
+// d_srcs: `lanes` WitnessSrc in device memory (s = nullptr without wire selectors).  d_evals: lane 0's slot 0; lane_stride, pi_off in elements.
+int witness_gather_lanes(Ctx& c, const void* d_srcs, uint32_t lanes, Fp* d_evals, uint64_t lane_stride, uint32_t n_wit, uint32_t n_sel, uint64_t pi_off, uint32_t n_pi) {
+    if (lanes == 0) return UZK_OK;
+    KernelScope ks(c, "witness_gather");
+    const uint32_t total16 = 2 * (n_wit + n_sel + n_pi);
+    const unsigned blocks = std::min<unsigned>((total16 + 255) / 256, 256u);
+    hipLaunchKernelGGL(witness_gather_kernel, dim3(blocks, lanes), dim3(256), 0, c.stream, static_cast<const WitnessSrc*>(d_srcs),
+                       reinterpret_cast<uint4*>(d_evals), lane_stride * 2, 2 * n_wit, 2 * n_sel, (uint32_t)(pi_off * 2), 2 * n_pi);
+    UZK_HIP(hipGetLastError());
+    return UZK_OK;
+}
+size_t witness_src_bytes() { return sizeof(WitnessSrc); }
+void witness_src_fill(void* host_entry, const void* w, const void* s) {
+    WitnessSrc& e = *static_cast<WitnessSrc*>(host_entry);
+    e.w = static_cast<const uint4*>(w); e.s = static_cast<const uint4*>(s);
 }
 
 // ---- evaluations ----------------------------------------------------------------------------------------------------------
@@ -138,6 +174,91 @@ __global__ __launch_bounds__(256) void poly_eval_lanes_kernel(const EvalPoly* __
         counters[slot] = 0;                   // ready for the next launch on this stream
     }
 }
+// Evaluations: poly_eval_lanes_kernel's scheme -- PER Horner steps per lane, the power table (x^PER)^t in LDS by doubling, the block's
+// weight, a tree over the 256 lane values -- with every product on the 29-bit limbs; the LDS arrays hold limb planes.  The block's
+// partial value leaves in wire form (the last block's sum over <= 64 partials stays on 8 x 32-bit words: one lane).
+template <int PER>
+__global__ __launch_bounds__(256) void poly_eval_lanes29_kernel(const EvalPoly* __restrict__ polys, const Fp* __restrict__ points, Fp* __restrict__ partial,
+                                                                uint32_t* __restrict__ counters, Fp* __restrict__ out_host) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using Z = LzOps<Fr29>;
+    using S8 = Lz<Fr29, 1, 8>;
+    constexpr int BLOCK = 256 * PER;
+    __shared__ uint32_t pw[9][256];
+    __shared__ uint32_t sh[9][256];
+    __shared__ uint32_t last;
+    const uint32_t tid = threadIdx.x, blk = blockIdx.x, stride = gridDim.x, k = blockIdx.y, b = blockIdx.z;
+    const uint32_t slot = b * gridDim.y + k;
+    const EvalPoly P = polys[k];
+    const uint64_t n = P.len;
+    const uint32_t nblocks = (uint32_t)((n + BLOCK - 1) / BLOCK);
+    if (n == 0 && blk == 0 && tid == 0) out_host[slot] = Fr::zero();
+    if (blk >= nblocks) return;
+    const Fp* c = P.p + (uint64_t)b * P.lane_stride;
+    const auto x = Z::ld(points[2 * b + P.pt]);
+    const uint64_t base = (uint64_t)blk * BLOCK + (uint64_t)tid * PER;
+    auto put = [&](uint32_t (*arr)[256], uint32_t i, const L29& v) {
+#pragma unroll
+        for (int w = 0; w < 9; ++w) arr[w][i] = v.l[w];
+    };
+    auto get = [&](uint32_t (*arr)[256], uint32_t i) { L29 v;
+#pragma unroll
+        for (int w = 0; w < 9; ++w) v.l[w] = arr[w][i];
+        return v; };
+    Lz<Fr29, 2, 48> h = Z::template relax<2, 48>(Z::zero());
+#pragma unroll
+    for (int e = PER - 1; e >= 0; --e) {
+        const uint64_t j = base + e;
+        const auto hx = Z::mul(h, x);                                   // < 11 M
+        if (j < n) h = Z::template relax<2, 48>(Z::add(hx, Z::ld(c[j])));
+        else h = Z::template relax<2, 48>(hx);
+    }
+    S8 s = Z::template relax<1, 8>(Z::sqr(x));                          // x^2 ... x^PER
+#pragma unroll
+    for (int e = 2; e < PER; e <<= 1) s = Z::template relax<1, 8>(Z::sqr(s));
+    if (tid == 0) put(pw, 0, Z::one().v);
+    __syncthreads();
+#pragma unroll
+    for (int lv = 0; lv < 8; ++lv) {
+        const uint32_t half = 1u << lv;
+        if (tid < half) { S8 t; t.v = get(pw, tid); put(pw, half + tid, Z::mul(t, s).v); }
+        s = Z::template relax<1, 8>(Z::sqr(s));
+        __syncthreads();
+    }
+    S8 wblk = Z::template relax<1, 8>(Z::one()), sp = s;                // s = x^BLOCK: the block's weight is s^blk
+    for (uint32_t e = blk; e; e >>= 1) {
+        if (e & 1) wblk = Z::template relax<1, 8>(Z::mul(wblk, sp));
+        sp = Z::template relax<1, 8>(Z::sqr(sp));
+    }
+    { S8 t; t.v = get(pw, tid); put(sh, tid, Z::mul(h, t).v); }         // < 4 M each, normalized
+    __syncthreads();
+    // 256 values < 4 M: the tree's sums stay below 1024 M; one carry step per level keeps the limbs normalized
+    for (uint32_t st = 128; st > 0; st >>= 1) {
+        if (tid < st) {
+            Lz<Fr29, 1, 1024> u, v;
+            u.v = get(sh, tid); v.v = get(sh, tid + st);
+            put(sh, tid, Z::norm(Z::add(u, v)).v);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        Lz<Fr29, 1, 1024> tot;
+        tot.v = get(sh, 0);
+        partial[(uint64_t)slot * stride + blk] = Z::to_wire(Z::mul(tot, wblk));
+        __threadfence();
+        last = (atomicAdd(&counters[slot], 1u) == nblocks - 1) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (last && tid == 0) {
+        __threadfence();
+        Fp acc = Fr::zero();
+        for (uint32_t j = 0; j < nblocks; ++j) acc = Fr::add(acc, partial[(uint64_t)slot * stride + j]);
+        out_host[slot] = acc;
+        counters[slot] = 0;                   // ready for the next launch on this stream
+    }
+#endif
+}
+
 // d_polys: `count` EvalPoly in device memory; d_counters: lanes * count zeroed words; out_host: pinned.  Asynchronous.
 int poly_eval_lanes(Ctx& c, const void* d_polys, uint32_t count, uint64_t max_len, const Fp* d_points, uint32_t lanes, uint32_t* d_counters, Fp* out_host_pinned) {
     if (count == 0 || lanes == 0) return UZK_OK;
@@ -147,7 +268,10 @@ int poly_eval_lanes(Ctx& c, const void* d_polys, uint32_t count, uint64_t max_le
     UZK_TRY(c.poly_tmp.reserve((size_t)lanes * count * blocks * sizeof(Fp)));
     KernelScope ks(c, "poly_eval");
     const dim3 grid((unsigned)blocks, count, lanes);
-    if (wide) hipLaunchKernelGGL(poly_eval_lanes_kernel<16>, grid, dim3(256), 0, c.stream, static_cast<const EvalPoly*>(d_polys), d_points, c.poly_tmp.as<Fp>(), d_counters, out_host_pinned);
+    const bool a29 = (c.tune_arith29 & 2) != 0;       // the products on the lazy 29-bit limbs (uzk_tune("arith29", mask) bit 1)
+    if (wide && a29) hipLaunchKernelGGL(poly_eval_lanes29_kernel<16>, grid, dim3(256), 0, c.stream, static_cast<const EvalPoly*>(d_polys), d_points, c.poly_tmp.as<Fp>(), d_counters, out_host_pinned);
+    else if (a29) hipLaunchKernelGGL(poly_eval_lanes29_kernel<4>, grid, dim3(256), 0, c.stream, static_cast<const EvalPoly*>(d_polys), d_points, c.poly_tmp.as<Fp>(), d_counters, out_host_pinned);
+    else if (wide) hipLaunchKernelGGL(poly_eval_lanes_kernel<16>, grid, dim3(256), 0, c.stream, static_cast<const EvalPoly*>(d_polys), d_points, c.poly_tmp.as<Fp>(), d_counters, out_host_pinned);
     else hipLaunchKernelGGL(poly_eval_lanes_kernel<4>, grid, dim3(256), 0, c.stream, static_cast<const EvalPoly*>(d_polys), d_points, c.poly_tmp.as<Fp>(), d_counters, out_host_pinned);
     UZK_HIP(hipGetLastError());
     return UZK_OK;
@@ -187,12 +311,62 @@ __global__ __launch_bounds__(256) void poly_lincomb_lanes_kernel(const LinPoly* 
     }
     if (live && sub == 0) out[(uint64_t)b * out_stride + j] = acc;
 }
+// ---- the same two lane kernels on the lazy 29-bit limbs (lz29.hpp; round 6) ------------------------------------------------------
+// Linear combination: two terms share one reduction (mul2); the running sum stays lazy between terms (one parallel carry step per
+// pair).  Value bound: every pair adds < 14 M, the host admits count <= 128 (< 900 M in all: the top limb stays below 2^32).
+template <int GS>
+__global__ __launch_bounds__(256) void poly_lincomb_lanes29_kernel(const LinPoly* __restrict__ polys, uint32_t count, const uint32_t* __restrict__ lens,
+                                                                   const Fp* __restrict__ scalars, Fp* __restrict__ out, uint64_t out_stride, uint64_t out_len) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using Z = LzOps<Fr29>;
+    using Acc = Lz<Fr29, 1, 1024>;
+    const uint32_t b = blockIdx.y;
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t j = gid / GS;
+    const uint32_t sub = (uint32_t)(gid % GS);
+    const bool live = j < out_len;
+    lens += (uint64_t)b * count; scalars += (uint64_t)b * count;
+    Acc acc = Z::template relax<1, 1024>(Z::zero());
+    if (live) {
+        auto term = [&](uint32_t k) { return polys[k].p[(uint64_t)b * polys[k].lane_stride + j]; };
+        for (uint32_t k = sub; k < count; k += 2 * GS) {
+            const uint32_t k2 = k + GS;
+            const bool has1 = j < lens[k], has2 = k2 < count && j < lens[k2];
+            if (has1 && has2) {
+                const auto t = Z::mul2(Z::ld(scalars[k]), Z::ld(term(k)), Z::ld(scalars[k2]), Z::ld(term(k2)));
+                acc = Z::template assume<1, 1024>(Z::norm(Z::add(acc, t)));
+            } else if (has1 || has2) {
+                const uint32_t kk = has1 ? k : k2;
+                const auto t = Z::mul(Z::ld(scalars[kk]), Z::ld(term(kk)));
+                acc = Z::template assume<1, 1024>(Z::norm(Z::add(acc, t)));
+            }
+        }
+    }
+    if constexpr (GS > 1) {
+#pragma unroll
+        for (int o = GS / 2; o > 0; o >>= 1) {
+            Acc q;
+#pragma unroll
+            for (int w = 0; w < 9; ++w) q.v.l[w] = (uint32_t)__shfl_down((int)acc.v.l[w], o);
+            if (sub + (uint32_t)o < (uint32_t)GS) acc = Z::template assume<1, 1024>(Z::norm(Z::add(acc, q)));
+        }
+    }
+    if (live && sub == 0) out[(uint64_t)b * out_stride + j] = Z::to_wire(acc);
+#endif
+}
+
+
 int poly_lincomb_lanes(Ctx& c, const void* d_polys, uint32_t count, const uint32_t* d_lens, const Fp* d_scalars, uint32_t lanes, Fp* d_out, uint64_t out_stride,
                        uint64_t out_len) {
     if (count == 0 || lanes == 0 || out_len == 0) return UZK_OK;
     KernelScope ks(c, "poly_lincomb");
     const LinPoly* polys = static_cast<const LinPoly*>(d_polys);
-    if (out_len <= (1ull << 17) && count >= 8)
+    const bool a29 = (c.tune_arith29 & 2) != 0 && count <= 128;      // (the 29-bit kernel's running sum is bounded for <= 128 terms)
+    if (a29 && out_len <= (1ull << 17) && count >= 8)
+        hipLaunchKernelGGL(poly_lincomb_lanes29_kernel<4>, dim3((unsigned)((out_len * 4 + 255) / 256), lanes), dim3(256), 0, c.stream, polys, count, d_lens, d_scalars, d_out, out_stride, out_len);
+    else if (a29)
+        hipLaunchKernelGGL(poly_lincomb_lanes29_kernel<1>, dim3((unsigned)((out_len + 255) / 256), lanes), dim3(256), 0, c.stream, polys, count, d_lens, d_scalars, d_out, out_stride, out_len);
+    else if (out_len <= (1ull << 17) && count >= 8)
         hipLaunchKernelGGL(poly_lincomb_lanes_kernel<4>, dim3((unsigned)((out_len * 4 + 255) / 256), lanes), dim3(256), 0, c.stream, polys, count, d_lens, d_scalars, d_out, out_stride, out_len);
     else
         hipLaunchKernelGGL(poly_lincomb_lanes_kernel<1>, dim3((unsigned)((out_len + 255) / 256), lanes), dim3(256), 0, c.stream, polys, count, d_lens, d_scalars, d_out, out_stride, out_len);
