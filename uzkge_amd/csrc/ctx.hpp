@@ -266,9 +266,6 @@ void quotient_lane(const Fp& alpha, const Fp& beta, const Fp& gamma, const Fp* k
 size_t quotient_lane_bytes();
 // rounds.hip: the lane kernels of the prover's rounds (device-resident argument entries are filled through the *_fill helpers)
 int hide_lanes(Ctx& c, Fp* d_coefs, uint64_t lane_stride, uint64_t slot_stride, uint32_t n, uint32_t slots, uint32_t lanes, const Fp* d_blinds);
-int witness_gather_lanes(Ctx& c, const void* d_srcs, uint32_t lanes, Fp* d_evals, uint64_t lane_stride, uint32_t n_wit, uint32_t n_sel, uint64_t pi_off, uint32_t n_pi);
-size_t witness_src_bytes();
-void witness_src_fill(void* host_entry, const void* w, const void* s);
 int poly_eval_lanes(Ctx& c, const void* d_polys, uint32_t count, uint64_t max_len, const Fp* d_points, uint32_t lanes, uint32_t* d_counters, Fp* out_host_pinned);
 void eval_poly_fill(void* host_entry, const void* p, uint64_t lane_stride, uint64_t len, uint32_t pt);
 size_t eval_poly_bytes();

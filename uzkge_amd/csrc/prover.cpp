@@ -382,26 +382,13 @@ int round1_lanes(Ctx& c, Prover& p, const std::shared_ptr<Circuit>& cir, uint32_
         }
         for (uint32_t j = 0; j < 3; ++j) hb[((size_t)b * slots + n_first) * 3 + j] = Fr::zero();
     }
-    // Inputs in pinned host memory (uzk_host_alloc): one gather kernel reads them over PCIe and zeroes the public-input slot
-    // (rounds.hip witness_gather_kernel); its source table travels in the round's argument block.
-    static const bool gather_ok = !(std::getenv("UZK_WITNESS_GATHER") && std::atoi(std::getenv("UZK_WITNESS_GATHER")) == 0);
-    bool gather = gather_ok && !inputs_on_device;
-    const size_t wb_ = (size_t)kWires * n * sizeof(Fp), sb_ = (size_t)kWsel * n * sizeof(Fp);
-    for (uint32_t b = 0; b < k && gather; ++b)
-        gather = is_pinned_block(L[b].witness, wb_) && (!has_wsel || is_pinned_block(L[b].wsel, sb_)) && (reinterpret_cast<uintptr_t>(L[b].witness) & 15) == 0 &&
-                 (reinterpret_cast<uintptr_t>(L[b].wsel) & 15) == 0;
-    const void* d_wsrc = nullptr;
-    if (gather) {
-        ARG_PUSH(ws, d_ws, char, (size_t)k * witness_src_bytes());
-        for (uint32_t b = 0; b < k; ++b) witness_src_fill(ws + (size_t)b * witness_src_bytes(), L[b].witness, L[b].wsel);
-        d_wsrc = d_ws;
-    }
     ROUND_TRY(p.args.upload(c.stream));
     // witness [5n] (and selectors [3n]) of every lane into its evaluation slots [10][n]
     const hipMemcpyKind kind = inputs_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    if (gather) {
-        ROUND_TRY(witness_gather_lanes(c, d_wsrc, k, p.d_evals, (uint64_t)kProofSlots * n, kWires * n, has_wsel ? kWsel * n : 0, (uint64_t)p.sl_pi() * n, n));
-    } else {
+    // (Measured and not kept, round 6: ONE kernel reading every lane's pinned witness over PCIe and zeroing the PI slot, instead of these
+    // 2 k copies + a memset -- 10 % SLOWER, 1460 against 1626 proofs/s lockstep8: a kernel that waits on PCIe holds a compute queue
+    // for the 0.7 ms the copy engines spend beside the other three launch sequences.  profiles/EXPERIMENTS.md, round 6.)
+    {
         std::vector<const void*> w(k), s(k);
         for (uint32_t b = 0; b < k; ++b) { w[b] = L[b].witness; s[b] = L[b].wsel; }
         const size_t wb = (size_t)kWires * n * sizeof(Fp), sb = (size_t)kWsel * n * sizeof(Fp), lane = (size_t)kProofSlots * n * sizeof(Fp);
@@ -416,8 +403,8 @@ int round1_lanes(Ctx& c, Prover& p, const std::shared_ptr<Circuit>& cir, uint32_
             for (uint32_t b = 0; b < k && !pageable; ++b) pageable = !is_pinned_block(w[b], wb) || (has_wsel && !is_pinned_block(s[b], sb));
         if (pageable) ROUND_HIP(hipStreamSynchronize(c.stream));   // the caller may reuse ordinary host memory on return
     }
-    // PI evaluations (pi_poly, helpers.rs:111-131): zero (the gather kernel has done that), then the online values at their constraint indices
-    if (!gather) ROUND_HIP(hipMemset2DAsync(p.evals(0, p.sl_pi()), (size_t)kProofSlots * n * sizeof(Fp), 0, (size_t)n * sizeof(Fp), k, c.stream));
+    // PI evaluations (pi_poly, helpers.rs:111-131): zero, then the online values at their constraint indices
+    ROUND_HIP(hipMemset2DAsync(p.evals(0, p.sl_pi()), (size_t)kProofSlots * n * sizeof(Fp), 0, (size_t)n * sizeof(Fp), k, c.stream));
     if (pi_count) {
         const size_t need = (size_t)pi_count * sizeof(uint32_t) + 16 + (size_t)k * pi_count * sizeof(Fp);
         if (p.h_pi_cap < need) {

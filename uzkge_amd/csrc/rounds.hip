@@ -71,40 +71,6 @@ int hide_lanes(Ctx& c, Fp* d_coefs, uint64_t lane_stride, uint64_t slot_stride, 
     return UZK_OK;
 }
 
-// ---- witness upload ------------------------------------------------------------------------------------------------------
-// Round 1's inputs from PINNED host memory (uzk_host_alloc: mapped, readable by the device): ONE kernel reads every lane's witness
-// [5n] and wire selectors [3n] over PCIe into the lane's evaluation slots and zeroes the public-input slot, instead of 2 k
-// hipMemcpyAsync + one hipMemset2DAsync -- each of which is a staging step of the runtime with a gap behind it on the stream
-// (profiles/r05f_gaps_*: a tenth of a queue's time sat between those copies).  16 bytes per lane per access, grid-stride.
-struct WitnessSrc { const uint4* w; const uint4* s; };
-__global__ __launch_bounds__(256) void witness_gather_kernel(const WitnessSrc* __restrict__ srcs, uint4* __restrict__ evals, uint64_t lane_stride16,
-                                                             uint32_t w16, uint32_t s16, uint32_t pi_off16, uint32_t pi16) {
-    const WitnessSrc src = srcs[blockIdx.y];
-    uint4* dst = evals + (uint64_t)blockIdx.y * lane_stride16;
-    const uint32_t total = w16 + s16 + pi16, step = gridDim.x * blockDim.x;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
-        if (i < w16) dst[i] = src.w[i];
-        else if (i < w16 + s16) dst[i] = src.s[i - w16];                     // the selectors' slots follow the wires'
-        else dst[pi_off16 + (i - w16 - s16)] = make_uint4(0, 0, 0, 0);
-    }
-}
-// d_srcs: `lanes` WitnessSrc in device memory (s = nullptr without wire selectors).  d_evals: lane 0's slot 0; lane_stride, pi_off in elements.
-int witness_gather_lanes(Ctx& c, const void* d_srcs, uint32_t lanes, Fp* d_evals, uint64_t lane_stride, uint32_t n_wit, uint32_t n_sel, uint64_t pi_off, uint32_t n_pi) {
-    if (lanes == 0) return UZK_OK;
-    KernelScope ks(c, "witness_gather");
-    const uint32_t total16 = 2 * (n_wit + n_sel + n_pi);
-    const unsigned blocks = std::min<unsigned>((total16 + 255) / 256, 256u);
-    hipLaunchKernelGGL(witness_gather_kernel, dim3(blocks, lanes), dim3(256), 0, c.stream, static_cast<const WitnessSrc*>(d_srcs),
-                       reinterpret_cast<uint4*>(d_evals), lane_stride * 2, 2 * n_wit, 2 * n_sel, (uint32_t)(pi_off * 2), 2 * n_pi);
-    UZK_HIP(hipGetLastError());
-    return UZK_OK;
-}
-size_t witness_src_bytes() { return sizeof(WitnessSrc); }
-void witness_src_fill(void* host_entry, const void* w, const void* s) {
-    WitnessSrc& e = *static_cast<WitnessSrc*>(host_entry);
-    e.w = static_cast<const uint4*>(w); e.s = static_cast<const uint4*>(s);
-}
-
 // ---- evaluations ----------------------------------------------------------------------------------------------------------
 // Polynomial k of lane b: len[k] coefficients at p[k] + b * lane_stride[k] (0 for a circuit polynomial every lane shares),
 // evaluated at points[2 b + pt[k]].  grid (blocks, count, lanes); the value goes straight to pinned host memory,
