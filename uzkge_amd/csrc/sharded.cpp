@@ -4,6 +4,7 @@
 // per chunk, each uploading only its part of the scalars -- and folds the N 96-byte partial sums on the host (uzk_g1_fold's
 // arithmetic).  Nothing moves between devices.  The process-per-GPU form of the same split, with the partial sums exchanged by
 // RCCL, is uzkge_amd/sharded.py (bench.py --gpus N); this is the form a single Rust process links.
+#include <algorithm>
 #include <condition_variable>
 #include <cstring>
 #include <deque>
@@ -136,6 +137,10 @@ int uzk_srs_register_sharded(const uzk_g1_affine* points, size_t n, const int* d
         c->lo = (size_t)((unsigned __int128)i * n / n_devices);
         c->hi = (size_t)((unsigned __int128)(i + 1) * n / n_devices);
         int rc = ctx_init_internal(c->ctx, c->device);
+        // A chunk's scalars always come from the host: stream them under the chunk's own accumulation from 2^19 points on (a single call
+        // starts at 2^22, where its first sub-chunk is a quarter of the vector; a chunk IS a fraction of one already).  Round 6, two and
+        // eight virtual shards of a 2^22-point MSM on one GPU: 7.7-8.3 -> 7.0-7.1 ms and 8.2-9.5 -> 7.2 ms.
+        c->ctx.tune_stream_min_log = std::min(c->ctx.tune_stream_min_log, 19);
         if (rc == UZK_OK) {
             CtxScope scope(&c->ctx);
             rc = uzk_srs_register(points + c->lo, c->hi - c->lo, &c->srs);
