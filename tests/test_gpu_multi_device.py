@@ -47,6 +47,32 @@ def test_sharded_msm_equals_the_single_msm_and_the_oracle(gpu, chunks, window_bi
         sh.release(); one.release()
 
 
+@pytest.mark.parametrize("log_n,chunks", [(20, 2), (21, 3), (20, 8)])
+def test_sharded_chunks_that_stream_their_scalars_equal_the_single_msm(gpu, log_n, chunks):
+    """Chunks of >= 2^19 points stream their host scalars in sub-chunks under their own accumulation (sharded.cpp; a single call
+    starts streaming at 2^22): 2^20 / 2 and 2^21 / 3 chunks stream, 2^20 / 8 do not -- the same commitment as one MSM on one context,
+    also for a vector shorter than the SRS (the last chunks run short or empty) and for the prover-like scalar mix."""
+    import torch
+    b = gpu
+    n = 1 << log_n
+    pts = torch.empty((n, 8), dtype=torch.int64, device="cuda")
+    sc = torch.empty((2 * n, 4), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    b.synth_points_random(pts.data_ptr(), n, 41)
+    b.synth_scalars(sc.data_ptr(), n, 42)
+    b.synth_scalars_mix(sc.data_ptr() + n * 32, n, 43)
+    hp = pts.cpu().numpy().view(np.uint64).reshape(-1, 8)
+    hs = sc.cpu().numpy().view(np.uint64).reshape(-1, 4)
+    one = b.Srs.from_device(pts.data_ptr(), n)
+    sh = b.ShardedSrs(hp, [0] * chunks, -1)
+    try:
+        for lo, count in ((0, n), (n, n), (0, n - 12345), (0, n // chunks + 7)):
+            s = hs[lo:lo + count]
+            assert affine_of(sh.msm(s)) == affine_of(b.msm(one, s)), (lo, count)
+    finally:
+        sh.release(); one.release()
+
+
 def test_a_context_on_a_named_device_carries_its_handles(gpu):
     """uzk_ctx_create_on(0): what is made under it lives on its device; a proof through a circuit and a prover made there equals
     the default context's."""
