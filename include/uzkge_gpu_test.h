@@ -17,7 +17,10 @@ extern "C" {
  * multi-subtrahend offsets of ec29.hpp, 20 the dual product, 21..23 the C++ forms of the
  * assembly products 10 / 16 / 20; 24 / 25 the constant-operand product (a * b as PLAIN integers mod M, b canonical; 25 with a lazy
  * first operand 2 (a + 4M)), 26 its companion constant floor(b 2^261 / M) mod 2^256, 27 the NTT's lazy reduction of a + b + 4M, raw
- * (value < 3M, congruent to a + b).  a, b, out: n elements (host memory). */
+ * (value < 3M, congruent to a + b); 28..33 the typed lazy arithmetic of lz29.hpp on canonical operands: 28 re-limb at offset -5 and
+ * back by exact division by 32 (identity), 29 a b, 30 a - b, 31 a b + b b (ld -> typed operation -> to_wire), 32 into the 2^266-form
+ * and back by exact division by 2^10 (identity), 33 a lazy chain 4 a - b across every offset the types generate.
+ * a, b, out: n elements (host memory). */
 int uzk_test_field_kat(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 /* op: 0 a + b (mixed add), 1 a + b (full XYZZ add), 2 2a, 3 a - b, 4 2(a + b); 5..7 the four-lane addition of the
  * small-MSM folds (ecquad.hpp): 5 a + b, 6 2(a + b) (its doubling branch), 7 (a + b) + (a - b); 8..10 the same three on the

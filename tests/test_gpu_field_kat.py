@@ -179,3 +179,22 @@ def test_the_product_entry_point_runs_the_same_primitives(gpu, field):
     a, b = rand_fr_wire(64, 5), rand_fr_wire(64, 6)          # < 2^252: valid words of either field
     for op in (0, 1, 2, 4, 5, 6, 7):
         assert np.array_equal(gpu.field_elementwise(field, op, a, b), gpu.field_op(field, op, a, b)), op
+
+
+@pytest.mark.parametrize("field,mod", [("fq", opy.P), ("fr", opy.R)])
+def test_typed_lazy_arithmetic_and_its_free_conversions(gpu, field, mod):
+    """lz29.hpp: a canonical wire word re-limbed at bit offset -5 is the 2^261-form; values return by exact division by 2^5 / 2^10.
+    Ops 28..33 against the 8 x 32-bit primitives (themselves held to the oracle above) on random and edge operands (0, 1, M - 1,
+    (M - 1) / 2, limb-boundary values, all pairs)."""
+    n = 1 << 14
+    e = _edge_values(mod)
+    a = np.concatenate([rand_fr_wire(n, 11), np.repeat(e, len(e), axis=0)])
+    b = np.concatenate([rand_fr_wire(n, 12), np.tile(e, (len(e), 1))])
+    mul, sub, sqr_b = gpu.field_op(field, 0, a, b), gpu.field_op(field, 2, a, b), gpu.field_op(field, 4, b, b)
+    assert np.array_equal(gpu.field_op(field, 28, a, b), a)
+    assert np.array_equal(gpu.field_op(field, 29, a, b), mul)
+    assert np.array_equal(gpu.field_op(field, 30, a, b), sub)
+    assert np.array_equal(gpu.field_op(field, 31, a, b), gpu.field_op(field, 1, mul, sqr_b))
+    assert np.array_equal(gpu.field_op(field, 32, a, b), a)
+    two_a = gpu.field_op(field, 1, a, a)
+    assert np.array_equal(gpu.field_op(field, 33, a, b), gpu.field_op(field, 2, gpu.field_op(field, 1, two_a, two_a), b))

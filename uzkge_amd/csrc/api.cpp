@@ -1149,7 +1149,7 @@ int uzk_field_op_device(int field, int op, const uint64_t* a, const uint64_t* b,
 int uzk_test_field_kat(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) try {
     API_LOCK;
     if (n > 0 && (!a || !b || !out)) { set_error("uzk_test_field_kat: null pointer"); return UZK_ERR_PARAMETER; }
-    if (field < 0 || field > 1 || op < 0 || op > 27) { set_error("uzk_test_field_kat: bad field/op"); return UZK_ERR_PARAMETER; }
+    if (field < 0 || field > 1 || op < 0 || op > 33) { set_error("uzk_test_field_kat: bad field/op"); return UZK_ERR_PARAMETER; }
     UZK_TRY(require_ready());
     return field_op_device(ctx(), field, op, as_fp(a), as_fp(b), reinterpret_cast<Fp*>(out), n);
 } catch (...) { return uzk::on_exception("uzk_test_field_kat"); }

@@ -6,6 +6,7 @@
 #include "ecquad29.hpp"
 #include "ec29l.hpp"
 #include "fp29.hpp"
+#include "lz29.hpp"
 
 namespace uzk {
 
@@ -73,6 +74,23 @@ __global__ __launch_bounds__(256) void field_op_kernel(int op, const Fp* __restr
         // reduce3 of the lazy sum x + y + 4M (x, y any 256-bit values: limbs < 2^31.4, value < 14.6M for Fr and Fq), RAW: the caller
         // checks the residue and the bound value < 3M
         case 27: r = F29::to_fp(F29::reduce3(F29::add(F29::add(F29::from_fp(x), F29::from_fp(y)), F29::constant(F29::Cfg::OFF4)))); break;
+        // ---- the typed lazy arithmetic (lz29.hpp) and its two free conversions; x, y canonical wire elements -----------------
+        // 28: re-limb at bit offset -5 (32 x = the 2^261-form), back by exact division by 32: the identity
+        case 28: r = F::canon(F29::template to_fp_div<5>(F29::from_fp_x32(x))); break;
+        // 29 / 30 / 31: x y, x - y, x y + y y through ld -> typed operation -> to_wire: the wire-form results of ops 0 / 2 and 0 + 4
+        case 29: { using Z = LzOps<F29>; r = Z::to_wire(Z::mul(Z::ld(x), Z::ld(y))); } break;
+        case 30: { using Z = LzOps<F29>; r = Z::to_wire(Z::norm(Z::sub(Z::ld(x), Z::ld(y)))); } break;
+        case 31: { using Z = LzOps<F29>; r = Z::to_wire(Z::mul2(Z::ld(x), Z::ld(y), Z::ld(y), Z::ld(y))); } break;
+        // 32: a value in 2^266-form leaves by exact division by 2^10: (x in 2^261-form) * 2^266 / 2^261 = the 2^266-form of x; -> x
+        case 32: { const L29 v = F29::mul(F29::from_fp_x32(x), F29::constant(F29::Cfg::R266)); r = F::canon(F29::template to_fp_div<10>(v)); } break;
+        // 33: a long lazy chain at the limb bounds: ((x + y) + (x - y)) - ((y - x) - x)  =  3 x - y  ... all typed, one carry step where the types ask
+        case 33: {
+            using Z = LzOps<F29>;
+            const auto a1 = Z::ld(x), b1 = Z::ld(y);
+            const auto s1 = Z::add(Z::add(a1, b1), Z::sub(a1, b1));                 // 2 x (+ 33 M), limbs < 6 units
+            const auto s2 = Z::norm(Z::sub(Z::norm(Z::sub(b1, a1)), a1));           // y - 2 x (+ offsets)
+            r = Z::to_wire(Z::mul(Z::norm(Z::sub(Z::norm(s1), s2)), Z::one()));     // (4 x - y) * 1, through a product: value back below 16 M
+        } break;
         default: r = F::to_mont(x); break;
     }
     out[i] = r;
