@@ -338,7 +338,9 @@ int main(int argc, char** argv) {
     in.load();
     const uint64_t circuit = make_circuit(in);
     double ms_up = 0;
-    const double ms = single_chain(in, circuit, reps, &ms_up);
+    // UZK_ROUNDS_NO_SINGLE=1: skip the single-proof latency phase (counter passes that should see the throughput phase only)
+    const bool no_single = std::getenv("UZK_ROUNDS_NO_SINGLE") && std::atoi(std::getenv("UZK_ROUNDS_NO_SINGLE")) != 0;
+    const double ms = no_single ? 0.0 : single_chain(in, circuit, reps, &ms_up);
     if (reps > 0) std::printf("{\"ms_per_chain\": %.4f, \"ms_per_chain_with_witness_upload\": %.4f, \"reps\": %d, \"blocks\": 5, \"n\": %llu}\n", ms, ms_up, reps, (unsigned long long)in.n);
 
     if ((threads > 1 || lanes > 1) && reps > 0) {
