@@ -221,7 +221,7 @@ struct KernelScope {
 
 // entry points implemented in the .hip files
 int ntt_run(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse, const Fp* coset_shift_host, uint32_t batch,
-            uint64_t in_stride = 0, uint64_t out_stride = 0);
+            uint64_t in_stride = 0, uint64_t out_stride = 0, uint64_t in_len = 0);
 void ntt_free_plans(Ctx& c);
 void msm_plan_info(Ctx& c, size_t n, int* window_bits, int* windows);
 int msm_run(Ctx& c, const Affine* points, const ScalarView& scalars, size_t n, uint32_t batch, Jac* out_host, int pre_c,

@@ -153,6 +153,10 @@ struct PassArgs {
     // Last pass: element i' of sub-transform r goes to out[out_mul * i' + r] (out_mul = 3 with m3, else 1), times
     // out_tw[r][i'] when given (coset post-scaling of the inverse transforms).
     uint64_t m3;
+    // First pass with m3 != 0: the caller's vectors hold at most in_len non-zero leading coefficients (0 = no statement).  With
+    // in_len <= m3 the two upper thirds are zero BY CONTRACT: they are not read, the radix-3 combination is the element itself, and
+    // elements at or beyond in_len start as zero (the prover's coset FFTs over 6n points of polynomials with n + 3 coefficients).
+    uint64_t in_len;
     const Fp* in_tw[3];    // limb planes of N (or m3) entries each
     Fp alpha[3], beta[3];  // 2^261-form
     uint32_t use_ab;       // alpha / beta present (else plain sums for every r is NOT implied: r != 0 always needs them)
@@ -368,11 +372,18 @@ __global__ __launch_bounds__(TILE / 4) __attribute__((amdgpu_waves_per_eu((!FIRS
             const uint32_t r = blockIdx.y % 3;
             const Fp* vec = in_base + (uint64_t)(blockIdx.y / 3) * a.in_vec_stride;
             const bool tabled = a.in_tw[r] != nullptr;
+            const bool short_in = a.in_len != 0 && a.in_len <= a.m3;          // wave-uniform
             L29 al, be;
-            if (r != 0) { al = F9::from_fp(a.alpha[r]); be = F9::from_fp(a.beta[r]); }
+            if (r != 0 && !short_in) { al = F9::from_fp(a.alpha[r]); be = F9::from_fp(a.beta[r]); }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const uint64_t j = i + (uint64_t)(q + t * Q) * a.stride;
+                if (short_in) {
+                    // x_(j + m3) = x_(j + 2 m3) = 0: the combination is x_j itself (canonical: normalized, value < M)
+                    if (j < a.in_len) { const L29 xa = F9::from_fp(vec[j]); x[t] = tabled ? F9::mul(xa, tw29_load(a.in_tw[r], a.m3, j)) : xa; }
+                    else x[t] = F9::zero();
+                    continue;
+                }
                 const L29 xa = F9::from_fp(vec[j]), xb = F9::from_fp(vec[j + a.m3]), xc = F9::from_fp(vec[j + 2 * a.m3]);
                 L29 y;
                 if (r == 0 && !a.use_ab) y = F9::add(F9::add(xa, xb), xc);                  // limbs < 3 * 2^29, value < 3M
@@ -739,7 +750,7 @@ static int ntt_pow2(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse,
         if (dst == src) dst = s1;   // only when in_place and npass is odd, at j == 0
         PassArgs a{};
         if (fx != nullptr) {
-            if (j == 0) { a.m3 = fx->m3; a.use_ab = fx->use_ab; for (int k = 0; k < 3; ++k) { a.in_tw[k] = fx->in_tw[k]; a.alpha[k] = fx->alpha[k]; a.beta[k] = fx->beta[k]; } }
+            if (j == 0) { a.m3 = fx->m3; a.in_len = fx->in_len; a.use_ab = fx->use_ab; for (int k = 0; k < 3; ++k) { a.in_tw[k] = fx->in_tw[k]; a.alpha[k] = fx->alpha[k]; a.beta[k] = fx->beta[k]; } }
             if (j == p->npass - 1) { a.out_mul = fx->out_mul; for (int k = 0; k < 3; ++k) a.out_tw[k] = fx->out_tw[k]; }
         }
         a.batch_stride = n;
@@ -903,8 +914,10 @@ static int get_fused(Ctx& c, uint64_t n, bool inverse, const Fp* shift, NttFused
 
 // `batch` independent transforms of n elements each (d_in -> d_out, may alias when the strides are equal); consecutive
 // vectors are in_stride / out_stride elements apart (0 = contiguous).
+// in_len (forward transforms over 3 * 2^k points only; 0 = no statement): every input vector is zero from index in_len on -- the
+// first pass then neither reads nor combines the zero thirds (PassArgs::in_len).
 int ntt_run(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse, const Fp* coset_shift_host, uint32_t batch,
-            uint64_t in_stride, uint64_t out_stride) {
+            uint64_t in_stride, uint64_t out_stride, uint64_t in_len) {
     if (!domain_supported(n)) {
         set_error("no evaluation domain of size %llu (need 2^k, k <= %d, or 3 * 2^k, k <= %d)", (unsigned long long)n, UZK_NTT_MAX_LOG2, UZK_NTT_MAX_LOG2_MIXED);
         return UZK_ERR_FFT;
@@ -922,7 +935,11 @@ int ntt_run(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse, const F
     if (sub_n >= 4096 && (n % 3 == 0 || coset_shift_host != nullptr)) {
         NttFused* f = nullptr;
         UZK_TRY(get_fused(c, n, inverse, coset_shift_host, &f));
-        if (n % 3 == 0) return ntt_pow2(c, d_in, d_out, sub_n, inverse, false, 3 * batch, &f->fx, in_stride, out_stride);
+        if (n % 3 == 0) {
+            PassArgs fx = f->fx;
+            fx.in_len = (!inverse && in_len != 0 && in_len <= sub_n) ? in_len : 0;
+            return ntt_pow2(c, d_in, d_out, sub_n, inverse, false, 3 * batch, &fx, in_stride, out_stride);
+        }
         return ntt_pow2(c, d_in, d_out, n, inverse, inverse, batch, &f->fx, in_stride, out_stride);
     }
     if (n % 3 != 0 && coset_shift_host == nullptr) return ntt_pow2(c, d_in, d_out, n, inverse, inverse, batch, nullptr, in_stride, out_stride);
@@ -930,7 +947,7 @@ int ntt_run(Ctx& c, const Fp* d_in, Fp* d_out, uint64_t n, bool inverse, const F
         // the separate scaling / decimation kernels (small or unfused transforms) work on contiguous batches: one vector at a time
         for (uint32_t b = 0; b < batch; ++b)
             UZK_TRY(ntt_run(c, d_in + (uint64_t)b * (in_stride ? in_stride : n), d_out + (uint64_t)b * (out_stride ? out_stride : n), n, inverse,
-                            coset_shift_host, 1, 0, 0));
+                            coset_shift_host, 1, 0, 0, 0));
         return UZK_OK;
     }
     const dim3 egrid((unsigned)((n + 255) / 256), batch);

@@ -497,8 +497,11 @@ int round3_lanes(Ctx& c, Prover& p, const Lane3* L, LaneStatus* st) {
     // One launch sequence for every lane: the lanes' slots lie a fixed stride apart.  A circuit without wire selectors uses seven of
     // a lane's ten slots; several lanes then transform the three idle ones along (zeros since the allocation, or what another circuit's
     // proof left there: never read) rather than launch once per lane -- 30 % more points in ONE launch against k launches.
-    if (p.np == kProofSlots || k > 1) ROUND_TRY(ntt_run(c, p.d_coefs, p.d_coset, m, false, &cir.k[1], k * kProofSlots));
-    else ROUND_TRY(ntt_run(c, p.coefs(0, 0), p.coset(0, 0), m, false, &cir.k[1], p.np));
+    // Every slot holds at most n + 3 coefficients (n from the iFFT, <= 3 blinds from hide_polynomial; zeros beyond since the
+    // allocation): the transform is told so and neither reads nor combines the two zero thirds of its 6n-point inputs (ntt_run in_len).
+    const uint64_t coef_len = (uint64_t)n + 8;
+    if (p.np == kProofSlots || k > 1) ROUND_TRY(ntt_run(c, p.d_coefs, p.d_coset, m, false, &cir.k[1], k * kProofSlots, 0, 0, coef_len));
+    else ROUND_TRY(ntt_run(c, p.coefs(0, 0), p.coset(0, 0), m, false, &cir.k[1], p.np, 0, 0, coef_len));
     {
         uzk_quotient_args qa;
         std::memset(&qa, 0, sizeof qa);
