@@ -88,7 +88,7 @@ int derive_cosets(Ctx& c, uint32_t n, const Fp& k1, const Fp* polys, Fp* cosets,
     const uint64_t m = 6ull * n;
     UZK_HIP(hipMemsetAsync(cosets, 0, (size_t)count * m * sizeof(Fp), c.stream));
     UZK_HIP(hipMemcpy2DAsync(cosets, (size_t)m * sizeof(Fp), polys, (size_t)n * sizeof(Fp), (size_t)n * sizeof(Fp), count, hipMemcpyDeviceToDevice, c.stream));
-    return ntt_run(c, cosets, cosets, m, false, &k1, count);
+    return ntt_run(c, cosets, cosets, m, false, &k1, count, 0, 0, /*in_len: n coefficients, zeros beyond*/ n);
 }
 
 // Installs `count` polynomials whose coefficient forms already sit in blk (polys area: [count][n], zero padded) as slots
