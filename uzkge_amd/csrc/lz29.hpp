@@ -3,7 +3,8 @@
 // products over ~60 loaded values, 18 terms) are too long for that, so here an element carries its bounds as template
 // parameters and every operation static_asserts its contract:
 //
-//     Lz<F, K, V>     every limb < K * (2^29 + 2^6)  (K = 1: normalized, or the output of one parallel carry step),
+//     Lz<F, K, V>     every limb BUT THE TOP ONE < K * (2^29 + 2^6)  (K = 1: normalized, or the output of one parallel carry step; the
+//                     top limb holds the rest of the value, < V * 2^29 / 169 + K * 2^29: the products' checks account for it),
 //                     value < V * M; the value is x * 2^261 mod M (2^261-form) unless stated otherwise.
 //
 // How values get here for free: a canonical element of the wire format (8 x 32-bit words, Montgomery radix 2^256: a = x 2^256)
@@ -116,9 +117,18 @@ struct LzOps {
         return r;
     }
     static constexpr int prod_v(int va, int vb) { return 1 + (va * vb + 168) / 169; }
+    // The TOP limb holds whatever the value has above 2^232: < V M / 2^232 = V * 2^29 / 169.9, i.e. kt(V) units of 2^29 -- more than K
+    // for large V.  A column of a product holds at most ONE term with a's top limb, ONE with b's, seven others and nine reduction
+    // terms (< 2^58 each): the 64-bit accumulator holds it when  kt(Va) Kb + kt(Vb) Ka + 7 Ka Kb + 9  <  64  (units of 2^58).
+    static constexpr int kt(int v) { return 1 + v / 169; }
+    static constexpr bool cols_fit(int ka, int va, int kb, int vb) {
+        const int ta = kt(va) > ka ? kt(va) : ka, tb = kt(vb) > kb ? kt(vb) : kb;
+        return ta * kb + tb * ka + 7 * ka * kb + 9 < 64;
+    }
     template <int Ka, int Va, int Kb, int Vb>
     __device__ __forceinline__ static E<1, prod_v(Va, Vb)> mul(const E<Ka, Va>& a, const E<Kb, Vb>& b) {
         static_assert(Ka * Kb <= 6, "product of the limb bounds exceeds 2^60.6: carry one operand first (norm)");
+        static_assert(cols_fit(Ka, Va, Kb, Vb), "a column of the product can overflow 64 bits (top limbs of large values)");
         static_assert(Va * Vb < 169 * 512, "value bound of a product");
         E<1, prod_v(Va, Vb)> r;
         r.v = F::mul(a.v, b.v);
@@ -127,6 +137,8 @@ struct LzOps {
     template <int K, int V>
     __device__ __forceinline__ static E<1, prod_v(V, V)> sqr(const E<K, V>& a) {
         static_assert(K <= 2, "squaring doubles the limbs: they must be below 2^30");
+        // (a column of the squaring: <= 4 doubled cross terms + one square; with the top limb in one of them)
+        static_assert(2 * (kt(V) > K ? kt(V) : K) * K + 6 * K * K + (kt(V) > K ? kt(V) : K) * (kt(V) > K ? kt(V) : K) + 9 < 64, "a column of the squaring can overflow 64 bits");
         E<1, prod_v(V, V)> r;
         r.v = F::sqr(a.v);
         return r;
@@ -135,6 +147,8 @@ struct LzOps {
     template <int Ka, int Va, int Kb, int Vb, int Kc, int Vc, int Kd, int Vd>
     __device__ __forceinline__ static E<1, 1 + (Va * Vb + Vc * Vd + 168) / 169> mul2(const E<Ka, Va>& a, const E<Kb, Vb>& b, const E<Kc, Vc>& c, const E<Kd, Vd>& d) {
         static_assert(Ka * Kb + Kc * Kd <= 6, "dual product: limb bounds");
+        static_assert((kt(Va) > Ka ? kt(Va) : Ka) * Kb + (kt(Vb) > Kb ? kt(Vb) : Kb) * Ka + 7 * Ka * Kb +
+                      (kt(Vc) > Kc ? kt(Vc) : Kc) * Kd + (kt(Vd) > Kd ? kt(Vd) : Kd) * Kc + 7 * Kc * Kd + 9 < 64, "a column of the dual product can overflow 64 bits");
         E<1, 1 + (Va * Vb + Vc * Vd + 168) / 169> r;
         r.v = F::mul2(a.v, b.v, c.v, d.v);
         return r;
